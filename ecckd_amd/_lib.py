@@ -1,0 +1,100 @@
+"""ctypes loader for libecckd_hip.so (the C ABI declared in include/ecckd_hip.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OK = 0
+OUT_OF_MEMORY = 130
+UNEXPECTED_EXCEPTION = 131
+PARAMETER_ERROR = 147
+PROCESSING_ERROR = 148
+
+F32 = 4
+F64 = 8
+
+AVG = {
+    "linear": 0,
+    "transmission": 1,
+    "transmission-2": 2,
+    "square-root": 3,
+    "logarithmic": 4,
+    "total-transmission": 5,
+}
+
+
+class EcckdError(RuntimeError):
+    """Raised when an ABI call returns a non-zero reference exit code."""
+
+    def __init__(self, code, message):
+        super().__init__(f"ecckd error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def library_path():
+    return os.path.join(_HERE, "libecckd_hip.so")
+
+
+_c_double_p = C.POINTER(C.c_double)
+_c_int64_p = C.POINTER(C.c_int64)
+_c_int32_p = C.POINTER(C.c_int32)
+_c_int16_p = C.POINTER(C.c_int16)
+
+# name -> (restype, argtypes); kept in one table so the symbol-export test can
+# check it against include/ecckd_hip.h.
+SIGNATURES = {
+    "ecckd_version": (C.c_int, []),
+    "ecckd_last_error": (C.c_char_p, []),
+    "ecckd_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ecckd_destroy": (C.c_int, [C.c_void_p]),
+    "ecckd_synchronize": (C.c_int, [C.c_void_p]),
+    "ecckd_stream": (C.c_void_p, [C.c_void_p]),
+    "ecckd_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ecckd_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ecckd_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ecckd_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ecckd_timer_begin": (C.c_int, [C.c_void_p]),
+    "ecckd_timer_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "ecckd_idealised_temperature": (C.c_int, [C.c_int, _c_double_p, _c_double_p]),
+    "ecckd_reorder_key_lw_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, _c_double_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t,
+                                           C.c_double, C.c_void_p, C.c_void_p]),
+    "ecckd_reorder_key_sw_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p,
+                                           C.c_void_p, C.c_int, C.c_size_t, C.c_double,
+                                           C.c_void_p, C.c_void_p]),
+    "ecckd_stable_argsort_bands_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int,
+                                                 _c_int64_p, _c_int64_p, C.c_void_p, C.c_void_p]),
+    "ecckd_band_ranges": (C.c_int, [C.c_size_t, _c_double_p, C.c_int, _c_double_p, _c_double_p,
+                                    _c_int16_p, _c_int64_p, _c_int64_p]),
+    "ecckd_reorder_spectrum": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, _c_double_p,
+                                         _c_double_p, C.c_void_p, C.c_int, _c_double_p, C.c_double,
+                                         C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
+                                         _c_int16_p, _c_int32_p]),
+}
+
+
+def load_library():
+    """Load the in-tree libecckd_hip.so; fails loudly if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        msg = load_library().ecckd_last_error()
+        raise EcckdError(rc, msg.decode("utf-8", "replace") if msg else "")

@@ -1,0 +1,66 @@
+// common.hpp - context, error plumbing and launch helpers shared by the HIP
+// translation units of libecckd_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+
+#include "../../include/ecckd_hip.h"
+
+// reference src/ecckd/constants.h:22-26
+#define ECCKD_ACCEL_GRAVITY 9.80665
+#define ECCKD_SPECIFIC_HEAT_AIR 1004.0
+#define ECCKD_LW_DIFFUSIVITY 1.66
+
+struct ecckd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cu = 256;
+  // growable device scratch (never shrinks; freed with the context)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // pinned host staging for small results
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+};
+
+namespace ecckd {
+
+void set_error(const char* fmt, ...);
+
+// Returns a reference exit code (see ecckd_hip.h) after recording the message.
+int fail(int code, const char* fmt, ...);
+
+int ensure_scratch(ecckd_ctx* ctx, size_t bytes);
+int ensure_pinned(ecckd_ctx* ctx, size_t bytes);
+
+}  // namespace ecckd
+
+#define ECCKD_HIP_CHECK(expr)                                                          \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      return ecckd::fail(_e == hipErrorOutOfMemory ? ECCKD_OUT_OF_MEMORY               \
+                                                   : ECCKD_UNEXPECTED_EXCEPTION,       \
+                         "%s failed at %s:%d: %s", #expr, __FILE__, __LINE__,          \
+                         hipGetErrorString(_e));                                       \
+    }                                                                                  \
+  } while (0)
+
+#define ECCKD_CHECK(expr)             \
+  do {                                \
+    int _rc = (expr);                 \
+    if (_rc != ECCKD_OK) return _rc;  \
+  } while (0)
+
+#define ECCKD_REQUIRE(cond, ...)                                        \
+  do {                                                                  \
+    if (!(cond)) return ecckd::fail(ECCKD_PARAMETER_ERROR, __VA_ARGS__); \
+  } while (0)
+
+static inline size_t ecckd_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

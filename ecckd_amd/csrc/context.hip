@@ -1,0 +1,203 @@
+// context.hip - context lifetime, device memory helpers, stream timing and the
+// error channel of the C ABI (include/ecckd_hip.h).
+#include "common.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace ecckd {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int ensure_scratch(ecckd_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return ECCKD_OK;
+  if (ctx->scratch) {
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ECCKD_HIP_CHECK(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+  }
+  size_t want = ecckd_align_up(bytes + bytes / 8, 1 << 20);
+  ECCKD_HIP_CHECK(hipMalloc(&ctx->scratch, want));
+  ctx->scratch_bytes = want;
+  return ECCKD_OK;
+}
+
+int ensure_pinned(ecckd_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pinned_bytes) return ECCKD_OK;
+  if (ctx->pinned) {
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ECCKD_HIP_CHECK(hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+  }
+  size_t want = ecckd_align_up(bytes * 2, 4096);
+  ECCKD_HIP_CHECK(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+  ctx->pinned_bytes = want;
+  return ECCKD_OK;
+}
+
+}  // namespace ecckd
+
+extern "C" {
+
+int ecckd_version(void) { return 100; }
+
+const char* ecckd_last_error(void) { return ecckd::g_err; }
+
+int ecckd_init(int device, ecckd_ctx** out) {
+  if (!out) return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_init: ctx is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    return ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION,
+                       "ecckd_init: no HIP device available (%s); there is no CPU fallback",
+                       e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  }
+  if (device < 0 || device >= ndev)
+    return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_init: device %d out of range [0,%d)", device, ndev);
+  ECCKD_HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  ECCKD_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    return ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION,
+                       "ecckd_init: device %d is %s; this library is built for gfx950 only",
+                       device, prop.gcnArchName);
+  }
+  ecckd_ctx* ctx = new ecckd_ctx();
+  ctx->device = device;
+  ctx->num_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    delete ctx;
+    return ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION, "ecckd_init: stream/event creation failed");
+  }
+  *out = ctx;
+  return ECCKD_OK;
+}
+
+int ecckd_destroy(ecckd_ctx* ctx) {
+  if (!ctx) return ECCKD_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  (void)hipEventDestroy(ctx->ev0);
+  (void)hipEventDestroy(ctx->ev1);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return ECCKD_OK;
+}
+
+int ecckd_synchronize(ecckd_ctx* ctx) {
+  ECCKD_REQUIRE(ctx, "ecckd_synchronize: ctx is NULL");
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
+}
+
+void* ecckd_stream(ecckd_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int ecckd_dev_alloc(ecckd_ctx* ctx, size_t bytes, void** d_ptr) {
+  ECCKD_REQUIRE(ctx && d_ptr, "ecckd_dev_alloc: NULL argument");
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  ECCKD_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 1));
+  return ECCKD_OK;
+}
+
+int ecckd_dev_free(ecckd_ctx* ctx, void* d_ptr) {
+  ECCKD_REQUIRE(ctx, "ecckd_dev_free: ctx is NULL");
+  if (!d_ptr) return ECCKD_OK;
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ECCKD_HIP_CHECK(hipFree(d_ptr));
+  return ECCKD_OK;
+}
+
+int ecckd_h2d(ecckd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  ECCKD_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "ecckd_h2d: NULL argument");
+  if (!bytes) return ECCKD_OK;
+  ECCKD_HIP_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
+}
+
+int ecckd_d2h(ecckd_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+  ECCKD_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "ecckd_d2h: NULL argument");
+  if (!bytes) return ECCKD_OK;
+  ECCKD_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
+}
+
+int ecckd_timer_begin(ecckd_ctx* ctx) {
+  ECCKD_REQUIRE(ctx, "ecckd_timer_begin: ctx is NULL");
+  ECCKD_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+  return ECCKD_OK;
+}
+
+int ecckd_timer_end(ecckd_ctx* ctx, float* ms) {
+  ECCKD_REQUIRE(ctx && ms, "ecckd_timer_end: NULL argument");
+  ECCKD_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+  ECCKD_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+  ECCKD_HIP_CHECK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return ECCKD_OK;
+}
+
+// reference src/ecckd/reorder_spectrum.cpp:121-124: T linear in ln p between
+// (1 Pa, 173.15 K) and (1e5 Pa, 288.15 K); adept::interp restated as linear
+// interpolation with linear extrapolation outside the knots.
+int ecckd_idealised_temperature(int nhl, const double* h_pressure_hl, double* h_temperature_hl) {
+  ECCKD_REQUIRE(nhl > 0 && h_pressure_hl && h_temperature_hl, "ecckd_idealised_temperature: bad argument");
+  const double x0 = std::log(1.0), x1 = std::log(100000.0);
+  const double y0 = 273.15 - 100.0, y1 = 273.15 + 15.0;
+  for (int i = 0; i < nhl; ++i) {
+    double w = (std::log(h_pressure_hl[i]) - x0) / (x1 - x0);
+    h_temperature_hl[i] = (1.0 - w) * y0 + w * y1;
+  }
+  return ECCKD_OK;
+}
+
+// reference src/ecckd/reorder_spectrum.cpp:277-289: membership uses the
+// unclamped bounds, last band closed on the right.
+int ecckd_band_ranges(size_t nwav, const double* h_wavenumber, int nband,
+                      const double* h_band_bound1, const double* h_band_bound2,
+                      int16_t* h_iband, int64_t* h_band_begin, int64_t* h_band_end) {
+  ECCKD_REQUIRE(h_wavenumber && nband > 0 && h_band_bound1 && h_band_bound2 && h_band_begin && h_band_end,
+                "ecckd_band_ranges: bad argument");
+  if (h_iband)
+    for (size_t j = 0; j < nwav; ++j) h_iband[j] = -1;
+  for (int b = 0; b < nband; ++b) {
+    int64_t first = 0, last = -1;
+    bool found = false;
+    for (size_t j = 0; j < nwav; ++j) {
+      double w = h_wavenumber[j];
+      bool in = (b < nband - 1) ? (w >= h_band_bound1[b] && w < h_band_bound2[b])
+                                : (w >= h_band_bound1[b] && w <= h_band_bound2[b]);
+      if (in) {
+        if (h_iband) h_iband[j] = (int16_t)b;
+        if (!found) { first = (int64_t)j; found = true; }
+        last = (int64_t)j;
+      }
+    }
+    h_band_begin[b] = first;
+    h_band_end[b] = last;
+  }
+  return ECCKD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// radix_sort.hip - K3: stable per-band argsort of the f64 sorting key on gfx950.
+//
+// Replaces reference src/ecckd/reorder_spectrum.cpp:262-300 (std::stable_sort of
+// an index vector with `key[i1] < key[i2]`, single thread, then the rank
+// scatter).  A least-significant-digit radix sort is stable by construction, so
+// the permutation is the unique one std::stable_sort produces for keys without
+// NaNs; -0.0 is canonicalised to +0.0 (they compare equal under `<`), NaN keys
+// sort after everything else (undefined behaviour in the reference).
+//
+// Layout: 64-bit order-preserving key image + 32-bit index payload, ping-pong
+// buffers in the context scratch.  8 passes of 8 bits; each pass is
+//   (1) per-tile digit histogram   (LDS integer atomics)
+//   (2) exclusive scan of the digit-major (digit, tile) table
+//   (3) stable scatter: each 64-wide wave ranks its elements with ballot
+//       matching (wave64: one 64-bit peer mask per element), waves of a block
+//       are ordered through an LDS count table.
+// Algorithmic traffic per pass: 8 B (histogram) + 12 B read + 12 B written.
+#include "common.hpp"
+
+#include <cstring>
+
+namespace {
+
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 elements per block
+
+__device__ __forceinline__ unsigned long long key_to_sortable(double k) {
+  if (k != k) return ~0ull;          // NaN last
+  if (k == 0.0) k = 0.0;             // -0.0 -> +0.0
+  unsigned long long b = (unsigned long long)__double_as_longlong(k);
+  return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ void __launch_bounds__(256)
+k_sort_prepare(size_t off, size_t n, const double* __restrict__ key,
+               unsigned long long* __restrict__ skey, unsigned* __restrict__ sidx) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  skey[i] = key_to_sortable(key[off + i]);
+  sidx[i] = (unsigned)(off + i);
+}
+
+// (1) tile histogram -> tile_hist[digit * ntiles + tile]
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_hist(size_t n, int shift, const unsigned long long* __restrict__ skey,
+            unsigned* __restrict__ tile_hist, unsigned ntiles) {
+  __shared__ unsigned s_hist[RADIX];
+  const int tid = threadIdx.x;
+  s_hist[tid] = 0;  // SORT_THREADS == RADIX
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * SORT_TILE;
+#pragma unroll
+  for (int it = 0; it < SORT_ITEMS; ++it) {
+    size_t i = base + (size_t)it * SORT_THREADS + tid;
+    if (i < n) {
+      unsigned d = (unsigned)(skey[i] >> shift) & (RADIX - 1);
+      atomicAdd(&s_hist[d], 1u);
+    }
+  }
+  __syncthreads();
+  tile_hist[(size_t)tid * ntiles + blockIdx.x] = s_hist[tid];
+}
+
+// (2) exclusive scan of m = RADIX*ntiles counters, single block.
+__global__ void __launch_bounds__(1024)
+k_sort_scan(unsigned* __restrict__ data, size_t m) {
+  __shared__ unsigned s_part[1024];
+  const int tid = threadIdx.x;
+  const size_t chunk = (m + 1023) / 1024;
+  const size_t lo = (size_t)tid * chunk;
+  const size_t hi = lo + chunk < m ? lo + chunk : m;
+  unsigned s = 0;
+  for (size_t i = lo; i < hi; ++i) s += data[i];
+  s_part[tid] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over the 1024 partials
+  for (int d = 1; d < 1024; d <<= 1) {
+    unsigned v = (tid >= d) ? s_part[tid - d] : 0u;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  unsigned run = (tid == 0) ? 0u : s_part[tid - 1];
+  for (size_t i = lo; i < hi; ++i) {
+    unsigned v = data[i];
+    data[i] = run;
+    run += v;
+  }
+}
+
+// (3) stable scatter.  Wave w of a block owns the contiguous sub-tile
+// [w*1024, (w+1)*1024) of the block's tile as 16 chunks of 64 consecutive
+// elements, so (chunk, lane) order is input order.
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_scatter(size_t n, int shift, const unsigned long long* __restrict__ skey_in,
+               const unsigned* __restrict__ sidx_in, unsigned long long* __restrict__ skey_out,
+               unsigned* __restrict__ sidx_out, const unsigned* __restrict__ tile_offs,
+               unsigned ntiles) {
+  __shared__ unsigned s_cnt[SORT_WAVES][RADIX];  // per-wave digit counts, then running offsets
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  for (int w = 0; w < SORT_WAVES; ++w) s_cnt[w][tid] = 0;
+  __syncthreads();
+
+  const size_t wave_base = (size_t)blockIdx.x * SORT_TILE + (size_t)wave * (SORT_ITEMS * 64);
+  unsigned long long k[SORT_ITEMS];
+  unsigned v[SORT_ITEMS];
+#pragma unroll
+  for (int c = 0; c < SORT_ITEMS; ++c) {
+    size_t i = wave_base + (size_t)c * 64 + lane;
+    bool valid = i < n;
+    k[c] = valid ? skey_in[i] : ~0ull;
+    v[c] = valid ? sidx_in[i] : 0u;
+    if (valid) atomicAdd(&s_cnt[wave][(unsigned)(k[c] >> shift) & (RADIX - 1)], 1u);
+  }
+  __syncthreads();
+  // thread `tid` owns digit `tid`: turn counts into per-wave start offsets
+  {
+    unsigned run = tile_offs[(size_t)tid * ntiles + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) {
+      unsigned cnt = s_cnt[w][tid];
+      s_cnt[w][tid] = run;
+      run += cnt;
+    }
+  }
+  __syncthreads();
+
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int c = 0; c < SORT_ITEMS; ++c) {
+    size_t i = wave_base + (size_t)c * 64 + lane;
+    bool valid = i < n;
+    unsigned d = (unsigned)(k[c] >> shift) & (RADIX - 1);
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < RADIX_BITS; ++b) {
+      unsigned long long vote = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? vote : ~vote;
+    }
+    unsigned rank = (unsigned)__popcll(peers & lt_mask);
+    unsigned count = (unsigned)__popcll(peers);
+    volatile unsigned* wcnt = s_cnt[wave];
+    unsigned start = 0;
+    if (valid) start = wcnt[d];
+    // all peers have read the running offset before the last peer bumps it:
+    // LDS operations of one wave execute in issue order.
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == count - 1) wcnt[d] = start + count;
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      size_t pos = (size_t)start + rank;
+      skey_out[pos] = k[c];
+      sidx_out[pos] = v[c];
+    }
+  }
+}
+
+// final: ordered_index[off+i] = idx[i]; rank[idx[i]] = off+i  (reorder_spectrum.cpp:297-300)
+__global__ void __launch_bounds__(256)
+k_sort_finish(size_t off, size_t n, const unsigned* __restrict__ sidx, int32_t* __restrict__ rank,
+              int32_t* __restrict__ ordered) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned src = sidx[i];
+  if (ordered) ordered[off + i] = (int32_t)src;
+  rank[src] = (int32_t)(off + i);
+}
+
+__global__ void __launch_bounds__(256)
+k_iota(size_t n, int32_t* __restrict__ a, int32_t* __restrict__ b) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  a[i] = (int32_t)i;
+  if (b) b[i] = (int32_t)i;
+}
+
+}  // namespace
+
+extern "C" int ecckd_stable_argsort_bands_dev(ecckd_ctx* ctx, size_t nwav, const double* d_key,
+                                              int nband, const int64_t* h_band_begin,
+                                              const int64_t* h_band_end, int32_t* d_rank,
+                                              int32_t* d_ordered_index) {
+  ECCKD_REQUIRE(ctx, "ecckd_stable_argsort_bands_dev: ctx is NULL");
+  ECCKD_REQUIRE(d_key && d_rank && h_band_begin && h_band_end && nband > 0,
+                "ecckd_stable_argsort_bands_dev: bad argument");
+  ECCKD_REQUIRE(nwav < (size_t)0x7fffffff, "ecckd_stable_argsort_bands_dev: nwav exceeds int32 range");
+  if (nwav == 0) return ECCKD_OK;
+  size_t nmax = 0;
+  for (int b = 0; b < nband; ++b) {
+    if (h_band_end[b] < h_band_begin[b]) continue;  // empty band
+    ECCKD_REQUIRE(h_band_begin[b] >= 0 && (size_t)h_band_end[b] < nwav,
+                  "ecckd_stable_argsort_bands_dev: band %d range [%lld,%lld] outside [0,%zu)", b,
+                  (long long)h_band_begin[b], (long long)h_band_end[b], nwav);
+    size_t n = (size_t)(h_band_end[b] - h_band_begin[b] + 1);
+    if (n > nmax) nmax = n;
+  }
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_iota, dim3((unsigned)((nwav + 255) / 256)), dim3(256), 0, ctx->stream, nwav, d_rank,
+                     d_ordered_index);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  if (nmax == 0) return ECCKD_OK;
+
+  const size_t ntiles_max = (nmax + SORT_TILE - 1) / SORT_TILE;
+  const size_t key_bytes = ecckd_align_up(nmax * sizeof(unsigned long long), 256);
+  const size_t idx_bytes = ecckd_align_up(nmax * sizeof(unsigned), 256);
+  const size_t hist_bytes = ecckd_align_up((size_t)RADIX * ntiles_max * sizeof(unsigned), 256);
+  ECCKD_CHECK(ecckd::ensure_scratch(ctx, 2 * key_bytes + 2 * idx_bytes + hist_bytes));
+  char* p = (char*)ctx->scratch;
+  unsigned long long* keys[2] = {(unsigned long long*)p, (unsigned long long*)(p + key_bytes)};
+  p += 2 * key_bytes;
+  unsigned* idxs[2] = {(unsigned*)p, (unsigned*)(p + idx_bytes)};
+  p += 2 * idx_bytes;
+  unsigned* hist = (unsigned*)p;
+
+  for (int b = 0; b < nband; ++b) {
+    if (h_band_end[b] < h_band_begin[b]) continue;
+    const size_t off = (size_t)h_band_begin[b];
+    const size_t n = (size_t)(h_band_end[b] - h_band_begin[b] + 1);
+    const unsigned ntiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+    const unsigned eblocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_sort_prepare, dim3(eblocks), dim3(256), 0, ctx->stream, off, n, d_key, keys[0], idxs[0]);
+    int cur = 0;
+    for (int pass = 0; pass < 64 / RADIX_BITS; ++pass) {
+      const int shift = pass * RADIX_BITS;
+      hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, keys[cur],
+                         hist, ntiles);
+      hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, ctx->stream, hist, (size_t)RADIX * ntiles);
+      hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift,
+                         keys[cur], idxs[cur], keys[cur ^ 1], idxs[cur ^ 1], hist, ntiles);
+      cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_sort_finish, dim3(eblocks), dim3(256), 0, ctx->stream, off, n, idxs[cur], d_rank,
+                       d_ordered_index);
+    ECCKD_HIP_CHECK(hipGetLastError());
+  }
+  return ECCKD_OK;
+}
