@@ -72,7 +72,31 @@ SIGNATURES = {
                                          _c_double_p, C.c_void_p, C.c_int, _c_double_p, C.c_double,
                                          C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
                                          _c_int16_p, _c_int32_p]),
+    "ecckd_gas_create_lw": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, _c_double_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_double,
+                                      C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ecckd_gas_destroy": (C.c_int, [C.c_void_p]),
+    "ecckd_gas_view": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                 C.POINTER(C.c_size_t)]),
+    "ecckd_gas_layer_weight": (C.c_int, [C.c_void_p, _c_double_p]),
+    "ecckd_gas_comp_cost": (C.c_double, [C.c_void_p, C.c_int]),
+    "ecckd_calc_error_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, _c_double_p,
+                                         _c_double_p, _c_double_p]),
+    "ecckd_partition_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ecckd_partition_destroy": (C.c_int, [C.c_void_p]),
+    "ecckd_partition_configure": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                                            C.c_int]),
+    "ecckd_partition_n": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.POINTER(C.c_int)]),
+    "ecckd_partition_e": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int),
+                                    _c_double_p, _c_double_p, C.c_int, C.POINTER(C.c_int)]),
+    "ecckd_partition_status_string": (C.c_char_p, [C.c_int]),
+    "ecckd_find_g_band": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_int,
+                                    C.c_int, C.c_int, C.POINTER(C.c_int), _c_double_p, _c_double_p, C.c_int,
+                                    C.POINTER(C.c_int), _c_double_p]),
 }
+
+ERROR_FN = C.CFUNCTYPE(C.c_int, C.c_int, _c_double_p, _c_double_p, _c_double_p, C.c_void_p)
 
 
 def load_library():

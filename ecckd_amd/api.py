@@ -218,3 +218,145 @@ def reorder_spectrum(ctx, pressure_hl, wavenumber, d_wavenumber, optical_depth, 
                                          _hptr(key), _hptr(col), _hptr(iband, C.c_int16),
                                          _hptr(rank, C.c_int32)))
     return key, col, iband, rank
+
+
+# ---------------------------------------------------------------------------------------
+# find_g_points
+
+class PartitionSearch:
+    """Equal-error partition search over a batched Python error callback
+    (ecckd_partition_*; replaces class Equipartition, equipartition.h:63-208)."""
+
+    def __init__(self, error_fn, resolution=0.0, partition_tolerance=0.05, partition_max_iterations=20,
+                 line_search_max_iterations=10, cubic=False, minimize_frac_range=True):
+        self.lib = _lib.load_library()
+        self.calls = []
+
+        def cb(n, b1, b2, err, _user):
+            try:
+                bb1 = [b1[i] for i in range(n)]
+                bb2 = [b2[i] for i in range(n)]
+                e = error_fn(bb1, bb2)
+                for i in range(n):
+                    err[i] = e[i]
+                self.calls.append((bb1, bb2, list(e)))
+                return 0
+            except Exception:  # surfaced as PROCESSING_ERROR by the search
+                import traceback
+                traceback.print_exc()
+                return _lib.PROCESSING_ERROR
+
+        self._cb = _lib.ERROR_FN(cb)
+        h = C.c_void_p()
+        check(self.lib.ecckd_partition_create(C.cast(self._cb, C.c_void_p), None, C.byref(h)))
+        self.handle = h
+        check(self.lib.ecckd_partition_configure(h, resolution, partition_tolerance, partition_max_iterations,
+                                                 line_search_max_iterations, int(cubic), int(minimize_frac_range)))
+
+    def __del__(self):
+        try:
+            self.lib.ecckd_partition_destroy(self.handle)
+        except Exception:
+            pass
+
+    def equipartition_n(self, bounds):
+        b = np.ascontiguousarray(bounds, dtype=np.float64).copy()
+        ni = b.size - 1
+        err = np.zeros(ni)
+        st = C.c_int()
+        check(self.lib.ecckd_partition_n(self.handle, ni, _hptr(b), _hptr(err), C.byref(st)))
+        return st.value, b, err
+
+    def equipartition_e(self, target_error, bound0=0.0, boundn=1.0, capacity=4096):
+        b = np.zeros(capacity + 1)
+        err = np.zeros(capacity)
+        ni, st = C.c_int(), C.c_int()
+        check(self.lib.ecckd_partition_e(self.handle, target_error, bound0, boundn, C.byref(ni), _hptr(b),
+                                         _hptr(err), capacity, C.byref(st)))
+        n = ni.value
+        return st.value, b[:n + 1].copy(), err[:n].copy()
+
+
+class GasLW:
+    """A prepared longwave gas (ecckd_gas_create_lw): find_g_points.cpp:872-1150 done once on
+    the device, then batched interval errors (CkdEquipartition::calc_error, :291-405)."""
+
+    def __init__(self, ctx, pressure_hl, temperature_hl, wavenumber, d_wavenumber, rank, optical_depth,
+                 bg_optical_depth=None, averaging_method="transmission", flux_weight=0.02, min_pressure=0.0,
+                 planck_hl_reuse=None):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        p = np.ascontiguousarray(pressure_hl, dtype=np.float64)
+        t = np.ascontiguousarray(temperature_hl, dtype=np.float64)
+        self.nlay = p.size - 1
+        if optical_depth.dim() != 2 or optical_depth.shape[0] != self.nlay:
+            raise EcckdError(_lib.PARAMETER_ERROR, "optical_depth must be (nlay, nwav)")
+        self.nwav = optical_depth.shape[1]
+        stride = optical_depth.stride(0) if self.nlay > 1 else self.nwav
+        if bg_optical_depth is not None and (bg_optical_depth.shape != optical_depth.shape or
+                                             bg_optical_depth.stride(0) != optical_depth.stride(0)):
+            raise EcckdError(_lib.PARAMETER_ERROR, "background optical depth must match the target's layout")
+        if averaging_method not in _lib.AVG:
+            raise EcckdError(_lib.PARAMETER_ERROR, f'Averaging method "{averaging_method}" not understood')
+        h = C.c_void_p()
+        ctx.fence_from_torch()
+        check(self.lib.ecckd_gas_create_lw(
+            ctx.handle, self.nlay, self.nwav, _hptr(p), _hptr(t), _dptr(wavenumber), _dptr(d_wavenumber),
+            _dptr(rank), _dptr(bg_optical_depth) if bg_optical_depth is not None else None,
+            _od_type(bg_optical_depth) if bg_optical_depth is not None else 0,
+            _dptr(optical_depth), _od_type(optical_depth), stride, _lib.AVG[averaging_method],
+            float(flux_weight), float(min_pressure),
+            C.c_void_p(planck_hl_reuse) if planck_hl_reuse else None, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ecckd_gas_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def view_ptr(self, name):
+        ptr, r, c = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        check(self.lib.ecckd_gas_view(self.handle, name.encode(), C.byref(ptr), C.byref(r), C.byref(c)))
+        return ptr.value, r.value, c.value
+
+    def view(self, name):
+        """Copy of a resident sorted array as a numpy array (rows, cols)."""
+        ptr, r, c = self.view_ptr(name)
+        out = np.empty((r, c), dtype=np.float64)
+        check(self.lib.ecckd_d2h(self.ctx.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes))
+        return out
+
+    def layer_weight(self):
+        w = np.empty(self.nlay)
+        check(self.lib.ecckd_gas_layer_weight(self.handle, _hptr(w)))
+        return w
+
+    def comp_cost(self, reset=False):
+        return float(self.lib.ecckd_gas_comp_cost(self.handle, int(reset)))
+
+    def calc_error_batch(self, ibegin, npoints, bound1, bound2):
+        b1 = np.ascontiguousarray(bound1, dtype=np.float64)
+        b2 = np.ascontiguousarray(bound2, dtype=np.float64)
+        err = np.empty(b1.size)
+        check(self.lib.ecckd_calc_error_batch(self.handle, int(ibegin), int(npoints), b1.size, _hptr(b1),
+                                              _hptr(b2), _hptr(err)))
+        return err
+
+    def find_g_band(self, ibegin, iend, heating_rate_tolerance, tolerance_tolerance=0.02, max_iterations=60,
+                    min_g_points=1, max_g_points=256, capacity=1024):
+        """find_g_points.cpp:1152-1266 for one band -> (status, bounds, error, comp_cost)."""
+        b = np.zeros(capacity + 1)
+        e = np.zeros(capacity)
+        ng, st, cc = C.c_int(), C.c_int(), C.c_double()
+        check(self.lib.ecckd_find_g_band(self.handle, int(ibegin), int(iend), float(heating_rate_tolerance),
+                                         float(tolerance_tolerance), int(max_iterations), int(min_g_points),
+                                         int(max_g_points), C.byref(ng), _hptr(b), _hptr(e), capacity,
+                                         C.byref(st), C.byref(cc)))
+        n = ng.value
+        return st.value, b[:n + 1].copy(), e[:n].copy(), cc.value

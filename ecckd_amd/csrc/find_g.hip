@@ -1,0 +1,862 @@
+// find_g.hip - K4/K5: the g-point search of find_g_points on gfx950.
+//
+// K4  ecckd_gas_create_lw    gas preparation, reference src/ecckd/find_g_points.cpp:872-1150:
+//       gather-reorder the columns by rank, Planck function, LW radiative
+//       transfer of background+target, heating rate, surface/TOA flux rows,
+//       averaging metric.  One sweep; results stay resident in HBM in SORTED
+//       order, (level, wavenumber) row-major.
+// K5  ecckd_calc_error_batch the interval error of CkdEquipartition::calc_error
+//       (find_g_points.cpp:291-405) = fit_optical_depth_lw (:54-106) +
+//       calc_cost_function_lw (calc_cost_function_lw.cpp:24-110) +
+//       radiative_transfer_lw_bb (radiative_transfer_lw.cpp:87-142), for a whole
+//       BATCH of intervals per call (the reference evaluates them one by one
+//       from OpenMP threads, equipartition.h:98-116).
+//
+// Design (MI355X): everything the fit and the "true" side of the cost need is a
+// plain SUM over the interval of per-point rows that do not depend on the
+// interval (metric*planck, planck, hr, flux rows).  K4 therefore also reduces
+// those rows over fixed 256-point tiles once; K5a sums tiles + the two ragged
+// ends, so the only pass that streams the band per evaluation is the grey-
+// optical-depth radiative transfer K5c: it reads planck (nlay+1) and background
+// optical depth (nlay) rows = (2*nlay+1)*8 B per point, coalesced 512-B wave
+// loads, with per-half-level flux sums reduced wave -> block -> interval in a
+// fixed order (bitwise reproducible; no float atomics).
+#include "common.hpp"
+#include "partition_search.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int TILE = 256;          // points per tile sum
+constexpr int RT_THREADS = 256;    // K5c block
+constexpr int PREP_THREADS = 256;  // K4 block
+
+__device__ constexpr double kPlanckH = 6.62606896e-34;
+__device__ constexpr double kLightC = 2.99792458e8;
+__device__ constexpr double kPi = 3.14159265358979323846;
+__device__ constexpr double kD = ECCKD_LW_DIFFUSIVITY;
+
+// ---------------------------------------------------------------------------
+// deterministic reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
+// sum over a 256-thread block; result valid in thread 0.  s4 = 4 doubles of LDS.
+__device__ __forceinline__ double block_sum_256(double v, double* s4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s4[wave] = v;
+  __syncthreads();
+  return ((s4[0] + s4[1]) + s4[2]) + s4[3];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// opaque handle
+struct ecckd_gas {
+  ecckd_ctx* ctx = nullptr;
+  int do_sw = 0;
+  int method = 0;
+  int nlay = 0;
+  size_t n = 0;  // wavenumbers (sorted order)
+  double flux_weight = 0.0;
+  double total_comp_cost = 0.0;
+  // device arrays, all in sorted order
+  double* planck_hl = nullptr;  // [nlay+1][n]
+  bool owns_planck = true;
+  double* bg_od = nullptr;      // [nlay][n]
+  double* w1 = nullptr;         // [nlay][n]  metric * weight          (log: log(metric)*weight)
+  double* w2 = nullptr;         // [nlay][n]  log only: weight of the denominator where metric > 0
+  double* cnt = nullptr;        // [nlay][n]  log only: 1 where metric > 0
+  double* hr = nullptr;         // [nlay][n]
+  double* fds = nullptr;        // [n] flux_dn_surf
+  double* fut = nullptr;        // [n] flux_up_toa
+  double* wn_sorted = nullptr;  // [n]
+  double* dwn_sorted = nullptr; // [n]
+  int32_t* ireorder = nullptr;  // [n]
+  // row table for interval sums
+  int nrows = 0;
+  const double** rows = nullptr;  // device array of nrows row pointers
+  double* tile_sums = nullptr;    // [nrows][ntiles]
+  size_t ntiles = 0;
+  // per-level constants on device: conv[nlay] | layer_weight[nlay]
+  double* lev = nullptr;
+  std::vector<double> h_pressure_hl;
+  std::vector<double> h_layer_weight;
+  // per-call work buffers (grown on demand)
+  void* work = nullptr;
+  size_t work_bytes = 0;
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+};
+
+namespace {
+
+// row layout helpers (must match k_fit / k_cost)
+struct RowLayout {
+  int nlay;
+  bool is_log;
+  __host__ __device__ int A(int l) const { return l; }
+  __host__ __device__ int B(int l) const { return nlay + l; }
+  __host__ __device__ int N(int l) const { return 2 * nlay + l; }  // log only
+  __host__ __device__ int H(int l) const { return (is_log ? 3 : 2) * nlay + l; }
+  __host__ __device__ int FDS() const { return (is_log ? 4 : 3) * nlay; }
+  __host__ __device__ int FUT() const { return (is_log ? 4 : 3) * nlay + 1; }
+  __host__ __device__ int total() const { return (is_log ? 4 : 3) * nlay + 2; }
+};
+
+// ---------------------------------------------------------------------------
+// K4 helpers
+__global__ void __launch_bounds__(256)
+k_invert_rank(size_t n, const int32_t* __restrict__ rank, int32_t* __restrict__ ireorder, int* __restrict__ err) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int32_t r = rank[j];
+  if (r < 0 || (size_t)r >= n) { atomicOr(err, 2); return; }
+  ireorder[r] = (int32_t)j;  // find_g_points.cpp:779-780
+}
+
+__device__ __forceinline__ double metric_of(int method, double od) {
+  // find_g_points.cpp:1119-1150
+  switch (method) {
+    case ECCKD_AVG_TRANSMISSION: return 1.0 - exp(-od * kD);
+    case ECCKD_AVG_TRANSMISSION_2: return 1.0 - exp(-od * kD * 2.0);
+    case ECCKD_AVG_SQUARE_ROOT: return sqrt(od);
+    default: return od;  // linear, logarithmic, total-transmission
+  }
+}
+
+// K4 (LW).  One thread per SORTED wavenumber i; source column j = ireorder[i].
+// Dynamic LDS: double[nlay][blockDim.x] for the down-sweep flux increments.
+template <typename BgT, typename OdT>
+__global__ void __launch_bounds__(PREP_THREADS)
+k_gas_prep_lw(int nlay, size_t n, size_t src_stride, int method,
+              const int32_t* __restrict__ ireorder, const double* __restrict__ hk /*[nhl] (h/k)/T*/,
+              const double* __restrict__ conv /*[nlay]*/,
+              const double* __restrict__ wn, const double* __restrict__ dwn,
+              const BgT* __restrict__ bg_src, const OdT* __restrict__ od_src,
+              const double* __restrict__ planck_reuse,
+              double* __restrict__ wn_sorted, double* __restrict__ dwn_sorted,
+              double* __restrict__ planck_hl, double* __restrict__ bg_od, double* __restrict__ w1,
+              double* __restrict__ w2, double* __restrict__ cnt,
+              double* __restrict__ hr, double* __restrict__ fds, double* __restrict__ fut) {
+  extern __shared__ double s_col[];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const size_t j = (size_t)ireorder[i];
+  const bool is_log = (method == ECCKD_AVG_LOGARITHMIC);
+
+  // planck_function.cpp:48-50 on the reordered wavenumbers (find_g_points.cpp:970-979)
+  const double w = wn[j], dw = dwn[j];
+  wn_sorted[i] = w;
+  dwn_sorted[i] = dw;
+  const double inv_cm_2_Hz = 100.0 * kLightC;
+  const double freq = w * inv_cm_2_Hz;
+  const double pref = (dw * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq);
+  auto planck_at = [&](int lev) -> double {
+    if (planck_reuse) return planck_reuse[(size_t)lev * n + i];
+    return pref / (exp(freq * hk[lev]) - 1.0);
+  };
+
+  double b_prev = planck_at(0);
+  if (!planck_reuse) planck_hl[i] = b_prev;
+  double dn = 0.0;
+  for (int l = 0; l < nlay; ++l) {
+    const double bg = bg_src ? (double)bg_src[(size_t)l * src_stride + j] : 0.0;
+    const double od = (double)od_src[(size_t)l * src_stride + j];
+    const double tau = bg + od;  // find_g_points.cpp:993
+    // radiative_transfer_lw.cpp:41-43
+    const double eps = 1.0 - exp(-kD * tau);
+    const double fac = (eps > 1.0e-5) ? 1.0 - eps * (1.0 / kD) / tau : 0.5 * eps;
+    const double b_next = planck_at(l + 1);
+    const double dn_next = dn * (1.0 - eps) + b_prev * (eps - fac) + b_next * fac;
+    s_col[l * bs + tid] = dn_next - dn;
+    const size_t o = (size_t)l * n + i;
+    bg_od[o] = bg;
+    if (!planck_reuse) planck_hl[(size_t)(l + 1) * n + i] = b_next;
+    const double m = metric_of(method, od);
+    if (!is_log) {
+      // numerator row of fit_optical_depth_lw (find_g_points.cpp:61-62): metric * planck_hl(l+1)
+      w1[o] = m * b_next;
+    } else {
+      // find_g_points.cpp:81-98: log(metric) weighted by planck_hl(l+1) over planck_hl(l), metric > 0 only
+      const bool pos = m > 0.0;
+      w1[o] = pos ? log(m) * b_next : 0.0;
+      w2[o] = pos ? b_prev : 0.0;
+      cnt[o] = pos ? 1.0 : 0.0;
+    }
+    dn = dn_next;
+    b_prev = b_next;
+  }
+  fds[i] = dn;  // flux_dn(end,__), find_g_points.cpp:1045
+  // surface: emissivity 1, surf_planck = planck at temperature_hl(end) (:976-978, :987-988)
+  double up = b_prev * 1.0 + (1.0 - 1.0) * dn;
+  for (int l = nlay - 1; l >= 0; --l) {
+    const double bg = bg_src ? (double)bg_src[(size_t)l * src_stride + j] : 0.0;
+    const double od = (double)od_src[(size_t)l * src_stride + j];
+    const double tau = bg + od;
+    const double eps = 1.0 - exp(-kD * tau);
+    const double fac = (eps > 1.0e-5) ? 1.0 - eps * (1.0 / kD) / tau : 0.5 * eps;
+    const double b_l = planck_at(l);
+    const double up_l = up * (1.0 - eps) + b_prev * (eps - fac) + b_l * fac;
+    // heating_rate.h:47-48
+    hr[(size_t)l * n + i] = conv[l] * (s_col[l * bs + tid] - up + up_l);
+    up = up_l;
+    b_prev = b_l;
+  }
+  fut[i] = up;  // flux_up(0,__), find_g_points.cpp:1052
+}
+
+// tile sums of every row: TS[r][t] = sum_{i in tile t} rows[r][i]
+__global__ void __launch_bounds__(TILE)
+k_tile_sums(int nrows, size_t n, size_t ntiles, const double* const* __restrict__ rows,
+            double* __restrict__ ts) {
+  __shared__ double s4[4];
+  const size_t t = blockIdx.x;
+  const size_t i = t * TILE + threadIdx.x;
+  for (int r = 0; r < nrows; ++r) {
+    const double v = (i < n) ? rows[r][i] : 0.0;
+    const double s = block_sum_256(v, s4);
+    if (threadIdx.x == 0) ts[(size_t)r * ntiles + t] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K5a: interval sums.  grid (nrows, nint); block 256.
+// sums[k][r] = sum_{i=i1_k..i2_k} rows[r][i] = ragged head + whole tiles + ragged tail
+struct Interval {
+  long long i1, i2;      // inclusive global sorted indices
+  long long chunk0;      // first RT chunk of this interval
+  long long npoints;     // band length (for the logarithmic fit)
+};
+
+__global__ void __launch_bounds__(256)
+k_interval_sums(int nrows, size_t ntiles, const Interval* __restrict__ iv,
+                const double* const* __restrict__ rows, const double* __restrict__ ts,
+                double* __restrict__ sums) {
+  __shared__ double s4[4];
+  const int r = blockIdx.x, k = blockIdx.y;
+  const long long i1 = iv[k].i1, i2 = iv[k].i2;
+  const double* row = rows[r];
+  const double* trow = ts + (size_t)r * ntiles;
+  const long long t1 = (i1 + TILE - 1) / TILE;   // first whole tile
+  const long long t2 = (i2 + 1) / TILE;          // one past the last whole tile
+  double acc = 0.0;
+  const int tid = threadIdx.x;
+  if (t1 >= t2) {
+    // no whole tile inside: at most 2*TILE-2 raw points
+    for (long long i = i1 + tid; i <= i2; i += 256) acc += row[i];
+  } else {
+    const long long head_end = t1 * TILE;  // exclusive
+    if (i1 + tid < head_end) acc += row[i1 + tid];
+    for (long long t = t1 + tid; t < t2; t += 256) acc += trow[t];
+    const long long tail = t2 * TILE + tid;
+    if (tail <= i2) acc += row[tail];
+  }
+  const double s = block_sum_256(acc, s4);
+  if (tid == 0) sums[(size_t)k * nrows + r] = s;
+}
+
+// K5b: fitted grey optical depth per (interval, layer).  grid nint, block 128.
+__global__ void __launch_bounds__(128)
+k_fit_lw(int nlay, int method, int nrows, const Interval* __restrict__ iv,
+         const double* __restrict__ sums, double* __restrict__ od_fit) {
+  const int k = blockIdx.x;
+  const RowLayout R{nlay, method == ECCKD_AVG_LOGARITHMIC};
+  const double* s = sums + (size_t)k * nrows;
+  for (int l = threadIdx.x; l < nlay; l += blockDim.x) {
+    const double a = s[R.A(l)], b = s[R.B(l)];
+    double fit;
+    switch (method) {
+      case ECCKD_AVG_LINEAR:
+        fit = a / b;
+        break;
+      case ECCKD_AVG_TRANSMISSION:  // find_g_points.cpp:64-68
+        fit = fabs(-log(1.0 - fmin(0.9999999999999999, a / b)) / kD);
+        break;
+      case ECCKD_AVG_TRANSMISSION_2:
+        fit = fabs(-log(1.0 - fmin(0.9999999999999999, a / b)) / (kD * 2.0));
+        break;
+      case ECCKD_AVG_SQUARE_ROOT: {
+        const double v = a / b;
+        fit = v * v;
+        break;
+      }
+      case ECCKD_AVG_LOGARITHMIC: {  // find_g_points.cpp:79-99
+        const double nnz = s[R.N(l)];
+        const double ntot = (double)(iv[k].i2 - iv[k].i1 + 1);
+        if (nnz == ntot) fit = exp(a / b);
+        else if (nnz == 0.0) fit = 0.0;
+        else fit = exp(a / b) * (nnz / ntot);
+        break;
+      }
+      default:
+        fit = nan("");
+    }
+    od_fit[(size_t)k * nlay + l] = fit;
+  }
+}
+
+// K5c: grey-optical-depth LW radiative transfer with broadband sums,
+// radiative_transfer_lw_bb (radiative_transfer_lw.cpp:87-142) for every interval.
+// One block = one chunk of `chunk_pts` consecutive points of ONE interval,
+// processed as sub-tiles of 256 points (one point per thread).  Per half-level
+// the 64 lanes' fluxes are reduced in the wave and lane 0 accumulates into
+// s_acc[wave][...]; the four waves are combined in order at the end and the
+// block writes its 2*(nlay+1) partial sums to `partial[chunk]`.
+// The up sweep re-evaluates emissivity and factor exactly as the reference does
+// (:128-137) from re-loaded rows (second touch is served by L2/Infinity Cache).
+__global__ void __launch_bounds__(RT_THREADS)
+k_rt_lw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv,
+           const double* __restrict__ planck_hl, const double* __restrict__ bg_od,
+           const double* __restrict__ od_fit, double* __restrict__ partial) {
+  extern __shared__ double s_mem[];  // [4][2*nhl] accumulators | [nlay] grey od
+  const int nhl = nlay + 1;
+  double* s_acc = s_mem;
+  double* s_grey = s_mem + 4 * 2 * nhl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // locate this block's interval: chunk0 is ascending
+  const long long chunk = blockIdx.x;
+  int lo = 0, hi = nint - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (iv[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
+  }
+  const int k = lo;
+  const long long c = chunk - iv[k].chunk0;
+  const long long p0 = iv[k].i1 + c * chunk_pts;
+  long long p1 = p0 + chunk_pts - 1;
+  if (p1 > iv[k].i2) p1 = iv[k].i2;
+
+  for (int t = tid; t < 4 * 2 * nhl; t += RT_THREADS) s_acc[t] = 0.0;
+  for (int l = tid; l < nlay; l += RT_THREADS) s_grey[l] = od_fit[(size_t)k * nlay + l];
+  __syncthreads();
+  double* acc_dn = s_acc + wave * 2 * nhl;
+  double* acc_up = acc_dn + nhl;
+
+  constexpr double THRESHOLD_EMISSIVITY = 1.0e-5;
+  for (long long base = p0; base <= p1; base += RT_THREADS) {
+    const long long i = base + tid;
+    const bool live = i <= p1;
+    const size_t ii = live ? (size_t)i : (size_t)p1;
+    // ---- down sweep (:109-124) ----
+    double flux = 0.0;
+    double b_prev = planck_hl[ii];
+    for (int l = 0; l < nlay; ++l) {
+      const double od = bg_od[(size_t)l * n + ii] + s_grey[l];
+      const double b_next = planck_hl[(size_t)(l + 1) * n + ii];
+      const double eps = 1.0 - exp(-kD * od);
+      const double fac = fmax(1.0 - (1.0 / kD) * fmax(eps, THRESHOLD_EMISSIVITY) /
+                                         fmax(od, THRESHOLD_EMISSIVITY / kD),
+                              0.5 * THRESHOLD_EMISSIVITY);
+      flux = flux * (1.0 - eps) + b_prev * (eps - fac) + b_next * fac;
+      const double s = wave_sum(live ? flux : 0.0);
+      if (lane == 0) acc_dn[l + 1] += s;
+      b_prev = b_next;
+    }
+    // ---- surface (:126-128), emissivity 1, surf_planck = planck_hl(nlay) ----
+    flux = b_prev * 1.0 + (1.0 - 1.0) * flux;
+    {
+      const double s = wave_sum(live ? flux : 0.0);
+      if (lane == 0) acc_up[nlay] += s;
+    }
+    // ---- up sweep (:130-141) ----
+    for (int l = nlay - 1; l >= 0; --l) {
+      const double od = bg_od[(size_t)l * n + ii] + s_grey[l];
+      const double b_l = planck_hl[(size_t)l * n + ii];
+      const double eps = 1.0 - exp(-kD * od);
+      const double fac = fmax(1.0 - (1.0 / kD) * fmax(eps, THRESHOLD_EMISSIVITY) /
+                                         fmax(od, THRESHOLD_EMISSIVITY / kD),
+                              0.5 * THRESHOLD_EMISSIVITY);
+      flux = flux * (1.0 - eps) + b_prev * (eps - fac) + b_l * fac;
+      const double s = wave_sum(live ? flux : 0.0);
+      if (lane == 0) acc_up[l] += s;
+      b_prev = b_l;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * nhl; t += RT_THREADS) {
+    partial[(size_t)chunk * 2 * nhl + t] =
+        ((s_acc[t] + s_acc[2 * nhl + t]) + s_acc[4 * nhl + t]) + s_acc[6 * nhl + t];
+  }
+}
+
+// K5d: combine chunk partials of each interval in order, heating rate, cost
+// (calc_cost_function_lw.cpp:100-109).  grid nint, block 1024 = 8 groups x 128.
+__global__ void __launch_bounds__(1024)
+k_cost_lw(int nlay, int method, int nrows, const Interval* __restrict__ iv, long long nchunks_total,
+          const double* __restrict__ partial, const double* __restrict__ sums,
+          const double* __restrict__ conv, const double* __restrict__ layer_weight,
+          double flux_weight, double* __restrict__ err) {
+  extern __shared__ double s_mem[];  // [8][2*nhl] | [2*nhl] | [nlay]
+  const int nhl = nlay + 1;
+  const int nv = 2 * nhl;
+  double* s_grp = s_mem;
+  double* s_flux = s_mem + 8 * nv;
+  double* s_term = s_flux + nv;
+  const int k = blockIdx.x;
+  const long long c0 = iv[k].chunk0;
+  const long long c1 = (k + 1 < (int)gridDim.x) ? iv[k + 1].chunk0 : nchunks_total;
+  const int tid = threadIdx.x;
+  const int g = tid >> 7, t = tid & 127;
+  for (int v = t; v < nv; v += 128) {
+    double a = 0.0;
+    for (long long c = c0 + g; c < c1; c += 8) a += partial[(size_t)c * nv + v];
+    s_grp[g * nv + v] = a;
+  }
+  __syncthreads();
+  for (int v = tid; v < nv; v += 1024) {
+    double a = 0.0;
+    for (int gg = 0; gg < 8; ++gg) a += s_grp[gg * nv + v];
+    s_flux[v] = a;
+  }
+  __syncthreads();
+  const RowLayout R{nlay, method == ECCKD_AVG_LOGARITHMIC};
+  const double* s = sums + (size_t)k * nrows;
+  const double* dn = s_flux;
+  const double* up = s_flux + nhl;
+  for (int l = tid; l < nlay; l += 1024) {
+    // heating_rate_single (heating_rate.h:55-72) and the weighted squared difference
+    const double hr_fit = conv[l] * (dn[l + 1] - dn[l] - up[l + 1] + up[l]);
+    const double d = hr_fit - s[R.H(l)];
+    s_term[l] = layer_weight[l] * (d * d);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double ss = 0.0;
+    for (int l = 0; l < nlay; ++l) ss += s_term[l];
+    const double hr_weight = 3600.0 * 24.0;
+    const double dsurf = dn[nlay] - s[R.FDS()];
+    const double dtoa = up[0] - s[R.FUT()];
+    err[k] = sqrt(hr_weight * hr_weight * ss + flux_weight * (dsurf * dsurf + dtoa * dtoa));
+  }
+}
+
+int gas_ensure_work(ecckd_gas* g, size_t dev_bytes, size_t pinned_bytes) {
+  if (dev_bytes > g->work_bytes) {
+    if (g->work) {
+      ECCKD_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+      ECCKD_HIP_CHECK(hipFree(g->work));
+      g->work = nullptr;
+      g->work_bytes = 0;
+    }
+    size_t want = ecckd_align_up(dev_bytes * 2, 1 << 20);
+    ECCKD_HIP_CHECK(hipMalloc(&g->work, want));
+    g->work_bytes = want;
+  }
+  if (pinned_bytes > g->pinned_bytes) {
+    if (g->pinned) {
+      ECCKD_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+      ECCKD_HIP_CHECK(hipHostFree(g->pinned));
+      g->pinned = nullptr;
+      g->pinned_bytes = 0;
+    }
+    size_t want = ecckd_align_up(pinned_bytes * 2, 4096);
+    ECCKD_HIP_CHECK(hipHostMalloc(&g->pinned, want, hipHostMallocDefault));
+    g->pinned_bytes = want;
+  }
+  return ECCKD_OK;
+}
+
+void gas_free(ecckd_gas* g) {
+  if (!g) return;
+  if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
+  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  if (g->owns_planck) fr(g->planck_hl);
+  fr(g->bg_od); fr(g->w1); fr(g->w2); fr(g->cnt); fr(g->hr); fr(g->fds); fr(g->fut);
+  fr(g->wn_sorted); fr(g->dwn_sorted); fr(g->ireorder); fr((void*)g->rows); fr(g->tile_sums);
+  fr(g->lev); fr(g->work);
+  if (g->pinned) (void)hipHostFree(g->pinned);
+  delete g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_pressure_hl,
+                        const double* h_temperature_hl, const double* d_wavenumber,
+                        const double* d_d_wavenumber, const int32_t* d_rank, const void* d_bg_od,
+                        int bg_type, const void* d_od, int od_type, size_t src_stride,
+                        int averaging_method, double flux_weight, double min_pressure,
+                        const double* d_planck_hl_reuse, ecckd_gas** out) {
+  ECCKD_REQUIRE(ctx && out, "ecckd_gas_create_lw: NULL ctx/out");
+  *out = nullptr;
+  ECCKD_REQUIRE(nlay > 0 && nwav > 0, "ecckd_gas_create_lw: empty problem (nlay=%d, nwav=%zu)", nlay, nwav);
+  ECCKD_REQUIRE(nwav < (size_t)0x7fffffff, "ecckd_gas_create_lw: nwav exceeds int32 rank range");
+  ECCKD_REQUIRE(h_pressure_hl && h_temperature_hl && d_wavenumber && d_d_wavenumber && d_rank && d_od,
+                "ecckd_gas_create_lw: NULL array argument");
+  ECCKD_REQUIRE(od_type == ECCKD_F32 || od_type == ECCKD_F64, "ecckd_gas_create_lw: od_type must be 4 or 8");
+  ECCKD_REQUIRE(!d_bg_od || bg_type == ECCKD_F32 || bg_type == ECCKD_F64, "ecckd_gas_create_lw: bg_type must be 4 or 8");
+  ECCKD_REQUIRE(src_stride >= nwav, "ecckd_gas_create_lw: src_stride < nwav");
+  // find_g_points.cpp:1146-1149: unknown averaging method is a PARAMETER_ERROR;
+  // total-transmission is shortwave-only (fit_optical_depth_lw has no such branch, :101-104)
+  ECCKD_REQUIRE(averaging_method >= ECCKD_AVG_LINEAR && averaging_method <= ECCKD_AVG_LOGARITHMIC,
+                "Averaging method %d not understood", averaging_method);
+  for (int i = 0; i <= nlay; ++i)
+    ECCKD_REQUIRE(h_pressure_hl[i] > 0.0 && h_temperature_hl[i] > 0.0 && (i == 0 || h_pressure_hl[i] > h_pressure_hl[i - 1]),
+                  "ecckd_gas_create_lw: pressure_hl must be positive and increasing, temperature_hl positive");
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  if ((size_t)nlay * 64 * sizeof(double) > 160 * 1024)
+    return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_gas_create_lw: nlay = %d exceeds the supported maximum (320)", nlay);
+
+  ecckd_gas* g = new ecckd_gas();
+  g->ctx = ctx;
+  g->do_sw = 0;
+  g->method = averaging_method;
+  g->nlay = nlay;
+  g->n = nwav;
+  g->flux_weight = flux_weight;
+  g->h_pressure_hl.assign(h_pressure_hl, h_pressure_hl + nlay + 1);
+  const bool is_log = averaging_method == ECCKD_AVG_LOGARITHMIC;
+  const size_t nhl = nlay + 1;
+  int rc = ECCKD_OK;
+#define GTRY(expr)                                                                       \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      rc = ecckd::fail(_e == hipErrorOutOfMemory ? ECCKD_OUT_OF_MEMORY : ECCKD_UNEXPECTED_EXCEPTION, \
+                       "%s failed: %s", #expr, hipGetErrorString(_e));                   \
+      gas_free(g);                                                                       \
+      return rc;                                                                         \
+    }                                                                                    \
+  } while (0)
+  const size_t mat = (size_t)nlay * nwav * sizeof(double);
+  if (d_planck_hl_reuse) {
+    g->planck_hl = const_cast<double*>(d_planck_hl_reuse);
+    g->owns_planck = false;
+  } else {
+    GTRY(hipMalloc((void**)&g->planck_hl, nhl * nwav * sizeof(double)));
+  }
+  GTRY(hipMalloc((void**)&g->bg_od, mat));
+  GTRY(hipMalloc((void**)&g->w1, mat));
+  if (is_log) {
+    GTRY(hipMalloc((void**)&g->w2, mat));
+    GTRY(hipMalloc((void**)&g->cnt, mat));
+  }
+  GTRY(hipMalloc((void**)&g->hr, mat));
+  GTRY(hipMalloc((void**)&g->fds, nwav * sizeof(double)));
+  GTRY(hipMalloc((void**)&g->fut, nwav * sizeof(double)));
+  GTRY(hipMalloc((void**)&g->wn_sorted, nwav * sizeof(double)));
+  GTRY(hipMalloc((void**)&g->dwn_sorted, nwav * sizeof(double)));
+  GTRY(hipMalloc((void**)&g->ireorder, nwav * sizeof(int32_t)));
+
+  // per-level constants: hk[nhl] | conv[nlay] | layer_weight[nlay] | flag
+  std::vector<double> lev(nhl + 2 * nlay + 1, 0.0);
+  const double hk = 6.62606896e-34 / 1.3806504e-23;
+  for (size_t i = 0; i < nhl; ++i) lev[i] = hk / h_temperature_hl[i];
+  g->h_layer_weight.resize(nlay);
+  {
+    // find_g_points.cpp:1093-1099
+    double s = 0.0;
+    for (int l = 0; l < nlay; ++l) {
+      lev[nhl + l] = -(ECCKD_ACCEL_GRAVITY / ECCKD_SPECIFIC_HEAT_AIR) / (h_pressure_hl[l + 1] - h_pressure_hl[l]);
+      double lw = std::sqrt(h_pressure_hl[l + 1]) - std::sqrt(h_pressure_hl[l]);
+      double pfl = 0.5 * (h_pressure_hl[l + 1] + h_pressure_hl[l]);
+      if (pfl < min_pressure) lw = 0.0;
+      g->h_layer_weight[l] = lw;
+    }
+    for (int l = 0; l < nlay; ++l) s += g->h_layer_weight[l];
+    for (int l = 0; l < nlay; ++l) {
+      g->h_layer_weight[l] /= s;
+      lev[nhl + nlay + l] = g->h_layer_weight[l];
+    }
+  }
+  GTRY(hipMalloc((void**)&g->lev, lev.size() * sizeof(double)));
+  GTRY(hipMemcpyAsync(g->lev, lev.data(), lev.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GTRY(hipStreamSynchronize(ctx->stream));
+  int* d_flag = (int*)(g->lev + nhl + 2 * nlay);
+
+  const unsigned eblocks = (unsigned)((nwav + 255) / 256);
+  hipLaunchKernelGGL(k_invert_rank, dim3(eblocks), dim3(256), 0, ctx->stream, nwav, d_rank, g->ireorder, d_flag);
+
+  int threads = PREP_THREADS;
+  while ((size_t)nlay * threads * sizeof(double) > 160 * 1024 && threads > 64) threads /= 2;
+  const size_t lds = (size_t)nlay * threads * sizeof(double);
+  const unsigned pblocks = (unsigned)((nwav + threads - 1) / threads);
+  const double* hkd = g->lev;
+  const double* convd = g->lev + nhl;
+#define LAUNCH_PREP(BG, OD)                                                                                   \
+  do {                                                                                                        \
+    GTRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gas_prep_lw<BG, OD>),                            \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                        \
+    hipLaunchKernelGGL((k_gas_prep_lw<BG, OD>), dim3(pblocks), dim3(threads), lds, ctx->stream, nlay, nwav,   \
+                       src_stride, averaging_method, g->ireorder, hkd, convd, d_wavenumber, d_d_wavenumber,   \
+                       (const BG*)d_bg_od, (const OD*)d_od, d_planck_hl_reuse, g->wn_sorted, g->dwn_sorted,   \
+                       g->planck_hl, g->bg_od, g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut);                  \
+  } while (0)
+  const bool bg32 = d_bg_od && bg_type == ECCKD_F32;
+  if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP(float, float);
+  else if (bg32) LAUNCH_PREP(float, double);
+  else if (od_type == ECCKD_F32) LAUNCH_PREP(double, float);
+  else LAUNCH_PREP(double, double);
+#undef LAUNCH_PREP
+  GTRY(hipGetLastError());
+
+  // row table + tile sums
+  const RowLayout R{nlay, is_log};
+  g->nrows = R.total();
+  std::vector<const double*> rows(g->nrows);
+  for (int l = 0; l < nlay; ++l) {
+    rows[R.A(l)] = g->w1 + (size_t)l * nwav;
+    // denominator of the fit: planck_hl(l+1) (find_g_points.cpp:62), or for the
+    // logarithmic method planck_hl(l) masked by metric > 0 (:87)
+    rows[R.B(l)] = is_log ? g->w2 + (size_t)l * nwav : g->planck_hl + (size_t)(l + 1) * nwav;
+    if (is_log) rows[R.N(l)] = g->cnt + (size_t)l * nwav;
+    rows[R.H(l)] = g->hr + (size_t)l * nwav;
+  }
+  rows[R.FDS()] = g->fds;
+  rows[R.FUT()] = g->fut;
+  GTRY(hipMalloc((void**)&g->rows, rows.size() * sizeof(double*)));
+  GTRY(hipMemcpyAsync((void*)g->rows, rows.data(), rows.size() * sizeof(double*), hipMemcpyHostToDevice, ctx->stream));
+  GTRY(hipStreamSynchronize(ctx->stream));
+  g->ntiles = (nwav + TILE - 1) / TILE;
+  GTRY(hipMalloc((void**)&g->tile_sums, (size_t)g->nrows * g->ntiles * sizeof(double)));
+  hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)g->ntiles), dim3(TILE), 0, ctx->stream, g->nrows, nwav, g->ntiles,
+                     (const double* const*)g->rows, g->tile_sums);
+  GTRY(hipGetLastError());
+  int flag = 0;
+  GTRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  GTRY(hipStreamSynchronize(ctx->stream));
+#undef GTRY
+  if (flag) {
+    gas_free(g);
+    return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_gas_create_lw: rank is not a permutation of 0..nwav-1");
+  }
+  *out = g;
+  return ECCKD_OK;
+}
+
+int ecckd_gas_destroy(ecckd_gas* gas) {
+  gas_free(gas);
+  return ECCKD_OK;
+}
+
+// device views of the resident, sorted arrays (for tests and for reuse of planck_hl)
+int ecckd_gas_view(ecckd_gas* gas, const char* name, const double** d_ptr, size_t* rows, size_t* cols) {
+  ECCKD_REQUIRE(gas && name && d_ptr, "ecckd_gas_view: NULL argument");
+  const size_t nlay = gas->nlay, n = gas->n;
+  size_t r = 0;
+  const double* p = nullptr;
+  if (!strcmp(name, "planck_hl")) { p = gas->planck_hl; r = nlay + 1; }
+  else if (!strcmp(name, "bg_optical_depth")) { p = gas->bg_od; r = nlay; }
+  else if (!strcmp(name, "weighted_metric")) { p = gas->w1; r = nlay; }
+  else if (!strcmp(name, "hr")) { p = gas->hr; r = nlay; }
+  else if (!strcmp(name, "flux_dn_surf")) { p = gas->fds; r = 1; }
+  else if (!strcmp(name, "flux_up_toa")) { p = gas->fut; r = 1; }
+  else if (!strcmp(name, "wavenumber")) { p = gas->wn_sorted; r = 1; }
+  else if (!strcmp(name, "d_wavenumber")) { p = gas->dwn_sorted; r = 1; }
+  else if (!strcmp(name, "ssi")) { p = nullptr; r = 1; }
+  if (!p) return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_gas_view: no array named \"%s\"", name);
+  *d_ptr = p;
+  if (rows) *rows = r;
+  if (cols) *cols = n;
+  return ECCKD_OK;
+}
+
+int ecckd_gas_layer_weight(ecckd_gas* gas, double* h_layer_weight) {
+  ECCKD_REQUIRE(gas && h_layer_weight, "ecckd_gas_layer_weight: NULL argument");
+  std::memcpy(h_layer_weight, gas->h_layer_weight.data(), gas->h_layer_weight.size() * sizeof(double));
+  return ECCKD_OK;
+}
+
+double ecckd_gas_comp_cost(ecckd_gas* gas, int reset) {
+  if (!gas) return 0.0;
+  double c = gas->total_comp_cost;
+  if (reset) gas->total_comp_cost = 0.0;
+  return c;
+}
+
+int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, const double* bound1,
+                           const double* bound2, double* error) {
+  ECCKD_REQUIRE(g && (n == 0 || (bound1 && bound2 && error)), "ecckd_calc_error_batch: NULL argument");
+  ECCKD_REQUIRE(npoints > 0 && ibegin + npoints <= g->n,
+                "ecckd_calc_error_batch: band [%zu,%zu) outside the spectrum (%zu points)", ibegin, ibegin + npoints, g->n);
+  if (n <= 0) return ECCKD_OK;
+  ecckd_ctx* ctx = g->ctx;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const int nlay = g->nlay, nhl = nlay + 1;
+
+  // index mapping and error paths of CkdEquipartition::calc_error (find_g_points.cpp:282-320)
+  std::vector<Interval> iv(n);
+  long long total_pts = 0;
+  for (int k = 0; k < n; ++k) {
+    const double b1 = bound1[k], b2 = bound2[k];
+    long long i1 = (long long)std::ceil(b1 * (double)(npoints - 1));
+    long long i2 = (long long)std::floor(b2 * (double)(npoints - 1));
+    if (i1 < 0 || i2 >= (long long)npoints || !(b1 == b1) || !(b2 == b2))
+      return ecckd::fail(ECCKD_PROCESSING_ERROR,
+                         "requested bounds %.17g-%.17g corresponding to indices %lld-%lld outside valid range 0-%zu",
+                         b1, b2, i1, i2, npoints - 1);
+    if (b2 < b1) return ecckd::fail(ECCKD_PROCESSING_ERROR, "requested bounds out of order: %.17g-%.17g", b1, b2);
+    if (i2 + 1 < i1) return ecckd::fail(ECCKD_PROCESSING_ERROR, "requested indices out of order: %lld-%lld", i1, i2);
+    if (i2 < i1) i2 = i1;
+    iv[k].i1 = (long long)ibegin + i1;
+    iv[k].i2 = (long long)ibegin + i2;
+    iv[k].npoints = (long long)npoints;
+    total_pts += i2 - i1 + 1;
+  }
+  for (int k = 0; k < n; ++k) g->total_comp_cost += bound2[k] - bound1[k];  // :320
+
+  // chunking: aim at ~8 blocks per CU, chunks are multiples of the 256-point sub-tile
+  long long target_blocks = (long long)ctx->num_cu * 8;
+  long long chunk_pts = (total_pts + target_blocks - 1) / target_blocks;
+  chunk_pts = (chunk_pts + RT_THREADS - 1) / RT_THREADS * RT_THREADS;
+  if (chunk_pts < RT_THREADS) chunk_pts = RT_THREADS;
+  long long nchunks = 0;
+  for (int k = 0; k < n; ++k) {
+    iv[k].chunk0 = nchunks;
+    nchunks += (iv[k].i2 - iv[k].i1 + 1 + chunk_pts - 1) / chunk_pts;
+  }
+
+  // device work layout: intervals | sums[n][nrows] | od_fit[n][nlay] | partial[nchunks][2nhl] | err[n]
+  const size_t iv_bytes = ecckd_align_up((size_t)n * sizeof(Interval), 256);
+  const size_t sums_bytes = ecckd_align_up((size_t)n * g->nrows * sizeof(double), 256);
+  const size_t fit_bytes = ecckd_align_up((size_t)n * nlay * sizeof(double), 256);
+  const size_t part_bytes = ecckd_align_up((size_t)nchunks * 2 * nhl * sizeof(double), 256);
+  const size_t err_bytes = ecckd_align_up((size_t)n * sizeof(double), 256);
+  ECCKD_CHECK(gas_ensure_work(g, iv_bytes + sums_bytes + fit_bytes + part_bytes + err_bytes, iv_bytes + err_bytes));
+  char* w = (char*)g->work;
+  Interval* d_iv = (Interval*)w; w += iv_bytes;
+  double* d_sums = (double*)w; w += sums_bytes;
+  double* d_fit = (double*)w; w += fit_bytes;
+  double* d_part = (double*)w; w += part_bytes;
+  double* d_err = (double*)w;
+  Interval* h_iv = (Interval*)g->pinned;
+  double* h_err = (double*)((char*)g->pinned + iv_bytes);
+  std::memcpy(h_iv, iv.data(), (size_t)n * sizeof(Interval));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, h_iv, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
+
+  hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv,
+                     (const double* const*)g->rows, g->tile_sums, d_sums);
+  hipLaunchKernelGGL(k_fit_lw, dim3(n), dim3(128), 0, ctx->stream, nlay, g->method, g->nrows, d_iv, d_sums, d_fit);
+  const size_t rt_lds = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
+  hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, ctx->stream, nlay, g->n,
+                     chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+  const size_t cost_lds = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
+  hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, ctx->stream, nlay, g->method, g->nrows, d_iv,
+                     nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, d_err);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  ECCKD_HIP_CHECK(hipMemcpyAsync(h_err, d_err, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  std::memcpy(error, h_err, (size_t)n * sizeof(double));
+  return ECCKD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// partition search over a host callback (replaces Equipartition, equipartition.h:63-208)
+struct ecckd_partition {
+  ecckd_error_fn fn = nullptr;
+  void* user = nullptr;
+  ecckd::PartitionSearch* ps = nullptr;
+};
+
+int ecckd_partition_create(ecckd_error_fn fn, void* user, ecckd_partition** out) {
+  ECCKD_REQUIRE(fn && out, "ecckd_partition_create: NULL argument");
+  ecckd_partition* p = new ecckd_partition();
+  p->fn = fn;
+  p->user = user;
+  p->ps = new ecckd::PartitionSearch(
+      [p](int n, const double* b1, const double* b2, double* e) { return p->fn(n, b1, b2, e, p->user); });
+  *out = p;
+  return ECCKD_OK;
+}
+
+int ecckd_partition_destroy(ecckd_partition* p) {
+  if (p) {
+    delete p->ps;
+    delete p;
+  }
+  return ECCKD_OK;
+}
+
+int ecckd_partition_configure(ecckd_partition* p, double resolution, double partition_tolerance,
+                              int partition_max_iterations, int line_search_max_iterations,
+                              int cubic_interpolation, int minimize_frac_range) {
+  ECCKD_REQUIRE(p, "ecckd_partition_configure: NULL handle");
+  p->ps->set_resolution(resolution);
+  p->ps->set_partition_tolerance(partition_tolerance);
+  p->ps->set_partition_max_iterations(partition_max_iterations);
+  p->ps->set_line_search_max_iterations(line_search_max_iterations);
+  p->ps->set_cubic_interpolation(cubic_interpolation != 0);
+  p->ps->set_minimize_frac_range(minimize_frac_range != 0);
+  return ECCKD_OK;
+}
+
+int ecckd_partition_n(ecckd_partition* p, int ni, double* bounds, double* error, int* status) {
+  ECCKD_REQUIRE(p && ni > 0 && bounds && error && status, "ecckd_partition_n: bad argument");
+  *status = p->ps->equipartition_n(ni, bounds, error);
+  if (p->ps->evaluator_status()) return p->ps->evaluator_status();
+  return ECCKD_OK;
+}
+
+int ecckd_partition_e(ecckd_partition* p, double target_error, double bound0, double boundn, int* ni,
+                      double* bounds, double* error, int capacity, int* status) {
+  ECCKD_REQUIRE(p && ni && bounds && error && status, "ecckd_partition_e: NULL argument");
+  std::vector<double> b, e;
+  int n = 0;
+  *status = p->ps->equipartition_e(target_error, bound0, boundn, n, b, e);
+  if (p->ps->evaluator_status()) return p->ps->evaluator_status();
+  *ni = n;
+  if (*status == ecckd::PS_INPUT_ERROR) return ECCKD_OK;
+  ECCKD_REQUIRE(n <= capacity, "ecckd_partition_e: %d intervals exceed the caller's capacity %d", n, capacity);
+  std::memcpy(bounds, b.data(), (size_t)(n + 1) * sizeof(double));
+  std::memcpy(error, e.data(), (size_t)n * sizeof(double));
+  return ECCKD_OK;
+}
+
+const char* ecckd_partition_status_string(int status) { return ecckd::partition_status_string(status); }
+
+// ---------------------------------------------------------------------------
+// One band of find_g_points.cpp:1152-1266 on a prepared gas: equipartition_e to the
+// heating-rate tolerance, then the min/max g-point restarts (:1232-1257).
+int ecckd_find_g_band(ecckd_gas* g, size_t ibegin, size_t iend, double heating_rate_tolerance,
+                      double tolerance_tolerance, int max_iterations, int min_g_points,
+                      int max_g_points, int* ng, double* bounds, double* error, int capacity,
+                      int* status, double* comp_cost) {
+  ECCKD_REQUIRE(g && ng && bounds && error && status, "ecckd_find_g_band: NULL argument");
+  ECCKD_REQUIRE(iend >= ibegin && iend < g->n, "ecckd_find_g_band: band [%zu,%zu] outside the spectrum", ibegin, iend);
+  const size_t npoints = iend - ibegin + 1;
+  const double cost0 = g->total_comp_cost;
+  int rc_eval = ECCKD_OK;
+  ecckd::PartitionSearch ps([&](int n, const double* b1, const double* b2, double* e) {
+    rc_eval = ecckd_calc_error_batch(g, ibegin, npoints, n, b1, b2, e);
+    return rc_eval;
+  });
+  // CkdEquipartition::init_lw (find_g_points.cpp:230-233) + :1180-1181
+  ps.set_resolution(1.0 / (double)npoints);
+  ps.set_minimize_frac_range(true);
+  ps.set_partition_max_iterations(max_iterations);
+  ps.set_partition_tolerance(tolerance_tolerance);
+  std::vector<double> b, e;
+  int n = 10;
+  int st = ps.equipartition_e(heating_rate_tolerance, 0.0, 1.0, n, b, e);
+  if (!ps.evaluator_status() && (n < min_g_points || n > max_g_points)) {
+    // :1232-1257 restart from bounds sqrt(i/ng)
+    n = (n < min_g_points) ? min_g_points : max_g_points;
+    b.resize(n + 1);
+    e.resize(n);
+    for (int i = 0; i <= n; ++i) b[i] = std::sqrt((double)i / (double)n);
+    st = ps.equipartition_n(n, b.data(), e.data());
+  }
+  if (ps.evaluator_status()) return rc_eval ? rc_eval : ECCKD_PROCESSING_ERROR;
+  *status = st;
+  *ng = n;
+  if (comp_cost) *comp_cost = g->total_comp_cost - cost0;
+  ECCKD_REQUIRE(n <= capacity, "ecckd_find_g_band: %d g points exceed the caller's capacity %d", n, capacity);
+  std::memcpy(bounds, b.data(), (size_t)(n + 1) * sizeof(double));
+  std::memcpy(error, e.data(), (size_t)n * sizeof(double));
+  return ECCKD_OK;
+}
+
+}  // extern "C"

@@ -10,7 +10,7 @@
 // Layout: 64-bit order-preserving key image + 32-bit index payload, ping-pong
 // buffers in the context scratch.  8 passes of 8 bits; each pass is
 //   (1) per-tile digit histogram   (LDS integer atomics)
-//   (2) exclusive scan of the digit-major (digit, tile) table
+//   (2) exclusive scan of the digit-major (digit, tile) table (one block per digit row)
 //   (3) stable scatter: each 64-wide wave ranks its elements with ballot
 //       matching (wave64: one 64-bit peer mask per element), waves of a block
 //       are ordered through an LDS count table.
@@ -65,31 +65,39 @@ k_sort_hist(size_t n, int shift, const unsigned long long* __restrict__ skey,
   tile_hist[(size_t)tid * ntiles + blockIdx.x] = s_hist[tid];
 }
 
-// (2) exclusive scan of m = RADIX*ntiles counters, single block.
-__global__ void __launch_bounds__(1024)
-k_sort_scan(unsigned* __restrict__ data, size_t m) {
-  __shared__ unsigned s_part[1024];
+// (2) one block per digit: exclusive scan of that digit's row of per-tile counts
+// (in place, coalesced) and the row total -> digit_total[digit].  The scan over
+// the 256 digit totals is done by every scatter block in LDS.
+__global__ void __launch_bounds__(256)
+k_sort_scan_rows(unsigned* __restrict__ tile_hist, unsigned ntiles, unsigned* __restrict__ digit_total) {
+  __shared__ unsigned s_wave[4];
+  __shared__ unsigned s_carry;
   const int tid = threadIdx.x;
-  const size_t chunk = (m + 1023) / 1024;
-  const size_t lo = (size_t)tid * chunk;
-  const size_t hi = lo + chunk < m ? lo + chunk : m;
-  unsigned s = 0;
-  for (size_t i = lo; i < hi; ++i) s += data[i];
-  s_part[tid] = s;
+  const int lane = tid & 63, wave = tid >> 6;
+  unsigned* row = tile_hist + (size_t)blockIdx.x * ntiles;
+  if (tid == 0) s_carry = 0;
   __syncthreads();
-  // Hillis-Steele inclusive scan over the 1024 partials
-  for (int d = 1; d < 1024; d <<= 1) {
-    unsigned v = (tid >= d) ? s_part[tid - d] : 0u;
+  for (unsigned base = 0; base < ntiles; base += 256) {
+    const unsigned i = base + tid;
+    const unsigned v = (i < ntiles) ? row[i] : 0u;
+    // inclusive scan inside the wave
+    unsigned x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wave[wave] = x;
     __syncthreads();
-    s_part[tid] += v;
+    unsigned woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w];
+    const unsigned carry = s_carry;
+    if (i < ntiles) row[i] = carry + woff + x - v;
+    __syncthreads();
+    if (tid == 255) s_carry = carry + woff + x;
     __syncthreads();
   }
-  unsigned run = (tid == 0) ? 0u : s_part[tid - 1];
-  for (size_t i = lo; i < hi; ++i) {
-    unsigned v = data[i];
-    data[i] = run;
-    run += v;
-  }
+  if (tid == 0) digit_total[blockIdx.x] = s_carry;
 }
 
 // (3) stable scatter.  Wave w of a block owns the contiguous sub-tile
@@ -99,12 +107,29 @@ __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_scatter(size_t n, int shift, const unsigned long long* __restrict__ skey_in,
                const unsigned* __restrict__ sidx_in, unsigned long long* __restrict__ skey_out,
                unsigned* __restrict__ sidx_out, const unsigned* __restrict__ tile_offs,
-               unsigned ntiles) {
+               unsigned ntiles, const unsigned* __restrict__ digit_total) {
   __shared__ unsigned s_cnt[SORT_WAVES][RADIX];  // per-wave digit counts, then running offsets
+  __shared__ unsigned s_dig[RADIX];              // exclusive scan of the digit totals
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
   for (int w = 0; w < SORT_WAVES; ++w) s_cnt[w][tid] = 0;
+  {
+    // exclusive scan of 256 digit totals: wave scan + 4 wave carries
+    const unsigned v0 = digit_total[tid];
+    unsigned x = v0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    s_dig[tid] = x;  // inclusive within the wave
+    __syncthreads();
+    unsigned woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_dig[w * 64 + 63];
+    __syncthreads();
+    s_dig[tid] = woff + x - v0;
+  }
   __syncthreads();
 
   const size_t wave_base = (size_t)blockIdx.x * SORT_TILE + (size_t)wave * (SORT_ITEMS * 64);
@@ -121,7 +146,7 @@ k_sort_scatter(size_t n, int shift, const unsigned long long* __restrict__ skey_
   __syncthreads();
   // thread `tid` owns digit `tid`: turn counts into per-wave start offsets
   {
-    unsigned run = tile_offs[(size_t)tid * ntiles + blockIdx.x];
+    unsigned run = s_dig[tid] + tile_offs[(size_t)tid * ntiles + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) {
       unsigned cnt = s_cnt[w][tid];
@@ -209,7 +234,7 @@ extern "C" int ecckd_stable_argsort_bands_dev(ecckd_ctx* ctx, size_t nwav, const
   const size_t ntiles_max = (nmax + SORT_TILE - 1) / SORT_TILE;
   const size_t key_bytes = ecckd_align_up(nmax * sizeof(unsigned long long), 256);
   const size_t idx_bytes = ecckd_align_up(nmax * sizeof(unsigned), 256);
-  const size_t hist_bytes = ecckd_align_up((size_t)RADIX * ntiles_max * sizeof(unsigned), 256);
+  const size_t hist_bytes = ecckd_align_up((size_t)RADIX * ntiles_max * sizeof(unsigned), 256) + 1024;
   ECCKD_CHECK(ecckd::ensure_scratch(ctx, 2 * key_bytes + 2 * idx_bytes + hist_bytes));
   char* p = (char*)ctx->scratch;
   unsigned long long* keys[2] = {(unsigned long long*)p, (unsigned long long*)(p + key_bytes)};
@@ -217,6 +242,7 @@ extern "C" int ecckd_stable_argsort_bands_dev(ecckd_ctx* ctx, size_t nwav, const
   unsigned* idxs[2] = {(unsigned*)p, (unsigned*)(p + idx_bytes)};
   p += 2 * idx_bytes;
   unsigned* hist = (unsigned*)p;
+  unsigned* digit_total = (unsigned*)(p + hist_bytes - 1024);
 
   for (int b = 0; b < nband; ++b) {
     if (h_band_end[b] < h_band_begin[b]) continue;
@@ -230,9 +256,9 @@ extern "C" int ecckd_stable_argsort_bands_dev(ecckd_ctx* ctx, size_t nwav, const
       const int shift = pass * RADIX_BITS;
       hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, keys[cur],
                          hist, ntiles);
-      hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, ctx->stream, hist, (size_t)RADIX * ntiles);
+      hipLaunchKernelGGL(k_sort_scan_rows, dim3(RADIX), dim3(256), 0, ctx->stream, hist, ntiles, digit_total);
       hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift,
-                         keys[cur], idxs[cur], keys[cur ^ 1], idxs[cur ^ 1], hist, ntiles);
+                         keys[cur], idxs[cur], keys[cur ^ 1], idxs[cur ^ 1], hist, ntiles, digit_total);
       cur ^= 1;
     }
     hipLaunchKernelGGL(k_sort_finish, dim3(eblocks), dim3(256), 0, ctx->stream, off, n, idxs[cur], d_rank,

@@ -124,6 +124,70 @@ int ecckd_reorder_spectrum(ecckd_ctx* ctx, int nlay, size_t nwav,
                            double* h_key, double* h_col_od, int16_t* h_iband,
                            int32_t* h_rank);
 
+/* ---- find_g_points: gas preparation (K4) -------------------------------------
+ * Replaces find_g_points.cpp:872-1150 for one gas: invert the rank from the order
+ * file (:779-780), gather-reorder background and target columns (:899, :927-929),
+ * Planck function on the reordered wavenumbers (:970-979), LW radiative transfer of
+ * background+target (:993-995), heating rate (:1041), surface/TOA flux rows
+ * (:1044-1053), layer weights (:1093-1099) and the averaging metric (:1119-1150).
+ * All inputs are in ORIGINAL wavenumber order; the handle keeps the results resident
+ * on the device in SORTED order.  d_bg_od may be NULL (no background_input:
+ * zeros, :902-905).  d_planck_hl_reuse: the planck_hl view of a previously created
+ * gas; the reference computes planck_hl only for the first gas and reuses it
+ * (:966-983) - pass NULL to compute it for this gas's ordering. */
+typedef struct ecckd_gas ecckd_gas;
+
+int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav,
+                        const double* h_pressure_hl, const double* h_temperature_hl,
+                        const double* d_wavenumber, const double* d_d_wavenumber,
+                        const int32_t* d_rank,
+                        const void* d_bg_od, int bg_type,
+                        const void* d_od, int od_type, size_t src_stride,
+                        int averaging_method, double flux_weight, double min_pressure,
+                        const double* d_planck_hl_reuse, ecckd_gas** gas);
+int ecckd_gas_destroy(ecckd_gas* gas);
+/* device view of a resident array: "planck_hl", "bg_optical_depth", "weighted_metric",
+ * "hr", "flux_dn_surf", "flux_up_toa", "wavenumber", "d_wavenumber" */
+int ecckd_gas_view(ecckd_gas* gas, const char* name, const double** d_ptr, size_t* rows, size_t* cols);
+int ecckd_gas_layer_weight(ecckd_gas* gas, double* h_layer_weight);
+/* total_comp_cost of find_g_points.cpp:320 accumulated by ecckd_calc_error_batch */
+double ecckd_gas_comp_cost(ecckd_gas* gas, int reset);
+
+/* ---- find_g_points: batched interval error (K5) ------------------------------
+ * Replaces the virtual Equipartition::calc_error (equipartition.h:95) as implemented
+ * by CkdEquipartition::calc_error (find_g_points.cpp:291-405) and the loop over it,
+ * Equipartition::calc_error_all (equipartition.h:98-116): error[k] for the n
+ * intervals [bound1[k], bound2[k]] (fractions of the band) of the band that starts
+ * at sorted index ibegin and has npoints points (CkdEquipartition::init_lw, :208-235).
+ * Returns ECCKD_PROCESSING_ERROR on the reference's throw(PROCESSING_ERROR) paths
+ * (:298-313).  Synchronous. */
+int ecckd_calc_error_batch(ecckd_gas* gas, size_t ibegin, size_t npoints, int n,
+                           const double* h_bound1, const double* h_bound2, double* h_error);
+
+/* ---- equal-error partition search over a batched error callback ---------------
+ * Replaces class Equipartition (equipartition.h:63-208, equipartition.cpp).  The
+ * callback evaluates n intervals at once and returns non-zero to abort.  status
+ * receives the EpStatus value (equipartition.h:32-40). */
+typedef int (*ecckd_error_fn)(int n, const double* bound1, const double* bound2, double* error, void* user);
+typedef struct ecckd_partition ecckd_partition;
+int ecckd_partition_create(ecckd_error_fn fn, void* user, ecckd_partition** p);
+int ecckd_partition_destroy(ecckd_partition* p);
+int ecckd_partition_configure(ecckd_partition* p, double resolution, double partition_tolerance,
+                              int partition_max_iterations, int line_search_max_iterations,
+                              int cubic_interpolation, int minimize_frac_range);
+int ecckd_partition_n(ecckd_partition* p, int ni, double* bounds, double* error, int* status);
+int ecckd_partition_e(ecckd_partition* p, double target_error, double bound0, double boundn,
+                      int* ni, double* bounds, double* error, int capacity, int* status);
+const char* ecckd_partition_status_string(int status);
+
+/* One band of the main loop, find_g_points.cpp:1152-1266 (no sub-bands / base split):
+ * equipartition_e to the heating-rate tolerance, restart with equipartition_n from
+ * bounds sqrt(i/ng) if ng is outside [min_g_points, max_g_points] (:1232-1257). */
+int ecckd_find_g_band(ecckd_gas* gas, size_t ibegin, size_t iend, double heating_rate_tolerance,
+                      double tolerance_tolerance, int max_iterations, int min_g_points,
+                      int max_g_points, int* ng, double* bounds, double* error, int capacity,
+                      int* status, double* comp_cost);
+
 #ifdef __cplusplus
 }
 #endif
