@@ -6,6 +6,7 @@ of device memory here) or numpy arrays where the reference keeps small host vect
 Every call goes through libecckd_hip.so; nothing here computes on the CPU.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -50,9 +51,12 @@ class Context:
         check(self.lib.ecckd_init(self.device_index, C.byref(h)))
         self.handle = h
         self._stream = None
+        self._children = weakref.WeakSet()  # handles that must be destroyed before the context
 
     def close(self):
         if getattr(self, "handle", None):
+            for child in list(self._children):
+                child.close()
             self.lib.ecckd_destroy(self.handle)
             self.handle = None
 
@@ -308,10 +312,12 @@ class GasLW:
             float(flux_weight), float(min_pressure),
             C.c_void_p(planck_hl_reuse) if planck_hl_reuse else None, C.byref(h)))
         self.handle = h
+        ctx._children.add(self)
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.ecckd_gas_destroy(self.handle)
+            if self.ctx.handle:  # the context must outlive its gases
+                self.lib.ecckd_gas_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -124,6 +124,12 @@ k_invert_rank(size_t n, const int32_t* __restrict__ rank, int32_t* __restrict__ 
   ireorder[r] = (int32_t)j;  // find_g_points.cpp:779-780
 }
 
+__global__ void __launch_bounds__(256)
+k_check_perm(size_t n, const int32_t* __restrict__ ireorder, int* __restrict__ err) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && ireorder[i] < 0) atomicOr(err, 2);
+}
+
 __device__ __forceinline__ double metric_of(int method, double od) {
   // find_g_points.cpp:1119-1150
   switch (method) {
@@ -578,7 +584,20 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   int* d_flag = (int*)(g->lev + nhl + 2 * nlay);
 
   const unsigned eblocks = (unsigned)((nwav + 255) / 256);
+  // rank must be a permutation: every slot of ireorder written exactly once.  Checked on the
+  // device BEFORE the gather kernel dereferences ireorder.
+  GTRY(hipMemsetAsync(g->ireorder, 0xFF, nwav * sizeof(int32_t), ctx->stream));
   hipLaunchKernelGGL(k_invert_rank, dim3(eblocks), dim3(256), 0, ctx->stream, nwav, d_rank, g->ireorder, d_flag);
+  hipLaunchKernelGGL(k_check_perm, dim3(eblocks), dim3(256), 0, ctx->stream, nwav, g->ireorder, d_flag);
+  {
+    int flag0 = 0;
+    GTRY(hipMemcpyAsync(&flag0, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GTRY(hipStreamSynchronize(ctx->stream));
+    if (flag0) {
+      gas_free(g);
+      return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_gas_create_lw: rank is not a permutation of 0..nwav-1");
+    }
+  }
 
   int threads = PREP_THREADS;
   while ((size_t)nlay * threads * sizeof(double) > 160 * 1024 && threads > 64) threads /= 2;

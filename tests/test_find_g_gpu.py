@@ -1,0 +1,189 @@
+"""GPU parity for find_g_points (rows a10-a13): gas preparation K4, batched interval error K5
+and the whole band search, against the CPU oracle and the reference-built partition search.
+
+Tolerances (fp64): resident rows (planck, hr, flux rows) rtol 1e-11 against the oracle (device
+exp() vs glibc, see test_reorder_gpu.py); interval errors rtol 1e-9 (sums over up to 1e5 points
+are re-associated: tiles + ragged ends, wave/block trees).  The partition search is discrete:
+given errors that agree to 1e-9 it must return the same number of g points and the same
+index boundaries.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_lw_case
+
+pytestmark = pytest.mark.gpu
+
+ERR_RTOL = 1e-9
+
+
+def _dev(ctx, a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=ctx.device)
+
+
+def _lw_problem(oracle, nwav, nlay=30, seed=21, method="transmission", with_bg=True, min_pressure=0.0):
+    """Synthetic target + background gas, reordered by the oracle; returns host arrays and the
+    oracle's band-local CkdEquipartition inputs (in sorted order)."""
+    from ecckd_amd import synthetic as syn
+    p, wn, dwn, od32 = make_lw_case(nwav, nlay=nlay, seed=seed)
+    od = od32.astype(np.float64)
+    bg = None
+    if with_bg:
+        _, _, _, bg32 = make_lw_case(nwav, nlay=nlay, seed=seed + 100, column_scale=3.0)
+        bg = bg32.astype(np.float64) * 0.7 + 1e-4
+    t_ideal = oracle.idealised_temperature(p)
+    key, col, _ = oracle.reorder_key(p, t_ideal, wn, dwn, od, None, 0.5)
+    _, oi, rank = oracle.stable_argsort_bands(wn, key, [0.0], [3260.0])
+    t_hl = syn.temperature_profile(p)
+    # oracle side of find_g_points.cpp:891-1150
+    ireorder = np.empty(nwav, dtype=np.int64)
+    ireorder[rank] = np.arange(nwav)
+    od_s = od[:, ireorder]
+    bg_s = bg[:, ireorder] if with_bg else np.zeros_like(od_s)
+    wn_s, dwn_s = wn[ireorder], dwn[ireorder]
+    planck = oracle.planck_function(t_hl, wn_s, dwn_s)
+    surf_planck = oracle.planck_function([t_hl[-1]], wn_s, dwn_s)[0]
+    fdn, fup = oracle.radiative_transfer_lw(planck, bg_s + od_s, np.ones(nwav), surf_planck)
+    hr = oracle.heating_rate(p, fdn, fup)
+    lw = oracle.layer_weight(p, min_pressure)
+    metric = oracle.metric(method, od_s)
+    orc = dict(p=p, t_hl=t_hl, wn=wn, dwn=dwn, od=od, bg=bg, rank=rank, planck=planck, surf_planck=surf_planck,
+               bg_s=bg_s, metric=metric, hr=hr, fds=fdn[-1].copy(), fut=fup[0].copy(), lw=lw, wn_s=wn_s)
+    return orc
+
+
+def _make_gas(ctx, o, method, flux_weight=0.02, min_pressure=0.0, od_dtype=np.float64):
+    from ecckd_amd import api
+    return api.GasLW(ctx, o["p"], o["t_hl"], _dev(ctx, o["wn"]), _dev(ctx, o["dwn"]),
+                     _dev(ctx, o["rank"].astype(np.int32)), _dev(ctx, o["od"].astype(od_dtype)),
+                     _dev(ctx, o["bg"]) if o["bg"] is not None else None, method, flux_weight, min_pressure)
+
+
+def _oracle_eq(oracle, o, method, flux_weight, i1=0, i2=None):
+    sl = slice(i1, None if i2 is None else i2 + 1)
+    n = o["bg_s"][:, sl].shape[1]
+    return oracle.CkdEquipartitionLW(method, flux_weight, o["lw"], o["p"], np.ones(n), o["surf_planck"][sl],
+                                     o["fds"][sl], o["fut"][sl], o["planck"][:, sl], o["bg_s"][:, sl],
+                                     o["metric"][:, sl], o["hr"][:, sl])
+
+
+@pytest.mark.parametrize("with_bg", [True, False])
+def test_gas_prep_matches_oracle(ctx, oracle, with_bg):
+    o = _lw_problem(oracle, 6000, nlay=30, with_bg=with_bg, min_pressure=50.0)
+    gas = _make_gas(ctx, o, "transmission", min_pressure=50.0)
+    assert np.array_equal(gas.view("wavenumber")[0], o["wn_s"])
+    assert np.array_equal(gas.view("bg_optical_depth"), o["bg_s"])
+    assert np.allclose(gas.view("planck_hl"), o["planck"], rtol=1e-11, atol=0)
+    assert np.allclose(gas.layer_weight(), o["lw"], rtol=1e-15)
+    # heating rate = conv * (net-flux difference): absolute error scales with conv * flux * eps,
+    # amplified on optically thin columns by the factor formula (see test_reorder_gpu.py)
+    conv = (9.80665 / 1004.0) / np.diff(o["p"])
+    tol = 1e-9 * np.abs(o["hr"]).max(axis=0, keepdims=True) + 1e-13 * conv[:, None] * o["fut"][None, :]
+    assert np.all(np.abs(gas.view("hr") - o["hr"]) <= tol)
+    assert np.allclose(gas.view("flux_dn_surf")[0], o["fds"], rtol=1e-10, atol=1e-300)
+    assert np.allclose(gas.view("flux_up_toa")[0], o["fut"], rtol=1e-10)
+    # weighted metric row l = metric(l) * planck_hl(l+1)
+    assert np.allclose(gas.view("weighted_metric"), o["metric"] * o["planck"][1:], rtol=1e-11, atol=1e-300)
+    gas.close()
+
+
+def test_gas_prep_rejects_bad_rank(ctx, oracle):
+    from ecckd_amd import EcckdError
+    o = _lw_problem(oracle, 500, nlay=10, with_bg=False)
+    o["rank"] = o["rank"].copy()
+    o["rank"][3] = 500
+    with pytest.raises(EcckdError) as e:
+        _make_gas(ctx, o, "linear")
+    assert e.value.code == 147
+
+
+@pytest.mark.parametrize("method", ["linear", "transmission", "transmission-2", "square-root", "logarithmic"])
+def test_interval_errors_match_oracle(ctx, oracle, method):
+    o = _lw_problem(oracle, 20000, nlay=30, seed=23, method=method)
+    gas = _make_gas(ctx, o, method, flux_weight=0.02)
+    eq = _oracle_eq(oracle, o, method, 0.02)
+    n = 20000
+    rs = np.random.RandomState(5)
+    cuts = np.sort(rs.uniform(0, 1, 11))
+    b1 = np.concatenate([[0.0], cuts, [0.0, 0.3, 0.99999, 0.5, 0.123456]])
+    b2 = np.concatenate([cuts, [1.0], [1.0, 0.3001, 1.0, 0.5, 0.123457]])
+    err = gas.calc_error_batch(0, n, b1, b2)
+    ref = np.array([eq.calc_error(x, y) for x, y in zip(b1, b2)])
+    assert np.all(np.isfinite(err))
+    assert np.allclose(err, ref, rtol=ERR_RTOL, atol=1e-12)
+    assert gas.comp_cost() == pytest.approx(eq.total_comp_cost, rel=1e-13)
+    gas.close()
+
+
+def test_interval_errors_band_offset_f32_and_flux_weight_zero(ctx, oracle):
+    # band = sorted indices [3000, 15999]; target optical depth kept as the file's FLOAT
+    o = _lw_problem(oracle, 20000, nlay=54, seed=29, method="transmission", with_bg=True)
+    gas = _make_gas(ctx, o, "transmission", flux_weight=0.0, od_dtype=np.float32)
+    i1, i2 = 3000, 15999
+    eq = _oracle_eq(oracle, o, "transmission", 0.0, i1, i2)
+    b1 = np.array([0.0, 0.25, 0.5, 0.9])
+    b2 = np.array([0.25, 0.5, 0.9, 1.0])
+    err = gas.calc_error_batch(i1, i2 - i1 + 1, b1, b2)
+    ref = np.array([eq.calc_error(x, y) for x, y in zip(b1, b2)])
+    assert np.allclose(err, ref, rtol=ERR_RTOL, atol=1e-12)
+    gas.close()
+
+
+def test_calc_error_processing_errors(ctx, oracle):
+    """find_g_points.cpp:298-313."""
+    from ecckd_amd import EcckdError
+    o = _lw_problem(oracle, 2000, nlay=10, with_bg=False)
+    gas = _make_gas(ctx, o, "linear")
+    for b1, b2 in [(-0.1, 0.5), (0.5, 1.1), (0.6, 0.4)]:
+        with pytest.raises(EcckdError) as e:
+            gas.calc_error_batch(0, 2000, [b1], [b2])
+        assert e.value.code == 148
+    # bounds closer than one point: upper index corrected to the lower (:314-318)
+    e1 = gas.calc_error_batch(0, 2000, [0.50001], [0.50002])
+    assert np.isfinite(e1[0])
+    gas.close()
+
+
+@pytest.mark.parametrize("method,tol", [("transmission", 0.08), ("linear", 0.15)])
+def test_find_g_band_matches_reference_search(ctx, oracle, method, tol):
+    """Whole band: product search + GPU errors vs the reference's equipartition.cpp (oracle/_ref)
+    driven by the oracle's calc_error.  Same ng, same index boundaries, errors to 1e-9."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    n = 30000
+    o = _lw_problem(oracle, n, nlay=30, seed=31, method=method)
+    gas = _make_gas(ctx, o, method, flux_weight=0.0)
+    st, b, e, cc = gas.find_g_band(0, n - 1, tol, tolerance_tolerance=0.01, max_iterations=60)
+    eq = _oracle_eq(oracle, o, method, 0.0)
+    ref = oracle.RefEquipartition(eq.calc_error, resolution=1.0 / n, partition_tolerance=0.01,
+                                  partition_max_iterations=60)
+    rst, rb, re = ref.equipartition_e(tol)
+    assert len(b) == len(rb) and len(b) >= 4
+    lower = lambda x: math.ceil(x * (n - 1))
+    upper = lambda x: math.floor(x * (n - 1))
+    assert [lower(x) for x in b[:-1]] == [lower(x) for x in rb[:-1]]
+    assert [upper(x) for x in b[1:]] == [upper(x) for x in rb[1:]]
+    assert st == rst
+    assert np.allclose(e, re, rtol=1e-8)
+    # trial bounds are continuous functions of the errors (interpolations), so the summed interval
+    # widths agree to the error tolerance, not bitwise
+    assert cc == pytest.approx(eq.total_comp_cost, rel=1e-6)
+    gas.close()
+
+
+def test_find_g_band_min_max_g_points(ctx, oracle):
+    """find_g_points.cpp:1232-1257: restart from sqrt(i/ng) when ng is outside [min, max]."""
+    n = 10000
+    o = _lw_problem(oracle, n, nlay=20, seed=37, method="transmission")
+    gas = _make_gas(ctx, o, "transmission", flux_weight=0.0)
+    st, b, e, _ = gas.find_g_band(0, n - 1, 0.1, 0.02, 30)
+    ng = len(e)
+    st2, b2, e2, _ = gas.find_g_band(0, n - 1, 0.1, 0.02, 30, min_g_points=ng + 3)
+    assert len(e2) == ng + 3 and b2[0] == 0.0 and b2[-1] == 1.0 and np.all(np.diff(b2) > 0)
+    if ng > 3:
+        st3, b3, e3, _ = gas.find_g_band(0, n - 1, 0.1, 0.02, 30, max_g_points=ng - 1)
+        assert len(e3) == ng - 1
+    gas.close()
