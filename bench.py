@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """bench.py - LW reorder + find_g_points hot path on synthetic CKDMIP-like spectra.
 
-One "step" = one pass of the hot path over one device-resident column
-(BASELINE.json configs[1]: LW FSCK, one band, nwav = 7.2e6, nlay = 54, FLOAT optical
-depths): K1 sorting key + K3 stable sort (reorder_spectrum.cpp:111-300) and, once the
-gas is prepared, the g-point partition search (find_g_points.cpp:1152-1266) with every
-interval-error evaluation on the device.  Metric = wavenumber-points/s =
-nwav * (1 + N_pass) / t, N_pass = sum of (bound2-bound1) over all calc_error calls
-(find_g_points.cpp:320), summed over ranks.  Ranks process independent (gas, band)
-shards (weak scaling, no data-path collective).
+One "step" = one pass of the hot path over one device-resident gas column
+(BASELINE.json configs[1]: LW FSCK = one band over 0-3260 cm-1, nwav = 7.2e6, nlay = 54,
+FLOAT optical depths as in the CKDMIP files, tolerance 0.0161 K/d as test/do_all_lw.sh:59-60):
+   K1 sorting key + K3 stable sort        (reorder_spectrum.cpp:111-300)
+   K4 gas preparation                     (find_g_points.cpp:872-1150)
+   g-point partition search, every interval-error evaluation batched on the device (K5)
+                                          (find_g_points.cpp:1152-1266)
+Metric = wavenumber-points/s = nwav * (1 + N_pass) / t, where N_pass is the reference's own
+work counter total_comp_cost = sum of (bound2 - bound1) over all calc_error calls
+(find_g_points.cpp:320).  Ranks process independent gases (weak scaling, no data-path
+collective); rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -21,45 +24,82 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nwav", type=int, default=7_200_000)
     ap.add_argument("--nlay", type=int, default=54)
-    ap.add_argument("--tolerance", type=float, default=0.0161)  # fsck, test/do_all_lw.sh:59-60
-    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    ap.add_argument("--tolerance", type=float, default=0.0161)   # fsck, test/do_all_lw.sh:59-60
+    ap.add_argument("--tolerance-tolerance", type=float, default=0.01)  # test/find_g_points_lw.sh
+    ap.add_argument("--max-iterations", type=int, default=60)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 15)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-find-g", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline_reorder(nwav_sample, nlay, seed):
-    """Oracle ("port") LW reorder on the host cores: K1 restatement + stable sort."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import pyoracle
+def make_inputs(xp, nwav, nlay, seed, device=None):
+    """Synthetic target gas + background (both FLOAT like the CKDMIP spectra files)."""
     from ecckd_amd import synthetic as syn
     p = syn.pressure_grid(nlay)
-    wn, dwn = syn.wavenumber_grid(nwav_sample)
-    od = syn.optical_depth(np, p, wn, seed, nlines=32).astype(np.float64)
-    t = pyoracle.idealised_temperature(p)
+    wn_h, dwn_h = syn.wavenumber_grid(nwav)
+    kw = dict(device=device, chunk=1 << 20) if device is not None else {}
+    wn = xp.as_tensor(wn_h, device=device) if device is not None else wn_h
+    od = syn.optical_depth(xp, p, wn, seed, nlines=32, **kw)
+    bg = syn.optical_depth(xp, p, wn, seed + 1000, nlines=24, column_scale=3.0, zero_fraction=0.0, **kw)
+    return p, wn_h, dwn_h, od, bg
+
+
+def cpu_baseline(nwav_s, nlay, seed, tol, tol_tol, max_it):
+    """The oracle ("port") on the host, one thread: reorder + gas prep + the reference-built
+    partition search (oracle/_ref) over the oracle's calc_error."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as o
+    from ecckd_amd import synthetic as syn
+    p, wn, dwn, od32, bg32 = make_inputs(np, nwav_s, nlay, seed)
+    od, bg = od32.astype(np.float64), bg32.astype(np.float64)
+    t_hl = syn.temperature_profile(p)
     t0 = time.perf_counter()
-    key, col, st = pyoracle.reorder_key(p, t, wn, dwn, od, None, 0.5)
-    pyoracle.stable_argsort_bands(wn, key, np.array([0.0]), np.array([3260.0]))
+    key, col, _ = o.reorder_key(p, o.idealised_temperature(p), wn, dwn, od, None, 0.5)
+    _, oi, rank = o.stable_argsort_bands(wn, key, [0.0], [3260.0])
+    ireorder = np.empty(nwav_s, dtype=np.int64)
+    ireorder[rank] = np.arange(nwav_s)
+    od_s, bg_s = od[:, ireorder], bg[:, ireorder]
+    planck = o.planck_function(t_hl, wn[ireorder], dwn[ireorder])
+    fdn, fup = o.radiative_transfer_lw(planck, bg_s + od_s, np.ones(nwav_s), planck[-1])
+    hr = o.heating_rate(p, fdn, fup)
+    eq = o.CkdEquipartitionLW("transmission", 0.0, o.layer_weight(p, 0.0), p, np.ones(nwav_s), planck[-1],
+                              fdn[-1].copy(), fup[0].copy(), planck, bg_s, o.metric("transmission", od_s), hr)
+    if o.ref_lib() is not None:
+        ref = o.RefEquipartition(eq.calc_error, resolution=1.0 / nwav_s, partition_tolerance=tol_tol,
+                                 partition_max_iterations=max_it)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        saved = os.dup(1)
+        os.dup2(devnull, 1)  # the reference search prints progress to stdout
+        try:
+            st, b, e = ref.equipartition_e(tol)
+        finally:
+            os.dup2(saved, 1)
+            os.close(devnull)
+        search = "reference equipartition.cpp (oracle/_ref)"
+    else:
+        raise RuntimeError("oracle/_ref not built")
     dt = time.perf_counter() - t0
-    return nwav_sample, dt
+    return nwav_s * (1.0 + eq.total_comp_cost), dt, len(e), eq.total_comp_cost, search
 
 
 def main():
     args = parse()
+    os.environ.setdefault("OMP_NUM_THREADS", "1")  # the CPU baseline is a single-thread port
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -70,29 +110,27 @@ def main():
     ctx = api.Context(local_rank)
     dev = ctx.device
     nwav, nlay = args.nwav, args.nlay
-    p = syn.pressure_grid(nlay)
-    wn_h, dwn_h = syn.wavenumber_grid(nwav)
+    # each rank owns a different synthetic gas: independent (gas, band) shards, SURVEY.md 8e
+    p, wn_h, dwn_h, od, bg = make_inputs(torch, nwav, nlay, syn.SEED_BASE + 1 + 17 * rank, device=dev)
     wn = torch.as_tensor(wn_h, device=dev)
     dwn = torch.as_tensor(dwn_h, device=dev)
-    # each rank owns a different synthetic gas (independent shard)
-    od = syn.optical_depth(torch, p, wn, syn.SEED_BASE + 1 + rank, nlines=32, device=dev, chunk=1 << 20)
-    t_hl = api.idealised_temperature(p)
+    t_ideal = api.idealised_temperature(p)
+    t_file = syn.temperature_profile(p)
     key = torch.empty(nwav, dtype=torch.float64, device=dev)
     col = torch.empty(nwav, dtype=torch.float64, device=dev)
     rnk = torch.empty(nwav, dtype=torch.int32, device=dev)
-    oi = torch.empty(nwav, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
+    info = {}
 
-    k1_ms = []
-
-    def step(timed):
-        ctx.timer_begin()
-        api.reorder_key_lw(ctx, p, t_hl, wn, dwn, od, 0.5, key=key, col_od=col)
-        ms = ctx.timer_end()
-        if timed:
-            k1_ms.append(ms)
-        api.stable_argsort_bands(ctx, key, [0], [nwav - 1], rank=rnk, ordered_index=oi, sync=False)
-        return 1.0  # passes over the spectrum in this step (1 for reorder)
+    def step():
+        api.reorder_key_lw(ctx, p, t_ideal, wn, dwn, od, 0.5, key=key, col_od=col)
+        api.stable_argsort_bands(ctx, key, [0], [nwav - 1], rank=rnk, want_ordered=False, sync=False)
+        gas = api.GasLW(ctx, p, t_file, wn, dwn, rnk, od, bg, "transmission", flux_weight=0.0)
+        st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance,
+                                       args.max_iterations)
+        gas.close()
+        info.update(ng=len(e), status=st, comp_cost=cc)
+        return 1.0 + cc  # passes over the spectrum in this step
 
     def barrier():
         ctx.synchronize()
@@ -101,14 +139,17 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
+    ctx.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     passes = 0.0
     for _ in range(args.steps):
-        passes += step(True)
+        passes += step()
     barrier()
     dt = time.perf_counter() - t0
+    rt_calls, rt_ms, rt_pts = ctx.profile_get("k_rt_lw_bb")
+    k1_calls, k1_ms, k1_pts = ctx.profile_get("k_reorder_key_lw")
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -119,8 +160,11 @@ def main():
 
     if rank == 0:
         points = nwav * passes
-        k1 = float(np.mean(k1_ms)) * 1e-3
-        k1_bytes = nwav * (nlay * od.element_size() + 32)  # nlay*s + 32 B per point
+        # dominant kernel: K5c k_rt_lw_bb.  Algorithmic bytes per point and pass:
+        # planck (nlay+1) + background optical depth (nlay) rows of f64 = (2*nlay+1)*8 B.
+        rt_bytes_per_pt = (2 * nlay + 1) * 8
+        rt_gbs = rt_pts * rt_bytes_per_pt / (rt_ms * 1e-3) / 1e9 if rt_ms > 0 else 0.0
+        k1_bytes_per_pt = nlay * od.element_size() + 32
         out = {
             "metric": "wavenumber-points/s (LW reorder+find_g)",
             "value": points / dt,
@@ -134,16 +178,28 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "LW FSCK 1 band, 1 synthetic gas/rank, nwav=%d, nlay=%d, od f32; reorder only"
-                       % (nwav, nlay), "passes_per_step": passes / args.steps / world},
-            "roofline": {"bound": "hbm", "kernel": "k_reorder_key_lw<float>", "achieved": k1_bytes / k1 / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_bytes / k1 / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "avg_ms": k1 * 1e3},
+            "config": {"workload": "configs[1]: LW FSCK (1 band 0-3260 cm-1), 1 synthetic gas + background per "
+                                   "rank, nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging transmission"
+                                   % (nwav, nlay, args.tolerance),
+                       "n_pass_per_step": (passes / args.steps / world) - 1.0, "ng": info.get("ng"),
+                       "search_status": info.get("status")},
+            "roofline": {"bound": "hbm", "kernel": "k_rt_lw_bb", "achieved": rt_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": rt_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "launches": rt_calls, "avg_launch_ms": rt_ms / max(rt_calls, 1),
+                         "algorithmic_bytes_per_point": rt_bytes_per_pt,
+                         "points_per_launch": rt_pts / max(rt_calls, 1),
+                         "share_of_step_time": rt_ms * 1e-3 / dt,
+                         "k_reorder_key_lw": {"avg_launch_ms": k1_ms / max(k1_calls, 1),
+                                              "achieved": k1_pts * k1_bytes_per_pt / max(k1_ms * 1e-3, 1e-12) / 1e9,
+                                              "algorithmic_bytes_per_point": k1_bytes_per_pt}},
         }
         if world == 1 and not args.no_cpu:
-            n_s, cdt = cpu_baseline_reorder(args.cpu_sample, nlay, syn.SEED_BASE + 1)
-            out["cpu_baseline"] = {"value": n_s / cdt, "unit": "wavenumber-points/s", "cores": os.cpu_count(),
-                                   "kind": "port", "sample": "oracle LW reorder of nwav=%d (same generator)" % n_s}
+            pts, cdt, cng, ccost, search = cpu_baseline(args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance,
+                                                        args.tolerance_tolerance, args.max_iterations)
+            out["cpu_baseline"] = {"value": pts / cdt, "unit": "wavenumber-points/s", "cores": 1, "kind": "port",
+                                   "sample": "oracle reorder + gas prep + %s over oracle calc_error, nwav=%d "
+                                             "(same generator, ng=%d, N_pass=%.1f, %.1f s)"
+                                             % (search, args.cpu_sample, cng, ccost, cdt)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

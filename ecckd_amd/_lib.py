@@ -55,6 +55,8 @@ SIGNATURES = {
     "ecckd_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ecckd_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ecckd_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ecckd_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "ecckd_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong), _c_double_p, _c_double_p]),
     "ecckd_timer_begin": (C.c_int, [C.c_void_p]),
     "ecckd_timer_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "ecckd_idealised_temperature": (C.c_int, [C.c_int, _c_double_p, _c_double_p]),

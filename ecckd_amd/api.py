@@ -88,6 +88,15 @@ class Context:
         torch = _torch()
         torch.cuda.current_stream(self.device).synchronize()
 
+    def profile_enable(self, on=True):
+        check(self.lib.ecckd_profile_enable(self.handle, int(on)))
+
+    def profile_get(self, kernel):
+        """(calls, total_ms, units) of a dominant kernel since profile_enable()."""
+        calls, ms, units = C.c_longlong(), C.c_double(), C.c_double()
+        check(self.lib.ecckd_profile_get(self.handle, kernel.encode(), C.byref(calls), C.byref(ms), C.byref(units)))
+        return calls.value, ms.value, units.value
+
     def timer_begin(self):
         check(self.lib.ecckd_timer_begin(self.handle))
 

@@ -27,6 +27,13 @@ struct ecckd_ctx {
   // pinned host staging for small results
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // optional per-kernel timing of the dominant kernels (HIP events on `stream`)
+  bool profile = false;
+  hipEvent_t pev0 = nullptr, pev1 = nullptr;
+  struct KernelStat { double ms = 0.0; double units = 0.0; long long calls = 0; };
+  KernelStat stat_rt_lw;     // k_rt_lw_bb: units = wavenumber points processed
+  KernelStat stat_key_lw;    // k_reorder_key_lw: units = wavenumber points
+  KernelStat stat_sort;      // whole K3 pass sequence: units = keys sorted
 };
 
 namespace ecckd {

@@ -100,6 +100,8 @@ int ecckd_destroy(ecckd_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
+  if (ctx->pev0) (void)hipEventDestroy(ctx->pev0);
+  if (ctx->pev1) (void)hipEventDestroy(ctx->pev1);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return ECCKD_OK;
@@ -141,6 +143,32 @@ int ecckd_d2h(ecckd_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
   if (!bytes) return ECCKD_OK;
   ECCKD_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
+}
+
+int ecckd_profile_enable(ecckd_ctx* ctx, int on) {
+  ECCKD_REQUIRE(ctx, "ecckd_profile_enable: ctx is NULL");
+  if (on && !ctx->pev0) {
+    ECCKD_HIP_CHECK(hipEventCreate(&ctx->pev0));
+    ECCKD_HIP_CHECK(hipEventCreate(&ctx->pev1));
+  }
+  ctx->profile = on != 0;
+  ctx->stat_rt_lw = ecckd_ctx::KernelStat();
+  ctx->stat_key_lw = ecckd_ctx::KernelStat();
+  ctx->stat_sort = ecckd_ctx::KernelStat();
+  return ECCKD_OK;
+}
+
+int ecckd_profile_get(ecckd_ctx* ctx, const char* kernel, long long* calls, double* ms, double* units) {
+  ECCKD_REQUIRE(ctx && kernel, "ecckd_profile_get: NULL argument");
+  const ecckd_ctx::KernelStat* st = nullptr;
+  if (!strcmp(kernel, "k_rt_lw_bb")) st = &ctx->stat_rt_lw;
+  else if (!strcmp(kernel, "k_reorder_key_lw")) st = &ctx->stat_key_lw;
+  else if (!strcmp(kernel, "radix_sort")) st = &ctx->stat_sort;
+  if (!st) return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_profile_get: unknown kernel \"%s\"", kernel);
+  if (calls) *calls = st->calls;
+  if (ms) *ms = st->ms;
+  if (units) *units = st->units;
   return ECCKD_OK;
 }
 

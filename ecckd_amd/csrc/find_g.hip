@@ -760,8 +760,10 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
                      (const double* const*)g->rows, g->tile_sums, d_sums);
   hipLaunchKernelGGL(k_fit_lw, dim3(n), dim3(128), 0, ctx->stream, nlay, g->method, g->nrows, d_iv, d_sums, d_fit);
   const size_t rt_lds = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
+  if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
   hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, ctx->stream, nlay, g->n,
                      chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+  if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
   const size_t cost_lds = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
   hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, ctx->stream, nlay, g->method, g->nrows, d_iv,
                      nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, d_err);
@@ -769,6 +771,13 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   ECCKD_HIP_CHECK(hipMemcpyAsync(h_err, d_err, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   std::memcpy(error, h_err, (size_t)n * sizeof(double));
+  if (ctx->profile) {
+    float ms = 0.f;
+    ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1));
+    ctx->stat_rt_lw.ms += ms;
+    ctx->stat_rt_lw.units += (double)total_pts;
+    ctx->stat_rt_lw.calls += 1;
+  }
   return ECCKD_OK;
 }
 

@@ -245,6 +245,7 @@ int ecckd_reorder_key_lw_dev(ecckd_ctx* ctx, int nlay, size_t nwav, const double
   int* d_flag = nullptr;
   ECCKD_CHECK(upload_level_consts(ctx, nlay, h_pressure_hl, h_temperature_hl, &d_lev, &d_flag));
   const unsigned blocks = (unsigned)((nwav + threads - 1) / threads);
+  if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
   if (od_type == ECCKD_F32) {
     ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reorder_key_lw<float>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -259,7 +260,16 @@ int ecckd_reorder_key_lw_dev(ecckd_ctx* ctx, int nlay, size_t nwav, const double
                        d_col_od, d_flag);
   }
   ECCKD_HIP_CHECK(hipGetLastError());
-  return check_flag(ctx, d_flag, "ecckd_reorder_key_lw_dev");
+  if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
+  ECCKD_CHECK(check_flag(ctx, d_flag, "ecckd_reorder_key_lw_dev"));
+  if (ctx->profile) {
+    float ms = 0.f;
+    ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1));
+    ctx->stat_key_lw.ms += ms;
+    ctx->stat_key_lw.units += (double)nwav;
+    ctx->stat_key_lw.calls += 1;
+  }
+  return ECCKD_OK;
 }
 
 int ecckd_reorder_key_sw_dev(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_pressure_hl,

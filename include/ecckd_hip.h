@@ -67,6 +67,11 @@ int ecckd_dev_alloc(ecckd_ctx* ctx, size_t bytes, void** d_ptr);
 int ecckd_dev_free(ecckd_ctx* ctx, void* d_ptr);
 int ecckd_h2d(ecckd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int ecckd_d2h(ecckd_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+/* per-kernel timing of the dominant kernels with HIP events on the context's stream:
+ * kernel = "k_rt_lw_bb" | "k_reorder_key_lw"; units = wavenumber points processed.
+ * Enabling resets the counters. */
+int ecckd_profile_enable(ecckd_ctx* ctx, int on);
+int ecckd_profile_get(ecckd_ctx* ctx, const char* kernel, long long* calls, double* ms, double* units);
 /* timing on the context's stream (hipEvent pair): begin .. end -> milliseconds */
 int ecckd_timer_begin(ecckd_ctx* ctx);
 int ecckd_timer_end(ecckd_ctx* ctx, float* ms);
