@@ -397,6 +397,166 @@ k_rt_lw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// fp64 helpers for the hot loops.
+//
+// exp(y) for y <= 0 (emissivity: eps = 1 - exp(-D*od)).  Cody-Waite reduction
+// y = k ln2 + r, |r| <= ln2/2, degree-12 Taylor/Horner in FMA, scaled with
+// ldexp.  Max error < 1 ulp on [-745, 0]; arguments below -745 flush to 0.
+__device__ __forceinline__ double exp_nonpos(double y) {
+  const double kf = __builtin_rint(y * 1.4426950408889634074);
+  double r = __builtin_fma(kf, -6.93147180369123816490e-01, y);
+  r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+  double p = 2.08767569878680989792e-09;            // 1/12!
+  p = __builtin_fma(p, r, 2.50521083854417187751e-08);  // 1/11!
+  p = __builtin_fma(p, r, 2.75573192239858906526e-07);  // 1/10!
+  p = __builtin_fma(p, r, 2.75573192239858906526e-06);  // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873015873e-05);  // 1/8!
+  p = __builtin_fma(p, r, 1.98412698412698412698e-04);  // 1/7!
+  p = __builtin_fma(p, r, 1.38888888888888888889e-03);  // 1/6!
+  p = __builtin_fma(p, r, 8.33333333333333333333e-03);  // 1/5!
+  p = __builtin_fma(p, r, 4.16666666666666666667e-02);  // 1/4!
+  p = __builtin_fma(p, r, 1.66666666666666666667e-01);  // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  const int k = (int)fmax(kf, -1100.0);
+  return __builtin_amdgcn_ldexp(p, k);
+}
+
+// a / b for b well inside the normal range: v_rcp_f64 seed + 2 Newton steps + 1 residual
+// correction (relative error < 1 ulp).
+__device__ __forceinline__ double fast_div(double a, double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  double q = a * y;
+  const double res = __builtin_fma(-b, q, a);
+  return __builtin_fma(res, y, q);
+}
+
+// K5c fast path: NLAY known at compile time.  The whole column (NLAY background
+// optical depths + NLAY+1 Planck values, 109 f64 for NLAY = 54) is loaded into
+// registers once; the down sweep overwrites it in place with the layer
+// transmittance 1-eps and the upward source term, so the up sweep needs no second
+// exp and no second read (the reference evaluates both twice,
+// radiative_transfer_lw.cpp:114,:131).  Per-half-level flux sums are reduced by a
+// transposed LDS pass every 16 levels: each lane parks its flux in a wave-private
+// [16][65] f64 tile (odd row stride: conflict-free ds_read_b64), then lane
+// (row r = lane%16, quarter q = lane/16) adds 16 values and two xor-shuffles
+// combine the quarters.  Fixed order everywhere: bitwise reproducible.
+template <int NLAY>
+__global__ void __launch_bounds__(RT_THREADS, 2)
+k_rt_lw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv,
+                const double* __restrict__ planck_hl, const double* __restrict__ bg_od,
+                const double* __restrict__ od_fit, double* __restrict__ partial) {
+  constexpr int NHL = NLAY + 1;
+  constexpr int NSLOT = 2 * NLAY + 1;            // dn[1..NLAY], up[NLAY..0]
+  constexpr int NCH = (NSLOT + 15) / 16;
+  constexpr int ROW = 65;
+  __shared__ double s_tile[4][16 * ROW];
+  __shared__ double s_out[4][NCH * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  const long long chunk = blockIdx.x;
+  int lo = 0, hi = nint - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (iv[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
+  }
+  const int k = lo;
+  const long long c = chunk - iv[k].chunk0;
+  const long long p0 = iv[k].i1 + c * chunk_pts;
+  long long p1 = p0 + chunk_pts - 1;
+  if (p1 > iv[k].i2) p1 = iv[k].i2;
+  const double* __restrict__ grey = od_fit + (size_t)k * NLAY;  // block-uniform -> scalar loads
+
+  double* tile = s_tile[wave];
+  const int rr = lane & 15, qq = lane >> 4;
+  double acc[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) acc[j] = 0.0;
+
+  constexpr double THRESHOLD_EMISSIVITY = 1.0e-5;
+  for (long long base = p0; base <= p1; base += RT_THREADS) {
+    const long long i = base + tid;
+    const bool live = i <= p1;
+    const size_t ii = live ? (size_t)i : (size_t)p1;
+    double a[NLAY];   // background optical depth -> 1 - eps
+    double b[NHL];    // planck -> upward source of the layer below each half level
+#pragma unroll
+    for (int l = 0; l < NLAY; ++l) a[l] = bg_od[(size_t)l * n + ii];
+#pragma unroll
+    for (int l = 0; l < NHL; ++l) b[l] = planck_hl[(size_t)l * n + ii];
+
+    int slot = 0;
+    auto push = [&](double flux) {
+      tile[(slot & 15) * ROW + lane] = live ? flux : 0.0;
+      if ((slot & 15) == 15 || slot == NSLOT - 1) {
+        const int ch = slot >> 4;
+        __builtin_amdgcn_wave_barrier();
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += tile[rr * ROW + qq * 16 + j];
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        acc[ch] += sum;
+        __builtin_amdgcn_wave_barrier();
+      }
+      ++slot;
+    };
+
+    double flux = 0.0;
+#pragma unroll
+    for (int l = 0; l < NLAY; ++l) {
+      const double od = a[l] + grey[l];
+      const double eps = 1.0 - exp_nonpos(-kD * od);
+      // radiative_transfer_lw.cpp:117-119
+      const double fac = fmax(1.0 - (1.0 / kD) * fast_div(fmax(eps, THRESHOLD_EMISSIVITY),
+                                                         fmax(od, THRESHOLD_EMISSIVITY / kD)),
+                              0.5 * THRESHOLD_EMISSIVITY);
+      const double emf = eps - fac;
+      flux = flux * (1.0 - eps) + b[l] * emf + b[l + 1] * fac;
+      const double src_up = b[l + 1] * emf + b[l] * fac;  // :138-139 source of the up sweep
+      a[l] = 1.0 - eps;
+      b[l] = src_up;
+      push(flux);
+    }
+    // surface (:126-128): emissivity 1, surf_planck = planck_hl(NLAY)
+    flux = b[NLAY] * 1.0 + (1.0 - 1.0) * flux;
+    push(flux);
+#pragma unroll
+    for (int l = NLAY - 1; l >= 0; --l) {
+      flux = flux * a[l] + b[l];
+      push(flux);
+    }
+    // a partially filled last tile row set must not leak into the next sub-tile
+    if ((NSLOT & 15) != 0) {
+#pragma unroll
+      for (int j = (NSLOT & 15); j < 16; ++j) tile[j * ROW + lane] = 0.0;
+    }
+  }
+
+  // lanes 0..15 of each wave hold the wave's sums for slots ch*16 + lane
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) s_out[wave][j * 16 + lane] = acc[j];
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * NHL; t += RT_THREADS) {
+    // slot of (direction, level): dn[l] = slot l-1 (dn[0] = 0), up[NLAY] = slot NLAY, up[l] = slot 2*NLAY - l
+    double v = 0.0;
+    int sl = -1;
+    if (t < NHL) { if (t > 0) sl = t - 1; }
+    else { sl = 2 * NLAY - (t - NHL); }
+    if (sl >= 0) v = ((s_out[0][sl] + s_out[1][sl]) + s_out[2][sl]) + s_out[3][sl];
+    partial[(size_t)chunk * 2 * NHL + t] = v;
+  }
+}
+
 // K5d: combine chunk partials of each interval in order, heating rate, cost
 // (calc_cost_function_lw.cpp:100-109).  grid nint, block 1024 = 8 groups x 128.
 __global__ void __launch_bounds__(1024)
@@ -728,7 +888,9 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   for (int k = 0; k < n; ++k) g->total_comp_cost += bound2[k] - bound1[k];  // :320
 
   // chunking: aim at ~8 blocks per CU, chunks are multiples of the 256-point sub-tile
-  long long target_blocks = (long long)ctx->num_cu * 8;
+  const bool fast_path = (nlay == 54 || nlay == 30);
+  // fast path: 2 resident blocks per CU (register-resident columns) -> one wave of blocks
+  long long target_blocks = (long long)ctx->num_cu * (fast_path ? 2 : 8);
   long long chunk_pts = (total_pts + target_blocks - 1) / target_blocks;
   chunk_pts = (chunk_pts + RT_THREADS - 1) / RT_THREADS * RT_THREADS;
   if (chunk_pts < RT_THREADS) chunk_pts = RT_THREADS;
@@ -761,8 +923,16 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   hipLaunchKernelGGL(k_fit_lw, dim3(n), dim3(128), 0, ctx->stream, nlay, g->method, g->nrows, d_iv, d_sums, d_fit);
   const size_t rt_lds = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
-  hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, ctx->stream, nlay, g->n,
-                     chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+  if (nlay == 54) {
+    hipLaunchKernelGGL(k_rt_lw_bb_fast<54>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
+                       chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+  } else if (nlay == 30) {
+    hipLaunchKernelGGL(k_rt_lw_bb_fast<30>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
+                       chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+  } else {
+    hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, ctx->stream, nlay, g->n,
+                       chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+  }
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
   const size_t cost_lds = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
   hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, ctx->stream, nlay, g->method, g->nrows, d_iv,
