@@ -78,6 +78,11 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_double,
                                       C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ecckd_gas_create_sw": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t,
+                                      C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.POINTER(C.c_void_p)]),
+    "ecckd_gas_set_band_albedo": (C.c_int, [C.c_void_p, C.c_double]),
     "ecckd_gas_destroy": (C.c_int, [C.c_void_p]),
     "ecckd_gas_view": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                  C.POINTER(C.c_size_t)]),
@@ -85,6 +90,8 @@ SIGNATURES = {
     "ecckd_gas_comp_cost": (C.c_double, [C.c_void_p, C.c_int]),
     "ecckd_calc_error_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, _c_double_p,
                                          _c_double_p, _c_double_p]),
+    "ecckd_fit_optical_depth": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, _c_double_p,
+                                          _c_double_p, _c_double_p]),
     "ecckd_partition_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "ecckd_partition_destroy": (C.c_int, [C.c_void_p]),
     "ecckd_partition_configure": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,

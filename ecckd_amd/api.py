@@ -363,6 +363,15 @@ class GasLW:
                                               _hptr(b2), _hptr(err)))
         return err
 
+    def fit_optical_depth(self, ibegin, npoints, bound1, bound2):
+        """fit_optical_depth_{lw,sw,sw_total_trans} for a batch of intervals -> (n, nlay)."""
+        b1 = np.ascontiguousarray(bound1, dtype=np.float64)
+        b2 = np.ascontiguousarray(bound2, dtype=np.float64)
+        out = np.empty((b1.size, self.nlay))
+        check(self.lib.ecckd_fit_optical_depth(self.handle, int(ibegin), int(npoints), b1.size, _hptr(b1),
+                                               _hptr(b2), _hptr(out)))
+        return out
+
     def find_g_band(self, ibegin, iend, heating_rate_tolerance, tolerance_tolerance=0.02, max_iterations=60,
                     min_g_points=1, max_g_points=256, capacity=1024):
         """find_g_points.cpp:1152-1266 for one band -> (status, bounds, error, comp_cost)."""
@@ -375,3 +384,39 @@ class GasLW:
                                          C.byref(st), C.byref(cc)))
         n = ng.value
         return st.value, b[:n + 1].copy(), e[:n].copy(), cc.value
+
+
+class GasSW(GasLW):
+    """A prepared shortwave gas (ecckd_gas_create_sw); same batched-error interface as GasLW."""
+
+    def __init__(self, ctx, pressure_hl, ssi, rank, optical_depth, bg_optical_depth=None,
+                 averaging_method="total-transmission", flux_weight=0.02, min_pressure=0.0, cos_sza=0.5,
+                 albedo=None, min_scaling=1.0, max_scaling=1.0):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        p = np.ascontiguousarray(pressure_hl, dtype=np.float64)
+        self.nlay = p.size - 1
+        if optical_depth.dim() != 2 or optical_depth.shape[0] != self.nlay:
+            raise EcckdError(_lib.PARAMETER_ERROR, "optical_depth must be (nlay, nwav)")
+        self.nwav = optical_depth.shape[1]
+        stride = optical_depth.stride(0) if self.nlay > 1 else self.nwav
+        if averaging_method not in _lib.AVG:
+            raise EcckdError(_lib.PARAMETER_ERROR, f'Averaging method "{averaging_method}" not understood')
+        # find_g_points.cpp:666-667
+        min_scaling = min(0.5, min_scaling)
+        max_scaling = max(2.5, max_scaling)
+        h = C.c_void_p()
+        ctx.fence_from_torch()
+        check(self.lib.ecckd_gas_create_sw(
+            ctx.handle, self.nlay, self.nwav, _hptr(p), _dptr(ssi), _dptr(albedo) if albedo is not None else None,
+            _dptr(rank), _dptr(bg_optical_depth) if bg_optical_depth is not None else None,
+            _od_type(bg_optical_depth) if bg_optical_depth is not None else 0,
+            _dptr(optical_depth), _od_type(optical_depth), stride, _lib.AVG[averaging_method],
+            float(flux_weight), float(min_pressure), float(cos_sza), float(min_scaling), float(max_scaling),
+            C.byref(h)))
+        self.handle = h
+        self.min_scaling, self.max_scaling = min_scaling, max_scaling
+        ctx._children.add(self)
+
+    def set_band_albedo(self, albedo):
+        check(self.lib.ecckd_gas_set_band_albedo(self.handle, float(albedo)))

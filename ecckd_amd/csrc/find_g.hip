@@ -59,6 +59,22 @@ __device__ __forceinline__ double block_sum_256(double v, double* s4) {
 
 }  // namespace
 
+// Row table of a gas: which summable per-point rows exist and where (indices into
+// ecckd_gas::rows / the per-interval sums).  Blocks of nlay consecutive rows start at the
+// given offsets; -1 = absent.
+struct RowMap {
+  int A = -1;     // numerator of the fit: metric * weight      (log: log(metric) * weight, metric > 0)
+  int B = -1;     // denominator of the fit: weight             (log: weight where metric > 0)
+  int N = -1;     // log only: count of metric > 0
+  int H = -1;     // true heating rate
+  int FDS = -1, FUT = -1;  // true surface-down / TOA-up flux (single rows)
+  // shortwave total-transmission extras (find_g_points.cpp:171-204, :263-278)
+  int TF = -1, TG = -1;    // direct-beam flux below each layer with / without the target gas
+  int HL = -1, HH = -1;    // true heating rate for min_scaling / max_scaling
+  int FDSL = -1, FUTL = -1, FDSH = -1, FUTH = -1;
+  int total = 0;
+};
+
 // ---------------------------------------------------------------------------
 // opaque handle
 struct ecckd_gas {
@@ -82,7 +98,18 @@ struct ecckd_gas {
   double* wn_sorted = nullptr;  // [n]
   double* dwn_sorted = nullptr; // [n]
   int32_t* ireorder = nullptr;  // [n]
+  // shortwave
+  double cos_sza = 0.5;
+  double surf_albedo = 0.0;  // band albedo of CkdEquipartition::init_sw (find_g_points.cpp:237-261)
+  double min_scaling = 1.0, max_scaling = 1.0;
+  double* ssi = nullptr;        // [n] sorted
+  double* tf = nullptr;         // [nlay][n] total-transmission: direct flux below layer l, bg+target
+  double* tg = nullptr;         // [nlay][n]                      ... background only
+  double* hr_low = nullptr;     // [nlay][n]
+  double* hr_high = nullptr;    // [nlay][n]
+  double* fx = nullptr;         // [4][n] fds_low, fut_low, fds_high, fut_high
   // row table for interval sums
+  RowMap rm;
   int nrows = 0;
   const double** rows = nullptr;  // device array of nrows row pointers
   double* tile_sums = nullptr;    // [nrows][ntiles]
@@ -99,19 +126,6 @@ struct ecckd_gas {
 };
 
 namespace {
-
-// row layout helpers (must match k_fit / k_cost)
-struct RowLayout {
-  int nlay;
-  bool is_log;
-  __host__ __device__ int A(int l) const { return l; }
-  __host__ __device__ int B(int l) const { return nlay + l; }
-  __host__ __device__ int N(int l) const { return 2 * nlay + l; }  // log only
-  __host__ __device__ int H(int l) const { return (is_log ? 3 : 2) * nlay + l; }
-  __host__ __device__ int FDS() const { return (is_log ? 4 : 3) * nlay; }
-  __host__ __device__ int FUT() const { return (is_log ? 4 : 3) * nlay + 1; }
-  __host__ __device__ int total() const { return (is_log ? 4 : 3) * nlay + 2; }
-};
 
 // ---------------------------------------------------------------------------
 // K4 helpers
@@ -274,13 +288,13 @@ k_interval_sums(int nrows, size_t ntiles, const Interval* __restrict__ iv,
 
 // K5b: fitted grey optical depth per (interval, layer).  grid nint, block 128.
 __global__ void __launch_bounds__(128)
-k_fit_lw(int nlay, int method, int nrows, const Interval* __restrict__ iv,
+k_fit_lw(int nlay, int method, RowMap R, const Interval* __restrict__ iv,
          const double* __restrict__ sums, double* __restrict__ od_fit) {
+#pragma clang fp contract(off)
   const int k = blockIdx.x;
-  const RowLayout R{nlay, method == ECCKD_AVG_LOGARITHMIC};
-  const double* s = sums + (size_t)k * nrows;
+  const double* s = sums + (size_t)k * R.total;
   for (int l = threadIdx.x; l < nlay; l += blockDim.x) {
-    const double a = s[R.A(l)], b = s[R.B(l)];
+    const double a = s[R.A + l], b = s[R.B + l];
     double fit;
     switch (method) {
       case ECCKD_AVG_LINEAR:
@@ -298,7 +312,7 @@ k_fit_lw(int nlay, int method, int nrows, const Interval* __restrict__ iv,
         break;
       }
       case ECCKD_AVG_LOGARITHMIC: {  // find_g_points.cpp:79-99
-        const double nnz = s[R.N(l)];
+        const double nnz = s[R.N + l];
         const double ntot = (double)(iv[k].i2 - iv[k].i1 + 1);
         if (nnz == ntot) fit = exp(a / b);
         else if (nnz == 0.0) fit = 0.0;
@@ -560,7 +574,7 @@ k_rt_lw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
 // K5d: combine chunk partials of each interval in order, heating rate, cost
 // (calc_cost_function_lw.cpp:100-109).  grid nint, block 1024 = 8 groups x 128.
 __global__ void __launch_bounds__(1024)
-k_cost_lw(int nlay, int method, int nrows, const Interval* __restrict__ iv, long long nchunks_total,
+k_cost_lw(int nlay, RowMap R, const Interval* __restrict__ iv, long long nchunks_total,
           const double* __restrict__ partial, const double* __restrict__ sums,
           const double* __restrict__ conv, const double* __restrict__ layer_weight,
           double flux_weight, double* __restrict__ err) {
@@ -587,14 +601,13 @@ k_cost_lw(int nlay, int method, int nrows, const Interval* __restrict__ iv, long
     s_flux[v] = a;
   }
   __syncthreads();
-  const RowLayout R{nlay, method == ECCKD_AVG_LOGARITHMIC};
-  const double* s = sums + (size_t)k * nrows;
+  const double* s = sums + (size_t)k * R.total;
   const double* dn = s_flux;
   const double* up = s_flux + nhl;
   for (int l = tid; l < nlay; l += 1024) {
     // heating_rate_single (heating_rate.h:55-72) and the weighted squared difference
     const double hr_fit = conv[l] * (dn[l + 1] - dn[l] - up[l + 1] + up[l]);
-    const double d = hr_fit - s[R.H(l)];
+    const double d = hr_fit - s[R.H + l];
     s_term[l] = layer_weight[l] * (d * d);
   }
   __syncthreads();
@@ -602,8 +615,279 @@ k_cost_lw(int nlay, int method, int nrows, const Interval* __restrict__ iv, long
     double ss = 0.0;
     for (int l = 0; l < nlay; ++l) ss += s_term[l];
     const double hr_weight = 3600.0 * 24.0;
-    const double dsurf = dn[nlay] - s[R.FDS()];
-    const double dtoa = up[0] - s[R.FUT()];
+    const double dsurf = dn[nlay] - s[R.FDS];
+    const double dtoa = up[0] - s[R.FUT];
+    err[k] = sqrt(hr_weight * hr_weight * ss + flux_weight * (dsurf * dsurf + dtoa * dtoa));
+  }
+}
+
+
+// ===========================================================================
+// Shortwave twins (find_g_points.cpp do_sw branches).
+//
+// K4-SW.  Gas preparation: direct-beam RT of background+target
+// (radiative_transfer_direct_sw, radiative_transfer_sw.cpp:26-43), heating rate from
+// the direct beam only (find_g_points.cpp:1003-1006, :1040-1041), metric * ssi rows, and
+// for the total-transmission method the per-point direct fluxes that
+// fit_optical_depth_sw_total_trans sums (:171-204) plus the two scaled "truth" fields
+// (:1011-1034, :1060-1090).  One thread per sorted wavenumber.
+template <typename BgT, typename OdT>
+__global__ void __launch_bounds__(PREP_THREADS)
+k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza, double min_scaling,
+              double max_scaling, const int32_t* __restrict__ ireorder, const double* __restrict__ conv,
+              const double* __restrict__ ssi_src, const double* __restrict__ albedo_src,
+              const BgT* __restrict__ bg_src, const OdT* __restrict__ od_src,
+              double* __restrict__ ssi_s, double* __restrict__ bg_od, double* __restrict__ w1,
+              double* __restrict__ w2, double* __restrict__ cnt, double* __restrict__ hr,
+              double* __restrict__ fds, double* __restrict__ fut, double* __restrict__ tf,
+              double* __restrict__ tg, double* __restrict__ hr_low, double* __restrict__ hr_high,
+              double* __restrict__ fx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t j = (size_t)ireorder[i];
+  const bool is_log = method == ECCKD_AVG_LOGARITHMIC;
+  const bool is_tt = method == ECCKD_AVG_TOTAL_TRANSMISSION;
+  const double s = ssi_src[j];
+  ssi_s[i] = s;
+  const double minus_sec_sza = -1.0 / cos_sza;
+  double flux = cos_sza * s;
+  double fl_low = flux, fl_high = flux;
+  double tfv = s, tgv = s;  // :178-179 start from ssi, not cos_sza*ssi
+  for (int l = 0; l < nlay; ++l) {
+    const double bg = bg_src ? (double)bg_src[(size_t)l * src_stride + j] : 0.0;
+    const double od = (double)od_src[(size_t)l * src_stride + j];
+    const size_t o = (size_t)l * n + i;
+    bg_od[o] = bg;
+    const double flux_next = flux * exp(minus_sec_sza * (bg + od));
+    hr[o] = conv[l] * (flux_next - flux);
+    flux = flux_next;
+    const double m = metric_of(method, od);
+    if (!is_log) {
+      w1[o] = m * s;
+    } else {
+      const bool pos = m > 0.0;
+      w1[o] = pos ? log(m) * s : 0.0;
+      w2[o] = pos ? s : 0.0;
+      cnt[o] = pos ? 1.0 : 0.0;
+    }
+    if (is_tt) {
+      // :191-192
+      tgv *= exp(-2.0 * bg);
+      tfv *= exp(-2.0 * (bg + od));
+      tg[o] = tgv;
+      tf[o] = tfv;
+      const double lo_next = fl_low * exp(minus_sec_sza * (bg + min_scaling * od));
+      hr_low[o] = conv[l] * (lo_next - fl_low);
+      fl_low = lo_next;
+      const double hi_next = fl_high * exp(minus_sec_sza * (bg + max_scaling * od));
+      hr_high[o] = conv[l] * (hi_next - fl_high);
+      fl_high = hi_next;
+    }
+  }
+  fds[i] = flux;
+  fut[i] = 0.0;  // find_g_points.cpp:1047-1050: no upwelling in the base truth
+  if (is_tt) {
+    fx[i] = fl_low;
+    fx[2 * n + i] = fl_high;
+    double up_low = 0.0, up_high = 0.0;
+    if (albedo_src) {
+      // radiative_transfer_norayleigh_sw (radiative_transfer_sw.cpp:72-76), two-stream secant 2
+      const double alb = albedo_src[j];
+      up_low = fl_low * alb;
+      up_high = fl_high * alb;
+      for (int l = nlay - 1; l >= 0; --l) {
+        const double bg = bg_src ? (double)bg_src[(size_t)l * src_stride + j] : 0.0;
+        const double od = (double)od_src[(size_t)l * src_stride + j];
+        up_low = up_low * exp(-2.0 * (bg + min_scaling * od));
+        up_high = up_high * exp(-2.0 * (bg + max_scaling * od));
+      }
+    }
+    fx[n + i] = up_low;
+    fx[3 * n + i] = up_high;
+  }
+}
+
+// K5b-SW: fit_optical_depth_sw (find_g_points.cpp:112-165) and
+// fit_optical_depth_sw_total_trans (:171-204) from the interval sums.
+// Writes npass fits per interval: pass 0 (and pass 1 for total-transmission:
+// fit*min_scaling, fit*max_scaling, :357 and :371).
+__global__ void __launch_bounds__(128)
+k_fit_sw(int nlay, int method, RowMap R, int nint, double min_scaling, double max_scaling,
+         const Interval* __restrict__ iv, const double* __restrict__ sums, double* __restrict__ od_fit) {
+#pragma clang fp contract(off)
+  extern __shared__ double s_fit[];  // [nlay]
+  const int k = blockIdx.x;
+  const double* s = sums + (size_t)k * R.total;
+  if (method != ECCKD_AVG_TOTAL_TRANSMISSION) {
+    for (int l = threadIdx.x; l < nlay; l += blockDim.x) {
+      const double a = s[R.A + l];
+      double fit;
+      if (method == ECCKD_AVG_LOGARITHMIC) {
+        const double b = s[R.B + l];
+        const double nnz = s[R.N + l];
+        const double ntot = (double)(iv[k].i2 - iv[k].i1 + 1);
+        if (nnz == ntot) fit = exp(a / b);
+        else if (nnz == 0.0) fit = 0.0;
+        else fit = exp(a / b) * (nnz / ntot);
+      } else {
+        const double norm_factor = 1.0 / s[R.B];  // sum(ssi(range(i1,i2)))
+        switch (method) {
+          case ECCKD_AVG_LINEAR: fit = a * norm_factor; break;
+          // :123-124: the clamp is applied BEFORE the normalisation
+          // contraction is OFF in this kernel: the product must be ROUNDED before the subtraction.
+          // A fused 1 - a*(1/b) keeps the rounding error of 1/b and goes negative when a == b
+          // (saturated interval), turning the reference's log(0) = -inf into log(<0) = NaN.
+          case ECCKD_AVG_TRANSMISSION:
+            fit = fabs(-log(1.0 - fmin(0.9999999999999999, a) * norm_factor) / kD); break;
+          case ECCKD_AVG_TRANSMISSION_2:
+            fit = fabs(-log(1.0 - fmin(0.9999999999999999, a) * norm_factor) / (kD * 2.0)); break;
+          case ECCKD_AVG_SQUARE_ROOT: { const double v = a * norm_factor; fit = v * v; break; }
+          default: fit = nan("");
+        }
+      }
+      od_fit[(size_t)k * nlay + l] = fit;
+    }
+    return;
+  }
+  // total-transmission: sequential in the layers (:189-203)
+  if (threadIdx.x == 0) {
+    const double ssum = s[R.B];
+    const double norm_factor = 1.0 / ssum;
+    double top = ssum, top_bg = ssum;
+    for (int iz = 0; iz < nlay; ++iz) {
+      const double base_bg = s[R.TG + iz];
+      const double base = s[R.TF + iz];
+      if (base_bg > 0.0 && base > 0.0) {
+        const double bg_od_fit = -0.5 * log(base_bg / top_bg);
+        s_fit[iz] = -0.5 * log(base / top) - bg_od_fit;
+      } else {
+        // :197-199: the WHOLE vector becomes the linear average, the loop continues
+        for (int kz = 0; kz < nlay; ++kz) s_fit[kz] = s[R.A + kz] * norm_factor;
+      }
+      top = base;
+      top_bg = base_bg;
+    }
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < nlay; l += blockDim.x) {
+    od_fit[(size_t)k * nlay + l] = s_fit[l] * min_scaling;
+    od_fit[((size_t)nint + k) * nlay + l] = s_fit[l] * max_scaling;
+  }
+}
+
+// K5c-SW: radiative_transfer_direct_sw_bb / _norayleigh_sw_bb
+// (radiative_transfer_sw.cpp:118-141, :147-184) for every interval: reads ssi and the
+// background optical depth rows, (nlay+1)*8 B per point.  partial[chunk] =
+// { sum ssi, dn[1..nlay], up[0..nlay] } (dn[0] = cos_sza * sum ssi is formed in K5d as the
+// reference does, :128).  Same chunking and reduction order as the LW kernel.
+__global__ void __launch_bounds__(RT_THREADS)
+k_rt_sw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv,
+           double cos_sza, double albedo, const double* __restrict__ ssi, const double* __restrict__ bg_od,
+           const double* __restrict__ od_fit, double* __restrict__ partial) {
+  extern __shared__ double s_mem[];  // [4][2*nhl] | [nlay]
+  const int nhl = nlay + 1;
+  double* s_acc = s_mem;
+  double* s_grey = s_mem + 4 * 2 * nhl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long chunk = blockIdx.x;
+  int lo = 0, hi = nint - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (iv[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
+  }
+  const int k = lo;
+  const long long c = chunk - iv[k].chunk0;
+  const long long p0 = iv[k].i1 + c * chunk_pts;
+  long long p1 = p0 + chunk_pts - 1;
+  if (p1 > iv[k].i2) p1 = iv[k].i2;
+  for (int t = tid; t < 4 * 2 * nhl; t += RT_THREADS) s_acc[t] = 0.0;
+  for (int l = tid; l < nlay; l += RT_THREADS) s_grey[l] = od_fit[(size_t)k * nlay + l];
+  __syncthreads();
+  double* acc_dn = s_acc + wave * 2 * nhl;
+  double* acc_up = acc_dn + nhl;
+  const double minus_sec_sza = -1.0 / cos_sza;
+  for (long long base = p0; base <= p1; base += RT_THREADS) {
+    const long long i = base + tid;
+    const bool live = i <= p1;
+    const size_t ii = live ? (size_t)i : (size_t)p1;
+    const double sv = live ? ssi[ii] : 0.0;
+    {
+      const double s0 = wave_sum(sv);
+      if (lane == 0) acc_dn[0] += s0;
+    }
+    double flux = cos_sza * sv;
+    for (int l = 0; l < nlay; ++l) {
+      flux = flux * exp(minus_sec_sza * (bg_od[(size_t)l * n + ii] + s_grey[l]));
+      const double sl = wave_sum(flux);
+      if (lane == 0) acc_dn[l + 1] += sl;
+    }
+    if (albedo > 0.0) {
+      flux *= albedo;
+      {
+        const double sl = wave_sum(flux);
+        if (lane == 0) acc_up[nlay] += sl;
+      }
+      for (int l = nlay - 1; l >= 0; --l) {
+        flux = flux * exp(-2.0 * (bg_od[(size_t)l * n + ii] + s_grey[l]));
+        const double sl = wave_sum(flux);
+        if (lane == 0) acc_up[l] += sl;
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * nhl; t += RT_THREADS) {
+    partial[(size_t)chunk * 2 * nhl + t] =
+        ((s_acc[t] + s_acc[2 * nhl + t]) + s_acc[4 * nhl + t]) + s_acc[6 * nhl + t];
+  }
+}
+
+// K5d-SW: calc_cost_function_sw (calc_cost_function_sw.cpp:86-109): heating rate from the
+// direct beam only (:92), truth rows selected by (rH, rFDS, rFUT).
+__global__ void __launch_bounds__(1024)
+k_cost_sw(int nlay, int ntotal, int rH, int rFDS, int rFUT, const Interval* __restrict__ iv,
+          long long nchunks_total, const double* __restrict__ partial, const double* __restrict__ sums,
+          const double* __restrict__ conv, const double* __restrict__ layer_weight, double flux_weight,
+          double cos_sza, double* __restrict__ err) {
+  extern __shared__ double s_mem[];
+  const int nhl = nlay + 1;
+  const int nv = 2 * nhl;
+  double* s_grp = s_mem;
+  double* s_flux = s_mem + 8 * nv;
+  double* s_term = s_flux + nv;
+  const int k = blockIdx.x;
+  const long long c0 = iv[k].chunk0;
+  const long long c1 = (k + 1 < (int)gridDim.x) ? iv[k + 1].chunk0 : nchunks_total;
+  const int tid = threadIdx.x;
+  const int g = tid >> 7, t = tid & 127;
+  for (int v = t; v < nv; v += 128) {
+    double a = 0.0;
+    for (long long c = c0 + g; c < c1; c += 8) a += partial[(size_t)c * nv + v];
+    s_grp[g * nv + v] = a;
+  }
+  __syncthreads();
+  for (int v = tid; v < nv; v += 1024) {
+    double a = 0.0;
+    for (int gg = 0; gg < 8; ++gg) a += s_grp[gg * nv + v];
+    s_flux[v] = a;
+  }
+  __syncthreads();
+  if (tid == 0) s_flux[0] = cos_sza * s_flux[0];  // flux_dn(0) = cos_sza*sum(ssi)
+  __syncthreads();
+  const double* s = sums + (size_t)k * ntotal;
+  const double* dn = s_flux;
+  const double* up = s_flux + nhl;
+  for (int l = tid; l < nlay; l += 1024) {
+    const double hr_fit = conv[l] * (dn[l + 1] - dn[l]);
+    const double d = hr_fit - s[rH + l];
+    s_term[l] = layer_weight[l] * (d * d);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double ss = 0.0;
+    for (int l = 0; l < nlay; ++l) ss += s_term[l];
+    const double hr_weight = 3600.0 * 24.0;
+    const double dsurf = dn[nlay] - s[rFDS];
+    const double dtoa = up[0] - s[rFUT];
     err[k] = sqrt(hr_weight * hr_weight * ss + flux_weight * (dsurf * dsurf + dtoa * dtoa));
   }
 }
@@ -639,6 +923,7 @@ void gas_free(ecckd_gas* g) {
   if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   if (g->owns_planck) fr(g->planck_hl);
+  fr(g->ssi); fr(g->tf); fr(g->tg); fr(g->hr_low); fr(g->hr_high); fr(g->fx);
   fr(g->bg_od); fr(g->w1); fr(g->w2); fr(g->cnt); fr(g->hr); fr(g->fds); fr(g->fut);
   fr(g->wn_sorted); fr(g->dwn_sorted); fr(g->ireorder); fr((void*)g->rows); fr(g->tile_sums);
   fr(g->lev); fr(g->work);
@@ -783,19 +1068,27 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   GTRY(hipGetLastError());
 
   // row table + tile sums
-  const RowLayout R{nlay, is_log};
-  g->nrows = R.total();
+  RowMap R;
+  R.A = 0;
+  R.B = nlay;
+  if (is_log) R.N = 2 * nlay;
+  R.H = (is_log ? 3 : 2) * nlay;
+  R.FDS = R.H + nlay;
+  R.FUT = R.FDS + 1;
+  R.total = R.FUT + 1;
+  g->rm = R;
+  g->nrows = R.total;
   std::vector<const double*> rows(g->nrows);
   for (int l = 0; l < nlay; ++l) {
-    rows[R.A(l)] = g->w1 + (size_t)l * nwav;
+    rows[R.A + l] = g->w1 + (size_t)l * nwav;
     // denominator of the fit: planck_hl(l+1) (find_g_points.cpp:62), or for the
     // logarithmic method planck_hl(l) masked by metric > 0 (:87)
-    rows[R.B(l)] = is_log ? g->w2 + (size_t)l * nwav : g->planck_hl + (size_t)(l + 1) * nwav;
-    if (is_log) rows[R.N(l)] = g->cnt + (size_t)l * nwav;
-    rows[R.H(l)] = g->hr + (size_t)l * nwav;
+    rows[R.B + l] = is_log ? g->w2 + (size_t)l * nwav : g->planck_hl + (size_t)(l + 1) * nwav;
+    if (is_log) rows[R.N + l] = g->cnt + (size_t)l * nwav;
+    rows[R.H + l] = g->hr + (size_t)l * nwav;
   }
-  rows[R.FDS()] = g->fds;
-  rows[R.FUT()] = g->fut;
+  rows[R.FDS] = g->fds;
+  rows[R.FUT] = g->fut;
   GTRY(hipMalloc((void**)&g->rows, rows.size() * sizeof(double*)));
   GTRY(hipMemcpyAsync((void*)g->rows, rows.data(), rows.size() * sizeof(double*), hipMemcpyHostToDevice, ctx->stream));
   GTRY(hipStreamSynchronize(ctx->stream));
@@ -813,6 +1106,189 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
     return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_gas_create_lw: rank is not a permutation of 0..nwav-1");
   }
   *out = g;
+  return ECCKD_OK;
+}
+
+
+// Shortwave gas (find_g_points.cpp do_sw branches of :872-1150).  d_albedo: per-wavenumber
+// surface albedo in ORIGINAL order (:921-923), used only for the up-welling of the two scaled
+// truth fields of the total-transmission method; NULL = direct beam only (:1027-1034).
+// min_scaling / max_scaling are the values AFTER the clamps of :666-667.
+int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_pressure_hl,
+                        const double* d_ssi, const double* d_albedo, const int32_t* d_rank,
+                        const void* d_bg_od, int bg_type, const void* d_od, int od_type,
+                        size_t src_stride, int averaging_method, double flux_weight,
+                        double min_pressure, double cos_sza, double min_scaling, double max_scaling,
+                        ecckd_gas** out) {
+  ECCKD_REQUIRE(ctx && out, "ecckd_gas_create_sw: NULL ctx/out");
+  *out = nullptr;
+  ECCKD_REQUIRE(nlay > 0 && nwav > 0, "ecckd_gas_create_sw: empty problem (nlay=%d, nwav=%zu)", nlay, nwav);
+  ECCKD_REQUIRE(nwav < (size_t)0x7fffffff, "ecckd_gas_create_sw: nwav exceeds int32 rank range");
+  ECCKD_REQUIRE(h_pressure_hl && d_ssi && d_rank && d_od, "ecckd_gas_create_sw: NULL array argument");
+  ECCKD_REQUIRE(od_type == ECCKD_F32 || od_type == ECCKD_F64, "ecckd_gas_create_sw: od_type must be 4 or 8");
+  ECCKD_REQUIRE(!d_bg_od || bg_type == ECCKD_F32 || bg_type == ECCKD_F64, "ecckd_gas_create_sw: bg_type must be 4 or 8");
+  ECCKD_REQUIRE(src_stride >= nwav, "ecckd_gas_create_sw: src_stride < nwav");
+  ECCKD_REQUIRE(averaging_method >= ECCKD_AVG_LINEAR && averaging_method <= ECCKD_AVG_TOTAL_TRANSMISSION,
+                "Averaging method %d not understood", averaging_method);
+  ECCKD_REQUIRE(cos_sza > 0.0, "ecckd_gas_create_sw: cos_sza must be positive");
+  for (int i = 0; i <= nlay; ++i)
+    ECCKD_REQUIRE(h_pressure_hl[i] > 0.0 && (i == 0 || h_pressure_hl[i] > h_pressure_hl[i - 1]),
+                  "ecckd_gas_create_sw: pressure_hl must be positive and increasing");
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+
+  ecckd_gas* g = new ecckd_gas();
+  g->ctx = ctx;
+  g->do_sw = 1;
+  g->method = averaging_method;
+  g->nlay = nlay;
+  g->n = nwav;
+  g->flux_weight = flux_weight;
+  g->cos_sza = cos_sza;
+  g->min_scaling = min_scaling;
+  g->max_scaling = max_scaling;
+  g->owns_planck = true;
+  g->h_pressure_hl.assign(h_pressure_hl, h_pressure_hl + nlay + 1);
+  const bool is_log = averaging_method == ECCKD_AVG_LOGARITHMIC;
+  const bool is_tt = averaging_method == ECCKD_AVG_TOTAL_TRANSMISSION;
+  const size_t nhl = nlay + 1;
+  int rc = ECCKD_OK;
+#define GTRY(expr)                                                                       \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      rc = ecckd::fail(_e == hipErrorOutOfMemory ? ECCKD_OUT_OF_MEMORY : ECCKD_UNEXPECTED_EXCEPTION, \
+                       "%s failed: %s", #expr, hipGetErrorString(_e));                   \
+      gas_free(g);                                                                       \
+      return rc;                                                                         \
+    }                                                                                    \
+  } while (0)
+  const size_t mat = (size_t)nlay * nwav * sizeof(double);
+  GTRY(hipMalloc((void**)&g->ssi, nwav * sizeof(double)));
+  GTRY(hipMalloc((void**)&g->bg_od, mat));
+  GTRY(hipMalloc((void**)&g->w1, mat));
+  if (is_log) {
+    GTRY(hipMalloc((void**)&g->w2, mat));
+    GTRY(hipMalloc((void**)&g->cnt, mat));
+  }
+  GTRY(hipMalloc((void**)&g->hr, mat));
+  GTRY(hipMalloc((void**)&g->fds, nwav * sizeof(double)));
+  GTRY(hipMalloc((void**)&g->fut, nwav * sizeof(double)));
+  if (is_tt) {
+    GTRY(hipMalloc((void**)&g->tf, mat));
+    GTRY(hipMalloc((void**)&g->tg, mat));
+    GTRY(hipMalloc((void**)&g->hr_low, mat));
+    GTRY(hipMalloc((void**)&g->hr_high, mat));
+    GTRY(hipMalloc((void**)&g->fx, 4 * nwav * sizeof(double)));
+  }
+  GTRY(hipMalloc((void**)&g->ireorder, nwav * sizeof(int32_t)));
+
+  // per-level constants: (unused hk)[nhl] | conv[nlay] | layer_weight[nlay] | flag
+  std::vector<double> lev(nhl + 2 * nlay + 1, 0.0);
+  g->h_layer_weight.resize(nlay);
+  {
+    double sw = 0.0;
+    for (int l = 0; l < nlay; ++l) {
+      lev[nhl + l] = -(ECCKD_ACCEL_GRAVITY / ECCKD_SPECIFIC_HEAT_AIR) / (h_pressure_hl[l + 1] - h_pressure_hl[l]);
+      double lw = std::sqrt(h_pressure_hl[l + 1]) - std::sqrt(h_pressure_hl[l]);
+      double pfl = 0.5 * (h_pressure_hl[l + 1] + h_pressure_hl[l]);
+      if (pfl < min_pressure) lw = 0.0;
+      g->h_layer_weight[l] = lw;
+    }
+    for (int l = 0; l < nlay; ++l) sw += g->h_layer_weight[l];
+    for (int l = 0; l < nlay; ++l) {
+      g->h_layer_weight[l] /= sw;
+      lev[nhl + nlay + l] = g->h_layer_weight[l];
+    }
+  }
+  GTRY(hipMalloc((void**)&g->lev, lev.size() * sizeof(double)));
+  GTRY(hipMemcpyAsync(g->lev, lev.data(), lev.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GTRY(hipStreamSynchronize(ctx->stream));
+  int* d_flag = (int*)(g->lev + nhl + 2 * nlay);
+
+  const unsigned eblocks = (unsigned)((nwav + 255) / 256);
+  GTRY(hipMemsetAsync(g->ireorder, 0xFF, nwav * sizeof(int32_t), ctx->stream));
+  hipLaunchKernelGGL(k_invert_rank, dim3(eblocks), dim3(256), 0, ctx->stream, nwav, d_rank, g->ireorder, d_flag);
+  hipLaunchKernelGGL(k_check_perm, dim3(eblocks), dim3(256), 0, ctx->stream, nwav, g->ireorder, d_flag);
+  {
+    int flag0 = 0;
+    GTRY(hipMemcpyAsync(&flag0, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GTRY(hipStreamSynchronize(ctx->stream));
+    if (flag0) {
+      gas_free(g);
+      return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_gas_create_sw: rank is not a permutation of 0..nwav-1");
+    }
+  }
+  const unsigned pblocks = (unsigned)((nwav + PREP_THREADS - 1) / PREP_THREADS);
+#define LAUNCH_PREP_SW(BG, OD)                                                                                  \
+  hipLaunchKernelGGL((k_gas_prep_sw<BG, OD>), dim3(pblocks), dim3(PREP_THREADS), 0, ctx->stream, nlay, nwav,    \
+                     src_stride, averaging_method, cos_sza, min_scaling, max_scaling, g->ireorder,              \
+                     g->lev + nhl, d_ssi, d_albedo, (const BG*)d_bg_od, (const OD*)d_od, g->ssi, g->bg_od,      \
+                     g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut, g->tf, g->tg, g->hr_low, g->hr_high, g->fx)
+  const bool bg32 = d_bg_od && bg_type == ECCKD_F32;
+  if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP_SW(float, float);
+  else if (bg32) LAUNCH_PREP_SW(float, double);
+  else if (od_type == ECCKD_F32) LAUNCH_PREP_SW(double, float);
+  else LAUNCH_PREP_SW(double, double);
+#undef LAUNCH_PREP_SW
+  GTRY(hipGetLastError());
+
+  RowMap R;
+  int next = 0;
+  R.A = next; next += nlay;
+  R.B = next; next += nlay;   // rows of ssi (masked by metric > 0 for the logarithmic method)
+  if (is_log) { R.N = next; next += nlay; }
+  R.H = next; next += nlay;
+  R.FDS = next++;
+  R.FUT = next++;
+  if (is_tt) {
+    R.TF = next; next += nlay;
+    R.TG = next; next += nlay;
+    R.HL = next; next += nlay;
+    R.HH = next; next += nlay;
+    R.FDSL = next++; R.FUTL = next++; R.FDSH = next++; R.FUTH = next++;
+  }
+  R.total = next;
+  g->rm = R;
+  g->nrows = R.total;
+  std::vector<const double*> rows(g->nrows);
+  for (int l = 0; l < nlay; ++l) {
+    rows[R.A + l] = g->w1 + (size_t)l * nwav;
+    rows[R.B + l] = is_log ? g->w2 + (size_t)l * nwav : g->ssi;
+    if (is_log) rows[R.N + l] = g->cnt + (size_t)l * nwav;
+    rows[R.H + l] = g->hr + (size_t)l * nwav;
+    if (is_tt) {
+      rows[R.TF + l] = g->tf + (size_t)l * nwav;
+      rows[R.TG + l] = g->tg + (size_t)l * nwav;
+      rows[R.HL + l] = g->hr_low + (size_t)l * nwav;
+      rows[R.HH + l] = g->hr_high + (size_t)l * nwav;
+    }
+  }
+  rows[R.FDS] = g->fds;
+  rows[R.FUT] = g->fut;
+  if (is_tt) {
+    rows[R.FDSL] = g->fx;
+    rows[R.FUTL] = g->fx + nwav;
+    rows[R.FDSH] = g->fx + 2 * nwav;
+    rows[R.FUTH] = g->fx + 3 * nwav;
+  }
+  GTRY(hipMalloc((void**)&g->rows, rows.size() * sizeof(double*)));
+  GTRY(hipMemcpyAsync((void*)g->rows, rows.data(), rows.size() * sizeof(double*), hipMemcpyHostToDevice, ctx->stream));
+  GTRY(hipStreamSynchronize(ctx->stream));
+  g->ntiles = (nwav + TILE - 1) / TILE;
+  GTRY(hipMalloc((void**)&g->tile_sums, (size_t)g->nrows * g->ntiles * sizeof(double)));
+  hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)g->ntiles), dim3(TILE), 0, ctx->stream, g->nrows, nwav, g->ntiles,
+                     (const double* const*)g->rows, g->tile_sums);
+  GTRY(hipGetLastError());
+  GTRY(hipStreamSynchronize(ctx->stream));
+#undef GTRY
+  *out = g;
+  return ECCKD_OK;
+}
+
+// band albedo of CkdEquipartition::init_sw (find_g_points.cpp:237-261, band_albedo(jband) :1169)
+int ecckd_gas_set_band_albedo(ecckd_gas* gas, double surf_albedo) {
+  ECCKD_REQUIRE(gas, "ecckd_gas_set_band_albedo: NULL handle");
+  gas->surf_albedo = surf_albedo;
   return ECCKD_OK;
 }
 
@@ -835,7 +1311,10 @@ int ecckd_gas_view(ecckd_gas* gas, const char* name, const double** d_ptr, size_
   else if (!strcmp(name, "flux_up_toa")) { p = gas->fut; r = 1; }
   else if (!strcmp(name, "wavenumber")) { p = gas->wn_sorted; r = 1; }
   else if (!strcmp(name, "d_wavenumber")) { p = gas->dwn_sorted; r = 1; }
-  else if (!strcmp(name, "ssi")) { p = nullptr; r = 1; }
+  else if (!strcmp(name, "ssi")) { p = gas->ssi; r = 1; }
+  else if (!strcmp(name, "hr_low")) { p = gas->hr_low; r = nlay; }
+  else if (!strcmp(name, "hr_high")) { p = gas->hr_high; r = nlay; }
+  else if (!strcmp(name, "flux_extras")) { p = gas->fx; r = 4; }
   if (!p) return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_gas_view: no array named \"%s\"", name);
   *d_ptr = p;
   if (rows) *rows = r;
@@ -854,6 +1333,56 @@ double ecckd_gas_comp_cost(ecckd_gas* gas, int reset) {
   double c = gas->total_comp_cost;
   if (reset) gas->total_comp_cost = 0.0;
   return c;
+}
+
+
+// The fitted grey optical depth alone: fit_optical_depth_lw / _sw / _sw_total_trans
+// (find_g_points.cpp:54-106, :112-165, :171-204) for n intervals -> h_od_fit[n][nlay]
+// (total-transmission: the unscaled fit).  Runs K5a + K5b only.
+int ecckd_fit_optical_depth(ecckd_gas* g, size_t ibegin, size_t npoints, int n, const double* bound1,
+                            const double* bound2, double* h_od_fit) {
+  ECCKD_REQUIRE(g && n > 0 && bound1 && bound2 && h_od_fit, "ecckd_fit_optical_depth: bad argument");
+  ECCKD_REQUIRE(npoints > 0 && ibegin + npoints <= g->n, "ecckd_fit_optical_depth: band outside the spectrum");
+  ecckd_ctx* ctx = g->ctx;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const int nlay = g->nlay;
+  std::vector<Interval> iv(n);
+  for (int k = 0; k < n; ++k) {
+    long long i1 = (long long)std::ceil(bound1[k] * (double)(npoints - 1));
+    long long i2 = (long long)std::floor(bound2[k] * (double)(npoints - 1));
+    if (i1 < 0 || i2 >= (long long)npoints || i2 + 1 < i1 || bound2[k] < bound1[k])
+      return ecckd::fail(ECCKD_PROCESSING_ERROR, "ecckd_fit_optical_depth: bad bounds %.17g-%.17g", bound1[k], bound2[k]);
+    if (i2 < i1) i2 = i1;
+    iv[k].i1 = (long long)ibegin + i1;
+    iv[k].i2 = (long long)ibegin + i2;
+    iv[k].chunk0 = k;
+    iv[k].npoints = (long long)npoints;
+  }
+  const size_t iv_bytes = ecckd_align_up((size_t)n * sizeof(Interval), 256);
+  const size_t sums_bytes = ecckd_align_up((size_t)n * g->nrows * sizeof(double), 256);
+  const size_t fit_bytes = ecckd_align_up((size_t)2 * n * nlay * sizeof(double), 256);
+  ECCKD_CHECK(gas_ensure_work(g, iv_bytes + sums_bytes + fit_bytes, iv_bytes + fit_bytes));
+  char* w = (char*)g->work;
+  Interval* d_iv = (Interval*)w; w += iv_bytes;
+  double* d_sums = (double*)w; w += sums_bytes;
+  double* d_fit = (double*)w;
+  std::memcpy(g->pinned, iv.data(), (size_t)n * sizeof(Interval));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, g->pinned, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv,
+                     (const double* const*)g->rows, g->tile_sums, d_sums);
+  if (g->do_sw) {
+    // unscaled fit: scaling factors of 1
+    hipLaunchKernelGGL(k_fit_sw, dim3(n), dim3(128), nlay * sizeof(double), ctx->stream, nlay, g->method, g->rm, n,
+                       1.0, 1.0, d_iv, d_sums, d_fit);
+  } else {
+    hipLaunchKernelGGL(k_fit_lw, dim3(n), dim3(128), 0, ctx->stream, nlay, g->method, g->rm, d_iv, d_sums, d_fit);
+  }
+  ECCKD_HIP_CHECK(hipGetLastError());
+  double* h = (double*)((char*)g->pinned + iv_bytes);
+  ECCKD_HIP_CHECK(hipMemcpyAsync(h, d_fit, (size_t)n * nlay * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  std::memcpy(h_od_fit, h, (size_t)n * nlay * sizeof(double));
+  return ECCKD_OK;
 }
 
 int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, const double* bound1,
@@ -900,12 +1429,12 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
     nchunks += (iv[k].i2 - iv[k].i1 + 1 + chunk_pts - 1) / chunk_pts;
   }
 
-  // device work layout: intervals | sums[n][nrows] | od_fit[n][nlay] | partial[nchunks][2nhl] | err[n]
+  // device work layout: intervals | sums[n][nrows] | od_fit[2][n][nlay] | partial[nchunks][2nhl] | err[2][n]
   const size_t iv_bytes = ecckd_align_up((size_t)n * sizeof(Interval), 256);
   const size_t sums_bytes = ecckd_align_up((size_t)n * g->nrows * sizeof(double), 256);
-  const size_t fit_bytes = ecckd_align_up((size_t)n * nlay * sizeof(double), 256);
+  const size_t fit_bytes = ecckd_align_up((size_t)2 * n * nlay * sizeof(double), 256);
   const size_t part_bytes = ecckd_align_up((size_t)nchunks * 2 * nhl * sizeof(double), 256);
-  const size_t err_bytes = ecckd_align_up((size_t)n * sizeof(double), 256);
+  const size_t err_bytes = ecckd_align_up((size_t)2 * n * sizeof(double), 256);
   ECCKD_CHECK(gas_ensure_work(g, iv_bytes + sums_bytes + fit_bytes + part_bytes + err_bytes, iv_bytes + err_bytes));
   char* w = (char*)g->work;
   Interval* d_iv = (Interval*)w; w += iv_bytes;
@@ -920,7 +1449,36 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
 
   hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv,
                      (const double* const*)g->rows, g->tile_sums, d_sums);
-  hipLaunchKernelGGL(k_fit_lw, dim3(n), dim3(128), 0, ctx->stream, nlay, g->method, g->nrows, d_iv, d_sums, d_fit);
+  if (g->do_sw) {
+    // CkdEquipartition::calc_error, shortwave branches (find_g_points.cpp:341-402)
+    const bool is_tt = g->method == ECCKD_AVG_TOTAL_TRANSMISSION;
+    const RowMap& R = g->rm;
+    hipLaunchKernelGGL(k_fit_sw, dim3(n), dim3(128), nlay * sizeof(double), ctx->stream, nlay, g->method, R, n,
+                       g->min_scaling, g->max_scaling, d_iv, d_sums, d_fit);
+    const size_t rt_lds_sw = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
+    const size_t cost_lds_sw = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
+    const int npass = is_tt ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+      hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
+                         chunk_pts, n, d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od,
+                         d_fit + (size_t)pass * n * nlay, d_part);
+      int rH = R.H, rFDS = R.FDS, rFUT = R.FUT;
+      if (is_tt) {
+        rH = pass == 0 ? R.HL : R.HH;
+        rFDS = pass == 0 ? R.FDSL : R.FDSH;
+        rFUT = pass == 0 ? R.FUTL : R.FUTH;
+      }
+      hipLaunchKernelGGL(k_cost_sw, dim3(n), dim3(1024), cost_lds_sw, ctx->stream, nlay, R.total, rH, rFDS, rFUT,
+                         d_iv, nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight,
+                         g->cos_sza, d_err + (size_t)pass * n);
+    }
+    ECCKD_HIP_CHECK(hipGetLastError());
+    ECCKD_HIP_CHECK(hipMemcpyAsync(h_err, d_err, (size_t)npass * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n; ++k) error[k] = is_tt ? 0.5 * (h_err[k] + h_err[n + k]) : h_err[k];  // :386
+    return ECCKD_OK;
+  }
+  hipLaunchKernelGGL(k_fit_lw, dim3(n), dim3(128), 0, ctx->stream, nlay, g->method, g->rm, d_iv, d_sums, d_fit);
   const size_t rt_lds = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
   if (nlay == 54) {
@@ -935,7 +1493,7 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   }
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
   const size_t cost_lds = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
-  hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, ctx->stream, nlay, g->method, g->nrows, d_iv,
+  hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, ctx->stream, nlay, g->rm, d_iv,
                      nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, d_err);
   ECCKD_HIP_CHECK(hipGetLastError());
   ECCKD_HIP_CHECK(hipMemcpyAsync(h_err, d_err, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

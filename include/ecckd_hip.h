@@ -150,9 +150,23 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav,
                         const void* d_od, int od_type, size_t src_stride,
                         int averaging_method, double flux_weight, double min_pressure,
                         const double* d_planck_hl_reuse, ecckd_gas** gas);
+/* Shortwave twin (find_g_points.cpp do_sw branches: radiative_transfer_direct_sw :1003-1006,
+ * the two scaled truth fields of the total-transmission method :1008-1034, :1060-1090).
+ * d_ssi and d_albedo (NULL = direct beam only) are per-wavenumber arrays in ORIGINAL order;
+ * min_scaling/max_scaling are the values after the clamps of :666-667.  The band albedo used
+ * by the fitted side (band_albedo(jband), :1169) is set with ecckd_gas_set_band_albedo before
+ * evaluating a band. */
+int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_pressure_hl,
+                        const double* d_ssi, const double* d_albedo, const int32_t* d_rank,
+                        const void* d_bg_od, int bg_type, const void* d_od, int od_type,
+                        size_t src_stride, int averaging_method, double flux_weight,
+                        double min_pressure, double cos_sza, double min_scaling, double max_scaling,
+                        ecckd_gas** gas);
+int ecckd_gas_set_band_albedo(ecckd_gas* gas, double surf_albedo);
 int ecckd_gas_destroy(ecckd_gas* gas);
 /* device view of a resident array: "planck_hl", "bg_optical_depth", "weighted_metric",
- * "hr", "flux_dn_surf", "flux_up_toa", "wavenumber", "d_wavenumber" */
+ * "hr", "flux_dn_surf", "flux_up_toa", "wavenumber", "d_wavenumber" (LW), "ssi", "hr_low",
+ * "hr_high", "flux_extras" (SW) */
 int ecckd_gas_view(ecckd_gas* gas, const char* name, const double** d_ptr, size_t* rows, size_t* cols);
 int ecckd_gas_layer_weight(ecckd_gas* gas, double* h_layer_weight);
 /* total_comp_cost of find_g_points.cpp:320 accumulated by ecckd_calc_error_batch */
@@ -168,6 +182,12 @@ double ecckd_gas_comp_cost(ecckd_gas* gas, int reset);
  * (:298-313).  Synchronous. */
 int ecckd_calc_error_batch(ecckd_gas* gas, size_t ibegin, size_t npoints, int n,
                            const double* h_bound1, const double* h_bound2, double* h_error);
+
+/* The fitted grey optical depth alone: replaces fit_optical_depth_lw / fit_optical_depth_sw /
+ * fit_optical_depth_sw_total_trans (find_g_points.cpp:54-106, :112-165, :171-204) for n
+ * intervals; h_od_fit[n][nlay]. */
+int ecckd_fit_optical_depth(ecckd_gas* gas, size_t ibegin, size_t npoints, int n,
+                            const double* h_bound1, const double* h_bound2, double* h_od_fit);
 
 /* ---- equal-error partition search over a batched error callback ---------------
  * Replaces class Equipartition (equipartition.h:63-208, equipartition.cpp).  The
