@@ -179,6 +179,6 @@ def test_fit_optical_depth_sw_matches_oracle(ctx, oracle, method):
         assert np.array_equal(np.isinf(fit[k]), np.isinf(ref))
         m = np.isfinite(ref)
         # log(1-v) amplifies near saturation; the total-transmission fit is a difference of two
-        # logs of order 1, so its absolute accuracy is a few 1e-16
-        assert np.allclose(fit[k][m], ref[m], rtol=1e-7, atol=5e-15)
+        # logs of order 1, so its absolute accuracy is that of the interval sums (~1e-14)
+        assert np.allclose(fit[k][m], ref[m], rtol=1e-7, atol=1e-13)
     gas.close()
