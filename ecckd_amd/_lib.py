@@ -100,10 +100,49 @@ SIGNATURES = {
     "ecckd_partition_e": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int),
                                     _c_double_p, _c_double_p, C.c_int, C.POINTER(C.c_int)]),
     "ecckd_partition_status_string": (C.c_char_p, [C.c_int]),
+    "ecckd_opt_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ecckd_opt_destroy": (C.c_int, [C.c_void_p]),
+    "ecckd_opt_nx": (C.c_size_t, [C.c_void_p]),
+    "ecckd_opt_initial_state": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
+    "ecckd_opt_cost_grad": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
+    "ecckd_opt_forward": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
+    "ecckd_opt_coefficients": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, _c_double_p]),
+    "ecckd_opt_minimize": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, _c_double_p, C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), _c_double_p, _c_double_p]),
     "ecckd_find_g_band": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_int,
                                     C.c_int, C.c_int, C.POINTER(C.c_int), _c_double_p, _c_double_p, C.c_int,
                                     C.POINTER(C.c_int), _c_double_p]),
 }
+
+
+
+class OptGas(C.Structure):
+    _fields_ = [("conc_dependence", C.c_int), ("is_active", C.c_int), ("nconc", C.c_int), ("vmr", _c_double_p),
+                ("reference_vmr", C.c_double), ("molar_abs", _c_double_p), ("min_molar_abs", _c_double_p),
+                ("max_molar_abs", _c_double_p)]
+
+
+class OptModel(C.Structure):
+    _fields_ = [("ng", C.c_int), ("nt", C.c_int), ("np", C.c_int), ("log_pressure", _c_double_p),
+                ("temperature", _c_double_p), ("ntp", C.c_int), ("temperature_planck", _c_double_p),
+                ("planck_function", _c_double_p), ("iband_per_g", C.POINTER(C.c_int)), ("ngas", C.c_int),
+                ("gases", C.POINTER(OptGas)), ("logarithmic_interpolation", C.c_int)]
+
+
+class OptScene(C.Structure):
+    _fields_ = [("ncol", C.c_int), ("nlay", C.c_int), ("nband", C.c_int), ("pressure_hl", _c_double_p),
+                ("temperature_hl", _c_double_p), ("vmr_fl", _c_double_p), ("gas_present", C.POINTER(C.c_int)),
+                ("surf_emissivity", _c_double_p), ("flux_dn", _c_double_p), ("flux_up", _c_double_p),
+                ("spectral_flux_dn_surf", _c_double_p), ("spectral_flux_up_toa", _c_double_p)]
+
+
+class OptConfig(C.Structure):
+    _fields_ = [("flux_weight", C.c_double), ("flux_profile_weight", C.c_double), ("broadband_weight", C.c_double),
+                ("spectral_boundary_weight", C.c_double), ("negative_od_penalty", C.c_double),
+                ("pressure_weight_power", C.c_double), ("prior_error", C.c_double), ("min_prior_error", C.c_double),
+                ("max_prior_error", C.c_double), ("prior_error_scaling", C.c_double), ("pressure_corr", C.c_double),
+                ("temperature_corr", C.c_double), ("conc_corr", C.c_double), ("cap_relative_linear", C.c_double)]
+
 
 ERROR_FN = C.CFUNCTYPE(C.c_int, C.c_int, _c_double_p, _c_double_p, _c_double_p, C.c_void_p)
 
@@ -113,6 +152,13 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm ships its own libamdhip64; it must be in the process BEFORE this library is
+    # loaded so that both resolve to ONE HIP runtime (two runtimes in one process: the second
+    # sees no device).  Importing torch does not initialise the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise ImportError(

@@ -420,3 +420,140 @@ class GasSW(GasLW):
 
     def set_band_albedo(self, albedo):
         check(self.lib.ecckd_gas_set_band_albedo(self.handle, float(albedo)))
+
+
+# ---------------------------------------------------------------------------------------
+# optimize_lut
+
+CONC = {"none": 0, "linear": 1, "lut": 2, "relative-linear": 3}
+
+
+class Optimizer:
+    """ecckd_opt_*: the cost function / gradient of solve_adept.cpp:240-292 and the L-BFGS driver
+    of :310-417 on the device.
+
+    model: dict(log_pressure[np], temperature[nt,np], temperature_planck[ntp], planck_function[ntp,ng],
+                iband_per_g[ng], gases=[dict(conc, active, molar_abs, vmr=None, reference_vmr=0,
+                                             min_molar_abs=None, max_molar_abs=None), ...])
+    scenes: list of dict(pressure_hl[ncol,nhl], temperature_hl, vmr_fl[ncol,ngas,nlay], flux_dn[ncol,nhl,nband],
+                         flux_up, gas_present=None, surf_emissivity=None, spectral_flux_dn_surf=None,
+                         spectral_flux_up_toa=None)
+    """
+
+    def __init__(self, ctx, model, scenes, **cfg):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        keep = []
+
+        def ptr(a, ctype=C.c_double):
+            if a is None:
+                return None
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(ctype))
+
+        gases = (_lib.OptGas * len(model["gases"]))()
+        for i, g in enumerate(model["gases"]):
+            ma = f64(g["molar_abs"])
+            gases[i].conc_dependence = CONC[g["conc"]]
+            gases[i].is_active = int(g.get("active", True))
+            gases[i].nconc = ma.shape[0] if g["conc"] == "lut" else 1
+            gases[i].vmr = ptr(f64(g["vmr"])) if g.get("vmr") is not None else None
+            gases[i].reference_vmr = float(g.get("reference_vmr", 0.0))
+            gases[i].molar_abs = ptr(ma)
+            gases[i].min_molar_abs = ptr(f64(g["min_molar_abs"])) if g.get("min_molar_abs") is not None else None
+            gases[i].max_molar_abs = ptr(f64(g["max_molar_abs"])) if g.get("max_molar_abs") is not None else None
+        temp = f64(model["temperature"])
+        pf = f64(model["planck_function"])
+        m = _lib.OptModel()
+        m.ng, m.nt, m.np = pf.shape[1], temp.shape[0], temp.shape[1]
+        m.log_pressure = ptr(f64(model["log_pressure"]))
+        m.temperature = ptr(temp)
+        m.ntp = pf.shape[0]
+        m.temperature_planck = ptr(f64(model["temperature_planck"]))
+        m.planck_function = ptr(pf)
+        m.iband_per_g = ptr(np.ascontiguousarray(model["iband_per_g"], dtype=np.int32), C.c_int)
+        m.ngas = len(model["gases"])
+        m.gases = gases
+        m.logarithmic_interpolation = int(model.get("logarithmic_interpolation", False))
+        sc = (_lib.OptScene * len(scenes))()
+        for i, s in enumerate(scenes):
+            p = f64(s["pressure_hl"])
+            fd = f64(s["flux_dn"])
+            sc[i].ncol, sc[i].nlay, sc[i].nband = p.shape[0], p.shape[1] - 1, fd.shape[2]
+            sc[i].pressure_hl = ptr(p)
+            sc[i].temperature_hl = ptr(f64(s["temperature_hl"]))
+            sc[i].vmr_fl = ptr(f64(s["vmr_fl"])) if s.get("vmr_fl") is not None else None
+            sc[i].gas_present = (ptr(np.ascontiguousarray(s["gas_present"], dtype=np.int32), C.c_int)
+                                 if s.get("gas_present") is not None else None)
+            sc[i].surf_emissivity = ptr(f64(s["surf_emissivity"])) if s.get("surf_emissivity") is not None else None
+            sc[i].flux_dn = ptr(fd)
+            sc[i].flux_up = ptr(f64(s["flux_up"]))
+            for k in ("spectral_flux_dn_surf", "spectral_flux_up_toa"):
+                setattr(sc[i], k, ptr(f64(s[k])) if s.get(k) is not None else None)
+        c = _lib.OptConfig()
+        defaults = dict(flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, spectral_boundary_weight=0.0,
+                        negative_od_penalty=1.0e4, pressure_weight_power=0.5, prior_error=1.0, min_prior_error=0.0,
+                        max_prior_error=0.0, prior_error_scaling=1.0, pressure_corr=0.8, temperature_corr=0.8,
+                        conc_corr=0.8, cap_relative_linear=0.8)
+        defaults.update(cfg)
+        for k, v in defaults.items():
+            setattr(c, k, float(v))
+        h = C.c_void_p()
+        check(self.lib.ecckd_opt_create(ctx.handle, C.byref(m), len(scenes), C.cast(sc, C.c_void_p), C.byref(c),
+                                        C.byref(h)))
+        self.handle = h
+        self.nx = int(self.lib.ecckd_opt_nx(h))
+        self.ng = m.ng
+        self.ncol = sum(int(s.ncol) for s in sc)
+        self.nlay = int(sc[0].nlay)
+        ctx._children.add(self)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            if self.ctx.handle:
+                self.lib.ecckd_opt_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def initial_state(self, bounds=False):
+        x = np.empty(self.nx)
+        if not bounds:
+            check(self.lib.ecckd_opt_initial_state(self.handle, _hptr(x), None, None))
+            return x
+        lo, hi = np.empty(self.nx), np.empty(self.nx)
+        check(self.lib.ecckd_opt_initial_state(self.handle, _hptr(x), _hptr(lo), _hptr(hi)))
+        return x, lo, hi
+
+    def cost_grad(self, x, want_grad=True):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        J = C.c_double()
+        g = np.empty(self.nx) if want_grad else None
+        check(self.lib.ecckd_opt_cost_grad(self.handle, _hptr(x), C.byref(J), _hptr(g) if want_grad else None))
+        return (J.value, g) if want_grad else J.value
+
+    def forward(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        od = np.empty((self.ncol, self.nlay, self.ng))
+        fl = np.empty((self.ncol, 2, self.nlay + 1, self.ng))
+        check(self.lib.ecckd_opt_forward(self.handle, _hptr(x), _hptr(od), _hptr(fl)))
+        return od, fl
+
+    def coefficients(self, x, gas, shape):
+        out = np.empty(shape)
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        check(self.lib.ecckd_opt_coefficients(self.handle, _hptr(xx), int(gas), _hptr(out)))
+        return out
+
+    def minimize(self, max_iterations=100, convergence_criterion=0.02, bounded=True):
+        x = np.empty(self.nx)
+        st, it = C.c_int(), C.c_int()
+        J, gn = C.c_double(), C.c_double()
+        check(self.lib.ecckd_opt_minimize(self.handle, int(max_iterations), float(convergence_criterion),
+                                          int(bounded), _hptr(x), C.byref(st), C.byref(it), C.byref(J), C.byref(gn)))
+        return dict(x=x, status=st.value, iterations=it.value, cost=J.value, gradient_norm=gn.value)

@@ -1,0 +1,1016 @@
+// optimize.hip - K8/K9: cost function and gradient of optimize_lut on gfx950, and the
+// L-BFGS driver that replaces solve_adept.
+//
+// Replaces reference src/ecckd/solve_adept.cpp:
+//   CkdOptimizable::calc_cost_function_gradient (:240-292)  -> ecckd_opt_cost_grad
+//   calc_cost_function_and_gradient (:72-211)               -> K8a forward + hand-written adjoint
+//   calc_total_optical_depth / CkdModel::calc_optical_depth
+//       (:24-69, ckd_model.cpp:925-1102)                    -> sparse LUT interpolation, host-built
+//   calc_cost_function_ckd_lw (calc_cost_function_lw.cpp:116-232)
+//   CkdModel::calc_background_cost_function (ckd_model.cpp:840-877) -> K9 Kronecker stencil
+//   solve_adept (:310-417, adept::Minimizer L-BFGS)         -> ecckd_opt_minimize
+//
+// Design.  The reference records ~1e6 (profile, layer, g) cells on an Adept tape and
+// reverses it, serially, every iteration.  Here:
+//  * The LUT interpolation weights depend only on (profile, layer, gas), not on g or on the
+//    state, so they are computed ONCE on the host into a fixed-width sparse table
+//    (cell -> up to 8 nodes per gas, coefficient = weight * interpolation weight).  The
+//    optical depth of a cell is then a gather of contiguous ng-long rows of the state
+//    (g is the fastest index of the LUT, ckd_model.cpp:153,216) - fully coalesced.
+//  * K8a: one block per profile, one thread per g point: gather, negative-OD penalty, LW
+//    two-stream forward sweep (fluxes kept in LDS), band sums, cost terms, then the
+//    HAND-DERIVED adjoint of the two sweeps -> dJ/d(optical depth) per cell.
+//  * K8b: the transpose of the gather as a second, host-built sparse table (node -> cells),
+//    so the gradient is accumulated in a fixed order with NO atomics (bitwise reproducible),
+//    fused with the chain rule x = ln k (:276-283).
+//  * K9: the prior.  The reference forms B = rho_t^|dt| * rho_p^|dp| (* rho_c^|dc|), inverts it
+//    densely with LAPACK and multiplies (ckd_model.cpp:706-713, :857).  B is a Kronecker
+//    product of AR(1) matrices, so B^-1 is the Kronecker product of tridiagonals: a 9- or
+//    27-point stencil per element.  Entries below 1e-6 are dropped as the reference does.
+// The dominant costs are launch latency and ~50 MB of traffic per iteration;
+// the metric is iterations per second.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr double kD = ECCKD_LW_DIFFUSIVITY;
+constexpr double MIN_X = -1.0e20;  // solve_adept.cpp:21
+constexpr int MAX_ENT = 8;
+
+struct GasInfo {
+  int conc = 0;       // 0 none, 1 linear, 2 lut, 3 relative-linear (ckd_model.cpp:1020-1086)
+  int active = 0;
+  int nconc = 1;
+  size_t nnode = 0;   // nconc*nt*np
+  size_t ix = 0;      // offset of this gas in the coefficient vector k
+  double reference_vmr = 0.0;
+  std::vector<double> vmr;
+  std::vector<double> sigma;  // background_error per g (ckd_model.cpp:672-683)
+};
+
+// per-dimension tridiagonal of an AR(1) inverse
+struct Tri { std::vector<double> lo, di, up; };
+
+Tri ar1_inverse(int n, double rho) {
+  Tri t;
+  t.lo.assign(n, 0.0); t.di.assign(n, 1.0); t.up.assign(n, 0.0);
+  if (n == 1) return t;
+  const double den = 1.0 - rho * rho;
+  for (int i = 0; i < n; ++i) {
+    t.di[i] = ((i == 0 || i == n - 1) ? 1.0 : 1.0 + rho * rho) / den;
+    if (i > 0) t.lo[i] = -rho / den;
+    if (i < n - 1) t.up[i] = -rho / den;
+  }
+  return t;
+}
+
+__device__ __forceinline__ double block_reduce_sum(double v, double* s_red) {
+  // fixed-order reduction over a block of up to 1024 threads; result valid in every thread
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwave = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < nwave; ++w) t += s_red[w];
+  return t;
+}
+
+struct ColConst {  // per-profile constant block layout in d_col: see host code
+  int dummy;
+};
+
+// K8a.  grid = ncolumns (all scenes), block = ng rounded up to 64.
+// LDS: tau[nlay][ng] | fdn[nhl][ng] | fup[nhl][ng] | Bdn[nhl][nband] | Bup[nhl][nband] |
+//      Gdn[nhl][nband] | Gup[nhl][nband] | red[16]
+__global__ void k_opt_forward_adjoint(
+    int nlay, int ng, int nband, int nent,
+    const double* __restrict__ k,            // [nk] coefficients of every gas
+    const int* __restrict__ ent_idx,         // [ncell][nent] start of an ng-long row of k, or -1
+    const double* __restrict__ ent_coef,     // [ncell][nent]
+    const int* __restrict__ band_of_g,       // [ng]
+    const double* __restrict__ planck_hl,    // [ncol][nhl][ng]
+    const double* __restrict__ surf_emis,    // [ncol][nband]
+    const double* __restrict__ conv,         // [ncol][nlay] heating-rate conversion
+    const double* __restrict__ layer_weight, // [ncol][nlay] normalised
+    const double* __restrict__ hr_true,      // [ncol][nlay][nband]
+    const double* __restrict__ fdn_true,     // [ncol][nhl][nband]
+    const double* __restrict__ fup_true,     // [ncol][nhl][nband]
+    const double* __restrict__ sfds,         // [ncol][ng] or NULL
+    const double* __restrict__ sfut,         // [ncol][ng] or NULL
+    double flux_weight, double flux_profile_weight, double broadband_weight,
+    double spectral_boundary_weight, double negative_od_penalty,
+    double* __restrict__ dtau,               // [ncell][ng] dJ/d(optical depth)
+    double* __restrict__ jcol,               // [ncol] cost of each profile (incl. penalty)
+    double* __restrict__ od_out,             // optional [ncell][ng] total optical depth (after clamp)
+    double* __restrict__ flux_out) {         // optional [ncol][2][nhl][ng]
+  extern __shared__ double smem[];
+  const int nhl = nlay + 1;
+  double* s_tau = smem;
+  double* s_fdn = s_tau + (size_t)nlay * ng;
+  double* s_fup = s_fdn + (size_t)nhl * ng;
+  double* s_bdn = s_fup + (size_t)nhl * ng;
+  double* s_bup = s_bdn + (size_t)nhl * nband;
+  double* s_gdn = s_bup + (size_t)nhl * nband;
+  double* s_gup = s_gdn + (size_t)nhl * nband;
+  double* s_red = s_gup + (size_t)nhl * nband;
+  const int col = blockIdx.x;
+  const int g = threadIdx.x;
+  const bool live = g < ng;
+  const double hr_weight = 3600.0 * 24.0;
+  const double* pl = planck_hl + (size_t)col * nhl * ng;
+  const size_t cell0 = (size_t)col * nlay;
+
+  // ---- optical depth: sparse gather (calc_total_optical_depth, solve_adept.cpp:24-69) and
+  //      the negative-OD penalty with clamp (:107-116)
+  double penalty = 0.0;
+  unsigned long long clamp0 = 0ull, clamp1 = 0ull;  // layers whose negative optical depth was clamped (nlay <= 128)
+  if (live) {
+    for (int l = 0; l < nlay; ++l) {
+      const int* ei = ent_idx + (cell0 + l) * nent;
+      const double* ec = ent_coef + (cell0 + l) * nent;
+      double tau = 0.0;
+      for (int e = 0; e < nent; ++e) {
+        const int idx = ei[e];
+        if (idx >= 0) tau += ec[e] * k[(size_t)idx + g];
+      }
+      if (tau < 0.0) {
+        // penalty = negative_od_penalty * tau^2, then the optical depth is SET to 0 (:110-113), so
+        // the only derivative that survives for this cell is the penalty's
+        penalty += tau * tau;
+        dtau[(cell0 + l) * ng + g] = 2.0 * negative_od_penalty * tau;
+        tau = 0.0;
+        if (l < 64) clamp0 |= 1ull << l; else clamp1 |= 1ull << (l - 64);
+      }
+      s_tau[l * ng + g] = tau;
+      if (od_out) od_out[(cell0 + l) * ng + g] = tau;
+    }
+  }
+  // ---- forward sweeps (radiative_transfer_lw.cpp:41-59) ----
+  if (live) {
+    double dn = 0.0;
+    s_fdn[g] = 0.0;
+    for (int l = 0; l < nlay; ++l) {
+      const double tau = s_tau[l * ng + g];
+      const double eps = 1.0 - exp(-kD * tau);
+      const double fac = (eps > 1.0e-5) ? 1.0 - eps * (1.0 / kD) / tau : 0.5 * eps;
+      dn = dn * (1.0 - eps) + pl[l * ng + g] * (eps - fac) + pl[(l + 1) * ng + g] * fac;
+      s_fdn[(l + 1) * ng + g] = dn;
+    }
+    const double es = surf_emis[(size_t)col * nband + band_of_g[g]];
+    double up = pl[nlay * ng + g] * es + (1.0 - es) * dn;  // surf_planck = planck_hl(end), optimize_lut.cpp:267
+    s_fup[nlay * ng + g] = up;
+    for (int l = nlay - 1; l >= 0; --l) {
+      const double tau = s_tau[l * ng + g];
+      const double eps = 1.0 - exp(-kD * tau);
+      const double fac = (eps > 1.0e-5) ? 1.0 - eps * (1.0 / kD) / tau : 0.5 * eps;
+      up = up * (1.0 - eps) + pl[(l + 1) * ng + g] * (eps - fac) + pl[l * ng + g] * fac;
+      s_fup[l * ng + g] = up;
+    }
+    if (flux_out) {
+      double* fo = flux_out + (size_t)col * 2 * nhl * ng;
+      for (int i = 0; i < nhl; ++i) {
+        fo[i * ng + g] = s_fdn[i * ng + g];
+        fo[(nhl + i) * ng + g] = s_fup[i * ng + g];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- band sums (calc_cost_function_lw.cpp:171-184) ----
+  for (int t = threadIdx.x; t < nhl * nband; t += blockDim.x) {
+    const int i = t / nband, b = t % nband;
+    double sd = 0.0, su = 0.0;
+    for (int gg = 0; gg < ng; ++gg) {
+      if (band_of_g[gg] == b) {
+        sd += s_fdn[i * ng + gg];
+        su += s_fup[i * ng + gg];
+      }
+    }
+    s_bdn[t] = sd;
+    s_bup[t] = su;
+  }
+  __syncthreads();
+  // ---- cost (:186-229) and its derivative w.r.t. the band fluxes ----
+  const double* cv = conv + (size_t)col * nlay;
+  const double* lw = layer_weight + (size_t)col * nlay;
+  const double* hrt = hr_true + (size_t)col * nlay * nband;
+  const double* fdt = fdn_true + (size_t)col * nhl * nband;
+  const double* fut = fup_true + (size_t)col * nhl * nband;
+  const double spec_scale = (1.0 - broadband_weight) / nband;
+  for (int t = threadIdx.x; t < nhl * nband; t += blockDim.x) { s_gdn[t] = 0.0; s_gup[t] = 0.0; }
+  __syncthreads();
+  double jpart = 0.0;
+  // heating-rate terms: thread per layer (the broadband residual needs all bands of a layer)
+  for (int l = threadIdx.x; l < nlay; l += blockDim.x) {
+    double rsum = 0.0;
+    for (int b = 0; b < nband; ++b) {
+      const double hrf = cv[l] * (s_bdn[(l + 1) * nband + b] - s_bdn[l * nband + b] -
+                                  s_bup[(l + 1) * nband + b] + s_bup[l * nband + b]);
+      rsum += hrf - hrt[l * nband + b];
+    }
+    for (int b = 0; b < nband; ++b) {
+      const double hrf = cv[l] * (s_bdn[(l + 1) * nband + b] - s_bdn[l * nband + b] -
+                                  s_bup[(l + 1) * nband + b] + s_bup[l * nband + b]);
+      const double r = hrf - hrt[l * nband + b];
+      jpart += spec_scale * hr_weight * hr_weight * lw[l] * r * r;
+      const double dhr = 2.0 * hr_weight * hr_weight * lw[l] * (spec_scale * r + broadband_weight * rsum);
+      // hr_l = conv_l * (dn[l+1] - dn[l] - up[l+1] + up[l]); layer l owns these four slots of
+      // the two half levels it touches -> accumulate per (l) into separate arrays to avoid races
+      atomicAdd(&s_gdn[(l + 1) * nband + b], dhr * cv[l]);
+      atomicAdd(&s_gdn[l * nband + b], -dhr * cv[l]);
+      atomicAdd(&s_gup[(l + 1) * nband + b], -dhr * cv[l]);
+      atomicAdd(&s_gup[l * nband + b], dhr * cv[l]);
+    }
+    jpart += broadband_weight * hr_weight * hr_weight * lw[l] * rsum * rsum;
+  }
+  __syncthreads();
+  // boundary-flux and flux-profile terms: thread per half level
+  for (int i = threadIdx.x; i < nhl; i += blockDim.x) {
+    const bool is_surf = (i == nlay), is_toa = (i == 0);
+    const bool interior = (i >= 1 && i <= nlay - 1);
+    double wd = 0.0, wu = 0.0;  // weights of the squared band residuals of dn / up at this level
+    if (is_surf) wd = flux_weight;
+    if (is_toa) wu = flux_weight;
+    if (interior && flux_profile_weight > 0.0) {
+      const double iw = flux_profile_weight * 0.5 * (lw[i - 1] + lw[i]);
+      wd = iw;
+      wu = iw;
+    }
+    if (wd != 0.0 || wu != 0.0) {
+      double sd = 0.0, su = 0.0;
+      for (int b = 0; b < nband; ++b) {
+        sd += s_bdn[i * nband + b] - fdt[i * nband + b];
+        su += s_bup[i * nband + b] - fut[i * nband + b];
+      }
+      for (int b = 0; b < nband; ++b) {
+        const double dd = s_bdn[i * nband + b] - fdt[i * nband + b];
+        const double du = s_bup[i * nband + b] - fut[i * nband + b];
+        jpart += spec_scale * (wd * dd * dd + wu * du * du);
+        s_gdn[i * nband + b] += 2.0 * wd * (spec_scale * dd + broadband_weight * sd);
+        s_gup[i * nband + b] += 2.0 * wu * (spec_scale * du + broadband_weight * su);
+      }
+      jpart += broadband_weight * (wd * sd * sd + wu * su * su);
+    }
+  }
+  __syncthreads();
+  // ---- adjoint of the two sweeps, per g ----
+  if (live) {
+    const int b = band_of_g[g];
+    const double es = surf_emis[(size_t)col * nband + b];
+    double g_dn_surf_extra = 0.0, g_up_toa_extra = 0.0;
+    if (spectral_boundary_weight > 0.0 && sfds && sfut) {
+      // :223-229 on the un-banded fluxes
+      const double a = s_fdn[nlay * ng + g] - sfds[(size_t)col * ng + g];
+      const double c = s_fup[g] - sfut[(size_t)col * ng + g];
+      jpart += spectral_boundary_weight * (a * a + c * c);
+      g_dn_surf_extra = 2.0 * spectral_boundary_weight * a;
+      g_up_toa_extra = 2.0 * spectral_boundary_weight * c;
+    }
+    // Adjoint of the up sweep.  It ran l = nlay-1 .. 0 (up_l from up_{l+1}), so the adjoint of
+    // up[l] is complete once levels 0..l-1 have been visited: u_bar[0] = seed[0],
+    // u_bar[l+1] = seed[l+1] + u_bar[l]*(1-eps_l).  u_bar[l] overwrites the forward up[l] in LDS
+    // (the forward values are re-generated from the surface in the combine loop below).
+    double up_bar = s_gup[b] + g_up_toa_extra;  // level 0
+    for (int l = 0; l < nlay; ++l) {
+      const double eps = 1.0 - exp(-kD * s_tau[l * ng + g]);
+      s_fup[l * ng + g] = up_bar;
+      up_bar = up_bar * (1.0 - eps) + s_gup[(l + 1) * nband + b];
+    }
+    // up_bar is now the adjoint of up[nlay]; through the surface condition it feeds dn[nlay].
+    double dn_bar = s_gdn[nlay * nband + b] + g_dn_surf_extra + up_bar * (1.0 - es);
+    // forward up[l+1] values: rebuild from the surface
+    double up_fwd_next = pl[nlay * ng + g] * es + (1.0 - es) * s_fdn[nlay * ng + g];  // up[nlay]
+    for (int l = nlay - 1; l >= 0; --l) {
+      const bool clamped = (l < 64) ? ((clamp0 >> l) & 1ull) : ((clamp1 >> (l - 64)) & 1ull);
+      const double tau = s_tau[l * ng + g];
+      const double ex = exp(-kD * tau);
+      const double eps = 1.0 - ex;
+      const bool thick = eps > 1.0e-5;
+      const double fac = thick ? 1.0 - eps * (1.0 / kD) / tau : 0.5 * eps;
+      const double b0 = pl[l * ng + g], b1 = pl[(l + 1) * ng + g];
+      const double ubar_l = s_fup[l * ng + g];  // adjoint of up[l]
+      const double dn_l = s_fdn[l * ng + g];
+      // partials of both sweeps for layer l
+      //   dn_{l+1} = dn_l*(1-eps) + B_l*(eps-fac) + B_{l+1}*fac
+      //   up_l     = up_{l+1}*(1-eps) + B_{l+1}*(eps-fac) + B_l*fac
+      const double t_bar = dn_bar * dn_l + ubar_l * up_fwd_next;
+      const double a_bar = dn_bar * b0 + ubar_l * b1;
+      const double f_bar = dn_bar * b1 + ubar_l * b0;
+      const double eps_bar = -t_bar + a_bar;
+      const double fac_bar = f_bar - a_bar;
+      // fac(eps, tau): thick: 1 - eps/(D tau); thin: eps/2   (radiative_transfer_lw.cpp:42-43)
+      const double dfac_deps = thick ? -(1.0 / kD) / tau : 0.5;
+      const double dfac_dtau = thick ? eps * (1.0 / kD) / (tau * tau) : 0.0;
+      const double tau_bar = (eps_bar + fac_bar * dfac_deps) * (kD * ex) + fac_bar * dfac_dtau;
+      if (!clamped) dtau[(cell0 + l) * ng + g] = tau_bar;
+      // propagate
+      const double up_l = up_fwd_next * (1.0 - eps) + b1 * (eps - fac) + b0 * fac;
+      up_fwd_next = up_l;
+      dn_bar = dn_bar * (1.0 - eps) + s_gdn[l * nband + b];
+    }
+  }
+  jpart += negative_od_penalty * penalty;
+  const double jtot = block_reduce_sum(jpart, s_red);
+  if (threadIdx.x == 0) jcol[col] = jtot;
+}
+
+// K8b + K9: gradient of the state.  One thread per (node, g) of the ACTIVE gases.
+//   grad_k = sum over the cells that reference this node of coef * dtau[cell][g]   (fixed order)
+//   grad_x = grad_k * k + B^-1 (x - x_prior) / sigma_g^2                            (:273-283)
+__global__ void __launch_bounds__(256)
+k_opt_gradient(size_t nx, int ng, const double* __restrict__ x, const double* __restrict__ x_prior,
+               const double* __restrict__ k, const int* __restrict__ ref_ptr /*[nnode+1]*/,
+               const int* __restrict__ ref_cell, const double* __restrict__ ref_coef,
+               const double* __restrict__ dtau,
+               // prior stencil: per node the three local indices and per gas/dimension tridiagonals
+               const int* __restrict__ node_gas, const int* __restrict__ node_ic,
+               const int* __restrict__ node_it, const int* __restrict__ node_ip,
+               const int* __restrict__ gas_dims /*[ngas][4]: nconc, nt, np, node0*/,
+               const double* __restrict__ tri /* per gas: c(3*nconc) | t(3*nt) | p(3*np) */,
+               const int* __restrict__ tri_off /*[ngas]*/, const double* __restrict__ inv_sigma2 /*[ngas][ng]*/,
+               int have_prior, double* __restrict__ grad, double* __restrict__ jb_part /*[nblocks]*/) {
+  __shared__ double s4[4];
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double jb = 0.0;
+  if (e < nx) {
+    const size_t node = e / ng;
+    const int g = (int)(e % ng);
+    double gk = 0.0;
+    for (int r = ref_ptr[node]; r < ref_ptr[node + 1]; ++r) gk += ref_coef[r] * dtau[(size_t)ref_cell[r] * ng + g];
+    const double xv = x[e];
+    double gx = 0.0;
+    if (xv > MIN_X) {
+      gx = gk * k[e];
+      if (have_prior) {
+        const int gas = node_gas[node];
+        const int nconc = gas_dims[gas * 4 + 0], nt = gas_dims[gas * 4 + 1], np = gas_dims[gas * 4 + 2];
+        const size_t node0 = (size_t)gas_dims[gas * 4 + 3];
+        const double* tc = tri + tri_off[gas];
+        const double* tt = tc + 3 * nconc;
+        const double* tp = tt + 3 * nt;
+        const int ic = node_ic[node], it = node_it[node], ip = node_ip[node];
+        double acc = 0.0;
+        for (int dc = -1; dc <= 1; ++dc) {
+          const int jc = ic + dc;
+          if (jc < 0 || jc >= nconc) continue;
+          const double wc = tc[(dc + 1) * nconc + ic];
+          if (wc == 0.0) continue;
+          for (int dt = -1; dt <= 1; ++dt) {
+            const int jt = it + dt;
+            if (jt < 0 || jt >= nt) continue;
+            const double wt = tt[(dt + 1) * nt + it];
+            if (wt == 0.0) continue;
+            for (int dp = -1; dp <= 1; ++dp) {
+              const int jp = ip + dp;
+              if (jp < 0 || jp >= np) continue;
+              const double w = wc * wt * tp[(dp + 1) * np + ip];
+              // MIN_ERROR_COVARIANCE, ckd_model.cpp:650,713
+              if (fabs(w) < 1.0e-6) continue;
+              const size_t nb = (node0 + ((size_t)jc * nt + jt) * np + jp) * ng + g;
+              acc += w * (x[nb] - x_prior[nb]);
+            }
+          }
+        }
+        const double gb = acc * inv_sigma2[(size_t)gas * ng + g];
+        jb = 0.5 * (xv - x_prior[e]) * gb;
+        gx += gb;
+      }
+      if (fabs(gx) < 1.0e-80) gx = 0.0;  // :286
+    }
+    grad[e] = gx;
+  }
+  // deterministic block partial of the background cost
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) jb += __shfl_down(jb, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s4[wave] = jb;
+  __syncthreads();
+  if (threadIdx.x == 0) jb_part[blockIdx.x] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
+}
+
+// k = exp(x) for the active part (:242-249)
+__global__ void __launch_bounds__(256)
+k_opt_exp(size_t nx, const double* __restrict__ x, double* __restrict__ k) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nx) k[e] = (x[e] > MIN_X) ? exp(x[e]) : 0.0;
+}
+
+}  // namespace
+
+struct ecckd_opt {
+  ecckd_ctx* ctx = nullptr;
+  int ng = 0, nt = 0, np = 0, nband = 0, ngas = 0, nlay = 0, nent = 0;
+  size_t nx = 0, nk = 0, ncol = 0, ncell = 0, nnode_active = 0;
+  std::vector<GasInfo> gases;       // in k order: active gases first
+  std::vector<int> user_to_k;       // user gas index -> position in `gases`
+  ecckd_opt_config cfg{};
+  bool have_prior = false;
+  bool have_boundary = false;
+  // host copies
+  std::vector<double> h_k0, h_kmin, h_kmax;
+  // device
+  double *d_k = nullptr, *d_x = nullptr, *d_xprior = nullptr, *d_grad = nullptr, *d_dtau = nullptr;
+  double *d_jcol = nullptr, *d_jb = nullptr;
+  int* d_ent_idx = nullptr; double* d_ent_coef = nullptr; int* d_band = nullptr;
+  double *d_planck = nullptr, *d_semis = nullptr, *d_conv = nullptr, *d_lw = nullptr;
+  double *d_hr = nullptr, *d_fdn = nullptr, *d_fup = nullptr, *d_sfds = nullptr, *d_sfut = nullptr;
+  int *d_ref_ptr = nullptr, *d_ref_cell = nullptr; double* d_ref_coef = nullptr;
+  int *d_node_gas = nullptr, *d_node_ic = nullptr, *d_node_it = nullptr, *d_node_ip = nullptr, *d_gas_dims = nullptr;
+  double* d_tri = nullptr; int* d_tri_off = nullptr; double* d_inv_sigma2 = nullptr;
+  double* d_od_out = nullptr; double* d_flux_out = nullptr;
+  unsigned grad_blocks = 0;
+  std::vector<double> h_jcol, h_jb;
+  // timing
+  long long n_eval = 0;
+};
+
+namespace {
+
+template <typename T>
+int upload(ecckd_ctx* ctx, T** d, const std::vector<T>& h) {
+  ECCKD_HIP_CHECK(hipMalloc((void**)d, std::max<size_t>(h.size(), 1) * sizeof(T)));
+  if (!h.empty())
+    ECCKD_HIP_CHECK(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
+}
+
+void opt_free(ecckd_opt* o) {
+  if (!o) return;
+  if (o->ctx) (void)hipStreamSynchronize(o->ctx->stream);
+  void* ptrs[] = {o->d_k, o->d_x, o->d_xprior, o->d_grad, o->d_dtau, o->d_jcol, o->d_jb, o->d_ent_idx, o->d_ent_coef,
+                  o->d_band, o->d_planck, o->d_semis, o->d_conv, o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds,
+                  o->d_sfut, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_node_gas, o->d_node_ic, o->d_node_it,
+                  o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2, o->d_od_out, o->d_flux_out};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete o;
+}
+
+// CkdModel::calc_planck_function, ckd_model.cpp:1121-1145
+void planck_lut(int ntp, const double* tpl, const double* pf, int ng, double t, double* out) {
+  const double d_t = tpl[1] - tpl[0], t0 = tpl[0];
+  const double tindex0 = (t - t0) / d_t;
+  if (tindex0 >= 0) {
+    int it0 = std::min((int)tindex0, ntp - 2);
+    const double w1 = tindex0 - it0, w0 = 1.0 - w1;
+    for (int g = 0; g < ng; ++g) out[g] = w0 * pf[(size_t)it0 * ng + g] + w1 * pf[(size_t)(it0 + 1) * ng + g];
+  } else {
+    for (int g = 0; g < ng; ++g) out[g] = (t / t0) * pf[g];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const ecckd_opt_scene* scenes,
+                     const ecckd_opt_config* cfg, ecckd_opt** out) {
+  ECCKD_REQUIRE(ctx && m && scenes && cfg && out && nscene > 0, "ecckd_opt_create: NULL/empty argument");
+  *out = nullptr;
+  ECCKD_REQUIRE(m->ng > 0 && m->ng <= 1024 && m->nt >= 2 && m->np >= 2 && m->ngas > 0 && m->gases &&
+                    m->log_pressure && m->temperature && m->iband_per_g,
+                "ecckd_opt_create: bad model dimensions (ng=%d nt=%d np=%d ngas=%d)", m->ng, m->nt, m->np, m->ngas);
+  ECCKD_REQUIRE(m->ntp >= 2 && m->temperature_planck && m->planck_function, "ecckd_opt_create: Planck look-up table missing");
+  ECCKD_REQUIRE(!m->logarithmic_interpolation,
+                "ecckd_opt_create: logarithmic LUT interpolation is not supported (ckd_model.h:359 default is linear)");
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const int ng = m->ng, nt = m->nt, np = m->np;
+  ecckd_opt* o = new ecckd_opt();
+  o->ctx = ctx;
+  o->ng = ng; o->nt = nt; o->np = np; o->ngas = m->ngas;
+  o->cfg = *cfg;
+  int nband = 0;
+  for (int g = 0; g < ng; ++g) nband = std::max(nband, m->iband_per_g[g] + 1);
+  o->nband = nband;
+
+  // ---- coefficient vector: active gases first (they are the state x), then fixed gases ----
+  std::vector<int> order;
+  for (int a = 1; a >= 0; --a)
+    for (int i = 0; i < m->ngas; ++i)
+      if ((m->gases[i].is_active != 0) == (a == 1)) order.push_back(i);
+  o->user_to_k.assign(m->ngas, -1);
+  size_t off = 0;
+  for (size_t pos = 0; pos < order.size(); ++pos) {
+    const ecckd_opt_gas& ug = m->gases[order[pos]];
+    GasInfo gi;
+    gi.conc = ug.conc_dependence;
+    gi.active = ug.is_active != 0;
+    gi.nconc = (ug.conc_dependence == 2) ? ug.nconc : 1;
+    if (!(ug.conc_dependence >= 0 && ug.conc_dependence <= 3) || !ug.molar_abs ||
+        (ug.conc_dependence == 2 && (ug.nconc < 2 || !ug.vmr))) {
+      opt_free(o);
+      return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_opt_create: gas %d is ill-defined", order[pos]);
+    }
+    gi.nnode = (size_t)gi.nconc * nt * np;
+    gi.ix = off;
+    gi.reference_vmr = ug.reference_vmr;
+    if (ug.conc_dependence == 2) gi.vmr.assign(ug.vmr, ug.vmr + ug.nconc);
+    off += gi.nnode * ng;
+    if (gi.active) { o->nx = off; o->nnode_active += gi.nnode; }
+    o->user_to_k[order[pos]] = (int)pos;
+    o->gases.push_back(gi);
+  }
+  o->nk = off;
+  ECCKD_REQUIRE(o->nx > 0, "ecckd_opt_create: no active gas to optimise");
+  ECCKD_REQUIRE(o->nk < (size_t)0x7fffffff, "ecckd_opt_create: coefficient vector too long for int32 indexing");
+  o->h_k0.assign(o->nk, 0.0);
+  o->h_kmin.assign(o->nx, 0.0);
+  o->h_kmax.assign(o->nx, 0.0);
+  bool have_minmax = true;
+  for (size_t pos = 0; pos < order.size(); ++pos) {
+    const ecckd_opt_gas& ug = m->gases[order[pos]];
+    const GasInfo& gi = o->gases[pos];
+    std::memcpy(&o->h_k0[gi.ix], ug.molar_abs, gi.nnode * ng * sizeof(double));
+    if (gi.active) {
+      if (ug.min_molar_abs && ug.max_molar_abs) {
+        std::memcpy(&o->h_kmin[gi.ix], ug.min_molar_abs, gi.nnode * ng * sizeof(double));
+        std::memcpy(&o->h_kmax[gi.ix], ug.max_molar_abs, gi.nnode * ng * sizeof(double));
+      } else {
+        have_minmax = false;
+      }
+    }
+  }
+  if (!have_minmax) { o->h_kmin.clear(); o->h_kmax.clear(); }
+
+  // cap_relative_linear_coeffts(0.8), optimize_lut.cpp:185, ckd_model.cpp:883-917
+  {
+    int ibg = -1;
+    for (size_t pos = 0; pos < o->gases.size(); ++pos)
+      if (o->gases[pos].conc == 0) ibg = (int)pos;  // the LAST gas with NONE, as the reference loop leaves it
+    if (ibg >= 0 && cfg->cap_relative_linear > 0.0) {
+      const GasInfo& bg = o->gases[ibg];
+      for (GasInfo& gi : o->gases) {
+        if (gi.active && gi.conc == 3 && gi.nnode == bg.nnode) {
+          for (size_t e = 0; e < gi.nnode * ng; ++e) {
+            const double cap = o->h_k0[bg.ix + e] / (gi.reference_vmr * cfg->cap_relative_linear);
+            if (o->h_k0[gi.ix + e] * (gi.reference_vmr * cfg->cap_relative_linear) > o->h_k0[bg.ix + e])
+              o->h_k0[gi.ix + e] = std::min(o->h_k0[gi.ix + e], cap);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- prior (create_error_covariances, ckd_model.cpp:646-832) ----
+  o->have_prior = true;  // the reference always adds calc_background_cost_function (:273)
+  std::vector<double> tri;
+  std::vector<int> tri_off(o->gases.size(), 0), gas_dims(o->gases.size() * 4, 0);
+  std::vector<double> inv_sigma2(o->gases.size() * ng, 0.0);
+  std::vector<int> node_gas, node_ic, node_it, node_ip;
+  {
+    size_t node0 = 0;
+    for (size_t pos = 0; pos < o->gases.size(); ++pos) {
+      GasInfo& gi = o->gases[pos];
+      gas_dims[pos * 4 + 0] = gi.nconc; gas_dims[pos * 4 + 1] = nt; gas_dims[pos * 4 + 2] = np;
+      gas_dims[pos * 4 + 3] = (int)node0;
+      if (!gi.active) continue;
+      tri_off[pos] = (int)tri.size();
+      const Tri tc = ar1_inverse(gi.nconc, cfg->conc_corr), tt = ar1_inverse(nt, cfg->temperature_corr),
+                tp = ar1_inverse(np, cfg->pressure_corr);
+      for (const Tri* t : {&tc, &tt, &tp}) {
+        tri.insert(tri.end(), t->lo.begin(), t->lo.end());
+        tri.insert(tri.end(), t->di.begin(), t->di.end());
+        tri.insert(tri.end(), t->up.begin(), t->up.end());
+      }
+      // background_error per g: fixed prior_error, or estimated from min/max (:679-745)
+      gi.sigma.assign(ng, cfg->prior_error > 0.0 ? cfg->prior_error : 1.0);
+      if (cfg->prior_error <= 0.0 && have_minmax) {
+        for (int g = 0; g < ng; ++g) {
+          double local_sum = 0.0;
+          int local_count = 0;
+          for (size_t nd = 0; nd < gi.nnode; ++nd) {
+            const size_t e = gi.ix + nd * ng + g;
+            if (o->h_k0[e] > 0.0) {
+              if (o->h_kmin[e] > 0.0) local_sum += 0.25 * std::log(o->h_kmax[e] / o->h_kmin[e]);
+              else local_sum += 0.5 * std::log(o->h_kmax[e] / o->h_k0[e]);
+              ++local_count;
+            }
+          }
+          if (local_count > 0) gi.sigma[g] = cfg->prior_error_scaling * local_sum / local_count;
+        }
+        if (cfg->min_prior_error > 0.0) for (double& sg : gi.sigma) sg = std::max(cfg->min_prior_error, sg);
+        if (cfg->max_prior_error > 0.0) for (double& sg : gi.sigma) sg = std::min(sg, cfg->max_prior_error);
+      }
+      for (int g = 0; g < ng; ++g) inv_sigma2[pos * ng + g] = 1.0 / (gi.sigma[g] * gi.sigma[g]);
+      for (int ic = 0; ic < gi.nconc; ++ic)
+        for (int it = 0; it < nt; ++it)
+          for (int ip = 0; ip < np; ++ip) {
+            node_gas.push_back((int)pos); node_ic.push_back(ic); node_it.push_back(it); node_ip.push_back(ip);
+          }
+      node0 += gi.nnode;
+    }
+  }
+
+  // ---- training scenes -> flat per-profile arrays and the sparse interpolation table ----
+  const int nlay = scenes[0].nlay;
+  if (nlay < 1 || nlay > 128) {
+    opt_free(o);
+    return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_opt_create: nlay = %d outside the supported range 1..128", nlay);
+  }
+  o->nlay = nlay;
+  const int nhl = nlay + 1;
+  size_t ncol = 0;
+  for (int s = 0; s < nscene; ++s) {
+    if (scenes[s].nlay != nlay || scenes[s].ncol <= 0 || !scenes[s].pressure_hl || !scenes[s].temperature_hl ||
+        !scenes[s].flux_dn || !scenes[s].flux_up || scenes[s].nband != nband) {
+      opt_free(o);
+      return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_opt_create: scene %d is inconsistent (nlay/nband/arrays)", s);
+    }
+    ncol += scenes[s].ncol;
+  }
+  o->ncol = ncol;
+  o->ncell = ncol * nlay;
+  int nent = 0;
+  for (const GasInfo& gi : o->gases) nent += (gi.conc == 2) ? 8 : 4;
+  o->nent = nent;
+  std::vector<int> ent_idx(o->ncell * nent, -1);
+  std::vector<double> ent_coef(o->ncell * nent, 0.0);
+  std::vector<double> planck(ncol * nhl * ng), semis(ncol * nband, 1.0), conv(ncol * nlay), lwv(ncol * nlay);
+  std::vector<double> hr(ncol * nlay * nband), fdn(ncol * nhl * nband), fup(ncol * nhl * nband);
+  std::vector<double> sfds, sfut;
+  bool any_boundary = false;
+  for (int s = 0; s < nscene; ++s) any_boundary = any_boundary || (scenes[s].spectral_flux_dn_surf && scenes[s].spectral_flux_up_toa);
+  o->have_boundary = any_boundary;
+  if (any_boundary) { sfds.assign(ncol * ng, 0.0); sfut.assign(ncol * ng, 0.0); }
+
+  const double log_p_0 = m->log_pressure[0];
+  const double d_log_p = m->log_pressure[1] - m->log_pressure[0];
+  const double d_t = m->temperature[1 * np + 0] - m->temperature[0];
+  const double global_weight = 1.0 / (ECCKD_ACCEL_GRAVITY * 0.001 * 28.970);
+  size_t col0 = 0;
+  for (int s = 0; s < nscene; ++s) {
+    const ecckd_opt_scene& sc = scenes[s];
+    for (int c = 0; c < sc.ncol; ++c) {
+      const size_t col = col0 + c;
+      const double* p = sc.pressure_hl + (size_t)c * nhl;
+      const double* T = sc.temperature_hl + (size_t)c * nhl;
+      for (int i = 0; i < nhl; ++i) planck_lut(m->ntp, m->temperature_planck, m->planck_function, ng, T[i], &planck[(col * nhl + i) * ng]);
+      if (sc.surf_emissivity) std::memcpy(&semis[col * nband], sc.surf_emissivity + (size_t)c * nband, nband * sizeof(double));
+      // layer weights, solve_adept.cpp:131-143
+      double wsum = 0.0;
+      for (int l = 0; l < nlay; ++l) {
+        double w;
+        if (cfg->pressure_weight_power == 0.5) w = std::sqrt(p[l + 1]) - std::sqrt(p[l]);
+        else if (cfg->pressure_weight_power == 1.0) w = p[l + 1] - p[l];
+        else w = std::pow(p[l + 1], cfg->pressure_weight_power) - std::pow(p[l], cfg->pressure_weight_power);
+        lwv[col * nlay + l] = w;
+        wsum += w;
+        conv[col * nlay + l] = -(ECCKD_ACCEL_GRAVITY / ECCKD_SPECIFIC_HEAT_AIR) / (p[l + 1] - p[l]);
+      }
+      for (int l = 0; l < nlay; ++l) lwv[col * nlay + l] /= wsum;
+      // truth: band fluxes and their heating rate (lbl_fluxes.cpp:380-388, heating_rate.h:30-50)
+      std::memcpy(&fdn[col * nhl * nband], sc.flux_dn + (size_t)c * nhl * nband, (size_t)nhl * nband * sizeof(double));
+      std::memcpy(&fup[col * nhl * nband], sc.flux_up + (size_t)c * nhl * nband, (size_t)nhl * nband * sizeof(double));
+      for (int l = 0; l < nlay; ++l)
+        for (int b = 0; b < nband; ++b) {
+          const double* d = &fdn[col * nhl * nband];
+          const double* u = &fup[col * nhl * nband];
+          hr[(col * nlay + l) * nband + b] =
+              conv[col * nlay + l] * (d[(l + 1) * nband + b] - d[l * nband + b] - u[(l + 1) * nband + b] + u[l * nband + b]);
+        }
+      if (any_boundary && sc.spectral_flux_dn_surf && sc.spectral_flux_up_toa) {
+        std::memcpy(&sfds[col * ng], sc.spectral_flux_dn_surf + (size_t)c * ng, ng * sizeof(double));
+        std::memcpy(&sfut[col * ng], sc.spectral_flux_up_toa + (size_t)c * ng, ng * sizeof(double));
+      }
+      // interpolation entries, ckd_model.cpp:960-1086
+      for (int l = 0; l < nlay; ++l) {
+        const size_t cell = col * nlay + l;
+        // full-level temperature, solve_adept.cpp:38-41
+        const double t_fl = (T[l] * p[l] + T[l + 1] * p[l + 1]) / (p[l] + p[l + 1]);
+        const double log_pressure_fl = std::log(0.5 * (p[l + 1] + p[l]));
+        double pindex0 = (log_pressure_fl - log_p_0) / d_log_p;
+        pindex0 = std::fmax(0.0, std::fmin(pindex0, np - 1.0001));
+        const int ip0 = (int)pindex0;
+        const double pw1 = pindex0 - ip0, pw0 = 1.0 - pw1;
+        const double t_0 = pw0 * m->temperature[ip0] + pw1 * m->temperature[ip0 + 1];
+        double tindex0 = (t_fl - t_0) / d_t;
+        tindex0 = std::fmax(0.0, std::fmin(tindex0, nt - 1.0001));
+        const int it0 = (int)tindex0;
+        const double tw1 = tindex0 - it0, tw0 = 1.0 - tw1;
+        const double simple_weight = global_weight * (p[l + 1] - p[l]);
+        int e = 0;
+        for (size_t pos = 0; pos < o->gases.size(); ++pos) {
+          const GasInfo& gi = o->gases[pos];
+          const int ugas = order[pos];
+          const int width = (gi.conc == 2) ? 8 : 4;
+          const bool present = sc.gas_present ? sc.gas_present[ugas] != 0 : true;
+          // ckd_model.cpp:995-1004, :1066-1073 and solve_adept.cpp:47-67: a gas without a
+          // concentration dependence always contributes with the dry-air weight; the others need
+          // their mole fraction from the training file and are skipped when it is absent
+          double weight = 0.0, vm = 0.0;
+          bool use = true;
+          if (gi.conc == 0) {
+            weight = simple_weight;
+          } else if (present && sc.vmr_fl) {
+            vm = sc.vmr_fl[((size_t)c * m->ngas + ugas) * nlay + l];
+            weight = (gi.conc == 3) ? simple_weight * (vm - gi.reference_vmr) : simple_weight * vm;
+          } else {
+            use = false;
+          }
+          if (use) {
+            if (gi.conc == 2) {
+              const double log_conc = std::log(vm);
+              const double d_log_c = std::log(gi.vmr[1] / gi.vmr[0]);
+              double cindex0 = (log_conc - std::log(gi.vmr[0])) / d_log_c;
+              cindex0 = std::fmax(0.0, std::fmin(cindex0, gi.nconc - 1.0001));
+              const int ic0 = (int)cindex0;
+              const double cw1 = cindex0 - ic0, cw0 = 1.0 - cw1;
+              int q = 0;
+              for (int dc = 0; dc < 2; ++dc)
+                for (int dt = 0; dt < 2; ++dt)
+                  for (int dp = 0; dp < 2; ++dp) {
+                    const size_t node = ((size_t)(ic0 + dc) * nt + (it0 + dt)) * np + (ip0 + dp);
+                    ent_idx[cell * nent + e + q] = (int)(gi.ix + node * ng);
+                    ent_coef[cell * nent + e + q] = weight * (dc ? cw1 : cw0) * (dt ? tw1 : tw0) * (dp ? pw1 : pw0);
+                    ++q;
+                  }
+            } else {
+              int q = 0;
+              for (int dt = 0; dt < 2; ++dt)
+                for (int dp = 0; dp < 2; ++dp) {
+                  const size_t node = (size_t)(it0 + dt) * np + (ip0 + dp);
+                  ent_idx[cell * nent + e + q] = (int)(gi.ix + node * ng);
+                  ent_coef[cell * nent + e + q] = weight * (dt ? tw1 : tw0) * (dp ? pw1 : pw0);
+                  ++q;
+                }
+            }
+          }
+          e += width;
+        }
+      }
+    }
+    col0 += sc.ncol;
+  }
+
+  // ---- transpose of the gather for the active nodes: node -> (cell, coef), in cell order ----
+  std::vector<int> ref_ptr(o->nnode_active + 1, 0);
+  for (size_t cell = 0; cell < o->ncell; ++cell)
+    for (int e = 0; e < nent; ++e) {
+      const int idx = ent_idx[cell * nent + e];
+      if (idx >= 0 && (size_t)idx < o->nx && ent_coef[cell * nent + e] != 0.0) ++ref_ptr[(size_t)idx / ng + 1];
+    }
+  for (size_t i = 0; i < o->nnode_active; ++i) ref_ptr[i + 1] += ref_ptr[i];
+  std::vector<int> ref_cell(ref_ptr.back());
+  std::vector<double> ref_coef(ref_ptr.back());
+  {
+    std::vector<int> fill(ref_ptr.begin(), ref_ptr.end() - 1);
+    for (size_t cell = 0; cell < o->ncell; ++cell)
+      for (int e = 0; e < nent; ++e) {
+        const int idx = ent_idx[cell * nent + e];
+        if (idx >= 0 && (size_t)idx < o->nx && ent_coef[cell * nent + e] != 0.0) {
+          const int slot = fill[(size_t)idx / ng]++;
+          ref_cell[slot] = (int)cell;
+          ref_coef[slot] = ent_coef[cell * nent + e];
+        }
+      }
+  }
+
+  std::vector<int> band(m->iband_per_g, m->iband_per_g + ng);
+  int rc = ECCKD_OK;
+#define UP(dst, vec) do { rc = upload(ctx, &o->dst, vec); if (rc) { opt_free(o); return rc; } } while (0)
+  UP(d_k, o->h_k0);
+  UP(d_ent_idx, ent_idx); UP(d_ent_coef, ent_coef); UP(d_band, band);
+  UP(d_planck, planck); UP(d_semis, semis); UP(d_conv, conv); UP(d_lw, lwv);
+  UP(d_hr, hr); UP(d_fdn, fdn); UP(d_fup, fup);
+  if (any_boundary) { UP(d_sfds, sfds); UP(d_sfut, sfut); }
+  UP(d_ref_ptr, ref_ptr); UP(d_ref_cell, ref_cell); UP(d_ref_coef, ref_coef);
+  UP(d_node_gas, node_gas); UP(d_node_ic, node_ic); UP(d_node_it, node_it); UP(d_node_ip, node_ip);
+  UP(d_gas_dims, gas_dims); UP(d_tri, tri); UP(d_tri_off, tri_off); UP(d_inv_sigma2, inv_sigma2);
+#undef UP
+  o->grad_blocks = (unsigned)((o->nx + 255) / 256);
+  auto dalloc = [&](double** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(double)); };
+  if (dalloc(&o->d_x, o->nx) != hipSuccess || dalloc(&o->d_xprior, o->nx) != hipSuccess ||
+      dalloc(&o->d_grad, o->nx) != hipSuccess || dalloc(&o->d_dtau, o->ncell * ng) != hipSuccess ||
+      dalloc(&o->d_jcol, ncol) != hipSuccess || dalloc(&o->d_jb, o->grad_blocks) != hipSuccess) {
+    opt_free(o);
+    return ecckd::fail(ECCKD_OUT_OF_MEMORY, "ecckd_opt_create: device allocation failed");
+  }
+  o->h_jcol.resize(ncol);
+  o->h_jb.resize(o->grad_blocks);
+  // x_prior = ln k0 (MIN_X where k0 <= 0), solve_adept.cpp:335-341
+  std::vector<double> xp(o->nx);
+  for (size_t e = 0; e < o->nx; ++e) xp[e] = o->h_k0[e] > 0.0 ? std::log(o->h_k0[e]) : MIN_X;
+  ECCKD_HIP_CHECK(hipMemcpyAsync(o->d_xprior, xp.data(), o->nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  *out = o;
+  return ECCKD_OK;
+}
+
+int ecckd_opt_destroy(ecckd_opt* o) {
+  opt_free(o);
+  return ECCKD_OK;
+}
+
+size_t ecckd_opt_nx(ecckd_opt* o) { return o ? o->nx : 0; }
+
+// Initial state and log-space bounds, solve_adept.cpp:335-353.  h_x_min/h_x_max may be NULL;
+// unbounded elements get -/+ infinity.  Returns the gas order of the state in h_gas_order
+// (user gas indices of the active gases, in state order) if not NULL.
+int ecckd_opt_initial_state(ecckd_opt* o, double* h_x, double* h_x_min, double* h_x_max) {
+  ECCKD_REQUIRE(o && h_x, "ecckd_opt_initial_state: NULL argument");
+  for (size_t e = 0; e < o->nx; ++e) h_x[e] = o->h_k0[e] > 0.0 ? std::log(o->h_k0[e]) : MIN_X;
+  if (h_x_min && h_x_max) {
+    for (size_t e = 0; e < o->nx; ++e) {
+      h_x_min[e] = -INFINITY;
+      h_x_max[e] = INFINITY;
+      if (!o->h_kmin.empty()) {
+        if (o->h_kmin[e] > 0.0) h_x_min[e] = std::log(o->h_kmin[e]);
+        if (o->h_kmax[e] > 0.0) h_x_max[e] = std::log(o->h_kmax[e]);
+        if (o->h_kmin[e] == 0.0 && o->h_k0[e] > 0.0 && o->h_kmax[e] > 0.0)
+          h_x_min[e] = std::min(3.0 * h_x[e] - 2.0 * h_x_max[e], h_x_max[e] - 1.0);
+      }
+    }
+  }
+  return ECCKD_OK;
+}
+
+// CkdOptimizable::calc_cost_function_gradient (solve_adept.cpp:240-292).
+int ecckd_opt_cost_grad(ecckd_opt* o, const double* h_x, double* J, double* h_grad) {
+  ECCKD_REQUIRE(o && h_x && J, "ecckd_opt_cost_grad: NULL argument");
+  ecckd_ctx* ctx = o->ctx;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(o->d_x, h_x, o->nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, o->d_x, o->d_k);
+  const int nlay = o->nlay, nhl = nlay + 1, ng = o->ng, nband = o->nband;
+  const int threads = (ng + 63) / 64 * 64;
+  const size_t lds = ((size_t)nlay * ng + 2 * (size_t)nhl * ng + 4 * (size_t)nhl * nband + 16) * sizeof(double);
+  ECCKD_REQUIRE(lds <= 160 * 1024, "ecckd_opt_cost_grad: nlay*ng too large for the per-profile LDS tile (%zu B)", lds);
+  ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_opt_forward_adjoint),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL(k_opt_forward_adjoint, dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream, nlay, ng, nband,
+                     o->nent, o->d_k, o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_planck, o->d_semis, o->d_conv,
+                     o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds, o->d_sfut, o->cfg.flux_weight,
+                     o->cfg.flux_profile_weight, o->cfg.broadband_weight, o->cfg.spectral_boundary_weight,
+                     o->cfg.negative_od_penalty, o->d_dtau, o->d_jcol, o->d_od_out, o->d_flux_out);
+  hipLaunchKernelGGL(k_opt_gradient, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, ng, o->d_x, o->d_xprior,
+                     o->d_k, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_dtau, o->d_node_gas, o->d_node_ic,
+                     o->d_node_it, o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2,
+                     o->have_prior ? 1 : 0, o->d_grad, o->d_jb);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jcol.data(), o->d_jcol, o->ncol * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jb.data(), o->d_jb, o->grad_blocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (h_grad) ECCKD_HIP_CHECK(hipMemcpyAsync(h_grad, o->d_grad, o->nx * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  double j = 0.0;
+  for (double v : o->h_jcol) j += v;  // scene/profile order, as the reference accumulates (:157)
+  double jb = 0.0;
+  for (double v : o->h_jb) jb += v;
+  *J = j + jb;
+  o->n_eval++;
+  return ECCKD_OK;
+}
+
+// Forward products for checking/diagnostics: total optical depth [ncol][nlay][ng] (after the
+// negative clamp) and the CKD fluxes [ncol][2][nlay+1][ng] (LblFluxes::calc_ckd_fluxes,
+// lbl_fluxes.cpp:443-471) at state h_x.
+int ecckd_opt_forward(ecckd_opt* o, const double* h_x, double* h_od, double* h_flux) {
+  ECCKD_REQUIRE(o && h_x, "ecckd_opt_forward: NULL argument");
+  ecckd_ctx* ctx = o->ctx;
+  const size_t nod = o->ncell * o->ng, nfl = o->ncol * 2 * (o->nlay + 1) * o->ng;
+  if (!o->d_od_out) ECCKD_HIP_CHECK(hipMalloc((void**)&o->d_od_out, nod * sizeof(double)));
+  if (!o->d_flux_out) ECCKD_HIP_CHECK(hipMalloc((void**)&o->d_flux_out, nfl * sizeof(double)));
+  double J;
+  int rc = ecckd_opt_cost_grad(o, h_x, &J, nullptr);
+  if (rc == ECCKD_OK) {
+    if (h_od) rc = ecckd_d2h(ctx, h_od, o->d_od_out, nod * sizeof(double));
+    if (rc == ECCKD_OK && h_flux) rc = ecckd_d2h(ctx, h_flux, o->d_flux_out, nfl * sizeof(double));
+  }
+  (void)hipFree(o->d_od_out); (void)hipFree(o->d_flux_out);
+  o->d_od_out = nullptr; o->d_flux_out = nullptr;
+  return rc;
+}
+
+// The optimised molar absorption coefficients of one (user-indexed) gas at state h_x:
+// k = exp(x), 0 where x is pinned at MIN_X (solve_adept.cpp:242-249).
+int ecckd_opt_coefficients(ecckd_opt* o, const double* h_x, int gas, double* h_molar_abs) {
+  ECCKD_REQUIRE(o && h_molar_abs && gas >= 0 && gas < o->ngas, "ecckd_opt_coefficients: bad argument");
+  const GasInfo& gi = o->gases[o->user_to_k[gas]];
+  for (size_t e = 0; e < gi.nnode * o->ng; ++e) {
+    const size_t ge = gi.ix + e;
+    if (gi.active && h_x) h_molar_abs[e] = h_x[ge] > MIN_X ? std::exp(h_x[ge]) : 0.0;
+    else h_molar_abs[e] = o->h_k0[ge];
+  }
+  return ECCKD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// solve_adept (solve_adept.cpp:310-417).  adept::Minimizer is a third-party L-BFGS that is not
+// available here (trajectory parity unpinned); this is a standard L-BFGS (m = 6,
+// two-loop recursion) with Armijo backtracking + curvature-guarded updates, the step capped at
+// max_step_size = 2 in the 2-norm (:331) and simple projection onto [x_min, x_max] when
+// bounded (:344-353).  Status values follow adept::MinimizerStatus (0 success, 2 max
+// iterations, 3 failed to converge, 6 invalid cost function, 7 invalid gradient).
+int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_criterion, int is_bounded,
+                       double* h_x, int* status, int* n_iterations, double* J_final, double* gnorm_final) {
+  ECCKD_REQUIRE(o && h_x && status, "ecckd_opt_minimize: NULL argument");
+  const size_t n = o->nx;
+  std::vector<double> x(n), xmin, xmax, g(n), xn(n), gn(n), d(n);
+  ECCKD_CHECK(ecckd_opt_initial_state(o, x.data(), nullptr, nullptr));
+  if (is_bounded && !o->h_kmin.empty()) {
+    xmin.resize(n); xmax.resize(n);
+    ECCKD_CHECK(ecckd_opt_initial_state(o, x.data(), xmin.data(), xmax.data()));
+  }
+  const bool bounded = !xmin.empty();
+  const int M = 6;
+  std::vector<std::vector<double>> S, Y;
+  std::vector<double> rho;
+  double J = 0.0;
+  ECCKD_CHECK(ecckd_opt_cost_grad(o, x.data(), &J, g.data()));
+  auto pnorm = [&](const std::vector<double>& xx, const std::vector<double>& gg) {
+    // norm of the projected gradient
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+      double gi = gg[i];
+      if (bounded && ((xx[i] <= xmin[i] && gi > 0.0) || (xx[i] >= xmax[i] && gi < 0.0))) gi = 0.0;
+      s += gi * gi;
+    }
+    return std::sqrt(s);
+  };
+  int st = 2;
+  int it = 0;
+  double gnorm = pnorm(x, g);
+  if (!(J == J)) { *status = 6; if (J_final) *J_final = J; return ECCKD_OK; }
+  for (it = 0; it < max_iterations; ++it) {
+    if (gnorm <= convergence_criterion) { st = 0; break; }
+    // two-loop recursion on the free variables
+    for (size_t i = 0; i < n; ++i) {
+      double gi = g[i];
+      if (bounded && ((x[i] <= xmin[i] && gi > 0.0) || (x[i] >= xmax[i] && gi < 0.0))) gi = 0.0;
+      d[i] = gi;
+    }
+    const int hist = (int)S.size();
+    std::vector<double> alpha(hist);
+    for (int j = hist - 1; j >= 0; --j) {
+      double a = 0.0;
+      for (size_t i = 0; i < n; ++i) a += S[j][i] * d[i];
+      a *= rho[j];
+      alpha[j] = a;
+      for (size_t i = 0; i < n; ++i) d[i] -= a * Y[j][i];
+    }
+    if (hist > 0) {
+      double yy = 0.0, sy = 0.0;
+      for (size_t i = 0; i < n; ++i) { yy += Y[hist - 1][i] * Y[hist - 1][i]; sy += S[hist - 1][i] * Y[hist - 1][i]; }
+      const double gamma = sy / yy;
+      for (size_t i = 0; i < n; ++i) d[i] *= gamma;
+    }
+    for (int j = 0; j < hist; ++j) {
+      double b = 0.0;
+      for (size_t i = 0; i < n; ++i) b += Y[j][i] * d[i];
+      b *= rho[j];
+      for (size_t i = 0; i < n; ++i) d[i] += (alpha[j] - b) * S[j][i];
+    }
+    double dg = 0.0, dn = 0.0;
+    for (size_t i = 0; i < n; ++i) { d[i] = -d[i]; dg += d[i] * g[i]; dn += d[i] * d[i]; }
+    dn = std::sqrt(dn);
+    if (!(dg < 0.0)) {  // not a descent direction: restart from steepest descent
+      S.clear(); Y.clear(); rho.clear();
+      dg = 0.0; dn = 0.0;
+      for (size_t i = 0; i < n; ++i) { d[i] = -g[i]; dg += d[i] * g[i]; dn += d[i] * d[i]; }
+      dn = std::sqrt(dn);
+    }
+    double step = (hist == 0) ? std::min(1.0, 1.0 / std::max(dn, 1e-300)) : 1.0;
+    const double max_step = 2.0;  // minimizer.set_max_step_size(2.0), solve_adept.cpp:331
+    if (step * dn > max_step) step = max_step / dn;
+    double Jn = J;
+    bool ok = false;
+    for (int ls = 0; ls < 30; ++ls) {
+      for (size_t i = 0; i < n; ++i) {
+        double v = x[i] + step * d[i];
+        if (bounded) v = std::min(std::max(v, xmin[i]), xmax[i]);
+        if (!(x[i] > MIN_X)) v = x[i];
+        xn[i] = v;
+      }
+      ECCKD_CHECK(ecckd_opt_cost_grad(o, xn.data(), &Jn, gn.data()));
+      if (Jn == Jn && Jn <= J + 1.0e-4 * step * dg) { ok = true; break; }
+      step *= 0.5;
+    }
+    if (!ok) { st = 3; break; }
+    // curvature pair
+    std::vector<double> s(n), y(n);
+    double sy = 0.0;
+    for (size_t i = 0; i < n; ++i) { s[i] = xn[i] - x[i]; y[i] = gn[i] - g[i]; sy += s[i] * y[i]; }
+    if (sy > 1.0e-12) {
+      if ((int)S.size() == M) { S.erase(S.begin()); Y.erase(Y.begin()); rho.erase(rho.begin()); }
+      S.push_back(std::move(s)); Y.push_back(std::move(y)); rho.push_back(1.0 / sy);
+    }
+    x.swap(xn); g.swap(gn); J = Jn;
+    gnorm = pnorm(x, g);
+    if (!(gnorm == gnorm)) { st = 7; break; }
+  }
+  std::memcpy(h_x, x.data(), n * sizeof(double));
+  *status = st;
+  if (n_iterations) *n_iterations = it;
+  if (J_final) *J_final = J;
+  if (gnorm_final) *gnorm_final = gnorm;
+  return ECCKD_OK;
+}
+
+}  // extern "C"

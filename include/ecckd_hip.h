@@ -213,6 +213,77 @@ int ecckd_find_g_band(ecckd_gas* gas, size_t ibegin, size_t iend, double heating
                       int max_g_points, int* ng, double* bounds, double* error, int capacity,
                       int* status, double* comp_cost);
 
+/* ---- optimize_lut: cost function, gradient and minimisation (K8/K9) ------------
+ * Replaces CkdOptimizable::calc_cost_function_gradient (solve_adept.cpp:240-292), i.e.
+ * calc_cost_function_and_gradient (:72-211: CkdModel::calc_optical_depth ckd_model.cpp:925-1102,
+ * negative-OD penalty, calc_cost_function_ckd_lw calc_cost_function_lw.cpp:116-232, Adept
+ * reverse pass) plus CkdModel::calc_background_cost_function (ckd_model.cpp:840-877), and
+ * solve_adept itself (:310-417).  Longwave, linear LUT interpolation.
+ * All arrays here are HOST arrays; the handle uploads them once. */
+typedef struct {
+  int conc_dependence;          /* 0 none, 1 linear, 2 look-up table, 3 relative-linear (ckd_model.cpp:418-482) */
+  int is_active;                /* in the gas list being optimised (optimize_lut.cpp:161) */
+  int nconc;                    /* conc_dependence 2: number of mole fractions */
+  const double* vmr;            /* [nconc], uniform in log (ckd_model.cpp:1006-1009) */
+  double reference_vmr;         /* conc_dependence 3 */
+  const double* molar_abs;      /* [(nconc)][nt][np][ng], g fastest */
+  const double* min_molar_abs;  /* same shape or NULL */
+  const double* max_molar_abs;
+} ecckd_opt_gas;
+
+typedef struct {
+  int ng, nt, np;
+  const double* log_pressure;        /* [np], evenly spaced (ckd_model.cpp:946-948) */
+  const double* temperature;         /* [nt][np] */
+  int ntp;
+  const double* temperature_planck;  /* [ntp] */
+  const double* planck_function;     /* [ntp][ng] */
+  const int* iband_per_g;            /* [ng] g point -> band of the training fluxes (ckd_model.h:287-306) */
+  int ngas;
+  const ecckd_opt_gas* gases;
+  int logarithmic_interpolation;     /* must be 0 (ckd_model.h:359) */
+} ecckd_opt_model;
+
+typedef struct {
+  int ncol, nlay, nband;
+  const double* pressure_hl;     /* [ncol][nlay+1] */
+  const double* temperature_hl;  /* [ncol][nlay+1] */
+  const double* vmr_fl;          /* [ncol][ngas][nlay], gases in MODEL order (LblFluxes::gas_mapping applied) */
+  const int* gas_present;        /* [ngas] 0 where the training file lacks the gas (gas_mapping < 0); NULL = all */
+  const double* surf_emissivity; /* [ncol][nband] or NULL = 1 (lbl_fluxes.cpp:395-396) */
+  const double* flux_dn;         /* [ncol][nlay+1][nband] LBL band fluxes (spectral_flux_dn_) */
+  const double* flux_up;
+  const double* spectral_flux_dn_surf;  /* [ncol][ng] or NULL (lbl_fluxes.cpp:301-328) */
+  const double* spectral_flux_up_toa;
+} ecckd_opt_scene;
+
+typedef struct {
+  double flux_weight, flux_profile_weight, broadband_weight, spectral_boundary_weight;
+  double negative_od_penalty;    /* optimize_lut.cpp:149 default 1e4 */
+  double pressure_weight_power;  /* solve_adept.cpp:131-143 default 0.5 */
+  double prior_error, min_prior_error, max_prior_error, prior_error_scaling;
+  double pressure_corr, temperature_corr, conc_corr;
+  double cap_relative_linear;    /* optimize_lut.cpp:185 passes 0.8; 0 disables */
+} ecckd_opt_config;
+
+typedef struct ecckd_opt ecckd_opt;
+int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* model, int nscene,
+                     const ecckd_opt_scene* scenes, const ecckd_opt_config* config, ecckd_opt** opt);
+int ecckd_opt_destroy(ecckd_opt* opt);
+/* length of the state vector x = ln(molar_abs) of the active gases, in model gas order */
+size_t ecckd_opt_nx(ecckd_opt* opt);
+/* initial state (MIN_X = -1e20 where the coefficient is 0) and log-space bounds, solve_adept.cpp:335-353 */
+int ecckd_opt_initial_state(ecckd_opt* opt, double* h_x, double* h_x_min, double* h_x_max);
+int ecckd_opt_cost_grad(ecckd_opt* opt, const double* h_x, double* J, double* h_grad);
+/* total optical depth [ncol][nlay][ng] and CKD fluxes [ncol][2][nlay+1][ng] at state h_x
+ * (calc_total_optical_depth, LblFluxes::calc_ckd_fluxes lbl_fluxes.cpp:443-471) */
+int ecckd_opt_forward(ecckd_opt* opt, const double* h_x, double* h_od, double* h_flux);
+int ecckd_opt_coefficients(ecckd_opt* opt, const double* h_x, int gas, double* h_molar_abs);
+/* status follows adept::MinimizerStatus: 0 success, 2 max iterations, 3 failed to converge,
+ * >= 6 anomalous (optimize_lut.cpp:315-319 exits 1 for those) */
+int ecckd_opt_minimize(ecckd_opt* opt, int max_iterations, double convergence_criterion, int is_bounded,
+                       double* h_x, int* status, int* n_iterations, double* J_final, double* gnorm_final);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,228 @@
+"""Synthetic CKD model + training scenes for the optimize_lut tests, and the CPU oracle of the
+total cost function (composition of oracle_ckd.c pieces exactly as solve_adept.cpp:72-211 does)."""
+import ctypes as C
+
+import numpy as np
+
+CONC = {"none": 0, "linear": 1, "lut": 2, "relative-linear": 3}
+
+
+def make_model(ng=12, nt=5, np_=16, nband=3, seed=0):
+    rs = np.random.RandomState(seed)
+    log_p = np.linspace(np.log(2.0), np.log(110000.0), np_)
+    t_mid = 200.0 + 12.0 * (log_p - log_p[0])               # p-dependent temperature grid
+    temperature = t_mid[None, :] + 20.0 * (np.arange(nt)[:, None] - (nt - 1) / 2)
+    tpl = np.arange(120.0, 351.0, 1.0)
+    # Planck function per g point: a few "spectral" bins of sigma T^4 shape
+    centre = np.linspace(300.0, 1500.0, ng)
+    x = 1.4388 * centre[None, :] / tpl[:, None]
+    planck = 8.0 * centre[None, :] ** 3 / np.expm1(x) * 1e-7
+    iband = np.sort(rs.randint(0, nband, ng)).astype(np.int32)
+    iband[0], iband[-1] = 0, nband - 1
+    for b in range(nband):                                  # every band populated
+        if not (iband == b).any():
+            iband[b] = b
+    iband = np.sort(iband)
+    g_strength = 10.0 ** np.linspace(-3.0, 1.5, ng)         # weak ... strong g points
+
+    def lut(nconc=None, scale=1.0):
+        shape = (nt, np_, ng) if nconc is None else (nconc, nt, np_, ng)
+        base = scale * g_strength * (1.0 + 0.3 * rs.uniform(size=shape))
+        pfac = np.exp(0.4 * (log_p - log_p[-1]))[:, None]   # pressure broadening-ish
+        base = base * (0.2 + pfac) if nconc is None else base * (0.2 + pfac)[None, None]
+        return base
+
+    vmr_h2o = np.exp(np.linspace(np.log(1e-6), np.log(4e-2), 4))
+    gases = [
+        dict(name="composite", conc="none", active=True, molar_abs=lut(scale=2e-4)),
+        dict(name="h2o", conc="lut", active=True, molar_abs=lut(4, scale=3.0), vmr=vmr_h2o),
+        dict(name="co2", conc="linear", active=True, molar_abs=lut(scale=30.0)),
+        dict(name="ch4", conc="relative-linear", active=True, molar_abs=lut(scale=50.0), reference_vmr=1.8e-6),
+        dict(name="o3", conc="linear", active=False, molar_abs=lut(scale=500.0)),
+    ]
+    gases[1]["molar_abs"][:, :, :, 0] = 0.0                 # a g point where h2o does not absorb: x pinned at MIN_X
+    for g in gases:
+        g["min_molar_abs"] = g["molar_abs"] * 0.5
+        g["max_molar_abs"] = g["molar_abs"] * 2.0
+    gases[2]["min_molar_abs"] = gases[2]["min_molar_abs"].copy()
+    gases[2]["min_molar_abs"][:, :, 3] = 0.0                # exercises the k_min == 0 bound rule
+    return dict(log_pressure=log_p, temperature=temperature, temperature_planck=tpl, planck_function=planck,
+                iband_per_g=iband, gases=gases, nband=nband)
+
+
+def make_scenes(model, nscene=2, ncol=4, nlay=18, seed=1, ch4_low=False):
+    rs = np.random.RandomState(seed)
+    ngas = len(model["gases"])
+    scenes = []
+    for s in range(nscene):
+        p = np.empty((ncol, nlay + 1))
+        T = np.empty((ncol, nlay + 1))
+        vmr = np.empty((ncol, ngas, nlay))
+        for c in range(ncol):
+            p[c] = np.concatenate([[1.0], np.exp(np.linspace(np.log(5.0), np.log(101325.0 - 2000 * c), nlay))])
+            T[c] = 210.0 + 80.0 * (p[c] / p[c, -1]) ** 0.25 + rs.uniform(-3, 3, nlay + 1) + 4.0 * s
+            pf = 0.5 * (p[c, 1:] + p[c, :-1]) / p[c, -1]
+            vmr[c, 0] = 1.0
+            vmr[c, 1] = np.clip(2e-2 * pf ** 3 * (1 + 0.5 * s) * rs.uniform(0.5, 1.5), 2e-6, 5e-2)
+            vmr[c, 2] = 4e-4 * (1.0 + s)
+            vmr[c, 3] = (0.9e-6 if ch4_low else 1.8e-6 * (1.0 + 0.5 * s)) * np.ones(nlay)
+            vmr[c, 4] = 5e-6 * np.exp(-((np.log(pf) + 5.0) / 1.5) ** 2) + 2e-8
+        present = np.ones(ngas, dtype=np.int32)
+        if s == 1:
+            present[4] = 0                                  # o3 missing from the second training file
+        scenes.append(dict(pressure_hl=p, temperature_hl=T, vmr_fl=vmr, gas_present=present))
+    return scenes
+
+
+class Oracle:
+    """Forward cost J(x) on the CPU: solve_adept.cpp:72-211 + :273 from oracle_ckd.c pieces."""
+
+    def __init__(self, pyoracle, model, scenes, cfg):
+        self.o, self.m, self.scenes, self.cfg = pyoracle, model, scenes, cfg
+        L = pyoracle.lib()
+        L.orc_calc_cost_function_ckd_lw.restype = C.c_double
+        self.L = L
+        self.active = [i for i, g in enumerate(model["gases"]) if g.get("active", True)]
+        self.sizes = [model["gases"][i]["molar_abs"].size for i in self.active]
+        self.x0 = np.concatenate([self._logk(model["gases"][i]["molar_abs"].ravel()) for i in self.active])
+        self._prior = None
+
+    @staticmethod
+    def _logk(k):
+        with np.errstate(divide="ignore"):
+            return np.where(k > 0.0, np.log(np.where(k > 0.0, k, 1.0)), -1.0e20)
+
+    def coeffs(self, x):
+        out = [g["molar_abs"] for g in self.m["gases"]]
+        off = 0
+        for i, n in zip(self.active, self.sizes):
+            xx = x[off:off + n]
+            out[i] = np.where(xx > -1.0e20, np.exp(np.minimum(xx, 700.0)), 0.0).reshape(self.m["gases"][i]["molar_abs"].shape)
+            off += n
+        return out
+
+    def optical_depth(self, x, scene):
+        m, P = self.m, self.o._p
+        ks = self.coeffs(x)
+        p, T, vmr = (np.ascontiguousarray(scene[k]) for k in ("pressure_hl", "temperature_hl", "vmr_fl"))
+        ncol, nhl = p.shape
+        nlay = nhl - 1
+        nt, np_ = m["temperature"].shape
+        ng = m["planck_function"].shape[1]
+        t_fl = np.ascontiguousarray((T[:, :-1] * p[:, :-1] + T[:, 1:] * p[:, 1:]) / (p[:, :-1] + p[:, 1:]))
+        total = np.zeros((ncol, nlay, ng))
+        tmp = np.empty((ncol, nlay, ng))
+        for i, g in enumerate(m["gases"]):
+            present = scene.get("gas_present") is None or scene["gas_present"][i]
+            if not present and g["conc"] != "none":
+                continue                                   # solve_adept.cpp:55-67
+            v = np.ascontiguousarray(vmr[:, i, :]) if (present and g["conc"] != "none") else None
+            k = np.ascontiguousarray(ks[i])
+            vl = np.ascontiguousarray(g["vmr"]) if g.get("vmr") is not None else None
+            rc = self.L.orc_ckd_optical_depth(C.c_int(ng), C.c_int(nt), C.c_int(np_), P(np.ascontiguousarray(m["log_pressure"])),
+                                              P(np.ascontiguousarray(m["temperature"])), C.c_int(CONC[g["conc"]]),
+                                              C.c_int(k.shape[0] if g["conc"] == "lut" else 1), P(vl),
+                                              C.c_double(g.get("reference_vmr", 0.0)), P(k), C.c_int(ncol), C.c_int(nlay),
+                                              P(p), P(t_fl), P(v), P(tmp))
+            assert rc == 0
+            total += tmp
+        return total
+
+    def planck(self, T):
+        m, P = self.m, self.o._p
+        T = np.ascontiguousarray(T).ravel()
+        ng = m["planck_function"].shape[1]
+        out = np.empty((T.size, ng))
+        self.L.orc_ckd_planck(C.c_int(m["planck_function"].shape[0]), P(np.ascontiguousarray(m["temperature_planck"])),
+                              P(np.ascontiguousarray(m["planck_function"])), C.c_int(ng), C.c_int(T.size), P(T), P(out))
+        return out
+
+    def fluxes(self, x, scene):
+        """CKD fluxes per g: (ncol, 2, nhl, ng), LblFluxes::calc_ckd_fluxes."""
+        od = np.maximum(self.optical_depth(x, scene), 0.0)
+        T = scene["temperature_hl"]
+        ncol, nhl = T.shape
+        ng = od.shape[2]
+        out = np.empty((ncol, 2, nhl, ng))
+        for c in range(ncol):
+            pl = self.planck(T[c])
+            d, u = self.o.radiative_transfer_lw(pl, od[c], np.ones(ng), pl[-1])
+            out[c, 0], out[c, 1] = d, u
+        return out
+
+    def band_fluxes(self, x, scene):
+        f = self.fluxes(x, scene)
+        ib = self.m["iband_per_g"]
+        nband = self.m["nband"]
+        return np.stack([f[:, :, :, ib == b].sum(-1) for b in range(nband)], axis=-1)  # (ncol,2,nhl,nband)
+
+    def cost_rt(self, x):
+        cfg, P = self.cfg, self.o._p
+        J = 0.0
+        nband = self.m["nband"]
+        ib = np.ascontiguousarray(self.m["iband_per_g"], dtype=np.int32)
+        for scene in self.scenes:
+            od = self.optical_depth(x, scene)
+            neg = od < 0.0
+            if neg.any():                                  # solve_adept.cpp:107-116
+                J += cfg["negative_od_penalty"] * np.sum(od[neg] ** 2)
+                od = np.where(neg, 0.0, od)
+            p, T = scene["pressure_hl"], scene["temperature_hl"]
+            ncol, nhl = p.shape
+            nlay = nhl - 1
+            ng = od.shape[2]
+            for c in range(ncol):
+                pw = cfg["pressure_weight_power"]
+                lw = (np.sqrt(p[c, 1:]) - np.sqrt(p[c, :-1])) if pw == 0.5 else (p[c, 1:] ** pw - p[c, :-1] ** pw)
+                lw = np.ascontiguousarray(lw / lw.sum())
+                pl = self.planck(T[c])
+                fd = np.ascontiguousarray(scene["flux_dn"][c])
+                fu = np.ascontiguousarray(scene["flux_up"][c])
+                hr = self.o.heating_rate(p[c], fd, fu)
+                sfd = scene.get("spectral_flux_dn_surf")
+                sfu = scene.get("spectral_flux_up_toa")
+                J += self.L.orc_calc_cost_function_ckd_lw(
+                    C.c_int(nlay), C.c_int(ng), C.c_int(nband), P(np.ascontiguousarray(p[c])), P(pl),
+                    P(np.ones(nband)), P(np.ascontiguousarray(pl[-1])), P(np.ascontiguousarray(od[c])), P(fd), P(fu),
+                    P(np.ascontiguousarray(hr)), P(np.ascontiguousarray(sfd[c])) if sfd is not None else None,
+                    P(np.ascontiguousarray(sfu[c])) if sfu is not None else None, C.c_double(cfg["flux_weight"]),
+                    C.c_double(cfg["flux_profile_weight"]), C.c_double(cfg["broadband_weight"]),
+                    C.c_double(cfg["spectral_boundary_weight"]), P(lw), None, None,
+                    ib.ctypes.data_as(C.POINTER(C.c_int)))
+        return J
+
+    def prior_matrices(self):
+        """Dense inverse covariance per active gas exactly as create_error_covariances builds it
+        (ckd_model.cpp:693-713, :760-780): pow(corr, |index difference|), LAPACK inverse, < 1e-6 zeroed."""
+        if self._prior is None:
+            cfg = self.cfg
+            nt, np_ = self.m["temperature"].shape
+            mats = []
+            for i in self.active:
+                g = self.m["gases"][i]
+                nconc = g["molar_abs"].shape[0] if g["conc"] == "lut" else 1
+                ic, it, ip = np.meshgrid(np.arange(nconc), np.arange(nt), np.arange(np_), indexing="ij")
+                ic, it, ip = ic.ravel(), it.ravel(), ip.ravel()
+                B = (cfg["temperature_corr"] ** np.abs(it[:, None] - it[None, :]) *
+                     cfg["pressure_corr"] ** np.abs(ip[:, None] - ip[None, :]))
+                if nconc > 1:
+                    B = B * cfg["conc_corr"] ** np.abs(ic[:, None] - ic[None, :])
+                Binv = np.linalg.inv(B)
+                Binv[np.abs(Binv) < 1.0e-6] = 0.0
+                mats.append(Binv)
+            self._prior = mats
+        return self._prior
+
+    def cost_prior(self, x, sigma):
+        """calc_background_cost_function (ckd_model.cpp:840-877) with dense matrices; returns (J, grad)."""
+        ng = self.m["planck_function"].shape[1]
+        J = 0.0
+        grad = np.zeros_like(x)
+        off = 0
+        for Binv, n in zip(self.prior_matrices(), self.sizes):
+            dx = (x[off:off + n] - self.x0[off:off + n]).reshape(-1, ng)
+            gl = (Binv @ dx) / sigma ** 2
+            J += 0.5 * np.sum(dx * gl)
+            grad[off:off + n] = gl.ravel()
+            off += n
+        return J, grad
