@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--max-iterations", type=int, default=60)
     ap.add_argument("--cpu-sample", type=int, default=1 << 15)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-lut-opt", action="store_true")
+    ap.add_argument("--lut-opt-iterations", type=int, default=40)
     return ap.parse_args()
 
 
@@ -90,6 +92,51 @@ def cpu_baseline(nwav_s, nlay, seed, tol, tol_tol, max_it):
         raise RuntimeError("oracle/_ref not built")
     dt = time.perf_counter() - t0
     return nwav_s * (1.0 + eq.total_comp_cost), dt, len(e), eq.total_comp_cost, search
+
+
+def lut_opt_bench(ctx, iterations):
+    """Second half of the headline metric: LUT-optimisation iterations/s (solve_adept.cpp:295-299 logs one
+    line per L-BFGS iteration).  Synthetic CKD model with the shapes of configs[4]: ng = 64, 6 x 53 (T, p)
+    grid, H2O look-up table with 12 mole fractions (nx ~ 3e5), 8 scenarios x 50 columns x 54 layers."""
+    from ecckd_amd import api, synthetic as syn
+    model = syn.ckd_model(ng=64, nt=6, np_=53, nband=13, seed=11, nconc=12)
+    truth = syn.ckd_model(ng=64, nt=6, np_=53, nband=13, seed=11, nconc=12)
+    rs = np.random.RandomState(12)
+    for g in truth["gases"]:
+        g["molar_abs"] = g["molar_abs"] * np.exp(0.25 * rs.normal(size=g["molar_abs"].shape))
+    scenes = syn.ckd_scenes(model, nscene=8, ncol=50, nlay=54, seed=13)
+    cfg = dict(flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, prior_error=4.0, pressure_corr=0.95,
+               temperature_corr=0.95, conc_corr=0.95)       # test/optimize_lut_lw.sh:55 final pass
+    ib = model["iband_per_g"]
+    nhl = 55
+    for s in scenes:                                         # placeholders, replaced by the truth model's fluxes
+        s["flux_dn"] = np.zeros((50, nhl, 13))
+        s["flux_up"] = np.zeros((50, nhl, 13))
+    t_opt = api.Optimizer(ctx, truth, scenes, **cfg)
+    _, fl = t_opt.forward(t_opt.initial_state())
+    t_opt.close()
+    band = np.stack([fl[..., ib == b].sum(-1) for b in range(13)], axis=-1)   # (ncol, 2, nhl, nband)
+    c0 = 0
+    for s in scenes:
+        s["flux_dn"] = np.ascontiguousarray(band[c0:c0 + 50, 0])
+        s["flux_up"] = np.ascontiguousarray(band[c0:c0 + 50, 1])
+        c0 += 50
+    opt = api.Optimizer(ctx, model, scenes, **cfg)
+    x0 = opt.initial_state()
+    J0, g0 = opt.cost_grad(x0)                               # warm-up
+    t0 = time.perf_counter()
+    res = opt.minimize(max_iterations=iterations, convergence_criterion=0.0, bounded=True)
+    dt = time.perf_counter() - t0
+    n_eval = 0
+    t1 = time.perf_counter()
+    for _ in range(20):
+        opt.cost_grad(x0)
+    dt_eval = (time.perf_counter() - t1) / 20
+    out = {"iters_per_s": res["iterations"] / dt, "iterations": res["iterations"], "nx": opt.nx,
+           "cells": 8 * 50 * 54 * 64, "cost_grad_ms": dt_eval * 1e3, "J0": J0, "J_final": res["cost"],
+           "status": res["status"]}
+    opt.close()
+    return out
 
 
 def main():
@@ -193,6 +240,8 @@ def main():
                                               "achieved": k1_pts * k1_bytes_per_pt / max(k1_ms * 1e-3, 1e-12) / 1e9,
                                               "algorithmic_bytes_per_point": k1_bytes_per_pt}},
         }
+        if world == 1 and not args.no_lut_opt:
+            out["lut_opt"] = lut_opt_bench(ctx, args.lut_opt_iterations)
         if world == 1 and not args.no_cpu:
             pts, cdt, cng, ccost, search = cpu_baseline(args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance,
                                                         args.tolerance_tolerance, args.max_iterations)

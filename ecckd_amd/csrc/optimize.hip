@@ -402,6 +402,150 @@ k_opt_exp(size_t nx, const double* __restrict__ x, double* __restrict__ k) {
   if (e < nx) k[e] = (x[e] > MIN_X) ? exp(x[e]) : 0.0;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Device-resident L-BFGS vector kernels.  All reductions are two-stage with a fixed order:
+// stage 1 writes one partial per block, stage 2 (inside the consumer kernel, or k_vec_finish)
+// sums the partials in index order.  Scalars live in a small device array `sc`.
+constexpr int VEC_BLOCKS = 256;   // partials per reduction
+constexpr int VEC_THREADS = 256;
+
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, double* s_tmp) {
+  // every block reduces the same VEC_BLOCKS partials in the same order
+  const int t = threadIdx.x;
+  double v = (t < VEC_BLOCKS) ? part[t] : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((t & 63) == 0) s_tmp[t >> 6] = v;
+  __syncthreads();
+  return ((s_tmp[0] + s_tmp[1]) + s_tmp[2]) + s_tmp[3];
+}
+
+__device__ __forceinline__ void write_partial(double v, double* __restrict__ part, double* s_tmp) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int t = threadIdx.x;
+  __syncthreads();
+  if ((t & 63) == 0) s_tmp[t >> 6] = v;
+  __syncthreads();
+  if (t == 0) part[blockIdx.x] = ((s_tmp[0] + s_tmp[1]) + s_tmp[2]) + s_tmp[3];
+}
+
+// q = projected gradient (0 at active bounds and at pinned elements); partial of |q|^2
+__global__ void __launch_bounds__(VEC_THREADS)
+k_vec_project(size_t n, const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ xmin,
+              const double* __restrict__ xmax, double* __restrict__ q, double* __restrict__ part) {
+  __shared__ double s_tmp[4];
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
+    double gi = g[i];
+    if (xmin && ((x[i] <= xmin[i] && gi > 0.0) || (x[i] >= xmax[i] && gi < 0.0))) gi = 0.0;
+    if (!(x[i] > MIN_X)) gi = 0.0;
+    q[i] = gi;
+    acc += gi * gi;
+  }
+  write_partial(acc, part, s_tmp);
+}
+
+// partial of a . b
+__global__ void __launch_bounds__(VEC_THREADS)
+k_vec_dot(size_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ part) {
+  __shared__ double s_tmp[4];
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS)
+    acc += a[i] * b[i];
+  write_partial(acc, part, s_tmp);
+}
+
+// first loop of the two-loop recursion: alpha = rho * (s . q) [from partials]; q -= alpha * y
+__global__ void __launch_bounds__(VEC_THREADS)
+k_vec_loop1(size_t n, const double* __restrict__ part, const double* __restrict__ rho, double* __restrict__ alpha_out,
+            const double* __restrict__ y, double* __restrict__ q) {
+  __shared__ double s_tmp[4];
+  const double a = rho[0] * sum_partials(part, s_tmp);
+  if (blockIdx.x == 0 && threadIdx.x == 0) alpha_out[0] = a;
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS)
+    q[i] -= a * y[i];
+}
+
+// q *= gamma
+__global__ void __launch_bounds__(VEC_THREADS)
+k_vec_scale(size_t n, const double* __restrict__ gamma, double* __restrict__ q) {
+  const double gm = gamma[0];
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) q[i] *= gm;
+}
+
+// second loop: beta = rho * (y . q) [from partials]; q += (alpha - beta) * s
+__global__ void __launch_bounds__(VEC_THREADS)
+k_vec_loop2(size_t n, const double* __restrict__ part, const double* __restrict__ rho, const double* __restrict__ alpha,
+            const double* __restrict__ sv, double* __restrict__ q) {
+  __shared__ double s_tmp[4];
+  const double b = rho[0] * sum_partials(part, s_tmp);
+  const double c = alpha[0] - b;
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS)
+    q[i] += c * sv[i];
+}
+
+// d = -q (or -g when restart); partials of d.g and d.d
+__global__ void __launch_bounds__(VEC_THREADS)
+k_vec_direction(size_t n, const double* __restrict__ q, const double* __restrict__ g, double* __restrict__ d,
+                double* __restrict__ part_dg, double* __restrict__ part_dd) {
+  __shared__ double s_tmp[4];
+  double a = 0.0, b = 0.0;
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
+    const double di = -q[i];
+    d[i] = di;
+    a += di * g[i];
+    b += di * di;
+  }
+  write_partial(a, part_dg, s_tmp);
+  write_partial(b, part_dd, s_tmp);
+}
+
+// xn = clamp(x + step*d); pinned elements stay
+__global__ void __launch_bounds__(VEC_THREADS)
+k_vec_step(size_t n, double step, const double* __restrict__ x, const double* __restrict__ d,
+           const double* __restrict__ xmin, const double* __restrict__ xmax, double* __restrict__ xn) {
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
+    double v = x[i] + step * d[i];
+    if (xmin) v = fmin(fmax(v, xmin[i]), xmax[i]);
+    if (!(x[i] > MIN_X)) v = x[i];
+    xn[i] = v;
+  }
+}
+
+// curvature pair s = xn - x, y = gn - g; partials of s.y and y.y
+__global__ void __launch_bounds__(VEC_THREADS)
+k_vec_pair(size_t n, const double* __restrict__ x, const double* __restrict__ xn, const double* __restrict__ g,
+           const double* __restrict__ gn, double* __restrict__ sv, double* __restrict__ yv,
+           double* __restrict__ part_sy, double* __restrict__ part_yy) {
+  __shared__ double s_tmp[4];
+  double a = 0.0, b = 0.0;
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
+    const double si = xn[i] - x[i], yi = gn[i] - g[i];
+    sv[i] = si;
+    yv[i] = yi;
+    a += si * yi;
+    b += yi * yi;
+  }
+  write_partial(a, part_sy, s_tmp);
+  write_partial(b, part_yy, s_tmp);
+}
+
+// sums up to 4 partial arrays into out[0..m)
+__global__ void __launch_bounds__(VEC_THREADS)
+k_vec_finish(int m, const double* __restrict__ p0, const double* __restrict__ p1, const double* __restrict__ p2,
+             const double* __restrict__ p3, double* __restrict__ out) {
+  __shared__ double s_tmp[4];
+  const double* ps[4] = {p0, p1, p2, p3};
+  for (int k = 0; k < m; ++k) {
+    const double v = sum_partials(ps[k], s_tmp);
+    if (threadIdx.x == 0) out[k] = v;
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 struct ecckd_opt {
@@ -427,6 +571,9 @@ struct ecckd_opt {
   double* d_od_out = nullptr; double* d_flux_out = nullptr;
   unsigned grad_blocks = 0;
   std::vector<double> h_jcol, h_jb;
+  // device L-BFGS workspace (allocated by ecckd_opt_minimize)
+  double *d_xmin = nullptr, *d_xmax = nullptr, *d_xn = nullptr, *d_gn = nullptr, *d_dir = nullptr, *d_q = nullptr;
+  double *d_S = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sc = nullptr;
   // timing
   long long n_eval = 0;
 };
@@ -448,7 +595,8 @@ void opt_free(ecckd_opt* o) {
   void* ptrs[] = {o->d_k, o->d_x, o->d_xprior, o->d_grad, o->d_dtau, o->d_jcol, o->d_jb, o->d_ent_idx, o->d_ent_coef,
                   o->d_band, o->d_planck, o->d_semis, o->d_conv, o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds,
                   o->d_sfut, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_node_gas, o->d_node_ic, o->d_node_it,
-                  o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2, o->d_od_out, o->d_flux_out};
+                  o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2, o->d_od_out, o->d_flux_out, o->d_xmin, o->d_xmax,
+                  o->d_xn, o->d_gn, o->d_dir, o->d_q, o->d_S, o->d_Y, o->d_part, o->d_sc};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete o;
@@ -833,12 +981,10 @@ int ecckd_opt_initial_state(ecckd_opt* o, double* h_x, double* h_x_min, double* 
 }
 
 // CkdOptimizable::calc_cost_function_gradient (solve_adept.cpp:240-292).
-int ecckd_opt_cost_grad(ecckd_opt* o, const double* h_x, double* J, double* h_grad) {
-  ECCKD_REQUIRE(o && h_x && J, "ecckd_opt_cost_grad: NULL argument");
+// cost and gradient at the DEVICE state d_x -> d_grad; J on the host (one stream sync).
+static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, double* J) {
   ecckd_ctx* ctx = o->ctx;
-  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
-  ECCKD_HIP_CHECK(hipMemcpyAsync(o->d_x, h_x, o->nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, o->d_x, o->d_k);
+  hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, d_x, o->d_k);
   const int nlay = o->nlay, nhl = nlay + 1, ng = o->ng, nband = o->nband;
   const int threads = (ng + 63) / 64 * 64;
   const size_t lds = ((size_t)nlay * ng + 2 * (size_t)nhl * ng + 4 * (size_t)nhl * nband + 16) * sizeof(double);
@@ -850,14 +996,13 @@ int ecckd_opt_cost_grad(ecckd_opt* o, const double* h_x, double* J, double* h_gr
                      o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds, o->d_sfut, o->cfg.flux_weight,
                      o->cfg.flux_profile_weight, o->cfg.broadband_weight, o->cfg.spectral_boundary_weight,
                      o->cfg.negative_od_penalty, o->d_dtau, o->d_jcol, o->d_od_out, o->d_flux_out);
-  hipLaunchKernelGGL(k_opt_gradient, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, ng, o->d_x, o->d_xprior,
+  hipLaunchKernelGGL(k_opt_gradient, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, ng, d_x, o->d_xprior,
                      o->d_k, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_dtau, o->d_node_gas, o->d_node_ic,
                      o->d_node_it, o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2,
-                     o->have_prior ? 1 : 0, o->d_grad, o->d_jb);
+                     o->have_prior ? 1 : 0, d_grad, o->d_jb);
   ECCKD_HIP_CHECK(hipGetLastError());
   ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jcol.data(), o->d_jcol, o->ncol * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jb.data(), o->d_jb, o->grad_blocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (h_grad) ECCKD_HIP_CHECK(hipMemcpyAsync(h_grad, o->d_grad, o->nx * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   double j = 0.0;
   for (double v : o->h_jcol) j += v;  // scene/profile order, as the reference accumulates (:157)
@@ -865,6 +1010,19 @@ int ecckd_opt_cost_grad(ecckd_opt* o, const double* h_x, double* J, double* h_gr
   for (double v : o->h_jb) jb += v;
   *J = j + jb;
   o->n_eval++;
+  return ECCKD_OK;
+}
+
+int ecckd_opt_cost_grad(ecckd_opt* o, const double* h_x, double* J, double* h_grad) {
+  ECCKD_REQUIRE(o && h_x && J, "ecckd_opt_cost_grad: NULL argument");
+  ecckd_ctx* ctx = o->ctx;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(o->d_x, h_x, o->nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ECCKD_CHECK(opt_cost_grad_dev(o, o->d_x, o->d_grad, J));
+  if (h_grad) {
+    ECCKD_HIP_CHECK(hipMemcpyAsync(h_grad, o->d_grad, o->nx * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
   return ECCKD_OK;
 }
 
@@ -911,70 +1069,92 @@ int ecckd_opt_coefficients(ecckd_opt* o, const double* h_x, int gas, double* h_m
 int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_criterion, int is_bounded,
                        double* h_x, int* status, int* n_iterations, double* J_final, double* gnorm_final) {
   ECCKD_REQUIRE(o && h_x && status, "ecckd_opt_minimize: NULL argument");
+  ecckd_ctx* ctx = o->ctx;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
   const size_t n = o->nx;
-  std::vector<double> x(n), xmin, xmax, g(n), xn(n), gn(n), d(n);
-  ECCKD_CHECK(ecckd_opt_initial_state(o, x.data(), nullptr, nullptr));
-  if (is_bounded && !o->h_kmin.empty()) {
-    xmin.resize(n); xmax.resize(n);
-    ECCKD_CHECK(ecckd_opt_initial_state(o, x.data(), xmin.data(), xmax.data()));
-  }
-  const bool bounded = !xmin.empty();
   const int M = 6;
-  std::vector<std::vector<double>> S, Y;
-  std::vector<double> rho;
-  double J = 0.0;
-  ECCKD_CHECK(ecckd_opt_cost_grad(o, x.data(), &J, g.data()));
-  auto pnorm = [&](const std::vector<double>& xx, const std::vector<double>& gg) {
-    // norm of the projected gradient
-    double s = 0.0;
-    for (size_t i = 0; i < n; ++i) {
-      double gi = gg[i];
-      if (bounded && ((xx[i] <= xmin[i] && gi > 0.0) || (xx[i] >= xmax[i] && gi < 0.0))) gi = 0.0;
-      s += gi * gi;
-    }
-    return std::sqrt(s);
+  // state, bounds and history live on the device; the host only sees scalars
+  std::vector<double> x0(n), xmin, xmax;
+  const bool bounded = is_bounded && !o->h_kmin.empty();
+  if (bounded) {
+    xmin.resize(n); xmax.resize(n);
+    ECCKD_CHECK(ecckd_opt_initial_state(o, x0.data(), xmin.data(), xmax.data()));
+  } else {
+    ECCKD_CHECK(ecckd_opt_initial_state(o, x0.data(), nullptr, nullptr));
+  }
+  auto dalloc = [&](double** p, size_t cnt) -> int {
+    if (*p) return ECCKD_OK;
+    ECCKD_HIP_CHECK(hipMalloc((void**)p, cnt * sizeof(double)));
+    return ECCKD_OK;
   };
-  int st = 2;
-  int it = 0;
-  double gnorm = pnorm(x, g);
+  ECCKD_CHECK(dalloc(&o->d_xn, n)); ECCKD_CHECK(dalloc(&o->d_gn, n)); ECCKD_CHECK(dalloc(&o->d_dir, n));
+  ECCKD_CHECK(dalloc(&o->d_q, n)); ECCKD_CHECK(dalloc(&o->d_S, (size_t)M * n)); ECCKD_CHECK(dalloc(&o->d_Y, (size_t)M * n));
+  ECCKD_CHECK(dalloc(&o->d_part, 4 * VEC_BLOCKS)); ECCKD_CHECK(dalloc(&o->d_sc, 64));
+  if (bounded) {
+    ECCKD_CHECK(dalloc(&o->d_xmin, n)); ECCKD_CHECK(dalloc(&o->d_xmax, n));
+    ECCKD_HIP_CHECK(hipMemcpyAsync(o->d_xmin, xmin.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ECCKD_HIP_CHECK(hipMemcpyAsync(o->d_xmax, xmax.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  ECCKD_HIP_CHECK(hipMemcpyAsync(o->d_x, x0.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const double* bmin = bounded ? o->d_xmin : nullptr;
+  const double* bmax = bounded ? o->d_xmax : nullptr;
+  double* x = o->d_x; double* g = o->d_grad; double* xn = o->d_xn; double* gn = o->d_gn;
+  double* part = o->d_part;                 // 4 partial arrays
+  // device scalars: sc[0..M) rho, sc[M..2M) alpha, sc[2M] gamma, sc[32..36) readback
+  double* sc = o->d_sc;
+  double* sc_rho = sc; double* sc_alpha = sc + M; double* sc_gamma = sc + 2 * M; double* sc_rb = sc + 32;
+  double h_rb[4];
+  auto readback = [&](int m) -> int {
+    ECCKD_HIP_CHECK(hipMemcpyAsync(h_rb, sc_rb, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return ECCKD_OK;
+  };
+  const dim3 vb(VEC_BLOCKS), vt(VEC_THREADS);
+
+  double J = 0.0;
+  ECCKD_CHECK(opt_cost_grad_dev(o, x, g, &J));
+  int st = 2, it = 0, hist = 0, head = 0;   // ring buffer: slot of pair j (0 = oldest) is (head + j) % M
+  double gnorm = 0.0;
   if (!(J == J)) { *status = 6; if (J_final) *J_final = J; return ECCKD_OK; }
-  for (it = 0; it < max_iterations; ++it) {
-    if (gnorm <= convergence_criterion) { st = 0; break; }
-    // two-loop recursion on the free variables
-    for (size_t i = 0; i < n; ++i) {
-      double gi = g[i];
-      if (bounded && ((x[i] <= xmin[i] && gi > 0.0) || (x[i] >= xmax[i] && gi < 0.0))) gi = 0.0;
-      d[i] = gi;
-    }
-    const int hist = (int)S.size();
-    std::vector<double> alpha(hist);
+  for (it = 0; it <= max_iterations; ++it) {
+    // projected gradient and its norm
+    hipLaunchKernelGGL(k_vec_project, vb, vt, 0, ctx->stream, n, x, g, bmin, bmax, o->d_q, part);
+    // two-loop recursion (solve with the L-BFGS inverse Hessian), all on the device
     for (int j = hist - 1; j >= 0; --j) {
-      double a = 0.0;
-      for (size_t i = 0; i < n; ++i) a += S[j][i] * d[i];
-      a *= rho[j];
-      alpha[j] = a;
-      for (size_t i = 0; i < n; ++i) d[i] -= a * Y[j][i];
+      const int slot = (head + j) % M;
+      hipLaunchKernelGGL(k_vec_dot, vb, vt, 0, ctx->stream, n, o->d_S + (size_t)slot * n, o->d_q, part + VEC_BLOCKS);
+      hipLaunchKernelGGL(k_vec_loop1, vb, vt, 0, ctx->stream, n, part + VEC_BLOCKS, sc_rho + slot, sc_alpha + slot,
+                         o->d_Y + (size_t)slot * n, o->d_q);
     }
-    if (hist > 0) {
-      double yy = 0.0, sy = 0.0;
-      for (size_t i = 0; i < n; ++i) { yy += Y[hist - 1][i] * Y[hist - 1][i]; sy += S[hist - 1][i] * Y[hist - 1][i]; }
-      const double gamma = sy / yy;
-      for (size_t i = 0; i < n; ++i) d[i] *= gamma;
-    }
+    if (hist > 0) hipLaunchKernelGGL(k_vec_scale, vb, vt, 0, ctx->stream, n, sc_gamma, o->d_q);
     for (int j = 0; j < hist; ++j) {
-      double b = 0.0;
-      for (size_t i = 0; i < n; ++i) b += Y[j][i] * d[i];
-      b *= rho[j];
-      for (size_t i = 0; i < n; ++i) d[i] += (alpha[j] - b) * S[j][i];
+      const int slot = (head + j) % M;
+      hipLaunchKernelGGL(k_vec_dot, vb, vt, 0, ctx->stream, n, o->d_Y + (size_t)slot * n, o->d_q, part + VEC_BLOCKS);
+      hipLaunchKernelGGL(k_vec_loop2, vb, vt, 0, ctx->stream, n, part + VEC_BLOCKS, sc_rho + slot, sc_alpha + slot,
+                         o->d_S + (size_t)slot * n, o->d_q);
     }
-    double dg = 0.0, dn = 0.0;
-    for (size_t i = 0; i < n; ++i) { d[i] = -d[i]; dg += d[i] * g[i]; dn += d[i] * d[i]; }
-    dn = std::sqrt(dn);
-    if (!(dg < 0.0)) {  // not a descent direction: restart from steepest descent
-      S.clear(); Y.clear(); rho.clear();
-      dg = 0.0; dn = 0.0;
-      for (size_t i = 0; i < n; ++i) { d[i] = -g[i]; dg += d[i] * g[i]; dn += d[i] * d[i]; }
-      dn = std::sqrt(dn);
+    hipLaunchKernelGGL(k_vec_direction, vb, vt, 0, ctx->stream, n, o->d_q, g, o->d_dir, part + 2 * VEC_BLOCKS,
+                       part + 3 * VEC_BLOCKS);
+    hipLaunchKernelGGL(k_vec_finish, dim3(1), vt, 0, ctx->stream, 3, part, part + 2 * VEC_BLOCKS, part + 3 * VEC_BLOCKS,
+                       part, sc_rb);
+    ECCKD_HIP_CHECK(hipGetLastError());
+    ECCKD_CHECK(readback(3));
+    gnorm = std::sqrt(h_rb[0]);
+    double dg = h_rb[1], dn = std::sqrt(h_rb[2]);
+    if (!(gnorm == gnorm)) { st = 7; break; }
+    if (gnorm <= convergence_criterion) { st = 0; break; }
+    if (it == max_iterations) { st = 2; break; }
+    if (!(dg < 0.0)) {
+      // not a descent direction: drop the history, steepest descent on the projected gradient
+      hist = 0; head = 0;
+      hipLaunchKernelGGL(k_vec_project, vb, vt, 0, ctx->stream, n, x, g, bmin, bmax, o->d_q, part);
+      hipLaunchKernelGGL(k_vec_direction, vb, vt, 0, ctx->stream, n, o->d_q, g, o->d_dir, part + 2 * VEC_BLOCKS,
+                         part + 3 * VEC_BLOCKS);
+      hipLaunchKernelGGL(k_vec_finish, dim3(1), vt, 0, ctx->stream, 3, part, part + 2 * VEC_BLOCKS,
+                         part + 3 * VEC_BLOCKS, part, sc_rb);
+      ECCKD_CHECK(readback(3));
+      dg = h_rb[1]; dn = std::sqrt(h_rb[2]);
+      if (!(dg < 0.0)) { st = 0; break; }  // projected gradient is zero
     }
     double step = (hist == 0) ? std::min(1.0, 1.0 / std::max(dn, 1e-300)) : 1.0;
     const double max_step = 2.0;  // minimizer.set_max_step_size(2.0), solve_adept.cpp:331
@@ -982,30 +1162,32 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
     double Jn = J;
     bool ok = false;
     for (int ls = 0; ls < 30; ++ls) {
-      for (size_t i = 0; i < n; ++i) {
-        double v = x[i] + step * d[i];
-        if (bounded) v = std::min(std::max(v, xmin[i]), xmax[i]);
-        if (!(x[i] > MIN_X)) v = x[i];
-        xn[i] = v;
-      }
-      ECCKD_CHECK(ecckd_opt_cost_grad(o, xn.data(), &Jn, gn.data()));
+      hipLaunchKernelGGL(k_vec_step, vb, vt, 0, ctx->stream, n, step, x, o->d_dir, bmin, bmax, xn);
+      ECCKD_CHECK(opt_cost_grad_dev(o, xn, gn, &Jn));
       if (Jn == Jn && Jn <= J + 1.0e-4 * step * dg) { ok = true; break; }
       step *= 0.5;
     }
     if (!ok) { st = 3; break; }
-    // curvature pair
-    std::vector<double> s(n), y(n);
-    double sy = 0.0;
-    for (size_t i = 0; i < n; ++i) { s[i] = xn[i] - x[i]; y[i] = gn[i] - g[i]; sy += s[i] * y[i]; }
+    // curvature pair into the next ring slot
+    const int slot = (hist < M) ? (head + hist) % M : head;
+    hipLaunchKernelGGL(k_vec_pair, vb, vt, 0, ctx->stream, n, x, xn, g, gn, o->d_S + (size_t)slot * n,
+                       o->d_Y + (size_t)slot * n, part, part + VEC_BLOCKS);
+    hipLaunchKernelGGL(k_vec_finish, dim3(1), vt, 0, ctx->stream, 2, part, part + VEC_BLOCKS, part, part, sc_rb);
+    ECCKD_CHECK(readback(2));
+    const double sy = h_rb[0], yy = h_rb[1];
     if (sy > 1.0e-12) {
-      if ((int)S.size() == M) { S.erase(S.begin()); Y.erase(Y.begin()); rho.erase(rho.begin()); }
-      S.push_back(std::move(s)); Y.push_back(std::move(y)); rho.push_back(1.0 / sy);
+      const double rho_gamma[2] = {1.0 / sy, sy / yy};
+      ECCKD_HIP_CHECK(hipMemcpyAsync(sc_rho + slot, &rho_gamma[0], sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      ECCKD_HIP_CHECK(hipMemcpyAsync(sc_gamma, &rho_gamma[1], sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // rho_gamma is a stack temporary
+      if (hist < M) ++hist; else head = (head + 1) % M;
     }
-    x.swap(xn); g.swap(gn); J = Jn;
-    gnorm = pnorm(x, g);
-    if (!(gnorm == gnorm)) { st = 7; break; }
+    std::swap(x, xn);
+    std::swap(g, gn);
+    J = Jn;
   }
-  std::memcpy(h_x, x.data(), n * sizeof(double));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(h_x, x, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   *status = st;
   if (n_iterations) *n_iterations = it;
   if (J_final) *J_final = J;

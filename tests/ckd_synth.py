@@ -7,71 +7,7 @@ import numpy as np
 CONC = {"none": 0, "linear": 1, "lut": 2, "relative-linear": 3}
 
 
-def make_model(ng=12, nt=5, np_=16, nband=3, seed=0):
-    rs = np.random.RandomState(seed)
-    log_p = np.linspace(np.log(2.0), np.log(110000.0), np_)
-    t_mid = 200.0 + 12.0 * (log_p - log_p[0])               # p-dependent temperature grid
-    temperature = t_mid[None, :] + 20.0 * (np.arange(nt)[:, None] - (nt - 1) / 2)
-    tpl = np.arange(120.0, 351.0, 1.0)
-    # Planck function per g point: a few "spectral" bins of sigma T^4 shape
-    centre = np.linspace(300.0, 1500.0, ng)
-    x = 1.4388 * centre[None, :] / tpl[:, None]
-    planck = 8.0 * centre[None, :] ** 3 / np.expm1(x) * 1e-7
-    iband = np.sort(rs.randint(0, nband, ng)).astype(np.int32)
-    iband[0], iband[-1] = 0, nband - 1
-    for b in range(nband):                                  # every band populated
-        if not (iband == b).any():
-            iband[b] = b
-    iband = np.sort(iband)
-    g_strength = 10.0 ** np.linspace(-3.0, 1.5, ng)         # weak ... strong g points
-
-    def lut(nconc=None, scale=1.0):
-        shape = (nt, np_, ng) if nconc is None else (nconc, nt, np_, ng)
-        base = scale * g_strength * (1.0 + 0.3 * rs.uniform(size=shape))
-        pfac = np.exp(0.4 * (log_p - log_p[-1]))[:, None]   # pressure broadening-ish
-        base = base * (0.2 + pfac) if nconc is None else base * (0.2 + pfac)[None, None]
-        return base
-
-    vmr_h2o = np.exp(np.linspace(np.log(1e-6), np.log(4e-2), 4))
-    gases = [
-        dict(name="composite", conc="none", active=True, molar_abs=lut(scale=2e-4)),
-        dict(name="h2o", conc="lut", active=True, molar_abs=lut(4, scale=3.0), vmr=vmr_h2o),
-        dict(name="co2", conc="linear", active=True, molar_abs=lut(scale=30.0)),
-        dict(name="ch4", conc="relative-linear", active=True, molar_abs=lut(scale=50.0), reference_vmr=1.8e-6),
-        dict(name="o3", conc="linear", active=False, molar_abs=lut(scale=500.0)),
-    ]
-    gases[1]["molar_abs"][:, :, :, 0] = 0.0                 # a g point where h2o does not absorb: x pinned at MIN_X
-    for g in gases:
-        g["min_molar_abs"] = g["molar_abs"] * 0.5
-        g["max_molar_abs"] = g["molar_abs"] * 2.0
-    gases[2]["min_molar_abs"] = gases[2]["min_molar_abs"].copy()
-    gases[2]["min_molar_abs"][:, :, 3] = 0.0                # exercises the k_min == 0 bound rule
-    return dict(log_pressure=log_p, temperature=temperature, temperature_planck=tpl, planck_function=planck,
-                iband_per_g=iband, gases=gases, nband=nband)
-
-
-def make_scenes(model, nscene=2, ncol=4, nlay=18, seed=1, ch4_low=False):
-    rs = np.random.RandomState(seed)
-    ngas = len(model["gases"])
-    scenes = []
-    for s in range(nscene):
-        p = np.empty((ncol, nlay + 1))
-        T = np.empty((ncol, nlay + 1))
-        vmr = np.empty((ncol, ngas, nlay))
-        for c in range(ncol):
-            p[c] = np.concatenate([[1.0], np.exp(np.linspace(np.log(5.0), np.log(101325.0 - 2000 * c), nlay))])
-            T[c] = 210.0 + 80.0 * (p[c] / p[c, -1]) ** 0.25 + rs.uniform(-3, 3, nlay + 1) + 4.0 * s
-            pf = 0.5 * (p[c, 1:] + p[c, :-1]) / p[c, -1]
-            vmr[c, 0] = 1.0
-            vmr[c, 1] = np.clip(2e-2 * pf ** 3 * (1 + 0.5 * s) * rs.uniform(0.5, 1.5), 2e-6, 5e-2)
-            vmr[c, 2] = 4e-4 * (1.0 + s)
-            vmr[c, 3] = (0.9e-6 if ch4_low else 1.8e-6 * (1.0 + 0.5 * s)) * np.ones(nlay)
-            vmr[c, 4] = 5e-6 * np.exp(-((np.log(pf) + 5.0) / 1.5) ** 2) + 2e-8
-        present = np.ones(ngas, dtype=np.int32)
-        if s == 1:
-            present[4] = 0                                  # o3 missing from the second training file
-        scenes.append(dict(pressure_hl=p, temperature_hl=T, vmr_fl=vmr, gas_present=present))
-    return scenes
+from ecckd_amd.synthetic import ckd_model as make_model, ckd_scenes as make_scenes  # noqa: E402,F401
 
 
 class Oracle:
