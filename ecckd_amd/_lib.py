@@ -21,6 +21,9 @@ AVG = {
     "square-root": 3,
     "logarithmic": 4,
     "total-transmission": 5,
+    "transmission-3": 6,
+    "transmission-10": 7,
+    "hybrid-logarithmic-transmission-3": 8,
 }
 
 
@@ -109,6 +112,15 @@ SIGNATURES = {
     "ecckd_opt_coefficients": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, _c_double_p]),
     "ecckd_opt_minimize": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, _c_double_p, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), _c_double_p, _c_double_p]),
+    "ecckd_gmap_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_void_p)]),
+    "ecckd_gmap_destroy": (C.c_int, [C.c_void_p]),
+    "ecckd_gmap_counts": (C.c_int, [C.c_void_p, _c_int64_p]),
+    "ecckd_average_to_gpoints": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_size_t, C.c_int, C.c_double, _c_double_p, _c_double_p,
+                                           _c_double_p]),
+    "ecckd_gpoint_fraction": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p]),
+    "ecckd_planck_lut": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p]),
     "ecckd_find_g_band": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_int,
                                     C.c_int, C.c_int, C.POINTER(C.c_int), _c_double_p, _c_double_p, C.c_int,
                                     C.POINTER(C.c_int), _c_double_p]),

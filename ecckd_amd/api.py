@@ -557,3 +557,69 @@ class Optimizer:
         check(self.lib.ecckd_opt_minimize(self.handle, int(max_iterations), float(convergence_criterion),
                                           int(bounded), _hptr(x), C.byref(st), C.byref(it), C.byref(J), C.byref(gn)))
         return dict(x=x, status=st.value, iterations=it.value, cost=J.value, gradient_norm=gn.value)
+
+
+# ---------------------------------------------------------------------------------------
+# create_look_up_table
+
+class GPointMap:
+    """ecckd_gmap_*: wavenumbers sorted by g point; the segmented reductions of
+    create_look_up_table.cpp (average_optical_depth_to_g_point, gpoint_fraction, Planck LUT)."""
+
+    def __init__(self, ctx, g_point, ng, wavenumber, d_wavenumber):
+        self.ctx, self.lib, self.ng = ctx, ctx.lib, int(ng)
+        self.nwav = g_point.numel()
+        h = C.c_void_p()
+        ctx.fence_from_torch()
+        check(self.lib.ecckd_gmap_create(ctx.handle, self.nwav, _dptr(g_point), self.ng, _dptr(wavenumber),
+                                         _dptr(d_wavenumber), C.byref(h)))
+        self.handle = h
+        ctx._children.add(self)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            if self.ctx.handle:
+                self.lib.ecckd_gmap_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counts(self):
+        c = np.empty(self.ng, dtype=np.int64)
+        check(self.lib.ecckd_gmap_counts(self.handle, _hptr(c, C.c_int64)))
+        return c
+
+    def average_optical_depth(self, pressure_hl, optical_depth, averaging_method="transmission",
+                              reference_surface_vmr=1.0, temperature_fl=None, ssi=None):
+        """average_optical_depth_to_g_point -> (molar_abs, min_molar_abs, max_molar_abs), each (nlay, ng)."""
+        p = np.ascontiguousarray(pressure_hl, dtype=np.float64)
+        nlay = p.size - 1
+        if averaging_method not in _lib.AVG:
+            raise EcckdError(_lib.PARAMETER_ERROR, f'averaging_method "{averaging_method}" not understood')
+        t = np.ascontiguousarray(temperature_fl, dtype=np.float64) if temperature_fl is not None else None
+        out = [np.empty((nlay, self.ng)) for _ in range(3)]
+        stride = optical_depth.stride(0) if nlay > 1 else self.nwav
+        self.ctx.fence_from_torch()
+        check(self.lib.ecckd_average_to_gpoints(self.handle, nlay, _hptr(p), _hptr(t) if t is not None else None,
+                                                _dptr(ssi) if ssi is not None else None, _dptr(optical_depth),
+                                                _od_type(optical_depth), stride, _lib.AVG[averaging_method],
+                                                float(reference_surface_vmr), _hptr(out[0]), _hptr(out[1]),
+                                                _hptr(out[2])))
+        return tuple(out)
+
+    def gpoint_fraction(self, wavenumber1, wavenumber2):
+        w1 = np.ascontiguousarray(wavenumber1, dtype=np.float64)
+        w2 = np.ascontiguousarray(wavenumber2, dtype=np.float64)
+        out = np.empty((self.ng, w1.size))
+        check(self.lib.ecckd_gpoint_fraction(self.handle, w1.size, _hptr(w1), _hptr(w2), _hptr(out)))
+        return out
+
+    def planck_lut(self, temperature_lut):
+        t = np.ascontiguousarray(temperature_lut, dtype=np.float64)
+        out = np.empty((t.size, self.ng))
+        check(self.lib.ecckd_planck_lut(self.handle, t.size, _hptr(t), _hptr(out)))
+        return out

@@ -52,6 +52,10 @@ extern "C" {
 #define ECCKD_AVG_SQUARE_ROOT 3
 #define ECCKD_AVG_LOGARITHMIC 4
 #define ECCKD_AVG_TOTAL_TRANSMISSION 5
+/* create_look_up_table only, average_optical_depth.cpp:60-126 */
+#define ECCKD_AVG_TRANSMISSION_3 6
+#define ECCKD_AVG_TRANSMISSION_10 7
+#define ECCKD_AVG_HYBRID_LOG_TRANSMISSION_3 8
 
 typedef struct ecckd_ctx ecckd_ctx;
 
@@ -283,6 +287,34 @@ int ecckd_opt_coefficients(ecckd_opt* opt, const double* h_x, int gas, double* h
  * >= 6 anomalous (optimize_lut.cpp:315-319 exits 1 for those) */
 int ecckd_opt_minimize(ecckd_opt* opt, int max_iterations, double convergence_criterion, int is_bounded,
                        double* h_x, int* status, int* n_iterations, double* J_final, double* gnorm_final);
+
+/* ---- create_look_up_table (K6/K7) ----------------------------------------------
+ * A g-point map: the wavenumbers sorted by g point once (stable), so that every g point is a
+ * contiguous segment.  d_g_point[nwav] as read from the g-points file (-1 = unassigned,
+ * create_look_up_table.cpp:92-106); wavenumbers must ascend. */
+typedef struct ecckd_gmap ecckd_gmap;
+int ecckd_gmap_create(ecckd_ctx* ctx, size_t nwav, const int32_t* d_g_point, int ng,
+                      const double* d_wavenumber, const double* d_d_wavenumber, ecckd_gmap** gmap);
+int ecckd_gmap_destroy(ecckd_gmap* gmap);
+/* wavenumbers per g point: zero = "occupies none of the spectrum" (create_look_up_table.cpp:111-118) */
+int ecckd_gmap_counts(ecckd_gmap* gmap, int64_t* h_counts);
+
+/* Replaces average_optical_depth_to_g_point (average_optical_depth.cpp:22-197) for one column:
+ * weights are the Planck function at h_temperature_fl[nlay] (longwave,
+ * create_look_up_table.cpp:316-327) or d_ssi[nwav] (shortwave, :335); exactly one of the two
+ * must be given.  Outputs (nlay, ng) row-major; min/max may be NULL.  reference_surface_vmr <= 0
+ * returns optical depths instead of molar absorption (:186-193). */
+int ecckd_average_to_gpoints(ecckd_gmap* gmap, int nlay, const double* h_pressure_hl,
+                             const double* h_temperature_fl, const double* d_ssi,
+                             const void* d_od, int od_type, size_t od_stride, int averaging_method,
+                             double reference_surface_vmr, double* h_molar_abs,
+                             double* h_min_molar_abs, double* h_max_molar_abs);
+/* create_look_up_table.cpp:537-548: h_gpoint_fraction[ng][nint] over the coarse intervals
+ * (wavenumber1, wavenumber2] */
+int ecckd_gpoint_fraction(ecckd_gmap* gmap, int nint, const double* h_wavenumber1,
+                          const double* h_wavenumber2, double* h_gpoint_fraction);
+/* create_look_up_table.cpp:581-591: h_planck_lut[nlut][ng] */
+int ecckd_planck_lut(ecckd_gmap* gmap, int nlut, const double* h_temperature_lut, double* h_planck_lut);
 
 #ifdef __cplusplus
 }

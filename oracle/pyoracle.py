@@ -19,7 +19,8 @@ dp = C.POINTER(C.c_double)
 i32p = C.POINTER(C.c_int32)
 
 AVG = {"linear": 0, "transmission": 1, "transmission-2": 2, "square-root": 3,
-       "logarithmic": 4, "total-transmission": 5}
+       "logarithmic": 4, "total-transmission": 5, "transmission-3": 6, "transmission-10": 7,
+       "hybrid-logarithmic-transmission-3": 8}
 
 
 def build(force=False):
@@ -292,3 +293,37 @@ class RefEquipartition:
                                           C.c_double(boundn), C.byref(ni), _p(b), _p(err), C.c_int(cap))
         n = ni.value
         return st, b[:n + 1].copy(), err[:n].copy()
+
+
+def average_optical_depth_to_g_point(ng, reference_surface_vmr, pressure_hl, g_point, od, weight, method):
+    """a15; returns (molar_abs, min, max, n_empty), each (nlay, ng)."""
+    od, weight = _f64(od), _f64(weight)
+    nlay, nwav = od.shape
+    p = _f64(pressure_hl)
+    pfl = _f64(0.5 * (p[1:] + p[:-1]))
+    gp = np.ascontiguousarray(g_point, dtype=np.int32)
+    out = [np.empty((nlay, ng)) for _ in range(3)]
+    L = lib()
+    L.orc_average_optical_depth_to_g_point.restype = C.c_int
+    ne = L.orc_average_optical_depth_to_g_point(C.c_int(ng), C.c_double(reference_surface_vmr), C.c_int(nlay),
+                                                C.c_size_t(nwav), _p(pfl), _p(p), _p(gp, C.c_int32), _p(od),
+                                                _p(weight), C.c_int(AVG[method]), _p(out[0]), _p(out[1]), _p(out[2]))
+    return out[0], out[1], out[2], ne
+
+
+def gpoint_fraction(ng, g_point, wavenumber, d_wavenumber, wavenumber1, wavenumber2):
+    gp = np.ascontiguousarray(g_point, dtype=np.int32)
+    w1, w2 = _f64(wavenumber1), _f64(wavenumber2)
+    out = np.empty((ng, w1.size))
+    lib().orc_gpoint_fraction(C.c_int(ng), C.c_int(w1.size), C.c_size_t(gp.size), _p(gp, C.c_int32), _p(_f64(wavenumber)),
+                              _p(_f64(d_wavenumber)), _p(w1), _p(w2), _p(out))
+    return out
+
+
+def planck_lut(ng, temperature_lut, g_point, wavenumber, d_wavenumber):
+    gp = np.ascontiguousarray(g_point, dtype=np.int32)
+    t = _f64(temperature_lut)
+    out = np.empty((t.size, ng))
+    lib().orc_planck_lut(C.c_int(ng), C.c_int(t.size), _p(t), C.c_size_t(gp.size), _p(gp, C.c_int32),
+                         _p(_f64(wavenumber)), _p(_f64(d_wavenumber)), _p(out))
+    return out
