@@ -121,6 +121,13 @@ SIGNATURES = {
                                            _c_double_p]),
     "ecckd_gpoint_fraction": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p]),
     "ecckd_planck_lut": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p]),
+    "ecckd_overlap_g_points": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _c_double_p, C.c_int,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int)]),
+    "ecckd_gas_g_point_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, _c_int32_p, _c_int32_p,
+                                        C.c_void_p]),
+    "ecckd_merge_g_points_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int,
+                                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, _c_int64_p]),
     "ecckd_find_g_band": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_int,
                                     C.c_int, C.c_int, C.POINTER(C.c_int), _c_double_p, _c_double_p, C.c_int,
                                     C.POINTER(C.c_int), _c_double_p]),

@@ -623,3 +623,57 @@ class GPointMap:
         out = np.empty((t.size, self.ng))
         check(self.lib.ecckd_planck_lut(self.handle, t.size, _hptr(t), _hptr(out)))
         return out
+
+
+# ---------------------------------------------------------------------------------------
+# find_g_points: overlap of the gases' g points (a14)
+
+def overlap_g_points(n_g_points, sorting_variables):
+    """overlap_g_points (single_gas_data.cpp:24-124).  n_g_points: (ngas, nband) ints;
+    sorting_variables: list of per-gas arrays (one value per single-gas g point).
+    Returns (ng, band_number[ng], g_min[ngas, ng], g_max[ngas, ng])."""
+    lib = _lib.load_library()
+    ngp = np.ascontiguousarray(n_g_points, dtype=np.int32)
+    ngas, nband = ngp.shape
+    offs = np.zeros(ngas, dtype=np.int32)
+    offs[1:] = np.cumsum([len(sv) for sv in sorting_variables])[:-1]
+    sv = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64) for x in sorting_variables]))
+    cap = int(ngp.sum()) + 1
+    ng = C.c_int()
+    band = np.empty(cap, dtype=np.int32)
+    gmin = np.empty((ngas, cap), dtype=np.int32)
+    gmax = np.empty((ngas, cap), dtype=np.int32)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    check(lib.ecckd_overlap_g_points(ngas, nband, ip(ngp), ip(offs), _hptr(sv), cap, C.byref(ng), ip(band), ip(gmin),
+                                     ip(gmax)))
+    n = ng.value
+    return n, band[:n].copy(), gmin[:, :n].copy(), gmax[:, :n].copy()
+
+
+def gas_g_point(ctx, rank, rank1, rank2):
+    """SingleGasData::store_g_points (single_gas_data.h:56-62) -> int32 device tensor."""
+    torch = _torch()
+    r1 = np.ascontiguousarray(rank1, dtype=np.int32)
+    r2 = np.ascontiguousarray(rank2, dtype=np.int32)
+    out = torch.empty(rank.numel(), dtype=torch.int32, device=ctx.device)
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_gas_g_point_dev(ctx.handle, rank.numel(), _dptr(rank), r1.size, _hptr(r1, C.c_int32),
+                                        _hptr(r2, C.c_int32), _dptr(out)))
+    return out
+
+
+def merge_g_points(ctx, gas_g_points, g_min, g_max):
+    """find_g_points.cpp:1459-1475 -> (g_point int32 device tensor, number unassigned)."""
+    torch = _torch()
+    gmin = np.ascontiguousarray(g_min, dtype=np.int32)
+    gmax = np.ascontiguousarray(g_max, dtype=np.int32)
+    ngas, ng = gmin.shape
+    n = gas_g_points[0].numel()
+    ptrs = (C.c_void_p * ngas)(*[t.data_ptr() for t in gas_g_points])
+    out = torch.empty(n, dtype=torch.int32, device=ctx.device)
+    cnt = C.c_int64()
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_merge_g_points_dev(ctx.handle, n, ngas, ptrs, ng, ng, ip(gmin), ip(gmax), _dptr(out),
+                                           C.byref(cnt)))
+    return out, cnt.value

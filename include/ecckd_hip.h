@@ -316,6 +316,24 @@ int ecckd_gpoint_fraction(ecckd_gmap* gmap, int nint, const double* h_wavenumber
 /* create_look_up_table.cpp:581-591: h_planck_lut[nlut][ng] */
 int ecckd_planck_lut(ecckd_gmap* gmap, int nlut, const double* h_temperature_lut, double* h_planck_lut);
 
+/* ---- find_g_points: spectral overlap of the gases (a14) ----------------------
+ * ecckd_overlap_g_points replaces overlap_g_points (single_gas_data.cpp:24-124), host-side:
+ *   h_n_g_points[ngas][nband]; h_sorting_variable = the gases' per-g-point median sorting
+ *   variables concatenated, gas i starting at h_gas_offset[i]; outputs *h_ng,
+ *   h_band_number[capacity], h_g_min/h_g_max[ngas][capacity].
+ * ecckd_gas_g_point_dev replaces SingleGasData::store_g_points (single_gas_data.h:56-62);
+ * ecckd_merge_g_points_dev replaces find_g_points.cpp:1459-1475 (h_d_gas_g_point: host array
+ * of ngas device pointers; g_min/g_max rows have `stride` elements). */
+int ecckd_overlap_g_points(int ngas, int nband, const int* h_n_g_points, const int* h_gas_offset,
+                           const double* h_sorting_variable, int capacity, int* h_ng,
+                           int* h_band_number, int* h_g_min, int* h_g_max);
+int ecckd_gas_g_point_dev(ecckd_ctx* ctx, size_t nwav, const int32_t* d_rank, int ng,
+                          const int32_t* h_rank1, const int32_t* h_rank2, int32_t* d_g_point);
+int ecckd_merge_g_points_dev(ecckd_ctx* ctx, size_t nwav, int ngas,
+                             const int32_t* const* h_d_gas_g_point, int ng, int stride,
+                             const int* h_g_min, const int* h_g_max, int32_t* d_g_point,
+                             int64_t* h_n_unassigned);
+
 #ifdef __cplusplus
 }
 #endif

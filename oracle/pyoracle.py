@@ -327,3 +327,40 @@ def planck_lut(ng, temperature_lut, g_point, wavenumber, d_wavenumber):
     lib().orc_planck_lut(C.c_int(ng), C.c_int(t.size), _p(t), C.c_size_t(gp.size), _p(gp, C.c_int32),
                          _p(_f64(wavenumber)), _p(_f64(d_wavenumber)), _p(out))
     return out
+
+
+def overlap_g_points(n_g_points, sorting_variables):
+    """a14 -- pure-Python restatement of overlap_g_points, reference src/ecckd/single_gas_data.cpp:24-124
+    (small integer logic).  Returns (ng, band_number, g_min[ngas][ng], g_max[ngas][ng])."""
+    ngp = np.asarray(n_g_points)
+    ngas, nband = ngp.shape
+    ng_band = [1 - ngas + int(ngp[:, b].sum()) for b in range(nband)]           # :30-38
+    ng = sum(ng_band)
+    band_number = np.repeat(np.arange(nband), ng_band)
+    g_min = np.zeros((ngas, ng), dtype=np.int64)
+    g_max = np.zeros((ngas, ng), dtype=np.int64)
+    ig = 0
+    ig_gas = [0] * ngas
+    for b in range(nband):
+        start = list(ig_gas)
+        for i in range(ngas):                                                    # :63-70
+            g_min[i, ig] = g_max[i, ig] = start[i]
+        for _ in range(1, ng_band[b]):
+            best, found = 1.0e30, -1
+            for i in range(ngas):                                                # :73-90
+                mine = 1.0e30
+                if ig_gas[i] < start[i] + ngp[i, b] - 1:
+                    mine = sorting_variables[i][ig_gas[i] + 1]
+                if mine < best:
+                    best, found = mine, i
+            assert found >= 0
+            ig_gas[found] += 1
+            ig += 1
+            for i in range(ngas):                                                # :103-112
+                if i == found:
+                    g_min[i, ig] = g_max[i, ig] = ig_gas[i]
+                else:
+                    g_min[i, ig], g_max[i, ig] = start[i], ig_gas[i]
+        ig += 1                                                                  # :118-121
+        ig_gas = [v + 1 for v in ig_gas]
+    return ng, band_number, g_min, g_max
