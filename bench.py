@@ -176,7 +176,7 @@ def main():
         st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance,
                                        args.max_iterations)
         gas.close()
-        info.update(ng=len(e), status=st, comp_cost=cc)
+        info.update(ng=len(e), status=st, comp_cost=cc, cost=float(np.sum(e)))
         return 1.0 + cc  # passes over the spectrum in this step
 
     def barrier():
@@ -197,13 +197,9 @@ def main():
     dt = time.perf_counter() - t0
     rt_calls, rt_ms, rt_pts = ctx.profile_get("k_rt_lw_bb")
     k1_calls, k1_ms, k1_pts = ctx.profile_get("k_reorder_key_lw")
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        pp = torch.tensor([passes], dtype=torch.float64, device=dev)
-        dist.all_reduce(pp, op=dist.ReduceOp.SUM)
-        passes = float(pp.item())
+    # the single collective of the path: max elapsed, total passes, total final cost (RCCL over xGMI)
+    from ecckd_amd import shard
+    dt, passes, total_cost = shard.reduce_scalars(dt, passes, info.get("cost", 0.0), device=dev)
 
     if rank == 0:
         points = nwav * passes
@@ -229,7 +225,7 @@ def main():
                                    "rank, nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging transmission"
                                    % (nwav, nlay, args.tolerance),
                        "n_pass_per_step": (passes / args.steps / world) - 1.0, "ng": info.get("ng"),
-                       "search_status": info.get("status")},
+                       "search_status": info.get("status"), "final_cost_sum_K_per_day": total_cost},
             "roofline": {"bound": "hbm", "kernel": "k_rt_lw_bb", "achieved": rt_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": rt_gbs / HBM_PEAK_GBS, "traffic": None,
                          "launches": rt_calls, "avg_launch_ms": rt_ms / max(rt_calls, 1),
