@@ -23,6 +23,7 @@
 // fixed order (bitwise reproducible; no float atomics).
 #include "common.hpp"
 #include "partition_search.hpp"
+#include "fastmath.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -184,7 +185,7 @@ k_gas_prep_lw(int nlay, size_t n, size_t src_stride, int method,
   const double pref = (dw * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq);
   auto planck_at = [&](int lev) -> double {
     if (planck_reuse) return planck_reuse[(size_t)lev * n + i];
-    return pref / (exp(freq * hk[lev]) - 1.0);
+    return ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[lev]) - 1.0);
   };
 
   double b_prev = planck_at(0);
@@ -195,8 +196,8 @@ k_gas_prep_lw(int nlay, size_t n, size_t src_stride, int method,
     const double od = (double)od_src[(size_t)l * src_stride + j];
     const double tau = bg + od;  // find_g_points.cpp:993
     // radiative_transfer_lw.cpp:41-43
-    const double eps = 1.0 - exp(-kD * tau);
-    const double fac = (eps > 1.0e-5) ? 1.0 - eps * (1.0 / kD) / tau : 0.5 * eps;
+    const double eps = 1.0 - ecckd::exp_fast(-kD * tau);
+    const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;
     const double b_next = planck_at(l + 1);
     const double dn_next = dn * (1.0 - eps) + b_prev * (eps - fac) + b_next * fac;
     s_col[l * bs + tid] = dn_next - dn;
@@ -224,8 +225,8 @@ k_gas_prep_lw(int nlay, size_t n, size_t src_stride, int method,
     const double bg = bg_src ? (double)bg_src[(size_t)l * src_stride + j] : 0.0;
     const double od = (double)od_src[(size_t)l * src_stride + j];
     const double tau = bg + od;
-    const double eps = 1.0 - exp(-kD * tau);
-    const double fac = (eps > 1.0e-5) ? 1.0 - eps * (1.0 / kD) / tau : 0.5 * eps;
+    const double eps = 1.0 - ecckd::exp_fast(-kD * tau);
+    const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;
     const double b_l = planck_at(l);
     const double up_l = up * (1.0 - eps) + b_prev * (eps - fac) + b_l * fac;
     // heating_rate.h:47-48

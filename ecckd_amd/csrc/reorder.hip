@@ -17,6 +17,7 @@
 // the per-layer net-flux increments of the down sweep in LDS, so HBM traffic
 // is the algorithmic minimum: nlay*sizeof(od) + 16 B read, 16 B written.
 #include "common.hpp"
+#include "fastmath.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -70,7 +71,7 @@ k_reorder_key_lw(int nlay, size_t nwav, size_t od_stride, const double* __restri
                       (freq * freq * freq);
 
   // ---- down sweep (radiative_transfer_lw.cpp:45-50) ----
-  double b_prev = pref / (exp(freq * hk[0]) - 1.0);
+  double b_prev = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[0]) - 1.0);
   double dn = 0.0;
   double col = 0.0;
   double thr_height = 0.0;
@@ -78,10 +79,10 @@ k_reorder_key_lw(int nlay, size_t nwav, size_t od_stride, const double* __restri
   const OdT* odp = od + j;
   for (int l = 0; l < nlay; ++l) {
     const double tau = (double)odp[(size_t)l * od_stride];
-    const double eps = 1.0 - exp(-ECCKD_LW_DIFFUSIVITY * tau);
+    const double eps = 1.0 - ecckd::exp_fast(-ECCKD_LW_DIFFUSIVITY * tau);
     // :42-43  factor = eps > 1e-5 ? 1 - eps*(1/D)/tau : 0.5*eps
-    const double fac = (eps > 1.0e-5) ? 1.0 - eps * (1.0 / ECCKD_LW_DIFFUSIVITY) / tau : 0.5 * eps;
-    const double b_next = pref / (exp(freq * hk[l + 1]) - 1.0);
+    const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / ECCKD_LW_DIFFUSIVITY), tau) : 0.5 * eps;
+    const double b_next = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[l + 1]) - 1.0);
     const double dn_next = dn * (1.0 - eps) + b_prev * (eps - fac) + b_next * fac;
     s_col[l * bs + tid] = dn_next - dn;
     // reorder_spectrum.cpp:199-222 (threshold height; in LW only its throw is observable)
@@ -102,9 +103,9 @@ k_reorder_key_lw(int nlay, size_t nwav, size_t od_stride, const double* __restri
   double up = b_prev * 1.0 + (1.0 - 1.0) * dn;
   for (int l = nlay - 1; l >= 0; --l) {
     const double tau = (double)odp[(size_t)l * od_stride];
-    const double eps = 1.0 - exp(-ECCKD_LW_DIFFUSIVITY * tau);
-    const double fac = (eps > 1.0e-5) ? 1.0 - eps * (1.0 / ECCKD_LW_DIFFUSIVITY) / tau : 0.5 * eps;
-    const double b_l = pref / (exp(freq * hk[l]) - 1.0);
+    const double eps = 1.0 - ecckd::exp_fast(-ECCKD_LW_DIFFUSIVITY * tau);
+    const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / ECCKD_LW_DIFFUSIVITY), tau) : 0.5 * eps;
+    const double b_l = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[l]) - 1.0);
     const double up_l = up * (1.0 - eps) + b_prev * (eps - fac) + b_l * fac;
     // heating_rate.h:47-48: conv * (dn[l+1]-dn[l]-up[l+1]+up[l]), left to right
     double hr = conv[l] * (s_col[l * bs + tid] - up + up_l);
@@ -124,6 +125,81 @@ k_reorder_key_lw(int nlay, size_t nwav, size_t od_stride, const double* __restri
   }
   double k = num / den;
   // :187-190
+  if (thr > 0.0 && col < thr) k = -thr + col;
+  key[j] = k;
+  col_od_out[j] = col;
+}
+
+
+// K1 fast path: NLAY known at compile time, one wave per SIMD (512 registers per lane: the
+// per-layer flux increment, emissivity and upward source of the whole column stay in
+// VGPR/AGPRs), ONE Planck exp and ONE emissivity exp per layer instead of two each, no LDS.
+template <int NLAY, typename OdT>
+__global__ void __launch_bounds__(KEY_THREADS, 1)
+k_reorder_key_lw_fast(size_t nwav, size_t od_stride, const double* __restrict__ lev,
+                      const double* __restrict__ wn, const double* __restrict__ dwn,
+                      const OdT* __restrict__ od, double thr, double* __restrict__ key,
+                      double* __restrict__ col_od_out, int* __restrict__ err_flag) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nwav) return;
+  const LevelLayout L{NLAY};
+  const double* hk = lev + L.hk();
+  const double* conv = lev + L.conv();
+  const double* dh = lev + L.dh();
+  const double* dhph = lev + L.dhph();
+  const double* phhl = lev + L.phhl();
+  const double inv_cm_2_Hz = 100.0 * kLightC;
+  const double freq = wn[j] * inv_cm_2_Hz;
+  const double pref = (dwn[j] * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) *
+                      (freq * freq * freq);
+  const OdT* odp = od + j;
+  OdT tau_in[NLAY];
+#pragma unroll
+  for (int l = 0; l < NLAY; ++l) tau_in[l] = odp[(size_t)l * od_stride];
+
+  double dd[NLAY];  // dn[l+1] - dn[l], later the clamped heating rate
+  double ee[NLAY];  // emissivity
+  double ss[NLAY];  // upward source B_{l+1}(eps - fac) + B_l fac
+  double b_prev = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[0]) - 1.0);
+  double dn = 0.0, col = 0.0, thr_height = 0.0;
+  bool crossed = false;
+#pragma unroll
+  for (int l = 0; l < NLAY; ++l) {
+    const double tau = (double)tau_in[l];
+    const double eps = 1.0 - ecckd::exp_fast(-ECCKD_LW_DIFFUSIVITY * tau);
+    const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / ECCKD_LW_DIFFUSIVITY), tau) : 0.5 * eps;
+    const double b_next = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[l + 1]) - 1.0);
+    const double emf = eps - fac;
+    const double dn_next = dn * (1.0 - eps) + b_prev * emf + b_next * fac;
+    dd[l] = dn_next - dn;
+    ee[l] = eps;
+    ss[l] = b_next * emf + b_prev * fac;
+    const double next_col = col + tau;
+    if (!crossed && next_col >= thr) {
+      thr_height = ((thr - col) * phhl[l + 1] + (next_col - thr) * phhl[l]) / fmax(1.0e-12, tau);
+      crossed = true;
+    }
+    col = next_col;
+    dn = dn_next;
+    b_prev = b_next;
+  }
+  if (col > thr && thr_height > 30.0) atomicOr(err_flag, 1);
+  double up = b_prev * 1.0 + (1.0 - 1.0) * dn;
+#pragma unroll
+  for (int l = NLAY - 1; l >= 0; --l) {
+    const double up_l = up * (1.0 - ee[l]) + ss[l];
+    double hr = conv[l] * (dd[l] - up + up_l);
+    if (hr > 0.0) hr = 0.0;
+    dd[l] = hr;
+    up = up_l;
+  }
+  double num = 0.0, den = 0.0;
+#pragma unroll
+  for (int l = 0; l < NLAY; ++l) {
+    num += dd[l] * dhph[l];
+    den += dd[l] * dh[l];
+  }
+  double k = num / den;
   if (thr > 0.0 && col < thr) k = -thr + col;
   key[j] = k;
   col_od_out[j] = col;
@@ -246,7 +322,15 @@ int ecckd_reorder_key_lw_dev(ecckd_ctx* ctx, int nlay, size_t nwav, const double
   ECCKD_CHECK(upload_level_consts(ctx, nlay, h_pressure_hl, h_temperature_hl, &d_lev, &d_flag));
   const unsigned blocks = (unsigned)((nwav + threads - 1) / threads);
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
-  if (od_type == ECCKD_F32) {
+  if (nlay == 54) {
+    const unsigned fblocks = (unsigned)((nwav + KEY_THREADS - 1) / KEY_THREADS);
+    if (od_type == ECCKD_F32)
+      hipLaunchKernelGGL((k_reorder_key_lw_fast<54, float>), dim3(fblocks), dim3(KEY_THREADS), 0, ctx->stream, nwav,
+                         od_stride, d_lev, d_wavenumber, d_d_wavenumber, (const float*)d_od, thr, d_key, d_col_od, d_flag);
+    else
+      hipLaunchKernelGGL((k_reorder_key_lw_fast<54, double>), dim3(fblocks), dim3(KEY_THREADS), 0, ctx->stream, nwav,
+                         od_stride, d_lev, d_wavenumber, d_d_wavenumber, (const double*)d_od, thr, d_key, d_col_od, d_flag);
+  } else if (od_type == ECCKD_F32) {
     ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reorder_key_lw<float>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k_reorder_key_lw<float>, dim3(blocks), dim3(threads), lds, ctx->stream, nlay, nwav,
