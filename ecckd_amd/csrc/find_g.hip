@@ -237,6 +237,97 @@ k_gas_prep_lw(int nlay, size_t n, size_t src_stride, int method,
   fut[i] = up;  // flux_up(0,__), find_g_points.cpp:1052
 }
 
+
+// K4 fast path, step 1: transposing scatter.  src is (layer, wavenumber) in ORIGINAL order;
+// dst[rank[j]][NLAY] holds the column of wavenumber j at its SORTED position, contiguous.
+// Reads are coalesced rows through an LDS tile; each point's NLAY values leave as one
+// contiguous wave store.  This replaces 2*NLAY random 4-byte gathers per point (64-byte sectors
+// for 4 useful bytes) by one contiguous NLAY*4-byte segment.
+template <int NLAY, typename SrcT>
+__global__ void __launch_bounds__(256)
+k_scatter_columns(size_t n, size_t src_stride, const int32_t* __restrict__ rank, const SrcT* __restrict__ src,
+                  SrcT* __restrict__ dst) {
+  __shared__ SrcT s_tile[NLAY][65];
+  const size_t j0 = (size_t)blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int l = wave; l < NLAY; l += 4) {
+    const size_t j = j0 + lane;
+    s_tile[l][lane] = (j < n) ? src[(size_t)l * src_stride + j] : (SrcT)0;
+  }
+  __syncthreads();
+  for (int p = wave; p < 64; p += 4) {
+    const size_t j = j0 + p;
+    if (j >= n) break;
+    const size_t r = (size_t)rank[j];
+    if (lane < NLAY) dst[r * NLAY + lane] = s_tile[lane][p];
+  }
+}
+
+// K4 fast path, step 2: as k_gas_prep_lw, NLAY known at compile time, one wave per SIMD, the
+// down-sweep increments / emissivity / upward source of the column in registers (one exp per
+// layer and half level instead of two), no LDS.  Linear/transmission/square-root metrics.
+template <int NLAY, typename BgT, typename OdT>
+__global__ void __launch_bounds__(PREP_THREADS, 1)
+k_gas_prep_lw_fast(size_t n, int method, const int32_t* __restrict__ ireorder, const double* __restrict__ hk,
+                   const double* __restrict__ conv, const double* __restrict__ wn, const double* __restrict__ dwn,
+                   const BgT* __restrict__ bg_col /* [n][NLAY] sorted, or NULL */,
+                   const OdT* __restrict__ od_col /* [n][NLAY] sorted */,
+                   double* __restrict__ wn_sorted, double* __restrict__ dwn_sorted, double* __restrict__ planck_hl,
+                   double* __restrict__ bg_od, double* __restrict__ w1, double* __restrict__ hr,
+                   double* __restrict__ fds, double* __restrict__ fut) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t j = (size_t)ireorder[i];
+  const double w = wn[j], dw = dwn[j];
+  wn_sorted[i] = w;
+  dwn_sorted[i] = dw;
+  const double inv_cm_2_Hz = 100.0 * kLightC;
+  const double freq = w * inv_cm_2_Hz;
+  const double pref = (dw * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq);
+  const BgT* bgc = bg_col ? bg_col + i * NLAY : nullptr;
+  const OdT* odc = od_col + i * NLAY;
+  double dd[NLAY], ee[NLAY], ss[NLAY];
+  double b_prev = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[0]) - 1.0);
+  planck_hl[i] = b_prev;
+  double dn = 0.0;
+#pragma unroll
+  for (int l = 0; l < NLAY; ++l) {
+    const double bg = bgc ? (double)bgc[l] : 0.0;
+    const double od = (double)odc[l];
+    const double tau = bg + od;
+    const double eps = 1.0 - ecckd::exp_fast(-kD * tau);
+    const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;
+    const double b_next = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[l + 1]) - 1.0);
+    const double emf = eps - fac;
+    const double dn_next = dn * (1.0 - eps) + b_prev * emf + b_next * fac;
+    dd[l] = dn_next - dn;
+    ee[l] = eps;
+    ss[l] = b_next * emf + b_prev * fac;
+    const size_t o = (size_t)l * n + i;
+    bg_od[o] = bg;
+    planck_hl[(size_t)(l + 1) * n + i] = b_next;
+    double m;
+    switch (method) {
+      case ECCKD_AVG_TRANSMISSION: m = 1.0 - ecckd::exp_fast(-od * kD); break;
+      case ECCKD_AVG_TRANSMISSION_2: m = 1.0 - ecckd::exp_fast(-od * kD * 2.0); break;
+      case ECCKD_AVG_SQUARE_ROOT: m = sqrt(od); break;
+      default: m = od;
+    }
+    w1[o] = m * b_next;
+    dn = dn_next;
+    b_prev = b_next;
+  }
+  fds[i] = dn;
+  double up = b_prev * 1.0 + (1.0 - 1.0) * dn;
+#pragma unroll
+  for (int l = NLAY - 1; l >= 0; --l) {
+    const double up_l = up * (1.0 - ee[l]) + ss[l];
+    hr[(size_t)l * n + i] = conv[l] * (dd[l] - up + up_l);
+    up = up_l;
+  }
+  fut[i] = up;
+}
+
 // tile sums of every row: TS[r][t] = sum_{i in tile t} rows[r][i]
 __global__ void __launch_bounds__(TILE)
 k_tile_sums(int nrows, size_t n, size_t ntiles, const double* const* __restrict__ rows,
@@ -1061,7 +1152,32 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
                        g->planck_hl, g->bg_od, g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut);                  \
   } while (0)
   const bool bg32 = d_bg_od && bg_type == ECCKD_F32;
-  if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP(float, float);
+  // fast path: 54 layers, FLOAT spectra (as stored in the CKDMIP files), no Planck reuse, no log metric
+  const bool fast = nlay == 54 && od_type == ECCKD_F32 && (!d_bg_od || bg32) && !is_log && !d_planck_hl_reuse;
+  if (fast) {
+    float *od_col = nullptr, *bg_col = nullptr;
+    GTRY(hipMalloc((void**)&od_col, (size_t)nwav * 54 * sizeof(float)));
+    if (d_bg_od) {
+      hipError_t e2 = hipMalloc((void**)&bg_col, (size_t)nwav * 54 * sizeof(float));
+      if (e2 != hipSuccess) { (void)hipFree(od_col); GTRY(e2); }
+    }
+    const unsigned tblocks = (unsigned)((nwav + 63) / 64);
+    hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
+                       (const float*)d_od, od_col);
+    if (d_bg_od)
+      hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
+                         (const float*)d_bg_od, bg_col);
+    const unsigned fblocks = (unsigned)((nwav + PREP_THREADS - 1) / PREP_THREADS);
+    hipLaunchKernelGGL((k_gas_prep_lw_fast<54, float, float>), dim3(fblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav,
+                       averaging_method, g->ireorder, hkd, convd, d_wavenumber, d_d_wavenumber, (const float*)bg_col,
+                       (const float*)od_col, g->wn_sorted, g->dwn_sorted, g->planck_hl, g->bg_od, g->w1, g->hr, g->fds,
+                       g->fut);
+    hipError_t e3 = hipGetLastError();
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(od_col);
+    if (bg_col) (void)hipFree(bg_col);
+    GTRY(e3);
+  } else if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP(float, float);
   else if (bg32) LAUNCH_PREP(float, double);
   else if (od_type == ECCKD_F32) LAUNCH_PREP(double, float);
   else LAUNCH_PREP(double, double);
