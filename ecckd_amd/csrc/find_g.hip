@@ -544,6 +544,51 @@ __device__ __forceinline__ double fast_div(double a, double b) {
   return __builtin_fma(res, y, q);
 }
 
+
+// Emissivity and factor of TWO layers at once with the two dependency chains interleaved in
+// the source: at 2 waves/SIMD the fp64 FMA latency is not covered by other waves, so the
+// instruction-level parallelism has to be in the stream itself (radiative_transfer_lw.cpp:114-119).
+__device__ __forceinline__ void eps_fac_pair(double od0, double od1, double& eps0, double& fac0,
+                                             double& eps1, double& fac1) {
+  constexpr double TE = 1.0e-5;
+  const double y0 = -kD * od0, y1 = -kD * od1;
+  const double k0 = __builtin_rint(y0 * 1.4426950408889634074), k1 = __builtin_rint(y1 * 1.4426950408889634074);
+  double r0 = __builtin_fma(k0, -6.93147180369123816490e-01, y0), r1 = __builtin_fma(k1, -6.93147180369123816490e-01, y1);
+  r0 = __builtin_fma(k0, -1.90821492927058770002e-10, r0); r1 = __builtin_fma(k1, -1.90821492927058770002e-10, r1);
+  // reciprocal seeds issued early: independent of the exp chains
+  const double d0 = fmax(od0, TE / kD), d1 = fmax(od1, TE / kD);
+  double q0 = __builtin_amdgcn_rcp(d0), q1 = __builtin_amdgcn_rcp(d1);
+  double p0 = 2.08767569878680989792e-09, p1 = 2.08767569878680989792e-09;
+#define ECCKD_STEP(c) p0 = __builtin_fma(p0, r0, c); p1 = __builtin_fma(p1, r1, c);
+  ECCKD_STEP(2.50521083854417187751e-08)
+  double e0 = __builtin_fma(-d0, q0, 1.0), e1 = __builtin_fma(-d1, q1, 1.0);
+  ECCKD_STEP(2.75573192239858906526e-07)
+  q0 = __builtin_fma(q0, e0, q0); q1 = __builtin_fma(q1, e1, q1);
+  ECCKD_STEP(2.75573192239858906526e-06)
+  e0 = __builtin_fma(-d0, q0, 1.0); e1 = __builtin_fma(-d1, q1, 1.0);
+  ECCKD_STEP(2.48015873015873015873e-05)
+  q0 = __builtin_fma(q0, e0, q0); q1 = __builtin_fma(q1, e1, q1);
+  ECCKD_STEP(1.98412698412698412698e-04)
+  ECCKD_STEP(1.38888888888888888889e-03)
+  ECCKD_STEP(8.33333333333333333333e-03)
+  ECCKD_STEP(4.16666666666666666667e-02)
+  ECCKD_STEP(1.66666666666666666667e-01)
+  ECCKD_STEP(0.5)
+  ECCKD_STEP(1.0)
+  ECCKD_STEP(1.0)
+#undef ECCKD_STEP
+  const int i0 = (int)fmax(k0, -1100.0), i1 = (int)fmax(k1, -1100.0);
+  eps0 = 1.0 - __builtin_amdgcn_ldexp(p0, i0);
+  eps1 = 1.0 - __builtin_amdgcn_ldexp(p1, i1);
+  // max(eps, TE) / max(od, TE/D) with one residual correction
+  const double n0 = fmax(eps0, TE), n1 = fmax(eps1, TE);
+  double t0 = n0 * q0, t1 = n1 * q1;
+  const double s0 = __builtin_fma(-d0, t0, n0), s1 = __builtin_fma(-d1, t1, n1);
+  t0 = __builtin_fma(s0, q0, t0); t1 = __builtin_fma(s1, q1, t1);
+  fac0 = fmax(1.0 - (1.0 / kD) * t0, 0.5 * TE);
+  fac1 = fmax(1.0 - (1.0 / kD) * t1, 0.5 * TE);
+}
+
 // K5c fast path: NLAY known at compile time.  The whole column (NLAY background
 // optical depths + NLAY+1 Planck values, 109 f64 for NLAY = 54) is loaded into
 // registers once; the down sweep overwrites it in place with the layer
@@ -616,19 +661,20 @@ k_rt_lw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
     };
 
     double flux = 0.0;
+    static_assert(NLAY % 2 == 0, "layers are processed in pairs");
 #pragma unroll
-    for (int l = 0; l < NLAY; ++l) {
-      const double od = a[l] + grey[l];
-      const double eps = 1.0 - exp_nonpos(-kD * od);
-      // radiative_transfer_lw.cpp:117-119
-      const double fac = fmax(1.0 - (1.0 / kD) * fast_div(fmax(eps, THRESHOLD_EMISSIVITY),
-                                                         fmax(od, THRESHOLD_EMISSIVITY / kD)),
-                              0.5 * THRESHOLD_EMISSIVITY);
-      const double emf = eps - fac;
-      flux = flux * (1.0 - eps) + b[l] * emf + b[l + 1] * fac;
-      const double src_up = b[l + 1] * emf + b[l] * fac;  // :138-139 source of the up sweep
-      a[l] = 1.0 - eps;
-      b[l] = src_up;
+    for (int l = 0; l < NLAY; l += 2) {
+      double eps0, fac0, eps1, fac1;
+      eps_fac_pair(a[l] + grey[l], a[l + 1] + grey[l + 1], eps0, fac0, eps1, fac1);
+      const double emf0 = eps0 - fac0, emf1 = eps1 - fac1;
+      const double bl = b[l], bm = b[l + 1], bn = b[l + 2];
+      flux = flux * (1.0 - eps0) + bl * emf0 + bm * fac0;
+      a[l] = 1.0 - eps0;
+      b[l] = bm * emf0 + bl * fac0;        // :138-139 source of the up sweep
+      push(flux);
+      flux = flux * (1.0 - eps1) + bm * emf1 + bn * fac1;
+      a[l + 1] = 1.0 - eps1;
+      b[l + 1] = bn * emf1 + bm * fac1;
       push(flux);
     }
     // surface (:126-128): emissivity 1, surf_planck = planck_hl(NLAY)
