@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--tolerance", type=float, default=0.0161)   # fsck, test/do_all_lw.sh:59-60
     ap.add_argument("--tolerance-tolerance", type=float, default=0.01)  # test/find_g_points_lw.sh
     ap.add_argument("--max-iterations", type=int, default=60)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 15)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lut-opt", action="store_true")
     ap.add_argument("--lut-opt-iterations", type=int, default=40)

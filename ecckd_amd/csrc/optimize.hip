@@ -91,7 +91,7 @@ struct ColConst {  // per-profile constant block layout in d_col: see host code
 // LDS: tau[nlay][ng] | fdn[nhl][ng] | fup[nhl][ng] | Bdn[nhl][nband] | Bup[nhl][nband] |
 //      Gdn[nhl][nband] | Gup[nhl][nband] | red[16]
 __global__ void k_opt_forward_adjoint(
-    int nlay, int ng, int nband, int nent,
+    int nlay, int ng, int ngpad, int nband, int nent,
     const double* __restrict__ k,            // [nk] coefficients of every gas
     const int* __restrict__ ent_idx,         // [ncell][nent] start of an ng-long row of k, or -1
     const double* __restrict__ ent_coef,     // [ncell][nent]
@@ -121,9 +121,15 @@ __global__ void k_opt_forward_adjoint(
   double* s_gdn = s_bup + (size_t)nhl * nband;
   double* s_gup = s_gdn + (size_t)nhl * nband;
   double* s_red = s_gup + (size_t)nhl * nband;
+  unsigned char* s_clamp = (unsigned char*)(s_red + 16);  // [nlay][ng] 1 where a negative optical depth was clamped
   const int col = blockIdx.x;
-  const int g = threadIdx.x;
-  const bool live = g < ng;
+  // blockDim = ngpad * (layer groups): the LUT gather is parallel over (layer group, g); the
+  // sweeps and their adjoint are sequential in the layers and run on the first group only
+  const int g = threadIdx.x % ngpad;
+  const int lgrp = threadIdx.x / ngpad;
+  const int nlgrp = blockDim.x / ngpad;
+  const bool in_range = g < ng;
+  const bool live = in_range && lgrp == 0;
   const double hr_weight = 3600.0 * 24.0;
   const double* pl = planck_hl + (size_t)col * nhl * ng;
   const size_t cell0 = (size_t)col * nlay;
@@ -131,9 +137,8 @@ __global__ void k_opt_forward_adjoint(
   // ---- optical depth: sparse gather (calc_total_optical_depth, solve_adept.cpp:24-69) and
   //      the negative-OD penalty with clamp (:107-116)
   double penalty = 0.0;
-  unsigned long long clamp0 = 0ull, clamp1 = 0ull;  // layers whose negative optical depth was clamped (nlay <= 128)
-  if (live) {
-    for (int l = 0; l < nlay; ++l) {
+  if (in_range) {
+    for (int l = lgrp; l < nlay; l += nlgrp) {
       const int* ei = ent_idx + (cell0 + l) * nent;
       const double* ec = ent_coef + (cell0 + l) * nent;
       double tau = 0.0;
@@ -147,12 +152,15 @@ __global__ void k_opt_forward_adjoint(
         penalty += tau * tau;
         dtau[(cell0 + l) * ng + g] = 2.0 * negative_od_penalty * tau;
         tau = 0.0;
-        if (l < 64) clamp0 |= 1ull << l; else clamp1 |= 1ull << (l - 64);
+        s_clamp[l * ng + g] = 1;
+      } else {
+        s_clamp[l * ng + g] = 0;
       }
       s_tau[l * ng + g] = tau;
       if (od_out) od_out[(cell0 + l) * ng + g] = tau;
     }
   }
+  __syncthreads();
   // ---- forward sweeps (radiative_transfer_lw.cpp:41-59) ----
   if (live) {
     double dn = 0.0;
@@ -288,7 +296,7 @@ __global__ void k_opt_forward_adjoint(
     // forward up[l+1] values: rebuild from the surface
     double up_fwd_next = pl[nlay * ng + g] * es + (1.0 - es) * s_fdn[nlay * ng + g];  // up[nlay]
     for (int l = nlay - 1; l >= 0; --l) {
-      const bool clamped = (l < 64) ? ((clamp0 >> l) & 1ull) : ((clamp1 >> (l - 64)) & 1ull);
+      const bool clamped = s_clamp[l * ng + g] != 0;
       const double tau = s_tau[l * ng + g];
       const double ex = exp(-kD * tau);
       const double eps = 1.0 - ex;
@@ -325,7 +333,7 @@ __global__ void k_opt_forward_adjoint(
 //   grad_k = sum over the cells that reference this node of coef * dtau[cell][g]   (fixed order)
 //   grad_x = grad_k * k + B^-1 (x - x_prior) / sigma_g^2                            (:273-283)
 __global__ void __launch_bounds__(256)
-k_opt_gradient(size_t nx, int ng, const double* __restrict__ x, const double* __restrict__ x_prior,
+k_opt_gradient(size_t nnode, int ng, int ngpad, const double* __restrict__ x, const double* __restrict__ x_prior,
                const double* __restrict__ k, const int* __restrict__ ref_ptr /*[nnode+1]*/,
                const int* __restrict__ ref_cell, const double* __restrict__ ref_coef,
                const double* __restrict__ dtau,
@@ -335,15 +343,26 @@ k_opt_gradient(size_t nx, int ng, const double* __restrict__ x, const double* __
                const int* __restrict__ gas_dims /*[ngas][4]: nconc, nt, np, node0*/,
                const double* __restrict__ tri /* per gas: c(3*nconc) | t(3*nt) | p(3*np) */,
                const int* __restrict__ tri_off /*[ngas]*/, const double* __restrict__ inv_sigma2 /*[ngas][ng]*/,
-               int have_prior, double* __restrict__ grad, double* __restrict__ jb_part /*[nblocks]*/) {
-  __shared__ double s4[4];
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+               int have_prior, double* __restrict__ grad, double* __restrict__ jb_part /*[nnode]*/) {
+  // one block per LUT node; blockDim = ngpad * (reference groups).  The references of a node
+  // (cells that interpolate from it) are dealt round-robin to the groups and the group sums are
+  // combined in group order: a fixed summation order without atomics.
+  extern __shared__ double s_acc[];  // [groups][ngpad] | [4]
+  const size_t node = blockIdx.x;
+  const int g = threadIdx.x % ngpad;
+  const int rg = threadIdx.x / ngpad;
+  const int nrg = blockDim.x / ngpad;
+  double* s4 = s_acc + (size_t)nrg * ngpad;
+  double part = 0.0;
+  if (g < ng)
+    for (int r = ref_ptr[node] + rg; r < ref_ptr[node + 1]; r += nrg) part += ref_coef[r] * dtau[(size_t)ref_cell[r] * ng + g];
+  s_acc[rg * ngpad + g] = part;
+  __syncthreads();
   double jb = 0.0;
-  if (e < nx) {
-    const size_t node = e / ng;
-    const int g = (int)(e % ng);
+  if (rg == 0 && g < ng) {
     double gk = 0.0;
-    for (int r = ref_ptr[node]; r < ref_ptr[node + 1]; ++r) gk += ref_coef[r] * dtau[(size_t)ref_cell[r] * ng + g];
+    for (int q = 0; q < nrg; ++q) gk += s_acc[q * ngpad + g];
+    const size_t e = node * ng + g;
     const double xv = x[e];
     double gx = 0.0;
     if (xv > MIN_X) {
@@ -390,9 +409,14 @@ k_opt_gradient(size_t nx, int ng, const double* __restrict__ x, const double* __
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) jb += __shfl_down(jb, off, 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwave = (blockDim.x + 63) >> 6;
   if (lane == 0) s4[wave] = jb;
   __syncthreads();
-  if (threadIdx.x == 0) jb_part[blockIdx.x] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < nwave; ++w) t += s4[w];
+    jb_part[node] = t;
+  }
 }
 
 // k = exp(x) for the active part (:242-249)
@@ -937,12 +961,12 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
   auto dalloc = [&](double** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(double)); };
   if (dalloc(&o->d_x, o->nx) != hipSuccess || dalloc(&o->d_xprior, o->nx) != hipSuccess ||
       dalloc(&o->d_grad, o->nx) != hipSuccess || dalloc(&o->d_dtau, o->ncell * ng) != hipSuccess ||
-      dalloc(&o->d_jcol, ncol) != hipSuccess || dalloc(&o->d_jb, o->grad_blocks) != hipSuccess) {
+      dalloc(&o->d_jcol, ncol) != hipSuccess || dalloc(&o->d_jb, o->nnode_active) != hipSuccess) {
     opt_free(o);
     return ecckd::fail(ECCKD_OUT_OF_MEMORY, "ecckd_opt_create: device allocation failed");
   }
   o->h_jcol.resize(ncol);
-  o->h_jb.resize(o->grad_blocks);
+  o->h_jb.resize(o->nnode_active);
   // x_prior = ln k0 (MIN_X where k0 <= 0), solve_adept.cpp:335-341
   std::vector<double> xp(o->nx);
   for (size_t e = 0; e < o->nx; ++e) xp[e] = o->h_k0[e] > 0.0 ? std::log(o->h_k0[e]) : MIN_X;
@@ -986,23 +1010,27 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
   ecckd_ctx* ctx = o->ctx;
   hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, d_x, o->d_k);
   const int nlay = o->nlay, nhl = nlay + 1, ng = o->ng, nband = o->nband;
-  const int threads = (ng + 63) / 64 * 64;
-  const size_t lds = ((size_t)nlay * ng + 2 * (size_t)nhl * ng + 4 * (size_t)nhl * nband + 16) * sizeof(double);
+  const int ngpad = (ng + 63) / 64 * 64;
+  const int lgroups = std::max(1, 256 / ngpad);
+  const int threads = ngpad * lgroups;
+  const size_t lds = ((size_t)nlay * ng + 2 * (size_t)nhl * ng + 4 * (size_t)nhl * nband + 16) * sizeof(double) +
+                     ecckd_align_up((size_t)nlay * ng, 16);
   ECCKD_REQUIRE(lds <= 160 * 1024, "ecckd_opt_cost_grad: nlay*ng too large for the per-profile LDS tile (%zu B)", lds);
   ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_opt_forward_adjoint),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL(k_opt_forward_adjoint, dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream, nlay, ng, nband,
+  hipLaunchKernelGGL(k_opt_forward_adjoint, dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream, nlay, ng, ngpad, nband,
                      o->nent, o->d_k, o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_planck, o->d_semis, o->d_conv,
                      o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds, o->d_sfut, o->cfg.flux_weight,
                      o->cfg.flux_profile_weight, o->cfg.broadband_weight, o->cfg.spectral_boundary_weight,
                      o->cfg.negative_od_penalty, o->d_dtau, o->d_jcol, o->d_od_out, o->d_flux_out);
-  hipLaunchKernelGGL(k_opt_gradient, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, ng, d_x, o->d_xprior,
+  hipLaunchKernelGGL(k_opt_gradient, dim3((unsigned)o->nnode_active), dim3(threads),
+                     ((size_t)lgroups * ngpad + 16) * sizeof(double), ctx->stream, o->nnode_active, ng, ngpad, d_x, o->d_xprior,
                      o->d_k, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_dtau, o->d_node_gas, o->d_node_ic,
                      o->d_node_it, o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2,
                      o->have_prior ? 1 : 0, d_grad, o->d_jb);
   ECCKD_HIP_CHECK(hipGetLastError());
   ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jcol.data(), o->d_jcol, o->ncol * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jb.data(), o->d_jb, o->grad_blocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jb.data(), o->d_jb, o->nnode_active * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   double j = 0.0;
   for (double v : o->h_jcol) j += v;  // scene/profile order, as the reference accumulates (:157)
