@@ -208,6 +208,14 @@ def main():
         rt_bytes_per_pt = (2 * nlay + 1) * 8
         rt_gbs = rt_pts * rt_bytes_per_pt / (rt_ms * 1e-3) / 1e9 if rt_ms > 0 else 0.0
         k1_bytes_per_pt = nlay * od.element_size() + 32
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+        # WRITE_SIZE collected separately; 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md section HBM),
+        # scaled to this run's points per launch
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_k_rt_lw_bb.json")
+        if os.path.exists(tpath) and rt_calls:
+            with open(tpath) as f:
+                traffic = json.load(f)["corrected_bytes_per_point"] * rt_pts / rt_calls
         out = {
             "metric": "wavenumber-points/s (LW reorder+find_g)",
             "value": points / dt,
@@ -227,7 +235,8 @@ def main():
                        "n_pass_per_step": (passes / args.steps / world) - 1.0, "ng": info.get("ng"),
                        "search_status": info.get("status"), "final_cost_sum_K_per_day": total_cost},
             "roofline": {"bound": "hbm", "kernel": "k_rt_lw_bb", "achieved": rt_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": rt_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": rt_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": rt_bytes_per_pt * rt_pts / max(rt_calls, 1),
                          "launches": rt_calls, "avg_launch_ms": rt_ms / max(rt_calls, 1),
                          "algorithmic_bytes_per_point": rt_bytes_per_pt,
                          "points_per_launch": rt_pts / max(rt_calls, 1),
