@@ -145,14 +145,17 @@ class OptModel(C.Structure):
     _fields_ = [("ng", C.c_int), ("nt", C.c_int), ("np", C.c_int), ("log_pressure", _c_double_p),
                 ("temperature", _c_double_p), ("ntp", C.c_int), ("temperature_planck", _c_double_p),
                 ("planck_function", _c_double_p), ("iband_per_g", C.POINTER(C.c_int)), ("ngas", C.c_int),
-                ("gases", C.POINTER(OptGas)), ("logarithmic_interpolation", C.c_int)]
+                ("gases", C.POINTER(OptGas)), ("logarithmic_interpolation", C.c_int),
+                ("solar_irradiance", _c_double_p), ("rayleigh_molar_scattering", _c_double_p)]
 
 
 class OptScene(C.Structure):
     _fields_ = [("ncol", C.c_int), ("nlay", C.c_int), ("nband", C.c_int), ("pressure_hl", _c_double_p),
                 ("temperature_hl", _c_double_p), ("vmr_fl", _c_double_p), ("gas_present", C.POINTER(C.c_int)),
                 ("surf_emissivity", _c_double_p), ("flux_dn", _c_double_p), ("flux_up", _c_double_p),
-                ("spectral_flux_dn_surf", _c_double_p), ("spectral_flux_up_toa", _c_double_p)]
+                ("spectral_flux_dn_surf", _c_double_p), ("spectral_flux_up_toa", _c_double_p),
+                ("mu0", _c_double_p), ("tsi", C.c_double), ("albedo", _c_double_p),
+                ("spectral_boundary_weights", _c_double_p)]
 
 
 class OptConfig(C.Structure):

@@ -464,18 +464,24 @@ class Optimizer:
             gases[i].min_molar_abs = ptr(f64(g["min_molar_abs"])) if g.get("min_molar_abs") is not None else None
             gases[i].max_molar_abs = ptr(f64(g["max_molar_abs"])) if g.get("max_molar_abs") is not None else None
         temp = f64(model["temperature"])
-        pf = f64(model["planck_function"])
         m = _lib.OptModel()
-        m.ng, m.nt, m.np = pf.shape[1], temp.shape[0], temp.shape[1]
+        if model.get("planck_function") is not None:
+            pf = f64(model["planck_function"])
+            m.ng, m.ntp = pf.shape[1], pf.shape[0]
+            m.temperature_planck = ptr(f64(model["temperature_planck"]))
+            m.planck_function = ptr(pf)
+        else:                                      # shortwave model: solar irradiance instead of a Planck LUT
+            m.ng, m.ntp = len(model["solar_irradiance"]), 0
+        m.nt, m.np = temp.shape[0], temp.shape[1]
         m.log_pressure = ptr(f64(model["log_pressure"]))
         m.temperature = ptr(temp)
-        m.ntp = pf.shape[0]
-        m.temperature_planck = ptr(f64(model["temperature_planck"]))
-        m.planck_function = ptr(pf)
         m.iband_per_g = ptr(np.ascontiguousarray(model["iband_per_g"], dtype=np.int32), C.c_int)
         m.ngas = len(model["gases"])
         m.gases = gases
         m.logarithmic_interpolation = int(model.get("logarithmic_interpolation", False))
+        m.solar_irradiance = ptr(f64(model["solar_irradiance"])) if model.get("solar_irradiance") is not None else None
+        m.rayleigh_molar_scattering = (ptr(f64(model["rayleigh_molar_scattering"]))
+                                       if model.get("rayleigh_molar_scattering") is not None else None)
         sc = (_lib.OptScene * len(scenes))()
         for i, s in enumerate(scenes):
             p = f64(s["pressure_hl"])
@@ -489,8 +495,9 @@ class Optimizer:
             sc[i].surf_emissivity = ptr(f64(s["surf_emissivity"])) if s.get("surf_emissivity") is not None else None
             sc[i].flux_dn = ptr(fd)
             sc[i].flux_up = ptr(f64(s["flux_up"]))
-            for k in ("spectral_flux_dn_surf", "spectral_flux_up_toa"):
+            for k in ("spectral_flux_dn_surf", "spectral_flux_up_toa", "mu0", "albedo", "spectral_boundary_weights"):
                 setattr(sc[i], k, ptr(f64(s[k])) if s.get(k) is not None else None)
+            sc[i].tsi = float(s.get("tsi", 0.0))
         c = _lib.OptConfig()
         defaults = dict(flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, spectral_boundary_weight=0.0,
                         negative_od_penalty=1.0e4, pressure_weight_power=0.5, prior_error=1.0, min_prior_error=0.0,

@@ -91,6 +91,7 @@ struct ColConst {  // per-profile constant block layout in d_col: see host code
 // LDS: tau[nlay][ng] | fdn[nhl][ng] | fup[nhl][ng] | Bdn[nhl][nband] | Bup[nhl][nband] |
 //      Gdn[nhl][nband] | Gup[nhl][nband] | red[16]
 __global__ void k_opt_forward_adjoint(
+    int do_sw, const double* __restrict__ mu0 /*[ncol], SW*/,
     int nlay, int ng, int ngpad, int nband, int nent,
     const double* __restrict__ k,            // [nk] coefficients of every gas
     const int* __restrict__ ent_idx,         // [ncell][nent] start of an ng-long row of k, or -1
@@ -161,8 +162,21 @@ __global__ void k_opt_forward_adjoint(
     }
   }
   __syncthreads();
-  // ---- forward sweeps (radiative_transfer_lw.cpp:41-59) ----
-  if (live) {
+  // ---- forward sweeps ----
+  // shortwave: are all band albedos > 0 (broadband/profile upwelling terms, calc_cost_function_sw.cpp:252,:264)?
+  // all <= 0 selects the direct-only model with zero upwelling (:145-150)
+  bool all_pos = true, all_nonpos = true;
+  double cos_sza = 1.0;
+  if (do_sw) {
+    for (int b = 0; b < nband; ++b) {
+      const bool pos = surf_emis[(size_t)col * nband + b] > 0.0;
+      all_pos = all_pos && pos;
+      all_nonpos = all_nonpos && !pos;
+    }
+    cos_sza = mu0[col];
+  }
+  if (live && !do_sw) {
+    // radiative_transfer_lw.cpp:41-59
     double dn = 0.0;
     s_fdn[g] = 0.0;
     for (int l = 0; l < nlay; ++l) {
@@ -182,6 +196,27 @@ __global__ void k_opt_forward_adjoint(
       up = up * (1.0 - eps) + pl[(l + 1) * ng + g] * (eps - fac) + pl[l * ng + g] * fac;
       s_fup[l * ng + g] = up;
     }
+  }
+  if (live && do_sw) {
+    // radiative_transfer_direct_sw / _norayleigh_sw (radiative_transfer_sw.cpp:26-77); row 0 of the
+    // per-profile "planck" block carries the scaled solar irradiance per g (solve_adept.cpp:176-186),
+    // surf_emis the effective band albedo.  Albedo 0 gives up = 0, which is the direct-only branch.
+    const double minus_sec_sza = -1.0 / cos_sza;
+    double dn = cos_sza * pl[g];
+    s_fdn[g] = dn;
+    for (int l = 0; l < nlay; ++l) {
+      dn = dn * exp(minus_sec_sza * s_tau[l * ng + g]);
+      s_fdn[(l + 1) * ng + g] = dn;
+    }
+    const double alb = all_nonpos ? 0.0 : surf_emis[(size_t)col * nband + band_of_g[g]];
+    double up = dn * alb;
+    s_fup[nlay * ng + g] = up;
+    for (int l = nlay - 1; l >= 0; --l) {
+      up = up * exp(-2.0 * s_tau[l * ng + g]);
+      s_fup[l * ng + g] = up;
+    }
+  }
+  if (live) {
     if (flux_out) {
       double* fo = flux_out + (size_t)col * 2 * nhl * ng;
       for (int i = 0; i < nhl; ++i) {
@@ -211,7 +246,10 @@ __global__ void k_opt_forward_adjoint(
   const double* hrt = hr_true + (size_t)col * nlay * nband;
   const double* fdt = fdn_true + (size_t)col * nhl * nband;
   const double* fut = fup_true + (size_t)col * nhl * nband;
-  const double spec_scale = (1.0 - broadband_weight) / nband;
+  // LW always mixes spectral and broadband (calc_cost_function_lw.cpp:209); SW only if broadband_weight > 0
+  // (calc_cost_function_sw.cpp:243)
+  const double spec_scale = (!do_sw || broadband_weight > 0.0) ? (1.0 - broadband_weight) / nband : 1.0;
+  const double up_in_hr = do_sw ? 0.0 : 1.0;  // SW heating rate from the direct beam only (:197)
   for (int t = threadIdx.x; t < nhl * nband; t += blockDim.x) { s_gdn[t] = 0.0; s_gup[t] = 0.0; }
   __syncthreads();
   double jpart = 0.0;
@@ -220,12 +258,12 @@ __global__ void k_opt_forward_adjoint(
     double rsum = 0.0;
     for (int b = 0; b < nband; ++b) {
       const double hrf = cv[l] * (s_bdn[(l + 1) * nband + b] - s_bdn[l * nband + b] -
-                                  s_bup[(l + 1) * nband + b] + s_bup[l * nband + b]);
+                                  up_in_hr * (s_bup[(l + 1) * nband + b] - s_bup[l * nband + b]));
       rsum += hrf - hrt[l * nband + b];
     }
     for (int b = 0; b < nband; ++b) {
       const double hrf = cv[l] * (s_bdn[(l + 1) * nband + b] - s_bdn[l * nband + b] -
-                                  s_bup[(l + 1) * nband + b] + s_bup[l * nband + b]);
+                                  up_in_hr * (s_bup[(l + 1) * nband + b] - s_bup[l * nband + b]));
       const double r = hrf - hrt[l * nband + b];
       jpart += spec_scale * hr_weight * hr_weight * lw[l] * r * r;
       const double dhr = 2.0 * hr_weight * hr_weight * lw[l] * (spec_scale * r + broadband_weight * rsum);
@@ -233,8 +271,10 @@ __global__ void k_opt_forward_adjoint(
       // the two half levels it touches -> accumulate per (l) into separate arrays to avoid races
       atomicAdd(&s_gdn[(l + 1) * nband + b], dhr * cv[l]);
       atomicAdd(&s_gdn[l * nband + b], -dhr * cv[l]);
-      atomicAdd(&s_gup[(l + 1) * nband + b], -dhr * cv[l]);
-      atomicAdd(&s_gup[l * nband + b], dhr * cv[l]);
+      if (!do_sw) {
+        atomicAdd(&s_gup[(l + 1) * nband + b], -dhr * cv[l]);
+        atomicAdd(&s_gup[l * nband + b], dhr * cv[l]);
+      }
     }
     jpart += broadband_weight * hr_weight * hr_weight * lw[l] * rsum * rsum;
   }
@@ -243,15 +283,20 @@ __global__ void k_opt_forward_adjoint(
   for (int i = threadIdx.x; i < nhl; i += blockDim.x) {
     const bool is_surf = (i == nlay), is_toa = (i == 0);
     const bool interior = (i >= 1 && i <= nlay - 1);
-    double wd = 0.0, wu = 0.0;  // weights of the squared band residuals of dn / up at this level
-    if (is_surf) wd = flux_weight;
-    if (is_toa) wu = flux_weight;
+    // weights of the squared band residuals of dn / up at this level: spectral (s) and broadband (b)
+    double wd_s = 0.0, wu_s = 0.0, wd_b = 0.0, wu_b = 0.0;
+    if (is_surf) { wd_s = flux_weight; wd_b = flux_weight; }
+    if (is_toa) {
+      // SW: 20 x on the spectral TOA upwelling (:214); its broadband term only if all albedos > 0 (:252)
+      wu_s = do_sw ? 20.0 * flux_weight : flux_weight;
+      wu_b = (!do_sw || all_pos) ? flux_weight : 0.0;
+    }
     if (interior && flux_profile_weight > 0.0) {
       const double iw = flux_profile_weight * 0.5 * (lw[i - 1] + lw[i]);
-      wd = iw;
-      wu = iw;
+      wd_s = iw; wu_s = iw; wd_b = iw;
+      wu_b = (!do_sw || all_pos) ? iw : 0.0;   // :264
     }
-    if (wd != 0.0 || wu != 0.0) {
+    if (wd_s != 0.0 || wu_s != 0.0) {
       double sd = 0.0, su = 0.0;
       for (int b = 0; b < nband; ++b) {
         sd += s_bdn[i * nband + b] - fdt[i * nband + b];
@@ -260,16 +305,43 @@ __global__ void k_opt_forward_adjoint(
       for (int b = 0; b < nband; ++b) {
         const double dd = s_bdn[i * nband + b] - fdt[i * nband + b];
         const double du = s_bup[i * nband + b] - fut[i * nband + b];
-        jpart += spec_scale * (wd * dd * dd + wu * du * du);
-        s_gdn[i * nband + b] += 2.0 * wd * (spec_scale * dd + broadband_weight * sd);
-        s_gup[i * nband + b] += 2.0 * wu * (spec_scale * du + broadband_weight * su);
+        jpart += spec_scale * (wd_s * dd * dd + wu_s * du * du);
+        s_gdn[i * nband + b] += 2.0 * (spec_scale * wd_s * dd + broadband_weight * wd_b * sd);
+        s_gup[i * nband + b] += 2.0 * (spec_scale * wu_s * du + broadband_weight * wu_b * su);
       }
-      jpart += broadband_weight * (wd * sd * sd + wu * su * su);
+      jpart += broadband_weight * (wd_b * sd * sd + wu_b * su * su);
     }
   }
   __syncthreads();
   // ---- adjoint of the two sweeps, per g ----
-  if (live) {
+  if (live && do_sw) {
+    const int b = band_of_g[g];
+    const double alb = all_nonpos ? 0.0 : surf_emis[(size_t)col * nband + b];
+    double g_dn_surf_extra = 0.0;
+    if (sfds && sfut) {
+      // calc_cost_function_sw.cpp:271-274: per-g weights (erythemal) on the surface direct flux
+      const double wgt = sfut[(size_t)col * ng + g];
+      const double a = s_fdn[nlay * ng + g] - sfds[(size_t)col * ng + g];
+      jpart += wgt * a * a;
+      g_dn_surf_extra = 2.0 * wgt * a;
+    }
+    // up_l = up_{l+1} * exp(-2 tau_l): d up_l / d tau_l = -2 up_l
+    double up_bar = s_gup[b];
+    for (int l = 0; l < nlay; ++l) {
+      const double tau = s_tau[l * ng + g];
+      if (s_clamp[l * ng + g] == 0) dtau[(cell0 + l) * ng + g] = up_bar * s_fup[l * ng + g] * (-2.0);
+      up_bar = up_bar * exp(-2.0 * tau) + s_gup[(l + 1) * nband + b];
+    }
+    // dn_{l+1} = dn_l * exp(-tau_l / mu0): d dn_{l+1} / d tau_l = -dn_{l+1} / mu0
+    const double minus_sec_sza = -1.0 / cos_sza;
+    double dn_bar = s_gdn[nlay * nband + b] + g_dn_surf_extra + up_bar * alb;
+    for (int l = nlay - 1; l >= 0; --l) {
+      const double tau = s_tau[l * ng + g];
+      if (s_clamp[l * ng + g] == 0) dtau[(cell0 + l) * ng + g] += dn_bar * s_fdn[(l + 1) * ng + g] * minus_sec_sza;
+      dn_bar = dn_bar * exp(minus_sec_sza * tau) + s_gdn[l * nband + b];
+    }
+  }
+  if (live && !do_sw) {
     const int b = band_of_g[g];
     const double es = surf_emis[(size_t)col * nband + b];
     double g_dn_surf_extra = 0.0, g_up_toa_extra = 0.0;
@@ -581,6 +653,8 @@ struct ecckd_opt {
   ecckd_opt_config cfg{};
   bool have_prior = false;
   bool have_boundary = false;
+  bool do_sw = false;
+  double* d_mu0 = nullptr;
   // host copies
   std::vector<double> h_k0, h_kmin, h_kmax;
   // device
@@ -620,7 +694,7 @@ void opt_free(ecckd_opt* o) {
                   o->d_band, o->d_planck, o->d_semis, o->d_conv, o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds,
                   o->d_sfut, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_node_gas, o->d_node_ic, o->d_node_it,
                   o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2, o->d_od_out, o->d_flux_out, o->d_xmin, o->d_xmax,
-                  o->d_xn, o->d_gn, o->d_dir, o->d_q, o->d_S, o->d_Y, o->d_part, o->d_sc};
+                  o->d_xn, o->d_gn, o->d_dir, o->d_q, o->d_S, o->d_Y, o->d_part, o->d_sc, o->d_mu0};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete o;
@@ -650,7 +724,9 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
   ECCKD_REQUIRE(m->ng > 0 && m->ng <= 1024 && m->nt >= 2 && m->np >= 2 && m->ngas > 0 && m->gases &&
                     m->log_pressure && m->temperature && m->iband_per_g,
                 "ecckd_opt_create: bad model dimensions (ng=%d nt=%d np=%d ngas=%d)", m->ng, m->nt, m->np, m->ngas);
-  ECCKD_REQUIRE(m->ntp >= 2 && m->temperature_planck && m->planck_function, "ecckd_opt_create: Planck look-up table missing");
+  const bool do_sw = m->solar_irradiance != nullptr;
+  ECCKD_REQUIRE(do_sw || (m->ntp >= 2 && m->temperature_planck && m->planck_function),
+                "ecckd_opt_create: Planck look-up table missing");
   ECCKD_REQUIRE(!m->logarithmic_interpolation,
                 "ecckd_opt_create: logarithmic LUT interpolation is not supported (ckd_model.h:359 default is linear)");
   ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
@@ -659,6 +735,7 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
   o->ctx = ctx;
   o->ng = ng; o->nt = nt; o->np = np; o->ngas = m->ngas;
   o->cfg = *cfg;
+  o->do_sw = do_sw;
   int nband = 0;
   for (int g = 0; g < ng; ++g) nband = std::max(nband, m->iband_per_g[g] + 1);
   o->nband = nband;
@@ -690,6 +767,11 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
     o->user_to_k[order[pos]] = (int)pos;
     o->gases.push_back(gi);
   }
+  // Rayleigh scattering (calc_total_optical_depth, solve_adept.cpp:33-36; ckd_model.h:242-252): a fixed
+  // one-node pseudo gas at the end of the coefficient vector
+  const bool have_rayleigh = do_sw && m->rayleigh_molar_scattering != nullptr;
+  const size_t rayleigh_ix = off;
+  if (have_rayleigh) off += ng;
   o->nk = off;
   ECCKD_REQUIRE(o->nx > 0, "ecckd_opt_create: no active gas to optimise");
   ECCKD_REQUIRE(o->nk < (size_t)0x7fffffff, "ecckd_opt_create: coefficient vector too long for int32 indexing");
@@ -711,6 +793,7 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
     }
   }
   if (!have_minmax) { o->h_kmin.clear(); o->h_kmax.clear(); }
+  if (have_rayleigh) std::memcpy(&o->h_k0[rayleigh_ix], m->rayleigh_molar_scattering, ng * sizeof(double));
 
   // cap_relative_linear_coeffts(0.8), optimize_lut.cpp:185, ckd_model.cpp:883-917
   {
@@ -792,7 +875,8 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
   size_t ncol = 0;
   for (int s = 0; s < nscene; ++s) {
     if (scenes[s].nlay != nlay || scenes[s].ncol <= 0 || !scenes[s].pressure_hl || !scenes[s].temperature_hl ||
-        !scenes[s].flux_dn || !scenes[s].flux_up || scenes[s].nband != nband) {
+        !scenes[s].flux_dn || !scenes[s].flux_up || scenes[s].nband != nband ||
+        (do_sw && (!scenes[s].mu0 || !scenes[s].albedo || !(scenes[s].tsi > 0.0)))) {
       opt_free(o);
       return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_opt_create: scene %d is inconsistent (nlay/nband/arrays)", s);
     }
@@ -800,7 +884,7 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
   }
   o->ncol = ncol;
   o->ncell = ncol * nlay;
-  int nent = 0;
+  int nent = have_rayleigh ? 1 : 0;
   for (const GasInfo& gi : o->gases) nent += (gi.conc == 2) ? 8 : 4;
   o->nent = nent;
   std::vector<int> ent_idx(o->ncell * nent, -1);
@@ -809,7 +893,13 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
   std::vector<double> hr(ncol * nlay * nband), fdn(ncol * nhl * nband), fup(ncol * nhl * nband);
   std::vector<double> sfds, sfut;
   bool any_boundary = false;
-  for (int s = 0; s < nscene; ++s) any_boundary = any_boundary || (scenes[s].spectral_flux_dn_surf && scenes[s].spectral_flux_up_toa);
+  for (int s = 0; s < nscene; ++s)
+    any_boundary = any_boundary || (scenes[s].spectral_flux_dn_surf &&
+                                    (do_sw ? scenes[s].spectral_boundary_weights != nullptr : scenes[s].spectral_flux_up_toa != nullptr));
+  std::vector<double> mu0v(do_sw ? ncol : 0);
+  double solar_sum = 0.0;
+  if (do_sw)
+    for (int g = 0; g < ng; ++g) solar_sum += m->solar_irradiance[g];
   o->have_boundary = any_boundary;
   if (any_boundary) { sfds.assign(ncol * ng, 0.0); sfut.assign(ncol * ng, 0.0); }
 
@@ -824,8 +914,16 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
       const size_t col = col0 + c;
       const double* p = sc.pressure_hl + (size_t)c * nhl;
       const double* T = sc.temperature_hl + (size_t)c * nhl;
-      for (int i = 0; i < nhl; ++i) planck_lut(m->ntp, m->temperature_planck, m->planck_function, ng, T[i], &planck[(col * nhl + i) * ng]);
-      if (sc.surf_emissivity) std::memcpy(&semis[col * nband], sc.surf_emissivity + (size_t)c * nband, nband * sizeof(double));
+      if (!do_sw) {
+        for (int i = 0; i < nhl; ++i) planck_lut(m->ntp, m->temperature_planck, m->planck_function, ng, T[i], &planck[(col * nhl + i) * ng]);
+        if (sc.surf_emissivity) std::memcpy(&semis[col * nband], sc.surf_emissivity + (size_t)c * nband, nband * sizeof(double));
+      } else {
+        // tsi_scaling * ckd_model.solar_irradiance() (solve_adept.cpp:176,186) in row 0; band albedo
+        const double tsi_scaling = sc.tsi / solar_sum;
+        for (int g = 0; g < ng; ++g) planck[(col * nhl) * ng + g] = tsi_scaling * m->solar_irradiance[g];
+        std::memcpy(&semis[col * nband], sc.albedo, nband * sizeof(double));
+        mu0v[col] = sc.mu0[c];
+      }
       // layer weights, solve_adept.cpp:131-143
       double wsum = 0.0;
       for (int l = 0; l < nlay; ++l) {
@@ -845,12 +943,16 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
         for (int b = 0; b < nband; ++b) {
           const double* d = &fdn[col * nhl * nband];
           const double* u = &fup[col * nhl * nband];
+          // LW: net flux divergence; SW: direct beam only (lbl_fluxes.cpp:365-369 passes an empty flux_up)
           hr[(col * nlay + l) * nband + b] =
-              conv[col * nlay + l] * (d[(l + 1) * nband + b] - d[l * nband + b] - u[(l + 1) * nband + b] + u[l * nband + b]);
+              do_sw ? conv[col * nlay + l] * (d[(l + 1) * nband + b] - d[l * nband + b])
+                    : conv[col * nlay + l] * (d[(l + 1) * nband + b] - d[l * nband + b] - u[(l + 1) * nband + b] + u[l * nband + b]);
         }
-      if (any_boundary && sc.spectral_flux_dn_surf && sc.spectral_flux_up_toa) {
+      if (any_boundary && sc.spectral_flux_dn_surf && (do_sw ? sc.spectral_boundary_weights != nullptr : sc.spectral_flux_up_toa != nullptr)) {
         std::memcpy(&sfds[col * ng], sc.spectral_flux_dn_surf + (size_t)c * ng, ng * sizeof(double));
-        std::memcpy(&sfut[col * ng], sc.spectral_flux_up_toa + (size_t)c * ng, ng * sizeof(double));
+        // SW: the second array carries the per-g weights (calc_cost_function_sw.cpp:271-274)
+        if (do_sw) std::memcpy(&sfut[col * ng], sc.spectral_boundary_weights, ng * sizeof(double));
+        else std::memcpy(&sfut[col * ng], sc.spectral_flux_up_toa + (size_t)c * ng, ng * sizeof(double));
       }
       // interpolation entries, ckd_model.cpp:960-1086
       for (int l = 0; l < nlay; ++l) {
@@ -917,6 +1019,11 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
           }
           e += width;
         }
+        if (have_rayleigh) {
+          // moles of air per unit area in the layer (ckd_model.h:246-247) times the molar scattering
+          ent_idx[cell * nent + e] = (int)rayleigh_ix;
+          ent_coef[cell * nent + e] = (p[l + 1] - p[l]) * (1.0 / (ECCKD_ACCEL_GRAVITY * 0.001 * 28.970));
+        }
       }
     }
     col0 += sc.ncol;
@@ -953,6 +1060,7 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
   UP(d_planck, planck); UP(d_semis, semis); UP(d_conv, conv); UP(d_lw, lwv);
   UP(d_hr, hr); UP(d_fdn, fdn); UP(d_fup, fup);
   if (any_boundary) { UP(d_sfds, sfds); UP(d_sfut, sfut); }
+  if (do_sw) UP(d_mu0, mu0v);
   UP(d_ref_ptr, ref_ptr); UP(d_ref_cell, ref_cell); UP(d_ref_coef, ref_coef);
   UP(d_node_gas, node_gas); UP(d_node_ic, node_ic); UP(d_node_it, node_it); UP(d_node_ip, node_ip);
   UP(d_gas_dims, gas_dims); UP(d_tri, tri); UP(d_tri_off, tri_off); UP(d_inv_sigma2, inv_sigma2);
@@ -1018,8 +1126,8 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
   ECCKD_REQUIRE(lds <= 160 * 1024, "ecckd_opt_cost_grad: nlay*ng too large for the per-profile LDS tile (%zu B)", lds);
   ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_opt_forward_adjoint),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL(k_opt_forward_adjoint, dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream, nlay, ng, ngpad, nband,
-                     o->nent, o->d_k, o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_planck, o->d_semis, o->d_conv,
+  hipLaunchKernelGGL(k_opt_forward_adjoint, dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream, o->do_sw ? 1 : 0,
+                     o->d_mu0, nlay, ng, ngpad, nband, o->nent, o->d_k, o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_planck, o->d_semis, o->d_conv,
                      o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds, o->d_sfut, o->cfg.flux_weight,
                      o->cfg.flux_profile_weight, o->cfg.broadband_weight, o->cfg.spectral_boundary_weight,
                      o->cfg.negative_od_penalty, o->d_dtau, o->d_jcol, o->d_od_out, o->d_flux_out);

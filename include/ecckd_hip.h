@@ -222,7 +222,8 @@ int ecckd_find_g_band(ecckd_gas* gas, size_t ibegin, size_t iend, double heating
  * calc_cost_function_and_gradient (:72-211: CkdModel::calc_optical_depth ckd_model.cpp:925-1102,
  * negative-OD penalty, calc_cost_function_ckd_lw calc_cost_function_lw.cpp:116-232, Adept
  * reverse pass) plus CkdModel::calc_background_cost_function (ckd_model.cpp:840-877), and
- * solve_adept itself (:310-417).  Longwave, linear LUT interpolation.
+ * solve_adept itself (:310-417).  Longwave (calc_cost_function_ckd_lw) and shortwave
+ * (calc_cost_function_ckd_sw, calc_cost_function_sw.cpp:116-277), linear LUT interpolation.
  * All arrays here are HOST arrays; the handle uploads them once. */
 typedef struct {
   int conc_dependence;          /* 0 none, 1 linear, 2 look-up table, 3 relative-linear (ckd_model.cpp:418-482) */
@@ -246,6 +247,10 @@ typedef struct {
   int ngas;
   const ecckd_opt_gas* gases;
   int logarithmic_interpolation;     /* must be 0 (ckd_model.h:359) */
+  /* shortwave (NULL / NULL = longwave model): solar irradiance per g point and the Rayleigh molar
+   * scattering coefficient per g point (ckd_model.h:242-252; kept fixed, not optimised) */
+  const double* solar_irradiance;           /* [ng] */
+  const double* rayleigh_molar_scattering;  /* [ng] or NULL */
 } ecckd_opt_model;
 
 typedef struct {
@@ -259,6 +264,11 @@ typedef struct {
   const double* flux_up;
   const double* spectral_flux_dn_surf;  /* [ncol][ng] or NULL (lbl_fluxes.cpp:301-328) */
   const double* spectral_flux_up_toa;
+  /* shortwave scenes (lbl_fluxes.cpp:68-148): columns already replicated per solar zenith angle */
+  const double* mu0;                        /* [ncol] */
+  double tsi;                               /* total solar irradiance of the training file (:127) */
+  const double* albedo;                     /* [nband] effective spectral albedo (:147-148, mask_rayleigh_up) */
+  const double* spectral_boundary_weights;  /* [ng] erythemal_weight * erythemal_spectrum_ (solve_adept.cpp:182) or NULL */
 } ecckd_opt_scene;
 
 typedef struct {

@@ -212,3 +212,107 @@ double orc_calc_cost_function_ckd_lw(int nlay, int ng, int nband, const double* 
   free(fdn_orig); free(fup_orig); free(semis); free(fdn); free(fup); free(hrf);
   return cost_fn;
 }
+
+/* a18 (SW) -- reference src/ecckd/calc_cost_function_sw.cpp:116-277, forward value.
+ * albedo[nband] is the effective spectral albedo per band; heating rate from the direct beam
+ * only (:197); TOA upwelling error weighted by 20 (:214); the broadband terms are applied only
+ * if broadband_weight > 0 (:243) and the upwelling ones only if all(albedo > 0) (:252, :264);
+ * spectral_boundary_weights[ng] multiplies the squared surface-down error per g (:271-274). */
+double orc_calc_cost_function_ckd_sw(int nlay, int ng, int nband, double cos_sza, const double* pressure_hl,
+                                     const double* ssi, const double* albedo, const double* optical_depth,
+                                     const double* flux_dn, const double* flux_up, const double* hr,
+                                     const double* spectral_flux_dn_surf, double flux_weight,
+                                     double flux_profile_weight, double broadband_weight,
+                                     const double* spectral_boundary_weights, const double* layer_weight,
+                                     const int* band_mapping) {
+  static const double hr_weight = 3600.0 * 24.0;
+  const int nhl = nlay + 1;
+  double* fdn_orig = (double*)malloc((size_t)nhl * ng * sizeof(double));
+  double* fup_orig = (double*)calloc((size_t)nhl * ng, sizeof(double));
+  int all_nonpos = 1, all_pos = 1;
+  for (int b = 0; b < nband; ++b) {
+    if (albedo[b] > 0.0) all_nonpos = 0;
+    if (!(albedo[b] > 0.0)) all_pos = 0;
+  }
+  if (all_nonpos) {
+    orc_radiative_transfer_direct_sw(nlay, (size_t)ng, cos_sza, ssi, optical_depth, fdn_orig);
+  } else {
+    double* alb_g = (double*)malloc((size_t)ng * sizeof(double));
+    for (int g = 0; g < ng; ++g) alb_g[g] = albedo[band_mapping[g]];
+    orc_radiative_transfer_norayleigh_sw(nlay, (size_t)ng, cos_sza, ssi, optical_depth, alb_g, fdn_orig, fup_orig);
+    free(alb_g);
+  }
+  double* fdn = (double*)calloc((size_t)nhl * nband, sizeof(double));
+  double* fup = (double*)calloc((size_t)nhl * nband, sizeof(double));
+  for (int b = 0; b < nband; ++b)
+    for (int i = 0; i < nhl; ++i) {
+      double sd = 0.0, su = 0.0;
+      for (int g = 0; g < ng; ++g)
+        if (band_mapping[g] == b) { sd += fdn_orig[i * ng + g]; su += fup_orig[i * ng + g]; }
+      fdn[i * nband + b] = sd;
+      fup[i * nband + b] = su;
+    }
+  double* hrf = (double*)malloc((size_t)nlay * nband * sizeof(double));
+  orc_heating_rate(nlay, (size_t)nband, pressure_hl, fdn, NULL, hrf);
+  double cost_fn = 0.0;
+  for (int b = 0; b < nband; ++b) {
+    double s = 0.0;
+    for (int l = 0; l < nlay; ++l) {
+      double d = hrf[l * nband + b] - hr[l * nband + b];
+      s += layer_weight[l] * d * d;
+    }
+    double ds = fdn[nlay * nband + b] - flux_dn[nlay * nband + b];
+    double dt = fup[b] - flux_up[b];
+    double local = hr_weight * hr_weight * s + flux_weight * (ds * ds + 20.0 * dt * dt);
+    if (flux_profile_weight > 0.0) {
+      for (int i = 1; i < nlay; ++i) {
+        double iw = flux_profile_weight * 0.5 * (layer_weight[i - 1] + layer_weight[i]);
+        double dd = fdn[i * nband + b] - flux_dn[i * nband + b];
+        double du = fup[i * nband + b] - flux_up[i * nband + b];
+        local += iw * (dd * dd + du * du);
+      }
+    }
+    cost_fn += local;
+  }
+  if (broadband_weight > 0.0) {
+    double sbb = 0.0;
+    for (int l = 0; l < nlay; ++l) {
+      double r = 0.0;
+      for (int b = 0; b < nband; ++b) r += hrf[l * nband + b] - hr[l * nband + b];
+      sbb += layer_weight[l] * (r * r);
+    }
+    cost_fn = (cost_fn * (1.0 - broadband_weight)) / nband + broadband_weight * hr_weight * hr_weight * sbb;
+    double rs = 0.0, rt = 0.0;
+    for (int b = 0; b < nband; ++b) {
+      rs += fdn[nlay * nband + b] - flux_dn[nlay * nband + b];
+      rt += fup[b] - flux_up[b];
+    }
+    cost_fn += broadband_weight * flux_weight * (rs * rs);
+    if (all_pos) cost_fn += broadband_weight * flux_weight * (rt * rt);
+    if (flux_profile_weight > 0.0) {
+      double spd = 0.0, spu = 0.0;
+      for (int i = 1; i < nlay; ++i) {
+        double iw = flux_profile_weight * 0.5 * (layer_weight[i - 1] + layer_weight[i]);
+        double ed = 0.0, eu = 0.0;
+        for (int b = 0; b < nband; ++b) {
+          ed += fdn[i * nband + b] - flux_dn[i * nband + b];
+          eu += fup[i * nband + b] - flux_up[i * nband + b];
+        }
+        spd += iw * (ed * ed);
+        spu += iw * (eu * eu);
+      }
+      cost_fn += broadband_weight * spd;
+      if (all_pos) cost_fn += broadband_weight * spu;
+    }
+  }
+  if (spectral_boundary_weights && spectral_flux_dn_surf) {
+    double s = 0.0;
+    for (int g = 0; g < ng; ++g) {
+      double a = fdn_orig[nlay * ng + g] - spectral_flux_dn_surf[g];
+      s += spectral_boundary_weights[g] * a * a;
+    }
+    cost_fn += s;
+  }
+  free(fdn_orig); free(fup_orig); free(fdn); free(fup); free(hrf);
+  return cost_fn;
+}

@@ -162,3 +162,104 @@ class Oracle:
             grad[off:off + n] = gl.ravel()
             off += n
         return J, grad
+
+
+def make_model_sw(seed=0, **kw):
+    """Shortwave variant of the synthetic model: solar irradiance + Rayleigh per g instead of a Planck LUT."""
+    m = make_model(seed=seed, **kw)
+    ng = m["planck_function"].shape[1]
+    rs = np.random.RandomState(seed + 99)
+    ssi = rs.uniform(0.5, 1.5, ng)
+    m["solar_irradiance"] = 1340.0 * ssi / ssi.sum()        # differs from the scenes' tsi: exercises tsi_scaling
+    m["rayleigh_molar_scattering"] = 10.0 ** rs.uniform(-7.0, -5.5, ng)
+    m["planck_function"] = None
+    m["temperature_planck"] = None
+    m["ng"] = ng
+    for g in m["gases"]:                                     # shortwave gases absorb less strongly
+        for k in ("molar_abs", "min_molar_abs", "max_molar_abs"):
+            g[k] = g[k] * 0.002
+    return m
+
+
+def make_scenes_sw(model, albedo, mu0=(1.0, 0.6, 0.25, 0.1), tsi=1361.0, boundary_weights=None, **kw):
+    """lbl_fluxes.cpp:68-148: every profile repeated per solar zenith angle (done here on the host)."""
+    base = make_scenes(model, **kw)
+    out = []
+    for s in base:
+        ncol = s["pressure_hl"].shape[0]
+        rep = lambda a: np.ascontiguousarray(np.repeat(a, len(mu0), axis=0))
+        t = dict(pressure_hl=rep(s["pressure_hl"]), temperature_hl=rep(s["temperature_hl"]), vmr_fl=rep(s["vmr_fl"]),
+                 gas_present=s["gas_present"], mu0=np.tile(np.asarray(mu0, dtype=np.float64), ncol), tsi=tsi,
+                 albedo=np.asarray(albedo, dtype=np.float64))
+        if boundary_weights is not None:
+            t["spectral_boundary_weights"] = np.asarray(boundary_weights, dtype=np.float64)
+        out.append(t)
+    return out
+
+
+class OracleSW(Oracle):
+    """Shortwave branch of solve_adept.cpp:172-200 from oracle_ckd.c / oracle_rt.c pieces."""
+
+    def __init__(self, pyoracle, model, scenes, cfg):
+        ng = model["ng"]
+        shim = dict(model, planck_function=np.zeros((2, ng)))   # Oracle only reads its shape
+        super().__init__(pyoracle, shim, scenes, cfg)
+        self.L.orc_calc_cost_function_ckd_sw.restype = C.c_double
+
+    def optical_depth(self, x, scene):
+        od = super().optical_depth(x, scene)
+        ray = self.m.get("rayleigh_molar_scattering")
+        if ray is not None:                                  # ckd_model.h:242-252
+            p = scene["pressure_hl"]
+            moles = (p[:, 1:] - p[:, :-1]) * (1.0 / (9.80665 * 0.001 * 28.970))
+            od = od + moles[:, :, None] * np.asarray(ray)[None, None, :]
+        return od
+
+    def ssi(self, scene):
+        return np.ascontiguousarray(scene["tsi"] / self.m["solar_irradiance"].sum() * self.m["solar_irradiance"])
+
+    def fluxes(self, x, scene):
+        od = np.maximum(self.optical_depth(x, scene), 0.0)
+        ncol, nlay, ng = od.shape
+        out = np.zeros((ncol, 2, nlay + 1, ng))
+        alb = scene["albedo"]
+        alb_g = np.ascontiguousarray(alb[self.m["iband_per_g"]])
+        for c in range(ncol):
+            if np.all(alb <= 0.0):
+                out[c, 0] = self.o.radiative_transfer_direct_sw(scene["mu0"][c], self.ssi(scene), od[c])
+            else:
+                out[c, 0], out[c, 1] = self.o.radiative_transfer_norayleigh_sw(scene["mu0"][c], self.ssi(scene), od[c], alb_g)
+        return out
+
+    def cost_rt(self, x):
+        cfg, P = self.cfg, self.o._p
+        J = 0.0
+        nband = self.m["nband"]
+        ib = np.ascontiguousarray(self.m["iband_per_g"], dtype=np.int32)
+        for scene in self.scenes:
+            od = self.optical_depth(x, scene)
+            neg = od < 0.0
+            if neg.any():
+                J += cfg["negative_od_penalty"] * np.sum(od[neg] ** 2)
+                od = np.where(neg, 0.0, od)
+            p = scene["pressure_hl"]
+            ncol, nhl = p.shape
+            nlay, ng = nhl - 1, od.shape[2]
+            ssi = self.ssi(scene)
+            for c in range(ncol):
+                pw = cfg["pressure_weight_power"]
+                lw = (np.sqrt(p[c, 1:]) - np.sqrt(p[c, :-1])) if pw == 0.5 else (p[c, 1:] ** pw - p[c, :-1] ** pw)
+                lw = np.ascontiguousarray(lw / lw.sum())
+                fd = np.ascontiguousarray(scene["flux_dn"][c])
+                fu = np.ascontiguousarray(scene["flux_up"][c])
+                hr = np.ascontiguousarray(self.o.heating_rate(p[c], fd, None))   # direct beam only
+                sfd = scene.get("spectral_flux_dn_surf")
+                sbw = scene.get("spectral_boundary_weights")
+                use_b = sfd is not None and sbw is not None
+                J += self.L.orc_calc_cost_function_ckd_sw(
+                    C.c_int(nlay), C.c_int(ng), C.c_int(nband), C.c_double(scene["mu0"][c]), P(np.ascontiguousarray(p[c])),
+                    P(ssi), P(np.ascontiguousarray(scene["albedo"])), P(np.ascontiguousarray(od[c])), P(fd), P(fu), P(hr),
+                    P(np.ascontiguousarray(sfd[c])) if use_b else None, C.c_double(cfg["flux_weight"]),
+                    C.c_double(cfg["flux_profile_weight"]), C.c_double(cfg["broadband_weight"]),
+                    P(np.ascontiguousarray(sbw)) if use_b else None, P(lw), ib.ctypes.data_as(C.POINTER(C.c_int)))
+        return J

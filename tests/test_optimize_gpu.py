@@ -167,3 +167,96 @@ def test_minimize_reduces_cost(ctx, oracle):
     # the CPU oracle agrees on the cost at the optimum
     assert orc.cost_rt(res["x"]) + orc.cost_prior(res["x"], cfg["prior_error"])[0] == pytest.approx(J1, rel=1e-9)
     opt.close()
+
+
+# ---- shortwave branch (calc_cost_function_ckd_sw, solve_adept.cpp:172-200) ---------------------------------
+
+def _problem_sw(oracle, seed=0, albedo=(0.15, 0.3, 0.06), boundary=False, ch4_low=False, **over):
+    cfg = dict(CFG, **over)
+    model = ckd_synth.make_model_sw(seed=seed)
+    truth = ckd_synth.make_model_sw(seed=seed)
+    rs = np.random.RandomState(seed + 5)
+    for g in truth["gases"]:
+        g["molar_abs"] = g["molar_abs"] * np.exp(0.25 * rs.normal(size=g["molar_abs"].shape))
+    ng = model["ng"]
+    bw = 0.02 * rs.uniform(size=ng) if boundary else None
+    scenes = ckd_synth.make_scenes_sw(model, albedo, boundary_weights=bw, ch4_low=ch4_low)
+    orc_truth = ckd_synth.OracleSW(oracle, truth, scenes, cfg)
+    for s in scenes:
+        bf = orc_truth.band_fluxes(orc_truth.x0, s)
+        s["flux_dn"], s["flux_up"] = np.ascontiguousarray(bf[:, 0]), np.ascontiguousarray(bf[:, 1])
+        if boundary:
+            s["spectral_flux_dn_surf"] = np.ascontiguousarray(orc_truth.fluxes(orc_truth.x0, s)[:, 0, -1, :])
+    orc = ckd_synth.OracleSW(oracle, model, scenes, cfg)
+    return model, scenes, cfg, orc
+
+
+def test_sw_forward(ctx, oracle):
+    model, scenes, cfg, orc = _problem_sw(oracle)
+    opt = _opt(ctx, model, scenes, cfg)
+    x0 = opt.initial_state()
+    assert np.allclose(x0, orc.x0, rtol=1e-15, atol=0)
+    od, fl = opt.forward(x0)
+    od_ref = np.concatenate([orc.optical_depth(x0, s) for s in scenes])
+    fl_ref = np.concatenate([orc.fluxes(x0, s) for s in scenes])
+    assert np.allclose(od, np.maximum(od_ref, 0.0), rtol=1e-12, atol=1e-300)
+    assert np.allclose(fl, fl_ref, rtol=1e-10, atol=1e-300)
+    assert fl[:, 1].max() > 0
+    opt.close()
+
+
+@pytest.mark.parametrize("variant", ["base", "spectral_only", "direct_only", "mixed_albedo", "boundary", "negative_od"])
+def test_sw_cost_and_gradient(ctx, oracle, variant):
+    kw = {}
+    if variant == "spectral_only":
+        kw = dict(broadband_weight=0.0)            # no 1/nband scaling in the shortwave (:243)
+    if variant == "direct_only":
+        kw = dict(albedo=(0.0, 0.0, -1.0))          # all(albedo <= 0): direct beam only, upwelling zero
+    if variant == "mixed_albedo":
+        kw = dict(albedo=(0.2, 0.0, 0.1))           # broadband upwelling terms dropped (:252, :264)
+    if variant == "boundary":
+        kw = dict(boundary=True)
+    if variant == "negative_od":
+        kw = dict(ch4_low=True)
+    model, scenes, cfg, orc = _problem_sw(oracle, seed=3, **kw)
+    opt = _opt(ctx, model, scenes, cfg)
+    rs = np.random.RandomState(1)
+    x0 = opt.initial_state()
+    free = x0 > -1.0e20
+    x = x0 + np.where(free, 0.2 * rs.normal(size=x0.size), 0.0)
+    if variant == "negative_od":
+        sizes = np.cumsum([0] + orc.sizes)
+        x[sizes[3]:sizes[4]] += 9.0
+    J, g = opt.cost_grad(x)
+    J_ref = orc.cost_rt(x) + orc.cost_prior(x, cfg["prior_error"])[0]
+    assert J == pytest.approx(J_ref, rel=1e-10)
+    if variant == "negative_od":
+        od = np.concatenate([orc.optical_depth(x, s) for s in scenes])
+        assert (od < 0).sum() > 10
+    assert np.all(g[~free] == 0.0)
+    for trial in range(3):
+        d = np.where(free, rs.normal(size=x.size), 0.0)
+        d /= np.linalg.norm(d)
+        h = 1e-5
+        fd = (orc.cost_rt(x + h * d) + orc.cost_prior(x + h * d, cfg["prior_error"])[0]
+              - orc.cost_rt(x - h * d) - orc.cost_prior(x - h * d, cfg["prior_error"])[0]) / (2 * h)
+        assert np.dot(g, d) == pytest.approx(fd, rel=2e-6, abs=1e-9 * abs(J))
+    idx = rs.choice(np.nonzero(free)[0], 12, replace=False)
+    for i in idx:
+        h = 1e-5
+        e = np.zeros_like(x); e[i] = h
+        fd = (opt.cost_grad(x + e, False) - opt.cost_grad(x - e, False)) / (2 * h)
+        assert g[i] == pytest.approx(fd, rel=1e-5, abs=1e-7 * np.abs(g).max())
+    opt.close()
+
+
+def test_sw_minimize_reduces_cost(ctx, oracle):
+    model, scenes, cfg, orc = _problem_sw(oracle, seed=7)
+    opt = _opt(ctx, model, scenes, cfg)
+    x0 = opt.initial_state()
+    J0, g0 = opt.cost_grad(x0)
+    res = opt.minimize(max_iterations=150, convergence_criterion=1e-3 * np.linalg.norm(g0), bounded=True)
+    assert res["status"] in (0, 2)
+    assert res["cost"] < 0.5 * J0
+    assert orc.cost_rt(res["x"]) + orc.cost_prior(res["x"], cfg["prior_error"])[0] == pytest.approx(res["cost"], rel=1e-9)
+    opt.close()
