@@ -57,8 +57,9 @@ def make_inputs(xp, nwav, nlay, seed, device=None):
 
 
 def cpu_baseline(nwav_s, nlay, seed, tol, tol_tol, max_it):
-    """The oracle ("port") on the host, one thread: reorder + gas prep + the reference-built
-    partition search (oracle/_ref) over the oracle's calc_error."""
+    """The oracle ("port") on the host with OpenMP at the reference's own sites (planck_function.cpp:50 over
+    levels, equipartition.h:101 over the intervals of calc_error_all, as find_g_points.cpp:231 enables it):
+    reorder + gas prep + the reference-built partition search (oracle/_ref) over the oracle's calc_error."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as o
     from ecckd_amd import synthetic as syn
@@ -78,7 +79,7 @@ def cpu_baseline(nwav_s, nlay, seed, tol, tol_tol, max_it):
                               fdn[-1].copy(), fup[0].copy(), planck, bg_s, o.metric("transmission", od_s), hr)
     if o.ref_lib() is not None:
         ref = o.RefEquipartition(eq.calc_error, resolution=1.0 / nwav_s, partition_tolerance=tol_tol,
-                                 partition_max_iterations=max_it)
+                                 partition_max_iterations=max_it, parallel=True)
         devnull = os.open(os.devnull, os.O_WRONLY)
         saved = os.dup(1)
         os.dup2(devnull, 1)  # the reference search prints progress to stdout
@@ -250,7 +251,7 @@ def main():
         if world == 1 and not args.no_cpu:
             pts, cdt, cng, ccost, search = cpu_baseline(args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance,
                                                         args.tolerance_tolerance, args.max_iterations)
-            out["cpu_baseline"] = {"value": pts / cdt, "unit": "wavenumber-points/s", "cores": 1, "kind": "port",
+            out["cpu_baseline"] = {"value": pts / cdt, "unit": "wavenumber-points/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": "oracle reorder + gas prep + %s over oracle calc_error, nwav=%d "
                                              "(same generator, ng=%d, N_pass=%.1f, %.1f s)"
                                              % (search, args.cpu_sample, cng, ccost, cdt)}

@@ -249,7 +249,7 @@ class RefEquipartition:
     """The REFERENCE's Equipartition (oracle/_ref) driven by a Python calc_error callable."""
 
     def __init__(self, calc_error, resolution=0.0, partition_tolerance=0.05, partition_max_iterations=20,
-                 line_search_max_iterations=10, cubic=False, minimize_frac_range=True, verbose=0):
+                 line_search_max_iterations=10, cubic=False, minimize_frac_range=True, verbose=0, parallel=False):
         r = ref_lib()
         if r is None:
             raise RuntimeError("oracle/_ref/libequipartition_ref.so not built")
@@ -270,7 +270,9 @@ class RefEquipartition:
         r.refep_set_line_search_max_iterations(self.h, C.c_int(line_search_max_iterations))
         r.refep_set_cubic_interpolation(self.h, C.c_int(1 if cubic else 0))
         r.refep_set_minimize_frac_range(self.h, C.c_int(1 if minimize_frac_range else 0))
-        r.refep_set_parallel(self.h, C.c_int(0))
+        # find_g_points.cpp:231 turns the OpenMP loop of calc_error_all on (equipartition.h:100-104); the tests keep
+        # it off so that the recorded call sequence is deterministic
+        r.refep_set_parallel(self.h, C.c_int(1 if parallel else 0))
 
     def __del__(self):
         try:
