@@ -131,7 +131,28 @@ SIGNATURES = {
     "ecckd_find_g_band": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_int,
                                     C.c_int, C.c_int, C.POINTER(C.c_int), _c_double_p, _c_double_p, C.c_int,
                                     C.POINTER(C.c_int), _c_double_p]),
+    "ecckd_regroup_rank_by_wavenumber_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                       C.c_size_t, C.c_int, _c_double_p, _c_int64_p]),
+    "ecckd_subband_setup_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                          C.c_double, C.c_double, C.c_double, C.c_int, _c_double_p,
+                                          C.POINTER(C.c_int), _c_int64_p, _c_int64_p, _c_int64_p]),
+    "ecckd_find_g_band_ex": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_int,
+                                       C.c_void_p, C.POINTER(C.c_int), _c_double_p, _c_double_p, _c_int64_p,
+                                       _c_int64_p, C.c_int, C.POINTER(C.c_int), _c_double_p]),
+    "ecckd_gas_median_sorting_variable": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_int64_p, _c_int64_p,
+                                                    _c_double_p]),
+    "ecckd_gather_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ecckd_invert_permutation_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }
+
+
+class BandOptions(C.Structure):
+    """ecckd_band_options (include/ecckd_hip.h)."""
+    _fields_ = [("min_g_points", C.c_int), ("max_g_points", C.c_int), ("nsubband", C.c_int),
+                ("isubband1", _c_int64_p), ("isubband2", _c_int64_p), ("iupperindex", C.c_int64),
+                ("g_split", C.c_double), ("base_split", C.c_double), ("nbase_wn_bound", C.c_int),
+                ("base_wn_bound", _c_double_p), ("d_wavenumber", C.c_void_p), ("d_rank", C.c_void_p),
+                ("nwav", C.c_size_t)]
 
 
 

@@ -386,6 +386,106 @@ class GasLW:
         return st.value, b[:n + 1].copy(), e[:n].copy(), cc.value
 
 
+    def find_g_band_ex(self, ibegin, iend, heating_rate_tolerance, tolerance_tolerance=0.02, max_iterations=60,
+                       min_g_points=1, max_g_points=256, subbands=None, g_split=0.0, base_split=1.0,
+                       base_wn_bound=None, wavenumber=None, rank=None, capacity=1024):
+        """Everything find_g_points.cpp:1152-1414 does for one band: sub-band searches (`subbands` =
+        (isubband1, isubband2, iupperindex) from subband_setup), min/max restarts, the base split (`rank` is
+        re-ranked in place when `base_wn_bound` has interior boundaries) and the rank range of each g point.
+        -> dict(status, bounds, error, rank1, rank2, comp_cost)."""
+        o = _lib.BandOptions()
+        o.min_g_points, o.max_g_points = int(min_g_points), int(max_g_points)
+        keep = []
+        if subbands is not None:
+            i1 = np.ascontiguousarray(subbands[0], dtype=np.int64)
+            i2 = np.ascontiguousarray(subbands[1], dtype=np.int64)
+            keep += [i1, i2]
+            o.nsubband = i1.size
+            o.isubband1 = i1.ctypes.data_as(C.POINTER(C.c_int64))
+            o.isubband2 = i2.ctypes.data_as(C.POINTER(C.c_int64))
+            o.iupperindex = int(subbands[2])
+        o.g_split, o.base_split = float(g_split), float(base_split)
+        if base_wn_bound is not None:
+            bw = np.ascontiguousarray(base_wn_bound, dtype=np.float64)
+            keep.append(bw)
+            o.nbase_wn_bound = bw.size
+            o.base_wn_bound = bw.ctypes.data_as(C.POINTER(C.c_double))
+            if bw.size > 2:
+                o.d_wavenumber, o.d_rank, o.nwav = wavenumber.data_ptr(), rank.data_ptr(), rank.numel()
+        b = np.zeros(capacity + 1)
+        e = np.zeros(capacity)
+        r1 = np.zeros(capacity, dtype=np.int64)
+        r2 = np.zeros(capacity, dtype=np.int64)
+        ng, st, cc = C.c_int(), C.c_int(), C.c_double()
+        self.ctx.fence_from_torch()
+        check(self.lib.ecckd_find_g_band_ex(self.handle, int(ibegin), int(iend), float(heating_rate_tolerance),
+                                            float(tolerance_tolerance), int(max_iterations), C.byref(o), C.byref(ng),
+                                            _hptr(b), _hptr(e), r1.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            r2.ctypes.data_as(C.POINTER(C.c_int64)), capacity, C.byref(st), C.byref(cc)))
+        n = ng.value
+        return dict(status=st.value, bounds=b[:n + 1].copy(), error=e[:n].copy(), rank1=r1[:n].copy(),
+                    rank2=r2[:n].copy(), comp_cost=cc.value)
+
+    def median_sorting_variable(self, sorting_variable_sorted, ind1, ind2):
+        """calc_median_sorting_variable (find_g_points.cpp:35-49) per g point; `sorting_variable_sorted` is a
+        device tensor in this gas's sorted order."""
+        i1 = np.ascontiguousarray(ind1, dtype=np.int64)
+        i2 = np.ascontiguousarray(ind2, dtype=np.int64)
+        out = np.zeros(i1.size)
+        self.ctx.fence_from_torch()
+        check(self.lib.ecckd_gas_median_sorting_variable(self.handle, _dptr(sorting_variable_sorted), i1.size,
+                                                         i1.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                         i2.ctypes.data_as(C.POINTER(C.c_int64)), _hptr(out)))
+        return out
+
+
+def regroup_rank_by_wavenumber(ctx, wavenumber, rank, rank_lo, rank_hi, wn_bound):
+    """Stable re-ranking of the ranks [rank_lo, rank_hi] by wavenumber group (find_g_points.cpp:832-866,
+    :1311-1346); `rank` (int32 device tensor, original order) is updated in place -> group sizes."""
+    wb = np.ascontiguousarray(wn_bound, dtype=np.float64)
+    cnt = np.zeros(wb.size - 1, dtype=np.int64)
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_regroup_rank_by_wavenumber_dev(ctx.handle, rank.numel(), _dptr(wavenumber), _dptr(rank),
+                                                       int(rank_lo), int(rank_hi), wb.size - 1, _hptr(wb),
+                                                       cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+    return cnt
+
+
+def subband_setup(ctx, wavenumber, rank, ibegin, iend, g_split, band_bound1, band_bound2, boundaries):
+    """find_g_points.cpp:799-868 for one band -> (isubband1, isubband2, iupperindex) or None if not split."""
+    bd = np.ascontiguousarray(boundaries, dtype=np.float64)
+    i1 = np.zeros(bd.size + 1, dtype=np.int64)
+    i2 = np.zeros(bd.size + 1, dtype=np.int64)
+    nsub, iup = C.c_int(), C.c_int64()
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_subband_setup_dev(ctx.handle, rank.numel(), _dptr(wavenumber), _dptr(rank), int(ibegin),
+                                          int(iend), float(g_split), float(band_bound1), float(band_bound2), bd.size,
+                                          _hptr(bd), C.byref(nsub), i1.ctypes.data_as(C.POINTER(C.c_int64)),
+                                          i2.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(iup)))
+    if nsub.value == 0:
+        return None
+    return i1[:nsub.value].copy(), i2[:nsub.value].copy(), int(iup.value)
+
+
+def gather_f64(ctx, src, index):
+    """dst[i] = src[index[i]] on the device (the reordering gathers of find_g_points.cpp:781,:865)."""
+    import torch
+    dst = torch.empty(index.numel(), dtype=torch.float64, device=src.device)
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_gather_f64_dev(ctx.handle, index.numel(), _dptr(src), _dptr(index), _dptr(dst)))
+    ctx.synchronize()          # the kernel ran on the context's stream, torch reads on its own
+    return dst
+
+
+def invert_permutation(ctx, perm):
+    """inverse[perm[i]] = i (ireorder from irank, find_g_points.cpp:778-779)."""
+    import torch
+    inv = torch.empty_like(perm)
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_invert_permutation_dev(ctx.handle, perm.numel(), _dptr(perm), _dptr(inv)))
+    return inv
+
+
 class GasSW(GasLW):
     """A prepared shortwave gas (ecckd_gas_create_sw); same batched-error interface as GasLW."""
 

@@ -1,0 +1,416 @@
+// find_g_band.hip - the per-band driver logic of find_g_points on top of the batched interval
+// errors: sub-bands of the optically thin part of a band (find_g_points.cpp:786-870, :1186-1229),
+// the plain search with its min/max g-point restarts (:1231-1258), the base split (:1265-1383),
+// the rank range of every g point (:1396-1401) and the median sorting variable (:35-49).
+// The index work that touches every wavenumber (re-ranking a rank range by wavenumber group,
+// gathers, the cumulative-weight search) runs on the device; the search itself is the host
+// PartitionSearch that drives ecckd_calc_error_batch.
+#include "gas.hpp"
+#include "partition_search.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int MAX_GROUPS = 32;
+struct GroupBounds {
+  int n;
+  double b[MAX_GROUPS + 1];
+};
+
+// key[r - lo] = wavenumber group of the point whose rank r lies in [lo, hi]; group sizes by integer
+// atomics (order-independent).  Group n = "in no group".
+__global__ void __launch_bounds__(256)
+k_regroup_key(size_t nwav, const double* __restrict__ wn, const int32_t* __restrict__ rank, long long lo,
+              long long hi, GroupBounds gb, double* __restrict__ key, unsigned long long* __restrict__ count) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nwav) return;
+  const long long r = rank[j];
+  if (r < lo || r > hi) return;
+  const double w = wn[j];
+  int s = gb.n;
+  for (int q = 0; q < gb.n; ++q)
+    if (w >= gb.b[q] && w < gb.b[q + 1]) { s = q; break; }
+  key[r - lo] = (double)s;
+  atomicAdd(&count[s], 1ULL);
+}
+
+__global__ void __launch_bounds__(256)
+k_regroup_apply(size_t nwav, int32_t* __restrict__ rank, long long lo, long long hi,
+                const int32_t* __restrict__ newpos) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nwav) return;
+  const long long r = rank[j];
+  if (r < lo || r > hi) return;
+  rank[j] = (int32_t)(lo + newpos[r - lo]);
+}
+
+__global__ void __launch_bounds__(256)
+k_gather_f64(size_t n, const double* __restrict__ src, const int32_t* __restrict__ index, double* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[index[i]];
+}
+
+__global__ void __launch_bounds__(256)
+k_invert_perm(size_t n, const int32_t* __restrict__ perm, int32_t* __restrict__ inv, int* __restrict__ err) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t r = perm[i];
+  if (r < 0 || (size_t)r >= n) { atomicOr(err, 1); return; }
+  inv[r] = (int32_t)i;
+}
+
+// calc_median_sorting_variable (find_g_points.cpp:35-49), one block per g point.
+// Pass 1: total weight of [i1, i2] (fixed strided order + fixed tree).  Pass 2: walk the interval
+// in chunks of 256 x 16 points; an exclusive scan of the 256 per-thread partial sums locates the
+// thread whose 16 points contain the first crossing of half the total, and that thread walks them.
+constexpr int MED_PER = 16;
+__global__ void __launch_bounds__(256)
+k_median_sorting(const long long* __restrict__ ind1, const long long* __restrict__ ind2,
+                 const double* __restrict__ weight, const double* __restrict__ sv, double* __restrict__ out) {
+  __shared__ double s_part[256];
+  __shared__ double s_scan[257];
+  __shared__ long long s_found;
+  __shared__ double s_carry;
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const long long i1 = ind1[k], i2 = ind2[k];
+  double acc = 0.0;
+  for (long long i = i1 + tid; i <= i2; i += 256) acc += weight[i];
+  s_part[tid] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) s_part[tid] += s_part[tid + off];
+    __syncthreads();
+  }
+  const double half = 0.5 * s_part[0];
+  if (tid == 0) { s_found = -1; s_carry = 0.0; }
+  __syncthreads();
+  // the reference loop runs iind = i1 .. i2-1 and falls through to i2 (:42-47)
+  for (long long base = i1; base < i2; base += 256 * MED_PER) {
+    const long long a = base + (long long)tid * MED_PER;
+    double part = 0.0;
+    for (int q = 0; q < MED_PER; ++q) {
+      const long long i = a + q;
+      if (i < i2) part += weight[i];
+    }
+    s_part[tid] = part;
+    __syncthreads();
+    if (tid == 0) {
+      double run = s_carry;
+      for (int t = 0; t < 256; ++t) { s_scan[t] = run; run += s_part[t]; }
+      s_scan[256] = run;
+    }
+    __syncthreads();
+    const double before = s_scan[tid], after = s_scan[tid + 1];
+    if (before < half && after >= half) {
+      double cum = before;
+      for (int q = 0; q < MED_PER; ++q) {
+        const long long i = a + q;
+        if (i >= i2) break;
+        cum += weight[i];
+        if (cum >= half) { s_found = i; break; }
+      }
+    }
+    __syncthreads();
+    if (s_found >= 0) break;
+    if (tid == 0) s_carry = s_scan[256];
+    __syncthreads();
+  }
+  if (tid == 0) out[k] = sv[s_found >= 0 ? s_found : i2];
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int ecckd_gather_f64_dev(ecckd_ctx* ctx, size_t n, const double* d_src, const int32_t* d_index, double* d_dst) {
+  ECCKD_REQUIRE(ctx && (n == 0 || (d_src && d_index && d_dst)), "ecckd_gather_f64_dev: NULL argument");
+  if (n == 0) return ECCKD_OK;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_gather_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, d_src, d_index, d_dst);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  return ECCKD_OK;
+}
+
+int ecckd_invert_permutation_dev(ecckd_ctx* ctx, size_t n, const int32_t* d_perm, int32_t* d_inverse) {
+  ECCKD_REQUIRE(ctx && (n == 0 || (d_perm && d_inverse)), "ecckd_invert_permutation_dev: NULL argument");
+  if (n == 0) return ECCKD_OK;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  DevBuf flag;
+  ECCKD_HIP_CHECK(hipMalloc(&flag.p, sizeof(int)));
+  ECCKD_HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, d_perm, d_inverse,
+                     (int*)flag.p);
+  int h = 0;
+  ECCKD_HIP_CHECK(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ECCKD_REQUIRE(h == 0, "ecckd_invert_permutation_dev: entries outside 0..n-1");
+  return ECCKD_OK;
+}
+
+int ecckd_regroup_rank_by_wavenumber_dev(ecckd_ctx* ctx, size_t nwav, const double* d_wavenumber, int32_t* d_rank,
+                                         size_t rank_lo, size_t rank_hi, int nsub, const double* h_wn_bound,
+                                         int64_t* h_count) {
+  ECCKD_REQUIRE(ctx && d_wavenumber && d_rank && h_wn_bound, "ecckd_regroup_rank_by_wavenumber_dev: NULL argument");
+  ECCKD_REQUIRE(nsub >= 1 && nsub <= MAX_GROUPS, "ecckd_regroup_rank_by_wavenumber_dev: 1..%d groups supported, got %d",
+                MAX_GROUPS, nsub);
+  ECCKD_REQUIRE(rank_lo <= rank_hi && rank_hi < nwav, "ecckd_regroup_rank_by_wavenumber_dev: rank range [%zu,%zu] outside 0..%zu",
+                rank_lo, rank_hi, nwav);
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const size_t m = rank_hi - rank_lo + 1;
+  GroupBounds gb;
+  gb.n = nsub;
+  for (int q = 0; q <= nsub; ++q) gb.b[q] = h_wn_bound[q];
+  DevBuf key, newpos, count;
+  ECCKD_HIP_CHECK(hipMalloc(&key.p, m * sizeof(double)));
+  ECCKD_HIP_CHECK(hipMalloc(&newpos.p, m * sizeof(int32_t)));
+  ECCKD_HIP_CHECK(hipMalloc(&count.p, (MAX_GROUPS + 1) * sizeof(unsigned long long)));
+  ECCKD_HIP_CHECK(hipMemsetAsync(count.p, 0, (MAX_GROUPS + 1) * sizeof(unsigned long long), ctx->stream));
+  // a rank that is not a permutation leaves holes: fill with the "no group" key so they are counted
+  const unsigned eblocks = (unsigned)((nwav + 255) / 256);
+  hipLaunchKernelGGL(k_regroup_key, dim3(eblocks), dim3(256), 0, ctx->stream, nwav, d_wavenumber, d_rank,
+                     (long long)rank_lo, (long long)rank_hi, gb, (double*)key.p, (unsigned long long*)count.p);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  unsigned long long h_cnt[MAX_GROUPS + 1];
+  ECCKD_HIP_CHECK(hipMemcpyAsync(h_cnt, count.p, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  unsigned long long assigned = 0;
+  for (int q = 0; q < nsub; ++q) {
+    assigned += h_cnt[q];
+    if (h_count) h_count[q] = (int64_t)h_cnt[q];
+  }
+  if (assigned != m) return ecckd::fail(ECCKD_PARAMETER_ERROR, "Failed to account for all wavenumbers in split");
+  const int64_t b0 = 0, b1 = (int64_t)m - 1;
+  ECCKD_CHECK(ecckd_stable_argsort_bands_dev(ctx, m, (const double*)key.p, 1, &b0, &b1, (int32_t*)newpos.p, nullptr));
+  hipLaunchKernelGGL(k_regroup_apply, dim3(eblocks), dim3(256), 0, ctx->stream, nwav, d_rank, (long long)rank_lo,
+                     (long long)rank_hi, (const int32_t*)newpos.p);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
+}
+
+int ecckd_subband_setup_dev(ecckd_ctx* ctx, size_t nwav, const double* d_wavenumber, int32_t* d_rank, size_t ibegin,
+                            size_t iend, double g_split, double band_bound1, double band_bound2, int nboundary,
+                            const double* h_boundary, int* nsubband, int64_t* h_isubband1, int64_t* h_isubband2,
+                            int64_t* iupperindex) {
+  ECCKD_REQUIRE(ctx && nsubband && h_isubband1 && h_isubband2 && iupperindex && (nboundary == 0 || h_boundary),
+                "ecckd_subband_setup_dev: NULL argument");
+  ECCKD_REQUIRE(ibegin <= iend && iend < nwav, "ecckd_subband_setup_dev: band [%zu,%zu] outside the spectrum", ibegin, iend);
+  *nsubband = 0;
+  *iupperindex = -1;
+  // :800-802 the band is split only if g_split > 0 and a boundary lies strictly inside it
+  std::vector<double> inside;
+  for (int q = 0; q < nboundary; ++q)
+    if (h_boundary[q] > band_bound1 && h_boundary[q] < band_bound2) inside.push_back(h_boundary[q]);
+  if (!(g_split > 0.0) || inside.empty()) return ECCKD_OK;
+  const long long irank1 = (long long)ibegin, irank3 = (long long)iend;
+  long long irank2 = irank3;
+  *iupperindex = irank3;
+  if (g_split < 1.0) irank2 = (long long)((double)irank1 + g_split * (double)(irank3 - irank1));  // :813-815 (int truncation)
+  const int nsub = 1 + (int)inside.size();
+  std::vector<double> wn_bound(nsub + 1);
+  wn_bound[0] = band_bound1;
+  wn_bound[nsub] = band_bound2 + 1.0;  // :824
+  for (int q = 0; q < nsub - 1; ++q) wn_bound[q + 1] = inside[q];
+  std::vector<int64_t> count(nsub);
+  ECCKD_CHECK(ecckd_regroup_rank_by_wavenumber_dev(ctx, nwav, d_wavenumber, d_rank, (size_t)irank1, (size_t)irank2, nsub,
+                                                   wn_bound.data(), count.data()));
+  long long first = irank1;
+  for (int q = 0; q < nsub; ++q) {
+    h_isubband1[q] = first;
+    h_isubband2[q] = first + count[q] - 1;
+    first = h_isubband2[q] + 1;
+  }
+  *nsubband = nsub;
+  return ECCKD_OK;
+}
+
+int ecckd_gas_median_sorting_variable(ecckd_gas* g, const double* d_sorting_variable_sorted, int n, const int64_t* h_ind1,
+                                      const int64_t* h_ind2, double* h_median) {
+  ECCKD_REQUIRE(g && d_sorting_variable_sorted && (n == 0 || (h_ind1 && h_ind2 && h_median)),
+                "ecckd_gas_median_sorting_variable: NULL argument");
+  if (n <= 0) return ECCKD_OK;
+  ecckd_ctx* ctx = g->ctx;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  for (int k = 0; k < n; ++k)
+    ECCKD_REQUIRE(h_ind1[k] >= 0 && h_ind1[k] <= h_ind2[k] && (size_t)h_ind2[k] < g->n,
+                  "ecckd_gas_median_sorting_variable: interval %d [%lld,%lld] outside the spectrum", k,
+                  (long long)h_ind1[k], (long long)h_ind2[k]);
+  // weight: surface Planck function (LW, :1405) or reordered solar irradiance (SW, :1408)
+  const double* weight = g->do_sw ? g->ssi : g->planck_hl + (size_t)g->nlay * g->n;
+  DevBuf buf;
+  ECCKD_HIP_CHECK(hipMalloc(&buf.p, (size_t)n * (2 * sizeof(long long) + sizeof(double))));
+  long long* d_i1 = (long long*)buf.p;
+  long long* d_i2 = d_i1 + n;
+  double* d_out = (double*)(d_i2 + n);
+  std::vector<long long> tmp(2 * (size_t)n);
+  for (int k = 0; k < n; ++k) { tmp[k] = h_ind1[k]; tmp[n + k] = h_ind2[k]; }
+  ECCKD_HIP_CHECK(hipMemcpyAsync(d_i1, tmp.data(), tmp.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_median_sorting, dim3(n), dim3(256), 0, ctx->stream, d_i1, d_i2, weight, d_sorting_variable_sorted, d_out);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  ECCKD_HIP_CHECK(hipMemcpyAsync(h_median, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
+}
+
+int ecckd_find_g_band_ex(ecckd_gas* g, size_t ibegin, size_t iend, double heating_rate_tolerance, double tolerance_tolerance,
+                         int max_iterations, const ecckd_band_options* opt, int* ng, double* bounds, double* error,
+                         int64_t* rank1, int64_t* rank2, int capacity, int* status, double* comp_cost) {
+  ECCKD_REQUIRE(g && opt && ng && bounds && error && status, "ecckd_find_g_band_ex: NULL argument");
+  ECCKD_REQUIRE(iend >= ibegin && iend < g->n, "ecckd_find_g_band_ex: band [%zu,%zu] outside the spectrum", ibegin, iend);
+  const size_t npoints = iend - ibegin + 1;
+  const double cost0 = g->total_comp_cost;
+  int rc_eval = ECCKD_OK;
+  ecckd::PartitionSearch ps([&](int n, const double* b1, const double* b2, double* e) {
+    rc_eval = ecckd_calc_error_batch(g, ibegin, npoints, n, b1, b2, e);
+    return rc_eval;
+  });
+  // CkdEquipartition::init_lw / init_sw (find_g_points.cpp:230-233, :256-261) + :1180-1181
+  ps.set_resolution(1.0 / (double)npoints);
+  ps.set_minimize_frac_range(true);
+  ps.set_partition_max_iterations(max_iterations);
+  ps.set_partition_tolerance(tolerance_tolerance);
+  // CkdEquipartition::lower_index / upper_index (:282-287)
+  auto lower_index = [&](double b) { return (long long)std::ceil(b * (double)(npoints - 1)); };
+  auto upper_index = [&](double b) { return (long long)std::floor(b * (double)(npoints - 1)); };
+
+  std::vector<double> b, e;
+  int n = 10;
+  int st = 0;
+  if (opt->nsubband > 1) {
+    // ---- :1186-1229 one search per sub-band of the optically thin part, then the overarching rest ----
+    ECCKD_REQUIRE(opt->isubband1 && opt->isubband2, "ecckd_find_g_band_ex: sub-band ranks missing");
+    const double denom = (double)(opt->iupperindex - opt->isubband1[0]);
+    n = 0;
+    for (int jsub = 0; jsub < opt->nsubband; ++jsub) {
+      std::vector<double> sb, se;
+      int nsubg = 4;
+      const double g_start = (double)(opt->isubband1[jsub] - opt->isubband1[0]) / denom;
+      const double g_end = (double)(opt->isubband2[jsub] - opt->isubband1[0]) / denom;
+      st = ps.equipartition_e(heating_rate_tolerance, g_start, g_end, nsubg, sb, se);
+      if (ps.evaluator_status()) return rc_eval ? rc_eval : ECCKD_PROCESSING_ERROR;
+      b.insert(b.begin() + n, sb.begin(), sb.end());
+      e.insert(e.end(), se.begin(), se.end());
+      n += nsubg;
+    }
+    if (opt->g_split < 1.0) {
+      std::vector<double> sb, se;
+      int nsubg = 4;
+      const double g_start = (double)(opt->isubband2[opt->nsubband - 1] - opt->isubband1[0]) / denom;
+      st = ps.equipartition_e(heating_rate_tolerance, g_start, 1.0, nsubg, sb, se);
+      if (ps.evaluator_status()) return rc_eval ? rc_eval : ECCKD_PROCESSING_ERROR;
+      if (n + nsubg < opt->min_g_points) {
+        nsubg = opt->min_g_points - n;
+        sb.resize(nsubg + 1);
+        se.resize(nsubg);
+        for (int i = 0; i <= nsubg; ++i)
+          sb[i] = opt->g_split + (1.0 - opt->g_split) * std::sqrt((double)i / (double)nsubg);
+        st = ps.equipartition_n(nsubg, sb.data(), se.data());
+        if (ps.evaluator_status()) return rc_eval ? rc_eval : ECCKD_PROCESSING_ERROR;
+      }
+      b.insert(b.begin() + n, sb.begin(), sb.end());
+      e.insert(e.end(), se.begin(), se.end());
+      n += nsubg;
+    }
+    b.resize(n + 1);
+  } else {
+    st = ps.equipartition_e(heating_rate_tolerance, 0.0, 1.0, n, b, e);
+    const int min_g = opt->min_g_points, max_g = opt->max_g_points > 0 ? opt->max_g_points : 0x7fffffff;
+    if (!ps.evaluator_status() && (n < min_g || n > max_g)) {
+      // :1232-1257 restart from bounds sqrt(i/ng)
+      n = (n < min_g) ? min_g : max_g;
+      b.resize(n + 1);
+      e.resize(n);
+      for (int i = 0; i <= n; ++i) b[i] = std::sqrt((double)i / (double)n);
+      st = ps.equipartition_n(n, b.data(), e.data());
+    }
+    if (ps.evaluator_status()) return rc_eval ? rc_eval : ECCKD_PROCESSING_ERROR;
+  }
+
+  // ---- :1265-1383 dissect the base g point by wavenumber and / or absorption ----
+  const int nwavsplit = opt->nbase_wn_bound >= 2 ? opt->nbase_wn_bound - 1 : 1;
+  const double base_split = opt->base_split == 0.0 ? 1.0 : opt->base_split;  // zero-initialised struct = no split
+  if (base_split != 1.0 || nwavsplit > 1) {
+    int nabssplit = 1;
+    if (base_split > 1.0) {
+      nabssplit = (int)base_split;
+      if (nabssplit == 1) return ecckd::fail(ECCKD_PARAMETER_ERROR, "Positive values of base_split must be at least 2");
+    } else {
+      nabssplit = 2 + (int)(base_split * n);  // always split into at least two (:1285)
+    }
+    const int nsplit = nwavsplit * nabssplit;
+    std::vector<long long> iwav1(nwavsplit), iwav2(nwavsplit);
+    iwav1[0] = (long long)ibegin;
+    iwav2[nwavsplit - 1] = (long long)iend;
+    if (nwavsplit > 1) {
+      ECCKD_REQUIRE(opt->base_wn_bound && opt->d_wavenumber && opt->d_rank && opt->nwav > 0,
+                    "ecckd_find_g_band_ex: wavenumber split of the base g point needs wavenumber and rank");
+      const long long ind2 = upper_index(b[1]) + (long long)ibegin;
+      // :1317 "iwav1(0) = 0": the new ranks are counted from 0, so the split is only consistent for a
+      // band that starts at rank 0; any other band ends in the reference's :1335-1338 error
+      if (ibegin != 0) return ecckd::fail(ECCKD_PARAMETER_ERROR, "Failed to account for all wavenumbers in split");
+      std::vector<int64_t> count(nwavsplit);
+      ECCKD_CHECK(ecckd_regroup_rank_by_wavenumber_dev(g->ctx, opt->nwav, opt->d_wavenumber, opt->d_rank, 0, (size_t)ind2,
+                                                       nwavsplit, opt->base_wn_bound, count.data()));
+      iwav1[0] = 0;
+      for (int q = 0; q < nwavsplit; ++q) {
+        if (q > 0) iwav1[q] = iwav2[q - 1] + 1;
+        iwav2[q] = iwav1[q] + count[q] - 1;
+      }
+    }
+    const double upper_bound = b[1];
+    double lower_bound_local = b[0];
+    e[0] = -1.0;  // first error is now incorrect (:1352)
+    int ibnd = 0;
+    for (int iw = 0; iw < nwavsplit; ++iw) {
+      const double upper_bound_local = upper_bound * (double)iwav2[iw] / (double)iwav2[nwavsplit - 1];
+      for (int ia = 0; ia < nabssplit; ++ia) {
+        if (ia < nabssplit - 1 || iw < nwavsplit - 1) {
+          b.insert(b.begin() + ibnd + 1,
+                   lower_bound_local + (upper_bound_local - lower_bound_local) * (double)(ia + 1) / (double)nabssplit);
+          e.insert(e.begin() + ibnd, -1.0);
+          ++ibnd;
+        }
+      }
+      lower_bound_local = upper_bound_local;
+    }
+    n += nsplit - 1;
+  }
+
+  for (int i = 0; i < n; ++i)
+    if (!(b[i + 1] - b[i] > 0.0)) return ecckd::fail(ECCKD_PARAMETER_ERROR, "Bounds are not monotonically increasing");  // :1390-1393
+
+  *status = st;
+  *ng = n;
+  if (comp_cost) *comp_cost = g->total_comp_cost - cost0;
+  ECCKD_REQUIRE(n <= capacity, "ecckd_find_g_band_ex: %d g points exceed the caller's capacity %d", n, capacity);
+  std::memcpy(bounds, b.data(), (size_t)(n + 1) * sizeof(double));
+  std::memcpy(error, e.data(), (size_t)n * sizeof(double));
+  for (int i = 0; i < n; ++i) {
+    if (rank1) rank1[i] = lower_index(b[i]) + (long long)ibegin;       // :1397
+    if (rank2) rank2[i] = upper_index(b[i + 1]) + (long long)ibegin;   // :1398
+  }
+  return ECCKD_OK;
+}
+
+int ecckd_find_g_band(ecckd_gas* g, size_t ibegin, size_t iend, double heating_rate_tolerance, double tolerance_tolerance,
+                      int max_iterations, int min_g_points, int max_g_points, int* ng, double* bounds, double* error,
+                      int capacity, int* status, double* comp_cost) {
+  ecckd_band_options opt;
+  std::memset(&opt, 0, sizeof(opt));
+  opt.min_g_points = min_g_points;
+  opt.max_g_points = max_g_points;
+  opt.base_split = 1.0;
+  return ecckd_find_g_band_ex(g, ibegin, iend, heating_rate_tolerance, tolerance_tolerance, max_iterations, &opt, ng,
+                              bounds, error, nullptr, nullptr, capacity, status, comp_cost);
+}
+
+}  // extern "C"

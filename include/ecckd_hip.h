@@ -217,6 +217,70 @@ int ecckd_find_g_band(ecckd_gas* gas, size_t ibegin, size_t iend, double heating
                       int max_g_points, int* ng, double* bounds, double* error, int capacity,
                       int* status, double* comp_cost);
 
+/* ---- sub-bands and base split of find_g_points --------------------------------
+ * find_g_points.cpp:786-870 (sub-bands of the optically thin part of a band) and :1311-1346
+ * (wavenumber split of the base g point) both re-rank a contiguous range of ranks
+ * [rank_lo, rank_hi] so that the points are grouped by wavenumber interval
+ * [h_wn_bound[s], h_wn_bound[s+1]) while keeping their rank order inside each group (a stable
+ * partition).  d_rank[nwav] (rank of every wavenumber, original order) is updated in place;
+ * h_count[nsub] receives the group sizes.  Returns ECCKD_PARAMETER_ERROR ("Failed to account
+ * for all wavenumbers in split", :855-858, :1335-1338) if a point of the range lies in no group. */
+int ecckd_regroup_rank_by_wavenumber_dev(ecckd_ctx* ctx, size_t nwav, const double* d_wavenumber,
+                                         int32_t* d_rank, size_t rank_lo, size_t rank_hi, int nsub,
+                                         const double* h_wn_bound, int64_t* h_count);
+
+/* Sub-band set-up of one band, find_g_points.cpp:799-868.  [ibegin, iend] is the rank range of
+ * the band (ibandloc(0), ibandloc(end)); h_boundary[nboundary] the configured
+ * subband_wavenumber_boundary.  Outputs: *nsubband (0 if the band is not split), the first /
+ * last rank of every sub-band (capacity nboundary + 1 each) and *iupperindex (:812).
+ * d_rank is re-ranked in place; create the gas from it afterwards. */
+int ecckd_subband_setup_dev(ecckd_ctx* ctx, size_t nwav, const double* d_wavenumber, int32_t* d_rank,
+                            size_t ibegin, size_t iend, double g_split, double band_bound1,
+                            double band_bound2, int nboundary, const double* h_boundary,
+                            int* nsubband, int64_t* h_isubband1, int64_t* h_isubband2,
+                            int64_t* iupperindex);
+
+/* Everything find_g_points does for one band after the gas is prepared (:1152-1414): the
+ * partition search (plain, :1231-1258, or per sub-band, :1186-1229), the base split
+ * (:1265-1383, incl. the re-ranking of the base g point by wavenumber) and the rank range of
+ * every g point (:1396-1401).  Zero-initialise the struct for the plain case. */
+typedef struct {
+  int min_g_points, max_g_points;
+  /* sub-bands, from ecckd_subband_setup_dev; nsubband <= 1: none */
+  int nsubband;
+  const int64_t* isubband1;
+  const int64_t* isubband2;
+  int64_t iupperindex;
+  double g_split;
+  /* base split: base_split == 1 and nbase_wn_bound < 3: none (:1268-1271) */
+  double base_split;
+  int nbase_wn_bound;             /* nwavsplit + 1 entries, or 0 */
+  const double* base_wn_bound;    /* band_bound1, interior boundaries, band_bound2 + 1 (:1294-1301) */
+  const double* d_wavenumber;     /* [nwav] original order; needed if nwavsplit > 1 */
+  int32_t* d_rank;                /* [nwav] original order, re-ranked in place if nwavsplit > 1 */
+  size_t nwav;
+} ecckd_band_options;
+int ecckd_find_g_band_ex(ecckd_gas* gas, size_t ibegin, size_t iend, double heating_rate_tolerance,
+                         double tolerance_tolerance, int max_iterations,
+                         const ecckd_band_options* opt, int* ng, double* bounds, double* error,
+                         int64_t* rank1, int64_t* rank2, int capacity, int* status,
+                         double* comp_cost);
+
+/* calc_median_sorting_variable (find_g_points.cpp:35-49) for n g points: the sorting variable
+ * at the point where the cumulative weight (LW: surface Planck function, SW: solar irradiance,
+ * :1404-1409) first reaches half of the interval's total.  d_sorting_variable_sorted[n points]
+ * is in the gas's sorted order (gather it with ecckd_gather_f64_dev).  The cumulative sum is a
+ * blocked scan, so the index can differ from the reference's sequential sum only where the
+ * cumulative weight is within ~1e-13 (relative) of one half. */
+int ecckd_gas_median_sorting_variable(ecckd_gas* gas, const double* d_sorting_variable_sorted, int n,
+                                      const int64_t* h_ind1, const int64_t* h_ind2, double* h_median);
+
+/* d_dst[i] = d_src[d_index[i]], i < n (the reordering gathers of find_g_points.cpp:781,:865). */
+int ecckd_gather_f64_dev(ecckd_ctx* ctx, size_t n, const double* d_src, const int32_t* d_index,
+                         double* d_dst);
+/* d_inverse[d_perm[i]] = i (ireorder(irank) = range(0,n-1), find_g_points.cpp:778-779). */
+int ecckd_invert_permutation_dev(ecckd_ctx* ctx, size_t n, const int32_t* d_perm, int32_t* d_inverse);
+
 /* ---- optimize_lut: cost function, gradient and minimisation (K8/K9) ------------
  * Replaces CkdOptimizable::calc_cost_function_gradient (solve_adept.cpp:240-292), i.e.
  * calc_cost_function_and_gradient (:72-211: CkdModel::calc_optical_depth ckd_model.cpp:925-1102,

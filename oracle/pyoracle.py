@@ -366,3 +366,9 @@ def overlap_g_points(n_g_points, sorting_variables):
         ig += 1                                                                  # :118-121
         ig_gas = [v + 1 for v in ig_gas]
     return ng, band_number, g_min, g_max
+
+
+def median_sorting_variable(sorting_variable, weight, i1, i2):
+    """calc_median_sorting_variable, find_g_points.cpp:35-49 (arrays in sorted order, inclusive indices)."""
+    return float(lib().orc_median_sorting_variable(_p(_f64(sorting_variable)), _p(_f64(weight)),
+                                                   C.c_size_t(int(i1)), C.c_size_t(int(i2))))

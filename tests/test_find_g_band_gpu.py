@@ -1,0 +1,282 @@
+"""GPU parity for the per-band driver logic of find_g_points (row a13): sub-bands of the optically
+thin part of a band (find_g_points.cpp:786-870, :1186-1229), min/max g-point restarts (:1231-1258),
+the base split (:1265-1383), rank ranges of the g points (:1396-1401) and the median sorting
+variable (:35-49).
+
+Oracle: a numpy restatement of those lines (below, each function cites them) that drives the
+REFERENCE's own Equipartition (oracle/_ref, built from equipartition.cpp) over the CPU oracle's
+calc_error.  Index results (re-ranked spectrum, rank ranges, number of g points) must be identical;
+bounds are continuous outputs of a line search over errors that agree to 1e-9 and are compared to 1e-7.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_lw_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(ctx, a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=ctx.device)
+
+
+# ---- numpy restatement of the reference driver -------------------------------------------------------------
+
+def ref_regroup(wn, irank, lo, hi, wn_bound, first=None):
+    """find_g_points.cpp:832-866 / :1319-1346: stable re-ranking of ranks [lo, hi] by wavenumber group."""
+    n = irank.size
+    ireorder = np.empty(n, dtype=np.int64)
+    ireorder[irank] = np.arange(n)
+    wn_s = wn[ireorder]
+    pos = np.arange(n)
+    irank_new = irank.copy()
+    start = lo if first is None else first
+    ends = []
+    for s in range(len(wn_bound) - 1):
+        index = np.nonzero((wn_s >= wn_bound[s]) & (wn_s < wn_bound[s + 1]) & (pos >= lo) & (pos <= hi))[0]
+        irank_new[ireorder[index]] = np.arange(start, start + index.size)
+        start += index.size
+        ends.append(start - 1)
+    return irank_new, ends
+
+
+def ref_subband_setup(wn, irank, ibegin, iend, g_split, bb1, bb2, boundaries):
+    """find_g_points.cpp:799-868 -> (irank_new, isubband1, isubband2, iupperindex) or None."""
+    boundaries = np.asarray(boundaries, dtype=np.float64)
+    inside = boundaries[(boundaries > bb1) & (boundaries < bb2)]
+    if not (g_split > 0.0 and inside.size):
+        return None
+    irank1, irank3 = ibegin, iend
+    irank2 = irank3
+    if g_split < 1.0:
+        irank2 = int(irank1 + g_split * (irank3 - irank1))
+    wn_bound = np.concatenate([[bb1], inside, [bb2 + 1.0]])
+    irank_new, ends = ref_regroup(wn, irank, irank1, irank2, wn_bound)
+    if ends[-1] != irank2:
+        raise ValueError("Failed to account for all wavenumbers in split")
+    i2 = np.array(ends, dtype=np.int64)
+    i1 = np.concatenate([[irank1], i2[:-1] + 1])
+    return irank_new, i1, i2, irank3
+
+
+def ref_band_driver(oracle, eq, npoints, ibegin, tol, tol_tol, max_it, min_g=1, max_g=256, sub=None, g_split=0.0,
+                    base_split=1.0, base_wn_bound=None, wn=None, irank=None):
+    """find_g_points.cpp:1180-1401 with the reference-built search; returns dict like find_g_band_ex."""
+    ref = oracle.RefEquipartition(eq.calc_error, resolution=1.0 / npoints, partition_tolerance=tol_tol,
+                                  partition_max_iterations=max_it)
+    lower = lambda b: int(np.ceil(b * (npoints - 1)))
+    upper = lambda b: int(np.floor(b * (npoints - 1)))
+    if sub is not None and len(sub[0]) > 1:
+        i1, i2, iup = sub
+        denom = float(iup - i1[0])
+        bounds, error, ng = [], [], 0
+        for j in range(len(i1)):
+            st, sb, se = ref.equipartition_e(tol, (i1[j] - i1[0]) / denom, (i2[j] - i1[0]) / denom)
+            bounds[ng:ng] = list(sb)
+            error += list(se)
+            ng += len(se)
+        if g_split < 1.0:
+            st, sb, se = ref.equipartition_e(tol, (i2[-1] - i1[0]) / denom, 1.0)
+            nsubg = len(se)
+            if ng + nsubg < min_g:
+                nsubg = min_g - ng
+                sb = g_split + (1.0 - g_split) * np.sqrt(np.arange(nsubg + 1) / float(nsubg))
+                st, sb, se = ref.equipartition_n(sb)
+            bounds[ng:ng] = list(sb)
+            error += list(se)
+            ng += nsubg
+        bounds = bounds[:ng + 1]
+    else:
+        st, b, e = ref.equipartition_e(tol)
+        ng = len(e)
+        if ng < min_g or ng > max_g:
+            ng = min_g if ng < min_g else max_g
+            st, b, e = ref.equipartition_n(np.sqrt(np.arange(ng + 1) / float(ng)))
+        bounds, error = list(b), list(e)
+    irank_out = irank
+    nwavsplit = 1 if base_wn_bound is None else len(base_wn_bound) - 1
+    if base_split != 1.0 or nwavsplit > 1:
+        nabssplit = int(base_split) if base_split > 1.0 else 2 + int(base_split * ng)
+        iend = ibegin + npoints - 1
+        iwav2 = [iend]
+        if nwavsplit > 1:
+            ind2 = upper(bounds[1]) + ibegin
+            irank_out, iwav2 = ref_regroup(wn, irank, 0, ind2, base_wn_bound, first=0)   # :1317 iwav1(0) = 0
+            if iwav2[-1] != ind2:
+                raise ValueError("Failed to account for all wavenumbers in split")
+        upper_bound, lower_local = bounds[1], bounds[0]
+        error[0] = -1.0
+        ibnd = 0
+        for iw in range(nwavsplit):
+            upper_local = upper_bound * iwav2[iw] / float(iwav2[-1])
+            for ia in range(nabssplit):
+                if ia < nabssplit - 1 or iw < nwavsplit - 1:
+                    bounds.insert(ibnd + 1, lower_local + (upper_local - lower_local) * (ia + 1) / float(nabssplit))
+                    error.insert(ibnd, -1.0)
+                    ibnd += 1
+            lower_local = upper_local
+        ng += nwavsplit * nabssplit - 1
+    bounds, error = np.array(bounds), np.array(error)
+    assert np.all(np.diff(bounds) > 0)
+    rank1 = np.array([lower(bounds[i]) + ibegin for i in range(ng)])
+    rank2 = np.array([upper(bounds[i + 1]) + ibegin for i in range(ng)])
+    return dict(status=st, bounds=bounds, error=error, rank1=rank1, rank2=rank2, irank=irank_out)
+
+
+# ---- problem set-up --------------------------------------------------------------------------------------------
+
+def _base(oracle, nwav, nlay=30, seed=31):
+    from ecckd_amd import synthetic as syn
+    p, wn, dwn, od32 = make_lw_case(nwav, nlay=nlay, seed=seed)
+    _, _, _, bg32 = make_lw_case(nwav, nlay=nlay, seed=seed + 100, column_scale=3.0)
+    od = od32.astype(np.float64)
+    bg = bg32.astype(np.float64) * 0.7 + 1e-4
+    key, col, _ = oracle.reorder_key(p, oracle.idealised_temperature(p), wn, dwn, od, None, 0.5)
+    _, _, rank = oracle.stable_argsort_bands(wn, key, [0.0], [3260.0])
+    return dict(p=p, t_hl=syn.temperature_profile(p), wn=wn, dwn=dwn, od=od, bg=bg, key=key,
+                rank=rank.astype(np.int64))
+
+
+def _sorted_side(oracle, o, rank, method="transmission"):
+    """Oracle side of find_g_points.cpp:891-1150 for a given rank."""
+    n = rank.size
+    ireorder = np.empty(n, dtype=np.int64)
+    ireorder[rank] = np.arange(n)
+    od_s, bg_s = o["od"][:, ireorder], o["bg"][:, ireorder]
+    wn_s, dwn_s = o["wn"][ireorder], o["dwn"][ireorder]
+    planck = oracle.planck_function(o["t_hl"], wn_s, dwn_s)
+    fdn, fup = oracle.radiative_transfer_lw(planck, bg_s + od_s, np.ones(n), planck[-1])
+    hr = oracle.heating_rate(o["p"], fdn, fup)
+    lw = oracle.layer_weight(o["p"], 0.0)
+    eq = oracle.CkdEquipartitionLW(method, 0.02, lw, o["p"], np.ones(n), planck[-1], fdn[-1].copy(), fup[0].copy(),
+                                   planck, bg_s, oracle.metric(method, od_s), hr)
+    return dict(eq=eq, ireorder=ireorder, surf_planck=planck[-1].copy(), key_s=o["key"][ireorder])
+
+
+def _gas(ctx, o, d_rank, method="transmission"):
+    from ecckd_amd import api
+    return api.GasLW(ctx, o["p"], o["t_hl"], _dev(ctx, o["wn"]), _dev(ctx, o["dwn"]), d_rank, _dev(ctx, o["od"]),
+                     _dev(ctx, o["bg"]), method, 0.02, 0.0)
+
+
+def _same_partition(got, ref):
+    assert len(got["error"]) == len(ref["error"])
+    assert np.array_equal(got["rank1"], ref["rank1"]) and np.array_equal(got["rank2"], ref["rank2"])
+    assert np.allclose(got["bounds"], ref["bounds"], rtol=0, atol=1e-7)
+    known = ref["error"] >= 0
+    assert np.array_equal(got["error"] < 0, ~known)                 # -1 marks of the base split
+    assert np.allclose(got["error"][known], ref["error"][known], rtol=1e-6)
+
+
+# ---- tests -----------------------------------------------------------------------------------------------------
+
+def test_regroup_is_the_reference_stable_partition(ctx, oracle):
+    from ecckd_amd import api, EcckdError
+    rs = np.random.RandomState(3)
+    n = 50000
+    wn = np.sort(rs.uniform(0.0, 3260.0, n))
+    rank = rs.permutation(n).astype(np.int64)
+    for lo, hi, wb in ((0, n - 1, [0.0, 500.0, 1800.0, 3261.0]), (1234, 40000, [0.0, 3261.0]),
+                       (7, 7, [0.0, 100.0, 3261.0]), (100, 30000, [0.0, 10.0, 20.0, 1000.0, 1000.5, 3261.0])):
+        want, ends = ref_regroup(wn, rank, lo, hi, np.array(wb))
+        d_rank = _dev(ctx, rank.astype(np.int32))
+        cnt = api.regroup_rank_by_wavenumber(ctx, _dev(ctx, wn), d_rank, lo, hi, wb)
+        assert np.array_equal(d_rank.cpu().numpy(), want)
+        assert np.array_equal(np.cumsum(cnt) + lo - 1, ends)
+        assert np.array_equal(np.sort(want), np.arange(n))          # still a permutation
+    # a point of the range in no group: the reference's "Failed to account for all wavenumbers" error
+    d_rank = _dev(ctx, rank.astype(np.int32))
+    with pytest.raises(EcckdError) as e:
+        api.regroup_rank_by_wavenumber(ctx, _dev(ctx, wn), d_rank, 0, n - 1, [0.0, 500.0, 3000.0])
+    assert e.value.code == 147
+    assert np.array_equal(d_rank.cpu().numpy(), rank)               # untouched
+
+
+def test_plain_band_with_min_and_max_restarts(ctx, oracle):
+    o = _base(oracle, 16000)
+    s = _sorted_side(oracle, o, o["rank"])
+    gas = _gas(ctx, o, _dev(ctx, o["rank"].astype(np.int32)))
+    n = o["rank"].size
+    for kw in (dict(), dict(min_g=14), dict(max_g=3)):
+        ref = ref_band_driver(oracle, s["eq"], n, 0, 0.05, 0.02, 40, **kw)
+        got = gas.find_g_band_ex(0, n - 1, 0.05, 0.02, 40, min_g_points=kw.get("min_g", 1),
+                                 max_g_points=kw.get("max_g", 256))
+        _same_partition(got, ref)
+        assert got["status"] == ref["status"]
+    gas.close()
+
+
+@pytest.mark.parametrize("g_split,min_g", [(0.6, 1), (0.6, 16), (1.0, 1)])
+def test_subbands(ctx, oracle, g_split, min_g):
+    from ecckd_amd import api
+    o = _base(oracle, 16000, seed=33)
+    n = o["rank"].size
+    boundaries = [900.0, 2000.0, 5000.0]                             # the last one is outside the band
+    want = ref_subband_setup(o["wn"], o["rank"], 0, n - 1, g_split, 0.0, 3260.0, boundaries)
+    d_rank = _dev(ctx, o["rank"].astype(np.int32))
+    sub = api.subband_setup(ctx, _dev(ctx, o["wn"]), d_rank, 0, n - 1, g_split, 0.0, 3260.0, boundaries)
+    assert sub is not None and want is not None
+    irank_new, i1, i2, iup = want
+    assert np.array_equal(d_rank.cpu().numpy(), irank_new)
+    assert np.array_equal(sub[0], i1) and np.array_equal(sub[1], i2) and sub[2] == iup
+    s = _sorted_side(oracle, o, irank_new)
+    gas = _gas(ctx, o, d_rank)
+    ref = ref_band_driver(oracle, s["eq"], n, 0, 0.05, 0.02, 40, min_g=min_g, sub=(i1, i2, iup), g_split=g_split)
+    got = gas.find_g_band_ex(0, n - 1, 0.05, 0.02, 40, min_g_points=min_g, subbands=sub, g_split=g_split)
+    _same_partition(got, ref)
+    # no split when g_split = 0 or no boundary inside the band (:800-802)
+    assert api.subband_setup(ctx, _dev(ctx, o["wn"]), d_rank, 0, n - 1, 0.0, 0.0, 3260.0, boundaries) is None
+    assert api.subband_setup(ctx, _dev(ctx, o["wn"]), d_rank, 0, n - 1, 0.5, 0.0, 3260.0, [4000.0]) is None
+    gas.close()
+
+
+@pytest.mark.parametrize("base_split,wn_bound", [(0.1, None), (3.0, None), (1.0, [0.0, 1200.0, 3261.0]),
+                                                 (2.0, [0.0, 700.0, 1500.0, 3261.0])])
+def test_base_split(ctx, oracle, base_split, wn_bound):
+    o = _base(oracle, 16000, seed=35)
+    n = o["rank"].size
+    s = _sorted_side(oracle, o, o["rank"])
+    d_rank = _dev(ctx, o["rank"].astype(np.int32))
+    gas = _gas(ctx, o, d_rank)
+    ref = ref_band_driver(oracle, s["eq"], n, 0, 0.05, 0.02, 40, base_split=base_split,
+                          base_wn_bound=None if wn_bound is None else np.array(wn_bound), wn=o["wn"], irank=o["rank"])
+    got = gas.find_g_band_ex(0, n - 1, 0.05, 0.02, 40, base_split=base_split, base_wn_bound=wn_bound,
+                             wavenumber=_dev(ctx, o["wn"]), rank=d_rank)
+    _same_partition(got, ref)
+    assert np.array_equal(d_rank.cpu().numpy(), ref["irank"])       # re-ranked base g point (or untouched)
+    gas.close()
+
+
+def test_base_split_errors(ctx, oracle):
+    from ecckd_amd import EcckdError
+    o = _base(oracle, 6000, seed=36)
+    n = o["rank"].size
+    d_rank = _dev(ctx, o["rank"].astype(np.int32))
+    gas = _gas(ctx, o, d_rank)
+    with pytest.raises(EcckdError) as e:                             # :1278-1281
+        gas.find_g_band_ex(0, n - 1, 0.05, 0.02, 40, base_split=1.5)
+    assert e.value.code == 147
+    gas.close()
+
+
+def test_median_sorting_variable(ctx, oracle):
+    from ecckd_amd import api
+    o = _base(oracle, 30000, seed=37)
+    n = o["rank"].size
+    s = _sorted_side(oracle, o, o["rank"])
+    d_rank = _dev(ctx, o["rank"].astype(np.int32))
+    gas = _gas(ctx, o, d_rank)
+    ireorder = api.invert_permutation(ctx, d_rank)
+    assert np.array_equal(ireorder.cpu().numpy(), s["ireorder"])
+    sv = api.gather_f64(ctx, _dev(ctx, o["key"]), ireorder)
+    assert np.array_equal(sv.cpu().numpy(), s["key_s"])
+    rs = np.random.RandomState(9)
+    cuts = np.sort(rs.choice(n, 14, replace=False))
+    ind1 = np.concatenate([[0], cuts, [5, n - 1, 0]])
+    ind2 = np.concatenate([cuts - 1, [n - 1], [5, n - 1, n - 1]])
+    ind2 = np.maximum(ind2, ind1)
+    got = gas.median_sorting_variable(sv, ind1, ind2)
+    want = np.array([oracle.median_sorting_variable(s["key_s"], s["surf_planck"], a, b) for a, b in zip(ind1, ind2)])
+    assert np.array_equal(got, want)
+    gas.close()
