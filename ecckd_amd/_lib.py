@@ -141,6 +141,7 @@ SIGNATURES = {
                                        _c_int64_p, C.c_int, C.POINTER(C.c_int), _c_double_p]),
     "ecckd_gas_median_sorting_variable": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_int64_p, _c_int64_p,
                                                     _c_double_p]),
+    "ecckd_run_ckd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     "ecckd_gather_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_invert_permutation_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }

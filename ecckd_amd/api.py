@@ -528,6 +528,75 @@ class GasSW(GasLW):
 CONC = {"none": 0, "linear": 1, "lut": 2, "relative-linear": 3}
 
 
+def _f64c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _keep_ptr(keep, a, ctype=C.c_double):
+    if a is None:
+        return None
+    keep.append(a)
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _opt_model(model, keep):
+    """dict -> ecckd_opt_model (arrays appended to `keep` stay alive with the caller)."""
+    f64, ptr = _f64c, lambda a, ct=C.c_double: _keep_ptr(keep, a, ct)
+    gases = (_lib.OptGas * len(model["gases"]))()
+    for i, g in enumerate(model["gases"]):
+        ma = f64(g["molar_abs"])
+        gases[i].conc_dependence = CONC[g["conc"]]
+        gases[i].is_active = int(g.get("active", True))
+        gases[i].nconc = ma.shape[0] if g["conc"] == "lut" else 1
+        gases[i].vmr = ptr(f64(g["vmr"])) if g.get("vmr") is not None else None
+        gases[i].reference_vmr = float(g.get("reference_vmr", 0.0))
+        gases[i].molar_abs = ptr(ma)
+        gases[i].min_molar_abs = ptr(f64(g["min_molar_abs"])) if g.get("min_molar_abs") is not None else None
+        gases[i].max_molar_abs = ptr(f64(g["max_molar_abs"])) if g.get("max_molar_abs") is not None else None
+    keep.append(gases)
+    temp = f64(model["temperature"])
+    m = _lib.OptModel()
+    if model.get("planck_function") is not None:
+        pf = f64(model["planck_function"])
+        m.ng, m.ntp = pf.shape[1], pf.shape[0]
+        m.temperature_planck = ptr(f64(model["temperature_planck"]))
+        m.planck_function = ptr(pf)
+    else:                                      # shortwave model: solar irradiance instead of a Planck LUT
+        m.ng, m.ntp = len(model["solar_irradiance"]), 0
+    m.nt, m.np = temp.shape[0], temp.shape[1]
+    m.log_pressure = ptr(f64(model["log_pressure"]))
+    m.temperature = ptr(temp)
+    m.iband_per_g = ptr(np.ascontiguousarray(model["iband_per_g"], dtype=np.int32), C.c_int)
+    m.ngas = len(model["gases"])
+    m.gases = gases
+    m.logarithmic_interpolation = int(model.get("logarithmic_interpolation", False))
+    m.solar_irradiance = ptr(f64(model["solar_irradiance"])) if model.get("solar_irradiance") is not None else None
+    m.rayleigh_molar_scattering = (ptr(f64(model["rayleigh_molar_scattering"]))
+                                   if model.get("rayleigh_molar_scattering") is not None else None)
+    return m
+
+
+def _opt_scene(sc, s, keep):
+    """Fill one ecckd_opt_scene from a dict."""
+    f64, ptr = _f64c, lambda a, ct=C.c_double: _keep_ptr(keep, a, ct)
+    p = f64(s["pressure_hl"])
+    sc.ncol, sc.nlay = p.shape[0], p.shape[1] - 1
+    sc.pressure_hl = ptr(p)
+    sc.temperature_hl = ptr(f64(s["temperature_hl"]))
+    sc.vmr_fl = ptr(f64(s["vmr_fl"])) if s.get("vmr_fl") is not None else None
+    sc.gas_present = (ptr(np.ascontiguousarray(s["gas_present"], dtype=np.int32), C.c_int)
+                      if s.get("gas_present") is not None else None)
+    sc.surf_emissivity = ptr(f64(s["surf_emissivity"])) if s.get("surf_emissivity") is not None else None
+    if s.get("flux_dn") is not None:
+        fd = f64(s["flux_dn"])
+        sc.nband = fd.shape[2]
+        sc.flux_dn = ptr(fd)
+        sc.flux_up = ptr(f64(s["flux_up"]))
+    for k in ("spectral_flux_dn_surf", "spectral_flux_up_toa", "mu0", "albedo", "spectral_boundary_weights"):
+        setattr(sc, k, ptr(f64(s[k])) if s.get(k) is not None else None)
+    sc.tsi = float(s.get("tsi", 0.0))
+
+
 class Optimizer:
     """ecckd_opt_*: the cost function / gradient of solve_adept.cpp:240-292 and the L-BFGS driver
     of :310-417 on the device.
@@ -543,61 +612,11 @@ class Optimizer:
     def __init__(self, ctx, model, scenes, **cfg):
         self.ctx = ctx
         self.lib = ctx.lib
-        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         keep = []
-
-        def ptr(a, ctype=C.c_double):
-            if a is None:
-                return None
-            keep.append(a)
-            return a.ctypes.data_as(C.POINTER(ctype))
-
-        gases = (_lib.OptGas * len(model["gases"]))()
-        for i, g in enumerate(model["gases"]):
-            ma = f64(g["molar_abs"])
-            gases[i].conc_dependence = CONC[g["conc"]]
-            gases[i].is_active = int(g.get("active", True))
-            gases[i].nconc = ma.shape[0] if g["conc"] == "lut" else 1
-            gases[i].vmr = ptr(f64(g["vmr"])) if g.get("vmr") is not None else None
-            gases[i].reference_vmr = float(g.get("reference_vmr", 0.0))
-            gases[i].molar_abs = ptr(ma)
-            gases[i].min_molar_abs = ptr(f64(g["min_molar_abs"])) if g.get("min_molar_abs") is not None else None
-            gases[i].max_molar_abs = ptr(f64(g["max_molar_abs"])) if g.get("max_molar_abs") is not None else None
-        temp = f64(model["temperature"])
-        m = _lib.OptModel()
-        if model.get("planck_function") is not None:
-            pf = f64(model["planck_function"])
-            m.ng, m.ntp = pf.shape[1], pf.shape[0]
-            m.temperature_planck = ptr(f64(model["temperature_planck"]))
-            m.planck_function = ptr(pf)
-        else:                                      # shortwave model: solar irradiance instead of a Planck LUT
-            m.ng, m.ntp = len(model["solar_irradiance"]), 0
-        m.nt, m.np = temp.shape[0], temp.shape[1]
-        m.log_pressure = ptr(f64(model["log_pressure"]))
-        m.temperature = ptr(temp)
-        m.iband_per_g = ptr(np.ascontiguousarray(model["iband_per_g"], dtype=np.int32), C.c_int)
-        m.ngas = len(model["gases"])
-        m.gases = gases
-        m.logarithmic_interpolation = int(model.get("logarithmic_interpolation", False))
-        m.solar_irradiance = ptr(f64(model["solar_irradiance"])) if model.get("solar_irradiance") is not None else None
-        m.rayleigh_molar_scattering = (ptr(f64(model["rayleigh_molar_scattering"]))
-                                       if model.get("rayleigh_molar_scattering") is not None else None)
+        m = _opt_model(model, keep)
         sc = (_lib.OptScene * len(scenes))()
         for i, s in enumerate(scenes):
-            p = f64(s["pressure_hl"])
-            fd = f64(s["flux_dn"])
-            sc[i].ncol, sc[i].nlay, sc[i].nband = p.shape[0], p.shape[1] - 1, fd.shape[2]
-            sc[i].pressure_hl = ptr(p)
-            sc[i].temperature_hl = ptr(f64(s["temperature_hl"]))
-            sc[i].vmr_fl = ptr(f64(s["vmr_fl"])) if s.get("vmr_fl") is not None else None
-            sc[i].gas_present = (ptr(np.ascontiguousarray(s["gas_present"], dtype=np.int32), C.c_int)
-                                 if s.get("gas_present") is not None else None)
-            sc[i].surf_emissivity = ptr(f64(s["surf_emissivity"])) if s.get("surf_emissivity") is not None else None
-            sc[i].flux_dn = ptr(fd)
-            sc[i].flux_up = ptr(f64(s["flux_up"]))
-            for k in ("spectral_flux_dn_surf", "spectral_flux_up_toa", "mu0", "albedo", "spectral_boundary_weights"):
-                setattr(sc[i], k, ptr(f64(s[k])) if s.get(k) is not None else None)
-            sc[i].tsi = float(s.get("tsi", 0.0))
+            _opt_scene(sc[i], s, keep)
         c = _lib.OptConfig()
         defaults = dict(flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, spectral_boundary_weight=0.0,
                         negative_od_penalty=1.0e4, pressure_weight_power=0.5, prior_error=1.0, min_prior_error=0.0,
@@ -668,6 +687,62 @@ class Optimizer:
 
 # ---------------------------------------------------------------------------------------
 # create_look_up_table
+
+def run_ckd(ctx, model, scene, gases=None, scalings=None, per_gas=True):
+    """run_ckd.cpp:27-373 for the profiles of `scene` (pressure_hl, temperature_hl, vmr_fl[ncol,ngas,nlay],
+    gas_present; shortwave: mu0[ncol], tsi).  `gases` restricts the gas list like the "gases" key (:68-74),
+    `scalings` = {gas index: factor} mirrors co2_scaling & co (:76-85, :288-307).  Returns the variables
+    run_ckd writes, keyed by their NetCDF names."""
+    ngas = len(model["gases"])
+    names = [g.get("name", str(i)) for i, g in enumerate(model["gases"])]
+    is_sw = model.get("solar_irradiance") is not None
+    sc_d = dict(scene)
+    if scalings:
+        vmr = np.array(scene["vmr_fl"], dtype=np.float64, copy=True)
+        for i, f in scalings.items():
+            vmr[:, i, :] *= f
+        sc_d["vmr_fl"] = vmr
+    present = np.ones(ngas, dtype=np.int32) if scene.get("gas_present") is None else np.array(scene["gas_present"], dtype=np.int32)
+    if gases is not None:
+        present = present * np.array([1 if (i in gases or names[i] in gases) else 0 for i in range(ngas)], dtype=np.int32)
+    p = _f64c(scene["pressure_hl"])
+    ncol, nhl = p.shape
+    nlay = nhl - 1
+    ng = len(model["iband_per_g"])
+
+    def one(mask, want_all):
+        keep = []
+        m = _opt_model(model, keep)
+        sc = _lib.OptScene()
+        _opt_scene(sc, dict(sc_d, gas_present=mask, flux_dn=None), keep)
+        od = np.empty((ncol, nlay, ng))
+        ray = np.empty((ncol, nlay, ng)) if (want_all and is_sw) else None
+        pl = np.empty((ncol, nhl, ng)) if want_all else None
+        fl = np.empty((ncol, 2, nhl, ng)) if want_all else None
+        check(ctx.lib.ecckd_run_ckd(ctx.handle, C.byref(m), C.byref(sc), _hptr(od), _hptr(ray) if ray is not None else None,
+                                    _hptr(pl) if pl is not None else None, _hptr(fl) if fl is not None else None))
+        return od, ray, pl, fl
+
+    od, ray, pl, fl = one(present, True)
+    dom = "sw" if is_sw else "lw"
+    out = {"pressure_hl": p, "optical_depth": od}
+    if per_gas:
+        for i in range(ngas):
+            if present[i]:
+                mask = np.zeros(ngas, dtype=np.int32)
+                mask[i] = 1
+                out[names[i] + "_optical_depth"] = one(mask, False)[0]
+    if not is_sw:
+        out["planck_hl"], out["planck_surf"] = pl, pl[:, -1, :].copy()
+        out["spectral_flux_dn_lw"], out["spectral_flux_up_lw"] = fl[:, 0], fl[:, 1]
+        out["flux_dn_lw"], out["flux_up_lw"] = fl[:, 0].sum(-1), fl[:, 1].sum(-1)
+    else:
+        out["rayleigh_optical_depth"] = ray
+        out["incoming_sw"] = pl[:, 0, :].copy()
+        out["spectral_flux_dn_direct_sw"] = fl[:, 0]
+        out["flux_dn_direct_sw"] = fl[:, 0].sum(-1)
+    return out
+
 
 class GPointMap:
     """ecckd_gmap_*: wavenumbers sorted by g point; the segmented reductions of

@@ -92,6 +92,7 @@ struct ColConst {  // per-profile constant block layout in d_col: see host code
 //      Gdn[nhl][nband] | Gup[nhl][nband] | red[16]
 __global__ void k_opt_forward_adjoint(
     int do_sw, const double* __restrict__ mu0 /*[ncol], SW*/,
+    int ray_ent /* run_ckd mode: entry of the Rayleigh term, added AFTER the clamp; else -1 */,
     int nlay, int ng, int ngpad, int nband, int nent,
     const double* __restrict__ k,            // [nk] coefficients of every gas
     const int* __restrict__ ent_idx,         // [ncell][nent] start of an ng-long row of k, or -1
@@ -142,10 +143,13 @@ __global__ void k_opt_forward_adjoint(
     for (int l = lgrp; l < nlay; l += nlgrp) {
       const int* ei = ent_idx + (cell0 + l) * nent;
       const double* ec = ent_coef + (cell0 + l) * nent;
-      double tau = 0.0;
+      double tau = 0.0, tau_ray = 0.0;
       for (int e = 0; e < nent; ++e) {
         const int idx = ei[e];
-        if (idx >= 0) tau += ec[e] * k[(size_t)idx + g];
+        if (idx >= 0) {
+          if (e == ray_ent) tau_ray = ec[e] * k[(size_t)idx + g];
+          else tau += ec[e] * k[(size_t)idx + g];
+        }
       }
       if (tau < 0.0) {
         // penalty = negative_od_penalty * tau^2, then the optical depth is SET to 0 (:110-113), so
@@ -157,8 +161,9 @@ __global__ void k_opt_forward_adjoint(
       } else {
         s_clamp[l * ng + g] = 0;
       }
+      if (od_out) od_out[(cell0 + l) * ng + g] = tau;   // run_ckd mode: molecular absorption only (run_ckd.cpp:318-326)
+      tau += tau_ray;
       s_tau[l * ng + g] = tau;
-      if (od_out) od_out[(cell0 + l) * ng + g] = tau;
     }
   }
   __syncthreads();
@@ -654,6 +659,8 @@ struct ecckd_opt {
   bool have_prior = false;
   bool have_boundary = false;
   bool do_sw = false;
+  int eval_ray_ent = -1;   // >= 0 only inside ecckd_run_ckd
+  int ray_ent = -1;        // entry index of the Rayleigh pseudo gas
   double* d_mu0 = nullptr;
   // host copies
   std::vector<double> h_k0, h_kmin, h_kmax;
@@ -886,6 +893,7 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
   o->ncell = ncol * nlay;
   int nent = have_rayleigh ? 1 : 0;
   for (const GasInfo& gi : o->gases) nent += (gi.conc == 2) ? 8 : 4;
+  o->ray_ent = have_rayleigh ? nent - 1 : -1;
   o->nent = nent;
   std::vector<int> ent_idx(o->ncell * nent, -1);
   std::vector<double> ent_coef(o->ncell * nent, 0.0);
@@ -1114,9 +1122,8 @@ int ecckd_opt_initial_state(ecckd_opt* o, double* h_x, double* h_x_min, double* 
 
 // CkdOptimizable::calc_cost_function_gradient (solve_adept.cpp:240-292).
 // cost and gradient at the DEVICE state d_x -> d_grad; J on the host (one stream sync).
-static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, double* J) {
+static int opt_launch_forward(ecckd_opt* o) {
   ecckd_ctx* ctx = o->ctx;
-  hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, d_x, o->d_k);
   const int nlay = o->nlay, nhl = nlay + 1, ng = o->ng, nband = o->nband;
   const int ngpad = (ng + 63) / 64 * 64;
   const int lgroups = std::max(1, 256 / ngpad);
@@ -1127,10 +1134,22 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
   ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_opt_forward_adjoint),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL(k_opt_forward_adjoint, dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream, o->do_sw ? 1 : 0,
-                     o->d_mu0, nlay, ng, ngpad, nband, o->nent, o->d_k, o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_planck, o->d_semis, o->d_conv,
+                     o->d_mu0, o->eval_ray_ent, nlay, ng, ngpad, nband, o->nent, o->d_k, o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_planck, o->d_semis, o->d_conv,
                      o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds, o->d_sfut, o->cfg.flux_weight,
                      o->cfg.flux_profile_weight, o->cfg.broadband_weight, o->cfg.spectral_boundary_weight,
                      o->cfg.negative_od_penalty, o->d_dtau, o->d_jcol, o->d_od_out, o->d_flux_out);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  return ECCKD_OK;
+}
+
+static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, double* J) {
+  ecckd_ctx* ctx = o->ctx;
+  hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, d_x, o->d_k);
+  const int ng = o->ng;
+  const int ngpad = (ng + 63) / 64 * 64;
+  const int lgroups = std::max(1, 256 / ngpad);
+  const int threads = ngpad * lgroups;
+  ECCKD_CHECK(opt_launch_forward(o));
   hipLaunchKernelGGL(k_opt_gradient, dim3((unsigned)o->nnode_active), dim3(threads),
                      ((size_t)lgroups * ngpad + 16) * sizeof(double), ctx->stream, o->nnode_active, ng, ngpad, d_x, o->d_xprior,
                      o->d_k, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_dtau, o->d_node_gas, o->d_node_ic,
@@ -1329,6 +1348,85 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   if (J_final) *J_final = J;
   if (gnorm_final) *gnorm_final = gnorm;
   return ECCKD_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// run_ckd (run_ckd.cpp:27-373): evaluate a CKD model on a set of profiles.  The gas optical depths
+// are summed and clamped at zero (:318), Rayleigh scattering is added after the clamp (:361), the
+// longwave fluxes come from radiative_transfer_lw with unit emissivity and the surface Planck
+// function at temperature_hl(end) (:343-347), the shortwave direct beam from
+// radiative_transfer_direct_sw at the scene's mu0 with tsi / sum(ssi) scaling (:358-363).
+// The coefficients are used as they are (no exp(log k) round trip).
+int ecckd_run_ckd(ecckd_ctx* ctx, const ecckd_opt_model* m, const ecckd_opt_scene* scene, double* h_od,
+                  double* h_rayleigh_od, double* h_planck_hl, double* h_flux) {
+  ECCKD_REQUIRE(ctx && m && scene && m->gases && m->iband_per_g, "ecckd_run_ckd: NULL argument");
+  ECCKD_REQUIRE(scene->ncol > 0 && scene->nlay > 0 && scene->pressure_hl && scene->temperature_hl,
+                "ecckd_run_ckd: scene needs pressure_hl and temperature_hl");
+  const bool do_sw = m->solar_irradiance != nullptr;
+  std::vector<ecckd_opt_gas> gases(m->gases, m->gases + m->ngas);
+  // gases outside the scene's list are skipped whatever their concentration dependence (run_ckd.cpp:270-276;
+  // the optimiser keeps concentration-independent gases, solve_adept.cpp:55-67): give them zero coefficients
+  size_t zsize = 0;
+  for (int i = 0; i < m->ngas; ++i)
+    zsize = std::max(zsize, (size_t)(m->gases[i].conc_dependence == 2 ? m->gases[i].nconc : 1) * m->nt * m->np * m->ng);
+  std::vector<double> zero_k(zsize, 0.0);
+  for (int i = 0; i < m->ngas; ++i) {
+    ecckd_opt_gas& g = gases[i];
+    g.is_active = 1;
+    g.min_molar_abs = nullptr;
+    g.max_molar_abs = nullptr;
+    if (scene->gas_present && !scene->gas_present[i]) g.molar_abs = zero_k.data();
+  }
+  ecckd_opt_model mm = *m;
+  mm.gases = gases.data();
+  int nband = 0;
+  for (int g = 0; g < m->ng; ++g) nband = std::max(nband, m->iband_per_g[g] + 1);
+  const size_t ncol = (size_t)scene->ncol, nhl = (size_t)scene->nlay + 1, nlay = (size_t)scene->nlay, ng = (size_t)m->ng;
+  std::vector<double> zeros(ncol * nhl * (size_t)nband, 0.0), albedo0((size_t)nband, 0.0);
+  ecckd_opt_scene sc = *scene;
+  sc.nband = nband;
+  sc.flux_dn = zeros.data();
+  sc.flux_up = zeros.data();
+  sc.surf_emissivity = nullptr;          // unit emissivity (:339-340)
+  sc.spectral_flux_dn_surf = nullptr;
+  sc.spectral_flux_up_toa = nullptr;
+  sc.spectral_boundary_weights = nullptr;
+  if (do_sw) sc.albedo = albedo0.data();  // direct beam only
+  ecckd_opt_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.pressure_weight_power = 0.5;
+  cfg.prior_error = 1.0;
+  cfg.pressure_corr = cfg.temperature_corr = cfg.conc_corr = 0.5;
+  ecckd_opt* o = nullptr;
+  ECCKD_CHECK(ecckd_opt_create(ctx, &mm, 1, &sc, &cfg, &o));
+  int rc = ECCKD_OK;
+  do {
+    hipError_t e = hipMemcpyAsync(o->d_k, o->h_k0.data(), o->nk * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&o->d_od_out, o->ncell * ng * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&o->d_flux_out, ncol * 2 * nhl * ng * sizeof(double));
+    if (e != hipSuccess) { rc = ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION, "ecckd_run_ckd: %s", hipGetErrorString(e)); break; }
+    o->eval_ray_ent = o->ray_ent;
+    rc = opt_launch_forward(o);
+    if (rc != ECCKD_OK) break;
+    if (h_od) rc = ecckd_d2h(ctx, h_od, o->d_od_out, o->ncell * ng * sizeof(double));
+    if (rc == ECCKD_OK && h_flux) rc = ecckd_d2h(ctx, h_flux, o->d_flux_out, ncol * 2 * nhl * ng * sizeof(double));
+    if (rc == ECCKD_OK && h_planck_hl) rc = ecckd_d2h(ctx, h_planck_hl, o->d_planck, ncol * nhl * ng * sizeof(double));
+  } while (0);
+  if (rc == ECCKD_OK && h_rayleigh_od) {
+    // CkdModel::calc_rayleigh_optical_depth (ckd_model.h:242-252)
+    for (size_t c = 0; c < ncol; ++c)
+      for (size_t l = 0; l < nlay; ++l) {
+        const double* p = scene->pressure_hl + c * nhl;
+        const double moles = (p[l + 1] - p[l]) * (1.0 / (ECCKD_ACCEL_GRAVITY * 0.001 * 28.970));
+        for (size_t g = 0; g < ng; ++g)
+          h_rayleigh_od[(c * nlay + l) * ng + g] = m->rayleigh_molar_scattering ? moles * m->rayleigh_molar_scattering[g] : 0.0;
+      }
+  }
+  (void)hipFree(o->d_od_out); (void)hipFree(o->d_flux_out);
+  o->d_od_out = nullptr; o->d_flux_out = nullptr;
+  ecckd_opt_destroy(o);
+  return rc;
 }
 
 }  // extern "C"

@@ -362,6 +362,21 @@ int ecckd_opt_coefficients(ecckd_opt* opt, const double* h_x, int gas, double* h
 int ecckd_opt_minimize(ecckd_opt* opt, int max_iterations, double convergence_criterion, int is_bounded,
                        double* h_x, int* status, int* n_iterations, double* J_final, double* gnorm_final);
 
+/* ---- run_ckd -------------------------------------------------------
+ * Replaces the compute part of run_ckd.cpp:27-373 for the profiles of one scene (flux arrays
+ * of the scene are ignored; mu0 and tsi are used for a shortwave model, run_ckd.cpp:92,:358
+ * passes REFERENCE_COS_SZA).  Outputs, any of which may be NULL:
+ *   h_od[ncol][nlay][ng]           sum of the gases' optical depths, clamped at 0 ("optical_depth", :318)
+ *   h_rayleigh_od[ncol][nlay][ng]  shortwave only ("rayleigh_optical_depth")
+ *   h_planck_hl[ncol][nlay+1][ng]  longwave "planck_hl" (row nlay = "planck_surf"); shortwave: row 0 of
+ *                                  every column = "incoming_sw" = tsi / sum(ssi) * ssi
+ *   h_flux[ncol][2][nlay+1][ng]    longwave: [0] = spectral_flux_dn_lw, [1] = spectral_flux_up_lw;
+ *                                  shortwave: [0] = spectral_flux_dn_direct_sw, [1] = 0
+ * Gases absent from the scene (gas_present[i] == 0) are skipped like run_ckd's "gases" list (:270-276);
+ * call once per gas with a one-hot gas_present for the "<gas>_optical_depth" variables. */
+int ecckd_run_ckd(ecckd_ctx* ctx, const ecckd_opt_model* model, const ecckd_opt_scene* scene, double* h_od,
+                  double* h_rayleigh_od, double* h_planck_hl, double* h_flux);
+
 /* ---- create_look_up_table (K6/K7) ----------------------------------------------
  * A g-point map: the wavenumbers sorted by g point once (stable), so that every g point is a
  * contiguous segment.  d_g_point[nwav] as read from the g-points file (-1 = unassigned,
