@@ -142,6 +142,9 @@ SIGNATURES = {
     "ecckd_gas_median_sorting_variable": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_int64_p, _c_int64_p,
                                                     _c_double_p]),
     "ecckd_run_ckd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    "ecckd_scale_lut": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p,
+                                  C.POINTER(C.c_int), C.c_double, _c_double_p, _c_double_p, C.POINTER(_c_double_p)]),
+    "ecckd_gmap_sum_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, _c_double_p]),
     "ecckd_gather_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_invert_permutation_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }
@@ -177,7 +180,7 @@ class OptScene(C.Structure):
                 ("surf_emissivity", _c_double_p), ("flux_dn", _c_double_p), ("flux_up", _c_double_p),
                 ("spectral_flux_dn_surf", _c_double_p), ("spectral_flux_up_toa", _c_double_p),
                 ("mu0", _c_double_p), ("tsi", C.c_double), ("albedo", _c_double_p),
-                ("spectral_boundary_weights", _c_double_p)]
+                ("spectral_boundary_weights", _c_double_p), ("temperature_fl", _c_double_p)]
 
 
 class OptConfig(C.Structure):

@@ -744,6 +744,25 @@ def run_ckd(ctx, model, scene, gases=None, scalings=None, per_gas=True):
     return out
 
 
+def scale_lut(ctx, model, flux_sums, pressure_hl, temperature_hl, vmr_fl, gas_present, mu0):
+    """scale_lut.cpp:117-189 + CkdModel::scale_optical_depth for one reference profile.  `flux_sums` (nz+1, ng)
+    from GPointMap.sum_rows of the LBL direct spectral flux.  -> (list of scaled molar_abs arrays, scaling[nz, ng])."""
+    keep = []
+    m = _opt_model(model, keep)
+    p = _f64c(pressure_hl)
+    nz = p.size - 1
+    ng = len(model["iband_per_g"])
+    outs = [np.empty_like(_f64c(g["molar_abs"])) for g in model["gases"]]
+    arr = (C.POINTER(C.c_double) * len(outs))(*[_hptr(o) for o in outs])
+    scaling = np.empty((nz, ng))
+    gp = np.ascontiguousarray(gas_present, dtype=np.int32)
+    vm = _f64c(vmr_fl)
+    check(ctx.lib.ecckd_scale_lut(ctx.handle, C.byref(m), nz, _hptr(p), _hptr(_f64c(temperature_hl)), _hptr(vm),
+                                  gp.ctypes.data_as(C.POINTER(C.c_int)), float(mu0), _hptr(_f64c(flux_sums)),
+                                  _hptr(scaling), arr))
+    return outs, scaling
+
+
 class GPointMap:
     """ecckd_gmap_*: wavenumbers sorted by g point; the segmented reductions of
     create_look_up_table.cpp (average_optical_depth_to_g_point, gpoint_fraction, Planck LUT)."""
@@ -792,6 +811,14 @@ class GPointMap:
                                                 float(reference_surface_vmr), _hptr(out[0]), _hptr(out[1]),
                                                 _hptr(out[2])))
         return tuple(out)
+
+    def sum_rows(self, rows):
+        """Per-g-point sums of every row of a (nrows, nwav) device tensor (scale_lut.cpp:119-124) -> (nrows, ng)."""
+        out = np.empty((rows.shape[0], self.ng))
+        self.ctx.fence_from_torch()
+        check(self.lib.ecckd_gmap_sum_rows(self.handle, rows.shape[0], _dptr(rows), _od_type(rows), rows.stride(0),
+                                           _hptr(out)))
+        return out
 
     def gpoint_fraction(self, wavenumber1, wavenumber2):
         w1 = np.ascontiguousarray(wavenumber1, dtype=np.float64)

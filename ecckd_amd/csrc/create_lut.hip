@@ -243,6 +243,34 @@ k_planck_lut_final(int nlut, int ng, const int* __restrict__ seg_chunk0, const d
   }
 }
 
+// Row sums per g point (scale_lut.cpp:119-124): partial[chunk][nrows], gathered through the g-sorted order.
+template <typename T>
+__global__ void __launch_bounds__(GA_THREADS)
+k_rowsum_partial(int nrows, size_t stride, const Chunk* __restrict__ chunks, const int32_t* __restrict__ order,
+                 const T* __restrict__ rows, double* __restrict__ partial) {
+  __shared__ double s_red[4];
+  const Chunk c = chunks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  size_t src[GA_PPT];
+  bool live[GA_PPT];
+#pragma unroll
+  for (int p = 0; p < GA_PPT; ++p) {
+    const long long i = c.p0 + (long long)p * GA_THREADS + tid;
+    live[p] = i <= c.p1;
+    src[p] = (size_t)order[live[p] ? i : c.p1];
+  }
+  for (int r = 0; r < nrows; ++r) {
+    double v = 0.0;
+#pragma unroll
+    for (int p = 0; p < GA_PPT; ++p) v += live[p] ? (double)rows[(size_t)r * stride + src[p]] : 0.0;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    if (tid == 0) partial[(size_t)blockIdx.x * nrows + r] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+  }
+}
+
 // K7b.  gpoint_fraction: grid (nint + 1, ng), block 64.  blockIdx.x == nint computes the total
 // spectral width of the g point; the others the width inside (wavenumber1, wavenumber2].
 __global__ void __launch_bounds__(64)
@@ -507,6 +535,33 @@ int ecckd_planck_lut(ecckd_gmap* m, int nlut, const double* h_temperature_lut, d
   hipLaunchKernelGGL(k_planck_lut_final, dim3(ng), dim3(256), 0, ctx->stream, nlut, ng, m->d_seg_chunk0, d_part, d_out);
   ECCKD_HIP_CHECK(hipGetLastError());
   return ecckd_d2h(ctx, h_planck_lut, d_out, (size_t)nlut * ng * sizeof(double));
+}
+
+
+int ecckd_gmap_sum_rows(ecckd_gmap* m, int nrows, const void* d_rows, int rows_type, size_t row_stride, double* h_sums) {
+  ECCKD_REQUIRE(m && nrows > 0 && d_rows && h_sums, "ecckd_gmap_sum_rows: bad argument");
+  ECCKD_REQUIRE(rows_type == ECCKD_F32 || rows_type == ECCKD_F64, "ecckd_gmap_sum_rows: rows_type must be ECCKD_F32 or ECCKD_F64");
+  ECCKD_REQUIRE(row_stride >= m->n, "ecckd_gmap_sum_rows: row stride %zu shorter than the spectrum (%zu)", row_stride, m->n);
+  ecckd_ctx* ctx = m->ctx;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const int ng = m->ng;
+  const size_t nchunk = m->chunks.size();
+  const size_t part_bytes = ecckd_align_up(std::max<size_t>(nchunk, 1) * nrows * sizeof(double), 256);
+  const size_t out_bytes = ecckd_align_up((size_t)nrows * ng * sizeof(double), 256);
+  ECCKD_CHECK(gmap_work(m, part_bytes + out_bytes));
+  double* d_part = (double*)m->work;
+  double* d_out = (double*)((char*)m->work + part_bytes);
+  if (nchunk > 0) {
+    if (rows_type == ECCKD_F32)
+      hipLaunchKernelGGL(k_rowsum_partial<float>, dim3((unsigned)nchunk), dim3(GA_THREADS), 0, ctx->stream, nrows, row_stride,
+                         m->d_chunks, m->order, (const float*)d_rows, d_part);
+    else
+      hipLaunchKernelGGL(k_rowsum_partial<double>, dim3((unsigned)nchunk), dim3(GA_THREADS), 0, ctx->stream, nrows, row_stride,
+                         m->d_chunks, m->order, (const double*)d_rows, d_part);
+  }
+  hipLaunchKernelGGL(k_planck_lut_final, dim3(ng), dim3(256), 0, ctx->stream, nrows, ng, m->d_seg_chunk0, d_part, d_out);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  return ecckd_d2h(ctx, h_sums, d_out, (size_t)nrows * ng * sizeof(double));
 }
 
 }  // extern "C"

@@ -93,6 +93,7 @@ struct ColConst {  // per-profile constant block layout in d_col: see host code
 __global__ void k_opt_forward_adjoint(
     int do_sw, const double* __restrict__ mu0 /*[ncol], SW*/,
     int ray_ent /* run_ckd mode: entry of the Rayleigh term, added AFTER the clamp; else -1 */,
+    int keep_negative /* scale_lut mode: the optical depth is reported without the clamp at zero */,
     int nlay, int ng, int ngpad, int nband, int nent,
     const double* __restrict__ k,            // [nk] coefficients of every gas
     const int* __restrict__ ent_idx,         // [ncell][nent] start of an ng-long row of k, or -1
@@ -151,6 +152,7 @@ __global__ void k_opt_forward_adjoint(
           else tau += ec[e] * k[(size_t)idx + g];
         }
       }
+      const double tau_raw = tau;
       if (tau < 0.0) {
         // penalty = negative_od_penalty * tau^2, then the optical depth is SET to 0 (:110-113), so
         // the only derivative that survives for this cell is the penalty's
@@ -161,7 +163,7 @@ __global__ void k_opt_forward_adjoint(
       } else {
         s_clamp[l * ng + g] = 0;
       }
-      if (od_out) od_out[(cell0 + l) * ng + g] = tau;   // run_ckd mode: molecular absorption only (run_ckd.cpp:318-326)
+      if (od_out) od_out[(cell0 + l) * ng + g] = (keep_negative && s_clamp[l * ng + g]) ? tau_raw : tau;   // run_ckd mode: molecular absorption only (run_ckd.cpp:318-326)
       tau += tau_ray;
       s_tau[l * ng + g] = tau;
     }
@@ -660,6 +662,7 @@ struct ecckd_opt {
   bool have_boundary = false;
   bool do_sw = false;
   int eval_ray_ent = -1;   // >= 0 only inside ecckd_run_ckd
+  int eval_keep_negative = 0;
   int ray_ent = -1;        // entry index of the Rayleigh pseudo gas
   double* d_mu0 = nullptr;
   // host copies
@@ -966,7 +969,8 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
       for (int l = 0; l < nlay; ++l) {
         const size_t cell = col * nlay + l;
         // full-level temperature, solve_adept.cpp:38-41
-        const double t_fl = (T[l] * p[l] + T[l + 1] * p[l + 1]) / (p[l] + p[l + 1]);
+        const double t_fl = sc.temperature_fl ? sc.temperature_fl[(size_t)c * nlay + l]
+                                              : (T[l] * p[l] + T[l + 1] * p[l + 1]) / (p[l] + p[l + 1]);
         const double log_pressure_fl = std::log(0.5 * (p[l + 1] + p[l]));
         double pindex0 = (log_pressure_fl - log_p_0) / d_log_p;
         pindex0 = std::fmax(0.0, std::fmin(pindex0, np - 1.0001));
@@ -1134,7 +1138,7 @@ static int opt_launch_forward(ecckd_opt* o) {
   ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_opt_forward_adjoint),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL(k_opt_forward_adjoint, dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream, o->do_sw ? 1 : 0,
-                     o->d_mu0, o->eval_ray_ent, nlay, ng, ngpad, nband, o->nent, o->d_k, o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_planck, o->d_semis, o->d_conv,
+                     o->d_mu0, o->eval_ray_ent, o->eval_keep_negative, nlay, ng, ngpad, nband, o->nent, o->d_k, o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_planck, o->d_semis, o->d_conv,
                      o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds, o->d_sfut, o->cfg.flux_weight,
                      o->cfg.flux_profile_weight, o->cfg.broadband_weight, o->cfg.spectral_boundary_weight,
                      o->cfg.negative_od_penalty, o->d_dtau, o->d_jcol, o->d_od_out, o->d_flux_out);
@@ -1358,8 +1362,8 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
 // function at temperature_hl(end) (:343-347), the shortwave direct beam from
 // radiative_transfer_direct_sw at the scene's mu0 with tsi / sum(ssi) scaling (:358-363).
 // The coefficients are used as they are (no exp(log k) round trip).
-int ecckd_run_ckd(ecckd_ctx* ctx, const ecckd_opt_model* m, const ecckd_opt_scene* scene, double* h_od,
-                  double* h_rayleigh_od, double* h_planck_hl, double* h_flux) {
+static int run_ckd_impl(ecckd_ctx* ctx, const ecckd_opt_model* m, const ecckd_opt_scene* scene, double* h_od,
+                        double* h_rayleigh_od, double* h_planck_hl, double* h_flux, int keep_negative) {
   ECCKD_REQUIRE(ctx && m && scene && m->gases && m->iband_per_g, "ecckd_run_ckd: NULL argument");
   ECCKD_REQUIRE(scene->ncol > 0 && scene->nlay > 0 && scene->pressure_hl && scene->temperature_hl,
                 "ecckd_run_ckd: scene needs pressure_hl and temperature_hl");
@@ -1407,6 +1411,7 @@ int ecckd_run_ckd(ecckd_ctx* ctx, const ecckd_opt_model* m, const ecckd_opt_scen
     if (e == hipSuccess) e = hipMalloc((void**)&o->d_flux_out, ncol * 2 * nhl * ng * sizeof(double));
     if (e != hipSuccess) { rc = ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION, "ecckd_run_ckd: %s", hipGetErrorString(e)); break; }
     o->eval_ray_ent = o->ray_ent;
+    o->eval_keep_negative = keep_negative;
     rc = opt_launch_forward(o);
     if (rc != ECCKD_OK) break;
     if (h_od) rc = ecckd_d2h(ctx, h_od, o->d_od_out, o->ncell * ng * sizeof(double));
@@ -1427,6 +1432,84 @@ int ecckd_run_ckd(ecckd_ctx* ctx, const ecckd_opt_model* m, const ecckd_opt_scen
   o->d_od_out = nullptr; o->d_flux_out = nullptr;
   ecckd_opt_destroy(o);
   return rc;
+}
+
+
+int ecckd_run_ckd(ecckd_ctx* ctx, const ecckd_opt_model* m, const ecckd_opt_scene* scene, double* h_od,
+                  double* h_rayleigh_od, double* h_planck_hl, double* h_flux) {
+  return run_ckd_impl(ctx, m, scene, h_od, h_rayleigh_od, h_planck_hl, h_flux, 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// scale_lut (scale_lut.cpp:117-189) + CkdModel::scale_optical_depth (ckd_model.cpp:1151-1176)
+int ecckd_scale_lut(ecckd_ctx* ctx, const ecckd_opt_model* m, int nz, const double* h_pressure_hl,
+                    const double* h_temperature_hl, const double* h_vmr_fl, const int* gas_present, double mu0,
+                    const double* h_flux_sums, double* h_scaling, double* const* h_molar_abs_out) {
+  ECCKD_REQUIRE(ctx && m && nz > 0 && h_pressure_hl && h_temperature_hl && h_flux_sums && h_molar_abs_out,
+                "ecckd_scale_lut: NULL argument");
+  const int ng = m->ng, np = m->np, nt = m->nt;
+  // od_best (:117-133)
+  std::vector<double> od_best((size_t)nz * ng), od_total((size_t)nz * ng), scaling((size_t)nz * ng);
+  for (int g = 0; g < ng; ++g) {
+    double flux_top = h_flux_sums[g];
+    for (int iz = 0; iz < nz; ++iz) {
+      const double flux_base = h_flux_sums[(size_t)(iz + 1) * ng + g];
+      od_best[(size_t)iz * ng + g] = (flux_base <= 0.0) ? -1.0 : -mu0 * std::log(flux_base / flux_top);
+      flux_top = flux_base;
+    }
+  }
+  // od_total (:137-182): the CKD model on the reference profile, plain-mean temperature (:108), no clamp
+  std::vector<double> t_fl(nz);
+  for (int l = 0; l < nz; ++l) t_fl[l] = 0.5 * (h_temperature_hl[l] + h_temperature_hl[l + 1]);
+  ecckd_opt_scene sc;
+  std::memset(&sc, 0, sizeof(sc));
+  sc.ncol = 1;
+  sc.nlay = nz;
+  sc.pressure_hl = h_pressure_hl;
+  sc.temperature_hl = h_temperature_hl;
+  sc.temperature_fl = t_fl.data();
+  sc.vmr_fl = h_vmr_fl;
+  sc.gas_present = gas_present;
+  const double mu0v[1] = {mu0};
+  sc.mu0 = mu0v;
+  sc.tsi = 1.0;
+  ECCKD_CHECK(run_ckd_impl(ctx, m, &sc, od_total.data(), nullptr, nullptr, nullptr, 1));
+  for (size_t i = 0; i < scaling.size(); ++i) scaling[i] = (od_best[i] <= 0.0) ? 1.0 : od_best[i] / od_total[i];  // :186-187
+  if (h_scaling) std::memcpy(h_scaling, scaling.data(), scaling.size() * sizeof(double));
+  // interp(log(pressure_fl), scaling, log_pressure_) (ckd_model.cpp:1152): per g point, linear in log p with
+  // linear extrapolation outside the profile
+  std::vector<double> x(nz);
+  for (int l = 0; l < nz; ++l) x[l] = std::log(0.5 * (h_pressure_hl[l] + h_pressure_hl[l + 1]));
+  std::vector<double> local((size_t)np * ng);
+  for (int ip = 0; ip < np; ++ip) {
+    const double xi = m->log_pressure[ip];
+    int j = 0;
+    if (nz >= 2) {
+      while (j < nz - 2 && xi > x[j + 1]) ++j;
+    }
+    for (int g = 0; g < ng; ++g) {
+      if (nz == 1) { local[(size_t)ip * ng + g] = scaling[g]; continue; }
+      const double w = (xi - x[j]) / (x[j + 1] - x[j]);
+      local[(size_t)ip * ng + g] = (1.0 - w) * scaling[(size_t)j * ng + g] + w * scaling[(size_t)(j + 1) * ng + g];
+    }
+  }
+  // every gas scaled equally (:1157-1175), then held inside [min, max]
+  for (int i = 0; i < m->ngas; ++i) {
+    const ecckd_opt_gas& ug = m->gases[i];
+    const int nconc = ug.conc_dependence == 2 ? ug.nconc : 1;
+    double* out = h_molar_abs_out[i];
+    ECCKD_REQUIRE(out && ug.molar_abs, "ecckd_scale_lut: gas %d has no coefficient buffer", i);
+    for (int ic = 0; ic < nconc; ++ic)
+      for (int it = 0; it < nt; ++it)
+        for (int ip = 0; ip < np; ++ip)
+          for (int g = 0; g < ng; ++g) {
+            const size_t e = (((size_t)ic * nt + it) * np + ip) * ng + g;
+            double v = ug.molar_abs[e] * local[(size_t)ip * ng + g];
+            if (ug.min_molar_abs && ug.max_molar_abs) v = std::fmax(ug.min_molar_abs[e], std::fmin(v, ug.max_molar_abs[e]));
+            out[e] = v;
+          }
+  }
+  return ECCKD_OK;
 }
 
 }  // extern "C"

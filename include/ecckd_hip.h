@@ -333,6 +333,9 @@ typedef struct {
   double tsi;                               /* total solar irradiance of the training file (:127) */
   const double* albedo;                     /* [nband] effective spectral albedo (:147-148, mask_rayleigh_up) */
   const double* spectral_boundary_weights;  /* [ng] erythemal_weight * erythemal_spectrum_ (solve_adept.cpp:182) or NULL */
+  /* optional [ncol][nlay] full-level temperature; NULL = pressure-weighted mean of temperature_hl
+   * (solve_adept.cpp:38-41, run_ckd.cpp:120-122).  scale_lut uses the plain mean (scale_lut.cpp:108). */
+  const double* temperature_fl;
 } ecckd_opt_scene;
 
 typedef struct {
@@ -377,6 +380,24 @@ int ecckd_opt_minimize(ecckd_opt* opt, int max_iterations, double convergence_cr
 int ecckd_run_ckd(ecckd_ctx* ctx, const ecckd_opt_model* model, const ecckd_opt_scene* scene, double* h_od,
                   double* h_rayleigh_od, double* h_planck_hl, double* h_flux);
 
+/* ---- scale_lut -----------------------------------------------------
+ * scale_lut.cpp:117-133 needs, per g point, the sum over its wavenumbers of every row of a
+ * (nrows, nwav) matrix (the LBL direct-beam spectral flux at each half level): h_sums[nrows][ng].
+ * Declared below, after ecckd_gmap: ecckd_gmap_sum_rows.
+ *
+ * ecckd_scale_lut does the rest of scale_lut.cpp:117-189 and CkdModel::scale_optical_depth
+ * (ckd_model.cpp:1151-1176) for one reference profile: od_best = -mu0 log(flux_base / flux_top) per layer
+ * and g point (-1 where the flux has vanished), od_total from the CKD model (NOT clamped at zero,
+ * plain-mean full-level temperature), scaling = od_best / od_total (1 where od_best <= 0), interpolated in
+ * log pressure to the model's grid (adept::interp restated as linear interpolation with linear
+ * extrapolation) and applied to every gas, clamped to [min, max] where those exist.
+ *   h_vmr_fl[ngas][nz] in model gas order; gas_present[ngas] = gas is in the LBL file's constituent list
+ *   (or is "composite"); h_scaling[nz][ng] (optional output); h_molar_abs_out[ngas] = caller buffers shaped
+ *   like each gas's molar_abs. */
+int ecckd_scale_lut(ecckd_ctx* ctx, const ecckd_opt_model* model, int nz, const double* h_pressure_hl,
+                    const double* h_temperature_hl, const double* h_vmr_fl, const int* gas_present, double mu0,
+                    const double* h_flux_sums, double* h_scaling, double* const* h_molar_abs_out);
+
 /* ---- create_look_up_table (K6/K7) ----------------------------------------------
  * A g-point map: the wavenumbers sorted by g point once (stable), so that every g point is a
  * contiguous segment.  d_g_point[nwav] as read from the g-points file (-1 = unassigned,
@@ -398,6 +419,9 @@ int ecckd_average_to_gpoints(ecckd_gmap* gmap, int nlay, const double* h_pressur
                              const void* d_od, int od_type, size_t od_stride, int averaging_method,
                              double reference_surface_vmr, double* h_molar_abs,
                              double* h_min_molar_abs, double* h_max_molar_abs);
+/* h_sums[nrows][ng] = sum over the wavenumbers of each g point of d_rows[r][.] (scale_lut.cpp:119-124) */
+int ecckd_gmap_sum_rows(ecckd_gmap* gmap, int nrows, const void* d_rows, int rows_type, size_t row_stride,
+                        double* h_sums);
 /* create_look_up_table.cpp:537-548: h_gpoint_fraction[ng][nint] over the coarse intervals
  * (wavenumber1, wavenumber2] */
 int ecckd_gpoint_fraction(ecckd_gmap* gmap, int nint, const double* h_wavenumber1,
