@@ -145,6 +145,12 @@ SIGNATURES = {
     "ecckd_scale_lut": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_double_p, _c_double_p, _c_double_p,
                                   C.POINTER(C.c_int), C.c_double, _c_double_p, _c_double_p, C.POINTER(_c_double_p)]),
     "ecckd_gmap_sum_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, _c_double_p]),
+    "ecckd_derive_d_wavenumber_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ecckd_merge_scaling": (C.c_int, [C.c_int, _c_double_p, C.c_double, C.c_double, C.c_double, _c_double_p, C.c_int,
+                                      _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    "ecckd_merge_spectrum_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, _c_double_p,
+                                           C.c_int, C.c_void_p, C.c_size_t]),
+    "ecckd_gmap_erythemal_spectrum": (C.c_int, [C.c_void_p, _c_double_p]),
     "ecckd_gather_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_invert_permutation_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }

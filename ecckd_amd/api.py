@@ -744,6 +744,47 @@ def run_ckd(ctx, model, scene, gases=None, scalings=None, per_gas=True):
     return out
 
 
+def derive_d_wavenumber(ctx, wavenumber):
+    """read_spectrum.cpp:55-65 for a grid stored without d_wavenumber (device tensor in, device tensor out)."""
+    import torch
+    out = torch.empty_like(wavenumber)
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_derive_d_wavenumber_dev(ctx.handle, wavenumber.numel(), _dptr(wavenumber), _dptr(out)))
+    ctx.synchronize()
+    return out
+
+
+def merge_scaling(pressure_hl, scaling=-1.0, conc=-1.0, reference_surface_vmr=-1.0, vmr_fl=None, pressure_conc=None,
+                  conc_req=None):
+    """read_merged_spectrum.cpp:117-147 -> (scaling_profile[nlay], vmr_fl row as stored at :153-165)."""
+    p = _f64c(pressure_hl)
+    nlay = p.size - 1
+    sp, vo = np.empty(nlay), np.empty(nlay)
+    v = _f64c(vmr_fl) if vmr_fl is not None else None
+    pc = _f64c(pressure_conc) if pressure_conc is not None else None
+    cr = _f64c(conc_req) if conc_req is not None else None
+    check(_lib.load_library().ecckd_merge_scaling(nlay, _hptr(p), float(scaling), float(conc), float(reference_surface_vmr),
+                                                  _hptr(v) if v is not None else None, 0 if pc is None else pc.size,
+                                                  _hptr(pc) if pc is not None else None,
+                                                  _hptr(cr) if cr is not None else None, _hptr(sp), _hptr(vo)))
+    return sp, vo
+
+
+def merge_spectrum(ctx, optical_depth, scaling_profile, merged=None):
+    """merged (+)= optical_depth * scaling(level) (read_merged_spectrum.cpp:152-166); FLOAT or DOUBLE device
+    tensor (nlay, nwav) in, DOUBLE device tensor out (allocated when `merged` is None)."""
+    import torch
+    first = merged is None
+    if first:
+        merged = torch.empty(optical_depth.shape, dtype=torch.float64, device=optical_depth.device)
+    sp = _f64c(scaling_profile)
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_merge_spectrum_dev(ctx.handle, optical_depth.shape[0], optical_depth.shape[1], _dptr(optical_depth),
+                                           _od_type(optical_depth), optical_depth.stride(0), _hptr(sp), int(first),
+                                           _dptr(merged), merged.stride(0)))
+    return merged
+
+
 def scale_lut(ctx, model, flux_sums, pressure_hl, temperature_hl, vmr_fl, gas_present, mu0):
     """scale_lut.cpp:117-189 + CkdModel::scale_optical_depth for one reference profile.  `flux_sums` (nz+1, ng)
     from GPointMap.sum_rows of the LBL direct spectral flux.  -> (list of scaled molar_abs arrays, scaling[nz, ng])."""
@@ -818,6 +859,12 @@ class GPointMap:
         self.ctx.fence_from_torch()
         check(self.lib.ecckd_gmap_sum_rows(self.handle, rows.shape[0], _dptr(rows), _od_type(rows), rows.stride(0),
                                            _hptr(out)))
+        return out
+
+    def erythemal_spectrum(self):
+        """sqrt(erythemal action spectrum) per g point, 5777 K Planck weighted (lbl_fluxes.cpp:198-230)."""
+        out = np.empty(self.ng)
+        check(self.lib.ecckd_gmap_erythemal_spectrum(self.handle, _hptr(out)))
         return out
 
     def gpoint_fraction(self, wavenumber1, wavenumber2):

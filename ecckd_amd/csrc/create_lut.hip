@@ -271,6 +271,43 @@ k_rowsum_partial(int nrows, size_t stride, const Chunk* __restrict__ chunks, con
   }
 }
 
+// Erythemal weight per g point (lbl_fluxes.cpp:198-230): partial[chunk][2] = { sum ery * planck, sum planck }
+__global__ void __launch_bounds__(GA_THREADS)
+k_erythemal_partial(const Chunk* __restrict__ chunks, const double* __restrict__ wn_s, const double* __restrict__ dwn_s,
+                    double* __restrict__ partial) {
+  __shared__ double s_red[2][4];
+  const Chunk c = chunks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double num = 0.0, den = 0.0;
+#pragma unroll
+  for (int p = 0; p < GA_PPT; ++p) {
+    const long long i = c.p0 + (long long)p * GA_THREADS + tid;
+    if (i > c.p1) continue;
+    const double wn = wn_s[i];
+    const double wavelength_nm = 1.0e7 / wn;
+    double ery = 0.0;
+    if (wavelength_nm > 250.0 && wavelength_nm <= 298.0) ery = 1.0;
+    if (wavelength_nm > 298.0 && wavelength_nm <= 328.0) ery = pow(10.0, 0.094 * (298.0 - wavelength_nm));
+    if (wavelength_nm > 328.0 && wavelength_nm <= 400.0) ery = pow(10.0, 0.015 * (140.0 - wavelength_nm));
+    ery = sqrt(ery);
+    // planck_function(5777 K), planck_function.cpp:22-54
+    const double inv_cm_2_Hz = 100.0 * kLightC;
+    const double freq = wn * inv_cm_2_Hz;
+    const double pref = (dwn_s[i] * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq);
+    const double pl = pref / (exp((6.62606896e-34 / 1.3806504e-23) * (freq / 5777.0)) - 1.0);
+    num += ery * pl;
+    den += pl;
+  }
+  num = wave_sum(num);
+  den = wave_sum(den);
+  if (lane == 0) { s_red[0][wave] = num; s_red[1][wave] = den; }
+  __syncthreads();
+  if (tid == 0) {
+    partial[(size_t)blockIdx.x * 2 + 0] = ((s_red[0][0] + s_red[0][1]) + s_red[0][2]) + s_red[0][3];
+    partial[(size_t)blockIdx.x * 2 + 1] = ((s_red[1][0] + s_red[1][1]) + s_red[1][2]) + s_red[1][3];
+  }
+}
+
 // K7b.  gpoint_fraction: grid (nint + 1, ng), block 64.  blockIdx.x == nint computes the total
 // spectral width of the g point; the others the width inside (wavenumber1, wavenumber2].
 __global__ void __launch_bounds__(64)
@@ -562,6 +599,29 @@ int ecckd_gmap_sum_rows(ecckd_gmap* m, int nrows, const void* d_rows, int rows_t
   hipLaunchKernelGGL(k_planck_lut_final, dim3(ng), dim3(256), 0, ctx->stream, nrows, ng, m->d_seg_chunk0, d_part, d_out);
   ECCKD_HIP_CHECK(hipGetLastError());
   return ecckd_d2h(ctx, h_sums, d_out, (size_t)nrows * ng * sizeof(double));
+}
+
+
+int ecckd_gmap_erythemal_spectrum(ecckd_gmap* m, double* h_erythemal) {
+  ECCKD_REQUIRE(m && h_erythemal, "ecckd_gmap_erythemal_spectrum: NULL argument");
+  ecckd_ctx* ctx = m->ctx;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const int ng = m->ng;
+  const size_t nchunk = m->chunks.size();
+  const size_t part_bytes = ecckd_align_up(std::max<size_t>(nchunk, 1) * 2 * sizeof(double), 256);
+  const size_t out_bytes = ecckd_align_up((size_t)2 * ng * sizeof(double), 256);
+  ECCKD_CHECK(gmap_work(m, part_bytes + out_bytes));
+  double* d_part = (double*)m->work;
+  double* d_out = (double*)((char*)m->work + part_bytes);
+  if (nchunk > 0)
+    hipLaunchKernelGGL(k_erythemal_partial, dim3((unsigned)nchunk), dim3(GA_THREADS), 0, ctx->stream, m->d_chunks, m->wn_s,
+                       m->dwn_s, d_part);
+  hipLaunchKernelGGL(k_planck_lut_final, dim3(ng), dim3(256), 0, ctx->stream, 2, ng, m->d_seg_chunk0, d_part, d_out);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  std::vector<double> nd(2 * (size_t)ng);
+  ECCKD_CHECK(ecckd_d2h(ctx, nd.data(), d_out, nd.size() * sizeof(double)));
+  for (int g = 0; g < ng; ++g) h_erythemal[g] = nd[g] / nd[(size_t)ng + g];
+  return ECCKD_OK;
 }
 
 }  // extern "C"

@@ -217,6 +217,24 @@ int ecckd_find_g_band(ecckd_gas* gas, size_t ibegin, size_t iend, double heating
                       int max_g_points, int* ng, double* bounds, double* error, int capacity,
                       int* status, double* comp_cost);
 
+/* ---- read_spectrum / read_merged_spectrum arithmetic (a1) ------------------------
+ * File access stays with the caller; these are the nwav-sized operations behind it.
+ * ecckd_derive_d_wavenumber_dev: read_spectrum.cpp:55-65, the spacing of a grid stored without
+ *   "d_wavenumber" (interior: half the distance between the neighbours; ends: half their neighbour's).
+ * ecckd_merge_scaling: the scaling of one constituent, read_merged_spectrum.cpp:117-147 - a requested
+ *   concentration profile (nconc > 0: interp in pressure, ends clamped, divided by the file's own mole
+ *   fraction) or the scalar rules (conc == 0 -> 0; conc > 0 -> conc / reference_surface_vmr, PARAMETER_ERROR
+ *   if the file has none; scaling < 0 -> 1).  h_vmr_fl_out[nlay] is the row of vmr_fl the reference
+ *   stores (:153-165); may be NULL.
+ * ecckd_merge_spectrum_dev: merged (+)= od * scaling(level), :152-166; `first` overwrites instead of
+ *   accumulating.  od is FLOAT (as in the CKDMIP files) or DOUBLE, merged is DOUBLE [nlay][merged_stride]. */
+int ecckd_derive_d_wavenumber_dev(ecckd_ctx* ctx, size_t nwav, const double* d_wavenumber, double* d_d_wavenumber);
+int ecckd_merge_scaling(int nlay, const double* h_pressure_hl, double scaling, double conc, double reference_surface_vmr,
+                        const double* h_vmr_fl_one_gas, int nconc, const double* h_pressure_conc,
+                        const double* h_conc_req, double* h_scaling_profile, double* h_vmr_fl_out);
+int ecckd_merge_spectrum_dev(ecckd_ctx* ctx, int nlay, size_t nwav, const void* d_od, int od_type, size_t od_stride,
+                             const double* h_scaling_profile, int first, double* d_merged, size_t merged_stride);
+
 /* ---- sub-bands and base split of find_g_points --------------------------------
  * find_g_points.cpp:786-870 (sub-bands of the optically thin part of a band) and :1311-1346
  * (wavenumber split of the base g point) both re-rank a contiguous range of ranks
@@ -422,6 +440,10 @@ int ecckd_average_to_gpoints(ecckd_gmap* gmap, int nlay, const double* h_pressur
 /* h_sums[nrows][ng] = sum over the wavenumbers of each g point of d_rows[r][.] (scale_lut.cpp:119-124) */
 int ecckd_gmap_sum_rows(ecckd_gmap* gmap, int nrows, const void* d_rows, int rows_type, size_t row_stride,
                         double* h_sums);
+/* LblFluxes::read, lbl_fluxes.cpp:198-230: the square root of the erythemal action spectrum (Webb et al.
+ * 2011) averaged over each g point with a 5777 K Planck weight, h_erythemal[ng]; NaN for an empty g point
+ * (0/0 as in the reference). */
+int ecckd_gmap_erythemal_spectrum(ecckd_gmap* gmap, double* h_erythemal);
 /* create_look_up_table.cpp:537-548: h_gpoint_fraction[ng][nint] over the coarse intervals
  * (wavenumber1, wavenumber2] */
 int ecckd_gpoint_fraction(ecckd_gmap* gmap, int nint, const double* h_wavenumber1,
