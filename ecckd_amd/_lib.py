@@ -53,6 +53,7 @@ SIGNATURES = {
     "ecckd_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "ecckd_destroy": (C.c_int, [C.c_void_p]),
     "ecckd_synchronize": (C.c_int, [C.c_void_p]),
+    "ecckd_trim_cache": (C.c_int, [C.c_void_p]),
     "ecckd_stream": (C.c_void_p, [C.c_void_p]),
     "ecckd_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "ecckd_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -34,6 +34,11 @@ struct ecckd_ctx {
   KernelStat stat_rt_lw;     // k_rt_lw_bb: units = wavenumber points processed
   KernelStat stat_key_lw;    // k_reorder_key_lw: units = wavenumber points
   KernelStat stat_sort;      // whole K3 pass sequence: units = keys sorted
+  // Caching device allocator (ecckd::dev_malloc / dev_release): blocks released by a handle are kept
+  // and handed out again for a request of the same size, so that preparing gas after gas (13 GB of
+  // resident rows each) does not pay hipMalloc / hipFree - page-table set-up that costs hundreds of
+  // milliseconds on some hosts - inside the sweep.  Everything runs on `stream`, so reuse is ordered.
+  void* cache_impl = nullptr;
 };
 
 namespace ecckd {
@@ -44,6 +49,11 @@ void set_error(const char* fmt, ...);
 int fail(int code, const char* fmt, ...);
 
 int ensure_scratch(ecckd_ctx* ctx, size_t bytes);
+// hipMalloc-compatible: returns hipSuccess / hipErrorOutOfMemory (after trimming the cache and retrying)
+hipError_t dev_malloc(ecckd_ctx* ctx, void** p, size_t bytes);
+void dev_release(ecckd_ctx* ctx, void* p);          // back to the cache (or hipFree above the cache limit)
+void dev_cache_trim(ecckd_ctx* ctx);                // hipFree every cached block
+void dev_cache_delete(ecckd_ctx* ctx);
 int ensure_pinned(ecckd_ctx* ctx, size_t bytes);
 
 }  // namespace ecckd

@@ -1,6 +1,9 @@
 // context.hip - context lifetime, device memory helpers, stream timing and the
 // error channel of the C ABI (include/ecckd_hip.h).
 #include "common.hpp"
+#include <map>
+#include <unordered_map>
+#include <cstdlib>
 
 #include <cmath>
 #include <cstring>
@@ -22,6 +25,70 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+namespace {
+struct DevCache {
+  std::unordered_map<void*, size_t> live;       // blocks handed out
+  std::multimap<size_t, void*> free_blocks;     // cached, by size
+  size_t cached_bytes = 0;
+  size_t limit_bytes = (size_t)96 << 30;        // 288 GB of HBM per GPU: keep up to 96 GB parked (ECCKD_CACHE_GB)
+};
+DevCache* cache_of(ecckd_ctx* ctx) {
+  if (!ctx->cache_impl) {
+    DevCache* c = new DevCache;
+    if (const char* e = std::getenv("ECCKD_CACHE_GB")) c->limit_bytes = (size_t)std::atof(e) * ((size_t)1 << 30);
+    ctx->cache_impl = c;
+  }
+  return (DevCache*)ctx->cache_impl;
+}
+}  // namespace
+
+hipError_t dev_malloc(ecckd_ctx* ctx, void** p, size_t bytes) {
+  DevCache* c = cache_of(ctx);
+  if (bytes == 0) bytes = 1;
+  auto it = c->free_blocks.find(bytes);
+  if (it != c->free_blocks.end()) {
+    *p = it->second;
+    c->cached_bytes -= bytes;
+    c->free_blocks.erase(it);
+    c->live[*p] = bytes;
+    return hipSuccess;
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory && !c->free_blocks.empty()) {
+    (void)hipGetLastError();
+    dev_cache_trim(ctx);
+    e = hipMalloc(p, bytes);
+  }
+  if (e == hipSuccess) c->live[*p] = bytes;
+  return e;
+}
+
+void dev_release(ecckd_ctx* ctx, void* p) {
+  if (!p) return;
+  DevCache* c = cache_of(ctx);
+  auto it = c->live.find(p);
+  if (it == c->live.end()) { (void)hipFree(p); return; }   // not ours (allocated before the cache existed)
+  const size_t bytes = it->second;
+  c->live.erase(it);
+  if (c->cached_bytes + bytes > c->limit_bytes) { (void)hipFree(p); return; }
+  c->free_blocks.emplace(bytes, p);
+  c->cached_bytes += bytes;
+}
+
+void dev_cache_delete(ecckd_ctx* ctx) {
+  delete (DevCache*)ctx->cache_impl;
+  ctx->cache_impl = nullptr;
+}
+
+void dev_cache_trim(ecckd_ctx* ctx) {
+  if (!ctx->cache_impl) return;
+  DevCache* c = (DevCache*)ctx->cache_impl;
+  if (!c->free_blocks.empty()) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
+  c->free_blocks.clear();
+  c->cached_bytes = 0;
 }
 
 int ensure_scratch(ecckd_ctx* ctx, size_t bytes) {
@@ -96,6 +163,8 @@ int ecckd_destroy(ecckd_ctx* ctx) {
   if (!ctx) return ECCKD_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  ecckd::dev_cache_trim(ctx);
+  ecckd::dev_cache_delete(ctx);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipEventDestroy(ctx->ev0);
@@ -104,6 +173,13 @@ int ecckd_destroy(ecckd_ctx* ctx) {
   if (ctx->pev1) (void)hipEventDestroy(ctx->pev1);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+  return ECCKD_OK;
+}
+
+int ecckd_trim_cache(ecckd_ctx* ctx) {
+  ECCKD_REQUIRE(ctx, "ecckd_trim_cache: ctx is NULL");
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  ecckd::dev_cache_trim(ctx);
   return ECCKD_OK;
 }
 

@@ -970,38 +970,31 @@ int gas_ensure_work(ecckd_gas* g, size_t dev_bytes, size_t pinned_bytes) {
   if (dev_bytes > g->work_bytes) {
     if (g->work) {
       ECCKD_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
-      ECCKD_HIP_CHECK(hipFree(g->work));
+      ecckd::dev_release(g->ctx, g->work);
       g->work = nullptr;
       g->work_bytes = 0;
     }
     size_t want = ecckd_align_up(dev_bytes * 2, 1 << 20);
-    ECCKD_HIP_CHECK(hipMalloc(&g->work, want));
+    ECCKD_HIP_CHECK(ecckd::dev_malloc(g->ctx, &g->work, want));
     g->work_bytes = want;
   }
-  if (pinned_bytes > g->pinned_bytes) {
-    if (g->pinned) {
-      ECCKD_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
-      ECCKD_HIP_CHECK(hipHostFree(g->pinned));
-      g->pinned = nullptr;
-      g->pinned_bytes = 0;
-    }
-    size_t want = ecckd_align_up(pinned_bytes * 2, 4096);
-    ECCKD_HIP_CHECK(hipHostMalloc(&g->pinned, want, hipHostMallocDefault));
-    g->pinned_bytes = want;
-  }
+  // the pinned staging area belongs to the context (one caller per context at a time)
+  ECCKD_CHECK(ecckd::ensure_pinned(g->ctx, pinned_bytes));
+  g->pinned = g->ctx->pinned;
+  g->pinned_bytes = g->ctx->pinned_bytes;
   return ECCKD_OK;
 }
 
 void gas_free(ecckd_gas* g) {
   if (!g) return;
-  if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
-  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  ecckd_ctx* ctx = g->ctx;
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  auto fr = [ctx](void* p) { if (p) ecckd::dev_release(ctx, p); };
   if (g->owns_planck) fr(g->planck_hl);
   fr(g->ssi); fr(g->tf); fr(g->tg); fr(g->hr_low); fr(g->hr_high); fr(g->fx);
   fr(g->bg_od); fr(g->w1); fr(g->w2); fr(g->cnt); fr(g->hr); fr(g->fds); fr(g->fut);
   fr(g->wn_sorted); fr(g->dwn_sorted); fr(g->ireorder); fr((void*)g->rows); fr(g->tile_sums);
   fr(g->lev); fr(g->work);
-  if (g->pinned) (void)hipHostFree(g->pinned);
   delete g;
 }
 
@@ -1061,20 +1054,20 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
     g->planck_hl = const_cast<double*>(d_planck_hl_reuse);
     g->owns_planck = false;
   } else {
-    GTRY(hipMalloc((void**)&g->planck_hl, nhl * nwav * sizeof(double)));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->planck_hl, nhl * nwav * sizeof(double)));
   }
-  GTRY(hipMalloc((void**)&g->bg_od, mat));
-  GTRY(hipMalloc((void**)&g->w1, mat));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->bg_od, mat));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->w1, mat));
   if (is_log) {
-    GTRY(hipMalloc((void**)&g->w2, mat));
-    GTRY(hipMalloc((void**)&g->cnt, mat));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->w2, mat));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->cnt, mat));
   }
-  GTRY(hipMalloc((void**)&g->hr, mat));
-  GTRY(hipMalloc((void**)&g->fds, nwav * sizeof(double)));
-  GTRY(hipMalloc((void**)&g->fut, nwav * sizeof(double)));
-  GTRY(hipMalloc((void**)&g->wn_sorted, nwav * sizeof(double)));
-  GTRY(hipMalloc((void**)&g->dwn_sorted, nwav * sizeof(double)));
-  GTRY(hipMalloc((void**)&g->ireorder, nwav * sizeof(int32_t)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->hr, mat));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->fds, nwav * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->fut, nwav * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->wn_sorted, nwav * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->dwn_sorted, nwav * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->ireorder, nwav * sizeof(int32_t)));
 
   // per-level constants: hk[nhl] | conv[nlay] | layer_weight[nlay] | flag
   std::vector<double> lev(nhl + 2 * nlay + 1, 0.0);
@@ -1097,7 +1090,7 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
       lev[nhl + nlay + l] = g->h_layer_weight[l];
     }
   }
-  GTRY(hipMalloc((void**)&g->lev, lev.size() * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->lev, lev.size() * sizeof(double)));
   GTRY(hipMemcpyAsync(g->lev, lev.data(), lev.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   GTRY(hipStreamSynchronize(ctx->stream));
   int* d_flag = (int*)(g->lev + nhl + 2 * nlay);
@@ -1138,10 +1131,10 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   const bool fast = nlay == 54 && od_type == ECCKD_F32 && (!d_bg_od || bg32) && !is_log && !d_planck_hl_reuse;
   if (fast) {
     float *od_col = nullptr, *bg_col = nullptr;
-    GTRY(hipMalloc((void**)&od_col, (size_t)nwav * 54 * sizeof(float)));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&od_col, (size_t)nwav * 54 * sizeof(float)));
     if (d_bg_od) {
-      hipError_t e2 = hipMalloc((void**)&bg_col, (size_t)nwav * 54 * sizeof(float));
-      if (e2 != hipSuccess) { (void)hipFree(od_col); GTRY(e2); }
+      hipError_t e2 = ecckd::dev_malloc(ctx, (void**)&bg_col, (size_t)nwav * 54 * sizeof(float));
+      if (e2 != hipSuccess) { ecckd::dev_release(ctx, od_col); GTRY(e2); }
     }
     const unsigned tblocks = (unsigned)((nwav + 63) / 64);
     hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
@@ -1156,8 +1149,9 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
                        g->fut);
     hipError_t e3 = hipGetLastError();
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(od_col);
-    if (bg_col) (void)hipFree(bg_col);
+    GTRY(hipStreamSynchronize(ctx->stream));
+    ecckd::dev_release(ctx, od_col);
+    if (bg_col) ecckd::dev_release(ctx, bg_col);
     GTRY(e3);
   } else if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP(float, float);
   else if (bg32) LAUNCH_PREP(float, double);
@@ -1188,11 +1182,11 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   }
   rows[R.FDS] = g->fds;
   rows[R.FUT] = g->fut;
-  GTRY(hipMalloc((void**)&g->rows, rows.size() * sizeof(double*)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->rows, rows.size() * sizeof(double*)));
   GTRY(hipMemcpyAsync((void*)g->rows, rows.data(), rows.size() * sizeof(double*), hipMemcpyHostToDevice, ctx->stream));
   GTRY(hipStreamSynchronize(ctx->stream));
   g->ntiles = (nwav + TILE - 1) / TILE;
-  GTRY(hipMalloc((void**)&g->tile_sums, (size_t)g->nrows * g->ntiles * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->tile_sums, (size_t)g->nrows * g->ntiles * sizeof(double)));
   hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)g->ntiles), dim3(TILE), 0, ctx->stream, g->nrows, nwav, g->ntiles,
                      (const double* const*)g->rows, g->tile_sums);
   GTRY(hipGetLastError());
@@ -1262,24 +1256,24 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
     }                                                                                    \
   } while (0)
   const size_t mat = (size_t)nlay * nwav * sizeof(double);
-  GTRY(hipMalloc((void**)&g->ssi, nwav * sizeof(double)));
-  GTRY(hipMalloc((void**)&g->bg_od, mat));
-  GTRY(hipMalloc((void**)&g->w1, mat));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->ssi, nwav * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->bg_od, mat));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->w1, mat));
   if (is_log) {
-    GTRY(hipMalloc((void**)&g->w2, mat));
-    GTRY(hipMalloc((void**)&g->cnt, mat));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->w2, mat));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->cnt, mat));
   }
-  GTRY(hipMalloc((void**)&g->hr, mat));
-  GTRY(hipMalloc((void**)&g->fds, nwav * sizeof(double)));
-  GTRY(hipMalloc((void**)&g->fut, nwav * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->hr, mat));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->fds, nwav * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->fut, nwav * sizeof(double)));
   if (is_tt) {
-    GTRY(hipMalloc((void**)&g->tf, mat));
-    GTRY(hipMalloc((void**)&g->tg, mat));
-    GTRY(hipMalloc((void**)&g->hr_low, mat));
-    GTRY(hipMalloc((void**)&g->hr_high, mat));
-    GTRY(hipMalloc((void**)&g->fx, 4 * nwav * sizeof(double)));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->tf, mat));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->tg, mat));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->hr_low, mat));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->hr_high, mat));
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->fx, 4 * nwav * sizeof(double)));
   }
-  GTRY(hipMalloc((void**)&g->ireorder, nwav * sizeof(int32_t)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->ireorder, nwav * sizeof(int32_t)));
 
   // per-level constants: (unused hk)[nhl] | conv[nlay] | layer_weight[nlay] | flag
   std::vector<double> lev(nhl + 2 * nlay + 1, 0.0);
@@ -1299,7 +1293,7 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
       lev[nhl + nlay + l] = g->h_layer_weight[l];
     }
   }
-  GTRY(hipMalloc((void**)&g->lev, lev.size() * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->lev, lev.size() * sizeof(double)));
   GTRY(hipMemcpyAsync(g->lev, lev.data(), lev.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   GTRY(hipStreamSynchronize(ctx->stream));
   int* d_flag = (int*)(g->lev + nhl + 2 * nlay);
@@ -1370,11 +1364,11 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
     rows[R.FDSH] = g->fx + 2 * nwav;
     rows[R.FUTH] = g->fx + 3 * nwav;
   }
-  GTRY(hipMalloc((void**)&g->rows, rows.size() * sizeof(double*)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->rows, rows.size() * sizeof(double*)));
   GTRY(hipMemcpyAsync((void*)g->rows, rows.data(), rows.size() * sizeof(double*), hipMemcpyHostToDevice, ctx->stream));
   GTRY(hipStreamSynchronize(ctx->stream));
   g->ntiles = (nwav + TILE - 1) / TILE;
-  GTRY(hipMalloc((void**)&g->tile_sums, (size_t)g->nrows * g->ntiles * sizeof(double)));
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->tile_sums, (size_t)g->nrows * g->ntiles * sizeof(double)));
   hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)g->ntiles), dim3(TILE), 0, ctx->stream, g->nrows, nwav, g->ntiles,
                      (const double* const*)g->rows, g->tile_sums);
   GTRY(hipGetLastError());

@@ -65,6 +65,9 @@ const char* ecckd_last_error(void);
 int ecckd_init(int device, ecckd_ctx** ctx);
 int ecckd_destroy(ecckd_ctx* ctx);
 int ecckd_synchronize(ecckd_ctx* ctx);
+/* Device buffers released by gas / g-point-map handles are parked in the context and reused for later
+ * handles of the same shapes (up to ECCKD_CACHE_GB, default 96); this returns them to the driver. */
+int ecckd_trim_cache(ecckd_ctx* ctx);
 /* the context's hipStream_t, for callers that record their own events */
 void* ecckd_stream(ecckd_ctx* ctx);
 int ecckd_dev_alloc(ecckd_ctx* ctx, size_t bytes, void** d_ptr);
