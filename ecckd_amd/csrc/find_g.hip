@@ -26,6 +26,7 @@
 #include "fastmath.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -525,28 +526,47 @@ __device__ __forceinline__ void eps_fac_pair(double od0, double od1, double& eps
   fac1 = fmax(1.0 - (1.0 / kD) * t1, 0.5 * TE);
 }
 
-// K5c fast path: NLAY known at compile time.  The whole column (NLAY background
-// optical depths + NLAY+1 Planck values, 109 f64 for NLAY = 54) is loaded into
-// registers once; the down sweep overwrites it in place with the layer
-// transmittance 1-eps and the upward source term, so the up sweep needs no second
-// exp and no second read (the reference evaluates both twice,
-// radiative_transfer_lw.cpp:114,:131).  Per-half-level flux sums are reduced by a
-// transposed LDS pass every 16 levels: each lane parks its flux in a wave-private
-// [16][65] f64 tile (odd row stride: conflict-free ds_read_b64), then lane
-// (row r = lane%16, quarter q = lane/16) adds 16 values and two xor-shuffles
-// combine the quarters.  Fixed order everywhere: bitwise reproducible.
+// Emissivity and factor of one layer (the tail of an odd-length half column).
+__device__ __forceinline__ void eps_fac_one(double od, double& eps, double& fac) {
+  constexpr double TE = 1.0e-5;
+  eps = 1.0 - exp_nonpos(-kD * od);
+  fac = fmax(1.0 - (1.0 / kD) * fast_div(fmax(eps, TE), fmax(od, TE / kD)), 0.5 * TE);
+}
+
+// K5c mirror path.  The two-stream equations are symmetric under turning the column upside down:
+// the up sweep through layer l, up_l = up_{l+1} t + B_{l+1}(eps-fac) + B_l fac, is the down sweep
+// dn_{l+1} = dn_l t + B_l(eps-fac) + B_{l+1} fac with the two Planck values exchanged
+// (radiative_transfer_lw.cpp:121-123,:138-139).  So a PAIR of waves shares 64 spectral points: the even
+// wave owns the upper NLAY/2 layers and loads them top-down, the odd wave owns the lower NLAY/2 layers
+// and loads them bottom-up, and both run the SAME instruction stream:
+//   first sweep  - even: downward from the top of the atmosphere (input 0),
+//                  odd:  upward from the surface (input = surface Planck function, emissivity 1),
+//                  keeping the layer transmittance and the source of the opposite direction;
+//   exchange     - through LDS, one barrier per tile: each wave receives the true flux that enters its
+//                  half from the other side;
+//   second sweep - even: upward through its half, odd: downward through its half.
+// Every flux is the exact sequential recurrence of the reference; nothing is recomputed.  Per-lane
+// state is NLAY+1 doubles instead of 2*NLAY+1, which fits 3 waves per SIMD - the dependent
+// v_fma_f64 chains need that (tools/fp64_latency.hip).  Level sums: as in the fast path, through a
+// wave-private transposed LDS tile every 16 slots.
 template <int NLAY>
-__global__ void __launch_bounds__(RT_THREADS, 2)
-k_rt_lw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv,
-                const double* __restrict__ planck_hl, const double* __restrict__ bg_od,
-                const double* __restrict__ od_fit, double* __restrict__ partial) {
+__global__ void __launch_bounds__(RT_THREADS, 3)
+k_rt_lw_bb_mirror(size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv,
+                  const double* __restrict__ planck_hl, const double* __restrict__ bg_od,
+                  const double* __restrict__ od_fit, double* __restrict__ partial) {
+  static_assert(NLAY % 2 == 0, "the column is split into two equal halves");
   constexpr int NHL = NLAY + 1;
-  constexpr int NSLOT = 2 * NLAY + 1;            // dn[1..NLAY], up[NLAY..0]
+  constexpr int H = NLAY / 2;
+  constexpr int NSLOT = 2 * H + 1;               // slot 0: input of the first sweep, 1..H first sweep, H+1..2H second
   constexpr int NCH = (NSLOT + 15) / 16;
   constexpr int ROW = 65;
+  constexpr int PTS = RT_THREADS / 2;            // points per block iteration: two wave pairs
   __shared__ double s_tile[4][16 * ROW];
   __shared__ double s_out[4][NCH * 16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double s_x[2][4][64];               // [tile parity][wave][lane] flux handed to the partner wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave & 1, pair = wave >> 1;
 
   const long long chunk = blockIdx.x;
   int lo = 0, hi = nint - 1;
@@ -559,7 +579,12 @@ k_rt_lw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
   const long long p0 = iv[k].i1 + c * chunk_pts;
   long long p1 = p0 + chunk_pts - 1;
   if (p1 > iv[k].i2) p1 = iv[k].i2;
-  const double* __restrict__ grey = od_fit + (size_t)k * NLAY;  // block-uniform -> scalar loads
+  // rows of this wave: layers / levels 0,1,2,.. (even wave) or NLAY-1,NLAY-2,.. / NLAY,NLAY-1,.. (odd wave)
+  const long long row_step = half ? -(long long)n : (long long)n;
+  const long long grey_step = half ? -1 : 1;
+  const double* __restrict__ grey = od_fit + (size_t)k * NLAY + (half ? NLAY - 1 : 0);  // wave-uniform -> scalar loads
+  const double* __restrict__ od0 = bg_od + (half ? (size_t)(NLAY - 1) * n : 0);
+  const double* __restrict__ pl0 = planck_hl + (half ? (size_t)NLAY * n : 0);
 
   double* tile = s_tile[wave];
   const int rr = lane & 15, qq = lane >> 4;
@@ -567,17 +592,17 @@ k_rt_lw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
 #pragma unroll
   for (int j = 0; j < NCH; ++j) acc[j] = 0.0;
 
-  constexpr double THRESHOLD_EMISSIVITY = 1.0e-5;
-  for (long long base = p0; base <= p1; base += RT_THREADS) {
-    const long long i = base + tid;
+  int parity = 0;
+  for (long long base = p0; base <= p1; base += PTS, parity ^= 1) {
+    const long long i = base + pair * 64 + lane;
     const bool live = i <= p1;
     const size_t ii = live ? (size_t)i : (size_t)p1;
-    double a[NLAY];   // background optical depth -> 1 - eps
-    double b[NHL];    // planck -> upward source of the layer below each half level
+    double a[H];       // optical depth -> transmittance
+    double b[H + 1];   // Planck function -> source of the second sweep
 #pragma unroll
-    for (int l = 0; l < NLAY; ++l) a[l] = bg_od[(size_t)l * n + ii];
+    for (int l = 0; l < H; ++l) a[l] = od0[(long long)l * row_step + (long long)ii];
 #pragma unroll
-    for (int l = 0; l < NHL; ++l) b[l] = planck_hl[(size_t)l * n + ii];
+    for (int l = 0; l <= H; ++l) b[l] = pl0[(long long)l * row_step + (long long)ii];
 
     int slot = 0;
     auto push = [&](double flux) {
@@ -596,51 +621,65 @@ k_rt_lw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
       ++slot;
     };
 
-    double flux = 0.0;
-    static_assert(NLAY % 2 == 0, "layers are processed in pairs");
-#pragma unroll
-    for (int l = 0; l < NLAY; l += 2) {
-      double eps0, fac0, eps1, fac1;
-      eps_fac_pair(a[l] + grey[l], a[l + 1] + grey[l + 1], eps0, fac0, eps1, fac1);
-      const double emf0 = eps0 - fac0, emf1 = eps1 - fac1;
-      const double bl = b[l], bm = b[l + 1], bn = b[l + 2];
-      flux = flux * (1.0 - eps0) + bl * emf0 + bm * fac0;
-      a[l] = 1.0 - eps0;
-      b[l] = bm * emf0 + bl * fac0;        // :138-139 source of the up sweep
-      push(flux);
-      flux = flux * (1.0 - eps1) + bm * emf1 + bn * fac1;
-      a[l + 1] = 1.0 - eps1;
-      b[l + 1] = bn * emf1 + bm * fac1;
-      push(flux);
-    }
-    // surface (:126-128): emissivity 1, surf_planck = planck_hl(NLAY)
-    flux = b[NLAY] * 1.0 + (1.0 - 1.0) * flux;
+    // input of the first sweep: nothing comes down at the top; the surface emits its Planck function (:126-128)
+    double flux = half ? b[0] : 0.0;
     push(flux);
+    auto layer = [&](int l, double eps, double fac) {
+      const double emf = eps - fac;
+      const double t = 1.0 - eps;
+      const double near = b[l], far = b[l + 1];
+      flux = flux * t + near * emf + far * fac;
+      a[l] = t;
+      b[l] = far * emf + near * fac;          // source of the opposite direction, for the second sweep
+      push(flux);
+    };
 #pragma unroll
-    for (int l = NLAY - 1; l >= 0; --l) {
+    for (int l = 0; l + 1 < H; l += 2) {
+      double eps0, fac0, eps1, fac1;
+      eps_fac_pair(a[l] + grey[(long long)l * grey_step], a[l + 1] + grey[(long long)(l + 1) * grey_step], eps0, fac0, eps1, fac1);
+      layer(l, eps0, fac0);
+      layer(l + 1, eps1, fac1);
+    }
+    if (H & 1) {
+      double eps0, fac0;
+      eps_fac_one(a[H - 1] + grey[(long long)(H - 1) * grey_step], eps0, fac0);
+      layer(H - 1, eps0, fac0);
+    }
+    // the flux that enters this half from the other side is the partner wave's result
+    s_x[parity][wave][lane] = flux;
+    __syncthreads();
+    flux = s_x[parity][wave ^ 1][lane];
+#pragma unroll
+    for (int l = H - 1; l >= 0; --l) {
       flux = flux * a[l] + b[l];
       push(flux);
     }
-    // a partially filled last tile row set must not leak into the next sub-tile
     if ((NSLOT & 15) != 0) {
 #pragma unroll
       for (int j = (NSLOT & 15); j < 16; ++j) tile[j * ROW + lane] = 0.0;
     }
   }
 
-  // lanes 0..15 of each wave hold the wave's sums for slots ch*16 + lane
   if (lane < 16) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) s_out[wave][j * 16 + lane] = acc[j];
   }
   __syncthreads();
   for (int t = tid; t < 2 * NHL; t += RT_THREADS) {
-    // slot of (direction, level): dn[l] = slot l-1 (dn[0] = 0), up[NLAY] = slot NLAY, up[l] = slot 2*NLAY - l
+    // even waves (0, 2): slot 1+i = dn[i+1], slot H+1+k = up[H-1-k];
+    // odd waves (1, 3):  slot 0 = up[NLAY], slot 1+i = up[NLAY-1-i], slot H+1+k = dn[H+1+k]
+    int par = -1, sl = -1;
+    if (t < NHL) {                       // flux_dn at level t
+      if (t >= 1 && t <= H) { par = 0; sl = t; }
+      else if (t > H) { par = 1; sl = t; }
+    } else {                             // flux_up at level u
+      const int u = t - NHL;
+      if (u == NLAY) { par = 1; sl = 0; }
+      else if (u >= H) { par = 1; sl = NLAY - u; }
+      else { par = 0; sl = 2 * H - u; }
+    }
     double v = 0.0;
-    int sl = -1;
-    if (t < NHL) { if (t > 0) sl = t - 1; }
-    else { sl = 2 * NLAY - (t - NHL); }
-    if (sl >= 0) v = ((s_out[0][sl] + s_out[1][sl]) + s_out[2][sl]) + s_out[3][sl];
+    if (sl >= 0) v = s_out[par][sl] + s_out[par + 2][sl];
     partial[(size_t)chunk * 2 * NHL + t] = v;
   }
 }
@@ -1511,8 +1550,9 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
 
   // chunking: aim at ~8 blocks per CU, chunks are multiples of the 256-point sub-tile
   const bool fast_path = (nlay == 54 || nlay == 30);
-  // fast path: 2 resident blocks per CU (register-resident columns) -> one wave of blocks
-  long long target_blocks = (long long)ctx->num_cu * (fast_path ? 2 : 8);
+  // mirror path: 3 resident blocks per CU (3 waves/SIMD) -> one wave of blocks; more chunks shorten K5c a
+  // little but lengthen the ordered combine in K5d by more
+  long long target_blocks = (long long)ctx->num_cu * (fast_path ? 3 : 8);
   long long chunk_pts = (total_pts + target_blocks - 1) / target_blocks;
   chunk_pts = (chunk_pts + RT_THREADS - 1) / RT_THREADS * RT_THREADS;
   if (chunk_pts < RT_THREADS) chunk_pts = RT_THREADS;
@@ -1575,10 +1615,10 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   const size_t rt_lds = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
   if (nlay == 54) {
-    hipLaunchKernelGGL(k_rt_lw_bb_fast<54>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
+    hipLaunchKernelGGL(k_rt_lw_bb_mirror<54>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
                        chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
   } else if (nlay == 30) {
-    hipLaunchKernelGGL(k_rt_lw_bb_fast<30>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
+    hipLaunchKernelGGL(k_rt_lw_bb_mirror<30>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
                        chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
   } else {
     hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, ctx->stream, nlay, g->n,
