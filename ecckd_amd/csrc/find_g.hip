@@ -200,49 +200,62 @@ k_scatter_columns(size_t n, size_t src_stride, const int32_t* __restrict__ rank,
   }
 }
 
-// K4 fast path, step 2: as k_gas_prep_lw, NLAY known at compile time, one wave per SIMD, the
-// down-sweep increments / emissivity / upward source of the column in registers (one exp per
-// layer and half level instead of two), no LDS.  Linear/transmission/square-root metrics.
+// K4 mirror path (same idea as K5c's, see k_rt_lw_bb_mirror): a pair of waves shares 64 points, the even
+// wave prepares the upper NLAY/2 layers top-down (first sweep = downwelling from the top of the
+// atmosphere), the odd wave the lower NLAY/2 layers bottom-up (first sweep = upwelling from the surface,
+// which emits its Planck function); the fluxes at the interface are exchanged through LDS and each wave
+// sweeps back through its half in the other direction, forming the heating rate on the way
+// (heating_rate_single, heating_rate.h:55-72, with the reference's order of operations).  Half the
+// per-lane state of the one-wave version -> two waves per SIMD with half as long dependency chains.
 template <int NLAY, typename BgT, typename OdT>
-__global__ void __launch_bounds__(PREP_THREADS, 1)
-k_gas_prep_lw_fast(size_t n, int method, const int32_t* __restrict__ ireorder, const double* __restrict__ hk,
-                   const double* __restrict__ conv, const double* __restrict__ wn, const double* __restrict__ dwn,
-                   const BgT* __restrict__ bg_col /* [n][NLAY] sorted, or NULL */,
-                   const OdT* __restrict__ od_col /* [n][NLAY] sorted */,
-                   double* __restrict__ wn_sorted, double* __restrict__ dwn_sorted, double* __restrict__ planck_hl,
-                   double* __restrict__ bg_od, double* __restrict__ w1, double* __restrict__ hr,
-                   double* __restrict__ fds, double* __restrict__ fut) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const size_t j = (size_t)ireorder[i];
+__global__ void __launch_bounds__(PREP_THREADS, 2)
+k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder, const double* __restrict__ hk,
+                     const double* __restrict__ conv, const double* __restrict__ wn, const double* __restrict__ dwn,
+                     const BgT* __restrict__ bg_col /* [n][NLAY] sorted, or NULL */,
+                     const OdT* __restrict__ od_col /* [n][NLAY] sorted */,
+                     double* __restrict__ wn_sorted, double* __restrict__ dwn_sorted, double* __restrict__ planck_hl,
+                     double* __restrict__ bg_od, double* __restrict__ w1, double* __restrict__ hr,
+                     double* __restrict__ fds, double* __restrict__ fut) {
+  static_assert(NLAY % 2 == 0 && PREP_THREADS == 256, "two wave pairs per block, equal halves");
+  constexpr int H = NLAY / 2;
+  __shared__ double s_x[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = wave & 1, pair = wave >> 1;
+  const size_t i = (size_t)blockIdx.x * 128 + (size_t)pair * 64 + lane;
+  const bool live = i < n;
+  const size_t ii = live ? i : n - 1;
+  const size_t j = (size_t)ireorder[ii];
   const double w = wn[j], dw = dwn[j];
-  wn_sorted[i] = w;
-  dwn_sorted[i] = dw;
+  if (live && half == 0) { wn_sorted[i] = w; dwn_sorted[i] = dw; }
   const double inv_cm_2_Hz = 100.0 * kLightC;
   const double freq = w * inv_cm_2_Hz;
   const double pref = (dw * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq);
-  const BgT* bgc = bg_col ? bg_col + i * NLAY : nullptr;
-  const OdT* odc = od_col + i * NLAY;
-  double dd[NLAY], ee[NLAY], ss[NLAY];
-  double b_prev = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[0]) - 1.0);
-  planck_hl[i] = b_prev;
-  double dn = 0.0;
+  const BgT* bgc = bg_col ? bg_col + ii * NLAY : nullptr;
+  const OdT* odc = od_col + ii * NLAY;
+  auto planck = [&](int level) { return ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[level]) - 1.0); };
+  // local layer l is layer l (even wave) or NLAY-1-l (odd wave); its near level is where the first sweep enters
+  double ee[H], s2[H], f1[H + 1];
+  int lev_near = half ? NLAY : 0;
+  double b_near = planck(lev_near);
+  if (live) planck_hl[(size_t)lev_near * n + i] = b_near;
+  double flux = half ? b_near : 0.0;           // surface: emissivity 1 (radiative_transfer_lw.cpp:52-53)
+  f1[0] = flux;
 #pragma unroll
-  for (int l = 0; l < NLAY; ++l) {
-    const double bg = bgc ? (double)bgc[l] : 0.0;
-    const double od = (double)odc[l];
+  for (int l = 0; l < H; ++l) {
+    const int L = half ? NLAY - 1 - l : l;
+    const int lev_far = half ? L : L + 1;
+    const double bg = bgc ? (double)bgc[L] : 0.0;
+    const double od = (double)odc[L];
     const double tau = bg + od;
     const double eps = 1.0 - ecckd::exp_fast(-kD * tau);
     const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;
-    const double b_next = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[l + 1]) - 1.0);
+    const double b_far = planck(lev_far);
     const double emf = eps - fac;
-    const double dn_next = dn * (1.0 - eps) + b_prev * emf + b_next * fac;
-    dd[l] = dn_next - dn;
+    const double next = flux * (1.0 - eps) + b_near * emf + b_far * fac;
     ee[l] = eps;
-    ss[l] = b_next * emf + b_prev * fac;
-    const size_t o = (size_t)l * n + i;
-    bg_od[o] = bg;
-    planck_hl[(size_t)(l + 1) * n + i] = b_next;
+    s2[l] = b_far * emf + b_near * fac;
+    f1[l + 1] = next;
     double m;
     switch (method) {
       case ECCKD_AVG_TRANSMISSION: m = 1.0 - ecckd::exp_fast(-od * kD); break;
@@ -250,19 +263,31 @@ k_gas_prep_lw_fast(size_t n, int method, const int32_t* __restrict__ ireorder, c
       case ECCKD_AVG_SQUARE_ROOT: m = sqrt(od); break;
       default: m = od;
     }
-    w1[o] = m * b_next;
-    dn = dn_next;
-    b_prev = b_next;
+    if (live) {
+      const size_t o = (size_t)L * n + i;
+      bg_od[o] = bg;
+      planck_hl[(size_t)lev_far * n + i] = b_far;   // level NLAY/2 is written by both waves with the same bits
+      w1[o] = m * (half ? b_near : b_far);          // weight = Planck function at the base of the layer
+    }
+    flux = next;
+    b_near = b_far;
   }
-  fds[i] = dn;
-  double up = b_prev * 1.0 + (1.0 - 1.0) * dn;
+  s_x[wave][lane] = flux;
+  __syncthreads();
+  flux = s_x[wave ^ 1][lane];
 #pragma unroll
-  for (int l = NLAY - 1; l >= 0; --l) {
-    const double up_l = up * (1.0 - ee[l]) + ss[l];
-    hr[(size_t)l * n + i] = conv[l] * (dd[l] - up + up_l);
-    up = up_l;
+  for (int l = H - 1; l >= 0; --l) {
+    const int L = half ? NLAY - 1 - l : l;
+    const double next = flux * (1.0 - ee[l]) + s2[l];
+    // conv * (dn(L+1) - dn(L) - up(L+1) + up(L)), left to right
+    const double net = half ? (next - flux) - f1[l] + f1[l + 1]        // second sweep is downwelling: flux = dn(L), next = dn(L+1)
+                            : (f1[l + 1] - f1[l]) - flux + next;       // second sweep is upwelling:   flux = up(L+1), next = up(L)
+    if (live) hr[(size_t)L * n + i] = conv[L] * net;
+    flux = next;
   }
-  fut[i] = up;
+  if (live) {
+    if (half) fds[i] = flux; else fut[i] = flux;
+  }
 }
 
 // tile sums of every row: TS[r][t] = sum_{i in tile t} rows[r][i]
@@ -1181,8 +1206,8 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
     if (d_bg_od)
       hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
                          (const float*)d_bg_od, bg_col);
-    const unsigned fblocks = (unsigned)((nwav + PREP_THREADS - 1) / PREP_THREADS);
-    hipLaunchKernelGGL((k_gas_prep_lw_fast<54, float, float>), dim3(fblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav,
+    const unsigned fblocks = (unsigned)((nwav + 127) / 128);
+    hipLaunchKernelGGL((k_gas_prep_lw_mirror<54, float, float>), dim3(fblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav,
                        averaging_method, g->ireorder, hkd, convd, d_wavenumber, d_d_wavenumber, (const float*)bg_col,
                        (const float*)od_col, g->wn_sorted, g->dwn_sorted, g->planck_hl, g->bg_od, g->w1, g->hr, g->fds,
                        g->fut);
