@@ -152,6 +152,24 @@ SIGNATURES = {
     "ecckd_merge_spectrum_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, _c_double_p,
                                            C.c_int, C.c_void_p, C.c_size_t]),
     "ecckd_gmap_erythemal_spectrum": (C.c_int, [C.c_void_p, _c_double_p]),
+    "ecckd_nc_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ecckd_nc_close": (C.c_int, [C.c_void_p]),
+    "ecckd_nc_inq_dim": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t)]),
+    "ecckd_nc_inq_var": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_size_t), C.c_int]),
+    "ecckd_nc_read_double": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong, _c_double_p, C.c_size_t]),
+    "ecckd_nc_read_att_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "ecckd_nc_read_att_double": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), _c_double_p, C.c_size_t]),
+    "ecckd_nc_create": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ecckd_nc_def_dim": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "ecckd_nc_def_var": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ecckd_nc_put_att_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "ecckd_nc_put_att_double": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, _c_double_p]),
+    "ecckd_nc_enddef": (C.c_int, [C.c_void_p]),
+    "ecckd_nc_write_double": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p, C.c_size_t]),
+    "ecckd_write_order_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, _c_double_p, _c_double_p,
+                                         C.c_size_t, _c_double_p, _c_double_p, _c_int16_p, _c_int32_p, _c_double_p,
+                                         _c_double_p]),
     "ecckd_gather_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_invert_permutation_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }

@@ -302,6 +302,39 @@ int ecckd_gather_f64_dev(ecckd_ctx* ctx, size_t n, const double* d_src, const in
 /* d_inverse[d_perm[i]] = i (ireorder(irank) = range(0,n-1), find_g_points.cpp:778-779). */
 int ecckd_invert_permutation_dev(ecckd_ctx* ctx, size_t n, const int32_t* d_perm, int32_t* d_inverse);
 
+/* ---- NetCDF classic files (file parts of a1, a9, a21) ----------------------------
+ * A self-contained reader / writer for the classic on-disk formats CDF-1, CDF-2 (64-bit offset)
+ * and CDF-5 (64-bit data): what the reference reads / writes for *.nc, *.cdf names
+ * (src/tools/DataFile.cpp:88-96, OutputDataFile.cpp:84-157).  NetCDF-4 / HDF5 (*.h5) is NOT handled:
+ * no HDF5 library in the image.  Reads convert every external type to double like
+ * nc_get_vara_double (DataFileEngineNetcdf.cpp:593-599); slice >= 0 selects one index of the
+ * slowest dimension like DataFile::read(M, "v", j) (:582-590), slice < 0 the whole variable.
+ * var == NULL or "" addresses the global attributes.  nc_type: 1 byte, 2 char, 3 short, 4 int,
+ * 5 float, 6 double (7-11: CDF-5 unsigned / 64-bit integers). */
+typedef struct ecckd_nc ecckd_nc;
+int ecckd_nc_open(const char* path, ecckd_nc** file);
+int ecckd_nc_close(ecckd_nc* file);
+int ecckd_nc_inq_dim(ecckd_nc* file, const char* name, size_t* length);
+int ecckd_nc_inq_var(ecckd_nc* file, const char* name, int* exists, int* nc_type, int* ndims, size_t* shape,
+                     int shape_capacity);
+int ecckd_nc_read_double(ecckd_nc* file, const char* name, long long slice, double* out, size_t capacity);
+int ecckd_nc_read_att_text(ecckd_nc* file, const char* var, const char* att, int* exists, char* out, size_t capacity);
+int ecckd_nc_read_att_double(ecckd_nc* file, const char* var, const char* att, int* nelems, double* out, size_t capacity);
+/* writing: define, ecckd_nc_enddef (picks CDF-1 / CDF-2 / CDF-5 from the sizes), then whole variables */
+int ecckd_nc_create(const char* path, ecckd_nc** file);
+int ecckd_nc_def_dim(ecckd_nc* file, const char* name, size_t length, int* dimid);
+int ecckd_nc_def_var(ecckd_nc* file, const char* name, int nc_type, int ndims, const int* dimids, int* varid);
+int ecckd_nc_put_att_text(ecckd_nc* file, const char* var, const char* att, const char* text);
+int ecckd_nc_put_att_double(ecckd_nc* file, const char* var, const char* att, int nc_type, int n, const double* values);
+int ecckd_nc_enddef(ecckd_nc* file);
+int ecckd_nc_write_double(ecckd_nc* file, const char* name, const double* data, size_t count);
+/* write_order (write_order.cpp:24-143): same variables, external types and attributes; `history` is the
+ * line OutputDataFile::append_history would add (may be NULL); column_optical_depth may be NULL (:88). */
+int ecckd_write_order_file(const char* path, const char* molecule, const char* config_str, const char* history, int nband,
+                           const double* band_bound1, const double* band_bound2, size_t nwav, const double* wavenumber,
+                           const double* d_wavenumber, const int16_t* iband, const int32_t* rank,
+                           const double* column_optical_depth, const double* sorting_variable);
+
 /* ---- optimize_lut: cost function, gradient and minimisation (K8/K9) ------------
  * Replaces CkdOptimizable::calc_cost_function_gradient (solve_adept.cpp:240-292), i.e.
  * calc_cost_function_and_gradient (:72-211: CkdModel::calc_optical_depth ckd_model.cpp:925-1102,

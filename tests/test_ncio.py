@@ -1,0 +1,175 @@
+"""The NetCDF classic reader / writer (file parts of rows a1, a9, a21) against an independent implementation
+(scipy.io.netcdf_file) in both directions, and against the reference's own classic data file
+(data/mie_droplet_scattering.nc, committed as tests/golden/mie_droplet_scattering.nc)."""
+import os
+
+import numpy as np
+import pytest
+from scipy.io import netcdf_file
+
+from ecckd_amd import ncio, EcckdError
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "mie_droplet_scattering.nc")
+
+
+def test_reads_the_reference_data_file():
+    ref = netcdf_file(GOLDEN, "r", mmap=False)
+    with ncio.NcFile(GOLDEN) as f:
+        assert f.dim("effective_radius") == 50 and f.dim("wavenumber") == 396
+        for name, v in ref.variables.items():
+            t, shape = f.var_info(name)
+            assert shape == v.shape and t == 5                     # all FLOAT
+            assert np.array_equal(f.read(name), np.asarray(v.data, dtype=np.float64))
+            assert f.att_text("long_name", name) == v.long_name.decode()
+        assert np.array_equal(f.read("asymmetry_factor", 7), ref.variables["asymmetry_factor"].data[7].astype(np.float64))
+        assert f.att_text("title") == ref.title.decode()
+        assert f.att_text("units", "wavenumber") == "cm-1"
+        assert f.att_text("no_such_attribute") is None and not f.exist("no_such_variable")
+    ref.close()
+
+
+@pytest.mark.parametrize("version", [1, 2])
+def test_reads_what_scipy_writes_including_records(tmp_path, version):
+    rs = np.random.RandomState(version)
+    p = str(tmp_path / "s.nc")
+    w = netcdf_file(p, "w", version=version)
+    w.createDimension("time", None)
+    w.createDimension("x", 5)
+    w.createDimension("y", 3)
+    w.history = "made by scipy"
+    w.scale = np.array([1.5, -2.5])
+    data = {}
+    for name, tc, dims in (("a", "d", ("x", "y")), ("b", "f", ("x",)), ("c", "i", ("y",)), ("d", "h", ("x",)),
+                           ("e", "b", ("y",)), ("r1", "d", ("time", "x")), ("r2", "h", ("time",)), ("s", "f", ())):
+        v = w.createVariable(name, tc, dims)
+        shape = tuple(4 if d == "time" else {"x": 5, "y": 3}[d] for d in dims)
+        arr = (rs.uniform(-100, 100, shape)).astype(tc)
+        if shape == ():
+            v[...] = arr
+        else:
+            v[:] = arr
+        v.units = "unit_" + name
+        data[name] = np.asarray(arr, dtype=np.float64)
+    w.close()
+    # the independent READER is the oracle (scipy's writer pads short record variables inconsistently)
+    r = netcdf_file(p, "r", mmap=False)
+    data = {k: np.asarray(v.data if v.shape else v.getValue(), dtype=np.float64) for k, v in r.variables.items()}
+    r.close()
+    with ncio.NcFile(p) as f:
+        assert f.dim("time") == 4
+        for name, arr in data.items():
+            assert np.array_equal(f.read(name), arr), name
+            assert f.att_text("units", name) == "unit_" + name
+        assert np.array_equal(f.read("r1", 2), data["r1"][2]) and np.array_equal(f.read("a", 4), data["a"][4])
+        assert f.att_text("history") == "made by scipy"
+        assert np.array_equal(f.att_values("scale"), [1.5, -2.5])
+
+
+def test_scipy_reads_what_the_writer_writes(tmp_path):
+    rs = np.random.RandomState(3)
+    p = str(tmp_path / "w.nc")
+    w = ncio.NcWriter(p)
+    w.define_dimension("level", 4)
+    w.define_dimension("g_point", 6)
+    want = {}
+    for name, t, dims in (("od", "float", ("level", "g_point")), ("k", "double", ("level", "g_point")), ("n", "int", ("g_point",)),
+                          ("band", "short", ("g_point",)), ("flag", "byte", ("level",)), ("scalar", "double", ())):
+        w.define_variable(name, t, *dims)
+        w.write_attribute("long_name", "the " + name, var=name)
+        shape = tuple({"level": 4, "g_point": 6}[d] for d in dims)
+        want[name] = np.round(rs.uniform(-100, 100, shape), 0 if t in ("int", "short", "byte") else 6)
+    w.write_attribute("title", "writer test")
+    w.write_attribute("valid_range", [0.0, 1.0], var="od")
+    w.end_define_mode()
+    for name, arr in want.items():
+        w.write(name, arr)
+    w.close()
+    r = netcdf_file(p, "r", mmap=False)
+    assert r.version_byte == 1 and r.title == b"writer test"
+    assert r.variables["od"].typecode() == "f" and r.variables["band"].typecode() == "h" and r.variables["flag"].typecode() == "b"
+    for name, arr in want.items():
+        got = np.asarray(r.variables[name].data if arr.shape else r.variables[name].getValue(), dtype=np.float64)
+        expect = arr.astype(np.float32).astype(np.float64) if name == "od" else arr
+        assert np.array_equal(got, expect), name
+        assert r.variables[name].long_name == ("the " + name).encode()
+    assert np.array_equal(r.variables["od"].valid_range, [0.0, 1.0])
+    r.close()
+
+
+def test_write_order_file(tmp_path):
+    """write_order.cpp:24-143: names, external types, attributes; read back by scipy and by read_order."""
+    rs = np.random.RandomState(4)
+    n = 1000
+    wn = np.linspace(0.0, 3260.0, n)
+    rank = rs.permutation(n).astype(np.int32)
+    iband = np.where(wn < 1500.0, 0, 1).astype(np.int16)
+    iband[:3] = -1
+    key = rs.uniform(-0.5, 12.0, n)
+    col = rs.lognormal(0, 3, n)
+    p = str(tmp_path / "order.nc")
+    ncio.write_order(p, [0.0, 1500.0], [1500.0, 3260.0], wn, np.full(n, wn[1] - wn[0]), iband, rank, key, col,
+                     molecule="h2o", config_str="iprofile 0\n", history="today: reorder_spectrum x.cfg")
+    r = netcdf_file(p, "r", mmap=False)
+    assert r.dimensions == {"band": 2, "wavenumber": n}
+    types = {k: v.typecode() for k, v in r.variables.items()}
+    assert types == dict(wavenumber1_band="f", wavenumber2_band="f", wavenumber="d", d_wavenumber="f", band_number="h",
+                         rank="i", column_optical_depth="f", sorting_variable="f")
+    assert r.title == b"Optimal reordering of the absorption spectrum of H2O" and r.molecule == b"h2o"
+    assert r.config == b"iprofile 0\n" and r.history.startswith(b"today")
+    assert r.variables["rank"].long_name == b"Rank when reordered" and r.variables["wavenumber"].units == b"cm-1"
+    assert b"rank(i) provides the rank of wavenumber i." in r.variables["rank"].comment
+    assert np.array_equal(r.variables["rank"].data, rank) and np.array_equal(r.variables["band_number"].data, iband)
+    assert np.array_equal(r.variables["wavenumber"].data, wn)
+    assert np.array_equal(r.variables["sorting_variable"].data, key.astype(np.float32))
+    r.close()
+    o = ncio.read_order(p)
+    assert np.array_equal(o["rank"], rank) and np.array_equal(o["band_number"], iband) and o["molecule"] == "h2o"
+    assert np.array_equal(o["sorting_variable"], key.astype(np.float32).astype(np.float64))
+    # without column optical depth and molecule (:88, :115-118)
+    ncio.write_order(p, [0.0], [3260.0], wn, np.full(n, 1.0), iband, rank, key)
+    r = netcdf_file(p, "r", mmap=False)
+    assert "column_optical_depth" not in r.variables and r.title == b"Optimal reordering of the absorption spectrum of a gas"
+    r.close()
+
+
+def test_read_spectrum(tmp_path):
+    """read_spectrum.cpp:20-87 on a CKDMIP-shaped classic file written by scipy."""
+    rs = np.random.RandomState(5)
+    ncol, nlev, nwav = 3, 6, 400
+    p = str(tmp_path / "spectra.nc")
+    w = netcdf_file(p, "w", version=2)
+    for d, n in (("column", ncol), ("half_level", nlev + 1), ("level", nlev), ("wavenumber", nwav)):
+        w.createDimension(d, n)
+    arrs = dict(pressure_hl=("f", ("column", "half_level"), np.sort(rs.uniform(1, 1e5, (ncol, nlev + 1)), axis=1)),
+                temperature_hl=("f", ("column", "half_level"), rs.uniform(190, 300, (ncol, nlev + 1))),
+                wavenumber=("d", ("wavenumber",), np.cumsum(rs.uniform(1e-3, 2e-3, nwav))),
+                mole_fraction_fl=("f", ("column", "level"), rs.uniform(1e-6, 1e-2, (ncol, nlev))),
+                optical_depth=("f", ("column", "level", "wavenumber"), rs.lognormal(-2, 2, (ncol, nlev, nwav))))
+    for name, (tc, dims, a) in arrs.items():
+        w.createVariable(name, tc, dims)[:] = a.astype(tc)
+    w.createVariable("reference_surface_mole_fraction", "f", ())[...] = np.float32(4.15e-4)
+    w.constituent_id = "co2"
+    w.close()
+    s = ncio.read_spectrum(p, iprofile=1)
+    assert s["ncol"] == ncol and s["molecule"] == "co2"
+    assert s["reference_surface_vmr"] == float(np.float32(4.15e-4))
+    for name, key in (("pressure_hl", "pressure_hl"), ("temperature_hl", "temperature_hl"), ("mole_fraction_fl", "vmr_fl"),
+                      ("optical_depth", "optical_depth")):
+        assert np.array_equal(s[key], arrs[name][2].astype(arrs[name][0])[1].astype(np.float64)), name
+    wn = arrs["wavenumber"][2]
+    assert np.array_equal(s["wavenumber_cm_1"], wn)
+    assert np.array_equal(s["d_wavenumber_cm_1"][1:-1], 0.5 * (wn[2:] - wn[:-2]))          # :58-65
+    assert s["d_wavenumber_cm_1"][0] == 0.5 * s["d_wavenumber_cm_1"][1]
+
+
+def test_rejects_hdf5_and_bad_calls(tmp_path):
+    p = tmp_path / "x.h5"
+    p.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    with pytest.raises(EcckdError) as e:
+        ncio.NcFile(str(p))
+    assert e.value.code == 147
+    with pytest.raises(EcckdError):
+        ncio.NcFile(str(tmp_path / "missing.nc"))
+    with ncio.NcFile(GOLDEN) as f:
+        with pytest.raises(EcckdError):
+            f.read("wavenumber", 400)                            # slice outside the slowest dimension
