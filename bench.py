@@ -142,15 +142,21 @@ def lut_opt_bench(ctx, iterations):
 
 def main():
     args = parse()
-    os.environ.setdefault("OMP_NUM_THREADS", "1")  # the CPU baseline is a single-thread port
+    # host threads for the CPU baseline: the GPU box gives 16 cores per GPU; more OpenMP threads than that only spin
+    ncores = min(16, len(os.sched_getaffinity(0)))
+    os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("ECCKD_BENCH_FORCE_DIST") == "1"   # the override exercises the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from ecckd_amd import api, synthetic as syn
@@ -183,7 +189,7 @@ def main():
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -251,14 +257,20 @@ def main():
         if world == 1 and not args.no_cpu:
             pts, cdt, cng, ccost, search = cpu_baseline(args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance,
                                                         args.tolerance_tolerance, args.max_iterations)
-            out["cpu_baseline"] = {"value": pts / cdt, "unit": "wavenumber-points/s", "cores": os.cpu_count(), "kind": "port",
+            out["cpu_baseline"] = {"value": pts / cdt, "unit": "wavenumber-points/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
                                    "sample": "oracle reorder + gas prep + %s over oracle calc_error, nwav=%d "
                                              "(same generator, ng=%d, N_pass=%.1f, %.1f s)"
                                              % (search, args.cpu_sample, cng, ccost, cdt)}
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
     ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    # RCCL leaves a version banner in the C stdio buffer of stdout; push it out first so that the JSON line
+    # is the LAST line of stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
