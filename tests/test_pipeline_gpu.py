@@ -1,0 +1,145 @@
+"""End-to-end slice of do_all_lw.sh on a small synthetic case, every hand-over going through the ABI:
+
+  spectra files (NetCDF classic) -> read_spectrum -> reorder_spectrum -> write_order / read_order
+  -> per gas: merged background, gas preparation, band search (2 bands), median sorting variable
+  -> overlap_g_points -> merged g-point map -> g-point averaging of each gas + Planck look-up table.
+
+The same chain is run with the CPU oracle (and the reference-built partition search); the index results
+(ranks, g-point boundaries, merged g-point map) must be identical, the averaged coefficients agree to 1e-9.
+"""
+import numpy as np
+import pytest
+import torch
+from scipy.io import netcdf_file
+
+from ecckd_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+NLAY, NWAV = 30, 12000
+BANDS = (np.array([0.0, 1300.0]), np.array([1300.0, 3260.0]))
+TOL, TOLTOL, MAXIT = 0.08, 0.02, 40
+
+
+def _write_spectrum(path, gas, p, t, wn, od, vmr):
+    w = netcdf_file(str(path), "w", version=2)
+    for d, n in (("column", 1), ("half_level", NLAY + 1), ("level", NLAY), ("wavenumber", wn.size)):
+        w.createDimension(d, n)
+    w.createVariable("pressure_hl", "d", ("column", "half_level"))[:] = p[None]
+    w.createVariable("temperature_hl", "d", ("column", "half_level"))[:] = t[None]
+    w.createVariable("wavenumber", "d", ("wavenumber",))[:] = wn
+    w.createVariable("mole_fraction_fl", "d", ("column", "level"))[:] = np.full((1, NLAY), vmr)
+    w.createVariable("optical_depth", "f", ("column", "level", "wavenumber"))[:] = od[None]
+    w.createVariable("reference_surface_mole_fraction", "d", ())[...] = vmr
+    w.constituent_id = gas
+    w.close()
+
+
+def test_files_to_gpoints(ctx, oracle, tmp_path):
+    from ecckd_amd import api, ncio
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=ctx.device)
+    p = syn.pressure_grid(NLAY)
+    t_hl = syn.temperature_profile(p)
+    wn, _ = syn.wavenumber_grid(NWAV)
+    gases = {"h2o": (41, 30.0, 5e-3), "co2": (43, 8.0, 4e-4)}
+    for g, (seed, scale, vmr) in gases.items():
+        od = syn.optical_depth(np, p, wn, syn.SEED_BASE + seed, nlines=40, column_scale=scale, dtype="float32")
+        _write_spectrum(tmp_path / f"{g}.nc", g, p, t_hl, wn, od, vmr)
+
+    # ---- reorder_spectrum for each gas, through the order file ----
+    spec, order = {}, {}
+    for g in gases:
+        s = ncio.read_spectrum(tmp_path / f"{g}.nc", 0)
+        assert s["molecule"] == g
+        dwn = s["d_wavenumber_cm_1"]                      # derived: the files carry no d_wavenumber
+        od32 = s["optical_depth"].astype(np.float32)
+        key, col, iband, rank = api.reorder_spectrum(ctx, s["pressure_hl"], wn, dwn, od32, None, 0.5, BANDS[0], BANDS[1])
+        ncio.write_order(tmp_path / f"order_{g}.nc", BANDS[0], BANDS[1], wn, dwn, iband, rank, key, col, molecule=g)
+        order[g] = ncio.read_order(tmp_path / f"order_{g}.nc")
+        assert np.array_equal(order[g]["rank"], rank)
+        # oracle side of the same step
+        okey, ocol, _ = oracle.reorder_key(p, oracle.idealised_temperature(p), wn, dwn, s["optical_depth"], None, 0.5)
+        _, _, orank = oracle.stable_argsort_bands(wn, key, BANDS[0], BANDS[1])    # same keys -> same stable order
+        assert np.allclose(key, okey, rtol=1e-9, atol=1e-12) and np.array_equal(rank, orank)
+        spec[g] = dict(s, od32=od32, dwn=dwn, key=key, rank=rank.astype(np.int64), iband=iband)
+
+    nband = 2
+    ib = spec["h2o"]["iband"]
+    band_rng = [(int(np.nonzero(ib == b)[0][0]), int(np.nonzero(ib == b)[0][-1])) for b in range(nband)]
+
+    # ---- find_g_points per gas (background = the other gas) ----
+    n_g_points, medians, gas_gp, ref_gas_gp = [], [], [], []
+    for g, other in (("h2o", "co2"), ("co2", "h2o")):
+        s, bg32 = spec[g], spec[other]["od32"]
+        d_rank = dev(s["rank"].astype(np.int32))
+        gas = api.GasLW(ctx, p, t_hl, dev(wn), dev(s["dwn"]), d_rank, dev(s["od32"]), dev(bg32), "transmission", 0.02, 0.0)
+        # oracle: the same preparation on the CPU (find_g_points.cpp:891-1150)
+        ireorder = np.empty(NWAV, dtype=np.int64)
+        ireorder[s["rank"]] = np.arange(NWAV)
+        od_s, bg_s = s["od32"].astype(np.float64)[:, ireorder], bg32.astype(np.float64)[:, ireorder]
+        planck = oracle.planck_function(t_hl, wn[ireorder], s["dwn"][ireorder])
+        fdn, fup = oracle.radiative_transfer_lw(planck, bg_s + od_s, np.ones(NWAV), planck[-1])
+        hr = oracle.heating_rate(p, fdn, fup)
+        key_s = s["key"][ireorder]
+        sv_sorted = api.gather_f64(ctx, dev(s["key"]), api.invert_permutation(ctx, d_rank))
+        r1_all, r2_all, med_all, ngp = [], [], [], []
+        o_r1, o_r2, o_med = [], [], []
+        for b, (i0, i1) in enumerate(band_rng):
+            res = gas.find_g_band_ex(i0, i1, TOL, TOLTOL, MAXIT)
+            r1_all += list(res["rank1"]); r2_all += list(res["rank2"]); ngp.append(len(res["error"]))
+            med_all += list(gas.median_sorting_variable(sv_sorted, res["rank1"], res["rank2"]))
+            sl = slice(i0, i1 + 1)
+            eq = oracle.CkdEquipartitionLW("transmission", 0.02, oracle.layer_weight(p, 0.0), p, np.ones(i1 - i0 + 1),
+                                           planck[-1][sl], fdn[-1][sl].copy(), fup[0][sl].copy(), planck[:, sl], bg_s[:, sl],
+                                           oracle.metric("transmission", od_s[:, sl]), hr[:, sl])
+            ref = oracle.RefEquipartition(eq.calc_error, resolution=1.0 / (i1 - i0 + 1), partition_tolerance=TOLTOL,
+                                          partition_max_iterations=MAXIT)
+            st, bnd, err = ref.equipartition_e(TOL)
+            npts = i1 - i0 + 1
+            for k in range(len(err)):
+                a, c = int(np.ceil(bnd[k] * (npts - 1))) + i0, int(np.floor(bnd[k + 1] * (npts - 1))) + i0
+                o_r1.append(a); o_r2.append(c)
+                o_med.append(oracle.median_sorting_variable(key_s, planck[-1], a, c))
+        assert r1_all == o_r1 and r2_all == o_r2, g
+        assert np.array_equal(med_all, o_med), g
+        n_g_points.append(ngp)
+        medians.append(np.array(med_all))
+        gas_gp.append(api.gas_g_point(ctx, d_rank, r1_all, r2_all))
+        ref_gp = np.full(NWAV, -1, dtype=np.int64)          # SingleGasData::store_g_points (single_gas_data.h:56-62)
+        for k, (a, c) in enumerate(zip(o_r1, o_r2)):
+            ref_gp[(s["rank"] >= a) & (s["rank"] <= c)] = k
+        ref_gas_gp.append(ref_gp)
+        assert np.array_equal(gas_gp[-1].cpu().numpy(), ref_gp)
+        gas.close()
+
+    # ---- overlap of the gases' g points and the merged map (find_g_points.cpp:1443-1475) ----
+    ng, band_number, g_min, g_max = api.overlap_g_points(n_g_points, medians)
+    ong, oband, omin, omax = oracle.overlap_g_points(n_g_points, medians)
+    assert ng == ong and np.array_equal(band_number, oband) and np.array_equal(g_min, omin) and np.array_equal(g_max, omax)
+    g_point, n_unassigned = api.merge_g_points(ctx, gas_gp, g_min, g_max)
+    ref_map = np.full(NWAV, -1, dtype=np.int64)
+    for ig in range(ng):
+        found = np.ones(NWAV, dtype=bool)
+        for k in range(2):
+            found &= (ref_gas_gp[k] >= g_min[k, ig]) & (ref_gas_gp[k] <= g_max[k, ig])
+        ref_map[found] = ig
+    assert np.array_equal(g_point.cpu().numpy(), ref_map) and n_unassigned == int((ref_map < 0).sum())
+    assert ng >= 4 and n_unassigned == 0
+
+    # ---- create_look_up_table pieces on the merged map: averaging of each gas + Planck look-up table ----
+    dwn = spec["h2o"]["dwn"]
+    gmap = api.GPointMap(ctx, g_point, ng, dev(wn), dev(dwn))
+    t_fl = 0.5 * (t_hl[1:] + t_hl[:-1])
+    for g, (_, _, vmr) in gases.items():
+        k_abs, k_min, k_max = gmap.average_optical_depth(p, dev(spec[g]["od32"]), "transmission", temperature_fl=t_fl,
+                                                         reference_surface_vmr=vmr)
+        planck_fl = oracle.planck_function(t_fl, wn, dwn)
+        ok, omn, omx, n_empty = oracle.average_optical_depth_to_g_point(ng, vmr, p, ref_map, spec[g]["od32"].astype(np.float64),
+                                                                       planck_fl, "transmission")
+        assert n_empty == 0
+        assert np.allclose(k_abs, ok, rtol=1e-9, atol=1e-300) and np.allclose(k_min, omn, rtol=1e-12) and np.allclose(k_max, omx, rtol=1e-12)
+    t_lut = np.arange(120.0, 351.0, 1.0)
+    got = gmap.planck_lut(t_lut)
+    want = oracle.planck_lut(ng, t_lut, ref_map, wn, dwn)
+    assert np.allclose(got, want, rtol=1e-11)
+    gmap.close()
