@@ -205,7 +205,8 @@ class OptScene(C.Structure):
                 ("surf_emissivity", _c_double_p), ("flux_dn", _c_double_p), ("flux_up", _c_double_p),
                 ("spectral_flux_dn_surf", _c_double_p), ("spectral_flux_up_toa", _c_double_p),
                 ("mu0", _c_double_p), ("tsi", C.c_double), ("albedo", _c_double_p),
-                ("spectral_boundary_weights", _c_double_p), ("temperature_fl", _c_double_p)]
+                ("spectral_boundary_weights", _c_double_p), ("temperature_fl", _c_double_p),
+                ("relative_flux_dn", _c_double_p), ("relative_flux_up", _c_double_p)]
 
 
 class OptConfig(C.Structure):

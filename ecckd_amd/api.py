@@ -592,7 +592,8 @@ def _opt_scene(sc, s, keep):
         sc.nband = fd.shape[2]
         sc.flux_dn = ptr(fd)
         sc.flux_up = ptr(f64(s["flux_up"]))
-    for k in ("spectral_flux_dn_surf", "spectral_flux_up_toa", "mu0", "albedo", "spectral_boundary_weights"):
+    for k in ("spectral_flux_dn_surf", "spectral_flux_up_toa", "mu0", "albedo", "spectral_boundary_weights",
+              "relative_flux_dn", "relative_flux_up"):
         setattr(sc, k, ptr(f64(s[k])) if s.get(k) is not None else None)
     sc.tsi = float(s.get("tsi", 0.0))
 

@@ -94,6 +94,7 @@ __global__ void k_opt_forward_adjoint(
     int do_sw, const double* __restrict__ mu0 /*[ncol], SW*/,
     int ray_ent /* run_ckd mode: entry of the Rayleigh term, added AFTER the clamp; else -1 */,
     int keep_negative /* scale_lut mode: the optical depth is reported without the clamp at zero */,
+    const double* __restrict__ rel_flux /* [ncol][2][nhl][ng] CKD fluxes of the relative-to scene, or NULL (solve_adept.cpp:118-125) */,
     int nlay, int ng, int ngpad, int nband, int nent,
     const double* __restrict__ k,            // [nk] coefficients of every gas
     const int* __restrict__ ent_idx,         // [ncell][nent] start of an ng-long row of k, or -1
@@ -237,10 +238,12 @@ __global__ void k_opt_forward_adjoint(
   for (int t = threadIdx.x; t < nhl * nband; t += blockDim.x) {
     const int i = t / nband, b = t % nband;
     double sd = 0.0, su = 0.0;
+    const double* rel = rel_flux ? rel_flux + (size_t)col * 2 * nhl * ng : nullptr;
     for (int gg = 0; gg < ng; ++gg) {
       if (band_of_g[gg] == b) {
-        sd += s_fdn[i * ng + gg];
-        su += s_fup[i * ng + gg];
+        // the relative-to fluxes are subtracted per g point before the band sums (calc_cost_function_lw.cpp:162-165)
+        sd += rel ? s_fdn[i * ng + gg] - rel[i * ng + gg] : s_fdn[i * ng + gg];
+        su += rel ? s_fup[i * ng + gg] - rel[(nhl + i) * ng + gg] : s_fup[i * ng + gg];
       }
     }
     s_bdn[t] = sd;
@@ -328,7 +331,8 @@ __global__ void k_opt_forward_adjoint(
     if (sfds && sfut) {
       // calc_cost_function_sw.cpp:271-274: per-g weights (erythemal) on the surface direct flux
       const double wgt = sfut[(size_t)col * ng + g];
-      const double a = s_fdn[nlay * ng + g] - sfds[(size_t)col * ng + g];
+      const double reld = rel_flux ? rel_flux[((size_t)col * 2 * nhl + nlay) * ng + g] : 0.0;
+      const double a = (s_fdn[nlay * ng + g] - reld) - sfds[(size_t)col * ng + g];
       jpart += wgt * a * a;
       g_dn_surf_extra = 2.0 * wgt * a;
     }
@@ -354,8 +358,10 @@ __global__ void k_opt_forward_adjoint(
     double g_dn_surf_extra = 0.0, g_up_toa_extra = 0.0;
     if (spectral_boundary_weight > 0.0 && sfds && sfut) {
       // :223-229 on the un-banded fluxes
-      const double a = s_fdn[nlay * ng + g] - sfds[(size_t)col * ng + g];
-      const double c = s_fup[g] - sfut[(size_t)col * ng + g];
+      const double reld = rel_flux ? rel_flux[((size_t)col * 2 * nhl + nlay) * ng + g] : 0.0;
+      const double relu = rel_flux ? rel_flux[((size_t)col * 2 * nhl + nhl) * ng + g] : 0.0;
+      const double a = (s_fdn[nlay * ng + g] - reld) - sfds[(size_t)col * ng + g];
+      const double c = (s_fup[g] - relu) - sfut[(size_t)col * ng + g];
       jpart += spectral_boundary_weight * (a * a + c * c);
       g_dn_surf_extra = 2.0 * spectral_boundary_weight * a;
       g_up_toa_extra = 2.0 * spectral_boundary_weight * c;
@@ -663,6 +669,7 @@ struct ecckd_opt {
   bool do_sw = false;
   int eval_ray_ent = -1;   // >= 0 only inside ecckd_run_ckd
   int eval_keep_negative = 0;
+  double* d_rel = nullptr;   // relative-to CKD fluxes [ncol][2][nhl][ng]
   int ray_ent = -1;        // entry index of the Rayleigh pseudo gas
   double* d_mu0 = nullptr;
   // host copies
@@ -704,7 +711,7 @@ void opt_free(ecckd_opt* o) {
                   o->d_band, o->d_planck, o->d_semis, o->d_conv, o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds,
                   o->d_sfut, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_node_gas, o->d_node_ic, o->d_node_it,
                   o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2, o->d_od_out, o->d_flux_out, o->d_xmin, o->d_xmax,
-                  o->d_xn, o->d_gn, o->d_dir, o->d_q, o->d_S, o->d_Y, o->d_part, o->d_sc, o->d_mu0};
+                  o->d_xn, o->d_gn, o->d_dir, o->d_q, o->d_S, o->d_Y, o->d_part, o->d_sc, o->d_mu0, o->d_rel};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete o;
@@ -1073,6 +1080,24 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
   UP(d_hr, hr); UP(d_fdn, fdn); UP(d_fup, fup);
   if (any_boundary) { UP(d_sfds, sfds); UP(d_sfut, sfut); }
   if (do_sw) UP(d_mu0, mu0v);
+  {
+    bool any_rel = false;
+    for (int s2 = 0; s2 < nscene; ++s2) any_rel = any_rel || (scenes[s2].relative_flux_dn && scenes[s2].relative_flux_up);
+    if (any_rel) {
+      std::vector<double> rel(ncol * 2 * nhl * ng, 0.0);
+      size_t c0 = 0;
+      for (int s2 = 0; s2 < nscene; ++s2) {
+        const ecckd_opt_scene& sc = scenes[s2];
+        if (sc.relative_flux_dn && sc.relative_flux_up)
+          for (size_t c = 0; c < (size_t)sc.ncol; ++c) {
+            std::memcpy(&rel[((c0 + c) * 2) * nhl * ng], sc.relative_flux_dn + c * nhl * ng, nhl * ng * sizeof(double));
+            std::memcpy(&rel[((c0 + c) * 2 + 1) * nhl * ng], sc.relative_flux_up + c * nhl * ng, nhl * ng * sizeof(double));
+          }
+        c0 += sc.ncol;
+      }
+      UP(d_rel, rel);
+    }
+  }
   UP(d_ref_ptr, ref_ptr); UP(d_ref_cell, ref_cell); UP(d_ref_coef, ref_coef);
   UP(d_node_gas, node_gas); UP(d_node_ic, node_ic); UP(d_node_it, node_it); UP(d_node_ip, node_ip);
   UP(d_gas_dims, gas_dims); UP(d_tri, tri); UP(d_tri_off, tri_off); UP(d_inv_sigma2, inv_sigma2);
@@ -1138,7 +1163,7 @@ static int opt_launch_forward(ecckd_opt* o) {
   ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_opt_forward_adjoint),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL(k_opt_forward_adjoint, dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream, o->do_sw ? 1 : 0,
-                     o->d_mu0, o->eval_ray_ent, o->eval_keep_negative, nlay, ng, ngpad, nband, o->nent, o->d_k, o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_planck, o->d_semis, o->d_conv,
+                     o->d_mu0, o->eval_ray_ent, o->eval_keep_negative, o->d_rel, nlay, ng, ngpad, nband, o->nent, o->d_k, o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_planck, o->d_semis, o->d_conv,
                      o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds, o->d_sfut, o->cfg.flux_weight,
                      o->cfg.flux_profile_weight, o->cfg.broadband_weight, o->cfg.spectral_boundary_weight,
                      o->cfg.negative_od_penalty, o->d_dtau, o->d_jcol, o->d_od_out, o->d_flux_out);
@@ -1396,6 +1421,8 @@ static int run_ckd_impl(ecckd_ctx* ctx, const ecckd_opt_model* m, const ecckd_op
   sc.spectral_flux_dn_surf = nullptr;
   sc.spectral_flux_up_toa = nullptr;
   sc.spectral_boundary_weights = nullptr;
+  sc.relative_flux_dn = nullptr;
+  sc.relative_flux_up = nullptr;
   if (do_sw) sc.albedo = albedo0.data();  // direct beam only
   ecckd_opt_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));

@@ -390,6 +390,12 @@ typedef struct {
   /* optional [ncol][nlay] full-level temperature; NULL = pressure-weighted mean of temperature_hl
    * (solve_adept.cpp:38-41, run_ckd.cpp:120-122).  scale_lut uses the plain mean (scale_lut.cpp:108). */
   const double* temperature_fl;
+  /* optional [ncol][nlay+1][ng]: CKD fluxes of the "relative_to" scene at the initial coefficients
+   * (optimize_lut.cpp:204-236, obtained with ecckd_opt_forward on that scene), subtracted from the forward
+   * model per g point (solve_adept.cpp:118-148, calc_cost_function_lw.cpp:162-165); the caller subtracts the
+   * relative-to LBL fluxes from flux_dn / flux_up itself (LblFluxes::subtract, optimize_lut.cpp:251-254) */
+  const double* relative_flux_dn;
+  const double* relative_flux_up;
 } ecckd_opt_scene;
 
 typedef struct {

@@ -224,6 +224,7 @@ double orc_calc_cost_function_ckd_sw(int nlay, int ng, int nband, double cos_sza
                                      const double* spectral_flux_dn_surf, double flux_weight,
                                      double flux_profile_weight, double broadband_weight,
                                      const double* spectral_boundary_weights, const double* layer_weight,
+                                     const double* relative_ckd_flux_dn, const double* relative_ckd_flux_up,
                                      const int* band_mapping) {
   static const double hr_weight = 3600.0 * 24.0;
   const int nhl = nlay + 1;
@@ -241,6 +242,12 @@ double orc_calc_cost_function_ckd_sw(int nlay, int ng, int nband, double cos_sza
     for (int g = 0; g < ng; ++g) alb_g[g] = albedo[band_mapping[g]];
     orc_radiative_transfer_norayleigh_sw(nlay, (size_t)ng, cos_sza, ssi, optical_depth, alb_g, fdn_orig, fup_orig);
     free(alb_g);
+  }
+  if (relative_ckd_flux_dn) { /* calc_cost_function_sw.cpp:160-163 */
+    for (size_t q = 0; q < (size_t)nhl * ng; ++q) {
+      fdn_orig[q] -= relative_ckd_flux_dn[q];
+      fup_orig[q] -= relative_ckd_flux_up[q];
+    }
   }
   double* fdn = (double*)calloc((size_t)nhl * nband, sizeof(double));
   double* fup = (double*)calloc((size_t)nhl * nband, sizeof(double));

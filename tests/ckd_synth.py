@@ -123,7 +123,9 @@ class Oracle:
                     P(np.ascontiguousarray(hr)), P(np.ascontiguousarray(sfd[c])) if sfd is not None else None,
                     P(np.ascontiguousarray(sfu[c])) if sfu is not None else None, C.c_double(cfg["flux_weight"]),
                     C.c_double(cfg["flux_profile_weight"]), C.c_double(cfg["broadband_weight"]),
-                    C.c_double(cfg["spectral_boundary_weight"]), P(lw), None, None,
+                    C.c_double(cfg["spectral_boundary_weight"]), P(lw),
+                    P(np.ascontiguousarray(scene["relative_flux_dn"][c])) if scene.get("relative_flux_dn") is not None else None,
+                    P(np.ascontiguousarray(scene["relative_flux_up"][c])) if scene.get("relative_flux_up") is not None else None,
                     ib.ctypes.data_as(C.POINTER(C.c_int)))
         return J
 
@@ -261,5 +263,8 @@ class OracleSW(Oracle):
                     P(ssi), P(np.ascontiguousarray(scene["albedo"])), P(np.ascontiguousarray(od[c])), P(fd), P(fu), P(hr),
                     P(np.ascontiguousarray(sfd[c])) if use_b else None, C.c_double(cfg["flux_weight"]),
                     C.c_double(cfg["flux_profile_weight"]), C.c_double(cfg["broadband_weight"]),
-                    P(np.ascontiguousarray(sbw)) if use_b else None, P(lw), ib.ctypes.data_as(C.POINTER(C.c_int)))
+                    P(np.ascontiguousarray(sbw)) if use_b else None, P(lw),
+                    P(np.ascontiguousarray(scene["relative_flux_dn"][c])) if scene.get("relative_flux_dn") is not None else None,
+                    P(np.ascontiguousarray(scene["relative_flux_up"][c])) if scene.get("relative_flux_up") is not None else None,
+                    ib.ctypes.data_as(C.POINTER(C.c_int)))
         return J

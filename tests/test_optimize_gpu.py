@@ -260,3 +260,49 @@ def test_sw_minimize_reduces_cost(ctx, oracle):
     assert res["cost"] < 0.5 * J0
     assert orc.cost_rt(res["x"]) + orc.cost_prior(res["x"], cfg["prior_error"])[0] == pytest.approx(res["cost"], rel=1e-9)
     opt.close()
+
+
+# ---- relative_to fluxes (optimize_lut.cpp:204-254, solve_adept.cpp:118-148) -----------------------------------
+
+@pytest.mark.parametrize("sw", [False, True])
+def test_relative_to_fluxes(ctx, oracle, sw):
+    """Training on the difference to a reference scene: the CKD fluxes of the relative-to scene at the initial
+    coefficients are subtracted from the forward model per g point, the LBL fluxes from the truth."""
+    model, scenes, cfg, orc = (_problem_sw if sw else _problem)(oracle, seed=9, boundary=True,
+                                                                **({} if sw else dict(spectral_boundary_weight=0.3)))
+    Orc = ckd_synth.OracleSW if sw else ckd_synth.Oracle
+    base, pert = scenes[0], scenes[1]
+    pert = dict(pert, pressure_hl=base["pressure_hl"], temperature_hl=base["temperature_hl"])   # same profiles, other gases
+    ref_opt = _opt(ctx, model, [dict(base)], cfg)
+    _, fl = ref_opt.forward(ref_opt.initial_state())            # CKD fluxes of the relative-to scene, (ncol, 2, nhl, ng)
+    ref_opt.close()
+    fl_ref = Orc(oracle, model, [base], cfg).fluxes(orc.x0, base)
+    assert np.allclose(fl, fl_ref, rtol=1e-10, atol=1e-300)
+    truth = Orc(oracle, model, [pert], cfg)
+    bf = truth.band_fluxes(truth.x0 + 0.1, pert) - truth.band_fluxes(truth.x0 + 0.1, base)       # "LBL" difference
+    train = dict(pert, flux_dn=np.ascontiguousarray(bf[:, 0]), flux_up=np.ascontiguousarray(bf[:, 1]),
+                 relative_flux_dn=np.ascontiguousarray(fl[:, 0]), relative_flux_up=np.ascontiguousarray(fl[:, 1]))
+    if "spectral_flux_dn_surf" in train:
+        f_p, f_b = truth.fluxes(truth.x0 + 0.1, pert), truth.fluxes(truth.x0 + 0.1, base)
+        train["spectral_flux_dn_surf"] = np.ascontiguousarray(f_p[:, 0, -1] - f_b[:, 0, -1])
+        if not sw:
+            train["spectral_flux_up_toa"] = np.ascontiguousarray(f_p[:, 1, 0] - f_b[:, 1, 0])
+    o2 = Orc(oracle, model, [train], cfg)
+    opt = _opt(ctx, model, [train], cfg)
+    rs = np.random.RandomState(2)
+    x0 = opt.initial_state()
+    free = x0 > -1.0e20
+    x = x0 + np.where(free, 0.15 * rs.normal(size=x0.size), 0.0)
+    J, g = opt.cost_grad(x)
+    assert J == pytest.approx(o2.cost_rt(x) + o2.cost_prior(x, cfg["prior_error"])[0], rel=1e-10)
+    # and it differs from the cost without the subtraction
+    plain = dict(train, relative_flux_dn=None, relative_flux_up=None)
+    assert abs(Orc(oracle, model, [plain], cfg).cost_rt(x) - o2.cost_rt(x)) > 1e-6 * abs(J)
+    for trial in range(2):
+        d = np.where(free, rs.normal(size=x.size), 0.0)
+        d /= np.linalg.norm(d)
+        h = 1e-5
+        fd = (o2.cost_rt(x + h * d) + o2.cost_prior(x + h * d, cfg["prior_error"])[0]
+              - o2.cost_rt(x - h * d) - o2.cost_prior(x - h * d, cfg["prior_error"])[0]) / (2 * h)
+        assert np.dot(g, d) == pytest.approx(fd, rel=2e-6, abs=1e-9 * abs(J))
+    opt.close()
