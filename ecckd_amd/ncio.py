@@ -175,3 +175,153 @@ def read_order(path):
                     sorting_variable=f.read("sorting_variable"), wavenumber=f.read("wavenumber"),
                     wavenumber1_band=f.read("wavenumber1_band"), wavenumber2_band=f.read("wavenumber2_band"),
                     molecule=f.att_text("molecule"))
+
+
+# ---- CKD definition files (CkdModel::read ckd_model.cpp:32-286, CkdModel::write :290-641) ----------------------
+
+K_NAME = "molar_absorption_coeff"          # constants.h:21
+CONC_CODE = {"none": 0, "linear": 1, "lut": 2, "relative-linear": 3}
+CONC_NAME = {v: k for k, v in CONC_CODE.items()}
+
+
+def write_ckd_model(path, model, model_id="", history="", config="", summary=""):
+    """CkdModel::write: the CKD definition file create_look_up_table and optimize_lut produce (classic format).
+
+    model: the dict api.Optimizer / api.run_ckd take (gases need a "name"), plus wavenumber1, wavenumber2,
+    gpoint_fraction[ng, nwav], wavenumber1_band, wavenumber2_band."""
+    w = NcWriter(path)
+    temp = np.asarray(model["temperature"], dtype=np.float64)
+    nt, npres = temp.shape
+    gf = np.asarray(model["gpoint_fraction"], dtype=np.float64)
+    ng, nwav = gf.shape
+    is_sw = model.get("solar_irradiance") is not None
+    w.define_dimension("temperature", nt)
+    w.define_dimension("pressure", npres)
+    w.define_dimension("g_point", ng)
+    if not is_sw:
+        w.define_dimension("temperature_planck", len(model["temperature_planck"]))
+    w.define_dimension("wavenumber", nwav)
+    w.define_dimension("band", len(model["wavenumber1_band"]))
+
+    def var(name, t, dims, long_name, units=None, comment=None):
+        w.define_variable(name, t, *dims)
+        w.write_attribute("long_name", long_name, var=name)
+        if units:
+            w.write_attribute("units", units, var=name)
+        if comment:
+            w.write_attribute("comment", comment, var=name)
+
+    var("n_gases", "int", (), "Number of gases treated", comment='The gases are listed in the global attribute "constituent_id".')
+    var("temperature", "float", ("temperature", "pressure"), "Temperature", "K")
+    var("pressure", "float", ("pressure",), "Pressure", "Pa")
+    if is_sw:
+        var("solar_irradiance", "float", ("g_point",), "Solar irradiance across each g point", "W m-2")
+    else:
+        var("temperature_planck", "float", ("temperature_planck",), "Temperature for Planck function look-up table", "K")
+        var("planck_function", "float", ("temperature_planck", "g_point"), "Planck function look-up table", "W m-2")
+    var("wavenumber1", "float", ("wavenumber",), "Lower wavenumber bound of spectral interval", "cm-1")
+    var("wavenumber2", "float", ("wavenumber",), "Upper wavenumber bound of spectral interval", "cm-1")
+    var("gpoint_fraction", "float", ("g_point", "wavenumber"), "Fraction of spectrum contributing to each g-point")
+    var("wavenumber1_band", "float", ("band",), "Lower wavenumber bound of band", "cm-1")
+    var("wavenumber2_band", "float", ("band",), "Upper wavenumber bound of band", "cm-1")
+    var("band_number", "short", ("g_point",), "Band number of each g point")
+    if is_sw and model.get("rayleigh_molar_scattering") is not None:
+        var("rayleigh_molar_scattering_coeff", "float", ("g_point",), "Rayleigh molar scattering coefficient in each g-point",
+            "m2 mol-1")
+    if model_id:
+        w.write_attribute("model_id", model_id)
+    names = [g["name"] for g in model["gases"]]
+    w.write_attribute("constituent_id", " ".join(names))
+    for g in model["gases"]:
+        mol, Mol = g["name"], g["name"].upper()
+        code = mol + "_conc_dependence_code"
+        var(code, "short", (), Mol + " concentration dependence code")
+        w.write_attribute("definition", "0: No dependence of absorption on concentration (background gases)\n"
+                          "1: Absorption varies linearly with concentration\n"
+                          "2: Look-up table for concentration-dependence of absorption\n"
+                          "3: Linear dependence on concentration minus a reference value", var=code)
+        k = mol + "_" + K_NAME
+        dims = ("temperature", "pressure", "g_point")
+        if g["conc"] == "lut":
+            w.define_dimension(mol + "_mole_fraction", len(g["vmr"]))
+            var(mol + "_mole_fraction", "float", (mol + "_mole_fraction",), Mol + " mole fraction for look-up table", "1")
+            dims = (mol + "_mole_fraction",) + dims
+        if g["conc"] == "relative-linear":
+            var(mol + "_reference_mole_fraction", "float", (), "Reference mole fraction of " + Mol, "1")
+        what = "background gases" if g["conc"] == "none" else Mol
+        var(k, "float", dims, "Molar absorption coefficient of " + what, "m2 mol-1")
+        if g.get("min_molar_abs") is not None and g.get("max_molar_abs") is not None:
+            var(k + "_min", "float", dims, "Minimum molar absorption coefficient of " + what, "m2 mol-1")
+            var(k + "_max", "float", dims, "Maximum molar absorption coefficient of " + what, "m2 mol-1")
+    if history:
+        w.write_attribute("history", history)
+    w.write_attribute("config", config)
+    w.write_attribute("summary", summary)
+    w.end_define_mode()
+    w.write("n_gases", [len(names)])
+    w.write("pressure", np.exp(np.asarray(model["log_pressure"], dtype=np.float64)))
+    w.write("temperature", temp)
+    if is_sw:
+        w.write("solar_irradiance", model["solar_irradiance"])
+        if model.get("rayleigh_molar_scattering") is not None:
+            w.write("rayleigh_molar_scattering_coeff", model["rayleigh_molar_scattering"])
+    else:
+        w.write("temperature_planck", model["temperature_planck"])
+        w.write("planck_function", model["planck_function"])
+    w.write("wavenumber1", model["wavenumber1"])
+    w.write("wavenumber2", model["wavenumber2"])
+    w.write("gpoint_fraction", gf)
+    w.write("wavenumber1_band", model["wavenumber1_band"])
+    w.write("wavenumber2_band", model["wavenumber2_band"])
+    w.write("band_number", model["iband_per_g"])
+    for g in model["gases"]:
+        mol = g["name"]
+        w.write(mol + "_conc_dependence_code", [CONC_CODE[g["conc"]]])
+        if g["conc"] == "lut":
+            w.write(mol + "_mole_fraction", g["vmr"])
+        if g["conc"] == "relative-linear":
+            w.write(mol + "_reference_mole_fraction", [g["reference_vmr"]])
+        w.write(mol + "_" + K_NAME, g["molar_abs"])
+        if g.get("min_molar_abs") is not None and g.get("max_molar_abs") is not None:
+            w.write(mol + "_" + K_NAME + "_min", g["min_molar_abs"])
+            w.write(mol + "_" + K_NAME + "_max", g["max_molar_abs"])
+    w.close()
+
+
+def read_ckd_model(path, active_gases=None):
+    """CkdModel::read -> the model dict of api.Optimizer / api.run_ckd (gases active as in `active_gases`, all if None)."""
+    with NcFile(path) as f:
+        m = {}
+        if f.exist("solar_irradiance"):
+            m["solar_irradiance"] = f.read("solar_irradiance")
+            m["planck_function"] = m["temperature_planck"] = None
+            if f.exist("rayleigh_molar_scattering_coeff"):
+                m["rayleigh_molar_scattering"] = f.read("rayleigh_molar_scattering_coeff")
+        else:
+            m["temperature_planck"] = f.read("temperature_planck")
+            m["planck_function"] = f.read("planck_function")
+        m["temperature"] = f.read("temperature")
+        m["log_pressure"] = np.log(f.read("pressure"))
+        for k in ("wavenumber1", "wavenumber2", "gpoint_fraction", "wavenumber1_band", "wavenumber2_band"):
+            m[k] = f.read(k)
+        m["iband_per_g"] = f.read("band_number").astype(np.int32)
+        m["nband"] = m["wavenumber1_band"].size
+        m["ng"] = m["gpoint_fraction"].shape[0]
+        m["model_id"] = f.att_text("model_id")
+        names = f.att_text("constituent_id").split(" ")
+        assert int(f.read("n_gases")) == len(names)
+        gases = []
+        for mol in names:
+            code = int(f.read(mol + "_conc_dependence_code"))
+            g = dict(name=mol, conc=CONC_NAME[code], molar_abs=f.read(mol + "_" + K_NAME),
+                     active=active_gases is None or mol in active_gases)
+            if code == 2:
+                g["vmr"] = f.read(mol + "_mole_fraction")
+            if code == 3:
+                g["reference_vmr"] = float(f.read(mol + "_reference_mole_fraction"))
+            if f.exist(mol + "_" + K_NAME + "_min"):
+                g["min_molar_abs"] = f.read(mol + "_" + K_NAME + "_min")
+                g["max_molar_abs"] = f.read(mol + "_" + K_NAME + "_max")
+            gases.append(g)
+        m["gases"] = gases
+    return m

@@ -173,3 +173,44 @@ def test_rejects_hdf5_and_bad_calls(tmp_path):
     with ncio.NcFile(GOLDEN) as f:
         with pytest.raises(EcckdError):
             f.read("wavenumber", 400)                            # slice outside the slowest dimension
+
+
+@pytest.mark.parametrize("sw", [False, True])
+def test_ckd_model_file_round_trip(tmp_path, sw):
+    """CkdModel::write / ::read (ckd_model.cpp:290-641, :32-286): names, types and the model dict round trip."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import ckd_synth
+    model = ckd_synth.make_model_sw(seed=2) if sw else ckd_synth.make_model(seed=2)
+    ng = len(model["iband_per_g"])
+    nwav = 33
+    rs = np.random.RandomState(1)
+    gf = rs.uniform(size=(ng, nwav)); gf /= gf.sum(0, keepdims=True)
+    model.update(wavenumber1=np.arange(nwav) * 10.0, wavenumber2=np.arange(1, nwav + 1) * 10.0, gpoint_fraction=gf,
+                 wavenumber1_band=np.array([0.0, 100.0, 200.0]), wavenumber2_band=np.array([100.0, 200.0, 330.0]))
+    p = str(tmp_path / "ckd.nc")
+    ncio.write_ckd_model(p, model, model_id="synthetic", config="x 1\n", summary="test")
+    r = netcdf_file(p, "r", mmap=False)
+    assert r.constituent_id == b"composite h2o co2 ch4 o3" and r.model_id == b"synthetic"
+    assert r.variables["h2o_conc_dependence_code"].getValue() == 2 and r.variables["ch4_conc_dependence_code"].getValue() == 3
+    assert r.variables["h2o_molar_absorption_coeff"].dimensions == ("h2o_mole_fraction", "temperature", "pressure", "g_point")
+    assert r.variables["composite_molar_absorption_coeff"].typecode() == "f" and r.variables["band_number"].typecode() == "h"
+    assert b"2: Look-up table" in r.variables["co2_conc_dependence_code"].definition
+    assert ("solar_irradiance" in r.variables) == sw and ("planck_function" in r.variables) == (not sw)
+    r.close()
+    back = ncio.read_ckd_model(p, active_gases=["h2o", "co2"])
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    assert np.array_equal(back["temperature"], f32(model["temperature"]))
+    assert np.allclose(back["log_pressure"], model["log_pressure"], rtol=1e-7)
+    assert np.array_equal(back["iband_per_g"], model["iband_per_g"]) and back["nband"] == 3
+    for g0, g1 in zip(model["gases"], back["gases"]):
+        assert g1["name"] == g0["name"] and g1["conc"] == g0["conc"] and g1["active"] == (g0["name"] in ("h2o", "co2"))
+        assert np.array_equal(g1["molar_abs"], f32(g0["molar_abs"])) and np.array_equal(g1["max_molar_abs"], f32(g0["max_molar_abs"]))
+        if g0["conc"] == "lut":
+            assert np.array_equal(g1["vmr"], f32(g0["vmr"]))
+        if g0["conc"] == "relative-linear":
+            assert g1["reference_vmr"] == float(np.float32(g0["reference_vmr"]))
+    if sw:
+        assert np.array_equal(back["solar_irradiance"], f32(model["solar_irradiance"])) and back["planck_function"] is None
+    else:
+        assert np.array_equal(back["planck_function"], f32(model["planck_function"]))
