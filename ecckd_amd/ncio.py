@@ -325,3 +325,123 @@ def read_ckd_model(path, active_gases=None):
             gases.append(g)
         m["gases"] = gases
     return m
+
+
+# ---- LBL training fluxes (LblFluxes::read lbl_fluxes.cpp:52-397, make_gas_mapping, mask_rayleigh_up, subtract) -----
+
+def read_lbl_fluxes(path, model_molecules, band_mapping=None, gmap=None, ctx=None):
+    """LblFluxes::read + make_gas_mapping -> a training-scene dict for api.Optimizer.
+
+    model_molecules: the CKD model's gas names in model order (CkdModel::molecules).
+    band_mapping:    optional narrow-band -> wide-band index per file band (:150-176, :272-296).
+    gmap, ctx:       an api.GPointMap of the g-points file and its context; with them the high-resolution boundary
+                     fluxes are summed per g point on the device (:180-246, :300-325) and the shortwave erythemal
+                     weights are formed (:198-230)."""
+    bm = None if band_mapping is None else np.asarray(band_mapping, dtype=np.int64)
+    with NcFile(path) as f:
+        p = f.read("pressure_hl")
+        t = f.read("temperature_hl")
+        vmr_file = f.read("mole_fraction_fl")                       # (column, gas, level)
+        ncol = p.shape[0]
+        is_sw = f.exist("mu0")
+        out = {"is_sw": is_sw}
+        dom = "sw" if is_sw else "lw"
+
+        def map_bands(a, wn1, wn2):                                  # sum narrow bands into wide ones
+            nb = int(bm.max()) + 1
+            new = np.stack([a[..., bm == j].sum(-1) for j in range(nb)], axis=-1)
+            return new, np.array([wn1[bm == j].min() for j in range(nb)]), np.array([wn2[bm == j].max() for j in range(nb)])
+
+        if is_sw:
+            mu0_all = f.read("mu0")
+            index_sza = [0, 2, 4]                                    # :82
+            nsza = len(index_sza)
+            rep = lambda a: np.repeat(a, nsza, axis=0)               # repeat_matrix / repeat_array3D
+            p, t, vmr_file = rep(p), rep(t), rep(vmr_file)
+            pick = lambda a: np.ascontiguousarray(a[:, index_sza].reshape((ncol * nsza,) + a.shape[2:]))
+            flux_dn, flux_up = pick(f.read("flux_dn_direct_sw")), pick(f.read("flux_up_sw"))
+            out["mu0"] = np.tile(mu0_all[index_sza], ncol)
+            out["tsi"] = float(flux_dn[0, 0] / out["mu0"][0])        # :116
+            have_band = False
+            if f.exist("spectral_flux_dn_direct_sw"):
+                sdn, sup = pick(f.read("spectral_flux_dn_direct_sw")), pick(f.read("spectral_flux_up_sw"))
+            elif f.exist("band_flux_dn_direct_sw"):
+                sdn, sup = pick(f.read("band_flux_dn_direct_sw")), pick(f.read("band_flux_up_sw"))
+                have_band = True
+                wn1, wn2 = f.read("band_wavenumber1_sw"), f.read("band_wavenumber2_sw")
+            else:
+                sdn = sup = None
+            if sdn is not None:
+                if have_band and bm is not None:
+                    sdn, wn1n, wn2n = map_bands(sdn, wn1, wn2)
+                    sup, _, _ = map_bands(sup, wn1, wn2)
+                    wn1, wn2 = wn1n, wn2n
+                out["albedo"] = sup[:, -1, :].sum(0) / sdn[:, -1, :].sum(0)      # effective_spectral_albedo_ (:147-148, :166-167)
+            ncol *= nsza
+            hi_dn, hi_up = "spectral_flux_dn_direct_surf_sw", "spectral_flux_up_toa_sw"
+        else:
+            flux_dn, flux_up = f.read("flux_dn_lw"), f.read("flux_up_lw")
+            have_band = False
+            if f.exist("spectral_flux_up_lw"):
+                sup, sdn = f.read("spectral_flux_up_lw"), f.read("spectral_flux_dn_lw")
+            elif f.exist("band_flux_up_lw"):
+                sup, sdn = f.read("band_flux_up_lw"), f.read("band_flux_dn_lw")
+                wn1, wn2 = f.read("band_wavenumber1_lw"), f.read("band_wavenumber2_lw")
+                have_band = True
+                if bm is not None:
+                    sup, wn1n, wn2n = map_bands(sup, wn1, wn2)
+                    sdn, _, _ = map_bands(sdn, wn1, wn2)
+                    wn1, wn2 = wn1n, wn2n
+            else:
+                sup = sdn = None
+            hi_dn, hi_up = "spectral_flux_dn_surf_lw", "spectral_flux_up_toa_lw"
+        out.update(pressure_hl=p, temperature_hl=t, broadband_flux_dn=flux_dn, broadband_flux_up=flux_up,
+                   flux_dn=sdn, flux_up=sup, have_band_fluxes=have_band)
+        if have_band:
+            out["band_wavenumber1"], out["band_wavenumber2"] = wn1, wn2
+
+        # high-resolution boundary fluxes summed per g point (device: ecckd_gmap_sum_rows)
+        if f.exist(hi_dn) and f.exist(hi_up) and gmap is not None and ctx is not None:
+            import torch
+            dn_rows, up_rows = [], []
+            nfile_col = f.var_info(hi_dn)[1][0]
+            for icol in range(nfile_col):
+                d, u = f.read(hi_dn, icol), f.read(hi_up, icol)      # LW: (wavenumber,), SW: (sza, wavenumber)
+                if is_sw:
+                    d, u = d[index_sza], u[index_sza]
+                dn_rows.append(np.atleast_2d(d)); up_rows.append(np.atleast_2d(u))
+            rows = torch.as_tensor(np.concatenate(dn_rows + up_rows), device=ctx.device)
+            sums = gmap.sum_rows(rows)
+            out["spectral_flux_dn_surf"], out["spectral_flux_up_toa"] = sums[:ncol], sums[ncol:]
+            if is_sw:
+                out["erythemal_spectrum"] = gmap.erythemal_spectrum()
+
+        # gases: the file's constituent list mapped onto the model's (make_gas_mapping); "h2o-no-continuum" -> "h2o"
+        file_gases = [m.split("-")[0] for m in f.att_text("constituent_id").split(" ")]
+        out["molecules"] = file_gases
+        nlay = p.shape[1] - 1
+        vmr = np.zeros((ncol, len(model_molecules), nlay))
+        present = np.zeros(len(model_molecules), dtype=np.int32)
+        for i, mol in enumerate(model_molecules):
+            if mol in file_gases:
+                vmr[:, i, :] = vmr_file[:, file_gases.index(mol), :]
+                present[i] = 1
+        out["vmr_fl"], out["gas_present"] = vmr, present
+    return out
+
+
+def mask_rayleigh_up(scene, max_no_rayleigh_wavenumber):
+    """LblFluxes::mask_rayleigh_up (lbl_fluxes.cpp:415-429): bands above the limit lose their upwelling."""
+    idx = scene["band_wavenumber2"] > max_no_rayleigh_wavenumber
+    if idx.any():
+        scene["albedo"] = np.where(idx, 0.0, scene["albedo"])
+        scene["flux_up"] = np.where(idx[None, None, :], 0.0, scene["flux_up"])
+        scene["broadband_flux_up"] = np.zeros_like(scene["broadband_flux_up"])
+    return scene
+
+
+def subtract_lbl_fluxes(scene, source):
+    """LblFluxes::subtract (:431-440): train on the difference to a relative-to scene."""
+    for k in ("flux_dn", "flux_up", "broadband_flux_dn", "broadband_flux_up"):
+        scene[k] = scene[k] - source[k]
+    return scene

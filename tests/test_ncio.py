@@ -214,3 +214,73 @@ def test_ckd_model_file_round_trip(tmp_path, sw):
         assert np.array_equal(back["solar_irradiance"], f32(model["solar_irradiance"])) and back["planck_function"] is None
     else:
         assert np.array_equal(back["planck_function"], f32(model["planck_function"]))
+
+
+def _write_lbl(path, sw, rs, ncol=4, nlev=5, nband=6):
+    w = netcdf_file(str(path), "w", version=2)
+    dims = dict(column=ncol, half_level=nlev + 1, level=nlev, gas=3, band=nband)
+    if sw:
+        dims["mu0"] = 5
+    for d, n in dims.items():
+        w.createDimension(d, n)
+    a = {}
+    a["pressure_hl"] = (("column", "half_level"), np.sort(rs.uniform(1, 1e5, (ncol, nlev + 1)), axis=1))
+    a["temperature_hl"] = (("column", "half_level"), rs.uniform(200, 300, (ncol, nlev + 1)))
+    a["mole_fraction_fl"] = (("column", "gas", "level"), rs.uniform(1e-6, 1e-2, (ncol, 3, nlev)))
+    if sw:
+        a["mu0"] = (("mu0",), np.array([0.1, 0.3, 0.5, 0.7, 0.9]))
+        a["flux_dn_direct_sw"] = (("column", "mu0", "half_level"), rs.uniform(1, 1000, (ncol, 5, nlev + 1)))
+        a["flux_up_sw"] = (("column", "mu0", "half_level"), rs.uniform(1, 100, (ncol, 5, nlev + 1)))
+        a["band_flux_dn_direct_sw"] = (("column", "mu0", "half_level", "band"), rs.uniform(1, 100, (ncol, 5, nlev + 1, nband)))
+        a["band_flux_up_sw"] = (("column", "mu0", "half_level", "band"), rs.uniform(1, 10, (ncol, 5, nlev + 1, nband)))
+        a["band_wavenumber1_sw"] = (("band",), np.arange(nband) * 1000.0 + 250.0)
+        a["band_wavenumber2_sw"] = (("band",), np.arange(1, nband + 1) * 1000.0 + 250.0)
+    else:
+        a["flux_dn_lw"] = (("column", "half_level"), rs.uniform(1, 400, (ncol, nlev + 1)))
+        a["flux_up_lw"] = (("column", "half_level"), rs.uniform(1, 400, (ncol, nlev + 1)))
+        a["band_flux_dn_lw"] = (("column", "half_level", "band"), rs.uniform(1, 40, (ncol, nlev + 1, nband)))
+        a["band_flux_up_lw"] = (("column", "half_level", "band"), rs.uniform(1, 40, (ncol, nlev + 1, nband)))
+        a["band_wavenumber1_lw"] = (("band",), np.arange(nband) * 500.0)
+        a["band_wavenumber2_lw"] = (("band",), np.arange(1, nband + 1) * 500.0)
+    for name, (d, v) in a.items():
+        w.createVariable(name, "d", d)[:] = v
+    w.constituent_id = "h2o-no-continuum o3 co2"
+    w.close()
+    return {k: v[1] for k, v in a.items()}
+
+
+@pytest.mark.parametrize("sw", [False, True])
+def test_read_lbl_fluxes(tmp_path, sw):
+    """LblFluxes::read (lbl_fluxes.cpp:52-397): SZA replication, band mapping, effective albedo, gas mapping."""
+    rs = np.random.RandomState(11)
+    p = tmp_path / "lbl.nc"
+    a = _write_lbl(p, sw, rs)
+    bm = np.array([0, 0, 1, 1, 1, 2])
+    s = ncio.read_lbl_fluxes(p, ["composite", "h2o", "co2", "ch4", "o3"], band_mapping=bm)
+    assert s["is_sw"] == sw and s["molecules"] == ["h2o", "o3", "co2"]
+    assert np.array_equal(s["gas_present"], [0, 1, 1, 0, 1])
+    ncol = 4 * (3 if sw else 1)
+    rep = (lambda x: np.repeat(x, 3, axis=0)) if sw else (lambda x: x)
+    assert np.array_equal(s["pressure_hl"], rep(a["pressure_hl"])) and s["vmr_fl"].shape == (ncol, 5, 5)
+    assert np.array_equal(s["vmr_fl"][:, 4], rep(a["mole_fraction_fl"])[:, 1]) and np.all(s["vmr_fl"][:, 3] == 0)
+    agg = lambda x: np.stack([x[..., bm == j].sum(-1) for j in range(3)], axis=-1)
+    if sw:
+        sel = lambda x: x[:, [0, 2, 4]].reshape((ncol,) + x.shape[2:])
+        assert np.array_equal(s["mu0"], np.tile([0.1, 0.5, 0.9], 4))
+        assert s["tsi"] == a["flux_dn_direct_sw"][0, 0, 0] / 0.1
+        dn, up = agg(sel(a["band_flux_dn_direct_sw"])), agg(sel(a["band_flux_up_sw"]))
+        assert np.allclose(s["flux_dn"], dn, rtol=1e-15) and np.allclose(s["flux_up"], up, rtol=1e-15)
+        assert np.allclose(s["albedo"], up[:, -1].sum(0) / dn[:, -1].sum(0), rtol=1e-15)
+        assert np.array_equal(s["band_wavenumber2"], [2250.0, 5250.0, 6250.0])
+        ncio.mask_rayleigh_up(s, 5000.0)
+        assert np.all(s["albedo"][1:] == 0) and s["albedo"][0] > 0 and np.all(s["flux_up"][..., 1:] == 0)
+        assert np.all(s["broadband_flux_up"] == 0)
+    else:
+        assert np.allclose(s["flux_dn"], agg(a["band_flux_dn_lw"]), rtol=1e-15)
+        assert np.array_equal(s["broadband_flux_up"], a["flux_up_lw"])
+        assert np.array_equal(s["band_wavenumber1"], [0.0, 1000.0, 2500.0])
+    other = dict(s, flux_dn=s["flux_dn"] * 0.25, flux_up=s["flux_up"] * 0.5, broadband_flux_dn=s["broadband_flux_dn"] * 0,
+                 broadband_flux_up=s["broadband_flux_up"] * 0)
+    before = s["flux_dn"].copy()
+    ncio.subtract_lbl_fluxes(s, other)
+    assert np.allclose(s["flux_dn"], 0.75 * before)
