@@ -887,23 +887,29 @@ k_fit_sw(int nlay, int method, RowMap R, int nint, double min_scaling, double ma
     }
     return;
   }
-  // total-transmission: sequential in the layers (:189-203)
-  if (threadIdx.x == 0) {
-    const double ssum = s[R.B];
-    const double norm_factor = 1.0 / ssum;
-    double top = ssum, top_bg = ssum;
-    for (int iz = 0; iz < nlay; ++iz) {
-      const double base_bg = s[R.TG + iz];
-      const double base = s[R.TF + iz];
-      if (base_bg > 0.0 && base > 0.0) {
-        const double bg_od_fit = -0.5 * log(base_bg / top_bg);
-        s_fit[iz] = -0.5 * log(base / top) - bg_od_fit;
-      } else {
-        // :197-199: the WHOLE vector becomes the linear average, the loop continues
-        for (int kz = 0; kz < nlay; ++kz) s_fit[kz] = s[R.A + kz] * norm_factor;
-      }
-      top = base;
-      top_bg = base_bg;
+  // total-transmission (:189-203).  The reference walks the layers in order; a layer whose direct beam has
+  // vanished replaces the WHOLE vector by the linear average and the walk continues, so the outcome is:
+  // layers above and at the LAST such layer carry the linear average, layers below it their own fit.
+  // One thread per layer; the last invalid layer is found with an integer LDS max.
+  __shared__ int s_last_invalid;
+  if (threadIdx.x == 0) s_last_invalid = -1;
+  __syncthreads();
+  const double ssum = s[R.B];
+  const double norm_factor = 1.0 / ssum;
+  for (int iz = threadIdx.x; iz < nlay; iz += blockDim.x) {
+    const double base_bg = s[R.TG + iz], base = s[R.TF + iz];
+    if (!(base_bg > 0.0 && base > 0.0)) atomicMax(&s_last_invalid, iz);
+  }
+  __syncthreads();
+  const int last_invalid = s_last_invalid;
+  for (int iz = threadIdx.x; iz < nlay; iz += blockDim.x) {
+    if (iz > last_invalid) {
+      const double top = iz == 0 ? ssum : s[R.TF + iz - 1];
+      const double top_bg = iz == 0 ? ssum : s[R.TG + iz - 1];
+      const double bg_od_fit = -0.5 * log(s[R.TG + iz] / top_bg);
+      s_fit[iz] = -0.5 * log(s[R.TF + iz] / top) - bg_od_fit;
+    } else {
+      s_fit[iz] = s[R.A + iz] * norm_factor;
     }
   }
   __syncthreads();
