@@ -985,6 +985,102 @@ k_rt_sw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __
   }
 }
 
+
+
+// K5c-SW fast path: NLAY known at compile time.  The column of total optical depths (background + grey) stays in
+// registers for both sweeps (direct beam down, radiative_transfer_sw.cpp:134-139, reflected beam up, :176-183:
+// two different exponents per layer, no sources), level sums through the wave-private transposed LDS tile of the
+// longwave path.  Slots: 0 = sum of the solar irradiance, 1..NLAY = flux_dn below each layer, NLAY+1 = flux_up at the
+// surface, NLAY+2.. = flux_up above each layer going up.
+template <int NLAY>
+__global__ void __launch_bounds__(RT_THREADS, 3)
+k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv, double cos_sza, double albedo,
+                const double* __restrict__ ssi, const double* __restrict__ bg_od, const double* __restrict__ od_fit,
+                double* __restrict__ partial) {
+  constexpr int NHL = NLAY + 1;
+  constexpr int NSLOT = 2 * NLAY + 2;
+  constexpr int NCH = (NSLOT + 15) / 16;
+  constexpr int ROW = 65;
+  __shared__ double s_tile[4][16 * ROW];
+  __shared__ double s_out[4][NCH * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long chunk = blockIdx.x;
+  int lo = 0, hi = nint - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (iv[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
+  }
+  const int k = lo;
+  const long long c = chunk - iv[k].chunk0;
+  const long long p0 = iv[k].i1 + c * chunk_pts;
+  long long p1 = p0 + chunk_pts - 1;
+  if (p1 > iv[k].i2) p1 = iv[k].i2;
+  const double* __restrict__ grey = od_fit + (size_t)k * NLAY;  // block-uniform -> scalar loads
+  double* tile = s_tile[wave];
+  const int rr = lane & 15, qq = lane >> 4;
+  double acc[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) acc[j] = 0.0;
+  const double minus_sec_sza = -1.0 / cos_sza;
+  const bool reflect = albedo > 0.0;                 // :366-373: no upwelling without a reflecting surface
+  for (long long base = p0; base <= p1; base += RT_THREADS) {
+    const long long i = base + tid;
+    const bool live = i <= p1;
+    const size_t ii = live ? (size_t)i : (size_t)p1;
+    double tau[NLAY];
+#pragma unroll
+    for (int l = 0; l < NLAY; ++l) tau[l] = bg_od[(size_t)l * n + ii];
+    const double sv = ssi[ii];
+    int slot = 0;
+    auto push = [&](double v) {
+      tile[(slot & 15) * ROW + lane] = live ? v : 0.0;
+      if ((slot & 15) == 15 || slot == NSLOT - 1) {
+        const int ch = slot >> 4;
+        __builtin_amdgcn_wave_barrier();
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += tile[rr * ROW + qq * 16 + j];
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        acc[ch] += sum;
+        __builtin_amdgcn_wave_barrier();
+      }
+      ++slot;
+    };
+    push(sv);
+    double flux = cos_sza * sv;
+#pragma unroll
+    for (int l = 0; l < NLAY; ++l) {
+      tau[l] += grey[l];
+      // a saturated interval fits an infinite optical depth (log(0), find_g_points.cpp:123-124): exp(-inf) = 0
+      const double xd = minus_sec_sza * tau[l];
+      flux = flux * (xd < -745.0 ? 0.0 : ecckd::exp_fast(xd));
+      push(flux);
+    }
+    flux = reflect ? flux * albedo : 0.0;
+    push(flux);
+#pragma unroll
+    for (int l = NLAY - 1; l >= 0; --l) {
+      const double xu = -2.0 * tau[l];
+      if (reflect) flux = flux * (xu < -745.0 ? 0.0 : ecckd::exp_fast(xu));
+      push(flux);
+    }
+    if ((NSLOT & 15) != 0) {
+#pragma unroll
+      for (int j = (NSLOT & 15); j < 16; ++j) tile[j * ROW + lane] = 0.0;
+    }
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) s_out[wave][j * 16 + lane] = acc[j];
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * NHL; t += RT_THREADS) {
+    // flux_dn level t = slot t; flux_up level u = slot NLAY + 1 + (NLAY - u)
+    const int sl = t < NHL ? t : NLAY + 1 + (NLAY - (t - NHL));
+    partial[(size_t)chunk * 2 * NHL + t] = ((s_out[0][sl] + s_out[1][sl]) + s_out[2][sl]) + s_out[3][sl];
+  }
+}
 // K5d-SW: calc_cost_function_sw (calc_cost_function_sw.cpp:86-109): heating rate from the
 // direct beam only (:92), truth rows selected by (rH, rFDS, rFUT).
 __global__ void __launch_bounds__(1024)
@@ -1623,9 +1719,16 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
     const size_t cost_lds_sw = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
     const int npass = is_tt ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
-      hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
-                         chunk_pts, n, d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od,
-                         d_fit + (size_t)pass * n * nlay, d_part);
+      if (nlay == 54)
+        hipLaunchKernelGGL(k_rt_sw_bb_fast<54>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, chunk_pts, n,
+                           d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, d_fit + (size_t)pass * n * nlay, d_part);
+      else if (nlay == 30)
+        hipLaunchKernelGGL(k_rt_sw_bb_fast<30>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, chunk_pts, n,
+                           d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, d_fit + (size_t)pass * n * nlay, d_part);
+      else
+        hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
+                           chunk_pts, n, d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od,
+                           d_fit + (size_t)pass * n * nlay, d_part);
       int rH = R.H, rFDS = R.FDS, rFUT = R.FUT;
       if (is_tt) {
         rH = pass == 0 ? R.HL : R.HH;
