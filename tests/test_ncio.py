@@ -1,6 +1,6 @@
 """The NetCDF classic reader / writer (file parts of rows a1, a9, a21) against an independent implementation
-(scipy.io.netcdf_file) in both directions, and against the reference's own classic data file
-(data/mie_droplet_scattering.nc, committed as tests/golden/mie_droplet_scattering.nc)."""
+(scipy.io.netcdf_file) in both directions, and on the reference's own classic data file
+(data/mie_droplet_scattering.nc, read in place when the reference tree is present)."""
 import os
 
 import numpy as np
@@ -9,9 +9,12 @@ from scipy.io import netcdf_file
 
 from ecckd_amd import ncio, EcckdError
 
-GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "mie_droplet_scattering.nc")
+# the reference's own NetCDF-classic data file, read where it lies (not copied into the repo); absent on the GPU box
+GOLDEN = "/root/reference/data/mie_droplet_scattering.nc"
+needs_reference = pytest.mark.skipif(not os.path.exists(GOLDEN), reason="reference tree not present")
 
 
+@needs_reference
 def test_reads_the_reference_data_file():
     ref = netcdf_file(GOLDEN, "r", mmap=False)
     with ncio.NcFile(GOLDEN) as f:
@@ -170,9 +173,16 @@ def test_rejects_hdf5_and_bad_calls(tmp_path):
     assert e.value.code == 147
     with pytest.raises(EcckdError):
         ncio.NcFile(str(tmp_path / "missing.nc"))
-    with ncio.NcFile(GOLDEN) as f:
+    q = str(tmp_path / "small.nc")
+    w = ncio.NcWriter(q)
+    w.define_dimension("wavenumber", 7)
+    w.define_variable("wavenumber", "double", "wavenumber")
+    w.end_define_mode()
+    w.write("wavenumber", np.arange(7.0))
+    w.close()
+    with ncio.NcFile(q) as f:
         with pytest.raises(EcckdError):
-            f.read("wavenumber", 400)                            # slice outside the slowest dimension
+            f.read("wavenumber", 7)                              # slice outside the slowest dimension
 
 
 @pytest.mark.parametrize("sw", [False, True])
