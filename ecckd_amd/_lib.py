@@ -170,6 +170,10 @@ SIGNATURES = {
     "ecckd_write_order_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, _c_double_p, _c_double_p,
                                          C.c_size_t, _c_double_p, _c_double_p, _c_int16_p, _c_int32_p, _c_double_p,
                                          _c_double_p]),
+    "ecckd_lbl_band_fluxes_lw": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p]),
+    "ecckd_lbl_band_fluxes_sw": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p]),
     "ecckd_gather_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_invert_permutation_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }

@@ -786,6 +786,36 @@ def merge_spectrum(ctx, optical_depth, scaling_profile, merged=None):
     return merged
 
 
+def lbl_band_fluxes_lw(ctx, temperature_hl, wavenumber, d_wavenumber, optical_depth, band_begin, band_end):
+    """Line-by-line longwave fluxes of one column summed per band (planck_function + radiative_transfer_lw):
+    device tensors wavenumber, d_wavenumber, optical_depth (nlay, nwav) -> (flux_dn, flux_up), each (nband, nlay+1)."""
+    t = _f64c(temperature_hl)
+    nlay = t.size - 1
+    b0 = np.ascontiguousarray(band_begin, dtype=np.int64)
+    b1 = np.ascontiguousarray(band_end, dtype=np.int64)
+    dn, up = np.empty((b0.size, nlay + 1)), np.empty((b0.size, nlay + 1))
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_lbl_band_fluxes_lw(ctx.handle, nlay, optical_depth.shape[1], _hptr(t), _dptr(wavenumber),
+                                           _dptr(d_wavenumber), _dptr(optical_depth), _od_type(optical_depth),
+                                           optical_depth.stride(0), b0.size, _hptr(b0, C.c_int64), _hptr(b1, C.c_int64),
+                                           _hptr(dn), _hptr(up)))
+    return dn, up
+
+
+def lbl_band_fluxes_sw(ctx, cos_sza, ssi, optical_depth, band_begin, band_end, albedo=None):
+    """Line-by-line shortwave direct (and, with a per-wavenumber albedo, reflected) fluxes summed per band."""
+    nlay = optical_depth.shape[0]
+    b0 = np.ascontiguousarray(band_begin, dtype=np.int64)
+    b1 = np.ascontiguousarray(band_end, dtype=np.int64)
+    dn, up = np.empty((b0.size, nlay + 1)), np.empty((b0.size, nlay + 1))
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_lbl_band_fluxes_sw(ctx.handle, nlay, optical_depth.shape[1], float(cos_sza), _dptr(ssi),
+                                           _dptr(albedo) if albedo is not None else None, _dptr(optical_depth),
+                                           _od_type(optical_depth), optical_depth.stride(0), b0.size, _hptr(b0, C.c_int64),
+                                           _hptr(b1, C.c_int64), _hptr(dn), _hptr(up)))
+    return dn, up
+
+
 def scale_lut(ctx, model, flux_sums, pressure_hl, temperature_hl, vmr_fl, gas_present, mu0):
     """scale_lut.cpp:117-189 + CkdModel::scale_optical_depth for one reference profile.  `flux_sums` (nz+1, ng)
     from GPointMap.sum_rows of the LBL direct spectral flux.  -> (list of scaled molar_abs arrays, scaling[nz, ng])."""

@@ -1,0 +1,237 @@
+// lbl_fluxes.hip - line-by-line band fluxes of one column (a stand-in for the external
+// CKDMIP tool that test/run_lw_lbl_evaluation.sh uses to make the training fluxes, restricted to the
+// no-scattering radiative transfer the reference itself contains):
+//   longwave:  planck_function (planck_function.cpp:22-54) + radiative_transfer_lw (radiative_transfer_lw.cpp:27-60,
+//              unit surface emissivity, surface Planck function at temperature_hl(end)), fluxes summed per band;
+//   shortwave: radiative_transfer_direct_sw / _norayleigh_sw (radiative_transfer_sw.cpp:26-77).
+// One thread per wavenumber; per half level the fluxes of a block are reduced wave -> block in a fixed order and
+// written as chunk partials, which the host adds in chunk order (bitwise reproducible).
+#include "common.hpp"
+#include "fastmath.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int LBL_THREADS = 256;
+__device__ constexpr double kPlanckH = 6.62606896e-34;
+__device__ constexpr double kLightC = 2.99792458e8;
+__device__ constexpr double kPi = 3.14159265358979323846;
+__device__ constexpr double kD = ECCKD_LW_DIFFUSIVITY;
+
+struct BandChunk { long long i1, i2; int band; int pad; };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
+// LDS: acc[4][2*nhl]
+template <typename OdT>
+__global__ void __launch_bounds__(LBL_THREADS)
+k_lbl_fluxes_lw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks, const double* __restrict__ hk,
+                const double* __restrict__ wn, const double* __restrict__ dwn, const OdT* __restrict__ od,
+                double* __restrict__ partial) {
+  extern __shared__ double s_acc[];
+  const int nhl = nlay + 1;
+  const BandChunk c = chunks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int t = tid; t < 4 * 2 * nhl; t += LBL_THREADS) s_acc[t] = 0.0;
+  __syncthreads();
+  double* acc_dn = s_acc + wave * 2 * nhl;
+  double* acc_up = acc_dn + nhl;
+  const long long i = c.i1 + tid;
+  const bool live = i <= c.i2;
+  const size_t j = live ? (size_t)i : (size_t)c.i2;
+  const double inv_cm_2_Hz = 100.0 * kLightC;
+  const double freq = wn[j] * inv_cm_2_Hz;
+  const double pref = live ? (dwn[j] * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq) : 0.0;
+  auto planck = [&](int level) { return ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[level]) - 1.0); };
+  auto layer = [&](int l, double& eps, double& fac) {
+    const double tau = (double)od[(size_t)l * od_stride + j];
+    eps = 1.0 - ecckd::exp_fast(-kD * tau);
+    fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;   // :41-43
+  };
+  // down sweep from zero at the top of the atmosphere (:45-50); dead lanes carry pref = 0 -> all fluxes 0
+  double flux = 0.0;
+  double b_prev = planck(0);
+  for (int l = 0; l < nlay; ++l) {
+    double eps, fac;
+    layer(l, eps, fac);
+    const double b_next = planck(l + 1);
+    flux = flux * (1.0 - eps) + b_prev * (eps - fac) + b_next * fac;
+    const double s = wave_sum(flux);
+    if (lane == 0) acc_dn[l + 1] += s;
+    b_prev = b_next;
+  }
+  // surface: emissivity 1, Planck function at temperature_hl(end) (:52-53)
+  flux = b_prev * 1.0 + (1.0 - 1.0) * flux;
+  {
+    const double s = wave_sum(flux);
+    if (lane == 0) acc_up[nlay] += s;
+  }
+  for (int l = nlay - 1; l >= 0; --l) {                                    // :55-59
+    double eps, fac;
+    layer(l, eps, fac);
+    const double b_l = planck(l);
+    flux = flux * (1.0 - eps) + b_prev * (eps - fac) + b_l * fac;
+    const double s = wave_sum(flux);
+    if (lane == 0) acc_up[l] += s;
+    b_prev = b_l;
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * nhl; t += LBL_THREADS)
+    partial[(size_t)blockIdx.x * 2 * nhl + t] = ((s_acc[t] + s_acc[2 * nhl + t]) + s_acc[4 * nhl + t]) + s_acc[6 * nhl + t];
+}
+
+template <typename OdT>
+__global__ void __launch_bounds__(LBL_THREADS)
+k_lbl_fluxes_sw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks, double cos_sza,
+                const double* __restrict__ ssi, const double* __restrict__ albedo /* per wavenumber or NULL */,
+                const OdT* __restrict__ od, double* __restrict__ partial) {
+  extern __shared__ double s_acc[];
+  const int nhl = nlay + 1;
+  const BandChunk c = chunks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int t = tid; t < 4 * 2 * nhl; t += LBL_THREADS) s_acc[t] = 0.0;
+  __syncthreads();
+  double* acc_dn = s_acc + wave * 2 * nhl;
+  double* acc_up = acc_dn + nhl;
+  const long long i = c.i1 + tid;
+  const bool live = i <= c.i2;
+  const size_t j = live ? (size_t)i : (size_t)c.i2;
+  const double minus_sec_sza = -1.0 / cos_sza;
+  double flux = live ? cos_sza * ssi[j] : 0.0;                              // radiative_transfer_sw.cpp:39
+  {
+    const double s = wave_sum(flux);
+    if (lane == 0) acc_dn[0] += s;
+  }
+  for (int l = 0; l < nlay; ++l) {
+    flux = flux * exp(minus_sec_sza * (double)od[(size_t)l * od_stride + j]);
+    const double s = wave_sum(flux);
+    if (lane == 0) acc_dn[l + 1] += s;
+  }
+  if (albedo) {                                                             // :70-76
+    flux = flux * albedo[j];
+    {
+      const double s = wave_sum(flux);
+      if (lane == 0) acc_up[nlay] += s;
+    }
+    for (int l = nlay - 1; l >= 0; --l) {
+      flux = flux * exp(-2.0 * (double)od[(size_t)l * od_stride + j]);
+      const double s = wave_sum(flux);
+      if (lane == 0) acc_up[l] += s;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * nhl; t += LBL_THREADS)
+    partial[(size_t)blockIdx.x * 2 * nhl + t] = ((s_acc[t] + s_acc[2 * nhl + t]) + s_acc[4 * nhl + t]) + s_acc[6 * nhl + t];
+}
+
+struct Buf {
+  void* p = nullptr;
+  ~Buf() { if (p) (void)hipFree(p); }
+};
+
+int make_chunks(size_t nwav, int nband, const int64_t* b0, const int64_t* b1, std::vector<BandChunk>& chunks) {
+  for (int b = 0; b < nband; ++b) {
+    if (b1[b] < b0[b]) continue;                       // empty band
+    ECCKD_REQUIRE(b0[b] >= 0 && (size_t)b1[b] < nwav, "band %d range [%lld,%lld] outside the spectrum", b, (long long)b0[b],
+                  (long long)b1[b]);
+    for (long long i = b0[b]; i <= b1[b]; i += LBL_THREADS)
+      chunks.push_back(BandChunk{i, std::min<long long>(i + LBL_THREADS - 1, b1[b]), b, 0});
+  }
+  return ECCKD_OK;
+}
+
+int combine(ecckd_ctx* ctx, int nlay, int nband, const std::vector<BandChunk>& chunks, const double* d_partial,
+            double* h_flux_dn, double* h_flux_up) {
+  const int nhl = nlay + 1;
+  std::vector<double> part(chunks.size() * 2 * nhl);
+  if (!chunks.empty()) ECCKD_CHECK(ecckd_d2h(ctx, part.data(), d_partial, part.size() * sizeof(double)));
+  std::fill(h_flux_dn, h_flux_dn + (size_t)nband * nhl, 0.0);
+  if (h_flux_up) std::fill(h_flux_up, h_flux_up + (size_t)nband * nhl, 0.0);
+  for (size_t c = 0; c < chunks.size(); ++c)          // chunk order = wavenumber order within each band
+    for (int i = 0; i < nhl; ++i) {
+      h_flux_dn[(size_t)chunks[c].band * nhl + i] += part[c * 2 * nhl + i];
+      if (h_flux_up) h_flux_up[(size_t)chunks[c].band * nhl + i] += part[c * 2 * nhl + nhl + i];
+    }
+  return ECCKD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ecckd_lbl_band_fluxes_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_temperature_hl,
+                             const double* d_wavenumber, const double* d_d_wavenumber, const void* d_od, int od_type,
+                             size_t od_stride, int nband, const int64_t* h_band_begin, const int64_t* h_band_end,
+                             double* h_flux_dn, double* h_flux_up) {
+  ECCKD_REQUIRE(ctx && nlay > 0 && h_temperature_hl && d_wavenumber && d_d_wavenumber && d_od && nband > 0 && h_band_begin &&
+                h_band_end && h_flux_dn && h_flux_up, "ecckd_lbl_band_fluxes_lw: bad argument");
+  ECCKD_REQUIRE(od_type == ECCKD_F32 || od_type == ECCKD_F64, "ecckd_lbl_band_fluxes_lw: od_type must be 4 or 8");
+  ECCKD_REQUIRE(od_stride >= nwav, "ecckd_lbl_band_fluxes_lw: od_stride (%zu) < nwav (%zu)", od_stride, nwav);
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const int nhl = nlay + 1;
+  std::vector<BandChunk> chunks;
+  ECCKD_CHECK(make_chunks(nwav, nband, h_band_begin, h_band_end, chunks));
+  std::vector<double> hk(nhl);
+  for (int i = 0; i < nhl; ++i) {
+    ECCKD_REQUIRE(h_temperature_hl[i] > 0.0, "ecckd_lbl_band_fluxes_lw: temperature_hl must be positive");
+    hk[i] = (6.62606896e-34 / 1.3806504e-23) / h_temperature_hl[i];
+  }
+  Buf d_chunks, d_hk, d_part;
+  if (!chunks.empty()) {
+    ECCKD_HIP_CHECK(hipMalloc(&d_chunks.p, chunks.size() * sizeof(BandChunk)));
+    ECCKD_HIP_CHECK(hipMalloc(&d_hk.p, nhl * sizeof(double)));
+    ECCKD_HIP_CHECK(hipMalloc(&d_part.p, chunks.size() * 2 * nhl * sizeof(double)));
+    ECCKD_CHECK(ecckd_h2d(ctx, d_chunks.p, chunks.data(), chunks.size() * sizeof(BandChunk)));
+    ECCKD_CHECK(ecckd_h2d(ctx, d_hk.p, hk.data(), nhl * sizeof(double)));
+    const size_t lds = (size_t)4 * 2 * nhl * sizeof(double);
+    if (od_type == ECCKD_F32)
+      hipLaunchKernelGGL(k_lbl_fluxes_lw<float>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, nlay,
+                         od_stride, (const BandChunk*)d_chunks.p, (const double*)d_hk.p, d_wavenumber, d_d_wavenumber,
+                         (const float*)d_od, (double*)d_part.p);
+    else
+      hipLaunchKernelGGL(k_lbl_fluxes_lw<double>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, nlay,
+                         od_stride, (const BandChunk*)d_chunks.p, (const double*)d_hk.p, d_wavenumber, d_d_wavenumber,
+                         (const double*)d_od, (double*)d_part.p);
+    ECCKD_HIP_CHECK(hipGetLastError());
+  }
+  return combine(ctx, nlay, nband, chunks, (const double*)d_part.p, h_flux_dn, h_flux_up);
+}
+
+int ecckd_lbl_band_fluxes_sw(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_sza, const double* d_ssi,
+                             const double* d_albedo, const void* d_od, int od_type, size_t od_stride, int nband,
+                             const int64_t* h_band_begin, const int64_t* h_band_end, double* h_flux_dn_direct,
+                             double* h_flux_up) {
+  ECCKD_REQUIRE(ctx && nlay > 0 && d_ssi && d_od && nband > 0 && h_band_begin && h_band_end && h_flux_dn_direct,
+                "ecckd_lbl_band_fluxes_sw: bad argument");
+  ECCKD_REQUIRE(cos_sza > 0.0, "ecckd_lbl_band_fluxes_sw: cos_sza must be positive");
+  ECCKD_REQUIRE(od_type == ECCKD_F32 || od_type == ECCKD_F64, "ecckd_lbl_band_fluxes_sw: od_type must be 4 or 8");
+  ECCKD_REQUIRE(od_stride >= nwav, "ecckd_lbl_band_fluxes_sw: od_stride (%zu) < nwav (%zu)", od_stride, nwav);
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const int nhl = nlay + 1;
+  std::vector<BandChunk> chunks;
+  ECCKD_CHECK(make_chunks(nwav, nband, h_band_begin, h_band_end, chunks));
+  Buf d_chunks, d_part;
+  if (!chunks.empty()) {
+    ECCKD_HIP_CHECK(hipMalloc(&d_chunks.p, chunks.size() * sizeof(BandChunk)));
+    ECCKD_HIP_CHECK(hipMalloc(&d_part.p, chunks.size() * 2 * nhl * sizeof(double)));
+    ECCKD_CHECK(ecckd_h2d(ctx, d_chunks.p, chunks.data(), chunks.size() * sizeof(BandChunk)));
+    const size_t lds = (size_t)4 * 2 * nhl * sizeof(double);
+    if (od_type == ECCKD_F32)
+      hipLaunchKernelGGL(k_lbl_fluxes_sw<float>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, nlay,
+                         od_stride, (const BandChunk*)d_chunks.p, cos_sza, d_ssi, d_albedo, (const float*)d_od, (double*)d_part.p);
+    else
+      hipLaunchKernelGGL(k_lbl_fluxes_sw<double>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, nlay,
+                         od_stride, (const BandChunk*)d_chunks.p, cos_sza, d_ssi, d_albedo, (const double*)d_od, (double*)d_part.p);
+    ECCKD_HIP_CHECK(hipGetLastError());
+  }
+  return combine(ctx, nlay, nband, chunks, (const double*)d_part.p, h_flux_dn_direct, h_flux_up);
+}
+
+}  // extern "C"

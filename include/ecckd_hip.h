@@ -302,6 +302,24 @@ int ecckd_gather_f64_dev(ecckd_ctx* ctx, size_t n, const double* d_src, const in
 /* d_inverse[d_perm[i]] = i (ireorder(irank) = range(0,n-1), find_g_points.cpp:778-779). */
 int ecckd_invert_permutation_dev(ecckd_ctx* ctx, size_t n, const int32_t* d_perm, int32_t* d_inverse);
 
+/* ---- line-by-line band fluxes --------------------------------------
+ * A stand-in for the external CKDMIP tool that makes the training fluxes (test/run_lw_lbl_evaluation.sh),
+ * restricted to the no-scattering radiative transfer the reference itself contains.  One column; the
+ * spectral fluxes are summed over the inclusive wavenumber index ranges [h_band_begin[b], h_band_end[b]]
+ * (ecckd_band_ranges) -> h_flux_*[nband][nlay+1], i.e. "band_flux_dn_lw" / "band_flux_up_lw" of a flux file.
+ *   longwave:  planck_function (planck_function.cpp:22-54) + radiative_transfer_lw (radiative_transfer_lw.cpp:27-60),
+ *              unit surface emissivity, surface Planck function at temperature_hl(end);
+ *   shortwave: radiative_transfer_direct_sw, and with d_albedo[nwav] != NULL radiative_transfer_norayleigh_sw
+ *              (radiative_transfer_sw.cpp:26-77); h_flux_up may be NULL.  No Rayleigh scattering. */
+int ecckd_lbl_band_fluxes_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_temperature_hl,
+                             const double* d_wavenumber, const double* d_d_wavenumber, const void* d_od, int od_type,
+                             size_t od_stride, int nband, const int64_t* h_band_begin, const int64_t* h_band_end,
+                             double* h_flux_dn, double* h_flux_up);
+int ecckd_lbl_band_fluxes_sw(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_sza, const double* d_ssi,
+                             const double* d_albedo, const void* d_od, int od_type, size_t od_stride, int nband,
+                             const int64_t* h_band_begin, const int64_t* h_band_end, double* h_flux_dn_direct,
+                             double* h_flux_up);
+
 /* ---- NetCDF classic files (file parts of a1, a9, a21) ----------------------------
  * A self-contained reader / writer for the classic on-disk formats CDF-1, CDF-2 (64-bit offset)
  * and CDF-5 (64-bit data): what the reference reads / writes for *.nc, *.cdf names
