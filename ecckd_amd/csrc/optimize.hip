@@ -541,69 +541,59 @@ __device__ __forceinline__ void write_partial(double v, double* __restrict__ par
   if (t == 0) part[blockIdx.x] = ((s_tmp[0] + s_tmp[1]) + s_tmp[2]) + s_tmp[3];
 }
 
-// q = projected gradient (0 at active bounds and at pinned elements); partial of |q|^2
+// ---- L-BFGS on the device, compact representation (Byrd, Nocedal & Schnabel 1994) -----------------------------
+// With S = [s_0 .. s_{m-1}], Y = [y_0 .. y_{m-1}] (oldest first), R = upper triangle of S^T Y, D = diag(s_i.y_i):
+//   H g = gamma g + S top - gamma Y u,   u = R^-1 (S^T g),   top = R^-T ((D + gamma Y^T Y) u - gamma Y^T g)
+// which is the two-loop recursion in matrix form.  All 2m dot products with the gradient come from ONE pass over
+// S and Y, the m x m solves run on the host, the direction is ONE more pass: four launches per iteration instead of
+// ~30, and two host synchronisations (the scalars of the direction, the cost of the trial point).
+constexpr int LB_M = 6;
+struct LbSlots { int n; int slot[LB_M]; };                       // ring slots of the pairs, oldest first
+struct LbCoef { double gamma; double cs[LB_M]; double cy[LB_M]; };
+
+// q = projected gradient (0 at active bounds and at pinned elements); partials [0] |q|^2, [1+a] S_a.q, [1+LB_M+a] Y_a.q
 __global__ void __launch_bounds__(VEC_THREADS)
-k_vec_project(size_t n, const double* __restrict__ x, const double* __restrict__ g, const double* __restrict__ xmin,
-              const double* __restrict__ xmax, double* __restrict__ q, double* __restrict__ part) {
+k_lb_project_dots(size_t n, LbSlots sl, const double* __restrict__ x, const double* __restrict__ g,
+                  const double* __restrict__ xmin, const double* __restrict__ xmax, double* __restrict__ q,
+                  const double* __restrict__ S, const double* __restrict__ Y, double* __restrict__ part) {
   __shared__ double s_tmp[4];
-  double acc = 0.0;
+  double acc = 0.0, as[LB_M], ay[LB_M];
+#pragma unroll
+  for (int a = 0; a < LB_M; ++a) { as[a] = 0.0; ay[a] = 0.0; }
   for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
     double gi = g[i];
     if (xmin && ((x[i] <= xmin[i] && gi > 0.0) || (x[i] >= xmax[i] && gi < 0.0))) gi = 0.0;
     if (!(x[i] > MIN_X)) gi = 0.0;
     q[i] = gi;
     acc += gi * gi;
+#pragma unroll
+    for (int a = 0; a < LB_M; ++a)
+      if (a < sl.n) {
+        as[a] += S[(size_t)sl.slot[a] * n + i] * gi;
+        ay[a] += Y[(size_t)sl.slot[a] * n + i] * gi;
+      }
   }
   write_partial(acc, part, s_tmp);
+#pragma unroll
+  for (int a = 0; a < LB_M; ++a)
+    if (a < sl.n) {
+      write_partial(as[a], part + (size_t)(1 + a) * VEC_BLOCKS, s_tmp);
+      write_partial(ay[a], part + (size_t)(1 + LB_M + a) * VEC_BLOCKS, s_tmp);
+    }
 }
 
-// partial of a . b
+// d = -gamma q - sum cs_a S_a + sum cy_a Y_a; partials of d.g and d.d
 __global__ void __launch_bounds__(VEC_THREADS)
-k_vec_dot(size_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ part) {
-  __shared__ double s_tmp[4];
-  double acc = 0.0;
-  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS)
-    acc += a[i] * b[i];
-  write_partial(acc, part, s_tmp);
-}
-
-// first loop of the two-loop recursion: alpha = rho * (s . q) [from partials]; q -= alpha * y
-__global__ void __launch_bounds__(VEC_THREADS)
-k_vec_loop1(size_t n, const double* __restrict__ part, const double* __restrict__ rho, double* __restrict__ alpha_out,
-            const double* __restrict__ y, double* __restrict__ q) {
-  __shared__ double s_tmp[4];
-  const double a = rho[0] * sum_partials(part, s_tmp);
-  if (blockIdx.x == 0 && threadIdx.x == 0) alpha_out[0] = a;
-  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS)
-    q[i] -= a * y[i];
-}
-
-// q *= gamma
-__global__ void __launch_bounds__(VEC_THREADS)
-k_vec_scale(size_t n, const double* __restrict__ gamma, double* __restrict__ q) {
-  const double gm = gamma[0];
-  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) q[i] *= gm;
-}
-
-// second loop: beta = rho * (y . q) [from partials]; q += (alpha - beta) * s
-__global__ void __launch_bounds__(VEC_THREADS)
-k_vec_loop2(size_t n, const double* __restrict__ part, const double* __restrict__ rho, const double* __restrict__ alpha,
-            const double* __restrict__ sv, double* __restrict__ q) {
-  __shared__ double s_tmp[4];
-  const double b = rho[0] * sum_partials(part, s_tmp);
-  const double c = alpha[0] - b;
-  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS)
-    q[i] += c * sv[i];
-}
-
-// d = -q (or -g when restart); partials of d.g and d.d
-__global__ void __launch_bounds__(VEC_THREADS)
-k_vec_direction(size_t n, const double* __restrict__ q, const double* __restrict__ g, double* __restrict__ d,
-                double* __restrict__ part_dg, double* __restrict__ part_dd) {
+k_lb_direction(size_t n, LbSlots sl, LbCoef cf, const double* __restrict__ q, const double* __restrict__ S,
+               const double* __restrict__ Y, const double* __restrict__ g, double* __restrict__ d,
+               double* __restrict__ part_dg, double* __restrict__ part_dd) {
   __shared__ double s_tmp[4];
   double a = 0.0, b = 0.0;
   for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
-    const double di = -q[i];
+    double di = -cf.gamma * q[i];
+#pragma unroll
+    for (int k = 0; k < LB_M; ++k)
+      if (k < sl.n) di += cf.cy[k] * Y[(size_t)sl.slot[k] * n + i] - cf.cs[k] * S[(size_t)sl.slot[k] * n + i];
     d[i] = di;
     a += di * g[i];
     b += di * di;
@@ -612,10 +602,25 @@ k_vec_direction(size_t n, const double* __restrict__ q, const double* __restrict
   write_partial(b, part_dd, s_tmp);
 }
 
-// xn = clamp(x + step*d); pinned elements stay
+// xn = clamp(x + step*d), pinned elements stay.  step < 0: chosen here from |d| (every block reduces the same partials
+// in the same order): first iteration min(1, 1/|d|), later 1, never longer than max_step (solve_adept.cpp:331);
+// out[0] = step, out[1] = d.d, out[2] = d.g
 __global__ void __launch_bounds__(VEC_THREADS)
-k_vec_step(size_t n, double step, const double* __restrict__ x, const double* __restrict__ d,
-           const double* __restrict__ xmin, const double* __restrict__ xmax, double* __restrict__ xn) {
+k_lb_step(size_t n, double step, int first, double max_step, const double* __restrict__ part_dg,
+          const double* __restrict__ part_dd, const double* __restrict__ x, const double* __restrict__ d,
+          const double* __restrict__ xmin, const double* __restrict__ xmax, double* __restrict__ xn,
+          double* __restrict__ out) {
+  __shared__ double s_tmp[4];
+  if (step < 0.0) {
+    const double dd = sum_partials(part_dd, s_tmp);
+    const double dn = sqrt(dd);
+    step = first ? fmin(1.0, 1.0 / fmax(dn, 1e-300)) : 1.0;
+    if (step * dn > max_step) step = max_step / dn;
+    if (blockIdx.x == 0) {
+      const double dg = sum_partials(part_dg, s_tmp);
+      if (threadIdx.x == 0) { out[0] = step; out[1] = dd; out[2] = dg; }
+    }
+  }
   for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
     double v = x[i] + step * d[i];
     if (xmin) v = fmin(fmax(v, xmin[i]), xmax[i]);
@@ -624,32 +629,48 @@ k_vec_step(size_t n, double step, const double* __restrict__ x, const double* __
   }
 }
 
-// curvature pair s = xn - x, y = gn - g; partials of s.y and y.y
+// curvature pair s = xn - x, y = gn - g into its ring slot; partials [0] s.y, [1] y.y,
+// [2+a] s.Y_a, [2+LB_M+a] S_a.y, [2+2 LB_M+a] y.Y_a for the pairs that stay
 __global__ void __launch_bounds__(VEC_THREADS)
-k_vec_pair(size_t n, const double* __restrict__ x, const double* __restrict__ xn, const double* __restrict__ g,
-           const double* __restrict__ gn, double* __restrict__ sv, double* __restrict__ yv,
-           double* __restrict__ part_sy, double* __restrict__ part_yy) {
+k_lb_pair_dots(size_t n, LbSlots sl, int new_slot, const double* __restrict__ x, const double* __restrict__ xn,
+               const double* __restrict__ g, const double* __restrict__ gn, double* __restrict__ S,
+               double* __restrict__ Y, double* __restrict__ part) {
   __shared__ double s_tmp[4];
-  double a = 0.0, b = 0.0;
+  double sy = 0.0, yy = 0.0, a1[LB_M], a2[LB_M], a3[LB_M];
+#pragma unroll
+  for (int a = 0; a < LB_M; ++a) { a1[a] = 0.0; a2[a] = 0.0; a3[a] = 0.0; }
   for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
     const double si = xn[i] - x[i], yi = gn[i] - g[i];
-    sv[i] = si;
-    yv[i] = yi;
-    a += si * yi;
-    b += yi * yi;
+    sy += si * yi;
+    yy += yi * yi;
+#pragma unroll
+    for (int a = 0; a < LB_M; ++a)
+      if (a < sl.n) {
+        const double sa = S[(size_t)sl.slot[a] * n + i], ya = Y[(size_t)sl.slot[a] * n + i];
+        a1[a] += si * ya;
+        a2[a] += sa * yi;
+        a3[a] += yi * ya;
+      }
+    S[(size_t)new_slot * n + i] = si;     // the slot being written is never among the pairs that stay
+    Y[(size_t)new_slot * n + i] = yi;
   }
-  write_partial(a, part_sy, s_tmp);
-  write_partial(b, part_yy, s_tmp);
+  write_partial(sy, part, s_tmp);
+  write_partial(yy, part + VEC_BLOCKS, s_tmp);
+#pragma unroll
+  for (int a = 0; a < LB_M; ++a)
+    if (a < sl.n) {
+      write_partial(a1[a], part + (size_t)(2 + a) * VEC_BLOCKS, s_tmp);
+      write_partial(a2[a], part + (size_t)(2 + LB_M + a) * VEC_BLOCKS, s_tmp);
+      write_partial(a3[a], part + (size_t)(2 + 2 * LB_M + a) * VEC_BLOCKS, s_tmp);
+    }
 }
 
-// sums up to 4 partial arrays into out[0..m)
+// out[k] = sum of partial array k, k < m (one block)
 __global__ void __launch_bounds__(VEC_THREADS)
-k_vec_finish(int m, const double* __restrict__ p0, const double* __restrict__ p1, const double* __restrict__ p2,
-             const double* __restrict__ p3, double* __restrict__ out) {
+k_lb_finish(int m, const double* __restrict__ part, double* __restrict__ out) {
   __shared__ double s_tmp[4];
-  const double* ps[4] = {p0, p1, p2, p3};
   for (int k = 0; k < m; ++k) {
-    const double v = sum_partials(ps[k], s_tmp);
+    const double v = sum_partials(part + (size_t)k * VEC_BLOCKS, s_tmp);
     if (threadIdx.x == 0) out[k] = v;
     __syncthreads();
   }
@@ -685,7 +706,12 @@ struct ecckd_opt {
   double* d_tri = nullptr; int* d_tri_off = nullptr; double* d_inv_sigma2 = nullptr;
   double* d_od_out = nullptr; double* d_flux_out = nullptr;
   unsigned grad_blocks = 0;
-  std::vector<double> h_jcol, h_jb;
+  // pinned host staging: per-profile costs, per-node prior terms, L-BFGS scalars (pageable read-backs cost
+  // ~30 us each through the runtime's staging path)
+  double* h_pin = nullptr;
+  double* h_jcol = nullptr;   // [ncol]
+  double* h_jb = nullptr;     // [nnode_active]
+  double* h_rb = nullptr;     // [64] + [4]
   // device L-BFGS workspace (allocated by ecckd_opt_minimize)
   double *d_xmin = nullptr, *d_xmax = nullptr, *d_xn = nullptr, *d_gn = nullptr, *d_dir = nullptr, *d_q = nullptr;
   double *d_S = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sc = nullptr;
@@ -714,6 +740,7 @@ void opt_free(ecckd_opt* o) {
                   o->d_xn, o->d_gn, o->d_dir, o->d_q, o->d_S, o->d_Y, o->d_part, o->d_sc, o->d_mu0, o->d_rel};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (o->h_pin) (void)hipHostFree(o->h_pin);
   delete o;
 }
 
@@ -1110,8 +1137,10 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
     opt_free(o);
     return ecckd::fail(ECCKD_OUT_OF_MEMORY, "ecckd_opt_create: device allocation failed");
   }
-  o->h_jcol.resize(ncol);
-  o->h_jb.resize(o->nnode_active);
+  ECCKD_HIP_CHECK(hipHostMalloc((void**)&o->h_pin, (ncol + o->nnode_active + 72) * sizeof(double), hipHostMallocDefault));
+  o->h_jcol = o->h_pin;
+  o->h_jb = o->h_pin + ncol;
+  o->h_rb = o->h_jb + o->nnode_active;
   // x_prior = ln k0 (MIN_X where k0 <= 0), solve_adept.cpp:335-341
   std::vector<double> xp(o->nx);
   for (size_t e = 0; e < o->nx; ++e) xp[e] = o->h_k0[e] > 0.0 ? std::log(o->h_k0[e]) : MIN_X;
@@ -1185,13 +1214,13 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
                      o->d_node_it, o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2,
                      o->have_prior ? 1 : 0, d_grad, o->d_jb);
   ECCKD_HIP_CHECK(hipGetLastError());
-  ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jcol.data(), o->d_jcol, o->ncol * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jb.data(), o->d_jb, o->nnode_active * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jcol, o->d_jcol, o->ncol * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jb, o->d_jb, o->nnode_active * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   double j = 0.0;
-  for (double v : o->h_jcol) j += v;  // scene/profile order, as the reference accumulates (:157)
+  for (size_t c = 0; c < o->ncol; ++c) j += o->h_jcol[c];  // scene/profile order, as the reference accumulates (:157)
   double jb = 0.0;
-  for (double v : o->h_jb) jb += v;
+  for (size_t c = 0; c < o->nnode_active; ++c) jb += o->h_jb[c];
   *J = j + jb;
   o->n_eval++;
   return ECCKD_OK;
@@ -1245,9 +1274,9 @@ int ecckd_opt_coefficients(ecckd_opt* o, const double* h_x, int gas, double* h_m
 
 // ---------------------------------------------------------------------------------------
 // solve_adept (solve_adept.cpp:310-417).  adept::Minimizer is a third-party L-BFGS that is not
-// available here (trajectory parity unpinned); this is a standard L-BFGS (m = 6,
-// two-loop recursion) with Armijo backtracking + curvature-guarded updates, the step capped at
-// max_step_size = 2 in the 2-norm (:331) and simple projection onto [x_min, x_max] when
+// available here (trajectory parity unpinned); this is a standard L-BFGS (m = 6, compact
+// representation, see the k_lb_* kernels) with Armijo backtracking + curvature-guarded updates, the step
+// capped at max_step_size = 2 in the 2-norm (:331) and simple projection onto [x_min, x_max] when
 // bounded (:344-353).  Status values follow adept::MinimizerStatus (0 success, 2 max
 // iterations, 3 failed to converge, 6 invalid cost function, 7 invalid gradient).
 int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_criterion, int is_bounded,
@@ -1256,7 +1285,7 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   ecckd_ctx* ctx = o->ctx;
   ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
   const size_t n = o->nx;
-  const int M = 6;
+  constexpr int M = LB_M;
   // state, bounds and history live on the device; the host only sees scalars
   std::vector<double> x0(n), xmin, xmax;
   const bool bounded = is_bounded && !o->h_kmin.empty();
@@ -1271,9 +1300,10 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
     ECCKD_HIP_CHECK(hipMalloc((void**)p, cnt * sizeof(double)));
     return ECCKD_OK;
   };
+  constexpr int NPART = 3 + 5 * M;   // project/dots: 1 + 2M | pair: 2 + 3M
   ECCKD_CHECK(dalloc(&o->d_xn, n)); ECCKD_CHECK(dalloc(&o->d_gn, n)); ECCKD_CHECK(dalloc(&o->d_dir, n));
   ECCKD_CHECK(dalloc(&o->d_q, n)); ECCKD_CHECK(dalloc(&o->d_S, (size_t)M * n)); ECCKD_CHECK(dalloc(&o->d_Y, (size_t)M * n));
-  ECCKD_CHECK(dalloc(&o->d_part, 4 * VEC_BLOCKS)); ECCKD_CHECK(dalloc(&o->d_sc, 64));
+  ECCKD_CHECK(dalloc(&o->d_part, (size_t)(NPART + 2) * VEC_BLOCKS)); ECCKD_CHECK(dalloc(&o->d_sc, 64));
   if (bounded) {
     ECCKD_CHECK(dalloc(&o->d_xmin, n)); ECCKD_CHECK(dalloc(&o->d_xmax, n));
     ECCKD_HIP_CHECK(hipMemcpyAsync(o->d_xmin, xmin.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1283,89 +1313,149 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   const double* bmin = bounded ? o->d_xmin : nullptr;
   const double* bmax = bounded ? o->d_xmax : nullptr;
   double* x = o->d_x; double* g = o->d_grad; double* xn = o->d_xn; double* gn = o->d_gn;
-  double* part = o->d_part;                 // 4 partial arrays
-  // device scalars: sc[0..M) rho, sc[M..2M) alpha, sc[2M] gamma, sc[32..36) readback
+  double* part_a = o->d_part;                                  // project + dots: 1 + 2M partial arrays
+  double* part_p = o->d_part + (size_t)(1 + 2 * M) * VEC_BLOCKS;   // pair: 2 + 3M
+  double* part_dg = o->d_part + (size_t)NPART * VEC_BLOCKS;
+  double* part_dd = part_dg + VEC_BLOCKS;
+  // device scalars read back: [0 .. 1+2M) direction dots, [1+2M .. 3+5M) pair dots, [56..59) step, d.d, d.g
   double* sc = o->d_sc;
-  double* sc_rho = sc; double* sc_alpha = sc + M; double* sc_gamma = sc + 2 * M; double* sc_rb = sc + 32;
-  double h_rb[4];
-  auto readback = [&](int m) -> int {
-    ECCKD_HIP_CHECK(hipMemcpyAsync(h_rb, sc_rb, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return ECCKD_OK;
-  };
+  double* sc_step = sc + 56;
+  double* h_rb = o->h_rb;
+  double* h_step = o->h_rb + 64;
   const dim3 vb(VEC_BLOCKS), vt(VEC_THREADS);
+  const double max_step = 2.0;  // minimizer.set_max_step_size(2.0), solve_adept.cpp:331
+
+  // host side of the compact representation: S^T Y and Y^T Y of the stored pairs, by ring slot
+  double SY[M][M] = {}, YY[M][M] = {};
+  int ord[M];        // ring slots, oldest first
+  int hist = 0;
+  double gamma = 1.0;
+  bool pending = false;   // a pair has been written to `pend_slot`; its dots are read with the next direction
+  int pend_slot = 0;
 
   double J = 0.0;
   ECCKD_CHECK(opt_cost_grad_dev(o, x, g, &J));
-  int st = 2, it = 0, hist = 0, head = 0;   // ring buffer: slot of pair j (0 = oldest) is (head + j) % M
+  int st = 2, it = 0;
   double gnorm = 0.0;
   if (!(J == J)) { *status = 6; if (J_final) *J_final = J; return ECCKD_OK; }
   for (it = 0; it <= max_iterations; ++it) {
-    // projected gradient and its norm
-    hipLaunchKernelGGL(k_vec_project, vb, vt, 0, ctx->stream, n, x, g, bmin, bmax, o->d_q, part);
-    // two-loop recursion (solve with the L-BFGS inverse Hessian), all on the device
-    for (int j = hist - 1; j >= 0; --j) {
-      const int slot = (head + j) % M;
-      hipLaunchKernelGGL(k_vec_dot, vb, vt, 0, ctx->stream, n, o->d_S + (size_t)slot * n, o->d_q, part + VEC_BLOCKS);
-      hipLaunchKernelGGL(k_vec_loop1, vb, vt, 0, ctx->stream, n, part + VEC_BLOCKS, sc_rho + slot, sc_alpha + slot,
-                         o->d_Y + (size_t)slot * n, o->d_q);
-    }
-    if (hist > 0) hipLaunchKernelGGL(k_vec_scale, vb, vt, 0, ctx->stream, n, sc_gamma, o->d_q);
-    for (int j = 0; j < hist; ++j) {
-      const int slot = (head + j) % M;
-      hipLaunchKernelGGL(k_vec_dot, vb, vt, 0, ctx->stream, n, o->d_Y + (size_t)slot * n, o->d_q, part + VEC_BLOCKS);
-      hipLaunchKernelGGL(k_vec_loop2, vb, vt, 0, ctx->stream, n, part + VEC_BLOCKS, sc_rho + slot, sc_alpha + slot,
-                         o->d_S + (size_t)slot * n, o->d_q);
-    }
-    hipLaunchKernelGGL(k_vec_direction, vb, vt, 0, ctx->stream, n, o->d_q, g, o->d_dir, part + 2 * VEC_BLOCKS,
-                       part + 3 * VEC_BLOCKS);
-    hipLaunchKernelGGL(k_vec_finish, dim3(1), vt, 0, ctx->stream, 3, part, part + 2 * VEC_BLOCKS, part + 3 * VEC_BLOCKS,
-                       part, sc_rb);
+    // projected gradient, its norm and S^T q, Y^T q in one pass (the pending pair included, as the newest)
+    LbSlots sl;
+    sl.n = hist + (pending ? 1 : 0);
+    for (int a = 0; a < hist; ++a) sl.slot[a] = ord[a];
+    if (pending) sl.slot[hist] = pend_slot;
+    for (int a = sl.n; a < M; ++a) sl.slot[a] = 0;
+    hipLaunchKernelGGL(k_lb_project_dots, vb, vt, 0, ctx->stream, n, sl, x, g, bmin, bmax, o->d_q, o->d_S, o->d_Y, part_a);
+    hipLaunchKernelGGL(k_lb_finish, dim3(1), vt, 0, ctx->stream, 1 + 2 * M, part_a, sc);
     ECCKD_HIP_CHECK(hipGetLastError());
-    ECCKD_CHECK(readback(3));
+    ECCKD_HIP_CHECK(hipMemcpyAsync(h_rb, sc, (size_t)(3 + 5 * M) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    int npairs = hist;           // pairs that enter this direction
+    if (pending) {
+      const double* rp = h_rb + 1 + 2 * M;   // s.y, y.y, s.Y_a, S_a.y, y.Y_a for a < hist
+      const double sy = rp[0], yy = rp[1];
+      if (sy > 1.0e-12) {
+        for (int a = 0; a < hist; ++a) {
+          SY[pend_slot][ord[a]] = rp[2 + a];
+          SY[ord[a]][pend_slot] = rp[2 + M + a];
+          YY[pend_slot][ord[a]] = YY[ord[a]][pend_slot] = rp[2 + 2 * M + a];
+        }
+        SY[pend_slot][pend_slot] = sy;
+        YY[pend_slot][pend_slot] = yy;
+        ord[hist++] = pend_slot;
+        gamma = sy / yy;
+        npairs = hist;
+      }
+      pending = false;
+    }
     gnorm = std::sqrt(h_rb[0]);
-    double dg = h_rb[1], dn = std::sqrt(h_rb[2]);
     if (!(gnorm == gnorm)) { st = 7; break; }
     if (gnorm <= convergence_criterion) { st = 0; break; }
     if (it == max_iterations) { st = 2; break; }
-    if (!(dg < 0.0)) {
-      // not a descent direction: drop the history, steepest descent on the projected gradient
-      hist = 0; head = 0;
-      hipLaunchKernelGGL(k_vec_project, vb, vt, 0, ctx->stream, n, x, g, bmin, bmax, o->d_q, part);
-      hipLaunchKernelGGL(k_vec_direction, vb, vt, 0, ctx->stream, n, o->d_q, g, o->d_dir, part + 2 * VEC_BLOCKS,
-                         part + 3 * VEC_BLOCKS);
-      hipLaunchKernelGGL(k_vec_finish, dim3(1), vt, 0, ctx->stream, 3, part, part + 2 * VEC_BLOCKS,
-                         part + 3 * VEC_BLOCKS, part, sc_rb);
-      ECCKD_CHECK(readback(3));
-      dg = h_rb[1]; dn = std::sqrt(h_rb[2]);
-      if (!(dg < 0.0)) { st = 0; break; }  // projected gradient is zero
-    }
-    double step = (hist == 0) ? std::min(1.0, 1.0 / std::max(dn, 1e-300)) : 1.0;
-    const double max_step = 2.0;  // minimizer.set_max_step_size(2.0), solve_adept.cpp:331
-    if (step * dn > max_step) step = max_step / dn;
-    double Jn = J;
+
+    bool restarted = false;
+    double Jn = J, step = 0.0, dg = 0.0;
     bool ok = false;
-    for (int ls = 0; ls < 30; ++ls) {
-      hipLaunchKernelGGL(k_vec_step, vb, vt, 0, ctx->stream, n, step, x, o->d_dir, bmin, bmax, xn);
+    for (;;) {
+      // coefficients of the direction: u = R^-1 p, top = R^-T ((D + gamma YY) u - gamma qy)
+      LbCoef cf;
+      cf.gamma = npairs > 0 ? gamma : 1.0;
+      for (int a = 0; a < M; ++a) { cf.cs[a] = 0.0; cf.cy[a] = 0.0; }
+      LbSlots sd;
+      sd.n = npairs;
+      for (int a = 0; a < M; ++a) sd.slot[a] = a < npairs ? ord[a] : 0;
+      if (npairs > 0) {
+        double pv[M], qv[M], u[M], w[M], top[M];
+        for (int a = 0; a < npairs; ++a) {
+          // position of pair a in the dot arrays of this iteration: the stored pairs first, the pending one last
+          pv[a] = h_rb[1 + a];
+          qv[a] = h_rb[1 + M + a];
+        }
+        for (int a = npairs - 1; a >= 0; --a) {
+          double v = pv[a];
+          for (int c = a + 1; c < npairs; ++c) v -= SY[ord[a]][ord[c]] * u[c];
+          u[a] = v / SY[ord[a]][ord[a]];
+        }
+        for (int a = 0; a < npairs; ++a) {
+          double v = SY[ord[a]][ord[a]] * u[a] - cf.gamma * qv[a];
+          for (int c = 0; c < npairs; ++c) v += cf.gamma * YY[ord[a]][ord[c]] * u[c];
+          w[a] = v;
+        }
+        for (int a = 0; a < npairs; ++a) {
+          double v = w[a];
+          for (int c = 0; c < a; ++c) v -= SY[ord[c]][ord[a]] * top[c];
+          top[a] = v / SY[ord[a]][ord[a]];
+        }
+        for (int a = 0; a < npairs; ++a) { cf.cs[a] = top[a]; cf.cy[a] = cf.gamma * u[a]; }
+      }
+      hipLaunchKernelGGL(k_lb_direction, vb, vt, 0, ctx->stream, n, sd, cf, o->d_q, o->d_S, o->d_Y, g, o->d_dir, part_dg, part_dd);
+      // the trial point with the step chosen on the device, then the cost there; one synchronisation for both
+      hipLaunchKernelGGL(k_lb_step, vb, vt, 0, ctx->stream, n, -1.0, npairs == 0 ? 1 : 0, max_step, part_dg, part_dd, x,
+                         o->d_dir, bmin, bmax, xn, sc_step);
+      ECCKD_HIP_CHECK(hipGetLastError());
+      ECCKD_HIP_CHECK(hipMemcpyAsync(h_step, sc_step, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
       ECCKD_CHECK(opt_cost_grad_dev(o, xn, gn, &Jn));
-      if (Jn == Jn && Jn <= J + 1.0e-4 * step * dg) { ok = true; break; }
-      step *= 0.5;
+      step = h_step[0];
+      dg = h_step[2];
+      if (!(dg < 0.0)) {
+        // not a descent direction: drop the history, steepest descent on the projected gradient
+        if (restarted || npairs == 0) { ok = false; st = 0; break; }   // projected gradient is zero
+        restarted = true;
+        hist = 0;
+        npairs = 0;
+        continue;
+      }
+      ok = (Jn == Jn && Jn <= J + 1.0e-4 * step * dg);
+      for (int ls = 1; !ok && ls < 30; ++ls) {
+        step *= 0.5;
+        hipLaunchKernelGGL(k_lb_step, vb, vt, 0, ctx->stream, n, step, 0, max_step, part_dg, part_dd, x, o->d_dir, bmin,
+                           bmax, xn, sc_step);
+        ECCKD_CHECK(opt_cost_grad_dev(o, xn, gn, &Jn));
+        ok = (Jn == Jn && Jn <= J + 1.0e-4 * step * dg);
+      }
+      if (!ok) st = 3;
+      break;
     }
-    if (!ok) { st = 3; break; }
-    // curvature pair into the next ring slot
-    const int slot = (hist < M) ? (head + hist) % M : head;
-    hipLaunchKernelGGL(k_vec_pair, vb, vt, 0, ctx->stream, n, x, xn, g, gn, o->d_S + (size_t)slot * n,
-                       o->d_Y + (size_t)slot * n, part, part + VEC_BLOCKS);
-    hipLaunchKernelGGL(k_vec_finish, dim3(1), vt, 0, ctx->stream, 2, part, part + VEC_BLOCKS, part, part, sc_rb);
-    ECCKD_CHECK(readback(2));
-    const double sy = h_rb[0], yy = h_rb[1];
-    if (sy > 1.0e-12) {
-      const double rho_gamma[2] = {1.0 / sy, sy / yy};
-      ECCKD_HIP_CHECK(hipMemcpyAsync(sc_rho + slot, &rho_gamma[0], sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-      ECCKD_HIP_CHECK(hipMemcpyAsync(sc_gamma, &rho_gamma[1], sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-      ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // rho_gamma is a stack temporary
-      if (hist < M) ++hist; else head = (head + 1) % M;
+    if (!ok) break;
+    // curvature pair into the next ring slot (replacing the oldest when the ring is full); its dots with the pairs
+    // that stay are read back together with the next direction's
+    if (hist == M) {
+      pend_slot = ord[0];
+      for (int a = 1; a < M; ++a) ord[a - 1] = ord[a];
+      --hist;
+    } else {
+      bool used[M] = {};
+      for (int a = 0; a < hist; ++a) used[ord[a]] = true;
+      pend_slot = 0;
+      while (used[pend_slot]) ++pend_slot;
     }
+    LbSlots sp;
+    sp.n = hist;
+    for (int a = 0; a < M; ++a) sp.slot[a] = a < hist ? ord[a] : 0;
+    hipLaunchKernelGGL(k_lb_pair_dots, vb, vt, 0, ctx->stream, n, sp, pend_slot, x, xn, g, gn, o->d_S, o->d_Y, part_p);
+    hipLaunchKernelGGL(k_lb_finish, dim3(1), vt, 0, ctx->stream, 2 + 3 * M, part_p, sc + 1 + 2 * M);
+    ECCKD_HIP_CHECK(hipGetLastError());
+    pending = true;
     std::swap(x, xn);
     std::swap(g, gn);
     J = Jn;
@@ -1378,7 +1468,6 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   if (gnorm_final) *gnorm_final = gnorm;
   return ECCKD_OK;
 }
-
 
 // ---------------------------------------------------------------------------------------
 // run_ckd (run_ckd.cpp:27-373): evaluate a CKD model on a set of profiles.  The gas optical depths
