@@ -30,6 +30,7 @@
 // The dominant costs are launch latency and ~50 MB of traffic per iteration;
 // the metric is iterations per second.
 #include "common.hpp"
+#include "fastmath.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -146,7 +147,22 @@ __global__ void k_opt_forward_adjoint(
       const int* ei = ent_idx + (cell0 + l) * nent;
       const double* ec = ent_coef + (cell0 + l) * nent;
       double tau = 0.0, tau_ray = 0.0;
-      for (int e = 0; e < nent; ++e) {
+      // four entries at a time: the index -> coefficient loads of a batch are independent, so their (L2) latencies
+      // overlap; the products are still added in entry order, absent entries (idx < 0) add an exact zero
+      int e = 0;
+      for (; e + 4 <= nent; e += 4) {
+        const int i0 = ei[e], i1 = ei[e + 1], i2 = ei[e + 2], i3 = ei[e + 3];
+        const double c0 = ec[e], c1 = ec[e + 1], c2 = ec[e + 2], c3 = ec[e + 3];
+        const double k0 = i0 >= 0 ? k[(size_t)i0 + g] : 0.0, k1 = i1 >= 0 ? k[(size_t)i1 + g] : 0.0;
+        const double k2 = i2 >= 0 ? k[(size_t)i2 + g] : 0.0, k3 = i3 >= 0 ? k[(size_t)i3 + g] : 0.0;
+        const double t0 = i0 >= 0 ? c0 * k0 : 0.0, t1 = i1 >= 0 ? c1 * k1 : 0.0;
+        const double t2 = i2 >= 0 ? c2 * k2 : 0.0, t3 = i3 >= 0 ? c3 * k3 : 0.0;
+        if (e == ray_ent) tau_ray = t0; else tau += t0;
+        if (e + 1 == ray_ent) tau_ray = t1; else tau += t1;
+        if (e + 2 == ray_ent) tau_ray = t2; else tau += t2;
+        if (e + 3 == ray_ent) tau_ray = t3; else tau += t3;
+      }
+      for (; e < nent; ++e) {
         const int idx = ei[e];
         if (idx >= 0) {
           if (e == ray_ent) tau_ray = ec[e] * k[(size_t)idx + g];
@@ -189,8 +205,8 @@ __global__ void k_opt_forward_adjoint(
     s_fdn[g] = 0.0;
     for (int l = 0; l < nlay; ++l) {
       const double tau = s_tau[l * ng + g];
-      const double eps = 1.0 - exp(-kD * tau);
-      const double fac = (eps > 1.0e-5) ? 1.0 - eps * (1.0 / kD) / tau : 0.5 * eps;
+      const double eps = 1.0 - ecckd::exp_fast(-kD * tau);
+      const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;
       dn = dn * (1.0 - eps) + pl[l * ng + g] * (eps - fac) + pl[(l + 1) * ng + g] * fac;
       s_fdn[(l + 1) * ng + g] = dn;
     }
@@ -199,8 +215,8 @@ __global__ void k_opt_forward_adjoint(
     s_fup[nlay * ng + g] = up;
     for (int l = nlay - 1; l >= 0; --l) {
       const double tau = s_tau[l * ng + g];
-      const double eps = 1.0 - exp(-kD * tau);
-      const double fac = (eps > 1.0e-5) ? 1.0 - eps * (1.0 / kD) / tau : 0.5 * eps;
+      const double eps = 1.0 - ecckd::exp_fast(-kD * tau);
+      const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;
       up = up * (1.0 - eps) + pl[(l + 1) * ng + g] * (eps - fac) + pl[l * ng + g] * fac;
       s_fup[l * ng + g] = up;
     }
@@ -372,7 +388,7 @@ __global__ void k_opt_forward_adjoint(
     // (the forward values are re-generated from the surface in the combine loop below).
     double up_bar = s_gup[b] + g_up_toa_extra;  // level 0
     for (int l = 0; l < nlay; ++l) {
-      const double eps = 1.0 - exp(-kD * s_tau[l * ng + g]);
+      const double eps = 1.0 - ecckd::exp_fast(-kD * s_tau[l * ng + g]);
       s_fup[l * ng + g] = up_bar;
       up_bar = up_bar * (1.0 - eps) + s_gup[(l + 1) * nband + b];
     }
@@ -383,10 +399,11 @@ __global__ void k_opt_forward_adjoint(
     for (int l = nlay - 1; l >= 0; --l) {
       const bool clamped = s_clamp[l * ng + g] != 0;
       const double tau = s_tau[l * ng + g];
-      const double ex = exp(-kD * tau);
+      const double ex = ecckd::exp_fast(-kD * tau);
       const double eps = 1.0 - ex;
       const bool thick = eps > 1.0e-5;
-      const double fac = thick ? 1.0 - eps * (1.0 / kD) / tau : 0.5 * eps;
+      const double rtau = thick ? ecckd::div_fast(1.0 / kD, tau) : 0.0;      // 1 / (D tau)
+      const double fac = thick ? 1.0 - eps * rtau : 0.5 * eps;
       const double b0 = pl[l * ng + g], b1 = pl[(l + 1) * ng + g];
       const double ubar_l = s_fup[l * ng + g];  // adjoint of up[l]
       const double dn_l = s_fdn[l * ng + g];
@@ -399,8 +416,8 @@ __global__ void k_opt_forward_adjoint(
       const double eps_bar = -t_bar + a_bar;
       const double fac_bar = f_bar - a_bar;
       // fac(eps, tau): thick: 1 - eps/(D tau); thin: eps/2   (radiative_transfer_lw.cpp:42-43)
-      const double dfac_deps = thick ? -(1.0 / kD) / tau : 0.5;
-      const double dfac_dtau = thick ? eps * (1.0 / kD) / (tau * tau) : 0.0;
+      const double dfac_deps = thick ? -rtau : 0.5;
+      const double dfac_dtau = thick ? eps * rtau * (kD * rtau) : 0.0;        // eps / (D tau^2)
       const double tau_bar = (eps_bar + fac_bar * dfac_deps) * (kD * ex) + fac_bar * dfac_dtau;
       if (!clamped) dtau[(cell0 + l) * ng + g] = tau_bar;
       // propagate
@@ -439,8 +456,22 @@ k_opt_gradient(size_t nnode, int ng, int ngpad, const double* __restrict__ x, co
   const int nrg = blockDim.x / ngpad;
   double* s4 = s_acc + (size_t)nrg * ngpad;
   double part = 0.0;
-  if (g < ng)
-    for (int r = ref_ptr[node] + rg; r < ref_ptr[node + 1]; r += nrg) part += ref_coef[r] * dtau[(size_t)ref_cell[r] * ng + g];
+  if (g < ng) {
+    // four references at a time (independent cell -> dtau loads in flight together), added in reference order
+    const int r1 = ref_ptr[node + 1];
+    int r = ref_ptr[node] + rg;
+    for (; r + 3 * nrg < r1; r += 4 * nrg) {
+      const int c0 = ref_cell[r], c1 = ref_cell[r + nrg], c2 = ref_cell[r + 2 * nrg], c3 = ref_cell[r + 3 * nrg];
+      const double w0 = ref_coef[r], w1 = ref_coef[r + nrg], w2 = ref_coef[r + 2 * nrg], w3 = ref_coef[r + 3 * nrg];
+      const double d0 = dtau[(size_t)c0 * ng + g], d1 = dtau[(size_t)c1 * ng + g];
+      const double d2 = dtau[(size_t)c2 * ng + g], d3 = dtau[(size_t)c3 * ng + g];
+      part += w0 * d0;
+      part += w1 * d1;
+      part += w2 * d2;
+      part += w3 * d3;
+    }
+    for (; r < r1; r += nrg) part += ref_coef[r] * dtau[(size_t)ref_cell[r] * ng + g];
+  }
   s_acc[rg * ngpad + g] = part;
   __syncthreads();
   double jb = 0.0;
