@@ -147,20 +147,34 @@ __global__ void k_opt_forward_adjoint(
       const int* ei = ent_idx + (cell0 + l) * nent;
       const double* ec = ent_coef + (cell0 + l) * nent;
       double tau = 0.0, tau_ray = 0.0;
-      // four entries at a time: the index -> coefficient loads of a batch are independent, so their (L2) latencies
+      // eight (then four) entries at a time: the index -> coefficient loads of a batch are independent, so their (L2) latencies
       // overlap; the products are still added in entry order, absent entries (idx < 0) add an exact zero
       int e = 0;
+      for (; e + 8 <= nent; e += 8) {
+        int ix[8];
+        double cv[8], kv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { ix[q] = ei[e + q]; cv[q] = ec[e + q]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) kv[q] = ix[q] >= 0 ? k[(size_t)ix[q] + g] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const double t = ix[q] >= 0 ? cv[q] * kv[q] : 0.0;
+          if (e + q == ray_ent) tau_ray = t; else tau += t;
+        }
+      }
       for (; e + 4 <= nent; e += 4) {
-        const int i0 = ei[e], i1 = ei[e + 1], i2 = ei[e + 2], i3 = ei[e + 3];
-        const double c0 = ec[e], c1 = ec[e + 1], c2 = ec[e + 2], c3 = ec[e + 3];
-        const double k0 = i0 >= 0 ? k[(size_t)i0 + g] : 0.0, k1 = i1 >= 0 ? k[(size_t)i1 + g] : 0.0;
-        const double k2 = i2 >= 0 ? k[(size_t)i2 + g] : 0.0, k3 = i3 >= 0 ? k[(size_t)i3 + g] : 0.0;
-        const double t0 = i0 >= 0 ? c0 * k0 : 0.0, t1 = i1 >= 0 ? c1 * k1 : 0.0;
-        const double t2 = i2 >= 0 ? c2 * k2 : 0.0, t3 = i3 >= 0 ? c3 * k3 : 0.0;
-        if (e == ray_ent) tau_ray = t0; else tau += t0;
-        if (e + 1 == ray_ent) tau_ray = t1; else tau += t1;
-        if (e + 2 == ray_ent) tau_ray = t2; else tau += t2;
-        if (e + 3 == ray_ent) tau_ray = t3; else tau += t3;
+        int ix[4];
+        double cv[4], kv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ix[q] = ei[e + q]; cv[q] = ec[e + q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kv[q] = ix[q] >= 0 ? k[(size_t)ix[q] + g] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double t = ix[q] >= 0 ? cv[q] * kv[q] : 0.0;
+          if (e + q == ray_ent) tau_ray = t; else tau += t;
+        }
       }
       for (; e < nent; ++e) {
         const int idx = ei[e];
@@ -229,14 +243,14 @@ __global__ void k_opt_forward_adjoint(
     double dn = cos_sza * pl[g];
     s_fdn[g] = dn;
     for (int l = 0; l < nlay; ++l) {
-      dn = dn * exp(minus_sec_sza * s_tau[l * ng + g]);
+      dn = dn * ecckd::exp_fast(minus_sec_sza * s_tau[l * ng + g]);
       s_fdn[(l + 1) * ng + g] = dn;
     }
     const double alb = all_nonpos ? 0.0 : surf_emis[(size_t)col * nband + band_of_g[g]];
     double up = dn * alb;
     s_fup[nlay * ng + g] = up;
     for (int l = nlay - 1; l >= 0; --l) {
-      up = up * exp(-2.0 * s_tau[l * ng + g]);
+      up = up * ecckd::exp_fast(-2.0 * s_tau[l * ng + g]);
       s_fup[l * ng + g] = up;
     }
   }
@@ -357,7 +371,7 @@ __global__ void k_opt_forward_adjoint(
     for (int l = 0; l < nlay; ++l) {
       const double tau = s_tau[l * ng + g];
       if (s_clamp[l * ng + g] == 0) dtau[(cell0 + l) * ng + g] = up_bar * s_fup[l * ng + g] * (-2.0);
-      up_bar = up_bar * exp(-2.0 * tau) + s_gup[(l + 1) * nband + b];
+      up_bar = up_bar * ecckd::exp_fast(-2.0 * tau) + s_gup[(l + 1) * nband + b];
     }
     // dn_{l+1} = dn_l * exp(-tau_l / mu0): d dn_{l+1} / d tau_l = -dn_{l+1} / mu0
     const double minus_sec_sza = -1.0 / cos_sza;
@@ -365,7 +379,7 @@ __global__ void k_opt_forward_adjoint(
     for (int l = nlay - 1; l >= 0; --l) {
       const double tau = s_tau[l * ng + g];
       if (s_clamp[l * ng + g] == 0) dtau[(cell0 + l) * ng + g] += dn_bar * s_fdn[(l + 1) * ng + g] * minus_sec_sza;
-      dn_bar = dn_bar * exp(minus_sec_sza * tau) + s_gdn[l * nband + b];
+      dn_bar = dn_bar * ecckd::exp_fast(minus_sec_sza * tau) + s_gdn[l * nband + b];
     }
   }
   if (live && !do_sw) {
