@@ -332,7 +332,12 @@ k_interval_sums(int nrows, size_t ntiles, const Interval* __restrict__ iv,
   } else {
     const long long head_end = t1 * TILE;  // exclusive
     if (i1 + tid < head_end) acc += row[i1 + tid];
-    for (long long t = t1 + tid; t < t2; t += 256) acc += trow[t];
+    long long t = t1 + tid;
+    for (; t + 768 < t2; t += 1024) {   // four tile sums at a time, added in tile order
+      const double q0 = trow[t], q1 = trow[t + 256], q2 = trow[t + 512], q3 = trow[t + 768];
+      acc += q0; acc += q1; acc += q2; acc += q3;
+    }
+    for (; t < t2; t += 256) acc += trow[t];
     const long long tail = t2 * TILE + tid;
     if (tail <= i2) acc += row[tail];
   }
@@ -729,7 +734,14 @@ k_cost_lw(int nlay, RowMap R, const Interval* __restrict__ iv, long long nchunks
   const int g = tid >> 7, t = tid & 127;
   for (int v = t; v < nv; v += 128) {
     double a = 0.0;
-    for (long long c = c0 + g; c < c1; c += 8) a += partial[(size_t)c * nv + v];
+    // four chunks at a time: independent loads in flight together, added in chunk order
+    long long c = c0 + g;
+    for (; c + 24 < c1; c += 32) {
+      const double p0 = partial[(size_t)c * nv + v], p1 = partial[(size_t)(c + 8) * nv + v];
+      const double p2 = partial[(size_t)(c + 16) * nv + v], p3 = partial[(size_t)(c + 24) * nv + v];
+      a += p0; a += p1; a += p2; a += p3;
+    }
+    for (; c < c1; c += 8) a += partial[(size_t)c * nv + v];
     s_grp[g * nv + v] = a;
   }
   __syncthreads();
@@ -1101,7 +1113,14 @@ k_cost_sw(int nlay, int ntotal, int rH, int rFDS, int rFUT, const Interval* __re
   const int g = tid >> 7, t = tid & 127;
   for (int v = t; v < nv; v += 128) {
     double a = 0.0;
-    for (long long c = c0 + g; c < c1; c += 8) a += partial[(size_t)c * nv + v];
+    // four chunks at a time: independent loads in flight together, added in chunk order
+    long long c = c0 + g;
+    for (; c + 24 < c1; c += 32) {
+      const double p0 = partial[(size_t)c * nv + v], p1 = partial[(size_t)(c + 8) * nv + v];
+      const double p2 = partial[(size_t)(c + 16) * nv + v], p3 = partial[(size_t)(c + 24) * nv + v];
+      a += p0; a += p1; a += p2; a += p3;
+    }
+    for (; c < c1; c += 8) a += partial[(size_t)c * nv + v];
     s_grp[g * nv + v] = a;
   }
   __syncthreads();
