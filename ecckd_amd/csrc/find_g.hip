@@ -1723,6 +1723,10 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   double* d_err = (double*)w;
   Interval* h_iv = (Interval*)g->pinned;
   double* h_err = (double*)((char*)g->pinned + iv_bytes);
+  // the errors are written straight into the pinned host buffer by the last kernel (a few bytes over PCIe): no
+  // device-to-host copy in the stream
+  double* h_err_dev = nullptr;
+  ECCKD_HIP_CHECK(hipHostGetDevicePointer((void**)&h_err_dev, h_err, 0));
   std::memcpy(h_iv, iv.data(), (size_t)n * sizeof(Interval));
   ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, h_iv, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
 
@@ -1780,9 +1784,8 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
   const size_t cost_lds = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
   hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, ctx->stream, nlay, g->rm, d_iv,
-                     nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, d_err);
+                     nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, h_err_dev);
   ECCKD_HIP_CHECK(hipGetLastError());
-  ECCKD_HIP_CHECK(hipMemcpyAsync(h_err, d_err, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   std::memcpy(error, h_err, (size_t)n * sizeof(double));
   if (ctx->profile) {
