@@ -1698,7 +1698,8 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   const bool fast_path = (nlay == 54 || nlay == 30);
   // mirror path: 3 resident blocks per CU (3 waves/SIMD) -> one wave of blocks; more chunks shorten K5c a
   // little but lengthen the ordered combine in K5d by more
-  long long target_blocks = (long long)ctx->num_cu * (fast_path ? 3 : 8);
+  static const int rt_bpc = std::getenv("ECCKD_RT_BPC") ? std::max(1, std::atoi(std::getenv("ECCKD_RT_BPC"))) : 3;   // tuning knob
+  long long target_blocks = (long long)ctx->num_cu * (fast_path ? rt_bpc : 8);
   long long chunk_pts = (total_pts + target_blocks - 1) / target_blocks;
   chunk_pts = (chunk_pts + RT_THREADS - 1) / RT_THREADS * RT_THREADS;
   if (chunk_pts < RT_THREADS) chunk_pts = RT_THREADS;
