@@ -294,13 +294,28 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
 __global__ void __launch_bounds__(TILE)
 k_tile_sums(int nrows, size_t n, size_t ntiles, const double* const* __restrict__ rows,
             double* __restrict__ ts) {
-  __shared__ double s4[4];
+  // four rows per round: four independent loads in flight, one barrier pair for the four block sums; each sum is the
+  // same tree as block_sum_256 (wave shuffle tree, then ((w0 + w1) + w2) + w3)
+  __shared__ double s4[4][4];
   const size_t t = blockIdx.x;
   const size_t i = t * TILE + threadIdx.x;
-  for (int r = 0; r < nrows; ++r) {
-    const double v = (i < n) ? rows[r][i] : 0.0;
-    const double s = block_sum_256(v, s4);
-    if (threadIdx.x == 0) ts[(size_t)r * ntiles + t] = s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r0 = 0; r0 < nrows; r0 += 4) {
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (r0 + q < nrows && i < n) ? rows[r0 + q][i] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = wave_sum(v[q]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s4[q][wave] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && r0 + (int)threadIdx.x < nrows) {
+      const int q = threadIdx.x;
+      ts[(size_t)(r0 + q) * ntiles + t] = ((s4[q][0] + s4[q][1]) + s4[q][2]) + s4[q][3];
+    }
   }
 }
 
