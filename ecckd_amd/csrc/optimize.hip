@@ -41,7 +41,6 @@ namespace {
 
 constexpr double kD = ECCKD_LW_DIFFUSIVITY;
 constexpr double MIN_X = -1.0e20;  // solve_adept.cpp:21
-constexpr int MAX_ENT = 8;
 
 struct GasInfo {
   int conc = 0;       // 0 none, 1 linear, 2 lut, 3 relative-linear (ckd_model.cpp:1020-1086)
@@ -83,10 +82,6 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* s_red) {
   for (int w = 0; w < nwave; ++w) t += s_red[w];
   return t;
 }
-
-struct ColConst {  // per-profile constant block layout in d_col: see host code
-  int dummy;
-};
 
 // K8a.  grid = ncolumns (all scenes), block = ng rounded up to 64.
 // LDS: tau[nlay][ng] | fdn[nhl][ng] | fup[nhl][ng] | Bdn[nhl][nband] | Bup[nhl][nband] |
