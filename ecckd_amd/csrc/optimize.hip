@@ -705,15 +705,13 @@ k_lb_pair_dots(size_t n, LbSlots sl, int new_slot, const double* __restrict__ x,
     }
 }
 
-// out[k] = sum of partial array k, k < m (one block)
+// out[k] = sum of partial array k: one block per array
 __global__ void __launch_bounds__(VEC_THREADS)
-k_lb_finish(int m, const double* __restrict__ part, double* __restrict__ out) {
+k_lb_finish(const double* __restrict__ part, double* __restrict__ out) {
   __shared__ double s_tmp[4];
-  for (int k = 0; k < m; ++k) {
-    const double v = sum_partials(part + (size_t)k * VEC_BLOCKS, s_tmp);
-    if (threadIdx.x == 0) out[k] = v;
-    __syncthreads();
-  }
+  const int k = blockIdx.x;
+  const double v = sum_partials(part + (size_t)k * VEC_BLOCKS, s_tmp);
+  if (threadIdx.x == 0) out[k] = v;
 }
 
 }  // namespace
@@ -1386,7 +1384,7 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
     if (pending) sl.slot[hist] = pend_slot;
     for (int a = sl.n; a < M; ++a) sl.slot[a] = 0;
     hipLaunchKernelGGL(k_lb_project_dots, vb, vt, 0, ctx->stream, n, sl, x, g, bmin, bmax, o->d_q, o->d_S, o->d_Y, part_a);
-    hipLaunchKernelGGL(k_lb_finish, dim3(1), vt, 0, ctx->stream, 1 + 2 * M, part_a, sc);
+    hipLaunchKernelGGL(k_lb_finish, dim3(1 + 2 * M), vt, 0, ctx->stream, part_a, sc);
     ECCKD_HIP_CHECK(hipGetLastError());
     ECCKD_HIP_CHECK(hipMemcpyAsync(h_rb, sc, (size_t)(3 + 5 * M) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1493,7 +1491,7 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
     sp.n = hist;
     for (int a = 0; a < M; ++a) sp.slot[a] = a < hist ? ord[a] : 0;
     hipLaunchKernelGGL(k_lb_pair_dots, vb, vt, 0, ctx->stream, n, sp, pend_slot, x, xn, g, gn, o->d_S, o->d_Y, part_p);
-    hipLaunchKernelGGL(k_lb_finish, dim3(1), vt, 0, ctx->stream, 2 + 3 * M, part_p, sc + 1 + 2 * M);
+    hipLaunchKernelGGL(k_lb_finish, dim3(2 + 3 * M), vt, 0, ctx->stream, part_p, sc + 1 + 2 * M);
     ECCKD_HIP_CHECK(hipGetLastError());
     pending = true;
     std::swap(x, xn);
