@@ -1,0 +1,142 @@
+"""Host-side mirrors of the reference executables' driver logic on top of the C ABI (api.py) and the classic
+NetCDF layer (ncio.py).  Only orchestration lives here; every nwav-sized operation runs on the device.
+
+create_look_up_table : src/ecckd/create_look_up_table.cpp:60-606 (without the base_wavenumber_boundary split)
+"""
+import numpy as np
+
+from . import api, ncio
+from ._lib import EcckdError, PARAMETER_ERROR
+
+
+def _to_device(od, dev):
+    """FLOAT on the device when the values are FLOAT (as stored in the CKDMIP files), else DOUBLE: nothing is rounded."""
+    import torch
+    od32 = od.astype(np.float32)
+    return torch.as_tensor(od32 if np.array_equal(od32.astype(np.float64), od) else od, device=dev)
+
+
+def remove_empty_g_points(g_point, band_number, solar_irradiance=None):
+    """create_look_up_table.cpp:111-168: g points that occupy none of the spectrum are dropped and the rest renumbered.
+    As in the reference, the new "band_number" of a kept g point is its OLD g-point index (:142), not its band."""
+    g_point = np.asarray(g_point)
+    ng = int(g_point.max()) + 1
+    present = np.zeros(ng, dtype=bool)
+    present[g_point[g_point >= 0]] = True
+    if present.all():
+        return g_point.astype(np.int32), np.asarray(band_number), solar_irradiance
+    g_point_map = np.nonzero(present)[0]
+    new_g = np.full(g_point.size, -1, dtype=np.int32)
+    lookup = np.full(ng, -1, dtype=np.int32)
+    lookup[g_point_map] = np.arange(g_point_map.size, dtype=np.int32)
+    ok = g_point >= 0
+    new_g[ok] = lookup[g_point[ok]]
+    if (new_g < 0).any():
+        raise EcckdError(1, "Some unassigned spectral points after mapping")          # THROW(1), :146-149
+    new_band = g_point_map.copy()
+    new_ssi = None if solar_irradiance is None else np.asarray(solar_irradiance)[g_point_map]
+    return new_g, new_band, new_ssi
+
+
+def create_look_up_table(ctx, g_point, band_number, band_wn1, band_wn2, gases, averaging_method="transmission",
+                         temperature_stride=1, ssi=None, solar_irradiance=None):
+    """The look-up-table assembly of create_look_up_table.cpp:225-606 from classic NetCDF spectra.
+
+    g_point[nwav], band_number[ng]: from the g-points file (find_g_points' output).
+    gases: list of dict(name=..., conc="none"|"linear"|"lut"|"relative-linear", and
+             conc == "none":  inputs=[dict(path=..., scaling=-1, conc=-1), ...]  (read_merged_spectrum of the well-mixed files)
+             otherwise:       inputs=[path, ...] (one file; one per mole fraction for "lut"), reference_conc for "relative-linear")
+    ssi[nwav] selects the shortwave (weights = solar spectral irradiance, :333-340), otherwise Planck weights at each
+    layer's temperature (:316-327).  Returns the model dict of api.Optimizer / ncio.write_ckd_model."""
+    import torch
+    is_sw = ssi is not None
+    g_point, band_number, solar_irradiance = remove_empty_g_points(g_point, band_number, solar_irradiance)
+    ng = int(g_point.max()) + 1
+    dev = ctx.device
+    d_ssi = torch.as_tensor(np.asarray(ssi, dtype=np.float64), device=dev) if is_sw else None
+    gmap = None
+    model = dict(gases=[], iband_per_g=np.asarray(band_number, dtype=np.int32))
+    temperature_fl = None
+
+    def column(s, od_dev, ref_vmr):
+        nonlocal gmap, temperature_fl
+        p, t = s["pressure_hl"], s["temperature_hl"]
+        if gmap is None:
+            wn = torch.as_tensor(s["wavenumber_cm_1"], device=dev)
+            dwn = torch.as_tensor(s["d_wavenumber_cm_1"], device=dev)
+            gmap = api.GPointMap(ctx, torch.as_tensor(g_point, device=dev), ng, wn, dwn)
+            model["log_pressure"] = np.log(0.5 * (p[1:] + p[:-1]))
+        t_fl = (t[:-1] * p[:-1] + t[1:] * p[1:]) / (p[:-1] + p[1:])                  # :310-311
+        out = gmap.average_optical_depth(p, od_dev, averaging_method, reference_surface_vmr=ref_vmr,
+                                         temperature_fl=None if is_sw else t_fl, ssi=d_ssi)
+        return t_fl, out
+
+    for spec in gases:
+        name, conc = spec["name"], spec["conc"]
+        if conc not in ("none", "linear", "lut", "relative-linear"):
+            raise EcckdError(PARAMETER_ERROR, f'conc_dependence "{conc}" not understood')
+        g = dict(name=name, conc=conc, active=True)
+        files = spec["inputs"]
+        nconc = len(files) if conc == "lut" else 1
+        tables, vmrs, tfl_rows = None, [], None
+        for iconc in range(nconc):
+            ncol, icol = 1, 0
+            while icol < ncol:
+                if conc == "none":
+                    # read_merged_spectrum (:293-296): sum of the scaled well-mixed spectra, accumulated on the device
+                    merged, first = None, None
+                    for item in files:
+                        s = ncio.read_spectrum(item["path"], icol * temperature_stride)
+                        first = first or s
+                        sp, _ = api.merge_scaling(s["pressure_hl"], item.get("scaling", -1.0), item.get("conc", -1.0),
+                                                  s["reference_surface_vmr"], s["vmr_fl"])
+                        merged = api.merge_spectrum(ctx, _to_device(s["optical_depth"], dev), sp, merged)
+                    s, od_dev, ref_vmr = first, merged, 1.0                            # reference_surface_vmr = 1 (:283)
+                else:
+                    s = ncio.read_spectrum(files[iconc], icol * temperature_stride)
+                    od_dev = _to_device(s["optical_depth"], dev)
+                    ref_vmr = s["reference_surface_vmr"]
+                    if conc == "lut" and ref_vmr < 0.0:
+                        raise EcckdError(PARAMETER_ERROR, "Invalid reference_surface_vmr for constructing VMR-dependent look-up table")
+                ncol = (s["ncol"] + temperature_stride - 1) // temperature_stride
+                t_fl, (k, kmin, kmax) = column(s, od_dev, ref_vmr)
+                if tables is None:
+                    shape = (nconc, ncol) + k.shape
+                    tables = [np.zeros(shape) for _ in range(3)]
+                    tfl_rows = np.zeros((ncol, k.shape[0]))
+                for tab, v in zip(tables, (k, kmin, kmax)):
+                    tab[iconc, icol] = v
+                tfl_rows[icol] = t_fl
+                icol += 1
+            if conc == "lut":
+                vmrs.append(ref_vmr)
+        temperature_fl = tfl_rows                                                     # the last gas's, as the reference keeps it
+        squeeze = (lambda a: a) if conc == "lut" else (lambda a: a[0])
+        g["molar_abs"], g["min_molar_abs"], g["max_molar_abs"] = (squeeze(t) for t in tables)
+        if conc == "lut":
+            g["vmr"] = np.array(vmrs)
+        if conc == "relative-linear":
+            if "reference_conc" not in spec:
+                raise EcckdError(PARAMETER_ERROR, f"{name}.reference_conc must be provided if conc_dependence is relative-linear")
+            g["reference_vmr"] = float(spec["reference_conc"])
+        model["gases"].append(g)
+
+    model["temperature"] = temperature_fl
+    # fraction of the spectrum contributing to each g point on a 10 (LW) / 50 (SW) cm-1 grid (:507-548)
+    dwav = 50 if is_sw else 10
+    startwav = int(np.floor(np.min(band_wn1) / dwav) * dwav)
+    endwav = int(np.ceil(np.max(band_wn2) / dwav) * dwav)
+    model["wavenumber1"] = dwav * np.arange(startwav // dwav, endwav // dwav, dtype=np.float64)
+    model["wavenumber2"] = dwav * np.arange(startwav // dwav + 1, endwav // dwav + 1, dtype=np.float64)
+    model["gpoint_fraction"] = gmap.gpoint_fraction(model["wavenumber1"], model["wavenumber2"])
+    model["wavenumber1_band"], model["wavenumber2_band"] = np.asarray(band_wn1, float), np.asarray(band_wn2, float)
+    model["nband"] = len(model["wavenumber1_band"])
+    if is_sw:
+        model["solar_irradiance"] = np.asarray(solar_irradiance, dtype=np.float64)
+        model["planck_function"] = model["temperature_planck"] = None
+    else:
+        model["temperature_planck"] = np.arange(120.0, 351.0)                         # :581
+        model["planck_function"] = gmap.planck_lut(model["temperature_planck"])        # :585-591
+    model["ng"] = ng
+    gmap.close()
+    return model

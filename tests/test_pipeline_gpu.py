@@ -143,3 +143,79 @@ def test_files_to_gpoints(ctx, oracle, tmp_path):
     want = oracle.planck_lut(ng, t_lut, ref_map, wn, dwn)
     assert np.allclose(got, want, rtol=1e-11)
     gmap.close()
+
+
+def test_create_look_up_table_from_files(ctx, oracle, tmp_path):
+    """create_look_up_table.cpp:225-606 through ecckd_amd.pipeline: every gas type, merged well-mixed background,
+    empty g point removal, gpoint_fraction, Planck look-up table; then the CKD file round trip and run_ckd."""
+    from ecckd_amd import api, ncio, pipeline
+    rs = np.random.RandomState(7)
+    nlay, nwav, ncol = 12, 6000, 3
+    p1 = syn.pressure_grid(nlay)
+    wn, _ = syn.wavenumber_grid(nwav)
+    p = np.tile(p1, (ncol, 1))
+    t = np.stack([syn.temperature_profile(p1) + 15.0 * (c - 1) for c in range(ncol)])
+
+    def write(path, gas, seed, scale, vmr):
+        w = netcdf_file(str(path), "w", version=2)
+        for d, n in (("column", ncol), ("half_level", nlay + 1), ("level", nlay), ("wavenumber", nwav)):
+            w.createDimension(d, n)
+        od = np.stack([syn.optical_depth(np, p1, wn, syn.SEED_BASE + seed, nlines=30, column_scale=scale * (1 + 0.1 * c),
+                                         dtype="float32") for c in range(ncol)])
+        w.createVariable("pressure_hl", "d", ("column", "half_level"))[:] = p
+        w.createVariable("temperature_hl", "d", ("column", "half_level"))[:] = t
+        w.createVariable("wavenumber", "d", ("wavenumber",))[:] = wn
+        w.createVariable("mole_fraction_fl", "d", ("column", "level"))[:] = np.full((ncol, nlay), vmr)
+        w.createVariable("optical_depth", "f", ("column", "level", "wavenumber"))[:] = od
+        w.createVariable("reference_surface_mole_fraction", "d", ())[...] = vmr
+        w.constituent_id = gas
+        w.close()
+        return od.astype(np.float64)
+
+    files = {}
+    for name, seed, scale, vmr in (("o2", 1, 0.5, 0.209), ("n2", 2, 0.2, 0.781), ("co2", 3, 8.0, 4e-4), ("ch4", 4, 2.0, 1.8e-6),
+                                   ("h2o_a", 5, 3.0, 1e-3), ("h2o_b", 6, 30.0, 1e-2)):
+        files[name] = (tmp_path / f"{name}.nc", write(tmp_path / f"{name}.nc", name.split("_")[0], seed, scale, vmr), vmr)
+    # a g-point map with one empty g point (5) to be removed
+    g_point = rs.randint(0, 7, nwav).astype(np.int32)
+    g_point[g_point == 5] = 6
+    band_number = np.array([0, 0, 0, 1, 1, 1, 1])
+    gases = [dict(name="composite", conc="none", inputs=[dict(path=files["o2"][0]), dict(path=files["n2"][0], scaling=0.5)]),
+             dict(name="co2", conc="linear", inputs=[files["co2"][0]]),
+             dict(name="ch4", conc="relative-linear", inputs=[files["ch4"][0]], reference_conc=1.8e-6),
+             dict(name="h2o", conc="lut", inputs=[files["h2o_a"][0], files["h2o_b"][0]])]
+    model = pipeline.create_look_up_table(ctx, g_point, band_number, [0.0, 1300.0], [1300.0, 3260.0], gases)
+    # ---- oracle ----
+    gp = g_point.copy()
+    gp[gp == 6] = 5                                               # renumbered
+    assert model["ng"] == 6 and np.array_equal(model["iband_per_g"], [0, 1, 2, 3, 4, 6])    # :142 keeps the OLD g index
+    dwn = np.empty(nwav); dwn[1:-1] = 0.5 * (wn[2:] - wn[:-2]); dwn[0] = 0.5 * dwn[1]; dwn[-1] = 0.5 * dwn[-2]
+    t_fl = (t[:, :-1] * p[:, :-1] + t[:, 1:] * p[:, 1:]) / (p[:, :-1] + p[:, 1:])
+    assert np.allclose(model["temperature"], t_fl, rtol=1e-15) and np.allclose(model["log_pressure"], np.log(0.5 * (p1[1:] + p1[:-1])))
+
+    def avg(od, vmr, c):
+        planck = oracle.planck_function(t_fl[c], wn, dwn)
+        return oracle.average_optical_depth_to_g_point(6, vmr, p1, gp, od, planck, "transmission")[:3]
+
+    by_name = {g["name"]: g for g in model["gases"]}
+    for c in range(ncol):
+        merged = files["o2"][1][c] + files["n2"][1][c] * 0.5
+        for got, want in zip((by_name["composite"][k][c] for k in ("molar_abs", "min_molar_abs", "max_molar_abs")), avg(merged, 1.0, c)):
+            assert np.allclose(got, want, rtol=1e-9, atol=1e-300)
+        assert np.allclose(by_name["co2"]["molar_abs"][c], avg(files["co2"][1][c], 4e-4, c)[0], rtol=1e-9, atol=1e-300)
+        assert np.allclose(by_name["ch4"]["molar_abs"][c], avg(files["ch4"][1][c], 1.8e-6, c)[0], rtol=1e-9, atol=1e-300)
+        for ic, key in enumerate(("h2o_a", "h2o_b")):
+            assert np.allclose(by_name["h2o"]["molar_abs"][ic, c], avg(files[key][1][c], files[key][2], c)[0], rtol=1e-9, atol=1e-300)
+    assert np.array_equal(by_name["h2o"]["vmr"], [1e-3, 1e-2]) and by_name["ch4"]["reference_vmr"] == 1.8e-6
+    assert model["wavenumber1"][0] == 0.0 and model["wavenumber2"][-1] == 3260.0 and model["wavenumber1"].size == 326
+    assert np.allclose(model["gpoint_fraction"], oracle.gpoint_fraction(6, gp, wn, dwn, model["wavenumber1"], model["wavenumber2"]), rtol=1e-12)
+    assert np.allclose(model["planck_function"], oracle.planck_lut(6, np.arange(120.0, 351.0), gp, wn, dwn), rtol=1e-11)
+    # ---- CKD file round trip, then the model runs ----
+    model["iband_per_g"] = np.array([0, 0, 0, 1, 1, 1], dtype=np.int32)      # a consistent band map for the evaluation below
+    path = tmp_path / "ckd.nc"
+    ncio.write_ckd_model(str(path), model, model_id="test")
+    back = ncio.read_ckd_model(str(path))
+    scene = dict(pressure_hl=p, temperature_hl=t, vmr_fl=np.stack([np.ones((ncol, nlay)), np.full((ncol, nlay), 4e-4),
+                                                                  np.full((ncol, nlay), 2.0e-6), np.full((ncol, nlay), 3e-3)], axis=1))
+    out = api.run_ckd(ctx, back, scene, per_gas=False)
+    assert np.all(np.isfinite(out["flux_dn_lw"])) and out["flux_up_lw"][:, -1].min() > 0 and out["optical_depth"].min() >= 0
