@@ -140,3 +140,78 @@ def create_look_up_table(ctx, g_point, band_number, band_wn1, band_wn2, gases, a
     model["ng"] = ng
     gmap.close()
     return model
+
+
+def iband_per_g(model, wavenumber1, wavenumber2):
+    """CkdModel::iband_per_g (ckd_model.h:287-306): the LBL band each g point lies in, from gpoint_fraction."""
+    gf, w1, w2 = np.asarray(model["gpoint_fraction"]), np.asarray(model["wavenumber1"]), np.asarray(model["wavenumber2"])
+    iband = np.full(gf.shape[0], -1, dtype=np.int32)
+    for ib in range(len(wavenumber1)):
+        weight = gf[:, (w1 >= wavenumber1[ib]) & (w2 <= wavenumber2[ib])].sum(axis=1)
+        if np.any((weight > 0.05) & ((weight < 0.95) | (weight > 1.05))):
+            raise EcckdError(1, "G-points do not lie entirely within requested bands")
+        iband[weight > 0.5] = ib
+    if np.any(iband < 0):
+        raise EcckdError(1, "Some g-points not inside a band")
+    return iband
+
+
+def optimize_lut(ctx, model, training_files, relative_to=None, band_mapping=None, gmap=None, max_iterations=3000,
+                 convergence_criterion=0.0, bounded=True, max_no_rayleigh_wavenumber=None, erythemal_weight=0.0, **cfg):
+    """The driver of optimize_lut.cpp:60-330 on top of api.Optimizer: training scenes from LBL flux files
+    (ncio.read_lbl_fluxes), optional "relative_to" file, bounded L-BFGS, optimised coefficients back into the model.
+
+    model: dict from ncio.read_ckd_model (its `active` flags select the gases being optimised, optimize_lut.cpp:161).
+    cfg:   flux_weight, flux_profile_weight, broadband_weight, spectral_boundary_weight, prior_error, ... (api.Optimizer).
+    Returns (model with optimised molar_abs, result dict of Optimizer.minimize)."""
+    names = [g["name"] for g in model["gases"]]
+    is_sw = model.get("solar_irradiance") is not None
+
+    def load(path):
+        s = ncio.read_lbl_fluxes(path, names, band_mapping=band_mapping, gmap=gmap, ctx=ctx)
+        if s["have_band_fluxes"]:
+            s["iband_per_g"] = iband_per_g(model, s["band_wavenumber1"], s["band_wavenumber2"])     # :273-276
+        if is_sw and max_no_rayleigh_wavenumber is not None:
+            ncio.mask_rayleigh_up(s, max_no_rayleigh_wavenumber)                                     # :278-283
+        if is_sw and erythemal_weight > 0.0 and "erythemal_spectrum" in s:
+            s["spectral_boundary_weights"] = erythemal_weight * s["erythemal_spectrum"]              # solve_adept.cpp:182
+        return s
+
+    rel = None
+    if relative_to is not None:                                                                      # :204-236
+        rel = load(relative_to)
+        m0 = dict(model, iband_per_g=rel.get("iband_per_g", model["iband_per_g"]))
+        ref_opt = api.Optimizer(ctx, m0, [_scene_for_optimizer(rel, is_sw)], **cfg)
+        _, fl = ref_opt.forward(ref_opt.initial_state())
+        ref_opt.close()
+    scenes = []
+    iband = None
+    for path in training_files:
+        s = load(path)
+        if rel is not None:
+            ncio.subtract_lbl_fluxes(s, rel)                                                         # :251-254
+        sc = _scene_for_optimizer(s, is_sw)
+        if rel is not None:
+            sc["relative_flux_dn"], sc["relative_flux_up"] = np.ascontiguousarray(fl[:, 0]), np.ascontiguousarray(fl[:, 1])
+        scenes.append(sc)
+        iband = s.get("iband_per_g", iband)
+    if not scenes:
+        raise EcckdError(PARAMETER_ERROR, '"training_input" not specified')
+    m = dict(model)
+    if iband is not None:
+        m["iband_per_g"] = iband
+    opt = api.Optimizer(ctx, m, scenes, **dict(dict(cap_relative_linear=0.8), **cfg))                # :185
+    res = opt.minimize(max_iterations=max_iterations, convergence_criterion=convergence_criterion, bounded=bounded)
+    out = dict(model, gases=[dict(g) for g in model["gases"]])
+    for i, g in enumerate(out["gases"]):
+        g["molar_abs"] = opt.coefficients(res["x"], i, np.asarray(g["molar_abs"]).shape)
+    opt.close()
+    return out, res
+
+
+def _scene_for_optimizer(s, is_sw):
+    keys = ["pressure_hl", "temperature_hl", "vmr_fl", "gas_present", "flux_dn", "flux_up", "spectral_flux_dn_surf",
+            "spectral_flux_up_toa", "spectral_boundary_weights"]
+    if is_sw:
+        keys += ["mu0", "tsi", "albedo"]
+    return {k: s[k] for k in keys if s.get(k) is not None}

@@ -219,3 +219,67 @@ def test_create_look_up_table_from_files(ctx, oracle, tmp_path):
                                                                   np.full((ncol, nlay), 2.0e-6), np.full((ncol, nlay), 3e-3)], axis=1))
     out = api.run_ckd(ctx, back, scene, per_gas=False)
     assert np.all(np.isfinite(out["flux_dn_lw"])) and out["flux_up_lw"][:, -1].min() > 0 and out["optical_depth"].min() >= 0
+
+
+def test_optimize_lut_from_files(ctx, oracle, tmp_path):
+    """optimize_lut.cpp driver through ecckd_amd.pipeline: CKD file + LBL band-flux files (made with run_ckd from a
+    "truth" model) -> bounded L-BFGS -> CKD file; the cost falls and the written file reproduces the optimised fluxes."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import ckd_synth
+    from ecckd_amd import api, ncio, pipeline
+    model = ckd_synth.make_model(seed=12)
+    ng = len(model["iband_per_g"])
+    nband = model["nband"]
+    # spectral description of the model: one 10 cm-1 interval per g point, bands as contiguous g ranges
+    gf = np.eye(ng)
+    ib = model["iband_per_g"]
+    model.update(wavenumber1=np.arange(ng) * 10.0, wavenumber2=np.arange(1, ng + 1) * 10.0, gpoint_fraction=gf,
+                 wavenumber1_band=np.array([10.0 * np.nonzero(ib == b)[0][0] for b in range(nband)]),
+                 wavenumber2_band=np.array([10.0 * (np.nonzero(ib == b)[0][-1] + 1) for b in range(nband)]))
+    ncio.write_ckd_model(str(tmp_path / "raw.nc"), model)
+    truth = dict(model, gases=[dict(g, molar_abs=g["molar_abs"] * np.exp(0.2 * np.random.RandomState(i).normal(size=g["molar_abs"].shape)))
+                               for i, g in enumerate(model["gases"])])
+    scenes = ckd_synth.make_scenes(model, nscene=2, ncol=4, nlay=16)
+    names = [g["name"] for g in model["gases"]]
+    paths = []
+    for k, sc in enumerate(scenes):
+        sc = dict(sc, gas_present=None)
+        out = api.run_ckd(ctx, truth, sc, per_gas=False)
+        band = lambda a: np.stack([a[..., ib == b].sum(-1) for b in range(nband)], axis=-1)
+        w = netcdf_file(str(tmp_path / f"lbl{k}.nc"), "w", version=2)
+        for d, n in (("column", 4), ("half_level", 17), ("level", 16), ("gas", len(names)), ("band", nband)):
+            w.createDimension(d, n)
+        for name, dims, a in (("pressure_hl", ("column", "half_level"), sc["pressure_hl"]),
+                              ("temperature_hl", ("column", "half_level"), sc["temperature_hl"]),
+                              ("mole_fraction_fl", ("column", "gas", "level"), sc["vmr_fl"]),
+                              ("flux_dn_lw", ("column", "half_level"), out["flux_dn_lw"]),
+                              ("flux_up_lw", ("column", "half_level"), out["flux_up_lw"]),
+                              ("band_flux_dn_lw", ("column", "half_level", "band"), band(out["spectral_flux_dn_lw"])),
+                              ("band_flux_up_lw", ("column", "half_level", "band"), band(out["spectral_flux_up_lw"])),
+                              ("band_wavenumber1_lw", ("band",), model["wavenumber1_band"]),
+                              ("band_wavenumber2_lw", ("band",), model["wavenumber2_band"])):
+            w.createVariable(name, "d", dims)[:] = a
+        w.constituent_id = " ".join(names)
+        w.close()
+        paths.append(str(tmp_path / f"lbl{k}.nc"))
+    raw = ncio.read_ckd_model(str(tmp_path / "raw.nc"), active_gases=["composite", "h2o", "co2", "ch4"])
+    assert np.array_equal(pipeline.iband_per_g(raw, raw["wavenumber1_band"], raw["wavenumber2_band"]), ib)
+    cfg = dict(flux_weight=0.2, flux_profile_weight=0.05, broadband_weight=0.4, prior_error=4.0, pressure_corr=0.95,
+               temperature_corr=0.95, conc_corr=0.9)
+    first = api.Optimizer(ctx, dict(raw), [pipeline._scene_for_optimizer(ncio.read_lbl_fluxes(q, names), False) for q in paths],
+                          **dict(cfg, cap_relative_linear=0.8))
+    J0 = first.cost_grad(first.initial_state(), False)
+    first.close()
+    opt_model, res = pipeline.optimize_lut(ctx, raw, paths, max_iterations=60, **cfg)
+    assert res["status"] in (0, 2) and res["cost"] < 0.5 * J0
+    ncio.write_ckd_model(str(tmp_path / "opt.nc"), opt_model, model_id="optimised")
+    back = ncio.read_ckd_model(str(tmp_path / "opt.nc"))
+    sc0 = dict(scenes[0], gas_present=None)
+    a = api.run_ckd(ctx, opt_model, sc0, per_gas=False)["flux_dn_lw"]
+    b = api.run_ckd(ctx, back, sc0, per_gas=False)["flux_dn_lw"]
+    assert np.allclose(a, b, rtol=1e-5)                               # the file stores FLOAT coefficients
+    # closer to the truth than the raw model
+    tr = api.run_ckd(ctx, truth, sc0, per_gas=False)["flux_dn_lw"]
+    r0 = api.run_ckd(ctx, raw, sc0, per_gas=False)["flux_dn_lw"]
+    assert np.abs(a - tr).max() < np.abs(r0 - tr).max()
