@@ -445,3 +445,65 @@ def subtract_lbl_fluxes(scene, source):
     for k in ("flux_dn", "flux_up", "broadband_flux_dn", "broadband_flux_up"):
         scene[k] = scene[k] - source[k]
     return scene
+
+
+# ---- g-points file (find_g_points.cpp:1487-1660) ------------------------------------------------------------
+
+def write_g_points(path, band_bound1, band_bound2, band_number, gases, wavenumber, g_point, solar_irradiance=None,
+                   config_str="", history=None):
+    """gases: list of dict(name, n_g_points[nband], band_number, rank1, rank2, error, sorting_variable, g_min, g_max,
+    g_point[nwav]) as SingleGasData holds them."""
+    w = NcWriter(path)
+    ng = len(band_number)
+    w.define_dimension("band", len(band_bound1))
+    w.define_dimension("g_point", ng)
+    for g in gases:
+        w.define_dimension(g["name"] + "_g_point", len(g["rank1"]))
+    w.define_dimension("wavenumber", len(wavenumber))
+    w.define_variable("n_gases", "int")
+    w.define_variable("wavenumber1_band", "float", "band")
+    w.define_variable("wavenumber2_band", "float", "band")
+    w.define_variable("band_number", "short", "g_point")
+    if solar_irradiance is not None:
+        w.define_variable("solar_irradiance", "float", "g_point")
+    for g in gases:
+        m, d = g["name"], g["name"] + "_g_point"
+        w.define_variable(m + "_n_g_points", "int", "band")
+        w.define_variable(m + "_band_number", "short", d)
+        w.define_variable(m + "_rank1", "int", d)
+        w.define_variable(m + "_rank2", "int", d)
+        w.define_variable(m + "_error", "float", d)
+        w.define_variable(m + "_sorting_variable", "float", d)
+        w.define_variable(m + "_g_min", "int", "g_point")
+        w.define_variable(m + "_g_max", "int", "g_point")
+    w.define_variable("wavenumber", "double", "wavenumber")
+    w.define_variable("g_point", "short", "wavenumber")
+    for g in gases:
+        w.define_variable(g["name"] + "_g_point", "short", "wavenumber")
+    w.write_attribute("constituent_id", " ".join(g["name"] for g in gases))
+    if history:
+        w.write_attribute("history", history)
+    w.write_attribute("config", config_str)
+    w.end_define_mode()
+    w.write("n_gases", [len(gases)])
+    w.write("wavenumber1_band", band_bound1)
+    w.write("wavenumber2_band", band_bound2)
+    w.write("band_number", band_number)
+    if solar_irradiance is not None:
+        w.write("solar_irradiance", solar_irradiance)
+    for g in gases:
+        m = g["name"]
+        for k in ("n_g_points", "band_number", "rank1", "rank2", "error", "sorting_variable", "g_min", "g_max", "g_point"):
+            w.write(m + "_" + k, g[k])
+    w.write("wavenumber", wavenumber)
+    w.write("g_point", g_point)
+    w.close()
+
+
+def read_g_points(path):
+    """What create_look_up_table and optimize_lut read from a g-points file (create_look_up_table.cpp:86-106)."""
+    with NcFile(path) as f:
+        return dict(g_point=f.read("g_point").astype(np.int32), band_number=f.read("band_number").astype(np.int32),
+                    wavenumber=f.read("wavenumber"), wavenumber1_band=f.read("wavenumber1_band"),
+                    wavenumber2_band=f.read("wavenumber2_band"),
+                    solar_irradiance=f.read("solar_irradiance") if f.exist("solar_irradiance") else None)

@@ -215,3 +215,75 @@ def _scene_for_optimizer(s, is_sw):
     if is_sw:
         keys += ["mu0", "tsi", "albedo"]
     return {k: s[k] for k in keys if s.get(k) is not None}
+
+
+def reorder_spectrum(ctx, input_path, output_path, band_bound1, band_bound2, iprofile=0, threshold_optical_depth=None,
+                     ssi=None, config_str="", history=None):
+    """reorder_spectrum.cpp:45-310 for one gas: spectrum file in, reordering file out.  Returns the order dict."""
+    s = ncio.read_spectrum(input_path, iprofile)
+    thr = threshold_optical_depth if threshold_optical_depth is not None else (0.5 if ssi is None else 0.25)
+    od = s["optical_depth"]
+    od32 = od.astype(np.float32)
+    od_in = od32 if np.array_equal(od32.astype(np.float64), od) else od
+    key, col, iband, rank = api.reorder_spectrum(ctx, s["pressure_hl"], s["wavenumber_cm_1"], s["d_wavenumber_cm_1"], od_in, ssi, thr,
+                                                 band_bound1, band_bound2)
+    ncio.write_order(output_path, band_bound1, band_bound2, s["wavenumber_cm_1"], s["d_wavenumber_cm_1"], iband, rank, key, col,
+                     molecule=s["molecule"] or "", config_str=config_str, history=history)
+    return dict(spectrum=s, key=key, column_optical_depth=col, band_number=iband, rank=rank)
+
+
+def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, output_path=None, averaging_method="transmission",
+                  flux_weight=0.02, min_pressure=0.0, tolerance_tolerance=0.02, max_iterations=60, iprofile=0):
+    """The longwave main loop of find_g_points.cpp:655-1660 over classic files: per gas the merged background, the gas
+    preparation, the band searches and the median sorting variables; then the overlap of the gases' g points, the merged
+    g-point map and the g-points file.
+
+    gases: list of dict(name, input=spectrum file, reordering_input=order file, background=[dict(path, scaling, conc), ...],
+                        min_g_points=1, max_g_points=256)."""
+    import torch
+    dev = ctx.device
+    nband = len(band_bound1)
+    per_gas, gas_gp = [], []
+    wn = None
+    tol = np.broadcast_to(np.asarray(heating_rate_tolerance, dtype=np.float64), (nband,))           # :762-771
+    for spec in gases:
+        s = ncio.read_spectrum(spec["input"], iprofile)
+        order = ncio.read_order(spec["reordering_input"])
+        wn, dwn = s["wavenumber_cm_1"], s["d_wavenumber_cm_1"]
+        d_wn, d_dwn = torch.as_tensor(wn, device=dev), torch.as_tensor(dwn, device=dev)
+        d_rank = torch.as_tensor(order["rank"], device=dev)
+        bg = None
+        for item in spec.get("background", []):                                                       # read_merged_spectrum (:891)
+            b = ncio.read_spectrum(item["path"], iprofile)
+            sp, _ = api.merge_scaling(b["pressure_hl"], item.get("scaling", -1.0), item.get("conc", -1.0),
+                                      b["reference_surface_vmr"], b["vmr_fl"])
+            bg = api.merge_spectrum(ctx, _to_device(b["optical_depth"], dev), sp, bg)
+        gas = api.GasLW(ctx, s["pressure_hl"], s["temperature_hl"], d_wn, d_dwn, d_rank, _to_device(s["optical_depth"], dev), bg,
+                        averaging_method, flux_weight, min_pressure)
+        sv_sorted = api.gather_f64(ctx, torch.as_tensor(order["sorting_variable"], device=dev), api.invert_permutation(ctx, d_rank))
+        iband = order["band_number"]
+        out = dict(name=spec["name"], n_g_points=[], band_number=[], rank1=[], rank2=[], error=[], sorting_variable=[])
+        for b in range(nband):
+            idx = np.nonzero(iband == b)[0]
+            res = gas.find_g_band_ex(int(idx[0]), int(idx[-1]), float(tol[b]), tolerance_tolerance, max_iterations,
+                                     min_g_points=spec.get("min_g_points", 1), max_g_points=spec.get("max_g_points", 256))
+            n = len(res["error"])
+            out["n_g_points"].append(n)
+            out["band_number"] += [b] * n
+            out["rank1"] += list(res["rank1"]); out["rank2"] += list(res["rank2"]); out["error"] += list(res["error"])
+            out["sorting_variable"] += list(gas.median_sorting_variable(sv_sorted, res["rank1"], res["rank2"]))
+        gas.close()
+        gp = api.gas_g_point(ctx, d_rank, out["rank1"], out["rank2"])
+        out["g_point"] = gp.cpu().numpy()
+        gas_gp.append(gp)
+        per_gas.append(out)
+    ng, band_number, g_min, g_max = api.overlap_g_points([g["n_g_points"] for g in per_gas],
+                                                         [np.asarray(g["sorting_variable"]) for g in per_gas])
+    g_point, n_unassigned = api.merge_g_points(ctx, gas_gp, g_min, g_max)
+    for k, g in enumerate(per_gas):
+        g["g_min"], g["g_max"] = g_min[k], g_max[k]
+    result = dict(ng=ng, band_number=band_number, g_point=g_point.cpu().numpy(), n_unassigned=n_unassigned, gases=per_gas,
+                  wavenumber=wn)
+    if output_path is not None:
+        ncio.write_g_points(output_path, band_bound1, band_bound2, band_number, per_gas, wn, result["g_point"])
+    return result

@@ -126,6 +126,24 @@ def test_files_to_gpoints(ctx, oracle, tmp_path):
     assert np.array_equal(g_point.cpu().numpy(), ref_map) and n_unassigned == int((ref_map < 0).sum())
     assert ng >= 4 and n_unassigned == 0
 
+    # ---- the same through the driver mirrors: reorder_spectrum -> order files -> find_g_points -> g-points file ----
+    from ecckd_amd import pipeline
+    for g in gases:
+        pipeline.reorder_spectrum(ctx, tmp_path / f"{g}.nc", tmp_path / f"order2_{g}.nc", BANDS[0], BANDS[1])
+        assert np.array_equal(ncio.read_order(tmp_path / f"order2_{g}.nc")["rank"], spec[g]["rank"])
+    res = pipeline.find_g_points(ctx, [dict(name="h2o", input=tmp_path / "h2o.nc", reordering_input=tmp_path / "order2_h2o.nc",
+                                            background=[dict(path=tmp_path / "co2.nc")]),
+                                       dict(name="co2", input=tmp_path / "co2.nc", reordering_input=tmp_path / "order2_co2.nc",
+                                            background=[dict(path=tmp_path / "h2o.nc")])],
+                                 BANDS[0], BANDS[1], TOL, output_path=tmp_path / "gpoints.nc", tolerance_tolerance=TOLTOL,
+                                 max_iterations=MAXIT)
+    assert res["ng"] == ng and np.array_equal(res["g_point"], ref_map) and res["n_unassigned"] == 0
+    gpf = ncio.read_g_points(tmp_path / "gpoints.nc")
+    assert np.array_equal(gpf["g_point"], ref_map) and np.array_equal(gpf["band_number"], band_number)
+    with ncio.NcFile(tmp_path / "gpoints.nc") as f:
+        assert f.att_text("constituent_id") == "h2o co2" and int(f.read("n_gases")) == 2
+        assert np.array_equal(f.read("h2o_rank1"), res["gases"][0]["rank1"]) and f.var_info("co2_g_point")[0] == 3
+
     # ---- create_look_up_table pieces on the merged map: averaging of each gas + Planck look-up table ----
     dwn = spec["h2o"]["dwn"]
     gmap = api.GPointMap(ctx, g_point, ng, dev(wn), dev(dwn))
