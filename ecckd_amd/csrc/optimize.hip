@@ -1471,6 +1471,14 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
         ECCKD_CHECK(opt_cost_grad_dev(o, xn, gn, &Jn));
         ok = (Jn == Jn && Jn <= J + 1.0e-4 * step * dg);
       }
+      if (!ok && npairs > 0 && !restarted) {
+        // the quasi-Newton direction did not give a sufficient decrease (typically many variables at their bounds):
+        // forget the history and try the projected steepest descent before giving up
+        restarted = true;
+        hist = 0;
+        npairs = 0;
+        continue;
+      }
       if (!ok) st = 3;
       break;
     }
