@@ -233,8 +233,11 @@ def reorder_spectrum(ctx, input_path, output_path, band_bound1, band_bound2, ipr
 
 
 def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, output_path=None, averaging_method="transmission",
-                  flux_weight=0.02, min_pressure=0.0, tolerance_tolerance=0.02, max_iterations=60, iprofile=0):
-    """The longwave main loop of find_g_points.cpp:655-1660 over classic files: per gas the merged background, the gas
+                  flux_weight=0.02, min_pressure=0.0, tolerance_tolerance=0.02, max_iterations=60, iprofile=0, ssi=None,
+                  max_no_rayleigh_wavenumber=10000.0, reference_albedo=0.15, cos_sza=0.5):
+    """The main loop of find_g_points.cpp:655-1660 over classic files (shortwave when `ssi[nwav]` is given: solar weights,
+    reference albedo 0.15 below max_no_rayleigh_wavenumber (:469, :522, :757-761, :921-923), REFERENCE_COS_SZA = 0.5,
+    per-gas min_scaling / max_scaling (:661-667)): per gas the merged background, the gas
     preparation, the band searches and the median sorting variables; then the overlap of the gases' g points, the merged
     g-point map and the g-points file.
 
@@ -258,13 +261,26 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
             sp, _ = api.merge_scaling(b["pressure_hl"], item.get("scaling", -1.0), item.get("conc", -1.0),
                                       b["reference_surface_vmr"], b["vmr_fl"])
             bg = api.merge_spectrum(ctx, _to_device(b["optical_depth"], dev), sp, bg)
-        gas = api.GasLW(ctx, s["pressure_hl"], s["temperature_hl"], d_wn, d_dwn, d_rank, _to_device(s["optical_depth"], dev), bg,
-                        averaging_method, flux_weight, min_pressure)
+        if ssi is None:
+            gas = api.GasLW(ctx, s["pressure_hl"], s["temperature_hl"], d_wn, d_dwn, d_rank, _to_device(s["optical_depth"], dev), bg,
+                            averaging_method, flux_weight, min_pressure)
+            band_albedo = None
+        else:
+            b2 = np.asarray(band_bound2, dtype=np.float64)
+            no_ray = b2 <= max_no_rayleigh_wavenumber
+            band_albedo = np.where(no_ray, reference_albedo, 0.0)                                     # :756-760
+            wn_limit = b2[no_ray].max() if no_ray.any() else 0.0                                      # :761
+            albedo = np.where(wn < wn_limit, reference_albedo, 0.0)                                   # :921-923
+            gas = api.GasSW(ctx, s["pressure_hl"], torch.as_tensor(np.asarray(ssi, dtype=np.float64), device=dev), d_rank,
+                            _to_device(s["optical_depth"], dev), bg, averaging_method, flux_weight, min_pressure, cos_sza,
+                            torch.as_tensor(albedo, device=dev), spec.get("min_scaling", 1.0), spec.get("max_scaling", 1.0))
         sv_sorted = api.gather_f64(ctx, torch.as_tensor(order["sorting_variable"], device=dev), api.invert_permutation(ctx, d_rank))
         iband = order["band_number"]
         out = dict(name=spec["name"], n_g_points=[], band_number=[], rank1=[], rank2=[], error=[], sorting_variable=[])
         for b in range(nband):
             idx = np.nonzero(iband == b)[0]
+            if band_albedo is not None:
+                gas.set_band_albedo(band_albedo[b])                                                   # init_sw(..., band_albedo(jband), ...)
             res = gas.find_g_band_ex(int(idx[0]), int(idx[-1]), float(tol[b]), tolerance_tolerance, max_iterations,
                                      min_g_points=spec.get("min_g_points", 1), max_g_points=spec.get("max_g_points", 256))
             n = len(res["error"])

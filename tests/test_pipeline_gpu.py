@@ -399,3 +399,71 @@ def test_do_all_lw_synthetic(ctx, oracle, tmp_path):
     print("heating-rate RMS error (K/day):", errs)
     assert np.isfinite(errs["raw"]) and errs["optimised"] < 0.9 * errs["raw"]
     assert errs["optimised"] < 1.0                               # K/day on this toy problem (tolerance 0.3 K/day per gas and band)
+
+
+def test_find_g_points_sw_from_files(ctx, oracle, tmp_path):
+    """Shortwave branch of the find_g_points driver (find_g_points.cpp:655-1660 with `ssi`): two bands either side of
+    max_no_rayleigh_wavenumber (band albedo 0.15 / 0), total-transmission averaging, solar-weighted medians; the band
+    searches are replayed by the CPU oracle + the reference-built partition search and must agree index for index."""
+    from ecckd_amd import api, ncio, pipeline
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    nwav, lo, hi, mu0 = 16000, 250.0, 50000.0, 0.5
+    b1, b2 = np.array([lo, 10000.0]), np.array([10000.0, hi])
+    p = syn.pressure_grid(NLAY)
+    t_hl = syn.temperature_profile(p)
+    wn, dwn = syn.wavenumber_grid(nwav, lo, hi)
+    ssi = syn.solar_spectral_irradiance(wn, dwn)
+    gases = {"h2o": (61, 5.0, 5e-3), "o3": (67, 1.5, 1e-6)}
+    for g, (seed, scale, vmr) in gases.items():
+        od = syn.optical_depth(np, p, wn, syn.SEED_BASE + seed, nlines=40, column_scale=scale, dtype="float32", lo=lo, hi=hi)
+        _write_spectrum(tmp_path / f"{g}.nc", g, p, t_hl, wn, od, vmr)
+        pipeline.reorder_spectrum(ctx, tmp_path / f"{g}.nc", tmp_path / f"order_{g}.nc", b1, b2, ssi=ssi)
+    specs = [dict(name="h2o", input=tmp_path / "h2o.nc", reordering_input=tmp_path / "order_h2o.nc",
+                  background=[dict(path=tmp_path / "o3.nc")]),
+             dict(name="o3", input=tmp_path / "o3.nc", reordering_input=tmp_path / "order_o3.nc",
+                  background=[dict(path=tmp_path / "h2o.nc")])]
+    tol = 0.03
+    res = pipeline.find_g_points(ctx, specs, b1, b2, tol, output_path=tmp_path / "gpoints_sw.nc", averaging_method="total-transmission",
+                                 tolerance_tolerance=TOLTOL, max_iterations=MAXIT, ssi=ssi)
+    assert res["n_unassigned"] == 0 and res["ng"] >= 4
+
+    # ---- oracle replay of every band search (find_g_points.cpp:891-1410) ----
+    albedo = np.where(wn < 10000.0, 0.15, 0.0)
+    lw = oracle.layer_weight(p, 0.0)
+    ods = {g: ncio.read_spectrum(tmp_path / f"{g}.nc", 0)["optical_depth"] for g in gases}
+    for k, (g, other) in enumerate((("h2o", "o3"), ("o3", "h2o"))):
+        order = ncio.read_order(tmp_path / f"order_{g}.nc")
+        rank, iband = order["rank"].astype(np.int64), order["band_number"]
+        ireorder = np.empty(nwav, dtype=np.int64)
+        ireorder[rank] = np.arange(nwav)
+        od_s, bg_s, ssi_s, alb_s = ods[g][:, ireorder], ods[other][:, ireorder], ssi[ireorder], albedo[ireorder]
+        key_s = order["sorting_variable"][ireorder]
+        fdn = oracle.radiative_transfer_direct_sw(mu0, ssi_s, bg_s + od_s)
+        hr = oracle.heating_rate(p, fdn, None)
+        ex = dict(min_scaling=0.5, max_scaling=2.5)
+        for tag, sc in (("low", 0.5), ("high", 2.5)):
+            d, u = oracle.radiative_transfer_norayleigh_sw(mu0, ssi_s, bg_s + sc * od_s, alb_s)
+            ex[f"flux_up_toa_{tag}"], ex[f"flux_dn_surf_{tag}"] = u[0].copy(), d[-1].copy()
+            ex[f"hr_{tag}"] = oracle.heating_rate(p, d, None)
+        metric = oracle.metric("total-transmission", od_s)
+        o_r1, o_r2, o_med = [], [], []
+        for b in range(2):
+            idx = np.nonzero(iband == b)[0]
+            i0, i1 = int(idx[0]), int(idx[-1])
+            sl, npts = slice(i0, i1 + 1), i1 - i0 + 1
+            exb = {kk: (v[..., sl] if isinstance(v, np.ndarray) else v) for kk, v in ex.items()}
+            eq = oracle.CkdEquipartitionSW("total-transmission", 0.02, lw, mu0, p, ssi_s[sl], 0.15 if b == 0 else 0.0,
+                                           fdn[-1][sl].copy(), np.zeros(npts), bg_s[:, sl], metric[:, sl], hr[:, sl], exb)
+            ref = oracle.RefEquipartition(eq.calc_error, resolution=1.0 / npts, partition_tolerance=TOLTOL,
+                                          partition_max_iterations=MAXIT)
+            st, bnd, err = ref.equipartition_e(tol)
+            for j in range(len(err)):
+                a, c = int(np.ceil(bnd[j] * (npts - 1))) + i0, int(np.floor(bnd[j + 1] * (npts - 1))) + i0
+                o_r1.append(a); o_r2.append(c)
+                o_med.append(oracle.median_sorting_variable(key_s, ssi_s, a, c))
+        got = res["gases"][k]
+        assert list(got["rank1"]) == o_r1 and list(got["rank2"]) == o_r2, g
+        assert np.array_equal(got["sorting_variable"], o_med), g
+    back = ncio.read_g_points(tmp_path / "gpoints_sw.nc")
+    assert np.array_equal(back["g_point"], res["g_point"])
