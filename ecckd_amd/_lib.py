@@ -176,6 +176,28 @@ SIGNATURES = {
                                            C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p]),
     "ecckd_gather_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_invert_permutation_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ecckd_cfg_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "ecckd_cfg_from_args": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]),
+    "ecckd_cfg_append_file": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "ecckd_cfg_append_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "ecckd_cfg_register": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "ecckd_cfg_destroy": (C.c_int, [C.c_void_p]),
+    "ecckd_cfg_file_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ecckd_cfg_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "ecckd_cfg_entry": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ecckd_cfg_exists": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "ecckd_cfg_get_boolean": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "ecckd_cfg_get_int": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ecckd_cfg_get_real": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, _c_double_p, C.POINTER(C.c_int)]),
+    "ecckd_cfg_get_string": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t,
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "ecckd_cfg_size": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int)]),
+    "ecckd_cfg_get_real_vector": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, _c_double_p, C.c_int, C.POINTER(C.c_int)]),
+    "ecckd_cfg_get_int_vector": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int,
+                                           C.POINTER(C.c_int)]),
+    "ecckd_cfg_sprint": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
 

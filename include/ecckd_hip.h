@@ -353,6 +353,45 @@ int ecckd_write_order_file(const char* path, const char* molecule, const char* c
                            const double* d_wavenumber, const int16_t* iband, const int32_t* rank,
                            const double* column_optical_depth, const double* sorting_variable);
 
+/* ---- configuration: `exe [key=value ...] [file.cfg]` (drop-in surface) ------
+ * Host-only.  Replaces DataFile(argc, argv) -> DataFileEngineCfg (src/tools/DataFileEngineCfg.cpp:61-80) and
+ * the rc_* functions of src/tools/readconfig.c it calls, one entry point per function used:
+ *   ecckd_cfg_from_args     the constructor: rc_read(NULL) + rc_register_files + rc_get_file (first argument
+ *                           without '=' whose name contains ".cfg") + rc_append + rc_register_args
+ *   ecckd_cfg_append_file   rc_append (readconfig.c:557-880; grammar in csrc/config.cpp)
+ *   ecckd_cfg_register      rc_register (:885-896); value NULL -> "1"
+ *   ecckd_cfg_exists        rc_exists;   ecckd_cfg_get_boolean  rc_get_boolean (:1262-1287)
+ *   ecckd_cfg_get_int/_real rc_assign_int / rc_assign_real (:1293-1407): *value untouched and *found = 0 when absent
+ *   ecckd_cfg_get_string    rc_get_string (isub < 0) / rc_get_substring (isub >= 0) (:1481-1500, :1622-1633)
+ *   ecckd_cfg_size          rc_size (:1653-1666): number of items and the declared [m][n]
+ *   ecckd_cfg_get_real_vector / _int_vector   rc_get_real_vector / rc_get_int_vector (:1720-1790)
+ *   ecckd_cfg_sprint        rc_sprint (:1113-1253): the string stored in the `config` attribute of every output file
+ * `scope` (may be NULL) is the section of DataFile::read(x, scope, name): rc_set_section(scope) around the call.
+ * Strings are copied into buf[cap] (always terminated) and *len receives the full length.
+ * A file that cannot be opened or parsed returns ECCKD_CANNOT_OPEN_MANDATORY_FILE like open_absolute (:32-52). */
+#define ECCKD_CANNOT_OPEN_MANDATORY_FILE 139
+typedef struct ecckd_cfg ecckd_cfg;
+int ecckd_cfg_create(ecckd_cfg** cfg);
+int ecckd_cfg_from_args(int argc, const char* const* argv, ecckd_cfg** cfg);
+int ecckd_cfg_append_file(ecckd_cfg* cfg, const char* path);
+int ecckd_cfg_append_text(ecckd_cfg* cfg, const char* text, const char* name);
+int ecckd_cfg_register(ecckd_cfg* cfg, const char* param, const char* value);
+int ecckd_cfg_destroy(ecckd_cfg* cfg);
+int ecckd_cfg_file_name(const ecckd_cfg* cfg, char* buf, size_t cap, size_t* len);
+int ecckd_cfg_count(const ecckd_cfg* cfg, int* n);
+int ecckd_cfg_entry(const ecckd_cfg* cfg, int i, char* param, size_t param_cap, char* value, size_t value_cap,
+                    size_t* value_len, int* has_value, int* m, int* n);
+int ecckd_cfg_exists(const ecckd_cfg* cfg, const char* scope, const char* param, int* exists);
+int ecckd_cfg_get_boolean(const ecckd_cfg* cfg, const char* scope, const char* param, int* value);
+int ecckd_cfg_get_int(const ecckd_cfg* cfg, const char* scope, const char* param, int* value, int* found);
+int ecckd_cfg_get_real(const ecckd_cfg* cfg, const char* scope, const char* param, double* value, int* found);
+int ecckd_cfg_get_string(const ecckd_cfg* cfg, const char* scope, const char* param, int isub, char* buf, size_t cap,
+                         size_t* len, int* found);
+int ecckd_cfg_size(const ecckd_cfg* cfg, const char* scope, const char* param, int* count, int* m, int* n);
+int ecckd_cfg_get_real_vector(const ecckd_cfg* cfg, const char* scope, const char* param, double* buf, int cap, int* len);
+int ecckd_cfg_get_int_vector(const ecckd_cfg* cfg, const char* scope, const char* param, int* buf, int cap, int* len);
+int ecckd_cfg_sprint(const ecckd_cfg* cfg, char* buf, size_t cap, size_t* len);
+
 /* ---- optimize_lut: cost function, gradient and minimisation (K8/K9) ------------
  * Replaces CkdOptimizable::calc_cost_function_gradient (solve_adept.cpp:240-292), i.e.
  * calc_cost_function_and_gradient (:72-211: CkdModel::calc_optical_depth ckd_model.cpp:925-1102,
