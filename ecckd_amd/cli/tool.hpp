@@ -1,0 +1,500 @@
+// Shared host code of the command-line tools (reorder_spectrum, find_g_points, ...).
+//
+// The tools are the process-level boundary of the reference: `exe [key=value ...] [file.cfg]`,
+// NetCDF files in and out, exit code 0 or one of src/include/EsaExitCodes.h.  Everything here sits ABOVE the
+// C ABI of include/ecckd_hip.h - the tools never touch HIP themselves.
+#pragma once
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/ecckd_hip.h"
+
+namespace tool {
+
+struct Fatal {
+  int code;
+  std::string msg;
+};
+
+[[noreturn]] inline void fail(int code, const char* fmt, ...) {
+  char buf[2048];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw Fatal{code, buf};
+}
+
+inline void ck(int rc) {
+  if (rc != ECCKD_OK) {
+    const char* m = ecckd_last_error();
+    throw Fatal{rc, m ? m : ""};
+  }
+}
+
+// ---- logging (src/include/Logging.h: LOG goes to stdout, errors to stderr) ----
+inline int& log_level() { static int lvl = 2; return lvl; }
+inline void set_log_level(const std::string& s) {
+  if (s == "error" || s == "0") log_level() = 0;
+  else if (s == "warning" || s == "1") log_level() = 1;
+  else if (s == "info" || s == "2") log_level() = 2;
+  else log_level() = 3;
+}
+#define LOG(...) do { if (tool::log_level() >= 2) { std::printf(__VA_ARGS__); std::fflush(stdout); } } while (0)
+#define WARN(...) do { if (tool::log_level() >= 1) { std::fprintf(stderr, "*** Warning: "); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } } while (0)
+
+// ---- configuration (DataFile config(argc, argv)) ----
+class Config {
+ public:
+  Config(int argc, const char* const* argv) { ck(ecckd_cfg_from_args(argc, argv, &c_)); }
+  ~Config() { ecckd_cfg_destroy(c_); }
+  Config(const Config&) = delete;
+  Config& operator=(const Config&) = delete;
+
+  bool exist(const std::string& name, const char* scope = nullptr) const {
+    int e = 0;
+    ck(ecckd_cfg_exists(c_, scope, name.c_str(), &e));
+    return e != 0;
+  }
+  // DataFile::read semantics: the variable is left untouched and false is returned when the key is absent
+  bool read(int& x, const std::string& name, const char* scope = nullptr) const {
+    int f = 0;
+    ck(ecckd_cfg_get_int(c_, scope, name.c_str(), &x, &f));
+    return f != 0;
+  }
+  bool read(double& x, const std::string& name, const char* scope = nullptr) const {
+    int f = 0;
+    ck(ecckd_cfg_get_real(c_, scope, name.c_str(), &x, &f));
+    return f != 0;
+  }
+  bool read(bool& x, const std::string& name, const char* scope = nullptr) const {
+    int v = 0;
+    ck(ecckd_cfg_get_boolean(c_, scope, name.c_str(), &v));
+    x = v != 0;
+    return true;
+  }
+  bool read(std::string& s, const std::string& name, const char* scope = nullptr, int index = -1) const {
+    size_t len = 0;
+    int f = 0;
+    ck(ecckd_cfg_get_string(c_, scope, name.c_str(), index, nullptr, 0, &len, &f));
+    if (!f) return false;
+    std::vector<char> buf(len + 1);
+    ck(ecckd_cfg_get_string(c_, scope, name.c_str(), index, buf.data(), buf.size(), &len, &f));
+    s.assign(buf.data(), len);
+    return true;
+  }
+  // the idx-th element of a numeric list (DataFile::read(Real&, name, j): rc_assign_real_element)
+  bool read_element(double& x, const std::string& name, int idx, const char* scope = nullptr) const {
+    std::string s;
+    if (!read(s, name, scope, idx)) return false;
+    char* end = nullptr;
+    const double v = std::strtod(s.c_str(), &end);
+    if (end == s.c_str()) return false;
+    x = v;
+    return true;
+  }
+  bool read(std::vector<double>& v, const std::string& name, const char* scope = nullptr) const {
+    int n = 0;
+    ck(ecckd_cfg_get_real_vector(c_, scope, name.c_str(), nullptr, 0, &n));
+    if (n == 0) return false;
+    v.resize(n);
+    ck(ecckd_cfg_get_real_vector(c_, scope, name.c_str(), v.data(), n, &n));
+    return true;
+  }
+  bool read(std::vector<int>& v, const std::string& name, const char* scope = nullptr) const {
+    int n = 0;
+    ck(ecckd_cfg_get_int_vector(c_, scope, name.c_str(), nullptr, 0, &n));
+    if (n == 0) return false;
+    v.resize(n);
+    ck(ecckd_cfg_get_int_vector(c_, scope, name.c_str(), v.data(), n, &n));
+    return true;
+  }
+  int count(const std::string& name, const char* scope = nullptr) const {
+    int c = 0;
+    ck(ecckd_cfg_size(c_, scope, name.c_str(), &c, nullptr, nullptr));
+    return c;
+  }
+  std::vector<std::string> read_list(const std::string& name, const char* scope = nullptr) const {
+    std::vector<std::string> out;
+    std::string s;
+    for (int i = 0; read(s, name, scope, i); ++i) out.push_back(s);
+    return out;
+  }
+  // config.read(config_str): the whole configuration as stored in the `config` attribute
+  std::string str() const {
+    size_t len = 0;
+    ck(ecckd_cfg_sprint(c_, nullptr, 0, &len));
+    std::vector<char> buf(len + 1);
+    ck(ecckd_cfg_sprint(c_, buf.data(), buf.size(), &len));
+    return std::string(buf.data(), len);
+  }
+
+ private:
+  ecckd_cfg* c_ = nullptr;
+};
+
+// ---- file search path (src/tools/file_manager.cpp:21-123) ----
+class SearchPath {
+ public:
+  SearchPath() {
+    if (const char* p = std::getenv("OPTSYN_PATH")) split(p, dirs_, false);
+    else dirs_.push_front(".");
+  }
+  void append(const std::string& path) { split(path, dirs_, false); }
+  void prepend(const std::string& path) {
+    std::deque<std::string> tmp;
+    split(path, tmp, false);
+    for (auto it = tmp.rbegin(); it != tmp.rend(); ++it) dirs_.push_front(*it);
+  }
+  void configure(const Config& config) {
+    std::string p;
+    if (config.read(p, "prepend_path")) prepend(p);
+    if (config.read(p, "append_path")) append(p);
+  }
+  // the full path of an existing file; throws CANNOT_OPEN_MANDATORY_FILE otherwise
+  std::string find(const std::string& name) const {
+    if (!name.empty() && name[0] == '/') {
+      if (readable(name)) return name;
+    } else {
+      for (const std::string& d : dirs_)
+        if (readable(d + "/" + name)) return d + "/" + name;
+    }
+    fail(ECCKD_CANNOT_OPEN_MANDATORY_FILE, "Cannot find \"%s\" in the search path", name.c_str());
+  }
+
+ private:
+  static bool readable(const std::string& p) {
+    FILE* f = std::fopen(p.c_str(), "r");
+    if (!f) return false;
+    std::fclose(f);
+    return true;
+  }
+  static void split(std::string path, std::deque<std::string>& out, bool) {
+    while (!path.empty()) {
+      const size_t end = path.find(':');
+      if (end == std::string::npos) { out.push_back(path); break; }
+      if (end > 0) out.push_back(path.substr(0, end));
+      path = path.substr(end + 1);
+    }
+  }
+  std::deque<std::string> dirs_;
+};
+
+// ---- NetCDF (classic) files ----
+class NcIn {
+ public:
+  explicit NcIn(const std::string& path) : path_(path) { ck(ecckd_nc_open(path.c_str(), &f_)); }
+  ~NcIn() { if (f_) ecckd_nc_close(f_); }
+  NcIn(const NcIn&) = delete;
+  NcIn& operator=(const NcIn&) = delete;
+
+  bool exist(const std::string& var, std::vector<size_t>* shape = nullptr, int* type = nullptr) const {
+    int e = 0, t = 0, nd = 0;
+    size_t sh[8] = {};
+    ck(ecckd_nc_inq_var(f_, var.c_str(), &e, &t, &nd, sh, 8));
+    if (e && shape) shape->assign(sh, sh + nd);
+    if (e && type) *type = t;
+    return e != 0;
+  }
+  std::vector<size_t> shape(const std::string& var) const {
+    std::vector<size_t> s;
+    if (!exist(var, &s)) fail(ECCKD_PARAMETER_ERROR, "Variable \"%s\" not found in %s", var.c_str(), path_.c_str());
+    return s;
+  }
+  // the whole variable (slice < 0) or one index of its slowest dimension
+  std::vector<double> read(const std::string& var, long long slice = -1) const {
+    std::vector<size_t> s = shape(var);
+    size_t n = 1;
+    for (size_t k = (slice >= 0 ? 1 : 0); k < s.size(); ++k) n *= s[k];
+    std::vector<double> out(n);
+    ck(ecckd_nc_read_double(f_, var.c_str(), slice, out.data(), n));
+    return out;
+  }
+  double read_scalar(const std::string& var) const { return read(var).at(0); }
+  bool att_text(const std::string& att, std::string& out, const char* var = nullptr) const {
+    int e = 0;
+    std::vector<char> buf(1 << 20);
+    ck(ecckd_nc_read_att_text(f_, var, att.c_str(), &e, buf.data(), buf.size()));
+    if (!e) return false;
+    out = buf.data();
+    return true;
+  }
+  const std::string& path() const { return path_; }
+
+ private:
+  std::string path_;
+  ecckd_nc* f_ = nullptr;
+};
+
+enum NcType { NC_BYTE_T = 1, NC_CHAR_T = 2, NC_SHORT_T = 3, NC_INT_T = 4, NC_FLOAT_T = 5, NC_DOUBLE_T = 6 };
+
+class NcOut {
+ public:
+  explicit NcOut(const std::string& path) { ck(ecckd_nc_create(path.c_str(), &f_)); }
+  ~NcOut() { if (f_) ecckd_nc_close(f_); }
+  NcOut(const NcOut&) = delete;
+  NcOut& operator=(const NcOut&) = delete;
+  void dim(const std::string& name, size_t len) {
+    int id = 0;
+    ck(ecckd_nc_def_dim(f_, name.c_str(), len, &id));
+    dims_.push_back({name, id});
+  }
+  void var(const std::string& name, int type, const std::vector<std::string>& dims = {}, const char* long_name = nullptr,
+           const char* units = nullptr) {
+    std::vector<int> ids;
+    for (const std::string& d : dims) {
+      int id = -1;
+      for (auto& p : dims_) if (p.first == d) id = p.second;
+      if (id < 0) fail(ECCKD_PARAMETER_ERROR, "Dimension \"%s\" not defined", d.c_str());
+      ids.push_back(id);
+    }
+    int vid = 0;
+    ck(ecckd_nc_def_var(f_, name.c_str(), type, (int)ids.size(), ids.data(), &vid));
+    if (long_name) att(long_name, "long_name", name.c_str());
+    if (units) att(units, "units", name.c_str());
+  }
+  void att(const std::string& text, const std::string& name, const char* var = nullptr) {
+    ck(ecckd_nc_put_att_text(f_, var, name.c_str(), text.c_str()));
+  }
+  void end_define() { ck(ecckd_nc_enddef(f_)); }
+  void write(const std::string& name, const std::vector<double>& v) { ck(ecckd_nc_write_double(f_, name.c_str(), v.data(), v.size())); }
+  template <class T>
+  void write_as_double(const std::string& name, const std::vector<T>& v) {
+    std::vector<double> d(v.begin(), v.end());
+    write(name, d);
+  }
+  void close() { if (f_) { ck(ecckd_nc_close(f_)); f_ = nullptr; } }
+
+ private:
+  ecckd_nc* f_ = nullptr;
+  std::vector<std::pair<std::string, int>> dims_;
+};
+
+// "<date>: <command line>" - the line OutputDataFile::append_history adds (OutputDataFile.cpp:1009-1048)
+inline std::string history_line(int argc, const char* const* argv) {
+  char stamp[64];
+  const std::time_t t = std::time(nullptr);
+  std::strftime(stamp, sizeof stamp, "%a %b %e %H:%M:%S %Y", std::gmtime(&t));
+  std::string s = std::string(stamp) + ":";
+  for (int i = 0; i < argc; ++i) { s += " "; s += argv[i]; }
+  return s;
+}
+
+// ---- one column of a CKDMIP spectral file (read_spectrum.cpp:20-87) ----
+struct Spectrum {
+  int ncol = 0, nlay = 0;
+  size_t nwav = 0;
+  std::vector<double> pressure_hl, temperature_hl, wavenumber_cm_1, d_wavenumber_cm_1, vmr_fl;
+  double reference_surface_vmr = -1.0;
+  std::string molecule;
+  std::vector<double> optical_depth;   // [nlay][nwav]; empty if not requested
+  bool od_is_float = false;            // stored as FLOAT in the file: can be shipped to the device as f32 without loss
+};
+
+inline void read_od_meta(const NcIn& f, int iprofile, int nlay, double& reference_surface_vmr, std::vector<double>& vmr_fl,
+                         std::string& molecule) {
+  reference_surface_vmr = f.exist("reference_surface_mole_fraction") ? f.read_scalar("reference_surface_mole_fraction") : -1.0;
+  std::vector<size_t> sh;
+  if (f.exist("mole_fraction_fl", &sh) && sh.size() == 2) vmr_fl = f.read("mole_fraction_fl", iprofile);
+  else vmr_fl.assign(nlay, -1.0);
+  molecule.clear();
+  if (!f.att_text("constituent_id", molecule)) f.att_text("molecules", molecule);
+}
+
+inline Spectrum read_spectrum(const std::string& path, int iprofile, bool want_od = true) {
+  NcIn f(path);
+  Spectrum s;
+  s.ncol = (int)f.shape("pressure_hl").at(0);
+  s.pressure_hl = f.read("pressure_hl", iprofile);
+  s.nlay = (int)s.pressure_hl.size() - 1;
+  if (f.exist("temperature_hl")) s.temperature_hl = f.read("temperature_hl", iprofile);
+  s.wavenumber_cm_1 = f.read("wavenumber");
+  s.nwav = s.wavenumber_cm_1.size();
+  if (f.exist("d_wavenumber")) {
+    s.d_wavenumber_cm_1 = f.read("d_wavenumber");
+  } else {   // :55-65
+    const size_t n = s.nwav;
+    s.d_wavenumber_cm_1.assign(n, 0.0);
+    for (size_t i = 1; i + 1 < n; ++i) s.d_wavenumber_cm_1[i] = 0.5 * (s.wavenumber_cm_1[i + 1] - s.wavenumber_cm_1[i - 1]);
+    if (n > 2) { s.d_wavenumber_cm_1[0] = 0.5 * s.d_wavenumber_cm_1[1]; s.d_wavenumber_cm_1[n - 1] = 0.5 * s.d_wavenumber_cm_1[n - 2]; }
+  }
+  read_od_meta(f, iprofile, s.nlay, s.reference_surface_vmr, s.vmr_fl, s.molecule);
+  if (want_od) {
+    int type = 0;
+    f.exist("optical_depth", nullptr, &type);
+    s.od_is_float = type == NC_FLOAT_T;
+    s.optical_depth = f.read("optical_depth", iprofile);
+    if (s.optical_depth.size() != (size_t)s.nlay * s.nwav)
+      fail(ECCKD_PARAMETER_ERROR, "optical_depth in %s is not (column, level, wavenumber)", path.c_str());
+  }
+  return s;
+}
+
+// ---- device ----
+class Device {
+ public:
+  Device() {
+    int dev = 0;
+    if (const char* e = std::getenv("ECCKD_DEVICE")) dev = std::atoi(e);
+    ck(ecckd_init(dev, &ctx_));
+  }
+  ~Device() { if (ctx_) ecckd_destroy(ctx_); }
+  Device(const Device&) = delete;
+  Device& operator=(const Device&) = delete;
+  ecckd_ctx* ctx() const { return ctx_; }
+
+ private:
+  ecckd_ctx* ctx_ = nullptr;
+};
+
+class DevBuf {
+ public:
+  DevBuf() = default;
+  DevBuf(const Device& d, size_t bytes) { alloc(d, bytes); }
+  ~DevBuf() { release(); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : ctx_(o.ctx_), p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); ctx_ = o.ctx_; p_ = o.p_; bytes_ = o.bytes_; o.p_ = nullptr; }
+    return *this;
+  }
+  void alloc(const Device& d, size_t bytes) {
+    release();
+    ctx_ = d.ctx();
+    bytes_ = bytes;
+    ck(ecckd_dev_alloc(ctx_, bytes ? bytes : 8, &p_));
+  }
+  void release() { if (p_) { ecckd_dev_free(ctx_, p_); p_ = nullptr; } }
+  template <class T> void upload(const Device& d, const std::vector<T>& v) {
+    alloc(d, v.size() * sizeof(T));
+    if (!v.empty()) ck(ecckd_h2d(ctx_, p_, v.data(), v.size() * sizeof(T)));
+  }
+  template <class T> std::vector<T> download() const {
+    std::vector<T> v(bytes_ / sizeof(T));
+    if (!v.empty()) ck(ecckd_d2h(ctx_, v.data(), p_, bytes_));
+    return v;
+  }
+  void* ptr() const { return p_; }
+  template <class T> T* as() const { return static_cast<T*>(p_); }
+  bool empty() const { return p_ == nullptr; }
+
+ private:
+  ecckd_ctx* ctx_ = nullptr;
+  void* p_ = nullptr;
+  size_t bytes_ = 0;
+};
+
+// optical depth to the device: FLOAT as stored when the file holds FLOAT, DOUBLE otherwise
+struct DevOd {
+  DevBuf buf;
+  int type = ECCKD_F64;
+};
+inline DevOd upload_od(const Device& d, const std::vector<double>& od, bool as_float) {
+  DevOd out;
+  if (as_float) {
+    std::vector<float> f(od.begin(), od.end());
+    out.buf.upload(d, f);
+    out.type = ECCKD_F32;
+  } else {
+    out.buf.upload(d, od);
+  }
+  return out;
+}
+
+// ---- read_merged_spectrum (read_merged_spectrum.cpp:20-185): keys <prefix>input / scaling / conc ----
+struct Merged {
+  Spectrum first;            // grid, pressures, temperatures of the first file (optical_depth released)
+  std::string molecules;
+  DevBuf d_od;               // DOUBLE [nlay][nwav] unless `single` is set
+  DevOd single;              // a single unscaled input is kept as stored
+  bool is_single = false;
+  const void* od_ptr() const { return is_single ? single.buf.ptr() : d_od.ptr(); }
+  int od_type() const { return is_single ? single.type : ECCKD_F64; }
+  std::vector<std::vector<double>> vmr_fl;   // one row per constituent (:153-165)
+};
+
+inline Merged read_merged_spectrum(const Device& dev, const Config& config, const SearchPath& paths, int iprofile,
+                                   const std::string& prefix) {
+  Merged m;
+  const std::vector<std::string> files = config.read_list(prefix + "input");
+  if (files.empty()) fail(ECCKD_PARAMETER_ERROR, "Unable to read input file names in %sinput", prefix.c_str());
+  if (config.exist(prefix + "conc_input"))
+    fail(ECCKD_PARAMETER_ERROR, "%sconc_input (concentration profile from a file) is not supported by this tool", prefix.c_str());
+  for (size_t ibg = 0; ibg < files.size(); ++ibg) {
+    double scaling = -1.0, conc = -1.0;
+    config.read_element(scaling, prefix + "scaling", (int)ibg);
+    config.read_element(conc, prefix + "conc", (int)ibg);
+    const std::string path = paths.find(files[ibg]);
+    LOG("  Reading %s\n", path.c_str());
+    Spectrum s;
+    if (ibg == 0) {
+      s = read_spectrum(path, iprofile);
+      m.molecules = s.molecule;
+    } else {
+      NcIn f(path);
+      int type = 0;
+      f.exist("optical_depth", nullptr, &type);
+      s.od_is_float = type == NC_FLOAT_T;
+      s.optical_depth = f.read("optical_depth", iprofile);
+      s.nlay = m.first.nlay;
+      s.nwav = m.first.nwav;
+      if (s.optical_depth.size() != (size_t)s.nlay * s.nwav)
+        fail(ECCKD_PARAMETER_ERROR, "%s: optical_depth does not match the grid of the first spectrum", path.c_str());
+      read_od_meta(f, iprofile, s.nlay, s.reference_surface_vmr, s.vmr_fl, s.molecule);
+      if (s.molecule.empty())
+        fail(ECCKD_PARAMETER_ERROR, "Found neither \"constituent_id\" nor \"molecules\" amongst the global attributes");
+      m.molecules += " " + s.molecule;
+    }
+    const std::vector<double>& p_hl = ibg == 0 ? s.pressure_hl : m.first.pressure_hl;
+    std::vector<double> profile(s.nlay), vmr_out(s.nlay);
+    ck(ecckd_merge_scaling(s.nlay, p_hl.data(), scaling, conc, s.reference_surface_vmr, s.vmr_fl.data(), 0, nullptr, nullptr,
+                           profile.data(), vmr_out.data()));
+    if (profile[0] != 1.0) LOG("    Scaling by %g\n", profile[0]);
+    m.vmr_fl.push_back(vmr_out);
+    const bool unscaled = profile[0] == 1.0;
+    if (files.size() == 1 && unscaled) {
+      m.single = upload_od(dev, s.optical_depth, s.od_is_float);
+      m.is_single = true;
+    } else {
+      if (ibg == 0) m.d_od.alloc(dev, (size_t)s.nlay * s.nwav * sizeof(double));
+      DevOd od = upload_od(dev, s.optical_depth, s.od_is_float);
+      ck(ecckd_merge_spectrum_dev(dev.ctx(), s.nlay, s.nwav, od.buf.ptr(), od.type, s.nwav, profile.data(), ibg == 0 ? 1 : 0,
+                                  m.d_od.as<double>(), s.nwav));
+      ck(ecckd_synchronize(dev.ctx()));
+    }
+    if (ibg == 0) {
+      s.optical_depth.clear();
+      s.optical_depth.shrink_to_fit();
+      m.first = std::move(s);
+    }
+  }
+  return m;
+}
+
+// ---- main wrapper: exit codes like THROW(code) (Logging.h:115-117) ----
+template <class Body>
+int run(int argc, char** argv, Body body) {
+  try {
+    Config config(argc, argv);
+    std::string lvl;
+    if (config.read(lvl, "log_level")) set_log_level(lvl);
+    return body(config);
+  } catch (const Fatal& f) {
+    std::fprintf(stderr, "*** Error: %s\n", f.msg.c_str());
+    return f.code ? f.code : 1;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "*** Error: %s\n", e.what());
+    return ECCKD_UNEXPECTED_EXCEPTION;
+  }
+}
+
+}  // namespace tool

@@ -227,6 +227,10 @@ def reorder_spectrum(ctx, input_path, output_path, band_bound1, band_bound2, ipr
     od_in = od32 if np.array_equal(od32.astype(np.float64), od) else od
     key, col, iband, rank = api.reorder_spectrum(ctx, s["pressure_hl"], s["wavenumber_cm_1"], s["d_wavenumber_cm_1"], od_in, ssi, thr,
                                                  band_bound1, band_bound2)
+    # the file stores the bounds clamped to the range of the data (reorder_spectrum.cpp:268-273)
+    wn = s["wavenumber_cm_1"]
+    band_bound1, band_bound2 = np.array(band_bound1, dtype=np.float64), np.array(band_bound2, dtype=np.float64)
+    band_bound1[0], band_bound2[-1] = max(wn[0], band_bound1[0]), min(wn[-1], band_bound2[-1])
     ncio.write_order(output_path, band_bound1, band_bound2, s["wavenumber_cm_1"], s["d_wavenumber_cm_1"], iband, rank, key, col,
                      molecule=s["molecule"] or "", config_str=config_str, history=history)
     return dict(spectrum=s, key=key, column_optical_depth=col, band_number=iband, rank=rank)
@@ -248,6 +252,7 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
     nband = len(band_bound1)
     per_gas, gas_gp = [], []
     wn = None
+    first_lw_gas = None
     tol = np.broadcast_to(np.asarray(heating_rate_tolerance, dtype=np.float64), (nband,))           # :762-771
     for spec in gases:
         s = ncio.read_spectrum(spec["input"], iprofile)
@@ -262,8 +267,13 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
                                       b["reference_surface_vmr"], b["vmr_fl"])
             bg = api.merge_spectrum(ctx, _to_device(b["optical_depth"], dev), sp, bg)
         if ssi is None:
+            # the reference evaluates the Planck function once, on the FIRST gas's reordered grid, and keeps using that
+            # matrix for the later gases (find_g_points.cpp:529, :970-984): reproduced, the first gas stays alive
+            reuse = first_lw_gas.view_ptr("planck_hl")[0] if first_lw_gas is not None else None
             gas = api.GasLW(ctx, s["pressure_hl"], s["temperature_hl"], d_wn, d_dwn, d_rank, _to_device(s["optical_depth"], dev), bg,
-                            averaging_method, flux_weight, min_pressure)
+                            averaging_method, flux_weight, min_pressure, planck_hl_reuse=reuse)
+            if first_lw_gas is None:
+                first_lw_gas = gas
             band_albedo = None
         else:
             b2 = np.asarray(band_bound2, dtype=np.float64)
@@ -277,22 +287,27 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
         sv_sorted = api.gather_f64(ctx, torch.as_tensor(order["sorting_variable"], device=dev), api.invert_permutation(ctx, d_rank))
         iband = order["band_number"]
         out = dict(name=spec["name"], n_g_points=[], band_number=[], rank1=[], rank2=[], error=[], sorting_variable=[])
+        min_gp = np.broadcast_to(np.asarray(spec.get("min_g_points", 1)), (nband,))                   # per band, :733-754
+        max_gp = np.broadcast_to(np.asarray(spec.get("max_g_points", 256)), (nband,))
         for b in range(nband):
             idx = np.nonzero(iband == b)[0]
             if band_albedo is not None:
                 gas.set_band_albedo(band_albedo[b])                                                   # init_sw(..., band_albedo(jband), ...)
             res = gas.find_g_band_ex(int(idx[0]), int(idx[-1]), float(tol[b]), tolerance_tolerance, max_iterations,
-                                     min_g_points=spec.get("min_g_points", 1), max_g_points=spec.get("max_g_points", 256))
+                                     min_g_points=int(min_gp[b]), max_g_points=int(max_gp[b]))
             n = len(res["error"])
             out["n_g_points"].append(n)
             out["band_number"] += [b] * n
             out["rank1"] += list(res["rank1"]); out["rank2"] += list(res["rank2"]); out["error"] += list(res["error"])
             out["sorting_variable"] += list(gas.median_sorting_variable(sv_sorted, res["rank1"], res["rank2"]))
-        gas.close()
+        if gas is not first_lw_gas:
+            gas.close()
         gp = api.gas_g_point(ctx, d_rank, out["rank1"], out["rank2"])
         out["g_point"] = gp.cpu().numpy()
         gas_gp.append(gp)
         per_gas.append(out)
+    if first_lw_gas is not None:
+        first_lw_gas.close()
     ng, band_number, g_min, g_max = api.overlap_g_points([g["n_g_points"] for g in per_gas],
                                                          [np.asarray(g["sorting_variable"]) for g in per_gas])
     g_point, n_unassigned = api.merge_g_points(ctx, gas_gp, g_min, g_max)

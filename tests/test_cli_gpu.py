@@ -1,0 +1,170 @@
+"""The command-line tools (bin/reorder_spectrum, bin/find_g_points) as a user of the reference would run them:
+`exe [key=value ...] [file.cfg]` on NetCDF files, exit code 0 or one of EsaExitCodes.h.  The tools are C++ above
+the C ABI and never see Python or torch; their output files must hold exactly what the host mirrors in
+ecckd_amd.pipeline produce (which tests/test_pipeline_gpu.py ties to the CPU oracle and the reference search)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.io import netcdf_file
+
+from ecckd_amd import synthetic as syn
+from test_pipeline_gpu import NLAY, _write_spectrum
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin")
+
+
+def run_tool(name, *args, cwd=None):
+    exe = os.path.join(BIN, name)
+    assert os.path.exists(exe), f"{exe} not built (python -c 'import __graft_entry__ as g; g.build()')"
+    return subprocess.run([exe, *[str(a) for a in args]], cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def _nc(path):
+    return netcdf_file(str(path), "r", mmap=False)
+
+
+def _make_lw_files(d, nwav=12000):
+    p = syn.pressure_grid(NLAY)
+    t_hl = syn.temperature_profile(p)
+    wn, _ = syn.wavenumber_grid(nwav)
+    for g, (seed, scale, vmr) in {"h2o": (41, 30.0, 5e-3), "co2": (43, 8.0, 4e-4)}.items():
+        od = syn.optical_depth(np, p, wn, syn.SEED_BASE + seed, nlines=40, column_scale=scale, dtype="float32")
+        _write_spectrum(d / f"{g}.nc", g, p, t_hl, wn, od, vmr)
+    return wn
+
+
+LW_CFG = """# written by tests/test_cli_gpu.py
+append_path "{d}"
+iprofile 0
+averaging_method "transmission"
+tolerance_tolerance 0.02
+flux_weight 0.02
+max_iterations 40
+heating_rate_tolerance 0.08
+gases h2o co2
+
+\\begin h2o
+  input h2o.nc
+  reordering_input order_h2o.nc
+  background_input "co2.nc"
+\\end h2o
+\\begin co2
+  input co2.nc
+  reordering_input order_co2.nc
+  background_input co2_bg_is_h2o.nc
+  min_g_points 2 1
+\\end co2
+"""
+
+
+def test_reorder_and_find_g_points_lw(ctx, tmp_path):
+    from ecckd_amd import ncio, pipeline
+    d = tmp_path
+    _make_lw_files(d)
+    os.symlink(d / "h2o.nc", d / "co2_bg_is_h2o.nc")
+    b1, b2 = np.array([0.0, 1300.0]), np.array([1300.0, 3260.0])
+    for g in ("h2o", "co2"):
+        r = run_tool("reorder_spectrum", f"input={d}/{g}.nc", f"output={d}/order_{g}.nc", "wavenumber1=0 1300",
+                     "wavenumber2=1300 3260", "iprofile=0")
+        assert r.returncode == 0, r.stderr
+        assert "Splitting the spectrum into 2 bands" in r.stdout
+        ref = pipeline.reorder_spectrum(ctx, d / f"{g}.nc", d / f"pyorder_{g}.nc", b1, b2)
+        got, exp = ncio.read_order(d / f"order_{g}.nc"), ncio.read_order(d / f"pyorder_{g}.nc")
+        for k in ("rank", "band_number", "sorting_variable", "wavenumber", "wavenumber1_band", "wavenumber2_band"):
+            assert np.array_equal(got[k], exp[k]), (g, k)
+        assert got["molecule"] == g and np.array_equal(got["rank"], ref["rank"])
+        f = _nc(d / f"order_{g}.nc")
+        assert b"wavenumber1={0 1300}" in f.config and b"reorder_spectrum" in f.history
+        assert f.variables["rank"].typecode() == "i" and f.variables["band_number"].typecode() == "h"
+        f.close()
+
+    (d / "find_g.cfg").write_text(LW_CFG.format(d=d))
+    r = run_tool("find_g_points", d / "find_g.cfg", f"output={d}/gpoints.nc", cwd="/")
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "*** FINDING G POINTS FOR H2O" in r.stdout and "*** COMPUTING SPECTRAL OVERLAP OF GASES" in r.stdout
+    exp = pipeline.find_g_points(ctx, [dict(name="h2o", input=d / "h2o.nc", reordering_input=d / "order_h2o.nc",
+                                            background=[dict(path=d / "co2.nc")]),
+                                       dict(name="co2", input=d / "co2.nc", reordering_input=d / "order_co2.nc",
+                                            background=[dict(path=d / "h2o.nc")], min_g_points=[2, 1])],
+                                 b1, b2, 0.08, tolerance_tolerance=0.02, max_iterations=40)
+    f = _nc(d / "gpoints.nc")
+    v = f.variables
+    assert int(v["n_gases"][...]) == 2 and f.constituent_id == b"h2o co2"
+    assert np.array_equal(v["g_point"][:], exp["g_point"]) and np.array_equal(v["band_number"][:], exp["band_number"])
+    for k, g in enumerate(("h2o", "co2")):
+        e = exp["gases"][k]
+        assert np.array_equal(v[g + "_n_g_points"][:], e["n_g_points"])
+        assert np.array_equal(v[g + "_rank1"][:], e["rank1"]) and np.array_equal(v[g + "_rank2"][:], e["rank2"])
+        assert np.array_equal(v[g + "_band_number"][:], e["band_number"])
+        assert np.array_equal(v[g + "_g_min"][:], e["g_min"][:exp["ng"]]) and np.array_equal(v[g + "_g_max"][:], e["g_max"][:exp["ng"]])
+        assert np.array_equal(v[g + "_g_point"][:], e["g_point"])
+        assert np.array_equal(v[g + "_error"][:], np.asarray(e["error"], dtype=np.float32))
+        assert np.array_equal(v[g + "_sorting_variable"][:], np.asarray(e["sorting_variable"], dtype=np.float32))
+    assert v["co2_n_g_points"][0] >= 2
+    assert b"h2o.background_input=co2.nc" in f.config
+    f.close()
+    back = ncio.read_g_points(d / "gpoints.nc")          # what create_look_up_table reads next
+    assert np.array_equal(back["g_point"], exp["g_point"])
+
+
+def test_find_g_points_sw(ctx, tmp_path):
+    from ecckd_amd import pipeline
+    d = tmp_path
+    nwav, lo, hi = 16000, 250.0, 50000.0
+    p = syn.pressure_grid(NLAY)
+    t_hl = syn.temperature_profile(p)
+    wn, dwn = syn.wavenumber_grid(nwav, lo, hi)
+    ssi = syn.solar_spectral_irradiance(wn, dwn)
+    w = netcdf_file(str(d / "ssi.nc"), "w", version=2)
+    w.createDimension("wavenumber", nwav)
+    w.createVariable("solar_spectral_irradiance", "d", ("wavenumber",))[:] = ssi
+    w.close()
+    for g, (seed, scale, vmr) in {"h2o": (61, 5.0, 5e-3), "o3": (67, 1.5, 1e-6)}.items():
+        od = syn.optical_depth(np, p, wn, syn.SEED_BASE + seed, nlines=40, column_scale=scale, dtype="float32", lo=lo, hi=hi)
+        _write_spectrum(d / f"{g}.nc", g, p, t_hl, wn, od, vmr)
+        r = run_tool("reorder_spectrum", f"input={g}.nc", f"output=order_{g}.nc", "ssi=ssi.nc", "wavenumber1=250 10000",
+                     "wavenumber2=10000 50000", cwd=d)
+        assert r.returncode == 0, r.stderr
+        assert "Assuming shortwave spectral region" in r.stdout
+    cfg = ("ssi ssi.nc\naveraging_method transmission\nheating_rate_tolerance 0.03\nmax_iterations 40\ngases h2o o3\n"
+           "\\begin h2o\n input h2o.nc\n reordering_input order_h2o.nc\n background_input o3.nc\n\\end h2o\n"
+           "\\begin o3\n input o3.nc\n reordering_input order_o3.nc\n background_input h2o.nc\n max_scaling 3.0\n\\end o3\n")
+    (d / "sw.cfg").write_text(cfg)
+    # the scripts override the averaging method on the command line (test/find_g_points_sw.sh:26)
+    r = run_tool("find_g_points", "averaging_method=total-transmission", "sw.cfg", "output=gpoints_sw.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    f = _nc(d / "order_h2o.nc")
+    b1, b2 = f.variables["wavenumber1_band"][:].astype(np.float64), f.variables["wavenumber2_band"][:].astype(np.float64)
+    f.close()
+    assert b1[0] == np.float32(wn[0]) and b2[-1] == np.float32(wn[-1])       # clamped to the data (reorder_spectrum.cpp:268-273)
+    specs = [dict(name="h2o", input=d / "h2o.nc", reordering_input=d / "order_h2o.nc", background=[dict(path=d / "o3.nc")]),
+             dict(name="o3", input=d / "o3.nc", reordering_input=d / "order_o3.nc", background=[dict(path=d / "h2o.nc")],
+                  max_scaling=3.0)]
+    exp = pipeline.find_g_points(ctx, specs, b1, b2, 0.03, averaging_method="total-transmission", max_iterations=40, ssi=ssi)
+    f = _nc(d / "gpoints_sw.nc")
+    v = f.variables
+    assert np.array_equal(v["g_point"][:], exp["g_point"])
+    for k, g in enumerate(("h2o", "o3")):
+        assert np.array_equal(v[g + "_rank1"][:], exp["gases"][k]["rank1"]) and np.array_equal(v[g + "_rank2"][:], exp["gases"][k]["rank2"])
+    solar = np.array([ssi[exp["g_point"] == ig].sum() for ig in range(exp["ng"])])
+    assert np.allclose(v["solar_irradiance"][:], solar, rtol=1e-6)
+    assert b"shortwave" in f.title
+    f.close()
+
+
+def test_exit_codes(tmp_path):
+    """THROW(code) -> process exit code (Logging.h:115-117, EsaExitCodes.h): the scripts run under `set -e`."""
+    r = run_tool("reorder_spectrum", "output=x.nc", cwd=tmp_path)
+    assert r.returncode == 147 and "\"input\" file not specified" in r.stderr          # PARAMETER_ERROR
+    r = run_tool("reorder_spectrum", "missing.cfg", cwd=tmp_path)
+    assert r.returncode == 139                                                          # CANNOT_OPEN_MANDATORY_FILE
+    r = run_tool("reorder_spectrum", "input=nothing.nc", "output=x.nc", cwd=tmp_path)
+    assert r.returncode == 139 and "nothing.nc" in r.stderr
+    (tmp_path / "bad.cfg").write_text("output g.nc\ngases h2o\n")
+    r = run_tool("find_g_points", "bad.cfg", cwd=tmp_path)
+    assert r.returncode == 147 and "heating_rate_tolerance not defined" in r.stderr

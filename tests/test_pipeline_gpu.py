@@ -69,15 +69,21 @@ def test_files_to_gpoints(ctx, oracle, tmp_path):
 
     # ---- find_g_points per gas (background = the other gas) ----
     n_g_points, medians, gas_gp, ref_gas_gp = [], [], [], []
+    first_gas = first_planck = None
     for g, other in (("h2o", "co2"), ("co2", "h2o")):
         s, bg32 = spec[g], spec[other]["od32"]
         d_rank = dev(s["rank"].astype(np.int32))
-        gas = api.GasLW(ctx, p, t_hl, dev(wn), dev(s["dwn"]), d_rank, dev(s["od32"]), dev(bg32), "transmission", 0.02, 0.0)
+        # The Planck matrix is evaluated once, on the first gas's reordered grid, and reused as it is by the later gases
+        # (find_g_points.cpp:529, :970-984): the first gas handle stays alive and lends its matrix.
+        gas = api.GasLW(ctx, p, t_hl, dev(wn), dev(s["dwn"]), d_rank, dev(s["od32"]), dev(bg32), "transmission", 0.02, 0.0,
+                        planck_hl_reuse=first_gas.view_ptr("planck_hl")[0] if first_gas is not None else None)
         # oracle: the same preparation on the CPU (find_g_points.cpp:891-1150)
         ireorder = np.empty(NWAV, dtype=np.int64)
         ireorder[s["rank"]] = np.arange(NWAV)
         od_s, bg_s = s["od32"].astype(np.float64)[:, ireorder], bg32.astype(np.float64)[:, ireorder]
-        planck = oracle.planck_function(t_hl, wn[ireorder], s["dwn"][ireorder])
+        if first_gas is None:
+            first_gas, first_planck = gas, oracle.planck_function(t_hl, wn[ireorder], s["dwn"][ireorder])
+        planck = first_planck
         fdn, fup = oracle.radiative_transfer_lw(planck, bg_s + od_s, np.ones(NWAV), planck[-1])
         hr = oracle.heating_rate(p, fdn, fup)
         key_s = s["key"][ireorder]
@@ -110,7 +116,9 @@ def test_files_to_gpoints(ctx, oracle, tmp_path):
             ref_gp[(s["rank"] >= a) & (s["rank"] <= c)] = k
         ref_gas_gp.append(ref_gp)
         assert np.array_equal(gas_gp[-1].cpu().numpy(), ref_gp)
-        gas.close()
+        if gas is not first_gas:
+            gas.close()
+    first_gas.close()
 
     # ---- overlap of the gases' g points and the merged map (find_g_points.cpp:1443-1475) ----
     ng, band_number, g_min, g_max = api.overlap_g_points(n_g_points, medians)
