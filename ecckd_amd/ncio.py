@@ -214,8 +214,13 @@ def write_ckd_model(path, model, model_id="", history="", config="", summary="")
     var("n_gases", "int", (), "Number of gases treated", comment='The gases are listed in the global attribute "constituent_id".')
     var("temperature", "float", ("temperature", "pressure"), "Temperature", "K")
     var("pressure", "float", ("pressure",), "Pressure", "Pa")
+    tsi = model.get("reference_total_solar_irradiance")
     if is_sw:
+        if tsi is not None and tsi > 0.0:                                                       # ckd_model.cpp:331-335
+            var("reference_total_solar_irradiance", "float", (), "Reference total solar irradiance", "W m-2")
         var("solar_irradiance", "float", ("g_point",), "Solar irradiance across each g point", "W m-2")
+        if model.get("solar_spectral_irradiance") is not None:                                  # :341-345
+            var("solar_spectral_irradiance", "float", ("wavenumber",), "Solar irradiance in each spectral interval", "W m-2")
     else:
         var("temperature_planck", "float", ("temperature_planck",), "Temperature for Planck function look-up table", "K")
         var("planck_function", "float", ("temperature_planck", "g_point"), "Planck function look-up table", "W m-2")
@@ -262,7 +267,11 @@ def write_ckd_model(path, model, model_id="", history="", config="", summary="")
     w.write("pressure", np.exp(np.asarray(model["log_pressure"], dtype=np.float64)))
     w.write("temperature", temp)
     if is_sw:
+        if tsi is not None and tsi > 0.0:
+            w.write("reference_total_solar_irradiance", [tsi])
         w.write("solar_irradiance", model["solar_irradiance"])
+        if model.get("solar_spectral_irradiance") is not None:
+            w.write("solar_spectral_irradiance", model["solar_spectral_irradiance"])
         if model.get("rayleigh_molar_scattering") is not None:
             w.write("rayleigh_molar_scattering_coeff", model["rayleigh_molar_scattering"])
     else:
@@ -297,6 +306,10 @@ def read_ckd_model(path, active_gases=None):
             m["planck_function"] = m["temperature_planck"] = None
             if f.exist("rayleigh_molar_scattering_coeff"):
                 m["rayleigh_molar_scattering"] = f.read("rayleigh_molar_scattering_coeff")
+            if f.exist("solar_spectral_irradiance"):
+                m["solar_spectral_irradiance"] = f.read("solar_spectral_irradiance")
+            if f.exist("reference_total_solar_irradiance"):
+                m["reference_total_solar_irradiance"] = float(f.read("reference_total_solar_irradiance"))
         else:
             m["temperature_planck"] = f.read("temperature_planck")
             m["planck_function"] = f.read("planck_function")

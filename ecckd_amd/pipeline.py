@@ -54,17 +54,18 @@ def create_look_up_table(ctx, g_point, band_number, band_wn1, band_wn2, gases, a
     ng = int(g_point.max()) + 1
     dev = ctx.device
     d_ssi = torch.as_tensor(np.asarray(ssi, dtype=np.float64), device=dev) if is_sw else None
-    gmap = None
+    gmap = hr_wavenumber = None
     model = dict(gases=[], iband_per_g=np.asarray(band_number, dtype=np.int32))
     temperature_fl = None
 
     def column(s, od_dev, ref_vmr):
-        nonlocal gmap, temperature_fl
+        nonlocal gmap, temperature_fl, hr_wavenumber
         p, t = s["pressure_hl"], s["temperature_hl"]
         if gmap is None:
             wn = torch.as_tensor(s["wavenumber_cm_1"], device=dev)
             dwn = torch.as_tensor(s["d_wavenumber_cm_1"], device=dev)
             gmap = api.GPointMap(ctx, torch.as_tensor(g_point, device=dev), ng, wn, dwn)
+            hr_wavenumber = np.asarray(s["wavenumber_cm_1"], dtype=np.float64)
             model["log_pressure"] = np.log(0.5 * (p[1:] + p[:-1]))
         t_fl = (t[:-1] * p[:-1] + t[1:] * p[1:]) / (p[:-1] + p[1:])                  # :310-311
         out = gmap.average_optical_depth(p, od_dev, averaging_method, reference_surface_vmr=ref_vmr,
@@ -134,6 +135,19 @@ def create_look_up_table(ctx, g_point, band_number, band_wn1, band_wn2, gases, a
     if is_sw:
         model["solar_irradiance"] = np.asarray(solar_irradiance, dtype=np.float64)
         model["planck_function"] = model["temperature_planck"] = None
+        # solar irradiance of each interval (:556-561) and the Rayleigh coefficient of each g point
+        # (CkdModel::calc_rayleigh_molar_scat, ckd_model.h:368-385; Bucholtz 1995, rayleigh_scattering.h:25-43)
+        w1, w2, ssi64 = model["wavenumber1"], model["wavenumber2"], np.asarray(ssi, dtype=np.float64)
+        k = np.searchsorted(w2, hr_wavenumber, side="left")                 # wavenumber1 < w <= wavenumber2
+        ok = (k < w2.size) & (hr_wavenumber > w1[np.minimum(k, w1.size - 1)])
+        model["solar_spectral_irradiance"] = np.bincount(k[ok], weights=ssi64[ok], minlength=w1.size)
+        um = 10000.0 / (0.5 * (w1 + w2))
+        xs = np.where(um < 0.5, 3.01577e-32 * um ** -(3.55212 + 1.35579 * um + 0.11563 / um),
+                      4.01061e-32 * um ** -(3.99668 + 0.00110298 * um + 0.0271393 / um))
+        molar_column = 1.0e5 / (9.80665 * 0.001 * 28.970)
+        trans_hr = np.exp(-molar_column * xs * 6.02214076e23 / 0.5)
+        gf, si = model["gpoint_fraction"], model["solar_spectral_irradiance"]
+        model["rayleigh_molar_scattering"] = -np.log(np.maximum(1.0e-14, (gf @ (si * trans_hr)) / (gf @ si))) * 0.5 / molar_column
     else:
         model["temperature_planck"] = np.arange(120.0, 351.0)                         # :581
         model["planck_function"] = gmap.planck_lut(model["temperature_planck"])        # :585-591
