@@ -265,3 +265,40 @@ def test_create_look_up_table(ctx, tmp_path, is_sw):
     f.close()
     back = ncio.read_ckd_model(str(d / "raw.nc"))              # what optimize_lut / run_ckd read next
     assert [g["name"] for g in back["gases"]] == ["composite", "co2", "ch4", "h2o"] and back["ng"] == 6
+
+
+def test_optimize_lut(ctx, tmp_path):
+    """bin/optimize_lut against the host mirror on the same files: the same library calls in the same order, so the
+    optimised coefficients in the two output files are identical."""
+    from ecckd_amd import ncio, pipeline
+    from test_pipeline_gpu import make_optimize_files
+    d = tmp_path
+    model, truth, scenes, paths, ib, names = make_optimize_files(ctx, d)
+    cfg = ("input raw.nc\noutput opt.nc\ntraining_input \"lbl0.nc\nlbl1.nc\"\ngases composite h2o co2 ch4\nmodel_id cli-test\n"
+           "flux_weight 0.2\nflux_profile_weight 0.05\nbroadband_weight 0.4\nprior_error 4.0\npressure_corr 0.95\n"
+           "temperature_corr 0.95\nconc_corr 0.9\nmax_iterations 40\nconvergence_criterion 0.0\n")
+    (d / "opt.cfg").write_text(cfg)
+    r = run_tool("optimize_lut", "opt.cfg", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "Optimizing coefficients of: composite h2o co2 ch4" in r.stdout and "Minimizer status" in r.stdout
+    raw = ncio.read_ckd_model(str(d / "raw.nc"), active_gases=["composite", "h2o", "co2", "ch4"])
+    opt_model, res = pipeline.optimize_lut(ctx, raw, paths, max_iterations=40, flux_weight=0.2, flux_profile_weight=0.05,
+                                           broadband_weight=0.4, prior_error=4.0, pressure_corr=0.95, temperature_corr=0.95,
+                                           conc_corr=0.9, min_prior_error=-1.0, max_prior_error=-1.0)
+    ncio.write_ckd_model(str(d / "py_opt.nc"), opt_model, model_id="cli-test")
+    _same_files(d / "opt.nc", d / "py_opt.nc")
+    f = _nc(d / "opt.nc")
+    assert f.model_id == b"cli-test" and b"training_input={lbl0.nc lbl1.nc}" in f.config
+    f.close()
+    # and relative to a reference scene (optimize_lut.cpp:204-254): the tool accepts it and still lowers the misfit
+    (d / "rel.cfg").write_text(cfg.replace("output opt.nc", "output opt_rel.nc").replace('"lbl0.nc\nlbl1.nc"', "lbl1.nc") + "relative_to lbl0.nc\n")
+    r = run_tool("optimize_lut", "rel.cfg", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    opt_rel, _ = pipeline.optimize_lut(ctx, raw, [paths[1]], relative_to=paths[0], max_iterations=40, flux_weight=0.2,
+                                       flux_profile_weight=0.05, broadband_weight=0.4, prior_error=4.0, pressure_corr=0.95,
+                                       temperature_corr=0.95, conc_corr=0.9, min_prior_error=-1.0, max_prior_error=-1.0)
+    ncio.write_ckd_model(str(d / "py_rel.nc"), opt_rel, model_id="cli-test")
+    _same_files(d / "opt_rel.nc", d / "py_rel.nc")
+    # exit codes
+    r = run_tool("optimize_lut", "input=raw.nc", "output=x.nc", cwd=d)
+    assert r.returncode == 147 and "training_input" in r.stderr

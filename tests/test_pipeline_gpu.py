@@ -247,9 +247,8 @@ def test_create_look_up_table_from_files(ctx, oracle, tmp_path):
     assert np.all(np.isfinite(out["flux_dn_lw"])) and out["flux_up_lw"][:, -1].min() > 0 and out["optical_depth"].min() >= 0
 
 
-def test_optimize_lut_from_files(ctx, oracle, tmp_path):
-    """optimize_lut.cpp driver through ecckd_amd.pipeline: CKD file + LBL band-flux files (made with run_ckd from a
-    "truth" model) -> bounded L-BFGS -> CKD file; the cost falls and the written file reproduces the optimised fluxes."""
+def make_optimize_files(ctx, tmp_path):
+    """A raw CKD definition (raw.nc) and two LBL band-flux training files made with run_ckd from a perturbed "truth"."""
     import sys, os
     sys.path.insert(0, os.path.dirname(__file__))
     import ckd_synth
@@ -289,6 +288,14 @@ def test_optimize_lut_from_files(ctx, oracle, tmp_path):
         w.constituent_id = " ".join(names)
         w.close()
         paths.append(str(tmp_path / f"lbl{k}.nc"))
+    return model, truth, scenes, paths, ib, names
+
+
+def test_optimize_lut_from_files(ctx, oracle, tmp_path):
+    """optimize_lut.cpp driver through ecckd_amd.pipeline: CKD file + LBL band-flux files (made with run_ckd from a
+    "truth" model) -> bounded L-BFGS -> CKD file; the cost falls and the written file reproduces the optimised fluxes."""
+    from ecckd_amd import api, ncio, pipeline
+    model, truth, scenes, paths, ib, names = make_optimize_files(ctx, tmp_path)
     raw = ncio.read_ckd_model(str(tmp_path / "raw.nc"), active_gases=["composite", "h2o", "co2", "ch4"])
     assert np.array_equal(pipeline.iband_per_g(raw, raw["wavenumber1_band"], raw["wavenumber2_band"]), ib)
     cfg = dict(flux_weight=0.2, flux_profile_weight=0.05, broadband_weight=0.4, prior_error=4.0, pressure_corr=0.95,
