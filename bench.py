@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lut-opt", action="store_true")
     ap.add_argument("--lut-opt-iterations", type=int, default=40)
+    # opt-in: the profile-sharded optimiser over ALL ranks (each rank trains on its own 8 x 50 profiles, one RCCL
+    # all-reduce of [gradient, cost] per evaluation).  Off by default so that the driver's scaling runs time the
+    # headline metric only.
+    ap.add_argument("--lut-dist", action="store_true")
     return ap.parse_args()
 
 
@@ -95,7 +99,7 @@ def cpu_baseline(nwav_s, nlay, seed, tol, tol_tol, max_it):
     return nwav_s * (1.0 + eq.total_comp_cost), dt, len(e), eq.total_comp_cost, search
 
 
-def lut_opt_bench(ctx, iterations):
+def lut_opt_bench(ctx, iterations, sharded=False, rank=0, world=1):
     """Second half of the headline metric: LUT-optimisation iterations/s (solve_adept.cpp:295-299 logs one
     line per L-BFGS iteration).  Synthetic CKD model with the shapes of configs[4]: ng = 64, 6 x 53 (T, p)
     grid, H2O look-up table with 12 mole fractions (nx ~ 3e5), 8 scenarios x 50 columns x 54 layers."""
@@ -105,7 +109,7 @@ def lut_opt_bench(ctx, iterations):
     rs = np.random.RandomState(12)
     for g in truth["gases"]:
         g["molar_abs"] = g["molar_abs"] * np.exp(0.25 * rs.normal(size=g["molar_abs"].shape))
-    scenes = syn.ckd_scenes(model, nscene=8, ncol=50, nlay=54, seed=13)
+    scenes = syn.ckd_scenes(model, nscene=8, ncol=50, nlay=54, seed=13 + 100 * rank)   # sharded: every rank its own profiles
     cfg = dict(flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, prior_error=4.0, pressure_corr=0.95,
                temperature_corr=0.95, conc_corr=0.95)       # test/optimize_lut_lw.sh:55 final pass
     ib = model["iband_per_g"]
@@ -123,6 +127,8 @@ def lut_opt_bench(ctx, iterations):
         s["flux_up"] = np.ascontiguousarray(band[c0:c0 + 50, 1])
         c0 += 50
     opt = api.Optimizer(ctx, model, scenes, **cfg)
+    if sharded:
+        opt.set_allreduce()
     x0 = opt.initial_state()
     J0, g0 = opt.cost_grad(x0)                               # warm-up
     t0 = time.perf_counter()
@@ -134,8 +140,11 @@ def lut_opt_bench(ctx, iterations):
         opt.cost_grad(x0)
     dt_eval = (time.perf_counter() - t1) / 20
     out = {"iters_per_s": res["iterations"] / dt, "iterations": res["iterations"], "nx": opt.nx,
-           "cells": 8 * 50 * 54 * 64, "cost_grad_ms": dt_eval * 1e3, "J0": J0, "J_final": res["cost"],
+           "cells": world * 8 * 50 * 54 * 64, "cost_grad_ms": dt_eval * 1e3, "J0": J0, "J_final": res["cost"],
            "status": res["status"]}
+    if sharded:
+        out["ranks"] = world
+        out["allreduce_bytes_per_evaluation"] = (opt.nx + 1) * 8
     opt.close()
     return out
 
@@ -208,6 +217,10 @@ def main():
     from ecckd_amd import shard
     dt, passes, total_cost = shard.reduce_scalars(dt, passes, info.get("cost", 0.0), device=dev)
 
+    lut_sharded = None
+    if args.lut_dist and use_dist and not args.no_lut_opt:
+        lut_sharded = lut_opt_bench(ctx, args.lut_opt_iterations, sharded=True, rank=rank, world=world)
+
     if rank == 0:
         points = nwav * passes
         # dominant kernel: K5c k_rt_lw_bb.  Algorithmic bytes per point and pass:
@@ -252,7 +265,9 @@ def main():
                                               "achieved": k1_pts * k1_bytes_per_pt / max(k1_ms * 1e-3, 1e-12) / 1e9,
                                               "algorithmic_bytes_per_point": k1_bytes_per_pt}},
         }
-        if world == 1 and not args.no_lut_opt:
+        if lut_sharded is not None:
+            out["lut_opt"] = lut_sharded
+        elif world == 1 and not args.no_lut_opt:
             out["lut_opt"] = lut_opt_bench(ctx, args.lut_opt_iterations)
         if world == 1 and not args.no_cpu:
             pts, cdt, cng, ccost, search = cpu_baseline(args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance,

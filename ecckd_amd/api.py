@@ -648,6 +648,18 @@ class Optimizer:
         except Exception:
             pass
 
+    def set_allreduce(self, group=None, add_prior=None):
+        """Profile-sharded optimisation (ecckd_opt_set_allreduce): this handle holds one rank's share of the training
+        profiles (shard.shard_scene_columns); [gradient, cost] is summed over `group` after every evaluation with one
+        all-reduce.  The prior is added by rank 0 unless `add_prior` says otherwise."""
+        import torch.distributed as dist
+        from . import shard
+        fn, keep = shard.make_allreduce_callback(group)
+        self._allreduce = (fn, keep)                      # the library keeps the pointer: keep the object alive
+        if add_prior is None:
+            add_prior = dist.get_rank(group) == 0
+        check(self.lib.ecckd_opt_set_allreduce(self.handle, C.cast(fn, C.c_void_p), None, int(bool(add_prior))))
+
     def initial_state(self, bounds=False):
         x = np.empty(self.nx)
         if not bounds:

@@ -753,6 +753,10 @@ struct ecckd_opt {
   // device L-BFGS workspace (allocated by ecckd_opt_minimize)
   double *d_xmin = nullptr, *d_xmax = nullptr, *d_xn = nullptr, *d_gn = nullptr, *d_dir = nullptr, *d_q = nullptr;
   double *d_S = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sc = nullptr;
+  // profile-sharded optimisation: sum of [gradient, J] over the ranks (ecckd_opt_set_allreduce)
+  ecckd_allreduce_fn reduce_fn = nullptr;
+  void* reduce_user = nullptr;
+  bool add_prior = true;     // exactly one rank contributes the prior term
   // timing
   long long n_eval = 0;
 };
@@ -1170,7 +1174,7 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
   o->grad_blocks = (unsigned)((o->nx + 255) / 256);
   auto dalloc = [&](double** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(double)); };
   if (dalloc(&o->d_x, o->nx) != hipSuccess || dalloc(&o->d_xprior, o->nx) != hipSuccess ||
-      dalloc(&o->d_grad, o->nx) != hipSuccess || dalloc(&o->d_dtau, o->ncell * ng) != hipSuccess ||
+      dalloc(&o->d_grad, o->nx + 1) != hipSuccess || dalloc(&o->d_dtau, o->ncell * ng) != hipSuccess ||
       dalloc(&o->d_jcol, ncol) != hipSuccess || dalloc(&o->d_jb, o->nnode_active) != hipSuccess) {
     opt_free(o);
     return ecckd::fail(ECCKD_OUT_OF_MEMORY, "ecckd_opt_create: device allocation failed");
@@ -1198,6 +1202,14 @@ size_t ecckd_opt_nx(ecckd_opt* o) { return o ? o->nx : 0; }
 // Initial state and log-space bounds, solve_adept.cpp:335-353.  h_x_min/h_x_max may be NULL;
 // unbounded elements get -/+ infinity.  Returns the gas order of the state in h_gas_order
 // (user gas indices of the active gases, in state order) if not NULL.
+int ecckd_opt_set_allreduce(ecckd_opt* o, ecckd_allreduce_fn fn, void* user, int add_prior) {
+  ECCKD_REQUIRE(o, "ecckd_opt_set_allreduce: NULL argument");
+  o->reduce_fn = fn;
+  o->reduce_user = user;
+  o->add_prior = fn == nullptr || add_prior != 0;
+  return ECCKD_OK;
+}
+
 int ecckd_opt_initial_state(ecckd_opt* o, double* h_x, double* h_x_min, double* h_x_max) {
   ECCKD_REQUIRE(o && h_x, "ecckd_opt_initial_state: NULL argument");
   for (size_t e = 0; e < o->nx; ++e) h_x[e] = o->h_k0[e] > 0.0 ? std::log(o->h_k0[e]) : MIN_X;
@@ -1240,6 +1252,8 @@ static int opt_launch_forward(ecckd_opt* o) {
 
 static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, double* J) {
   ecckd_ctx* ctx = o->ctx;
+  const bool reduce = o->reduce_fn != nullptr && o->d_od_out == nullptr;   // not for the diagnostic forward pass
+  const bool prior = o->have_prior && (!reduce || o->add_prior);
   hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, d_x, o->d_k);
   const int ng = o->ng;
   const int ngpad = (ng + 63) / 64 * 64;
@@ -1250,7 +1264,7 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
                      ((size_t)lgroups * ngpad + 16) * sizeof(double), ctx->stream, o->nnode_active, ng, ngpad, d_x, o->d_xprior,
                      o->d_k, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_dtau, o->d_node_gas, o->d_node_ic,
                      o->d_node_it, o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2,
-                     o->have_prior ? 1 : 0, d_grad, o->d_jb);
+                     prior ? 1 : 0, d_grad, o->d_jb);
   ECCKD_HIP_CHECK(hipGetLastError());
   ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jcol, o->d_jcol, o->ncol * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jb, o->d_jb, o->nnode_active * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1258,8 +1272,21 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
   double j = 0.0;
   for (size_t c = 0; c < o->ncol; ++c) j += o->h_jcol[c];  // scene/profile order, as the reference accumulates (:157)
   double jb = 0.0;
-  for (size_t c = 0; c < o->nnode_active; ++c) jb += o->h_jb[c];
+  if (prior)
+    for (size_t c = 0; c < o->nnode_active; ++c) jb += o->h_jb[c];
   *J = j + jb;
+  if (reduce) {
+    // the cost rides in the slot behind the gradient: ONE collective of nx + 1 doubles per evaluation
+    double* slot = o->h_rb + 70;
+    *slot = *J;
+    ECCKD_HIP_CHECK(hipMemcpyAsync(d_grad + o->nx, slot, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int rc = o->reduce_fn(d_grad, o->nx + 1, (void*)ctx->stream, o->reduce_user);
+    if (rc != 0) return ecckd::fail(ECCKD_PROCESSING_ERROR, "ecckd_opt: the all-reduce callback failed (%d)", rc);
+    ECCKD_HIP_CHECK(hipMemcpyAsync(slot, d_grad + o->nx, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *J = *slot;
+  }
   o->n_eval++;
   return ECCKD_OK;
 }
@@ -1339,7 +1366,7 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
     return ECCKD_OK;
   };
   constexpr int NPART = 3 + 5 * M;   // project/dots: 1 + 2M | pair: 2 + 3M
-  ECCKD_CHECK(dalloc(&o->d_xn, n)); ECCKD_CHECK(dalloc(&o->d_gn, n)); ECCKD_CHECK(dalloc(&o->d_dir, n));
+  ECCKD_CHECK(dalloc(&o->d_xn, n)); ECCKD_CHECK(dalloc(&o->d_gn, n + 1)); ECCKD_CHECK(dalloc(&o->d_dir, n));
   ECCKD_CHECK(dalloc(&o->d_q, n)); ECCKD_CHECK(dalloc(&o->d_S, (size_t)M * n)); ECCKD_CHECK(dalloc(&o->d_Y, (size_t)M * n));
   ECCKD_CHECK(dalloc(&o->d_part, (size_t)(NPART + 2) * VEC_BLOCKS)); ECCKD_CHECK(dalloc(&o->d_sc, 64));
   if (bounded) {

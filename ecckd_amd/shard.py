@@ -39,3 +39,77 @@ def reduce_scalars(elapsed_s, passes, cost, device=None, group=None):
     b = buf.cpu().numpy()
     # fixed rank order: every rank computes bit-identical totals
     return float(b[:, 0].max()), float(np.add.reduce(b[:, 1])), float(np.add.reduce(b[:, 2]))
+
+
+# ---- optimize_lut: training profiles sharded over the ranks (optimize_lut row) -------------------
+
+_PER_COLUMN = ("pressure_hl", "temperature_hl", "vmr_fl", "flux_dn", "flux_up", "spectral_flux_dn_surf", "spectral_flux_up_toa",
+               "surf_emissivity", "mu0", "temperature_fl", "relative_flux_dn", "relative_flux_up")
+
+
+def column_range(ncol, rank, world_size):
+    """Contiguous share [begin, end) of `ncol` training profiles owned by `rank` (sizes differ by at most one)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, extra = divmod(ncol, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_scene_columns(scene, rank, world_size):
+    """The scene dict of api.Optimizer restricted to this rank's profiles.  Everything indexed by column is sliced;
+    per-band / per-g-point quantities (effective albedo, boundary weights, tsi, gas_present) describe the whole
+    training set and are shared.  Every rank must keep at least one profile."""
+    ncol = np.asarray(scene["pressure_hl"]).shape[0]
+    b, e = column_range(ncol, rank, world_size)
+    if e <= b:
+        raise ValueError(f"rank {rank} of {world_size} would get none of the {ncol} profiles")
+    out = dict(scene)
+    for k in _PER_COLUMN:
+        if scene.get(k) is not None:
+            out[k] = np.ascontiguousarray(np.asarray(scene[k])[b:e])
+    return out
+
+
+def make_allreduce_callback(group=None):
+    """The ecckd_allreduce_fn for ecckd_opt_set_allreduce: ONE all-reduce (SUM) of the buffer [gradient, cost] per
+    cost-function evaluation, over torch.distributed - backend "nccl" is RCCL over xGMI on the GPU box; with the
+    "gloo" backend (CPU tests, or several ranks on one GPU) the buffer is staged through the host.
+    Returns (ctypes callback, keep-alive); a Python exception inside the callback becomes a non-zero return code,
+    which the library reports as PROCESSING_ERROR."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+
+    backend = dist.get_backend(group)
+
+    class _DevView:                                            # a (count,) float64 view of a raw device pointer
+        def __init__(self, ptr, count):
+            self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    def reduce(ptr, count, on_device):
+        if on_device:
+            t = torch.as_tensor(_DevView(ptr, count), device="cuda")
+            if backend == "gloo":
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize()
+        else:
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(count,))
+            dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM, group=group)
+
+    def cb(d_buf, count, stream, user):
+        try:
+            reduce(d_buf, count, on_device=not bool(user))
+            return 0
+        except Exception as exc:                                # never let an exception cross the C boundary
+            import sys
+            print(f"ecckd all-reduce callback failed: {exc!r}", file=sys.stderr)
+            return 1
+
+    fn = _lib.ALLREDUCE_FN(cb)
+    return fn, (cb, reduce)

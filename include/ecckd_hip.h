@@ -482,6 +482,19 @@ int ecckd_opt_coefficients(ecckd_opt* opt, const double* h_x, int gas, double* h
 int ecckd_opt_minimize(ecckd_opt* opt, int max_iterations, double convergence_criterion, int is_bounded,
                        double* h_x, int* status, int* n_iterations, double* J_final, double* gnorm_final);
 
+/* Profile-sharded optimisation over several GPUs (optimize_lut row, "profiles sharded"): the cost
+ * function is a sum over training profiles (calc_cost_function_and_gradient accumulates it profile by profile,
+ * solve_adept.cpp:157), so every rank creates its handle from ITS share of the columns of every scene and the
+ * ranks only have to agree on  sum_ranks [dJ/dx (nx doubles), J]  after each evaluation.  `fn` is called once per
+ * evaluation with that device buffer (count = nx + 1 doubles; the context's stream is idle when it is called)
+ * and must return 0 after summing it in place over the ranks - one RCCL all-reduce (ecckd_amd/shard.py makes
+ * the callback from torch.distributed).  The prior term (CkdModel::calc_background_cost_function) is not a sum over
+ * profiles: exactly one rank passes add_prior = 1.  With identical reduced values on every rank the L-BFGS
+ * iterations of ecckd_opt_minimize take the same decisions everywhere, so every rank returns the same state.
+ * fn == NULL restores single-GPU behaviour.  ecckd_opt_forward never calls fn. */
+typedef int (*ecckd_allreduce_fn)(void* d_buf, size_t count, void* stream, void* user);
+int ecckd_opt_set_allreduce(ecckd_opt* opt, ecckd_allreduce_fn fn, void* user, int add_prior);
+
 /* ---- run_ckd -------------------------------------------------------
  * Replaces the compute part of run_ckd.cpp:27-373 for the profiles of one scene (flux arrays
  * of the scene are ignored; mu0 and tsi are used for a shortwave model, run_ckd.cpp:92,:358

@@ -76,3 +76,81 @@ def test_shard_tasks_properties():
         shard.shard_tasks(5, 2, 2)
     # without an initialised process group the reduction is the identity
     assert shard.reduce_scalars(1.0, 2.0, 3.0) == (1.0, 2.0, 3.0)
+
+
+# ---- optimize_lut: profiles sharded over the ranks, one all-reduce of [gradient, cost] per evaluation ----
+
+def _quadratic(seed, ncol, nx):
+    rs = np.random.RandomState(seed)
+    return rs.normal(size=(ncol, 3, nx)), rs.normal(size=(ncol, 3))      # per-profile rows: J = sum_c 0.5 |A_c x - b_c|^2
+
+
+def _cost_grad(A, b, x):
+    r = np.einsum("cij,j->ci", A, x) - b
+    return 0.5 * float((r * r).sum()), np.einsum("cij,ci->j", A, r)
+
+
+def _opt_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import torch.distributed as dist
+    from ecckd_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ncol, nx = 7, 11
+    A, b = _quadratic(3, ncol, nx)
+    scene = dict(pressure_hl=np.zeros((ncol, 5)), temperature_hl=np.zeros((ncol, 5)), flux_dn=A, flux_up=b, albedo=np.arange(4.0), tsi=1361.0,
+                 gas_present=np.ones(3, dtype=np.int32))
+    mine = shard.shard_scene_columns(scene, rank, world)
+    fn, keep = shard.make_allreduce_callback()
+    x = np.linspace(-1.0, 1.0, nx)
+    out = []
+    for it in range(3):                                       # a few "evaluations": every rank must see the same sums
+        J, g = _cost_grad(mine["flux_dn"], mine["flux_up"], x)
+        buf = np.concatenate([g, [J]])                        # the layout ecckd_opt hands to the callback: [gradient, cost]
+        rc = fn(buf.ctypes.data_as(C.c_void_p), buf.size, None, C.c_void_p(1))      # user != NULL: host buffer (CPU test)
+        assert rc == 0
+        out.append(buf.copy())
+        x = x - 0.01 * buf[:-1]                               # identical step on every rank
+    q.put((rank, mine["pressure_hl"].shape[0], mine["albedo"].tolist(), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_profile_sharded_cost_and_gradient():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_opt_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [4, 3] and res[0][2] == res[1][2] == [0.0, 1.0, 2.0, 3.0]     # 7 profiles -> 4 + 3; shared fields whole
+    A, b = _quadratic(3, 7, 11)
+    x = np.linspace(-1.0, 1.0, 11)
+    for it in range(3):
+        J, g = _cost_grad(A, b, x)
+        for r in res:
+            assert np.allclose(r[3][it][:-1], g, rtol=1e-13, atol=1e-13) and r[3][it][-1] == pytest.approx(J, rel=1e-13)
+        assert np.array_equal(res[0][3][it], res[1][3][it])      # bit-identical on both ranks: same L-BFGS decisions
+        x = x - 0.01 * res[0][3][it][:-1]
+
+
+def test_column_range_properties():
+    sys.path.insert(0, ROOT)
+    from ecckd_amd import shard
+    for n in (1, 2, 7, 50, 150):
+        for w in (1, 2, 4, 8):
+            if n < w:
+                continue
+            r = [shard.column_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            sizes = [e - b for b, e in r]
+            assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.shard_scene_columns(dict(pressure_hl=np.zeros((1, 3))), 1, 2)
