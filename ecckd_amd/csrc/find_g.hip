@@ -233,7 +233,11 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   const double pref = (dw * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq);
   const BgT* bgc = bg_col ? bg_col + ii * NLAY : nullptr;
   const OdT* odc = od_col + ii * NLAY;
-  auto planck = [&](int level) { return ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[level]) - 1.0); };
+  // polynomial coefficients and the other literals pinned in SGPRs (fastmath.hpp): without this a third of
+  // the kernel's instructions were s_mov / v_mov pairs rebuilding 64-bit constants next to their uses
+  const ecckd::ExpConsts ek = ecckd::exp_consts();
+  const double neg_d = ecckd::sgpr_pin(-kD), inv_d = ecckd::sgpr_pin(1.0 / kD), thin = ecckd::sgpr_pin(1.0e-5);
+  auto planck = [&](int level) { return ecckd::div_fast(pref, ecckd::exp_fast_s(freq * hk[level], ek) - 1.0); };
   // local layer l is layer l (even wave) or NLAY-1-l (odd wave); its near level is where the first sweep enters
   double ee[H], s2[H], f1[H + 1];
   int lev_near = half ? NLAY : 0;
@@ -248,8 +252,8 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     const double bg = bgc ? (double)bgc[L] : 0.0;
     const double od = (double)odc[L];
     const double tau = bg + od;
-    const double eps = 1.0 - ecckd::exp_fast(-kD * tau);
-    const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;
+    const double eps = 1.0 - ecckd::exp_fast_s(neg_d * tau, ek);
+    const double fac = (eps > thin) ? 1.0 - ecckd::div_fast(eps * inv_d, tau) : 0.5 * eps;
     const double b_far = planck(lev_far);
     const double emf = eps - fac;
     const double next = flux * (1.0 - eps) + b_near * emf + b_far * fac;
@@ -258,8 +262,8 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     f1[l + 1] = next;
     double m;
     switch (method) {
-      case ECCKD_AVG_TRANSMISSION: m = 1.0 - ecckd::exp_fast(-od * kD); break;
-      case ECCKD_AVG_TRANSMISSION_2: m = 1.0 - ecckd::exp_fast(-od * kD * 2.0); break;
+      case ECCKD_AVG_TRANSMISSION: m = 1.0 - ecckd::exp_fast_s(-od * kD, ek); break;
+      case ECCKD_AVG_TRANSMISSION_2: m = 1.0 - ecckd::exp_fast_s(-od * kD * 2.0, ek); break;
       case ECCKD_AVG_SQUARE_ROOT: m = sqrt(od); break;
       default: m = od;
     }

@@ -152,23 +152,29 @@ k_reorder_key_lw_fast(size_t nwav, size_t od_stride, const double* __restrict__ 
   const double freq = wn[j] * inv_cm_2_Hz;
   const double pref = (dwn[j] * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) *
                       (freq * freq * freq);
+  const ecckd::ExpConsts ek = ecckd::exp_consts();
+  const double neg_d = ecckd::sgpr_pin(-ECCKD_LW_DIFFUSIVITY), inv_d = ecckd::sgpr_pin(1.0 / ECCKD_LW_DIFFUSIVITY);
+  const double thin = ecckd::sgpr_pin(1.0e-5);
   const OdT* odp = od + j;
+  // the optical depths are fetched a quarter of the column ahead of their use
+  constexpr int AHEAD = 14;
   OdT tau_in[NLAY];
 #pragma unroll
-  for (int l = 0; l < NLAY; ++l) tau_in[l] = odp[(size_t)l * od_stride];
+  for (int l = 0; l < AHEAD; ++l) tau_in[l] = odp[(size_t)l * od_stride];
 
   double dd[NLAY];  // dn[l+1] - dn[l], later the clamped heating rate
   double ee[NLAY];  // emissivity
   double ss[NLAY];  // upward source B_{l+1}(eps - fac) + B_l fac
-  double b_prev = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[0]) - 1.0);
+  double b_prev = ecckd::div_fast(pref, ecckd::exp_fast_s(freq * hk[0], ek) - 1.0);
   double dn = 0.0, col = 0.0, thr_height = 0.0;
   bool crossed = false;
 #pragma unroll
   for (int l = 0; l < NLAY; ++l) {
+    if (l + AHEAD < NLAY) tau_in[l + AHEAD] = odp[(size_t)(l + AHEAD) * od_stride];
     const double tau = (double)tau_in[l];
-    const double eps = 1.0 - ecckd::exp_fast(-ECCKD_LW_DIFFUSIVITY * tau);
-    const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / ECCKD_LW_DIFFUSIVITY), tau) : 0.5 * eps;
-    const double b_next = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[l + 1]) - 1.0);
+    const double eps = 1.0 - ecckd::exp_fast_s(neg_d * tau, ek);
+    const double fac = (eps > thin) ? 1.0 - ecckd::div_fast(eps * inv_d, tau) : 0.5 * eps;
+    const double b_next = ecckd::div_fast(pref, ecckd::exp_fast_s(freq * hk[l + 1], ek) - 1.0);
     const double emf = eps - fac;
     const double dn_next = dn * (1.0 - eps) + b_prev * emf + b_next * fac;
     dd[l] = dn_next - dn;
