@@ -269,9 +269,10 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     }
     if (live) {
       const size_t o = (size_t)L * n + i;
-      bg_od[o] = bg;
-      planck_hl[(size_t)lev_far * n + i] = b_far;   // level NLAY/2 is written by both waves with the same bits
-      w1[o] = m * (half ? b_near : b_far);          // weight = Planck function at the base of the layer
+      // written once, read by later kernels: streaming stores
+      __builtin_nontemporal_store(bg, &bg_od[o]);
+      __builtin_nontemporal_store(b_far, &planck_hl[(size_t)lev_far * n + i]);   // level NLAY/2 is written by both waves with the same bits
+      __builtin_nontemporal_store(m * (half ? b_near : b_far), &w1[o]);          // weight = Planck function at the base of the layer
     }
     flux = next;
     b_near = b_far;
@@ -286,7 +287,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     // conv * (dn(L+1) - dn(L) - up(L+1) + up(L)), left to right
     const double net = half ? (next - flux) - f1[l] + f1[l + 1]        // second sweep is downwelling: flux = dn(L), next = dn(L+1)
                             : (f1[l + 1] - f1[l]) - flux + next;       // second sweep is upwelling:   flux = up(L+1), next = up(L)
-    if (live) hr[(size_t)L * n + i] = conv[L] * net;
+    if (live) __builtin_nontemporal_store(conv[L] * net, &hr[(size_t)L * n + i]);
     flux = next;
   }
   if (live) {
@@ -649,9 +650,9 @@ k_rt_lw_bb_mirror(size_t n, long long chunk_pts, int nint, const Interval* __res
     double a[H];       // optical depth -> transmittance
     double b[H + 1];   // Planck function -> source of the second sweep
 #pragma unroll
-    for (int l = 0; l < H; ++l) a[l] = od0[(long long)l * row_step + (long long)ii];
+    for (int l = 0; l < H; ++l) a[l] = __builtin_nontemporal_load(&od0[(long long)l * row_step + (long long)ii]);
 #pragma unroll
-    for (int l = 0; l <= H; ++l) b[l] = pl0[(long long)l * row_step + (long long)ii];
+    for (int l = 0; l <= H; ++l) b[l] = __builtin_nontemporal_load(&pl0[(long long)l * row_step + (long long)ii]);
 
     int slot = 0;
     auto push = [&](double flux) {
