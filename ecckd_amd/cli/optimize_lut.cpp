@@ -8,8 +8,10 @@
 // prior_error, min_prior_error, max_prior_error, prior_error_scaling, temperature_corr, pressure_corr, conc_corr,
 // convergence_criterion, max_iterations, negative_od_penalty, bounded_minimization, max_no_rayleigh_wavenumber,
 // prepend_path, append_path, log_level.
-// Not handled: rayleigh_prior_error > 0 (Rayleigh scattering as an optimised pseudo-gas) and the high-resolution
-// boundary terms (spectral_boundary_weight / erythemal_weight > 0, "gpointfile").
+// spectral_boundary_weight / erythemal_weight with "gpointfile": the high-resolution surface / top-of-atmosphere
+// fluxes of the training files are summed per g point on the GPU (ecckd_gmap_sum_rows, lbl_fluxes.cpp:180-246,
+// :300-325).  Not handled: rayleigh_prior_error > 0 (Rayleigh scattering as an optimised pseudo-gas) and g points
+// saved inside the CKD file (CkdModel::read_g_points).
 // The cost function, its gradient and the L-BFGS iteration run on the GPU (ecckd_opt_*); adept::Minimizer is
 // replaced by the library's own L-BFGS, so iteration counts differ from the reference's.
 #include <algorithm>
@@ -32,6 +34,14 @@ struct Scene {
   // mapped onto the model
   std::vector<double> vmr_fl, relative_dn, relative_up;
   std::vector<int> gas_present, iband_per_g;
+  // high-resolution boundary fluxes summed per g point [ncol][ng], erythemal weights [ng] (shortwave)
+  std::vector<double> flux_dn_surf_g, flux_up_toa_g, erythemal, boundary_weights;
+};
+
+struct GPointMap {   // the g point of every wavenumber ("gpointfile"), sorted once on the device
+  ecckd_gmap* gmap = nullptr;
+  size_t nwav = 0;
+  int ng = 0;
 };
 
 // sum the file's narrow bands into the wide bands of band_mapping (:150-176, :272-296)
@@ -43,7 +53,7 @@ void map_bands(std::vector<double>& a, size_t nrow, int nb_file, const std::vect
   a.swap(out);
 }
 
-Scene read_lbl_fluxes(const std::string& path, const std::vector<int>& band_mapping) {
+Scene read_lbl_fluxes(const std::string& path, const std::vector<int>& band_mapping, const Device& dev, const GPointMap& gp) {
   NcIn f(path);
   Scene s;
   std::vector<size_t> sh = f.shape("pressure_hl");
@@ -127,6 +137,43 @@ Scene read_lbl_fluxes(const std::string& path, const std::vector<int>& band_mapp
         w2[band_mapping[j]] = std::max(w2[band_mapping[j]], s.wn2[j]);
       }
       s.wn1 = w1; s.wn2 = w2; s.nband = nb_new;
+    }
+  }
+  // high-resolution fluxes at the boundaries -> sums over the wavenumbers of each g point (:180-246, :300-325)
+  const std::string hi_dn = s.is_sw ? "spectral_flux_dn_direct_surf_sw" : "spectral_flux_dn_surf_lw";
+  const std::string hi_up = s.is_sw ? "spectral_flux_up_toa_sw" : "spectral_flux_up_toa_lw";
+  if (f.exist(hi_dn) && f.exist(hi_up)) {
+    if (!gp.gmap) {
+      WARN("Surface/TOA spectral fluxes ignored because g-point file not provided");
+    } else {
+      LOG("  Mapping high-resolution boundary fluxes to g-points\n");
+      const size_t nwav = f.shape(hi_dn).back();
+      if (nwav != gp.nwav) fail(ECCKD_PARAMETER_ERROR, "%s: %zu spectral points, the g-point file has %zu", path.c_str(), nwav, gp.nwav);
+      const int nsza_file = s.is_sw ? (int)f.shape(hi_dn).at(1) : 1;
+      s.flux_dn_surf_g.assign((size_t)s.ncol * gp.ng, 0.0);
+      s.flux_up_toa_g.assign((size_t)s.ncol * gp.ng, 0.0);
+      DevBuf d_rows(dev, (size_t)2 * nsza * nwav * sizeof(double));
+      std::vector<double> rows((size_t)2 * nsza * nwav), sums((size_t)2 * nsza * gp.ng);
+      for (int c = 0; c < ncol_file; ++c) {
+        const std::vector<double> dn = f.read(hi_dn, c), up = f.read(hi_up, c);      // LW: [nwav]; SW: [nsza_file][nwav]
+        for (int k = 0; k < nsza; ++k) {
+          const size_t off = (size_t)(s.is_sw ? index_sza[k] : 0) * nwav;
+          if (off + nwav > dn.size() || nsza_file <= (s.is_sw ? index_sza[k] : 0)) fail(ECCKD_PARAMETER_ERROR, "%s: unexpected shape of %s", path.c_str(), hi_dn.c_str());
+          std::copy(dn.begin() + off, dn.begin() + off + nwav, rows.begin() + (size_t)k * nwav);
+          std::copy(up.begin() + off, up.begin() + off + nwav, rows.begin() + (size_t)(nsza + k) * nwav);
+        }
+        ck(ecckd_h2d(dev.ctx(), d_rows.ptr(), rows.data(), rows.size() * sizeof(double)));
+        ck(ecckd_gmap_sum_rows(gp.gmap, 2 * nsza, d_rows.ptr(), ECCKD_F64, nwav, sums.data()));
+        for (int k = 0; k < nsza; ++k) {
+          std::copy(sums.begin() + (size_t)k * gp.ng, sums.begin() + (size_t)(k + 1) * gp.ng, s.flux_dn_surf_g.begin() + ((size_t)c * nsza + k) * gp.ng);
+          std::copy(sums.begin() + (size_t)(nsza + k) * gp.ng, sums.begin() + (size_t)(nsza + k + 1) * gp.ng,
+                    s.flux_up_toa_g.begin() + ((size_t)c * nsza + k) * gp.ng);
+        }
+      }
+      if (s.is_sw) {   // :198-230
+        s.erythemal.resize(gp.ng);
+        ck(ecckd_gmap_erythemal_spectrum(gp.gmap, s.erythemal.data()));
+      }
     }
   }
   if (s.is_sw) {   // effective spectral albedo (:147-148, :166-167): surface sums over every column
@@ -225,6 +272,8 @@ ecckd_opt_scene scene_view(const Scene& s) {
   o.flux_up = s.flux_up.data();
   if (s.is_sw) { o.mu0 = s.mu0.data(); o.tsi = s.tsi; o.albedo = s.albedo.data(); }
   if (!s.relative_dn.empty()) { o.relative_flux_dn = s.relative_dn.data(); o.relative_flux_up = s.relative_up.data(); }
+  if (!s.flux_dn_surf_g.empty()) { o.spectral_flux_dn_surf = s.flux_dn_surf_g.data(); o.spectral_flux_up_toa = s.flux_up_toa_g.data(); }
+  if (!s.boundary_weights.empty()) o.spectral_boundary_weights = s.boundary_weights.data();
   return o;
 }
 
@@ -272,8 +321,6 @@ int main(int argc, char** argv) {
     config.read(oc.negative_od_penalty, "negative_od_penalty");
     if (config.exist("bounded_minimization")) config.read(is_bounded, "bounded_minimization");
     if (rayleigh_prior_error > 0.0) fail(ECCKD_PARAMETER_ERROR, "rayleigh_prior_error > 0 (optimised Rayleigh scattering) is not supported by this tool");
-    if (oc.spectral_boundary_weight > 0.0 || erythemal_weight > 0.0)
-      fail(ECCKD_PARAMETER_ERROR, "spectral_boundary_weight / erythemal_weight are not supported by this tool");
     std::vector<int> band_mapping;
     if (config.exist("band_mapping")) config.read(band_mapping, "band_mapping");
 
@@ -286,10 +333,36 @@ int main(int argc, char** argv) {
       if (!found) WARN("gas \"%s\" is not in %s", g.c_str(), input.c_str());
     }
 
+    // ---- the g point of every wavenumber, for the high-resolution boundary fluxes (:166-182) ----
+    Device dev;
+    GPointMap gp;
+    DevBuf d_g_point, d_wn, d_dwn;
+    std::string gpoint_filename;
+    if (config.read(gpoint_filename, "gpointfile")) {
+      NcIn f(paths.find(gpoint_filename));
+      std::vector<int32_t> g_point;
+      for (double v : f.read("g_point")) g_point.push_back((int32_t)v);
+      if (model.ng != *std::max_element(g_point.begin(), g_point.end()) + 1)
+        fail(ECCKD_PARAMETER_ERROR, "Number of g-points in %s does not match number in %s", input.c_str(), gpoint_filename.c_str());
+      std::vector<double> wn = f.read("wavenumber"), dwn(wn.size(), 0.0);
+      for (size_t i = 1; i + 1 < wn.size(); ++i) dwn[i] = 0.5 * (wn[i + 1] - wn[i - 1]);
+      if (wn.size() > 2) { dwn[0] = 0.5 * dwn[1]; dwn[wn.size() - 1] = 0.5 * dwn[wn.size() - 2]; }
+      gp.nwav = g_point.size();
+      gp.ng = model.ng;
+      d_g_point.upload(dev, g_point);
+      d_wn.upload(dev, wn);
+      d_dwn.upload(dev, dwn);
+      ck(ecckd_gmap_create(dev.ctx(), gp.nwav, d_g_point.as<int32_t>(), gp.ng, d_wn.as<double>(), d_dwn.as<double>(), &gp.gmap));
+    }
+
     auto load = [&](const std::string& name) {
       const std::string path = paths.find(name);
       LOG("Reading %s\n", path.c_str());
-      Scene s = read_lbl_fluxes(path, band_mapping);
+      Scene s = read_lbl_fluxes(path, band_mapping, dev, gp);
+      if (s.is_sw && erythemal_weight > 0.0 && !s.erythemal.empty()) {   // solve_adept.cpp:182
+        s.boundary_weights.resize(s.erythemal.size());
+        for (size_t g = 0; g < s.erythemal.size(); ++g) s.boundary_weights[g] = erythemal_weight * s.erythemal[g];
+      }
       if (s.is_sw != model.is_sw) fail(ECCKD_PARAMETER_ERROR, "%s and the CKD model are not for the same spectral region", path.c_str());
       if (s.have_band) s.iband_per_g = iband_per_g(model, s.wn1, s.wn2);          // :273-276
       else s.iband_per_g = model.band_number;
@@ -304,7 +377,6 @@ int main(int argc, char** argv) {
       return s;
     };
 
-    Device dev;
     // ---- optional "relative_to" scene: CKD fluxes at the initial coefficients (:204-236) ----
     std::string relative_to_file;
     Scene rel;
@@ -364,6 +436,7 @@ int main(int argc, char** argv) {
         status >= 0 && status < 9 ? status_str[status] : "unknown", niter, J, gnorm);
     for (size_t i = 0; i < model.gases.size(); ++i) ck(ecckd_opt_coefficients(opt, x.data(), (int)i, model.gases[i].molar_abs.data()));
     ck(ecckd_opt_destroy(opt));
+    if (gp.gmap) ck(ecckd_gmap_destroy(gp.gmap));
 
     LOG("Writing %s\n", output.c_str());
     write_ckd(output, model, history_line(argc, argv), config.str());

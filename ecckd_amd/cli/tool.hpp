@@ -427,8 +427,17 @@ inline Merged read_merged_spectrum(const Device& dev, const Config& config, cons
   Merged m;
   const std::vector<std::string> files = config.read_list(prefix + "input");
   if (files.empty()) fail(ECCKD_PARAMETER_ERROR, "Unable to read input file names in %sinput", prefix.c_str());
-  if (config.exist(prefix + "conc_input"))
-    fail(ECCKD_PARAMETER_ERROR, "%sconc_input (concentration profile from a file) is not supported by this tool", prefix.c_str());
+  // a concentration file to scale the spectra to (:47-61): pressure_fl and <molecule>_mole_fraction_fl of one profile
+  std::string conc_file_name;
+  int iprof_conc = -1;
+  std::vector<double> pressure_conc;
+  std::string conc_path;
+  if (config.read(conc_file_name, prefix + "conc_input")) {
+    if (!config.read(iprof_conc, prefix + "iprofile"))
+      fail(ECCKD_PARAMETER_ERROR, "Concentration file specified without profile number in \"iprofile\"");
+    conc_path = paths.find(conc_file_name);
+    pressure_conc = NcIn(conc_path).read("pressure_fl", iprof_conc);
+  }
   for (size_t ibg = 0; ibg < files.size(); ++ibg) {
     double scaling = -1.0, conc = -1.0;
     config.read_element(scaling, prefix + "scaling", (int)ibg);
@@ -455,12 +464,20 @@ inline Merged read_merged_spectrum(const Device& dev, const Config& config, cons
       m.molecules += " " + s.molecule;
     }
     const std::vector<double>& p_hl = ibg == 0 ? s.pressure_hl : m.first.pressure_hl;
-    std::vector<double> profile(s.nlay), vmr_out(s.nlay);
-    ck(ecckd_merge_scaling(s.nlay, p_hl.data(), scaling, conc, s.reference_surface_vmr, s.vmr_fl.data(), 0, nullptr, nullptr,
+    std::vector<double> profile(s.nlay), vmr_out(s.nlay), conc_req;
+    if (iprof_conc >= 0) {   // :104-116
+      const std::string mol = s.molecule.substr(0, s.molecule.find(' '));
+      conc_req = NcIn(conc_path).read(mol + "_mole_fraction_fl", iprof_conc);
+      if (conc_req.size() != pressure_conc.size()) fail(ECCKD_PARAMETER_ERROR, "%s: %s_mole_fraction_fl does not match pressure_fl", conc_path.c_str(), mol.c_str());
+    }
+    ck(ecckd_merge_scaling(s.nlay, p_hl.data(), scaling, conc, s.reference_surface_vmr, s.vmr_fl.data(), (int)conc_req.size(),
+                           conc_req.empty() ? nullptr : pressure_conc.data(), conc_req.empty() ? nullptr : conc_req.data(),
                            profile.data(), vmr_out.data()));
-    if (profile[0] != 1.0) LOG("    Scaling by %g\n", profile[0]);
+    bool unscaled = true;
+    for (double v : profile) unscaled = unscaled && v == 1.0;
+    if (iprof_conc >= 0) LOG("    Scaling to target concentration profile\n");
+    else if (!unscaled) LOG("    Scaling by %g\n", profile[0]);
     m.vmr_fl.push_back(vmr_out);
-    const bool unscaled = profile[0] == 1.0;
     if (files.size() == 1 && unscaled) {
       m.single = upload_od(dev, s.optical_depth, s.od_is_float);
       m.is_single = true;

@@ -86,11 +86,17 @@ def create_look_up_table(ctx, g_point, band_number, band_wn1, band_wn2, gases, a
                 if conc == "none":
                     # read_merged_spectrum (:293-296): sum of the scaled well-mixed spectra, accumulated on the device
                     merged, first = None, None
+                    ci = spec.get("conc_input")                          # dict(path, iprofile): read_merged_spectrum.cpp:47-61
                     for item in files:
                         s = ncio.read_spectrum(item["path"], icol * temperature_stride)
                         first = first or s
+                        pc = cr = None
+                        if ci is not None:
+                            with ncio.NcFile(ci["path"]) as cf:
+                                pc = cf.read("pressure_fl", ci["iprofile"])
+                                cr = cf.read(s["molecule"].split(" ")[0] + "_mole_fraction_fl", ci["iprofile"])
                         sp, _ = api.merge_scaling(s["pressure_hl"], item.get("scaling", -1.0), item.get("conc", -1.0),
-                                                  s["reference_surface_vmr"], s["vmr_fl"])
+                                                  s["reference_surface_vmr"], s["vmr_fl"], pressure_conc=pc, conc_req=cr)
                         merged = api.merge_spectrum(ctx, _to_device(s["optical_depth"], dev), sp, merged)
                     s, od_dev, ref_vmr = first, merged, 1.0                            # reference_surface_vmr = 1 (:283)
                 else:

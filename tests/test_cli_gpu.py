@@ -233,8 +233,16 @@ def test_create_look_up_table(ctx, tmp_path, is_sw):
         w.close()
     ncio.write_g_points(d / "gpoints.nc", b1, b2, band_number, [], wn, g_point, solar_irradiance=solar, config_str="tolerance=0.1",
                         history="earlier: find_g_points")
+    # a concentration file for the well-mixed pair (read_merged_spectrum.cpp:47-61, :104-116): other pressures, two profiles
+    w = netcdf_file(str(d / "conc.nc"), "w", version=2)
+    w.createDimension("column", 2); w.createDimension("level", 5)
+    pc = np.geomspace(50.0, 9.0e4, 5)
+    w.createVariable("pressure_fl", "d", ("column", "level"))[:] = np.stack([pc, pc])
+    w.createVariable("o2_mole_fraction_fl", "d", ("column", "level"))[:] = np.stack([np.full(5, 0.3), np.linspace(0.18, 0.22, 5)])
+    w.createVariable("n2_mole_fraction_fl", "d", ("column", "level"))[:] = np.stack([np.full(5, 0.5), np.linspace(0.70, 0.80, 5)])
+    w.close()
     cfg = ("input gpoints.nc\noutput raw.nc\ngases composite co2 ch4 h2o\n"
-           "\\begin composite\n conc_dependence none\n input \"o2.nc n2.nc\"\n scaling -1 0.5\n\\end composite\n"
+           "\\begin composite\n conc_dependence none\n input \"o2.nc n2.nc\"\n conc_input conc.nc\n iprofile 1\n\\end composite\n"
            "\\begin co2\n conc_dependence linear\n input co2.nc\n\\end co2\n"
            "\\begin ch4\n conc_dependence relative-linear\n input ch4.nc\n reference_conc 1.8e-6\n\\end ch4\n"
            "\\begin h2o\n conc_dependence lut\n input \"h2o_a.nc\nh2o_b.nc\"\n\\end h2o\n")
@@ -243,7 +251,8 @@ def test_create_look_up_table(ctx, tmp_path, is_sw):
     assert r.returncode == 0, r.stderr + r.stdout
     assert "occupies none of the spectrum" in r.stderr
 
-    gases = [dict(name="composite", conc="none", inputs=[dict(path=d / "o2.nc"), dict(path=d / "n2.nc", scaling=0.5)]),
+    gases = [dict(name="composite", conc="none", inputs=[dict(path=d / "o2.nc"), dict(path=d / "n2.nc")],
+                  conc_input=dict(path=d / "conc.nc", iprofile=1)),
              dict(name="co2", conc="linear", inputs=[d / "co2.nc"]),
              dict(name="ch4", conc="relative-linear", inputs=[d / "ch4.nc"], reference_conc=1.8e-6),
              dict(name="h2o", conc="lut", inputs=[d / "h2o_a.nc", d / "h2o_b.nc"])]
@@ -261,7 +270,7 @@ def test_create_look_up_table(ctx, tmp_path, is_sw):
         fa.close(); fb.close()
     f = _nc(d / "raw.nc")
     assert f.history.startswith(b"earlier: find_g_points\n") and b"create_look_up_table lut.cfg" in f.history
-    assert b"composite.scaling={-1 0.5}" in f.config
+    assert b"composite.conc_input=conc.nc" in f.config
     f.close()
     back = ncio.read_ckd_model(str(d / "raw.nc"))              # what optimize_lut / run_ckd read next
     assert [g["name"] for g in back["gases"]] == ["composite", "co2", "ch4", "h2o"] and back["ng"] == 6
@@ -302,3 +311,40 @@ def test_optimize_lut(ctx, tmp_path):
     # exit codes
     r = run_tool("optimize_lut", "input=raw.nc", "output=x.nc", cwd=d)
     assert r.returncode == 147 and "training_input" in r.stderr
+
+
+def test_optimize_lut_boundary_fluxes(ctx, tmp_path):
+    """The scripts' longwave options (test/optimize_lut_lw.sh:55, :339): spectral_boundary_weight with a gpointfile -
+    the high-resolution surface / TOA fluxes of the training files are summed per g point on the device."""
+    import torch
+    from ecckd_amd import api, ncio, pipeline
+    from test_pipeline_gpu import make_optimize_files
+    d = tmp_path
+    model, truth, scenes, paths, ib, names = make_optimize_files(ctx, d, boundary=True)
+    cfg = ("input raw.nc\noutput opt.nc\ntraining_input \"lbl0.nc lbl1.nc\"\nprior_error 4.0\nbroadband_weight 0.8\n"
+           "flux_profile_weight 0.2\ntemperature_corr 0.95\npressure_corr 0.95\nconc_corr 0.95\nspectral_boundary_weight 0.1\n"
+           "max_iterations 30\nconvergence_criterion 0.0\n")
+    (d / "opt.cfg").write_text(cfg)
+    r = run_tool("optimize_lut", "opt.cfg", "gpointfile=gpoints.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "Mapping high-resolution boundary fluxes to g-points" in r.stdout and "ALL GASES" in r.stdout
+    gp = ncio.read_g_points(str(d / "gpoints.nc"))
+    wn = gp["wavenumber"]
+    dwn = np.empty_like(wn); dwn[1:-1] = 0.5 * (wn[2:] - wn[:-2]); dwn[0] = 0.5 * dwn[1]; dwn[-1] = 0.5 * dwn[-2]
+    dev = ctx.device
+    gmap = api.GPointMap(ctx, torch.as_tensor(gp["g_point"], device=dev), int(gp["g_point"].max()) + 1, torch.as_tensor(wn, device=dev),
+                         torch.as_tensor(dwn, device=dev))
+    raw = ncio.read_ckd_model(str(d / "raw.nc"))
+    kw = dict(max_iterations=30, flux_weight=0.02, flux_profile_weight=0.2, broadband_weight=0.8, prior_error=4.0, pressure_corr=0.95,
+              temperature_corr=0.95, conc_corr=0.95, min_prior_error=-1.0, max_prior_error=-1.0)
+    with_b, _ = pipeline.optimize_lut(ctx, raw, paths, gmap=gmap, spectral_boundary_weight=0.1, **kw)
+    without, _ = pipeline.optimize_lut(ctx, raw, paths, **kw)
+    gmap.close()
+    ncio.write_ckd_model(str(d / "py.nc"), with_b)
+    _same_files(d / "opt.nc", d / "py.nc")
+    assert any(not np.array_equal(a["molar_abs"], b["molar_abs"]) for a, b in zip(with_b["gases"], without["gases"]))   # the term acts
+    # without the g-point file the boundary fluxes are ignored with a warning, as in the reference (lbl_fluxes.cpp:300-305)
+    r = run_tool("optimize_lut", "opt.cfg", "output=opt2.nc", cwd=d)
+    assert r.returncode == 0 and "ignored because g-point file not provided" in r.stderr
+    ncio.write_ckd_model(str(d / "py2.nc"), without)
+    _same_files(d / "opt2.nc", d / "py2.nc")

@@ -247,8 +247,9 @@ def test_create_look_up_table_from_files(ctx, oracle, tmp_path):
     assert np.all(np.isfinite(out["flux_dn_lw"])) and out["flux_up_lw"][:, -1].min() > 0 and out["optical_depth"].min() >= 0
 
 
-def make_optimize_files(ctx, tmp_path):
-    """A raw CKD definition (raw.nc) and two LBL band-flux training files made with run_ckd from a perturbed "truth"."""
+def make_optimize_files(ctx, tmp_path, boundary=False):
+    """A raw CKD definition (raw.nc) and two LBL band-flux training files made with run_ckd from a perturbed "truth".
+    boundary=True adds the high-resolution surface / TOA fluxes (5 wavenumbers per g point) and gpoints.nc."""
     import sys, os
     sys.path.insert(0, os.path.dirname(__file__))
     import ckd_synth
@@ -285,9 +286,20 @@ def make_optimize_files(ctx, tmp_path):
                               ("band_wavenumber1_lw", ("band",), model["wavenumber1_band"]),
                               ("band_wavenumber2_lw", ("band",), model["wavenumber2_band"])):
             w.createVariable(name, "d", dims)[:] = a
+        if boundary:
+            K = 5
+            share = np.array([0.1, 0.3, 0.2, 0.25, 0.15])                        # how a g point's flux spreads over its wavenumbers
+            w.createDimension("wavenumber", ng * K)
+            hi = lambda a: (a[:, :, None] * share[None, None, :]).reshape(a.shape[0], ng * K)
+            w.createVariable("spectral_flux_dn_surf_lw", "d", ("column", "wavenumber"))[:] = hi(out["spectral_flux_dn_lw"][:, -1, :])
+            w.createVariable("spectral_flux_up_toa_lw", "d", ("column", "wavenumber"))[:] = hi(out["spectral_flux_up_lw"][:, 0, :])
         w.constituent_id = " ".join(names)
         w.close()
         paths.append(str(tmp_path / f"lbl{k}.nc"))
+    if boundary:
+        wn_hi = (np.arange(ng * 5) + 0.5) * 2.0
+        ncio.write_g_points(str(tmp_path / "gpoints.nc"), model["wavenumber1_band"], model["wavenumber2_band"], ib, [], wn_hi,
+                            np.repeat(np.arange(ng), 5))
     return model, truth, scenes, paths, ib, names
 
 
