@@ -1,6 +1,8 @@
 // The CKD-definition file (CkdModel::read ckd_model.cpp:32-286, CkdModel::write :290-641), classic NetCDF:
 // what create_look_up_table writes and optimize_lut / scale_lut / run_ckd read and write.
 #pragma once
+#include <algorithm>
+
 #include "tool.hpp"
 
 namespace tool {
@@ -188,6 +190,46 @@ inline CkdFile read_ckd(const std::string& path) {
   if ((int)f.read_scalar("n_gases") != (int)m.gases.size())
     fail(ECCKD_PARAMETER_ERROR, "%s: n_gases does not match constituent_id", path.c_str());
   return m;
+}
+
+// ---- the library's view of a CKD definition (ecckd_opt_model): pointers into a CkdFile that must outlive it ----
+struct ModelView {   // ecckd_opt_model over a CkdFile (pointers into it)
+  ecckd_opt_model m;
+  std::vector<ecckd_opt_gas> gases;
+  std::vector<double> log_pressure;
+  std::vector<int> iband;
+};
+
+inline void make_model(const CkdFile& f, const std::vector<std::string>& active, const std::vector<int>& iband, ModelView& v) {
+  std::memset(&v.m, 0, sizeof v.m);
+  v.log_pressure.resize(f.np);
+  for (int i = 0; i < f.np; ++i) v.log_pressure[i] = std::log(f.pressure[i]);
+  v.iband = iband;
+  v.gases.resize(f.gases.size());
+  for (size_t i = 0; i < f.gases.size(); ++i) {
+    const GasTable& g = f.gases[i];
+    ecckd_opt_gas& o = v.gases[i];
+    std::memset(&o, 0, sizeof o);
+    o.conc_dependence = g.conc;
+    o.is_active = active.empty() || std::find(active.begin(), active.end(), g.name) != active.end();
+    o.nconc = g.conc == CONC_LUT ? (int)g.vmr.size() : 0;
+    o.vmr = g.conc == CONC_LUT ? g.vmr.data() : nullptr;
+    o.reference_vmr = g.reference_vmr;
+    o.molar_abs = g.molar_abs.data();
+    o.min_molar_abs = g.min_molar_abs.empty() ? nullptr : g.min_molar_abs.data();
+    o.max_molar_abs = g.max_molar_abs.empty() ? nullptr : g.max_molar_abs.data();
+  }
+  v.m.ng = f.ng; v.m.nt = f.nt; v.m.np = f.np;
+  v.m.log_pressure = v.log_pressure.data();
+  v.m.temperature = f.temperature.data();
+  v.m.ntp = (int)f.temperature_planck.size();
+  v.m.temperature_planck = f.is_sw ? nullptr : f.temperature_planck.data();
+  v.m.planck_function = f.is_sw ? nullptr : f.planck_function.data();
+  v.m.iband_per_g = v.iband.data();
+  v.m.ngas = (int)v.gases.size();
+  v.m.gases = v.gases.data();
+  v.m.solar_irradiance = f.is_sw ? f.solar_irradiance.data() : nullptr;
+  v.m.rayleigh_molar_scattering = f.is_sw && !f.rayleigh_molar_scattering.empty() ? f.rayleigh_molar_scattering.data() : nullptr;
 }
 
 }  // namespace tool

@@ -348,3 +348,48 @@ def test_optimize_lut_boundary_fluxes(ctx, tmp_path):
     assert r.returncode == 0 and "ignored because g-point file not provided" in r.stderr
     ncio.write_ckd_model(str(d / "py2.nc"), without)
     _same_files(d / "opt2.nc", d / "py2.nc")
+
+
+def test_run_ckd(ctx, tmp_path):
+    """bin/run_ckd on a CKDMIP-style concentration file against api.run_ckd (which tests/test_run_ckd_gpu.py ties to the
+    oracle): every variable run_ckd.cpp writes, the gas list, a concentration scaling, write_od_only."""
+    from ecckd_amd import api, ncio
+    from test_pipeline_gpu import make_optimize_files
+    d = tmp_path
+    model, truth, scenes, paths, ib, names = make_optimize_files(ctx, d)
+    sc = dict(scenes[0], gas_present=None)
+    ncol, nhl = sc["pressure_hl"].shape
+    w = netcdf_file(str(d / "conc.nc"), "w", version=2)
+    for dim, n in (("column", ncol), ("half_level", nhl), ("level", nhl - 1)):
+        w.createDimension(dim, n)
+    w.createVariable("pressure_hl", "d", ("column", "half_level"))[:] = sc["pressure_hl"]
+    w.createVariable("temperature_hl", "d", ("column", "half_level"))[:] = sc["temperature_hl"]
+    for i, g in enumerate(model["gases"]):
+        if g["conc"] != "none":                                   # the well-mixed composite has no concentration variable
+            w.createVariable(names[i] + "_mole_fraction_fl", "d", ("column", "level"))[:] = sc["vmr_fl"][:, i, :]
+    w.experiment = "synthetic profiles"
+    w.close()
+    back = ncio.read_ckd_model(str(d / "raw.nc"))
+    r = run_tool("run_ckd", "ckd_model=raw.nc", "input=conc.nc", "output=out.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "assuming no concentration dependence" in r.stdout
+    exp = api.run_ckd(ctx, back, sc)
+    f = _nc(d / "out.nc")
+    assert set(exp) == set(f.variables), set(exp) ^ set(f.variables)
+    for k, v in exp.items():
+        assert f.variables[k].typecode() == "f"
+        assert np.allclose(f.variables[k][...], v, rtol=2e-6, atol=1e-30), k
+    assert f.experiment == b"synthetic profiles" and b"run_ckd ckd_model=raw.nc" in f.history
+    f.close()
+    # gas list + scaling + write_od_only (:68-90, :270-307)
+    ico2 = names.index("co2")
+    r = run_tool("run_ckd", "ckd_model=raw.nc", "input=conc.nc", "output=out2.nc", "gases=composite co2", "co2_scaling=2", "write_od_only=1", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    exp2 = api.run_ckd(ctx, back, sc, gases=["composite", "co2"], scalings={ico2: 2.0}, per_gas=False)
+    f = _nc(d / "out2.nc")
+    assert set(f.variables) == {"pressure_hl", "optical_depth", "planck_hl"}
+    assert np.allclose(f.variables["optical_depth"][...], exp2["optical_depth"], rtol=2e-6, atol=1e-30)
+    assert not np.allclose(exp2["optical_depth"], exp["optical_depth"])
+    f.close()
+    r = run_tool("run_ckd", "input=conc.nc", "output=x.nc", cwd=d)
+    assert r.returncode == 147 and "ckd_model" in r.stderr
