@@ -393,3 +393,64 @@ def test_run_ckd(ctx, tmp_path):
     f.close()
     r = run_tool("run_ckd", "input=conc.nc", "output=x.nc", cwd=d)
     assert r.returncode == 147 and "ckd_model" in r.stderr
+
+
+def test_scale_lut(ctx, tmp_path):
+    """bin/scale_lut (step 4b of test/do_all_sw.sh) against api.scale_lut + GPointMap.sum_rows on the same files."""
+    import torch
+    import ckd_synth
+    from ecckd_amd import api, ncio
+    d = tmp_path
+    model = ckd_synth.make_model_sw(seed=8)
+    ng, names = model["ng"], [g["name"] for g in model["gases"]]
+    ib, nband = model["iband_per_g"], model["nband"]
+    model.update(wavenumber1=250.0 + np.arange(ng) * 50.0, wavenumber2=250.0 + np.arange(1, ng + 1) * 50.0, gpoint_fraction=np.eye(ng),
+                 wavenumber1_band=np.array([250.0 + 50.0 * np.nonzero(ib == b)[0][0] for b in range(nband)]),
+                 wavenumber2_band=np.array([250.0 + 50.0 * (np.nonzero(ib == b)[0][-1] + 1) for b in range(nband)]))
+    ncio.write_ckd_model(str(d / "raw_sw.nc"), model)
+    K = 4
+    wn = 250.0 + (np.arange(ng * K) + 0.5) * (50.0 / K)
+    g_point = np.repeat(np.arange(ng), K)
+    ncio.write_g_points(str(d / "gpoints_sw.nc"), model["wavenumber1_band"], model["wavenumber2_band"], ib, [], wn, g_point,
+                        solar_irradiance=model["solar_irradiance"])
+    scene = ckd_synth.make_scenes(model, nscene=1, ncol=1, nlay=20)[0]
+    p, T, vmr = scene["pressure_hl"][0], scene["temperature_hl"][0], scene["vmr_fl"][0]
+    file_gases = [n for n in names if n not in ("composite", "ch4")]          # ch4 is not in the line-by-line file
+    rs = np.random.RandomState(3)
+    mu0 = 0.5
+    flux = np.empty((p.size, ng))
+    flux[0] = mu0 * rs.uniform(5.0, 30.0, ng)
+    for l in range(p.size - 1):
+        flux[l + 1] = flux[l] * np.exp(-rs.uniform(0.01, 0.4, ng) / mu0)
+    flux[12:, 3] = 0.0                                                         # one beam extinguished half way down
+    share = np.array([0.4, 0.1, 0.3, 0.2])
+    hi = (flux[:, :, None] * share[None, None, :]).reshape(p.size, ng * K)
+    w = netcdf_file(str(d / "lbl_sw.nc"), "w", version=2)
+    for dim, n in (("column", 1), ("half_level", p.size), ("level", p.size - 1), ("gas", len(file_gases)), ("sza", 5), ("wavenumber", ng * K)):
+        w.createDimension(dim, n)
+    w.createVariable("mu0", "d", ("sza",))[:] = [mu0, 0.4, 0.3, 0.2, 0.1]
+    w.createVariable("pressure_hl", "d", ("column", "half_level"))[:] = p[None]
+    w.createVariable("temperature_hl", "d", ("column", "half_level"))[:] = T[None]
+    w.createVariable("mole_fraction_fl", "d", ("column", "gas", "level"))[:] = np.stack([vmr[names.index(n)] for n in file_gases])[None]
+    w.createVariable("spectral_flux_dn_direct_sw", "d", ("column", "half_level", "wavenumber"))[:] = hi[None]
+    w.constituent_id = " ".join(n + ("-no-continuum" if n == "h2o" else "") for n in file_gases)
+    w.close()
+    r = run_tool("scale_lut", "input=raw_sw.nc", "output=scaled.nc", "gpointfile=gpoints_sw.nc", "lblfile=lbl_sw.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "Renaming h2o-no-continuum to h2o" in r.stdout
+
+    back = ncio.read_ckd_model(str(d / "raw_sw.nc"))
+    dev = ctx.device
+    dwn = np.empty_like(wn); dwn[1:-1] = 0.5 * (wn[2:] - wn[:-2]); dwn[0] = 0.5 * dwn[1]; dwn[-1] = 0.5 * dwn[-2]
+    gm = api.GPointMap(ctx, torch.as_tensor(g_point.astype(np.int32), device=dev), ng, torch.as_tensor(wn, device=dev), torch.as_tensor(dwn, device=dev))
+    sums = gm.sum_rows(torch.as_tensor(hi, device=dev))
+    gm.close()
+    present = np.array([1 if (n == "composite" or n in file_gases) else 0 for n in names], dtype=np.int32)
+    vm = np.where(present[:, None] == 1, vmr, 0.0)
+    outs, scaling = api.scale_lut(ctx, back, sums, p, T, vm, present, mu0)
+    assert np.all(scaling[11:, 3] == 1.0) and np.abs(scaling - 1.0).max() > 0.05
+    scaled = dict(back, gases=[dict(g, molar_abs=o) for g, o in zip(back["gases"], outs)])
+    ncio.write_ckd_model(str(d / "py_scaled.nc"), scaled)
+    _same_files(d / "scaled.nc", d / "py_scaled.nc")
+    r = run_tool("scale_lut", "input=raw_sw.nc", "output=x.nc", "lblfile=lbl_sw.nc", cwd=d)
+    assert r.returncode == 147 and "gpointfile not provided" in r.stderr
