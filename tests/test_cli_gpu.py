@@ -454,3 +454,54 @@ def test_scale_lut(ctx, tmp_path):
     _same_files(d / "scaled.nc", d / "py_scaled.nc")
     r = run_tool("scale_lut", "input=raw_sw.nc", "output=x.nc", "lblfile=lbl_sw.nc", cwd=d)
     assert r.returncode == 147 and "gpointfile not provided" in r.stderr
+
+
+def test_do_all_lw_with_the_tools(ctx, oracle, tmp_path):
+    """test/do_all_lw.sh with the binaries only: reorder_spectrum -> find_g_points -> create_look_up_table -> optimize_lut ->
+    run_ckd (raw and optimised definitions), every hand-over a NetCDF file, every option a config key.  The line-by-line
+    training fluxes (external ckdmip_lw in the reference's scripts) come from the LBL stand-in.  Judged like the scripts' own
+    evaluation: heating-rate RMS error against the line-by-line fluxes (plot/calc_hr_error.m)."""
+    from test_pipeline_gpu import hr_error_against_lbl, make_do_all_inputs
+    d = tmp_path
+    inp = make_do_all_inputs(ctx, d)
+    ok = lambda r: (r.returncode == 0, r.stderr + r.stdout)
+    for g in ("h2o", "co2"):
+        r = run_tool("reorder_spectrum", f"input=present_{g}.nc", f"output=order_{g}.nc", "wavenumber1=0 1300", "wavenumber2=1300 3260", cwd=d)
+        assert ok(r)[0], ok(r)[1]
+    (d / "find_g.cfg").write_text(
+        "heating_rate_tolerance 0.3\nmax_iterations 30\naveraging_method transmission\ngases h2o co2\n"
+        "\\begin h2o\n input present_h2o.nc\n reordering_input order_h2o.nc\n background_input present_co2.nc\n\\end h2o\n"
+        "\\begin co2\n input present_co2.nc\n reordering_input order_co2.nc\n background_input present_h2o.nc\n\\end co2\n")
+    r = run_tool("find_g_points", "find_g.cfg", "output=gpoints.nc", cwd=d)
+    assert ok(r)[0], ok(r)[1]
+    (d / "lut.cfg").write_text(
+        "input gpoints.nc\noutput raw_ckd.nc\ngases h2o co2\n"
+        "\\begin h2o\n conc_dependence lut\n input \"ideal_h2o.nc ideal_h2o_x4.nc\"\n\\end h2o\n"
+        "\\begin co2\n conc_dependence linear\n input ideal_co2.nc\n\\end co2\n")
+    r = run_tool("create_look_up_table", "lut.cfg", cwd=d)
+    assert ok(r)[0], ok(r)[1]
+    r = run_tool("optimize_lut", "input=raw_ckd.nc", "output=ckd.nc", "training_input=lbl.nc", "max_iterations=80", "flux_weight=0.2",
+                 "flux_profile_weight=0.05", "broadband_weight=0.5", "prior_error=8.0", "convergence_criterion=0", "model_id=do_all_lw", cwd=d)
+    assert ok(r)[0], ok(r)[1]
+    # evaluation profiles for run_ckd: the training file's own columns
+    ncol, nlay = inp["ncol"], inp["nlay"]
+    w = netcdf_file(str(d / "eval.nc"), "w", version=2)
+    for dim, n in (("column", ncol), ("half_level", nlay + 1), ("level", nlay)):
+        w.createDimension(dim, n)
+    w.createVariable("pressure_hl", "d", ("column", "half_level"))[:] = np.tile(inp["p1"], (ncol, 1))
+    w.createVariable("temperature_hl", "d", ("column", "half_level"))[:] = inp["T"]
+    for i, g in enumerate(("h2o", "co2")):
+        w.createVariable(g + "_mole_fraction_fl", "d", ("column", "level"))[:] = inp["vmr"][:, i, :]
+    w.close()
+    errs = {}
+    for tag, ckd in (("raw", "raw_ckd.nc"), ("optimised", "ckd.nc")):
+        r = run_tool("run_ckd", f"ckd_model={ckd}", "input=eval.nc", f"output=fluxes_{tag}.nc", cwd=d)
+        assert ok(r)[0], ok(r)[1]
+        f = _nc(d / f"fluxes_{tag}.nc")
+        errs[tag] = hr_error_against_lbl(oracle, inp, f.variables["flux_dn_lw"][...].astype(np.float64), f.variables["flux_up_lw"][...].astype(np.float64))
+        f.close()
+    print("heating-rate RMS error (K/day), tools only:", errs)
+    assert np.isfinite(errs["raw"]) and errs["optimised"] < 0.9 * errs["raw"] and errs["optimised"] < 1.0
+    f = _nc(d / "ckd.nc")
+    assert f.model_id == b"do_all_lw" and f.history.count(b"\n") >= 2          # find_g_points, create_look_up_table, optimize_lut lines
+    f.close()

@@ -330,12 +330,11 @@ def test_optimize_lut_from_files(ctx, oracle, tmp_path):
     assert np.abs(a - tr).max() < np.abs(r0 - tr).max()
 
 
-def test_do_all_lw_synthetic(ctx, oracle, tmp_path):
-    """The whole chain of test/do_all_lw.sh on a small synthetic problem, every step through the driver mirrors:
-    reorder_spectrum -> find_g_points -> create_look_up_table -> LBL training fluxes -> optimize_lut -> run_ckd,
-    judged by the heating-rate RMS error of plot/calc_hr_error.m against the line-by-line fluxes."""
-    from ecckd_amd import api, ncio, pipeline
-    from test_run_ckd_gpu import calc_hr_error
+def make_do_all_inputs(ctx, tmp_path):
+    """Inputs of the do_all_lw chain on a small synthetic problem: "present" spectra of two gases (1 column), "idealised"
+    spectra (3 temperature columns, water vapour also at 4x), and a line-by-line training file (lbl.nc) with the band fluxes
+    of three evaluation columns computed by the LBL stand-in (ecckd_lbl_band_fluxes_lw)."""
+    from ecckd_amd import api, ncio
     dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=ctx.device)
     nlay, nwav = 16, 8000
     p1 = syn.pressure_grid(nlay)
@@ -365,22 +364,7 @@ def test_do_all_lw_synthetic(ctx, oracle, tmp_path):
         write(tmp_path / f"present_{g}.nc", g, [t0])
         write(tmp_path / f"ideal_{g}.nc", g, ideal_t)
     write(tmp_path / "ideal_h2o_x4.nc", "h2o", ideal_t, factor=4.0)
-    # 1-2. reorder each gas, partition
-    for g in base:
-        pipeline.reorder_spectrum(ctx, tmp_path / f"present_{g}.nc", tmp_path / f"order_{g}.nc", bands[0], bands[1])
-    gp = pipeline.find_g_points(ctx, [dict(name="h2o", input=tmp_path / "present_h2o.nc", reordering_input=tmp_path / "order_h2o.nc",
-                                           background=[dict(path=tmp_path / "present_co2.nc")]),
-                                      dict(name="co2", input=tmp_path / "present_co2.nc", reordering_input=tmp_path / "order_co2.nc",
-                                           background=[dict(path=tmp_path / "present_h2o.nc")])],
-                                bands[0], bands[1], 0.3, output_path=tmp_path / "gpoints.nc", max_iterations=30)
-    assert 4 <= gp["ng"] <= 40 and gp["n_unassigned"] == 0
-    gpf = ncio.read_g_points(tmp_path / "gpoints.nc")
-    # 3. raw look-up table
-    raw = pipeline.create_look_up_table(ctx, gpf["g_point"], gpf["band_number"], bands[0], bands[1],
-                                        [dict(name="h2o", conc="lut", inputs=[tmp_path / "ideal_h2o.nc", tmp_path / "ideal_h2o_x4.nc"]),
-                                         dict(name="co2", conc="linear", inputs=[tmp_path / "ideal_co2.nc"])])
-    ncio.write_ckd_model(str(tmp_path / "raw_ckd.nc"), raw)
-    # 4. line-by-line training fluxes of three evaluation columns (other temperatures, other gas amounts)
+    # line-by-line training fluxes of three evaluation columns (other temperatures, other gas amounts)
     ncol = 3
     T = np.stack([t0 - 8.0, t0 + 3.0, t0 + 11.0])
     amount = {"h2o": np.array([0.7, 1.5, 3.0]), "co2": np.array([1.0, 2.0, 0.5])}
@@ -405,24 +389,52 @@ def test_do_all_lw_synthetic(ctx, oracle, tmp_path):
         w.createVariable(name, "d", dims)[:] = a
     w.constituent_id = "h2o co2"
     w.close()
-    # 5. optimise
+    return dict(p1=p1, wn=wn, bands=bands, base=base, ncol=ncol, T=T, vmr=vmr, bdn=bdn, bup=bup, nlay=nlay)
+
+
+def hr_error_against_lbl(oracle, inp, flux_dn, flux_up):
+    """Heating-rate RMS error (plot/calc_hr_error.m) of broadband fluxes (ncol, nhl) against the line-by-line ones."""
+    from test_run_ckd_gpu import calc_hr_error
+    p1, ncol = inp["p1"], inp["ncol"]
+    hr_of = lambda dn, up: np.stack([oracle.heating_rate(p1, dn[c][:, None], up[c][:, None])[:, 0] for c in range(ncol)]) * 86400.0
+    P = np.tile(p1, (ncol, 1))
+    return calc_hr_error(P.T / 100.0, hr_of(flux_dn, flux_up).T, hr_of(inp["bdn"].sum(-1), inp["bup"].sum(-1)).T)
+
+
+def test_do_all_lw_synthetic(ctx, oracle, tmp_path):
+    """The whole chain of test/do_all_lw.sh on a small synthetic problem, every step through the driver mirrors:
+    reorder_spectrum -> find_g_points -> create_look_up_table -> LBL training fluxes -> optimize_lut -> run_ckd,
+    judged by the heating-rate RMS error of plot/calc_hr_error.m against the line-by-line fluxes."""
+    from ecckd_amd import api, ncio, pipeline
+    inp = make_do_all_inputs(ctx, tmp_path)
+    bands, p1, ncol = inp["bands"], inp["p1"], inp["ncol"]
+    # 1-2. reorder each gas, partition
+    for g in inp["base"]:
+        pipeline.reorder_spectrum(ctx, tmp_path / f"present_{g}.nc", tmp_path / f"order_{g}.nc", bands[0], bands[1])
+    gp = pipeline.find_g_points(ctx, [dict(name="h2o", input=tmp_path / "present_h2o.nc", reordering_input=tmp_path / "order_h2o.nc",
+                                           background=[dict(path=tmp_path / "present_co2.nc")]),
+                                      dict(name="co2", input=tmp_path / "present_co2.nc", reordering_input=tmp_path / "order_co2.nc",
+                                           background=[dict(path=tmp_path / "present_h2o.nc")])],
+                                bands[0], bands[1], 0.3, output_path=tmp_path / "gpoints.nc", max_iterations=30)
+    assert 4 <= gp["ng"] <= 40 and gp["n_unassigned"] == 0
+    gpf = ncio.read_g_points(tmp_path / "gpoints.nc")
+    # 3. raw look-up table
+    raw = pipeline.create_look_up_table(ctx, gpf["g_point"], gpf["band_number"], bands[0], bands[1],
+                                        [dict(name="h2o", conc="lut", inputs=[tmp_path / "ideal_h2o.nc", tmp_path / "ideal_h2o_x4.nc"]),
+                                         dict(name="co2", conc="linear", inputs=[tmp_path / "ideal_co2.nc"])])
+    ncio.write_ckd_model(str(tmp_path / "raw_ckd.nc"), raw)
+    # 4-5. optimise against the line-by-line training fluxes
     model = ncio.read_ckd_model(str(tmp_path / "raw_ckd.nc"))
     opt_model, res = pipeline.optimize_lut(ctx, model, [str(tmp_path / "lbl.nc")], max_iterations=80, flux_weight=0.2,
                                            flux_profile_weight=0.05, broadband_weight=0.5, prior_error=8.0)
     print("optimize_lut:", {k: v for k, v in res.items() if k != "x"})
     assert res["status"] in (0, 2, 3)                            # optimize_lut.cpp:315-324 fails only for status >= 6
     # 6. evaluate both models against the line-by-line heating rates
-    scene = dict(pressure_hl=np.tile(p1, (ncol, 1)), temperature_hl=T, vmr_fl=vmr)
-    P = np.tile(p1, (ncol, 1))
-
-    def hr_of(dn, up):
-        return np.stack([oracle.heating_rate(p1, dn[c][:, None], up[c][:, None])[:, 0] for c in range(ncol)]) * 86400.0
-
-    hr_lbl = hr_of(bdn.sum(-1), bup.sum(-1))
+    scene = dict(pressure_hl=np.tile(p1, (ncol, 1)), temperature_hl=inp["T"], vmr_fl=inp["vmr"])
     errs = {}
     for tag, m in (("raw", model), ("optimised", opt_model)):
         out = api.run_ckd(ctx, m, scene, per_gas=False)
-        errs[tag] = calc_hr_error(P.T / 100.0, hr_of(out["flux_dn_lw"], out["flux_up_lw"]).T, hr_lbl.T)
+        errs[tag] = hr_error_against_lbl(oracle, inp, out["flux_dn_lw"], out["flux_up_lw"])
     print("heating-rate RMS error (K/day):", errs)
     assert np.isfinite(errs["raw"]) and errs["optimised"] < 0.9 * errs["raw"]
     assert errs["optimised"] < 1.0                               # K/day on this toy problem (tolerance 0.3 K/day per gas and band)
