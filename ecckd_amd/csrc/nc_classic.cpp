@@ -1,7 +1,8 @@
 // nc_classic.cpp - a self-contained reader / writer for the NetCDF CLASSIC on-disk formats
 // (CDF-1, CDF-2 "64-bit offset", CDF-5 "64-bit data"), which is what the reference produces and
 // consumes for files named *.nc / *.cdf (src/tools/DataFile.cpp:88-96, OutputDataFile.cpp:84-157).
-// The image has no NetCDF library; NetCDF-4 (*.h5, HDF5 container) is NOT handled here.
+// The image has no NetCDF library.  NetCDF-4 files (HDF5 containers) are recognised by their signature and READ
+// through nc_hdf5.cpp (the system's HDF5 library, loaded at run time); everything written is classic.
 //
 // Layout (NetCDF classic format specification): big-endian throughout;
 //   header = magic numrecs dim_list gatt_list var_list;  lists = tag(4) nelems [entries] or ABSENT (two zeros);
@@ -13,6 +14,7 @@
 // (src/tools/DataFileEngineNetcdf.cpp:593-599); `slice` selects one index of the slowest dimension
 // like DataFile::read(M, "v", j) (:582-590).
 #include "common.hpp"
+#include "nc_hdf5.hpp"
 
 #include <algorithm>
 #include <cctype>
@@ -94,6 +96,7 @@ void encode(unsigned char* p, int t, double v) {
 }  // namespace
 
 struct ecckd_nc {
+  ecckd::H5File* h5 = nullptr;   // set for a NetCDF-4 file opened for reading; the classic fields are then unused
   FILE* fp = nullptr;
   bool writing = false, defining = false;
   int version = 1;
@@ -284,6 +287,18 @@ int ecckd_nc_open(const char* path, ecckd_nc** out) {
   *out = nullptr;
   FILE* fp = std::fopen(path, "rb");
   if (!fp) return ecckd::fail(ECCKD_PARAMETER_ERROR, "cannot open %s for reading", path);
+  unsigned char magic[8] = {};
+  if (std::fread(magic, 1, 8, fp) == 8 && ecckd::h5_is_hdf5(magic)) {
+    std::fclose(fp);
+    ecckd::H5File* h5 = nullptr;
+    ECCKD_CHECK(ecckd::h5_open(path, &h5));
+    ecckd_nc* f = new ecckd_nc;
+    f->h5 = h5;
+    f->path = path;
+    *out = f;
+    return ECCKD_OK;
+  }
+  std::rewind(fp);
   ecckd_nc* f = new ecckd_nc;
   f->fp = fp;
   f->path = path;
@@ -295,6 +310,7 @@ int ecckd_nc_open(const char* path, ecckd_nc** out) {
 
 int ecckd_nc_close(ecckd_nc* f) {
   if (!f) return ECCKD_OK;
+  if (f->h5) { ecckd::h5_close(f->h5); delete f; return ECCKD_OK; }
   int rc = ECCKD_OK;
   if (f->writing && f->defining) rc = ecckd::fail(ECCKD_PROCESSING_ERROR, "%s closed while still in define mode", f->path.c_str());
   if (f->fp && std::fclose(f->fp) != 0) rc = ecckd::fail(ECCKD_PROCESSING_ERROR, "error closing %s", f->path.c_str());
@@ -304,6 +320,7 @@ int ecckd_nc_close(ecckd_nc* f) {
 
 int ecckd_nc_inq_dim(ecckd_nc* f, const char* name, size_t* len) {
   ECCKD_REQUIRE(f && name && len, "ecckd_nc_inq_dim: NULL argument");
+  if (f->h5) return ecckd::h5_inq_dim(f->h5, name, len);
   for (const Dim& d : f->dims)
     if (d.name == name) { *len = (size_t)(d.len == 0 ? f->numrecs : d.len); return ECCKD_OK; }
   return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: no dimension \"%s\"", f->path.c_str(), name);
@@ -311,6 +328,7 @@ int ecckd_nc_inq_dim(ecckd_nc* f, const char* name, size_t* len) {
 
 int ecckd_nc_inq_var(ecckd_nc* f, const char* name, int* exists, int* nc_type, int* ndims, size_t* shape, int shape_capacity) {
   ECCKD_REQUIRE(f && name && exists, "ecckd_nc_inq_var: NULL argument");
+  if (f->h5) return ecckd::h5_inq_var(f->h5, name, exists, nc_type, ndims, shape, shape_capacity);
   const Var* v = f->find(name);
   *exists = v ? 1 : 0;
   if (!v) return ECCKD_OK;
@@ -327,6 +345,7 @@ int ecckd_nc_inq_var(ecckd_nc* f, const char* name, int* exists, int* nc_type, i
 
 int ecckd_nc_read_double(ecckd_nc* f, const char* name, long long slice, double* out, size_t capacity) {
   ECCKD_REQUIRE(f && name && out && !f->writing, "ecckd_nc_read_double: bad argument");
+  if (f->h5) return ecckd::h5_read_double(f->h5, name, slice, out, capacity);
   const Var* v = f->find(name);
   if (!v) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: no variable \"%s\"", f->path.c_str(), name);
   std::vector<uint64_t> sh;
@@ -376,6 +395,7 @@ static const Att* find_att(ecckd_nc* f, const char* var, const char* att, int* r
 
 int ecckd_nc_read_att_text(ecckd_nc* f, const char* var, const char* att, int* exists, char* out, size_t capacity) {
   ECCKD_REQUIRE(f && att && exists, "ecckd_nc_read_att_text: NULL argument");
+  if (f->h5) return ecckd::h5_read_att_text(f->h5, var, att, exists, out, capacity);
   int rc;
   const Att* a = find_att(f, var, att, &rc);
   if (rc != ECCKD_OK) return rc;
@@ -390,6 +410,7 @@ int ecckd_nc_read_att_text(ecckd_nc* f, const char* var, const char* att, int* e
 
 int ecckd_nc_read_att_double(ecckd_nc* f, const char* var, const char* att, int* nelems, double* out, size_t capacity) {
   ECCKD_REQUIRE(f && att && nelems, "ecckd_nc_read_att_double: NULL argument");
+  if (f->h5) return ecckd::h5_read_att_double(f->h5, var, att, nelems, out, capacity);
   int rc;
   const Att* a = find_att(f, var, att, &rc);
   if (rc != ECCKD_OK) return rc;

@@ -1,0 +1,281 @@
+// nc_hdf5.cpp - reading NetCDF-4 files (HDF5 containers: the CKDMIP spectra, everything the reference's scripts
+// name *.h5) through the system's HDF5 C library, loaded at run time.
+//
+// The image ships no NetCDF library and no HDF5 development package, but an HDF5 1.10 shared library is present
+// (/opt/conda/lib).  It is dlopen'ed on first use - ECCKD_HDF5_LIB, then the usual sonames - so the product has no
+// link-time dependency and classic files keep working where the library is missing.  Only what DataFile does with a
+// NetCDF-4 file on the hot path is provided (src/tools/DataFileEngineNetcdf.cpp): existence and shape of a variable,
+// whole-variable or one-slice reads converted to double (nc_get_vara_double, :593-599; the HDF5 filters - shuffle,
+// deflate - run inside H5Dread), numeric and text attributes, dimension lengths.  Writing stays classic: the
+// NetCDF library the reference links detects the format from the file's first bytes, not from its name, so a classic
+// file called *.h5 is read back correctly by both sides.
+#include <dlfcn.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "nc_hdf5.hpp"
+
+namespace {
+
+typedef int64_t hid_t;
+typedef unsigned long long hsize_t;
+typedef int herr_t;
+typedef int htri_t;
+
+struct Api {
+  void* lib = nullptr;
+  herr_t (*H5open)();
+  herr_t (*H5Eset_auto2)(hid_t, void*, void*);
+  hid_t (*H5Fopen)(const char*, unsigned, hid_t);
+  herr_t (*H5Fclose)(hid_t);
+  htri_t (*H5Lexists)(hid_t, const char*, hid_t);
+  hid_t (*H5Dopen2)(hid_t, const char*, hid_t);
+  herr_t (*H5Dclose)(hid_t);
+  hid_t (*H5Dget_space)(hid_t);
+  hid_t (*H5Dget_type)(hid_t);
+  herr_t (*H5Dread)(hid_t, hid_t, hid_t, hid_t, hid_t, void*);
+  int (*H5Sget_simple_extent_ndims)(hid_t);
+  int (*H5Sget_simple_extent_dims)(hid_t, hsize_t*, hsize_t*);
+  long long (*H5Sget_simple_extent_npoints)(hid_t);
+  herr_t (*H5Sselect_hyperslab)(hid_t, int, const hsize_t*, const hsize_t*, const hsize_t*, const hsize_t*);
+  hid_t (*H5Screate_simple)(int, const hsize_t*, const hsize_t*);
+  herr_t (*H5Sclose)(hid_t);
+  int (*H5Tget_class)(hid_t);
+  size_t (*H5Tget_size)(hid_t);
+  int (*H5Tget_sign)(hid_t);
+  htri_t (*H5Tis_variable_str)(hid_t);
+  hid_t (*H5Tcopy)(hid_t);
+  herr_t (*H5Tset_size)(hid_t, size_t);
+  herr_t (*H5Tclose)(hid_t);
+  htri_t (*H5Aexists_by_name)(hid_t, const char*, const char*, hid_t);
+  hid_t (*H5Aopen_by_name)(hid_t, const char*, const char*, hid_t, hid_t);
+  hid_t (*H5Aget_type)(hid_t);
+  hid_t (*H5Aget_space)(hid_t);
+  herr_t (*H5Aread)(hid_t, hid_t, void*);
+  herr_t (*H5Aclose)(hid_t);
+  hid_t* native_double = nullptr;   // H5T_NATIVE_DOUBLE_g
+  hid_t* c_s1 = nullptr;            // H5T_C_S1_g
+  std::string error;
+};
+
+Api* api() {
+  static Api a;
+  static bool tried = false;
+  if (tried) return a.lib ? &a : nullptr;
+  tried = true;
+  std::vector<std::string> names;
+  if (const char* e = std::getenv("ECCKD_HDF5_LIB")) names.push_back(e);
+  for (const char* n : {"libhdf5.so", "libhdf5_serial.so", "libhdf5.so.103", "libhdf5.so.200", "libhdf5_serial.so.103",
+                        "/opt/conda/lib/libhdf5.so", "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so"})
+    names.push_back(n);
+  for (const std::string& n : names) {
+    a.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (a.lib) break;
+  }
+  if (!a.lib) { a.error = "no HDF5 shared library found (set ECCKD_HDF5_LIB)"; return nullptr; }
+  bool ok = true;
+  auto sym = [&](const char* name) -> void* {
+    void* p = dlsym(a.lib, name);
+    if (!p) { ok = false; a.error = std::string("HDF5 library lacks ") + name; }
+    return p;
+  };
+#define LOAD(f) a.f = reinterpret_cast<decltype(a.f)>(sym(#f))
+  LOAD(H5open); LOAD(H5Eset_auto2); LOAD(H5Fopen); LOAD(H5Fclose); LOAD(H5Lexists); LOAD(H5Dopen2); LOAD(H5Dclose);
+  LOAD(H5Dget_space); LOAD(H5Dget_type); LOAD(H5Dread); LOAD(H5Sget_simple_extent_ndims); LOAD(H5Sget_simple_extent_dims);
+  LOAD(H5Sget_simple_extent_npoints); LOAD(H5Sselect_hyperslab); LOAD(H5Screate_simple); LOAD(H5Sclose); LOAD(H5Tget_class);
+  LOAD(H5Tget_size); LOAD(H5Tget_sign); LOAD(H5Tis_variable_str); LOAD(H5Tcopy); LOAD(H5Tset_size); LOAD(H5Tclose);
+  LOAD(H5Aexists_by_name); LOAD(H5Aopen_by_name); LOAD(H5Aget_type); LOAD(H5Aget_space); LOAD(H5Aread); LOAD(H5Aclose);
+#undef LOAD
+  a.native_double = static_cast<hid_t*>(sym("H5T_NATIVE_DOUBLE_g"));
+  a.c_s1 = static_cast<hid_t*>(sym("H5T_C_S1_g"));
+  if (!ok) { dlclose(a.lib); a.lib = nullptr; return nullptr; }
+  a.H5open();
+  a.H5Eset_auto2(0, nullptr, nullptr);   // failures are reported through ecckd_last_error, not HDF5's stack dump
+  return &a;
+}
+
+// NetCDF external type of an HDF5 datatype (classic numbering, CDF-5 for the rest)
+int nc_type_of(Api* a, hid_t t) {
+  const int cls = a->H5Tget_class(t);
+  const size_t size = a->H5Tget_size(t);
+  if (cls == 1) return size == 4 ? 5 : 6;                       // H5T_FLOAT
+  if (cls == 3) return 2;                                       // H5T_STRING -> char
+  if (cls == 0) {                                               // H5T_INTEGER
+    const bool uns = a->H5Tget_sign(t) == 0;
+    switch (size) {
+      case 1: return uns ? 7 : 1;
+      case 2: return uns ? 8 : 3;
+      case 4: return uns ? 9 : 4;
+      default: return uns ? 11 : 10;
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+namespace ecckd {
+
+struct H5File {
+  Api* a = nullptr;
+  hid_t file = -1;
+  std::string path;
+};
+
+bool h5_is_hdf5(const unsigned char* magic8) {
+  static const unsigned char sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+  return std::memcmp(magic8, sig, 8) == 0;
+}
+
+int h5_open(const char* path, H5File** out) {
+  Api* a = api();
+  if (!a) {
+    return fail(ECCKD_PARAMETER_ERROR, "%s is a NetCDF-4 / HDF5 file and %s", path, "no usable HDF5 shared library was found (set ECCKD_HDF5_LIB)");
+  }
+  const hid_t f = a->H5Fopen(path, 0u /* H5F_ACC_RDONLY */, 0);
+  if (f < 0) return fail(ECCKD_PARAMETER_ERROR, "cannot open %s as an HDF5 file", path);
+  H5File* h = new H5File;
+  h->a = a; h->file = f; h->path = path;
+  *out = h;
+  return ECCKD_OK;
+}
+
+void h5_close(H5File* h) {
+  if (!h) return;
+  if (h->file >= 0) h->a->H5Fclose(h->file);
+  delete h;
+}
+
+int h5_inq_var(H5File* h, const char* name, int* exists, int* nc_type, int* ndims, size_t* shape, int shape_capacity) {
+  Api* a = h->a;
+  *exists = a->H5Lexists(h->file, name, 0) > 0 ? 1 : 0;
+  if (!*exists) return ECCKD_OK;
+  const hid_t d = a->H5Dopen2(h->file, name, 0);
+  if (d < 0) { *exists = 0; return ECCKD_OK; }   // a group, not a variable
+  const hid_t sp = a->H5Dget_space(d), t = a->H5Dget_type(d);
+  const int nd = a->H5Sget_simple_extent_ndims(sp);
+  hsize_t dims[32] = {};
+  if (nd > 0) a->H5Sget_simple_extent_dims(sp, dims, nullptr);
+  if (nc_type) *nc_type = nc_type_of(a, t);
+  if (ndims) *ndims = nd < 0 ? 0 : nd;
+  int rc = ECCKD_OK;
+  if (shape) {
+    if (nd > shape_capacity) rc = fail(ECCKD_PARAMETER_ERROR, "%s: \"%s\" has %d dimensions", h->path.c_str(), name, nd);
+    else for (int k = 0; k < nd; ++k) shape[k] = (size_t)dims[k];
+  }
+  a->H5Tclose(t); a->H5Sclose(sp); a->H5Dclose(d);
+  return rc;
+}
+
+int h5_inq_dim(H5File* h, const char* name, size_t* len) {
+  int exists = 0, nd = 0;
+  size_t shape[32];
+  ECCKD_CHECK(h5_inq_var(h, name, &exists, nullptr, &nd, shape, 32));   // a NetCDF-4 dimension is a (scale) dataset of its name
+  if (!exists || nd != 1) return fail(ECCKD_PARAMETER_ERROR, "%s: no dimension \"%s\"", h->path.c_str(), name);
+  *len = shape[0];
+  return ECCKD_OK;
+}
+
+int h5_read_double(H5File* h, const char* name, long long slice, double* out, size_t capacity) {
+  Api* a = h->a;
+  if (a->H5Lexists(h->file, name, 0) <= 0) return fail(ECCKD_PARAMETER_ERROR, "%s: no variable \"%s\"", h->path.c_str(), name);
+  const hid_t d = a->H5Dopen2(h->file, name, 0);
+  if (d < 0) return fail(ECCKD_PARAMETER_ERROR, "%s: cannot open variable \"%s\"", h->path.c_str(), name);
+  const hid_t sp = a->H5Dget_space(d);
+  const int nd = a->H5Sget_simple_extent_ndims(sp);
+  hsize_t dims[32] = {};
+  if (nd > 0) a->H5Sget_simple_extent_dims(sp, dims, nullptr);
+  hsize_t total = 1;
+  for (int k = 0; k < nd; ++k) total *= dims[k];
+  int rc = ECCKD_OK;
+  hid_t mem = 0 /* H5S_ALL */, fsel = 0;
+  if (slice >= 0) {
+    if (nd < 1 || (hsize_t)slice >= dims[0]) {
+      rc = fail(ECCKD_PARAMETER_ERROR, "%s: slice %lld of \"%s\" outside 0..%llu", h->path.c_str(), slice, name, nd < 1 ? 0ull : dims[0]);
+    } else {
+      hsize_t start[32] = {}, count[32];
+      start[0] = (hsize_t)slice;
+      count[0] = 1;
+      total = 1;
+      for (int k = 1; k < nd; ++k) { count[k] = dims[k]; total *= dims[k]; }
+      a->H5Sselect_hyperslab(sp, 0 /* H5S_SELECT_SET */, start, nullptr, count, nullptr);
+      mem = a->H5Screate_simple(1, &total, nullptr);
+      fsel = sp;
+    }
+  }
+  if (rc == ECCKD_OK && total > capacity)
+    rc = fail(ECCKD_PARAMETER_ERROR, "ecckd_nc_read_double: \"%s\" needs %llu values, buffer holds %zu", name, total, capacity);
+  if (rc == ECCKD_OK && total > 0 && a->H5Dread(d, *a->native_double, mem, fsel, 0, out) < 0)
+    rc = fail(ECCKD_PROCESSING_ERROR, "%s: reading \"%s\" failed (missing filter plug-in?)", h->path.c_str(), name);
+  if (mem > 0) a->H5Sclose(mem);
+  a->H5Sclose(sp); a->H5Dclose(d);
+  return rc;
+}
+
+static hid_t open_att(H5File* h, const char* var, const char* att) {
+  Api* a = h->a;
+  const char* obj = (var && var[0]) ? var : "/";
+  if (obj[0] != '/' && a->H5Lexists(h->file, obj, 0) <= 0) return -2;
+  if (a->H5Aexists_by_name(h->file, obj, att, 0) <= 0) return -1;
+  return a->H5Aopen_by_name(h->file, obj, att, 0, 0);
+}
+
+int h5_read_att_text(H5File* h, const char* var, const char* att, int* exists, char* out, size_t capacity) {
+  Api* a = h->a;
+  const hid_t at = open_att(h, var, att);
+  if (at == -2) return fail(ECCKD_PARAMETER_ERROR, "%s: no variable \"%s\"", h->path.c_str(), var);
+  *exists = at >= 0 ? 1 : 0;
+  if (at < 0) return ECCKD_OK;
+  int rc = ECCKD_OK;
+  const hid_t t = a->H5Aget_type(at);
+  std::string text;
+  if (a->H5Tget_class(t) != 3) {
+    rc = fail(ECCKD_PARAMETER_ERROR, "attribute \"%s\" is not text", att);
+  } else if (a->H5Tis_variable_str(t) > 0) {       // NC_STRING: the library allocates
+    char* p = nullptr;
+    const hid_t mt = a->H5Tcopy(*a->c_s1);
+    a->H5Tset_size(mt, (size_t)-1 /* H5T_VARIABLE */);
+    if (a->H5Aread(at, mt, &p) < 0) rc = fail(ECCKD_PROCESSING_ERROR, "%s: reading attribute \"%s\" failed", h->path.c_str(), att);
+    if (p) { text = p; std::free(p); }
+    a->H5Tclose(mt);
+  } else {                                         // NC_CHAR: fixed-length string (possibly an array of them)
+    const size_t size = a->H5Tget_size(t);
+    const hid_t sp = a->H5Aget_space(at);
+    const long long n = a->H5Sget_simple_extent_npoints(sp);
+    a->H5Sclose(sp);
+    std::vector<char> buf(size * (size_t)(n > 0 ? n : 1) + 1, '\0');
+    if (a->H5Aread(at, t, buf.data()) < 0) rc = fail(ECCKD_PROCESSING_ERROR, "%s: reading attribute \"%s\" failed", h->path.c_str(), att);
+    text.assign(buf.data(), strnlen(buf.data(), buf.size() - 1));
+  }
+  a->H5Tclose(t); a->H5Aclose(at);
+  if (rc != ECCKD_OK || !out) return rc;
+  if (text.size() + 1 > capacity) return fail(ECCKD_PARAMETER_ERROR, "attribute \"%s\" needs %zu bytes", att, text.size() + 1);
+  std::memcpy(out, text.c_str(), text.size() + 1);
+  return ECCKD_OK;
+}
+
+int h5_read_att_double(H5File* h, const char* var, const char* att, int* nelems, double* out, size_t capacity) {
+  Api* a = h->a;
+  const hid_t at = open_att(h, var, att);
+  if (at == -2) return fail(ECCKD_PARAMETER_ERROR, "%s: no variable \"%s\"", h->path.c_str(), var);
+  *nelems = -1;
+  if (at < 0) return ECCKD_OK;
+  const hid_t sp = a->H5Aget_space(at);
+  const long long n = a->H5Sget_simple_extent_npoints(sp);
+  a->H5Sclose(sp);
+  *nelems = (int)n;
+  int rc = ECCKD_OK;
+  if (out) {
+    if ((size_t)n > capacity) rc = fail(ECCKD_PARAMETER_ERROR, "attribute \"%s\" has %lld values", att, n);
+    else if (a->H5Aread(at, *a->native_double, out) < 0) rc = fail(ECCKD_PARAMETER_ERROR, "attribute \"%s\" is not numeric", att);
+  }
+  a->H5Aclose(at);
+  return rc;
+}
+
+}  // namespace ecckd

@@ -142,7 +142,7 @@ def read_spectrum(path, iprofile=0):
             dwn[-1] = 0.5 * dwn[-2]
             out["d_wavenumber_cm_1"] = dwn
         out["molecule"] = f.att_text("constituent_id")
-        out["reference_surface_vmr"] = (float(f.read("reference_surface_mole_fraction"))
+        out["reference_surface_vmr"] = (float(f.read("reference_surface_mole_fraction").reshape(-1)[0])
                                         if f.exist("reference_surface_mole_fraction") else -1.0)     # :68-73
         info = f.var_info("mole_fraction_fl")
         if info is not None and len(info[1]) == 2:                                                  # :76-82
@@ -309,7 +309,7 @@ def read_ckd_model(path, active_gases=None):
             if f.exist("solar_spectral_irradiance"):
                 m["solar_spectral_irradiance"] = f.read("solar_spectral_irradiance")
             if f.exist("reference_total_solar_irradiance"):
-                m["reference_total_solar_irradiance"] = float(f.read("reference_total_solar_irradiance"))
+                m["reference_total_solar_irradiance"] = float(f.read("reference_total_solar_irradiance").reshape(-1)[0])
         else:
             m["temperature_planck"] = f.read("temperature_planck")
             m["planck_function"] = f.read("planck_function")

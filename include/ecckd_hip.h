@@ -323,8 +323,10 @@ int ecckd_lbl_band_fluxes_sw(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_s
 /* ---- NetCDF classic files (file parts of a1, a9, a21) ----------------------------
  * A self-contained reader / writer for the classic on-disk formats CDF-1, CDF-2 (64-bit offset)
  * and CDF-5 (64-bit data): what the reference reads / writes for *.nc, *.cdf names
- * (src/tools/DataFile.cpp:88-96, OutputDataFile.cpp:84-157).  NetCDF-4 / HDF5 (*.h5) is NOT handled:
- * no HDF5 library in the image.  Reads convert every external type to double like
+ * (src/tools/DataFile.cpp:88-96, OutputDataFile.cpp:84-157).  NetCDF-4 files (HDF5 containers, the *.h5
+ * names of the scripts) are recognised by their signature and READ through the system's HDF5 library,
+ * loaded at run time (csrc/nc_hdf5.cpp; ECCKD_HDF5_LIB overrides the search); files are always WRITTEN in
+ * the classic format, which the NetCDF library reads back whatever the file is called.  Reads convert every external type to double like
  * nc_get_vara_double (DataFileEngineNetcdf.cpp:593-599); slice >= 0 selects one index of the
  * slowest dimension like DataFile::read(M, "v", j) (:582-590), slice < 0 the whole variable.
  * var == NULL or "" addresses the global attributes.  nc_type: 1 byte, 2 char, 3 short, 4 int,

@@ -505,3 +505,41 @@ def test_do_all_lw_with_the_tools(ctx, oracle, tmp_path):
     f = _nc(d / "ckd.nc")
     assert f.model_id == b"do_all_lw" and f.history.count(b"\n") >= 2          # find_g_points, create_look_up_table, optimize_lut lines
     f.close()
+
+
+def test_tools_read_netcdf4_inputs(ctx, tmp_path):
+    """The scripts' file names end in .h5 (NetCDF-4).  Inputs in that format are read through the HDF5 library; outputs are
+    classic files whatever they are called (the NetCDF library detects the format from the content), so a chain of *.h5
+    names works: spectrum.h5 -> reorder_spectrum -> order.h5 -> find_g_points -> gpoints.h5."""
+    import h5_fixture as h5
+    from ecckd_amd import ncio
+    if not h5.available():
+        pytest.skip("no HDF5 shared library with the deflate filter in this environment")
+    d = tmp_path
+    nwav = 6000
+    p = syn.pressure_grid(NLAY)
+    t_hl = syn.temperature_profile(p)
+    wn, _ = syn.wavenumber_grid(nwav)
+    od = syn.optical_depth(np, p, wn, syn.SEED_BASE + 71, nlines=40, column_scale=20.0, dtype="float32")
+    _write_spectrum(d / "h2o.nc", "h2o", p, t_hl, wn, od, 5e-3)
+    h5.write(d / "h2o.h5", {
+        "pressure_hl": (p[None], "f8", None, None), "temperature_hl": (t_hl[None], "f8", None, None),
+        "wavenumber": (wn, "f8", (1000,), None), "mole_fraction_fl": (np.full((1, NLAY), 5e-3), "f8", None, None),
+        "reference_surface_mole_fraction": (5e-3, "f8", None, None),
+        "optical_depth": (od[None], "f4", (1, NLAY, 512), None)}, {"constituent_id": "h2o"})
+    for ext in ("nc", "h5"):
+        r = run_tool("reorder_spectrum", f"input=h2o.{ext}", f"output=order_{ext}.h5", "wavenumber1=0 1300", "wavenumber2=1300 3260", cwd=d)
+        assert r.returncode == 0, r.stderr + r.stdout
+    a, b = ncio.read_order(d / "order_nc.h5"), ncio.read_order(d / "order_h5.h5")
+    for k in ("rank", "band_number", "sorting_variable", "wavenumber"):
+        assert np.array_equal(a[k], b[k]), k
+    assert b["molecule"] == "h2o"
+    cfg = ("heating_rate_tolerance 0.1\nmax_iterations 30\naveraging_method transmission\ngases h2o\n"
+           "\\begin h2o\n input h2o.h5\n reordering_input order_h5.h5\n\\end h2o\n")
+    (d / "g.cfg").write_text(cfg)
+    r = run_tool("find_g_points", "g.cfg", "output=gpoints.h5", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    (d / "g2.cfg").write_text(cfg.replace("input h2o.h5", "input h2o.nc").replace("order_h5.h5", "order_nc.h5"))
+    r = run_tool("find_g_points", "g2.cfg", "output=gpoints_nc.h5", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert np.array_equal(ncio.read_g_points(d / "gpoints.h5")["g_point"], ncio.read_g_points(d / "gpoints_nc.h5")["g_point"])

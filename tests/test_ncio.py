@@ -294,3 +294,64 @@ def test_read_lbl_fluxes(tmp_path, sw):
     before = s["flux_dn"].copy()
     ncio.subtract_lbl_fluxes(s, other)
     assert np.allclose(s["flux_dn"], 0.75 * before)
+
+
+# ---- NetCDF-4 (HDF5) read path: csrc/nc_hdf5.cpp over the system's HDF5 library ----
+
+import sys  # noqa: E402
+
+
+def _h5_spectrum(path, vlen=False):
+    import h5_fixture as h5
+    rs = np.random.RandomState(5)
+    ncol, nlay, nwav = 3, 6, 1000
+    od = (rs.uniform(0, 2, (ncol, nlay, nwav)) ** 4).astype(np.float32)
+    od[:, :, ::7] = 0.0
+    p = np.cumsum(rs.uniform(1.0, 100.0, (ncol, nlay + 1)), axis=1)
+    t = rs.uniform(200.0, 300.0, (ncol, nlay + 1))
+    wn = np.linspace(0.0, 3260.0, nwav)
+    vmr = rs.uniform(1e-4, 1e-3, (ncol, nlay))
+    h5.write(path, {
+        "pressure_hl": (p, "f4", None, {"units": "Pa"}),
+        "temperature_hl": (t, "f4", None, {"units": "K", "valid_range": [100.0, 400.0]}),
+        "wavenumber": (wn, "f8", (250,), {"long_name": "Wavenumber"}),
+        "mole_fraction_fl": (vmr, "f4", None, None),
+        "reference_surface_mole_fraction": (np.float32(4e-4), "f4", None, None),
+        "optical_depth": (od, "f4", (1, nlay, 256), {"long_name": "Layer optical depth"}),         # chunked + shuffle + deflate
+        "band_index": (np.arange(nwav) % 3, "i2", None, None),
+    }, {"constituent_id": ("co2",) if vlen else "co2", "title": "synthetic NetCDF-4 spectrum", "profile_scale": 2.5})
+    return od, p.astype(np.float32), t.astype(np.float32), wn, vmr.astype(np.float32)
+
+
+@pytest.mark.parametrize("vlen", [False, True])
+def test_netcdf4_spectrum_is_read_through_hdf5(tmp_path, vlen):
+    """What read_spectrum needs from a CKDMIP *.h5 file: shapes, one-column slices of the deflated optical depth, FLOAT ->
+    double conversion, derived d_wavenumber, text attributes stored as fixed-length (NC_CHAR) or variable-length (NC_STRING)."""
+    sys.path.insert(0, os.path.dirname(__file__))
+    import h5_fixture as h5
+    from ecckd_amd import ncio
+    if not h5.available():
+        pytest.skip("no HDF5 shared library with the deflate filter in this environment")
+    path = tmp_path / "spectrum.h5"
+    od, p, t, wn, vmr = _h5_spectrum(path, vlen)
+    with ncio.NcFile(path) as f:
+        assert f.exist("optical_depth") and not f.exist("d_wavenumber")
+        name, shape = f.var_info("optical_depth")[0], f.var_info("optical_depth")[1]
+        assert tuple(shape) == od.shape
+        assert f.att_text("constituent_id") == "co2" and f.att_text("title") == "synthetic NetCDF-4 spectrum"
+        assert f.att_text("units", "pressure_hl") == "Pa" and f.att_text("nothing") is None
+        assert np.array_equal(f.read("optical_depth"), od.astype(np.float64))
+        assert np.array_equal(f.read("optical_depth", 2), od[2].astype(np.float64))
+        assert np.array_equal(f.read("band_index"), np.arange(1000) % 3)
+        assert float(f.read("reference_surface_mole_fraction").reshape(-1)[0]) == np.float32(4e-4)
+    for icol in (0, 2):
+        s = ncio.read_spectrum(path, icol)
+        assert s["ncol"] == 3 and s["molecule"] == "co2"
+        assert np.array_equal(s["optical_depth"], od[icol].astype(np.float64))
+        assert np.array_equal(s["pressure_hl"], p[icol].astype(np.float64)) and np.array_equal(s["temperature_hl"], t[icol].astype(np.float64))
+        assert np.array_equal(s["wavenumber_cm_1"], wn) and np.array_equal(s["vmr_fl"], vmr[icol].astype(np.float64))
+        dwn = s["d_wavenumber_cm_1"]
+        assert np.allclose(dwn[1:-1], 0.5 * (wn[2:] - wn[:-2])) and dwn[0] == 0.5 * dwn[1]
+    with pytest.raises(Exception):
+        with ncio.NcFile(path) as f:
+            f.read("no_such_variable")
