@@ -240,6 +240,20 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   auto planck = [&](int level) { return ecckd::div_fast(pref, ecckd::exp_fast_s(freq * hk[level], ek) - 1.0); };
   // local layer l is layer l (even wave) or NLAY-1-l (odd wave); its near level is where the first sweep enters
   double ee[H], s2[H], f1[H + 1];
+  // All inputs of this wave's half column are fetched BEFORE the first store: on this hardware the counter a load
+  // waits on also counts the stores issued before it, so a load inside the layer loop would wait for the previous
+  // layer's four row stores to complete and the kernel would run at one store latency per layer.
+  OdT od_in[H];
+  BgT bg_in[H];
+#pragma unroll
+  for (int l = 0; l < H; ++l) od_in[l] = odc[half ? NLAY - 1 - l : l];
+  if (bg_col) {   // uniform: one block of loads
+#pragma unroll
+    for (int l = 0; l < H; ++l) bg_in[l] = bgc[half ? NLAY - 1 - l : l];
+  } else {
+#pragma unroll
+    for (int l = 0; l < H; ++l) bg_in[l] = (BgT)0;
+  }
   int lev_near = half ? NLAY : 0;
   double b_near = planck(lev_near);
   if (live) planck_hl[(size_t)lev_near * n + i] = b_near;
@@ -249,8 +263,8 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   for (int l = 0; l < H; ++l) {
     const int L = half ? NLAY - 1 - l : l;
     const int lev_far = half ? L : L + 1;
-    const double bg = bgc ? (double)bgc[L] : 0.0;
-    const double od = (double)odc[L];
+    const double bg = (double)bg_in[l];
+    const double od = (double)od_in[l];
     const double tau = bg + od;
     const double eps = 1.0 - ecckd::exp_fast_s(neg_d * tau, ek);
     const double fac = (eps > thin) ? 1.0 - ecckd::div_fast(eps * inv_d, tau) : 0.5 * eps;
