@@ -128,14 +128,29 @@ k_gas_prep_lw(int nlay, size_t n, size_t src_stride, int method,
   double b_prev = planck_at(0);
   if (!planck_reuse) planck_hl[i] = b_prev;
   double dn = 0.0;
-  for (int l = 0; l < nlay; ++l) {
-    const double bg = bg_src ? (double)bg_src[(size_t)l * src_stride + j] : 0.0;
-    const double od = (double)od_src[(size_t)l * src_stride + j];
+  // inputs are fetched eight layers at a time, ahead of that chunk's stores: a load issued after a store waits for the
+  // store to complete on this hardware, so one load per layer would cost one store latency per layer
+  constexpr int CH = 8;
+  for (int l0 = 0; l0 < nlay; l0 += CH) {
+  double bgv[CH], odv[CH], plv[CH];
+#pragma unroll
+  for (int q = 0; q < CH; ++q) {
+    const int lq = l0 + q < nlay ? l0 + q : nlay - 1;
+    bgv[q] = bg_src ? (double)bg_src[(size_t)lq * src_stride + j] : 0.0;
+    odv[q] = (double)od_src[(size_t)lq * src_stride + j];
+    plv[q] = planck_reuse ? planck_reuse[(size_t)(lq + 1) * n + i] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < CH; ++q) {
+    const int l = l0 + q;
+    if (l >= nlay) break;
+    const double bg = bgv[q];
+    const double od = odv[q];
     const double tau = bg + od;  // find_g_points.cpp:993
     // radiative_transfer_lw.cpp:41-43
     const double eps = 1.0 - ecckd::exp_fast(-kD * tau);
     const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;
-    const double b_next = planck_at(l + 1);
+    const double b_next = planck_reuse ? plv[q] : planck_at(l + 1);
     const double dn_next = dn * (1.0 - eps) + b_prev * (eps - fac) + b_next * fac;
     s_col[l * bs + tid] = dn_next - dn;
     const size_t o = (size_t)l * n + i;
@@ -155,21 +170,33 @@ k_gas_prep_lw(int nlay, size_t n, size_t src_stride, int method,
     dn = dn_next;
     b_prev = b_next;
   }
+  }
   fds[i] = dn;  // flux_dn(end,__), find_g_points.cpp:1045
   // surface: emissivity 1, surf_planck = planck at temperature_hl(end) (:976-978, :987-988)
   double up = b_prev * 1.0 + (1.0 - 1.0) * dn;
-  for (int l = nlay - 1; l >= 0; --l) {
-    const double bg = bg_src ? (double)bg_src[(size_t)l * src_stride + j] : 0.0;
-    const double od = (double)od_src[(size_t)l * src_stride + j];
-    const double tau = bg + od;
+  for (int l0 = nlay - 1; l0 >= 0; l0 -= CH) {
+  double bgv[CH], odv[CH], plv[CH];
+#pragma unroll
+  for (int q = 0; q < CH; ++q) {
+    const int lq = l0 - q >= 0 ? l0 - q : 0;
+    bgv[q] = bg_src ? (double)bg_src[(size_t)lq * src_stride + j] : 0.0;
+    odv[q] = (double)od_src[(size_t)lq * src_stride + j];
+    plv[q] = planck_reuse ? planck_reuse[(size_t)lq * n + i] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < CH; ++q) {
+    const int l = l0 - q;
+    if (l < 0) break;
+    const double tau = bgv[q] + odv[q];
     const double eps = 1.0 - ecckd::exp_fast(-kD * tau);
     const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;
-    const double b_l = planck_at(l);
+    const double b_l = planck_reuse ? plv[q] : planck_at(l);
     const double up_l = up * (1.0 - eps) + b_prev * (eps - fac) + b_l * fac;
     // heating_rate.h:47-48
     hr[(size_t)l * n + i] = conv[l] * (s_col[l * bs + tid] - up + up_l);
     up = up_l;
     b_prev = b_l;
+  }
   }
   fut[i] = up;  // flux_up(0,__), find_g_points.cpp:1052
 }
@@ -837,9 +864,23 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
   double flux = cos_sza * s;
   double fl_low = flux, fl_high = flux;
   double tfv = s, tgv = s;  // :178-179 start from ssi, not cos_sza*ssi
-  for (int l = 0; l < nlay; ++l) {
-    const double bg = bg_src ? (double)bg_src[(size_t)l * src_stride + j] : 0.0;
-    const double od = (double)od_src[(size_t)l * src_stride + j];
+  // inputs are fetched eight layers at a time, ahead of that chunk's stores: a load issued after a store waits for the
+  // store to complete on this hardware, so one load per layer would cost one store latency per layer
+  constexpr int CH = 8;
+  for (int l0 = 0; l0 < nlay; l0 += CH) {
+  double bgv[CH], odv[CH];
+#pragma unroll
+  for (int q = 0; q < CH; ++q) {
+    const int lq = l0 + q < nlay ? l0 + q : nlay - 1;
+    bgv[q] = bg_src ? (double)bg_src[(size_t)lq * src_stride + j] : 0.0;
+    odv[q] = (double)od_src[(size_t)lq * src_stride + j];
+  }
+#pragma unroll
+  for (int q = 0; q < CH; ++q) {
+    const int l = l0 + q;
+    if (l >= nlay) break;
+    const double bg = bgv[q];
+    const double od = odv[q];
     const size_t o = (size_t)l * n + i;
     bg_od[o] = bg;
     const double flux_next = flux * exp(minus_sec_sza * (bg + od));
@@ -867,6 +908,7 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
       hr_high[o] = conv[l] * (hi_next - fl_high);
       fl_high = hi_next;
     }
+  }
   }
   fds[i] = flux;
   fut[i] = 0.0;  // find_g_points.cpp:1047-1050: no upwelling in the base truth
