@@ -20,6 +20,11 @@ BIN = os.path.join(ROOT, "bin")
 
 def run_tool(name, *args, cwd=None):
     exe = os.path.join(BIN, name)
+    if not os.path.exists(exe):                      # a fresh checkout: build the library and the tools first
+        import sys
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
     assert os.path.exists(exe), f"{exe} not built (python -c 'import __graft_entry__ as g; g.build()')"
     return subprocess.run([exe, *[str(a) for a in args]], cwd=cwd, capture_output=True, text=True, timeout=600)
 
