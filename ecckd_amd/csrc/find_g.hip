@@ -234,12 +234,14 @@ k_scatter_columns(size_t n, size_t src_stride, const int32_t* __restrict__ rank,
 // sweeps back through its half in the other direction, forming the heating rate on the way
 // (heating_rate_single, heating_rate.h:55-72, with the reference's order of operations).  Half the
 // per-lane state of the one-wave version -> two waves per SIMD with half as long dependency chains.
-template <int NLAY, typename BgT, typename OdT>
+// REUSE: the Planck matrix of an earlier gas is read instead of evaluated (find_g_points.cpp:970-984 keeps the first
+// gas's matrix for all later gases); its rows are fetched with the other inputs and planck_hl is not written.
+template <int NLAY, typename BgT, typename OdT, bool REUSE>
 __global__ void __launch_bounds__(PREP_THREADS, 2)
 k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder, const double* __restrict__ hk,
                      const double* __restrict__ conv, const double* __restrict__ wn, const double* __restrict__ dwn,
                      const BgT* __restrict__ bg_col /* [n][NLAY] sorted, or NULL */,
-                     const OdT* __restrict__ od_col /* [n][NLAY] sorted */,
+                     const OdT* __restrict__ od_col /* [n][NLAY] sorted */, const double* __restrict__ planck_reuse,
                      double* __restrict__ wn_sorted, double* __restrict__ dwn_sorted, double* __restrict__ planck_hl,
                      double* __restrict__ bg_od, double* __restrict__ w1, double* __restrict__ hr,
                      double* __restrict__ fds, double* __restrict__ fut) {
@@ -264,7 +266,16 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   // the kernel's instructions were s_mov / v_mov pairs rebuilding 64-bit constants next to their uses
   const ecckd::ExpConsts ek = ecckd::exp_consts();
   const double neg_d = ecckd::sgpr_pin(-kD), inv_d = ecckd::sgpr_pin(1.0 / kD), thin = ecckd::sgpr_pin(1.0e-5);
-  auto planck = [&](int level) { return ecckd::div_fast(pref, ecckd::exp_fast_s(freq * hk[level], ek) - 1.0); };
+  double pl_in[REUSE ? H + 1 : 1];
+  if (REUSE) {
+#pragma unroll
+    for (int l = 0; l <= H; ++l) pl_in[REUSE ? l : 0] = planck_reuse[(size_t)(half ? NLAY - l : l) * n + ii];
+  }
+  // local level l is level l (even wave) or NLAY - l (odd wave)
+  auto planck = [&](int level) {
+    if (REUSE) return pl_in[REUSE ? (half ? NLAY - level : level) : 0];
+    return ecckd::div_fast(pref, ecckd::exp_fast_s(freq * hk[level], ek) - 1.0);
+  };
   // local layer l is layer l (even wave) or NLAY-1-l (odd wave); its near level is where the first sweep enters
   double ee[H], s2[H], f1[H + 1];
   // All inputs of this wave's half column are fetched BEFORE the first store: on this hardware the counter a load
@@ -283,7 +294,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   }
   int lev_near = half ? NLAY : 0;
   double b_near = planck(lev_near);
-  if (live) planck_hl[(size_t)lev_near * n + i] = b_near;
+  if (!REUSE && live) planck_hl[(size_t)lev_near * n + i] = b_near;
   double flux = half ? b_near : 0.0;           // surface: emissivity 1 (radiative_transfer_lw.cpp:52-53)
   f1[0] = flux;
 #pragma unroll
@@ -312,7 +323,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
       const size_t o = (size_t)L * n + i;
       // written once, read by later kernels: streaming stores
       __builtin_nontemporal_store(bg, &bg_od[o]);
-      __builtin_nontemporal_store(b_far, &planck_hl[(size_t)lev_far * n + i]);   // level NLAY/2 is written by both waves with the same bits
+      if (!REUSE) __builtin_nontemporal_store(b_far, &planck_hl[(size_t)lev_far * n + i]);   // level NLAY/2 is written by both waves with the same bits
       __builtin_nontemporal_store(m * (half ? b_near : b_far), &w1[o]);          // weight = Planck function at the base of the layer
     }
     flux = next;
@@ -1388,26 +1399,36 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
                        g->planck_hl, g->bg_od, g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut);                  \
   } while (0)
   const bool bg32 = d_bg_od && bg_type == ECCKD_F32;
-  // fast path: 54 layers, FLOAT spectra (as stored in the CKDMIP files), no Planck reuse, no log metric
-  const bool fast = nlay == 54 && od_type == ECCKD_F32 && (!d_bg_od || bg32) && !is_log && !d_planck_hl_reuse;
+  // fast path: 54 layers, FLOAT target spectrum (as stored in the CKDMIP files), FLOAT or DOUBLE (merged) background,
+  // with or without the Planck matrix of an earlier gas, no log metric
+  const bool fast = nlay == 54 && od_type == ECCKD_F32 && !is_log;
   if (fast) {
-    float *od_col = nullptr, *bg_col = nullptr;
+    float* od_col = nullptr;
+    void* bg_col = nullptr;
+    const size_t bg_elem = bg32 ? sizeof(float) : sizeof(double);
     GTRY(ecckd::dev_malloc(ctx, (void**)&od_col, (size_t)nwav * 54 * sizeof(float)));
     if (d_bg_od) {
-      hipError_t e2 = ecckd::dev_malloc(ctx, (void**)&bg_col, (size_t)nwav * 54 * sizeof(float));
+      hipError_t e2 = ecckd::dev_malloc(ctx, &bg_col, (size_t)nwav * 54 * bg_elem);
       if (e2 != hipSuccess) { ecckd::dev_release(ctx, od_col); GTRY(e2); }
     }
     const unsigned tblocks = (unsigned)((nwav + 63) / 64);
     hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
                        (const float*)d_od, od_col);
-    if (d_bg_od)
+    if (d_bg_od && bg32)
       hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
-                         (const float*)d_bg_od, bg_col);
+                         (const float*)d_bg_od, (float*)bg_col);
+    else if (d_bg_od)
+      hipLaunchKernelGGL((k_scatter_columns<54, double>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
+                         (const double*)d_bg_od, (double*)bg_col);
     const unsigned fblocks = (unsigned)((nwav + 127) / 128);
-    hipLaunchKernelGGL((k_gas_prep_lw_mirror<54, float, float>), dim3(fblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav,
-                       averaging_method, g->ireorder, hkd, convd, d_wavenumber, d_d_wavenumber, (const float*)bg_col,
-                       (const float*)od_col, g->wn_sorted, g->dwn_sorted, g->planck_hl, g->bg_od, g->w1, g->hr, g->fds,
-                       g->fut);
+#define LAUNCH_MIRROR(BG, REUSE)                                                                                              \
+  hipLaunchKernelGGL((k_gas_prep_lw_mirror<54, BG, float, REUSE>), dim3(fblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav,    \
+                     averaging_method, g->ireorder, hkd, convd, d_wavenumber, d_d_wavenumber, (const BG*)bg_col,               \
+                     (const float*)od_col, d_planck_hl_reuse, g->wn_sorted, g->dwn_sorted, g->planck_hl, g->bg_od, g->w1,      \
+                     g->hr, g->fds, g->fut)
+    if (bg32 || !d_bg_od) { if (d_planck_hl_reuse) LAUNCH_MIRROR(float, true); else LAUNCH_MIRROR(float, false); }
+    else { if (d_planck_hl_reuse) LAUNCH_MIRROR(double, true); else LAUNCH_MIRROR(double, false); }
+#undef LAUNCH_MIRROR
     hipError_t e3 = hipGetLastError();
     (void)hipStreamSynchronize(ctx->stream);
     GTRY(hipStreamSynchronize(ctx->stream));

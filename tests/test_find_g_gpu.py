@@ -187,3 +187,45 @@ def test_find_g_band_min_max_g_points(ctx, oracle):
         st3, b3, e3, _ = gas.find_g_band(0, n - 1, 0.1, 0.02, 30, max_g_points=ng - 1)
         assert len(e3) == ng - 1
     gas.close()
+
+
+@pytest.mark.parametrize("bg_kind", ["none", "float", "double"])
+@pytest.mark.parametrize("reuse", [False, True])
+def test_gas_prep_fast_path_54_layers(ctx, oracle, bg_kind, reuse):
+    """The 54-layer FLOAT-spectrum preparation (k_scatter_columns + k_gas_prep_lw_mirror) in every instantiation the
+    find_g_points driver reaches: no / FLOAT / DOUBLE (merged) background, own Planck matrix or the one of an earlier
+    gas (find_g_points.cpp:970-984 keeps the first gas's matrix although the later gases are ordered differently)."""
+    from ecckd_amd import api
+    n = 9000
+    o = _lw_problem(oracle, n, nlay=54, seed=31, with_bg=bg_kind != "none", min_pressure=20.0)
+    od32 = o["od"].astype(np.float32)                      # _lw_problem's target is FLOAT-valued already
+    bg = None
+    if bg_kind == "float":
+        bg = o["bg"].astype(np.float32)
+        o["bg_s"] = bg.astype(np.float64)[:, np.argsort(o["rank"])]
+    elif bg_kind == "double":
+        bg = o["bg"]
+    first = None
+    planck, surf = o["planck"], o["surf_planck"]
+    if reuse:
+        o1 = _lw_problem(oracle, n, nlay=54, seed=37, with_bg=False)
+        first = _make_gas(ctx, o1, "transmission", od_dtype=np.float32)
+        planck, surf = o1["planck"], o1["planck"][-1]        # the matrix of the FIRST gas's ordering, as it is
+    ireorder = np.argsort(o["rank"])
+    od_s = o["od"][:, ireorder]
+    fdn, fup = oracle.radiative_transfer_lw(planck, o["bg_s"] + od_s, np.ones(n), surf)
+    hr = oracle.heating_rate(o["p"], fdn, fup)
+    gas = api.GasLW(ctx, o["p"], o["t_hl"], _dev(ctx, o["wn"]), _dev(ctx, o["dwn"]), _dev(ctx, o["rank"].astype(np.int32)),
+                    _dev(ctx, od32), _dev(ctx, bg) if bg is not None else None, "transmission", 0.02, 20.0,
+                    planck_hl_reuse=first.view_ptr("planck_hl")[0] if first is not None else None)
+    assert np.array_equal(gas.view("bg_optical_depth"), o["bg_s"])
+    assert np.allclose(gas.view("planck_hl"), planck, rtol=1e-11, atol=0)
+    conv = (9.80665 / 1004.0) / np.diff(o["p"])
+    tol = 1e-9 * np.abs(hr).max(axis=0, keepdims=True) + 1e-13 * conv[:, None] * fup[0][None, :]
+    assert np.all(np.abs(gas.view("hr") - hr) <= tol)
+    assert np.allclose(gas.view("flux_dn_surf")[0], fdn[-1], rtol=1e-10, atol=1e-300)
+    assert np.allclose(gas.view("flux_up_toa")[0], fup[0], rtol=1e-10)
+    assert np.allclose(gas.view("weighted_metric"), o["metric"] * planck[1:], rtol=1e-11, atol=1e-300)
+    gas.close()
+    if first is not None:
+        first.close()
