@@ -229,3 +229,85 @@ def test_gas_prep_fast_path_54_layers(ctx, oracle, bg_kind, reuse):
     gas.close()
     if first is not None:
         first.close()
+
+
+class _DevView:
+    """A (rows, cols) float64 view of one of the gas's resident arrays, without copying it to the host."""
+    def __init__(self, ptr, rows, cols):
+        self.__cuda_array_interface__ = {"shape": (rows, cols), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def test_full_size_find_g_against_oracle_slices(ctx, oracle):
+    """BASELINE full size (nwav = 7.2e6, nlay = 54, FLOAT spectra, one band): the oracle cannot run the whole problem in
+    seconds, so it replays (a) the gas preparation of three 4096-point windows of the sorted spectrum (start, deep inside,
+    end) and (b) the interval errors of a 20 000-point band placed deep inside it, from the device's own prepared rows;
+    (c) repeated and regrouped batches give bit-identical errors; (d) the full-band search converges within its tolerance."""
+    from ecckd_amd import api, synthetic as syn
+    nwav, nlay = 7_200_000, 54
+    dev = ctx.device
+    p = syn.pressure_grid(nlay)
+    wn_h, dwn_h = syn.wavenumber_grid(nwav)
+    wn, dwn = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
+    od = syn.optical_depth(torch, p, wn, syn.SEED_BASE + 1, nlines=32, device=dev, chunk=1 << 20)
+    bg = syn.optical_depth(torch, p, wn, syn.SEED_BASE + 1001, nlines=24, column_scale=3.0, zero_fraction=0.0, device=dev, chunk=1 << 20)
+    t_hl = syn.temperature_profile(p)
+    key, col = api.reorder_key_lw(ctx, p, api.idealised_temperature(p), wn, dwn, od, 0.5)
+    rank, _ = api.stable_argsort_bands(ctx, key, [0], [nwav - 1], want_ordered=False)
+    gas = api.GasLW(ctx, p, t_hl, wn, dwn, rank, od, bg, "transmission", flux_weight=0.02)
+    ireorder = api.invert_permutation(ctx, rank).long()
+    view = lambda name: torch.as_tensor(_DevView(*gas.view_ptr(name)), device=dev)
+    planck_d, bg_d, hr_d, w1_d = view("planck_hl"), view("bg_optical_depth"), view("hr"), view("weighted_metric")
+    fds_d, fut_d = view("flux_dn_surf"), view("flux_up_toa")
+    conv = (9.80665 / 1004.0) / np.diff(p)
+
+    def window(i1, n):
+        idx = ireorder[i1:i1 + n]
+        return (od[:, idx].double().cpu().numpy(), bg[:, idx].double().cpu().numpy(), wn_h[idx.cpu().numpy()], dwn_h[idx.cpu().numpy()])
+
+    # (a) preparation of three windows
+    for i1 in (0, 5_000_001, nwav - 4096):
+        od_s, bg_s, wn_s, dwn_s = window(i1, 4096)
+        sl = slice(i1, i1 + 4096)
+        planck = oracle.planck_function(t_hl, wn_s, dwn_s)
+        fdn, fup = oracle.radiative_transfer_lw(planck, bg_s + od_s, np.ones(4096), planck[-1])
+        hr = oracle.heating_rate(p, fdn, fup)
+        assert np.array_equal(bg_d[:, sl].cpu().numpy(), bg_s)
+        assert np.allclose(planck_d[:, sl].cpu().numpy(), planck, rtol=1e-11, atol=0)
+        tol = 1e-9 * np.abs(hr).max(axis=0, keepdims=True) + 1e-13 * conv[:, None] * fup[0][None, :]
+        assert np.all(np.abs(hr_d[:, sl].cpu().numpy() - hr) <= tol)
+        assert np.allclose(fds_d[0, sl].cpu().numpy(), fdn[-1], rtol=1e-10, atol=1e-300)
+        assert np.allclose(fut_d[0, sl].cpu().numpy(), fup[0], rtol=1e-10)
+        assert np.allclose(w1_d[:, sl].cpu().numpy(), oracle.metric("transmission", od_s) * planck[1:], rtol=1e-11, atol=1e-300)
+
+    # (b) interval errors of a band deep inside the spectrum, from the device's prepared rows
+    i1, n = 4_321_987, 20_000
+    sl = slice(i1, i1 + n)
+    od_s = window(i1, n)[0]
+    pl = planck_d[:, sl].cpu().numpy()
+    eq = oracle.CkdEquipartitionLW("transmission", 0.02, oracle.layer_weight(p, 0.0), p, np.ones(n), pl[-1], fds_d[0, sl].cpu().numpy(),
+                                   fut_d[0, sl].cpu().numpy(), pl, bg_d[:, sl].cpu().numpy(), oracle.metric("transmission", od_s),
+                                   hr_d[:, sl].cpu().numpy())
+    b1 = np.array([0.0, 0.2, 0.55, 0.9, 0.0])
+    b2 = np.array([0.2, 0.55, 0.9, 1.0, 1.0])
+    err = gas.calc_error_batch(i1, n, b1, b2)
+    ref = np.array([eq.calc_error(x, y) for x, y in zip(b1, b2)])
+    assert np.allclose(err, ref, rtol=ERR_RTOL, atol=1e-12)
+
+    # (c) the whole band: a repeated batch gives the same bits (fixed-order reductions, no atomics); the same intervals in
+    # other batches are split into chunks of another size, which moves the sums by rounding only
+    e_all = gas.calc_error_batch(0, nwav, [0.0, 0.3, 0.7], [0.3, 0.7, 1.0])
+    assert np.array_equal(e_all, gas.calc_error_batch(0, nwav, [0.0, 0.3, 0.7], [0.3, 0.7, 1.0]))
+    e_rev = gas.calc_error_batch(0, nwav, [0.7, 0.0, 0.3], [1.0, 0.3, 0.7])
+    e_one = np.array([gas.calc_error_batch(0, nwav, [a], [b])[0] for a, b in ((0.0, 0.3), (0.3, 0.7), (0.7, 1.0))])
+    assert np.allclose(e_all, e_one, rtol=1e-12, atol=0) and np.allclose(e_all, e_rev[[1, 2, 0]], rtol=1e-12, atol=0)
+    assert np.all(np.isfinite(e_all)) and np.all(e_all > 0)
+
+    gas.close()
+    # (d) the band search of the bench workload (flux_weight 0 as test/find_g_points_lw.sh): converges, and the errors it
+    # reports are those of its final intervals
+    gas = api.GasLW(ctx, p, t_hl, wn, dwn, rank, od, bg, "transmission", flux_weight=0.0)
+    st, b, e, cc = gas.find_g_band(0, nwav - 1, 0.0161, 0.01, 60)
+    assert st == 0 and len(e) >= 4 and b[0] == 0.0 and b[-1] == 1.0 and np.all(np.diff(b) > 0)
+    assert np.all(np.isfinite(e)) and np.all(e > 0) and cc > len(e) and e[:-1].max() <= 0.0161 * 1.0101
+    assert np.allclose(gas.calc_error_batch(0, nwav, b[:-1], b[1:]), e, rtol=1e-12, atol=0)
+    gas.close()
