@@ -15,6 +15,9 @@ struct GasTable {   // SingleGasData<false> (single_gas_data.h)
   std::vector<double> vmr;            // LUT: mole fractions of the table
   double reference_vmr = 0.0;         // relative-linear
   std::vector<double> molar_abs, min_molar_abs, max_molar_abs;   // [nconc][nt][np][ng] (nconc only for LUT)
+  // conc_dependence none: the gases merged into this one and their mole fractions [ngas][np] (ckd_model.cpp:431-438)
+  std::string composite_molecules;
+  std::vector<double> composite_vmr;
   size_t nconc() const { return conc == CONC_LUT ? vmr.size() : 1; }
 };
 
@@ -32,6 +35,12 @@ struct CkdFile {
   std::vector<int> band_number;                                      // [ng]
   std::vector<GasTable> gases;
   std::string history, config;                                       // of the file this model came from
+  // the g point of every high-resolution wavenumber, stored by create_look_up_table when it changed the numbering of the
+  // g-points file (CkdModel::save_g_points, ckd_model.h:314-318); read back by optimize_lut / scale_lut in preference to
+  // "gpointfile" (read_g_points, :324-333).  `save_g_points` is set only by the tool that creates them (:471).
+  std::vector<double> wavenumber_hr;
+  std::vector<int> g_point_hr;
+  bool save_g_points = false;
 };
 
 static const char* const K_NAME = "molar_absorption_coeff";   // constants.h:21
@@ -51,6 +60,7 @@ inline void write_ckd(const std::string& path, const CkdFile& m, const std::stri
   if (!m.is_sw) f.dim("temperature_planck", m.temperature_planck.size());
   f.dim("wavenumber", nwav);
   f.dim("band", m.wavenumber1_band.size());
+  if (m.save_g_points) f.dim("wavenumber_hr", m.wavenumber_hr.size());
   f.var("n_gases", NC_INT_T, {}, "Number of gases treated");
   f.att("The gases are listed in the global attribute \"constituent_id\".", "comment", "n_gases");
   f.var("temperature", NC_FLOAT_T, {"temperature", "pressure"}, "Temperature", "K");
@@ -71,6 +81,10 @@ inline void write_ckd(const std::string& path, const CkdFile& m, const std::stri
   f.var("wavenumber1_band", NC_FLOAT_T, {"band"}, "Lower wavenumber bound of band", "cm-1");
   f.var("wavenumber2_band", NC_FLOAT_T, {"band"}, "Upper wavenumber bound of band", "cm-1");
   f.var("band_number", NC_SHORT_T, {"g_point"}, "Band number of each g point");
+  if (m.save_g_points) {
+    f.var("wavenumber_hr", NC_DOUBLE_T, {"wavenumber_hr"}, "High-resolution wavenumber", "cm-1");
+    f.var("g_point", NC_SHORT_T, {"wavenumber_hr"}, "G point");
+  }
   if (m.is_sw && !m.rayleigh_molar_scattering.empty())
     f.var("rayleigh_molar_scattering_coeff", NC_FLOAT_T, {"g_point"}, "Rayleigh molar scattering coefficient in each g-point",
           "m2 mol-1");
@@ -100,6 +114,13 @@ inline void write_ckd(const std::string& path, const CkdFile& m, const std::stri
       f.var(k + "_min", NC_FLOAT_T, dims, ("Minimum molar absorption coefficient of " + what).c_str(), "m2 mol-1");
       f.var(k + "_max", NC_FLOAT_T, dims, ("Maximum molar absorption coefficient of " + what).c_str(), "m2 mol-1");
     }
+    if (g.conc == CONC_NONE && !g.composite_vmr.empty()) {
+      f.dim(mol + "_gas", g.composite_vmr.size() / m.np);
+      f.var(mol + "_mole_fraction", NC_FLOAT_T, {mol + "_gas", "pressure"}, ("Mole fractions of the gases that make up " + Mol).c_str(), "1");
+      f.att("The gases that make up " + Mol + " are listed in the global attribute \"" + mol + "_constituent_id\".", "comment",
+            (mol + "_mole_fraction").c_str());
+      f.att(g.composite_molecules, mol + "_constituent_id");
+    }
   }
   // the history of the g-points file, then this command (CkdModel::write :603-616)
   std::string history = m.history;
@@ -126,11 +147,16 @@ inline void write_ckd(const std::string& path, const CkdFile& m, const std::stri
   f.write("wavenumber1_band", m.wavenumber1_band);
   f.write("wavenumber2_band", m.wavenumber2_band);
   f.write_as_double("band_number", m.band_number);
+  if (m.save_g_points) {
+    f.write("wavenumber_hr", m.wavenumber_hr);
+    f.write_as_double("g_point", m.g_point_hr);
+  }
   for (const GasTable& g : m.gases) {
     const std::string mol = g.name, k = mol + "_" + K_NAME;
     f.write(mol + "_conc_dependence_code", {(double)g.conc});
     if (g.conc == CONC_LUT) f.write(mol + "_mole_fraction", g.vmr);
     if (g.conc == CONC_RELATIVE_LINEAR) f.write(mol + "_reference_mole_fraction", {g.reference_vmr});
+    if (g.conc == CONC_NONE && !g.composite_vmr.empty()) f.write(mol + "_mole_fraction", g.composite_vmr);
     f.write(k, g.molar_abs);
     if (!g.min_molar_abs.empty() && !g.max_molar_abs.empty()) {
       f.write(k + "_min", g.min_molar_abs);
@@ -165,6 +191,10 @@ inline CkdFile read_ckd(const std::string& path) {
   m.wavenumber1_band = f.read("wavenumber1_band");
   m.wavenumber2_band = f.read("wavenumber2_band");
   for (double b : f.read("band_number")) m.band_number.push_back((int)b);
+  if (f.exist("g_point")) {   // ckd_model.cpp:72-75
+    m.wavenumber_hr = f.read("wavenumber_hr");
+    for (double g : f.read("g_point")) m.g_point_hr.push_back((int)g);
+  }
   f.att_text("model_id", m.model_id);
   f.att_text("history", m.history);
   f.att_text("config", m.config);
@@ -182,6 +212,10 @@ inline CkdFile read_ckd(const std::string& path) {
       g.molar_abs = f.read(k);
       if (g.conc == CONC_LUT) g.vmr = f.read(g.name + "_mole_fraction");
       if (g.conc == CONC_RELATIVE_LINEAR) g.reference_vmr = f.read_scalar(g.name + "_reference_mole_fraction");
+      if (g.conc == CONC_NONE && f.exist(g.name + "_mole_fraction")) {   // :193-195
+        g.composite_vmr = f.read(g.name + "_mole_fraction");
+        f.att_text(g.name + "_constituent_id", g.composite_molecules);
+      }
       if (f.exist(k + "_min")) { g.min_molar_abs = f.read(k + "_min"); g.max_molar_abs = f.read(k + "_max"); }
       m.gases.push_back(std::move(g));
     }

@@ -6,7 +6,8 @@
 // Keys (:38-82, :243-246, :259, :364): input (g-points file), output, ssi, temperature_stride, averaging_method,
 // gases, prepend_path, append_path, log_level; per gas conc_dependence (none | linear | lut | relative-linear),
 // input (+ scaling / conc for "none": read_merged_spectrum), reference_conc.
-// Not handled: base_wavenumber_boundary (:63-65, :170-223, re-splitting of base g points by wavenumber).
+// base_wavenumber_boundary (:63-65, :160-223) splits the base g point of the bands it falls into by wavenumber; when that
+// or the removal of empty g points changes the numbering, the g point of every wavenumber is stored in the output.
 // The averaging, the g-point fractions and the Planck look-up table run on the GPU (ecckd_gmap_*).
 #include <algorithm>
 
@@ -21,8 +22,8 @@ int main(int argc, char** argv) {
     std::string input, output, ssi_file_name;
     if (!config.read(output, "output")) fail(ECCKD_PARAMETER_ERROR, "\"output\" file not specified");
     if (!config.read(input, "input")) fail(ECCKD_PARAMETER_ERROR, "\"input\" file not specified");
-    if (config.exist("base_wavenumber_boundary"))
-      fail(ECCKD_PARAMETER_ERROR, "base_wavenumber_boundary is not supported by this tool");
+    std::vector<double> base_wavenumber_boundary;
+    config.read(base_wavenumber_boundary, "base_wavenumber_boundary");
     std::vector<double> ssi, ssi_wavenumber;
     double tsi = -1.0;
     const bool do_sw = config.read(ssi_file_name, "ssi");
@@ -74,7 +75,48 @@ int main(int argc, char** argv) {
           model.solar_irradiance = s;
         }
         ng = (int)kept.size();
+        model.save_g_points = true;      // :575-577: the numbering no longer matches the g-points file
       }
+    }
+
+    // ---- base g points split by wavenumber (:160-223); the high-resolution wavenumbers are those of the ssi file ----
+    if (!base_wavenumber_boundary.empty()) {
+      if (!do_sw) fail(ECCKD_PARAMETER_ERROR, "base_wavenumber_boundary needs the \"ssi\" file (its wavenumbers and irradiances, :198-214)");
+      if (ssi_wavenumber.size() != nwav) fail(ECCKD_PARAMETER_ERROR, "the ssi file has %zu wavenumbers, the g-points file %zu", ssi_wavenumber.size(), nwav);
+      const int nband = (int)model.wavenumber1_band.size();
+      for (int iband = 0; iband < nband; ++iband) {
+        std::vector<double> inner;
+        for (double w : base_wavenumber_boundary) if (w > model.wavenumber1_band[iband] && w < model.wavenumber2_band[iband]) inner.push_back(w);
+        if (inner.empty()) continue;
+        const int m = (int)inner.size();
+        LOG("Splitting base g-point of band %d into %d\n", iband, m + 1);
+        int ig = -1;
+        for (int g = 0; g < ng; ++g) if (band_number[g] == iband) { ig = g; break; }
+        if (ig < 0) fail(ECCKD_PARAMETER_ERROR, "band %d has no g points", iband);
+        const int new_ng = ng + m;
+        std::vector<int> new_band(new_ng, iband);
+        std::vector<double> new_solar(new_ng, 0.0);
+        for (int g = 0; g <= ig; ++g) new_band[g] = band_number[g];
+        for (int g = 0; g < ig; ++g) new_solar[g] = model.solar_irradiance[g];
+        for (int g = ig + 1; g < ng; ++g) { new_band[g + m] = band_number[g]; new_solar[g + m] = model.solar_irradiance[g]; }
+        std::vector<double> bounds;
+        bounds.push_back(model.wavenumber1_band[iband]);
+        bounds.insert(bounds.end(), inner.begin(), inner.end());
+        bounds.push_back(model.wavenumber2_band[iband]);
+        for (size_t i = 0; i < nwav; ++i) {
+          const int g = g_point[i];
+          if (g > ig) g_point[i] = g + m;
+          else if (g == ig) {
+            const double w = ssi_wavenumber[i];
+            for (int k = 0; k <= m; ++k) if (w >= bounds[k] && w < bounds[k + 1]) { g_point[i] = ig + k; break; }
+          }
+        }
+        for (size_t i = 0; i < nwav; ++i) if (g_point[i] >= ig && g_point[i] <= ig + m) new_solar[g_point[i]] += ssi[i];
+        band_number = new_band;
+        model.solar_irradiance = new_solar;
+        ng = new_ng;
+      }
+      model.save_g_points = true;
     }
     model.ng = ng;
     model.band_number = band_number;
@@ -104,6 +146,10 @@ int main(int argc, char** argv) {
                       std::vector<double>& t_fl) {
       if (!gmap) {
         if (s.nwav != nwav) fail(ECCKD_PARAMETER_ERROR, "spectra have %zu points, the g-points file %zu", s.nwav, nwav);
+        if (model.save_g_points) {
+          model.wavenumber_hr = s.wavenumber_cm_1;
+          model.g_point_hr.assign(g_point.begin(), g_point.end());
+        }
         d_wn.upload(dev, s.wavenumber_cm_1);
         d_dwn.upload(dev, s.d_wavenumber_cm_1);
         ck(ecckd_gmap_create(dev.ctx(), nwav, d_g_point.as<int32_t>(), ng, d_wn.as<double>(), d_dwn.as<double>(), &gmap));
@@ -156,6 +202,11 @@ int main(int argc, char** argv) {
             merged = read_merged_spectrum(dev, config, paths, iprofile, gas_str + ".");
             d_od = merged.od_ptr();
             od_type = merged.od_type();
+            if (icol == 0) {   // :311-313
+              gas.composite_molecules = merged.molecules;
+              gas.composite_vmr.clear();
+              for (const std::vector<double>& row : merged.vmr_fl) gas.composite_vmr.insert(gas.composite_vmr.end(), row.begin(), row.end());
+            }
           } else {
             const std::string path = paths.find(files[iconc]);
             LOG("  Reading temperature profile %d from %s\n", iprofile, path.c_str());

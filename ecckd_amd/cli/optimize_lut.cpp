@@ -10,8 +10,8 @@
 // prepend_path, append_path, log_level.
 // spectral_boundary_weight / erythemal_weight with "gpointfile": the high-resolution surface / top-of-atmosphere
 // fluxes of the training files are summed per g point on the GPU (ecckd_gmap_sum_rows, lbl_fluxes.cpp:180-246,
-// :300-325).  Not handled: rayleigh_prior_error > 0 (Rayleigh scattering as an optimised pseudo-gas) and g points
-// saved inside the CKD file (CkdModel::read_g_points).
+// :300-325); g points stored inside the CKD file take precedence over "gpointfile" (CkdModel::read_g_points).
+// Not handled: rayleigh_prior_error > 0 (Rayleigh scattering as an optimised pseudo-gas).
 // The cost function, its gradient and the L-BFGS iteration run on the GPU (ecckd_opt_*); adept::Minimizer is
 // replaced by the library's own L-BFGS, so iteration counts differ from the reference's.
 #include <algorithm>
@@ -299,13 +299,20 @@ int main(int argc, char** argv) {
     GPointMap gp;
     DevBuf d_g_point, d_wn, d_dwn;
     std::string gpoint_filename;
-    if (config.read(gpoint_filename, "gpointfile")) {
+    std::vector<int32_t> g_point;
+    std::vector<double> wn;
+    if (!model.g_point_hr.empty()) {   // stored by create_look_up_table (CkdModel::read_g_points, :166)
+      g_point.assign(model.g_point_hr.begin(), model.g_point_hr.end());
+      wn = model.wavenumber_hr;
+    } else if (config.read(gpoint_filename, "gpointfile")) {
       NcIn f(paths.find(gpoint_filename));
-      std::vector<int32_t> g_point;
       for (double v : f.read("g_point")) g_point.push_back((int32_t)v);
       if (model.ng != *std::max_element(g_point.begin(), g_point.end()) + 1)
         fail(ECCKD_PARAMETER_ERROR, "Number of g-points in %s does not match number in %s", input.c_str(), gpoint_filename.c_str());
-      std::vector<double> wn = f.read("wavenumber"), dwn(wn.size(), 0.0);
+      wn = f.read("wavenumber");
+    }
+    if (!g_point.empty()) {
+      std::vector<double> dwn(wn.size(), 0.0);
       for (size_t i = 1; i + 1 < wn.size(); ++i) dwn[i] = 0.5 * (wn[i + 1] - wn[i - 1]);
       if (wn.size() > 2) { dwn[0] = 0.5 * dwn[1]; dwn[wn.size() - 1] = 0.5 * dwn[wn.size() - 2]; }
       gp.nwav = g_point.size();

@@ -6,7 +6,7 @@
 // Keys (:27-104): input (CKD definition), output, gpointfile (g point of every wavenumber), lblfile (line-by-line
 // fluxes with spectral_flux_dn_direct_sw), prepend_path, append_path, log_level.
 // The per-g-point sums of the line-by-line flux (ecckd_gmap_sum_rows) and the scaling itself (ecckd_scale_lut) run
-// on the GPU.  Not handled: g points stored inside the CKD file (CkdModel::read_g_points).
+// on the GPU.  G points stored inside the CKD file take precedence over "gpointfile" (CkdModel::read_g_points).
 #include <sstream>
 
 #include "ckd_file.hpp"
@@ -22,16 +22,19 @@ int main(int argc, char** argv) {
     if (!config.read(output, "output")) fail(ECCKD_PARAMETER_ERROR, "\"output\" file not specified");
     CkdFile model = read_ckd(paths.find(input));
     const int ng = model.ng, ngas_model = (int)model.gases.size();
-    if (!config.read(gpoint_filename, "gpointfile")) fail(ECCKD_PARAMETER_ERROR, "gpointfile not provided");
     std::vector<int32_t> g_point;
     std::vector<double> wn;
-    {
+    if (!model.g_point_hr.empty()) {   // stored by create_look_up_table (CkdModel::read_g_points, :52)
+      g_point.assign(model.g_point_hr.begin(), model.g_point_hr.end());
+      wn = model.wavenumber_hr;
+    } else {
+      if (!config.read(gpoint_filename, "gpointfile")) fail(ECCKD_PARAMETER_ERROR, "gpointfile not provided");
       NcIn f(paths.find(gpoint_filename));
       wn = f.read("wavenumber");
       for (double v : f.read("g_point")) g_point.push_back((int32_t)v);
+      if (ng != *std::max_element(g_point.begin(), g_point.end()) + 1)
+        fail(ECCKD_PARAMETER_ERROR, "Number of g-points in %s does not match number in %s", input.c_str(), gpoint_filename.c_str());
     }
-    if (ng != *std::max_element(g_point.begin(), g_point.end()) + 1)
-      fail(ECCKD_PARAMETER_ERROR, "Number of g-points in %s does not match number in %s", input.c_str(), gpoint_filename.c_str());
     if (!config.read(lbl_filename, "lblfile")) fail(ECCKD_PARAMETER_ERROR, "lblfile not provided");
 
     // ---- the first profile / zenith angle of the line-by-line file (:83-112) ----

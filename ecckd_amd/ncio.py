@@ -202,6 +202,9 @@ def write_ckd_model(path, model, model_id="", history="", config="", summary="")
         w.define_dimension("temperature_planck", len(model["temperature_planck"]))
     w.define_dimension("wavenumber", nwav)
     w.define_dimension("band", len(model["wavenumber1_band"]))
+    save_gp = bool(model.get("save_g_points")) and model.get("g_point_hr") is not None       # CkdModel::save_g_points, ckd_model.h:314-318
+    if save_gp:
+        w.define_dimension("wavenumber_hr", len(model["wavenumber_hr"]))
 
     def var(name, t, dims, long_name, units=None, comment=None):
         w.define_variable(name, t, *dims)
@@ -230,6 +233,9 @@ def write_ckd_model(path, model, model_id="", history="", config="", summary="")
     var("wavenumber1_band", "float", ("band",), "Lower wavenumber bound of band", "cm-1")
     var("wavenumber2_band", "float", ("band",), "Upper wavenumber bound of band", "cm-1")
     var("band_number", "short", ("g_point",), "Band number of each g point")
+    if save_gp:
+        var("wavenumber_hr", "double", ("wavenumber_hr",), "High-resolution wavenumber", "cm-1")
+        var("g_point", "short", ("wavenumber_hr",), "G point")
     if is_sw and model.get("rayleigh_molar_scattering") is not None:
         var("rayleigh_molar_scattering_coeff", "float", ("g_point",), "Rayleigh molar scattering coefficient in each g-point",
             "m2 mol-1")
@@ -258,6 +264,12 @@ def write_ckd_model(path, model, model_id="", history="", config="", summary="")
         if g.get("min_molar_abs") is not None and g.get("max_molar_abs") is not None:
             var(k + "_min", "float", dims, "Minimum molar absorption coefficient of " + what, "m2 mol-1")
             var(k + "_max", "float", dims, "Maximum molar absorption coefficient of " + what, "m2 mol-1")
+        if g["conc"] == "none" and g.get("composite_vmr") is not None:                         # ckd_model.cpp:431-438
+            cv = np.atleast_2d(np.asarray(g["composite_vmr"], dtype=np.float64))
+            w.define_dimension(mol + "_gas", cv.shape[0])
+            var(mol + "_mole_fraction", "float", (mol + "_gas", "pressure"), "Mole fractions of the gases that make up " + Mol, "1",
+                comment='The gases that make up ' + Mol + ' are listed in the global attribute "' + mol + '_constituent_id".')
+            w.write_attribute(mol + "_constituent_id", g.get("composite_molecules", ""))
     if history:
         w.write_attribute("history", history)
     w.write_attribute("config", config)
@@ -283,6 +295,9 @@ def write_ckd_model(path, model, model_id="", history="", config="", summary="")
     w.write("wavenumber1_band", model["wavenumber1_band"])
     w.write("wavenumber2_band", model["wavenumber2_band"])
     w.write("band_number", model["iband_per_g"])
+    if save_gp:
+        w.write("wavenumber_hr", model["wavenumber_hr"])
+        w.write("g_point", model["g_point_hr"])
     for g in model["gases"]:
         mol = g["name"]
         w.write(mol + "_conc_dependence_code", [CONC_CODE[g["conc"]]])
@@ -290,6 +305,8 @@ def write_ckd_model(path, model, model_id="", history="", config="", summary="")
             w.write(mol + "_mole_fraction", g["vmr"])
         if g["conc"] == "relative-linear":
             w.write(mol + "_reference_mole_fraction", [g["reference_vmr"]])
+        if g["conc"] == "none" and g.get("composite_vmr") is not None:
+            w.write(mol + "_mole_fraction", np.atleast_2d(g["composite_vmr"]))
         w.write(mol + "_" + K_NAME, g["molar_abs"])
         if g.get("min_molar_abs") is not None and g.get("max_molar_abs") is not None:
             w.write(mol + "_" + K_NAME + "_min", g["min_molar_abs"])
@@ -318,6 +335,8 @@ def read_ckd_model(path, active_gases=None):
         for k in ("wavenumber1", "wavenumber2", "gpoint_fraction", "wavenumber1_band", "wavenumber2_band"):
             m[k] = f.read(k)
         m["iband_per_g"] = f.read("band_number").astype(np.int32)
+        if f.exist("g_point"):                                                            # ckd_model.cpp:72-75; not written back (:471)
+            m["wavenumber_hr"], m["g_point_hr"] = f.read("wavenumber_hr"), f.read("g_point").astype(np.int32)
         m["nband"] = m["wavenumber1_band"].size
         m["ng"] = m["gpoint_fraction"].shape[0]
         m["model_id"] = f.att_text("model_id")
@@ -331,7 +350,10 @@ def read_ckd_model(path, active_gases=None):
             if code == 2:
                 g["vmr"] = f.read(mol + "_mole_fraction")
             if code == 3:
-                g["reference_vmr"] = float(f.read(mol + "_reference_mole_fraction"))
+                g["reference_vmr"] = float(f.read(mol + "_reference_mole_fraction").reshape(-1)[0])
+            if code == 0 and f.exist(mol + "_mole_fraction"):                             # :193-195
+                g["composite_vmr"] = f.read(mol + "_mole_fraction")
+                g["composite_molecules"] = f.att_text(mol + "_constituent_id") or ""
             if f.exist(mol + "_" + K_NAME + "_min"):
                 g["min_molar_abs"] = f.read(mol + "_" + K_NAME + "_min")
                 g["max_molar_abs"] = f.read(mol + "_" + K_NAME + "_max")

@@ -38,8 +38,34 @@ def remove_empty_g_points(g_point, band_number, solar_irradiance=None):
     return new_g, new_band, new_ssi
 
 
+def split_base_g_points(g_point, band_number, band_wn1, band_wn2, base_wavenumber_boundary, wavenumber, ssi, solar_irradiance):
+    """create_look_up_table.cpp:160-223: the base (first) g point of every band that contains one of the boundaries is split by
+    wavenumber; the g points above move up.  Returns (g_point, band_number, solar_irradiance)."""
+    g_point = np.array(g_point, dtype=np.int32)
+    band_number = np.array(band_number, dtype=np.int64)
+    solar = np.array(solar_irradiance, dtype=np.float64)
+    bwb = np.asarray(base_wavenumber_boundary, dtype=np.float64)
+    for iband in range(len(band_wn1)):
+        inner = bwb[(bwb > band_wn1[iband]) & (bwb < band_wn2[iband])]
+        if inner.size == 0:
+            continue
+        m = inner.size
+        ig = int(np.nonzero(band_number == iband)[0].min())
+        new_band = np.concatenate([band_number[:ig + 1], np.full(m, iband), band_number[ig + 1:]])
+        new_solar = np.concatenate([solar[:ig], np.zeros(m + 1), solar[ig + 1:]])
+        bounds = np.concatenate([[band_wn1[iband]], inner, [band_wn2[iband]]])
+        old = g_point.copy()
+        g_point = np.where(old > ig, old + m, old)
+        for k in range(m + 1):
+            g_point[(old == ig) & (wavenumber >= bounds[k]) & (wavenumber < bounds[k + 1])] = ig + k
+        for k in range(m + 1):
+            new_solar[ig + k] = ssi[g_point == ig + k].sum()
+        band_number, solar = new_band, new_solar
+    return g_point, band_number, solar
+
+
 def create_look_up_table(ctx, g_point, band_number, band_wn1, band_wn2, gases, averaging_method="transmission",
-                         temperature_stride=1, ssi=None, solar_irradiance=None):
+                         temperature_stride=1, ssi=None, solar_irradiance=None, base_wavenumber_boundary=None, ssi_wavenumber=None):
     """The look-up-table assembly of create_look_up_table.cpp:225-606 from classic NetCDF spectra.
 
     g_point[nwav], band_number[ng]: from the g-points file (find_g_points' output).
@@ -50,7 +76,15 @@ def create_look_up_table(ctx, g_point, band_number, band_wn1, band_wn2, gases, a
     layer's temperature (:316-327).  Returns the model dict of api.Optimizer / ncio.write_ckd_model."""
     import torch
     is_sw = ssi is not None
+    ng_file = int(np.asarray(g_point).max()) + 1
     g_point, band_number, solar_irradiance = remove_empty_g_points(g_point, band_number, solar_irradiance)
+    save_g_points = int(g_point.max()) + 1 != ng_file                     # the numbering left the g-points file's (:575-577)
+    if base_wavenumber_boundary is not None and len(base_wavenumber_boundary) > 0:
+        if not is_sw or ssi_wavenumber is None:
+            raise EcckdError(PARAMETER_ERROR, "base_wavenumber_boundary needs the ssi file (its wavenumbers and irradiances)")
+        g_point, band_number, solar_irradiance = split_base_g_points(g_point, band_number, band_wn1, band_wn2, base_wavenumber_boundary,
+                                                                      np.asarray(ssi_wavenumber), np.asarray(ssi), solar_irradiance)
+        save_g_points = True
     ng = int(g_point.max()) + 1
     dev = ctx.device
     d_ssi = torch.as_tensor(np.asarray(ssi, dtype=np.float64), device=dev) if is_sw else None
@@ -87,6 +121,7 @@ def create_look_up_table(ctx, g_point, band_number, band_wn1, band_wn2, gases, a
                     # read_merged_spectrum (:293-296): sum of the scaled well-mixed spectra, accumulated on the device
                     merged, first = None, None
                     ci = spec.get("conc_input")                          # dict(path, iprofile): read_merged_spectrum.cpp:47-61
+                    rows_vmr, mols = [], []
                     for item in files:
                         s = ncio.read_spectrum(item["path"], icol * temperature_stride)
                         first = first or s
@@ -95,9 +130,12 @@ def create_look_up_table(ctx, g_point, band_number, band_wn1, band_wn2, gases, a
                             with ncio.NcFile(ci["path"]) as cf:
                                 pc = cf.read("pressure_fl", ci["iprofile"])
                                 cr = cf.read(s["molecule"].split(" ")[0] + "_mole_fraction_fl", ci["iprofile"])
-                        sp, _ = api.merge_scaling(s["pressure_hl"], item.get("scaling", -1.0), item.get("conc", -1.0),
-                                                  s["reference_surface_vmr"], s["vmr_fl"], pressure_conc=pc, conc_req=cr)
+                        sp, vrow = api.merge_scaling(s["pressure_hl"], item.get("scaling", -1.0), item.get("conc", -1.0),
+                                                     s["reference_surface_vmr"], s["vmr_fl"], pressure_conc=pc, conc_req=cr)
+                        rows_vmr.append(vrow); mols.append(s["molecule"])
                         merged = api.merge_spectrum(ctx, _to_device(s["optical_depth"], dev), sp, merged)
+                    if icol == 0:                                         # create_look_up_table.cpp:311-313
+                        g["composite_vmr"], g["composite_molecules"] = np.stack(rows_vmr), " ".join(mols)
                     s, od_dev, ref_vmr = first, merged, 1.0                            # reference_surface_vmr = 1 (:283)
                 else:
                     s = ncio.read_spectrum(files[iconc], icol * temperature_stride)
@@ -158,6 +196,8 @@ def create_look_up_table(ctx, g_point, band_number, band_wn1, band_wn2, gases, a
         model["temperature_planck"] = np.arange(120.0, 351.0)                         # :581
         model["planck_function"] = gmap.planck_lut(model["temperature_planck"])        # :585-591
     model["ng"] = ng
+    if save_g_points:
+        model["save_g_points"], model["wavenumber_hr"], model["g_point_hr"] = True, hr_wavenumber, g_point
     gmap.close()
     return model
 

@@ -252,7 +252,9 @@ def test_create_look_up_table(ctx, tmp_path, is_sw):
            "\\begin ch4\n conc_dependence relative-linear\n input ch4.nc\n reference_conc 1.8e-6\n\\end ch4\n"
            "\\begin h2o\n conc_dependence lut\n input \"h2o_a.nc\nh2o_b.nc\"\n\\end h2o\n")
     (d / "lut.cfg").write_text(cfg)
-    r = run_tool("create_look_up_table", "lut.cfg", *(["ssi=ssi.nc"] if is_sw else []), cwd=d)
+    # shortwave: also split the base g point of the upper band at 20 000 cm-1 (create_lut_sw.sh:187 does this for one band structure)
+    extra = ["ssi=ssi.nc", "base_wavenumber_boundary=20000"] if is_sw else []
+    r = run_tool("create_look_up_table", "lut.cfg", *extra, cwd=d)
     assert r.returncode == 0, r.stderr + r.stdout
     assert "occupies none of the spectrum" in r.stderr
 
@@ -261,10 +263,20 @@ def test_create_look_up_table(ctx, tmp_path, is_sw):
              dict(name="co2", conc="linear", inputs=[d / "co2.nc"]),
              dict(name="ch4", conc="relative-linear", inputs=[d / "ch4.nc"], reference_conc=1.8e-6),
              dict(name="h2o", conc="lut", inputs=[d / "h2o_a.nc", d / "h2o_b.nc"])]
-    model = pipeline.create_look_up_table(ctx, g_point, band_number, b1, b2, gases, ssi=ssi, solar_irradiance=solar)
+    model = pipeline.create_look_up_table(ctx, g_point, band_number, b1, b2, gases, ssi=ssi, solar_irradiance=solar,
+                                          base_wavenumber_boundary=[20000.0] if is_sw else None, ssi_wavenumber=wn if is_sw else None)
+    ng_out = 7 if is_sw else 6                                   # 7 in the file - 1 empty (+ 1 from the split)
+    assert model["ng"] == ng_out and model["save_g_points"] and model["g_point_hr"].max() == ng_out - 1
     if is_sw:
         model["reference_total_solar_irradiance"] = 1361.0
-        assert model["rayleigh_molar_scattering"].shape == (6,) and np.all(model["rayleigh_molar_scattering"] > 0)
+        assert model["rayleigh_molar_scattering"].shape == (ng_out,) and np.all(model["rayleigh_molar_scattering"] > 0)
+        # After the removal of the empty g point the "band numbers" are the OLD g indices [0, 1, 2, 3, 4, 6] (:142), so the
+        # first g point "of band 1" is g point 1: it is the one divided at 20 000 cm-1 into 1 and 2, the rest move up by one.
+        old1 = (g_point == 1)
+        assert np.array_equal(model["g_point_hr"][old1], np.where(wn[old1] < 20000.0, 1, 2))
+        assert np.array_equal(model["g_point_hr"][g_point == 3], np.full((g_point == 3).sum(), 4))
+        assert np.array_equal(model["iband_per_g"], [0, 1, 1, 2, 3, 4, 6])
+        assert np.allclose(model["solar_irradiance"][[1, 2]], [ssi[old1 & (wn < 20000.0)].sum(), ssi[old1 & (wn >= 20000.0)].sum()])
         # shorter wavelengths scatter more: the coefficient of a g point made of the upper band only is larger
     ncio.write_ckd_model(str(d / "py.nc"), model)
     _same_files(d / "raw.nc", d / "py.nc", skip=("rayleigh_molar_scattering_coeff",))
@@ -278,7 +290,9 @@ def test_create_look_up_table(ctx, tmp_path, is_sw):
     assert b"composite.conc_input=conc.nc" in f.config
     f.close()
     back = ncio.read_ckd_model(str(d / "raw.nc"))              # what optimize_lut / run_ckd read next
-    assert [g["name"] for g in back["gases"]] == ["composite", "co2", "ch4", "h2o"] and back["ng"] == 6
+    assert [g["name"] for g in back["gases"]] == ["composite", "co2", "ch4", "h2o"] and back["ng"] == ng_out
+    assert back["gases"][0]["composite_molecules"] == "o2 n2" and back["gases"][0]["composite_vmr"].shape == (2, nlay)
+    assert np.array_equal(back["g_point_hr"], model["g_point_hr"]) and np.array_equal(back["wavenumber_hr"], wn)
 
 
 def test_optimize_lut(ctx, tmp_path):
@@ -348,6 +362,12 @@ def test_optimize_lut_boundary_fluxes(ctx, tmp_path):
     ncio.write_ckd_model(str(d / "py.nc"), with_b)
     _same_files(d / "opt.nc", d / "py.nc")
     assert any(not np.array_equal(a["molar_abs"], b["molar_abs"]) for a, b in zip(with_b["gases"], without["gases"]))   # the term acts
+    # g points stored in the CKD file (CkdModel::save_g_points / read_g_points) replace the g-point file
+    stored = dict(raw, save_g_points=True, wavenumber_hr=wn, g_point_hr=gp["g_point"])
+    ncio.write_ckd_model(str(d / "raw_with_g.nc"), stored)
+    r = run_tool("optimize_lut", "opt.cfg", "input=raw_with_g.nc", "output=opt3.nc", cwd=d)
+    assert r.returncode == 0 and "Mapping high-resolution boundary fluxes to g-points" in r.stdout, r.stderr + r.stdout
+    _same_files(d / "opt3.nc", d / "py.nc")                      # and the output does not carry them on (ckd_model.h:471)
     # without the g-point file the boundary fluxes are ignored with a warning, as in the reference (lbl_fluxes.cpp:300-305)
     r = run_tool("optimize_lut", "opt.cfg", "output=opt2.nc", cwd=d)
     assert r.returncode == 0 and "ignored because g-point file not provided" in r.stderr
