@@ -244,10 +244,18 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
                      const OdT* __restrict__ od_col /* [n][NLAY] sorted */, const double* __restrict__ planck_reuse,
                      double* __restrict__ wn_sorted, double* __restrict__ dwn_sorted, double* __restrict__ planck_hl,
                      double* __restrict__ bg_od, double* __restrict__ w1, double* __restrict__ hr,
-                     double* __restrict__ fds, double* __restrict__ fut) {
+                     double* __restrict__ fds, double* __restrict__ fut,
+                     double* __restrict__ wave_part /* [3*NLAY+2][nw]: sums over this wave's 64 points of every summable row */,
+                     size_t nw) {
   static_assert(NLAY % 2 == 0 && PREP_THREADS == 256, "two wave pairs per block, equal halves");
   constexpr int H = NLAY / 2;
   __shared__ double s_x[4][64];
+  // Row sums over the wave's 64 points, formed while the values are still in registers (they used to be re-read from
+  // HBM by k_tile_sums: 1 312 B per point).  Sixteen rows at a time go through a wave-private transposed LDS tile: lane
+  // (rr, qq) adds the 16 points qq*16.. of row rr in index order, the four quarters are combined by two xor-shuffles.
+  constexpr int ROWW = 65;
+  constexpr int NPUSH = 3 * H + 1;                 // w1 and Planck row per layer, heating rate per layer, boundary flux
+  __shared__ double s_sum[4][16 * ROWW];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = wave & 1, pair = wave >> 1;
@@ -262,6 +270,31 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   const double pref = (dw * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq);
   const BgT* bgc = bg_col ? bg_col + ii * NLAY : nullptr;
   const OdT* odc = od_col + ii * NLAY;
+  const size_t wid = (size_t)blockIdx.x * 2 + pair;          // index of this pair's 64 points among the 64-point groups
+  double* sum_tile = s_sum[wave];
+  const int rr = lane & 15, qq = lane >> 4;
+  int slot = 0;
+  // rows of the table ecckd_gas_create_lw builds: A = w1 (0..NLAY), B = planck_hl(l+1) (NLAY..), H = hr (2 NLAY..), then the two boundary rows
+  auto row_of_slot = [&](int sl) -> int {
+    if (sl < 2 * H) { const int l = sl >> 1; const int L = half ? NLAY - 1 - l : l; return ((sl & 1) ? NLAY : 0) + L; }
+    if (sl < 3 * H) { const int l = H - 1 - (sl - 2 * H); const int L = half ? NLAY - 1 - l : l; return 2 * NLAY + L; }
+    return 3 * NLAY + (half ? 0 : 1);
+  };
+  auto push = [&](double v) {
+    sum_tile[(slot & 15) * ROWW + lane] = live ? v : 0.0;
+    if ((slot & 15) == 15 || slot == NPUSH - 1) {
+      const int base = slot & ~15, count = slot - base + 1;
+      __builtin_amdgcn_wave_barrier();
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum += sum_tile[rr * ROWW + qq * 16 + j];
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      if (wave_part && qq == 0 && rr < count && wid < nw) wave_part[(size_t)row_of_slot(base + rr) * nw + wid] = sum;
+      __builtin_amdgcn_wave_barrier();
+    }
+    ++slot;
+  };
   // polynomial coefficients and the other literals pinned in SGPRs (fastmath.hpp): without this a third of
   // the kernel's instructions were s_mov / v_mov pairs rebuilding 64-bit constants next to their uses
   const ecckd::ExpConsts ek = ecckd::exp_consts();
@@ -326,6 +359,8 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
       if (!REUSE) __builtin_nontemporal_store(b_far, &planck_hl[(size_t)lev_far * n + i]);   // level NLAY/2 is written by both waves with the same bits
       __builtin_nontemporal_store(m * (half ? b_near : b_far), &w1[o]);          // weight = Planck function at the base of the layer
     }
+    push(m * (half ? b_near : b_far));
+    push(half ? b_near : b_far);                    // planck_hl(L + 1), the denominator row of the fit
     flux = next;
     b_near = b_far;
   }
@@ -339,12 +374,30 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     // conv * (dn(L+1) - dn(L) - up(L+1) + up(L)), left to right
     const double net = half ? (next - flux) - f1[l] + f1[l + 1]        // second sweep is downwelling: flux = dn(L), next = dn(L+1)
                             : (f1[l + 1] - f1[l]) - flux + next;       // second sweep is upwelling:   flux = up(L+1), next = up(L)
-    if (live) __builtin_nontemporal_store(conv[L] * net, &hr[(size_t)L * n + i]);
+    const double hrv = conv[L] * net;
+    if (live) __builtin_nontemporal_store(hrv, &hr[(size_t)L * n + i]);
+    push(hrv);
     flux = next;
   }
   if (live) {
     if (half) fds[i] = flux; else fut[i] = flux;
   }
+  push(flux);
+}
+
+// tile sums from the per-wave sums K4 leaves: TS[r][t] = ((W[4t] + W[4t+1]) + W[4t+2]) + W[4t+3]
+__global__ void __launch_bounds__(256)
+k_combine_wave_sums(int nrows, size_t nw, size_t ntiles, const double* __restrict__ wp, double* __restrict__ ts) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (t >= ntiles || r >= nrows) return;
+  const double* w = wp + (size_t)r * nw + 4 * t;
+  const size_t left = nw - 4 * t;
+  double s = w[0];
+  if (left > 1) s += w[1];
+  if (left > 2) s += w[2];
+  if (left > 3) s += w[3];
+  ts[(size_t)r * ntiles + t] = s;
 }
 
 // tile sums of every row: TS[r][t] = sum_{i in tile t} rows[r][i]
@@ -1402,6 +1455,8 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   // fast path: 54 layers, FLOAT target spectrum (as stored in the CKDMIP files), FLOAT or DOUBLE (merged) background,
   // with or without the Planck matrix of an earlier gas, no log metric
   const bool fast = nlay == 54 && od_type == ECCKD_F32 && !is_log;
+  double* wave_part = nullptr;   // fast path: per-wave row sums left by K4, combined into the tile sums below
+  size_t nw64 = 0;
   if (fast) {
     float* od_col = nullptr;
     void* bg_col = nullptr;
@@ -1421,11 +1476,16 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
       hipLaunchKernelGGL((k_scatter_columns<54, double>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
                          (const double*)d_bg_od, (double*)bg_col);
     const unsigned fblocks = (unsigned)((nwav + 127) / 128);
+    nw64 = (nwav + 63) / 64;
+    {
+      hipError_t e4 = ecckd::dev_malloc(ctx, (void**)&wave_part, (size_t)(3 * 54 + 2) * nw64 * sizeof(double));
+      if (e4 != hipSuccess) { ecckd::dev_release(ctx, od_col); if (bg_col) ecckd::dev_release(ctx, bg_col); GTRY(e4); }
+    }
 #define LAUNCH_MIRROR(BG, REUSE)                                                                                              \
   hipLaunchKernelGGL((k_gas_prep_lw_mirror<54, BG, float, REUSE>), dim3(fblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav,    \
                      averaging_method, g->ireorder, hkd, convd, d_wavenumber, d_d_wavenumber, (const BG*)bg_col,               \
                      (const float*)od_col, d_planck_hl_reuse, g->wn_sorted, g->dwn_sorted, g->planck_hl, g->bg_od, g->w1,      \
-                     g->hr, g->fds, g->fut)
+                     g->hr, g->fds, g->fut, wave_part, nw64)
     if (bg32 || !d_bg_od) { if (d_planck_hl_reuse) LAUNCH_MIRROR(float, true); else LAUNCH_MIRROR(float, false); }
     else { if (d_planck_hl_reuse) LAUNCH_MIRROR(double, true); else LAUNCH_MIRROR(double, false); }
 #undef LAUNCH_MIRROR
@@ -1469,8 +1529,19 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   GTRY(hipStreamSynchronize(ctx->stream));
   g->ntiles = (nwav + TILE - 1) / TILE;
   GTRY(ecckd::dev_malloc(ctx, (void**)&g->tile_sums, (size_t)g->nrows * g->ntiles * sizeof(double)));
-  hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)g->ntiles), dim3(TILE), 0, ctx->stream, g->nrows, nwav, g->ntiles,
-                     (const double* const*)g->rows, g->tile_sums);
+  if (wave_part) {
+    static_assert(TILE == 256, "a tile is four 64-point groups");
+    hipLaunchKernelGGL(k_combine_wave_sums, dim3((unsigned)((g->ntiles + 255) / 256), (unsigned)g->nrows), dim3(256), 0, ctx->stream,
+                       g->nrows, nw64, g->ntiles, wave_part, g->tile_sums);
+    hipError_t e5 = hipGetLastError();
+    (void)hipStreamSynchronize(ctx->stream);
+    ecckd::dev_release(ctx, wave_part);
+    wave_part = nullptr;
+    GTRY(e5);
+  } else {
+    hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)g->ntiles), dim3(TILE), 0, ctx->stream, g->nrows, nwav, g->ntiles,
+                       (const double* const*)g->rows, g->tile_sums);
+  }
   GTRY(hipGetLastError());
   int flag = 0;
   GTRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
