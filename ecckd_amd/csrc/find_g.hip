@@ -1455,17 +1455,33 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   // fast path: 54 layers, FLOAT target spectrum (as stored in the CKDMIP files), FLOAT or DOUBLE (merged) background,
   // with or without the Planck matrix of an earlier gas, no log metric
   const bool fast = nlay == 54 && od_type == ECCKD_F32 && !is_log;
-  double* wave_part = nullptr;   // fast path: per-wave row sums left by K4, combined into the tile sums below
+  // temporaries of the fast path; whatever is still held when the function returns (error paths included) goes back to
+  // the context's cache once the stream has drained
+  struct Temps {
+    ecckd_ctx* ctx;
+    void* p[3] = {nullptr, nullptr, nullptr};
+    void drop(void*& q) {
+      for (void*& r : p)
+        if (r && r == q) { ecckd::dev_release(ctx, r); r = nullptr; }
+      q = nullptr;
+    }
+    ~Temps() {
+      bool any = false;
+      for (void* r : p) any = any || r;
+      if (!any) return;
+      (void)hipStreamSynchronize(ctx->stream);
+      for (void* r : p) if (r) ecckd::dev_release(ctx, r);
+    }
+  } temps{ctx};
+  void*& od_col_v = temps.p[0];
+  void*& bg_col = temps.p[1];
+  void*& wave_part_v = temps.p[2];   // per-wave row sums left by K4, combined into the tile sums below
   size_t nw64 = 0;
   if (fast) {
-    float* od_col = nullptr;
-    void* bg_col = nullptr;
     const size_t bg_elem = bg32 ? sizeof(float) : sizeof(double);
-    GTRY(ecckd::dev_malloc(ctx, (void**)&od_col, (size_t)nwav * 54 * sizeof(float)));
-    if (d_bg_od) {
-      hipError_t e2 = ecckd::dev_malloc(ctx, &bg_col, (size_t)nwav * 54 * bg_elem);
-      if (e2 != hipSuccess) { ecckd::dev_release(ctx, od_col); GTRY(e2); }
-    }
+    GTRY(ecckd::dev_malloc(ctx, &od_col_v, (size_t)nwav * 54 * sizeof(float)));
+    if (d_bg_od) GTRY(ecckd::dev_malloc(ctx, &bg_col, (size_t)nwav * 54 * bg_elem));
+    float* od_col = (float*)od_col_v;
     const unsigned tblocks = (unsigned)((nwav + 63) / 64);
     hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
                        (const float*)d_od, od_col);
@@ -1477,10 +1493,8 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
                          (const double*)d_bg_od, (double*)bg_col);
     const unsigned fblocks = (unsigned)((nwav + 127) / 128);
     nw64 = (nwav + 63) / 64;
-    {
-      hipError_t e4 = ecckd::dev_malloc(ctx, (void**)&wave_part, (size_t)(3 * 54 + 2) * nw64 * sizeof(double));
-      if (e4 != hipSuccess) { ecckd::dev_release(ctx, od_col); if (bg_col) ecckd::dev_release(ctx, bg_col); GTRY(e4); }
-    }
+    GTRY(ecckd::dev_malloc(ctx, &wave_part_v, (size_t)(3 * 54 + 2) * nw64 * sizeof(double)));
+    double* wave_part = (double*)wave_part_v;
 #define LAUNCH_MIRROR(BG, REUSE)                                                                                              \
   hipLaunchKernelGGL((k_gas_prep_lw_mirror<54, BG, float, REUSE>), dim3(fblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav,    \
                      averaging_method, g->ireorder, hkd, convd, d_wavenumber, d_d_wavenumber, (const BG*)bg_col,               \
@@ -1489,12 +1503,10 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
     if (bg32 || !d_bg_od) { if (d_planck_hl_reuse) LAUNCH_MIRROR(float, true); else LAUNCH_MIRROR(float, false); }
     else { if (d_planck_hl_reuse) LAUNCH_MIRROR(double, true); else LAUNCH_MIRROR(double, false); }
 #undef LAUNCH_MIRROR
-    hipError_t e3 = hipGetLastError();
-    (void)hipStreamSynchronize(ctx->stream);
+    GTRY(hipGetLastError());
     GTRY(hipStreamSynchronize(ctx->stream));
-    ecckd::dev_release(ctx, od_col);
-    if (bg_col) ecckd::dev_release(ctx, bg_col);
-    GTRY(e3);
+    temps.drop(od_col_v);
+    temps.drop(bg_col);
   } else if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP(float, float);
   else if (bg32) LAUNCH_PREP(float, double);
   else if (od_type == ECCKD_F32) LAUNCH_PREP(double, float);
@@ -1529,15 +1541,13 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   GTRY(hipStreamSynchronize(ctx->stream));
   g->ntiles = (nwav + TILE - 1) / TILE;
   GTRY(ecckd::dev_malloc(ctx, (void**)&g->tile_sums, (size_t)g->nrows * g->ntiles * sizeof(double)));
-  if (wave_part) {
+  if (wave_part_v) {
     static_assert(TILE == 256, "a tile is four 64-point groups");
     hipLaunchKernelGGL(k_combine_wave_sums, dim3((unsigned)((g->ntiles + 255) / 256), (unsigned)g->nrows), dim3(256), 0, ctx->stream,
-                       g->nrows, nw64, g->ntiles, wave_part, g->tile_sums);
-    hipError_t e5 = hipGetLastError();
-    (void)hipStreamSynchronize(ctx->stream);
-    ecckd::dev_release(ctx, wave_part);
-    wave_part = nullptr;
-    GTRY(e5);
+                       g->nrows, nw64, g->ntiles, (const double*)wave_part_v, g->tile_sums);
+    GTRY(hipGetLastError());
+    GTRY(hipStreamSynchronize(ctx->stream));
+    temps.drop(wave_part_v);
   } else {
     hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)g->ntiles), dim3(TILE), 0, ctx->stream, g->nrows, nwav, g->ntiles,
                        (const double* const*)g->rows, g->tile_sums);
