@@ -438,19 +438,12 @@ struct Interval {
   long long npoints;     // band length (for the logarithmic fit)
 };
 
-__global__ void __launch_bounds__(256)
-k_interval_sums(int nrows, size_t ntiles, const Interval* __restrict__ iv,
-                const double* const* __restrict__ rows, const double* __restrict__ ts,
-                double* __restrict__ sums) {
-  __shared__ double s4[4];
-  const int r = blockIdx.x, k = blockIdx.y;
-  const long long i1 = iv[k].i1, i2 = iv[k].i2;
-  const double* row = rows[r];
-  const double* trow = ts + (size_t)r * ntiles;
+// this thread's share of sum_{i=i1..i2} row[i]: ragged head + whole tiles (from the tile sums) + ragged tail
+__device__ __forceinline__ double interval_row_acc(const double* __restrict__ row, const double* __restrict__ trow,
+                                                   long long i1, long long i2, int tid) {
   const long long t1 = (i1 + TILE - 1) / TILE;   // first whole tile
   const long long t2 = (i2 + 1) / TILE;          // one past the last whole tile
   double acc = 0.0;
-  const int tid = threadIdx.x;
   if (t1 >= t2) {
     // no whole tile inside: at most 2*TILE-2 raw points
     for (long long i = i1 + tid; i <= i2; i += 256) acc += row[i];
@@ -466,8 +459,67 @@ k_interval_sums(int nrows, size_t ntiles, const Interval* __restrict__ iv,
     const long long tail = t2 * TILE + tid;
     if (tail <= i2) acc += row[tail];
   }
+  return acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_interval_sums(int nrows, size_t ntiles, const Interval* __restrict__ iv,
+                const double* const* __restrict__ rows, const double* __restrict__ ts,
+                double* __restrict__ sums) {
+  __shared__ double s4[4];
+  const int r = blockIdx.x, k = blockIdx.y;
+  const int tid = threadIdx.x;
+  const double acc = interval_row_acc(rows[r], ts + (size_t)r * ntiles, iv[k].i1, iv[k].i2, tid);
   const double s = block_sum_256(acc, s4);
   if (tid == 0) sums[(size_t)k * nrows + r] = s;
+}
+
+// fit_optical_depth_lw (find_g_points.cpp:54-106) for one layer from the interval's sums: a = sum of the weighted metric,
+// b = sum of the weights, nnz = number of points with a positive metric (logarithmic method), ntot = points of the interval
+__device__ __forceinline__ double fit_lw_layer(int method, double a, double b, double nnz, double ntot) {
+#pragma clang fp contract(off)
+  switch (method) {
+    case ECCKD_AVG_LINEAR: return a / b;
+    case ECCKD_AVG_TRANSMISSION: return fabs(-log(1.0 - fmin(0.9999999999999999, a / b)) / kD);             // :64-68
+    case ECCKD_AVG_TRANSMISSION_2: return fabs(-log(1.0 - fmin(0.9999999999999999, a / b)) / (kD * 2.0));
+    case ECCKD_AVG_SQUARE_ROOT: { const double v = a / b; return v * v; }
+    case ECCKD_AVG_LOGARITHMIC:                                                                              // :79-99
+      if (nnz == ntot) return exp(a / b);
+      if (nnz == 0.0) return 0.0;
+      return exp(a / b) * (nnz / ntot);
+    default: return nan("");
+  }
+}
+
+// K5a + K5b in one launch for the longwave: the fit of layer l needs only the sums of its own rows (A+l, B+l and, for the
+// logarithmic method, N+l), so the block that owns layer l adds up those rows and finishes the fit itself; the remaining
+// rows (heating rate, boundary fluxes) get one block each as before.  grid (nlay + rows from R.H on, nint), block 256.
+__global__ void __launch_bounds__(256)
+k_interval_sums_fit_lw(int nlay, int method, RowMap R, size_t ntiles, const Interval* __restrict__ iv,
+                       const double* const* __restrict__ rows, const double* __restrict__ ts,
+                       double* __restrict__ sums, double* __restrict__ od_fit) {
+  __shared__ double s4[4];
+  const int bx = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+  const long long i1 = iv[k].i1, i2 = iv[k].i2;
+  double* out = sums + (size_t)k * R.total;
+  if (bx >= nlay) {
+    const int r = R.H + (bx - nlay);
+    const double s = block_sum_256(interval_row_acc(rows[r], ts + (size_t)r * ntiles, i1, i2, tid), s4);
+    if (tid == 0) out[r] = s;
+    return;
+  }
+  const int l = bx;
+  const bool is_log = method == ECCKD_AVG_LOGARITHMIC;
+  const double a = block_sum_256(interval_row_acc(rows[R.A + l], ts + (size_t)(R.A + l) * ntiles, i1, i2, tid), s4);
+  const double b = block_sum_256(interval_row_acc(rows[R.B + l], ts + (size_t)(R.B + l) * ntiles, i1, i2, tid), s4);
+  double nnz = 0.0;
+  if (is_log) nnz = block_sum_256(interval_row_acc(rows[R.N + l], ts + (size_t)(R.N + l) * ntiles, i1, i2, tid), s4);
+  if (tid == 0) {
+    out[R.A + l] = a;
+    out[R.B + l] = b;
+    if (is_log) out[R.N + l] = nnz;
+    od_fit[(size_t)k * nlay + l] = fit_lw_layer(method, a, b, nnz, (double)(i2 - i1 + 1));
+  }
 }
 
 // K5b: fitted grey optical depth per (interval, layer).  grid nint, block 128.
@@ -1909,8 +1961,12 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   std::memcpy(h_iv, iv.data(), (size_t)n * sizeof(Interval));
   ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, h_iv, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
 
-  hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv,
-                     (const double* const*)g->rows, g->tile_sums, d_sums);
+  if (!g->do_sw)
+    hipLaunchKernelGGL(k_interval_sums_fit_lw, dim3(nlay + (g->rm.total - g->rm.H), n), dim3(256), 0, ctx->stream, nlay, g->method,
+                       g->rm, g->ntiles, d_iv, (const double* const*)g->rows, g->tile_sums, d_sums, d_fit);
+  else
+    hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv,
+                       (const double* const*)g->rows, g->tile_sums, d_sums);
   if (g->do_sw) {
     // CkdEquipartition::calc_error, shortwave branches (find_g_points.cpp:341-402)
     const bool is_tt = g->method == ECCKD_AVG_TOTAL_TRANSMISSION;
@@ -1947,7 +2003,6 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
     for (int k = 0; k < n; ++k) error[k] = is_tt ? 0.5 * (h_err[k] + h_err[n + k]) : h_err[k];  // :386
     return ECCKD_OK;
   }
-  hipLaunchKernelGGL(k_fit_lw, dim3(n), dim3(128), 0, ctx->stream, nlay, g->method, g->rm, d_iv, d_sums, d_fit);
   const size_t rt_lds = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
   if (nlay == 54) {
