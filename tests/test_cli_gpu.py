@@ -568,3 +568,58 @@ def test_tools_read_netcdf4_inputs(ctx, tmp_path):
     r = run_tool("find_g_points", "g2.cfg", "output=gpoints_nc.h5", cwd=d)
     assert r.returncode == 0, r.stderr + r.stdout
     assert np.array_equal(ncio.read_g_points(d / "gpoints.h5")["g_point"], ncio.read_g_points(d / "gpoints_nc.h5")["g_point"])
+
+
+def test_optimize_lut_shortwave(ctx, tmp_path):
+    """bin/optimize_lut on a shortwave definition: zenith-angle selection (columns x [0, 2, 4] of the file's five angles),
+    total solar irradiance and effective band albedo from the training file, upwelling masked above
+    max_no_rayleigh_wavenumber, "h2o-no-continuum" mapped to h2o - identical to the host mirror on the same files."""
+    import ckd_synth
+    from ecckd_amd import api, ncio, pipeline
+    d = tmp_path
+    model = ckd_synth.make_model_sw(seed=8)
+    ng, names = model["ng"], [g["name"] for g in model["gases"]]
+    ib, nband = model["iband_per_g"], model["nband"]
+    first = np.array([np.nonzero(ib == b)[0][0] for b in range(nband)])
+    last = np.array([np.nonzero(ib == b)[0][-1] for b in range(nband)])
+    model.update(wavenumber1=250.0 + np.arange(ng) * 400.0, wavenumber2=250.0 + np.arange(1, ng + 1) * 400.0, gpoint_fraction=np.eye(ng),
+                 wavenumber1_band=250.0 + 400.0 * first, wavenumber2_band=250.0 + 400.0 * (last + 1))
+    ncio.write_ckd_model(str(d / "raw_sw.nc"), model)
+    raw = ncio.read_ckd_model(str(d / "raw_sw.nc"))
+    truth = dict(raw, gases=[dict(g, molar_abs=g["molar_abs"] * np.exp(0.2 * np.random.RandomState(i).normal(size=g["molar_abs"].shape)))
+                             for i, g in enumerate(raw["gases"])])
+    ncol, nlay, mu0_file = 3, 12, np.array([0.9, 0.7, 0.5, 0.3, 0.1])
+    base = ckd_synth.make_scenes(raw, nscene=1, ncol=ncol, nlay=nlay)[0]
+    file_gases = [n for n in names if n != "composite"]
+    dn_b = np.empty((ncol, 5, nlay + 1, nband))
+    for k, mu in enumerate(mu0_file):
+        sc = dict(base, gas_present=None, mu0=np.full(ncol, mu), tsi=1361.0)
+        fl = api.run_ckd(ctx, truth, sc, per_gas=False)["spectral_flux_dn_direct_sw"]       # run_ckd itself uses mu0 = 0.5 (:358) ...
+        dn_b[:, k] = np.stack([fl[..., ib == b].sum(-1) for b in range(nband)], axis=-1) * (mu / 0.5)   # ... any positive profile will do
+    up_b = 0.1 * dn_b[:, :, -1:, :] * np.linspace(0.5, 1.0, nlay + 1)[None, None, :, None]
+    w = netcdf_file(str(d / "lbl_sw.nc"), "w", version=2)
+    for dim, n in (("column", ncol), ("mu0", 5), ("half_level", nlay + 1), ("level", nlay), ("gas", len(file_gases)), ("band", nband)):
+        w.createDimension(dim, n)
+    vmr = np.stack([base["vmr_fl"][:, names.index(n), :] for n in file_gases], axis=1)
+    for name, dims, a in (("mu0", ("mu0",), mu0_file), ("pressure_hl", ("column", "half_level"), base["pressure_hl"]),
+                          ("temperature_hl", ("column", "half_level"), base["temperature_hl"]),
+                          ("mole_fraction_fl", ("column", "gas", "level"), vmr),
+                          ("flux_dn_direct_sw", ("column", "mu0", "half_level"), dn_b.sum(-1)), ("flux_up_sw", ("column", "mu0", "half_level"), up_b.sum(-1)),
+                          ("band_flux_dn_direct_sw", ("column", "mu0", "half_level", "band"), dn_b),
+                          ("band_flux_up_sw", ("column", "mu0", "half_level", "band"), up_b),
+                          ("band_wavenumber1_sw", ("band",), model["wavenumber1_band"]), ("band_wavenumber2_sw", ("band",), model["wavenumber2_band"])):
+        w.createVariable(name, "d", dims)[:] = a
+    w.constituent_id = " ".join(n + ("-no-continuum" if n == "h2o" else "") for n in file_gases)
+    w.close()
+    limit = float(model["wavenumber2_band"][nband // 2])                 # bands above this lose their upwelling
+    r = run_tool("optimize_lut", "input=raw_sw.nc", "output=opt_sw.nc", "training_input=lbl_sw.nc", "prior_error=2.0", "broadband_weight=0.4",
+                 "flux_weight=0.3", "flux_profile_weight=0.05", "temperature_corr=0.8", "pressure_corr=0.8", "conc_corr=0.8",
+                 "max_iterations=25", "convergence_criterion=0", f"max_no_rayleigh_wavenumber={limit}", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    opt, res = pipeline.optimize_lut(ctx, raw, [str(d / "lbl_sw.nc")], max_iterations=25, max_no_rayleigh_wavenumber=limit, prior_error=2.0,
+                                     broadband_weight=0.4, flux_weight=0.3, flux_profile_weight=0.05, temperature_corr=0.8, pressure_corr=0.8,
+                                     conc_corr=0.8, min_prior_error=-1.0, max_prior_error=-1.0)
+    assert res["status"] in (0, 2, 3) and res["iterations"] > 3
+    ncio.write_ckd_model(str(d / "py_sw.nc"), opt)
+    _same_files(d / "opt_sw.nc", d / "py_sw.nc")
+    assert any(not np.array_equal(a["molar_abs"], b["molar_abs"]) for a, b in zip(opt["gases"], raw["gases"]))
