@@ -129,7 +129,9 @@ int main(int argc, char** argv) {
                                           "total-transmission", "transmission-3", "transmission-10", "hybrid-logarithmic-transmission-3"};
     int method = -1;
     for (int k = 0; k < 9; ++k) if (averaging_method == methods[k]) method = k;
-    if (method < 0) fail(ECCKD_PARAMETER_ERROR, "Averaging method \"%s\" not understood", averaging_method.c_str());
+    // average_optical_depth_to_g_point (average_optical_depth.cpp:43-133) has no total-transmission branch
+    if (method < 0 || averaging_method == "total-transmission")
+      fail(ECCKD_PARAMETER_ERROR, "averaging_method \"%s\" not understood", averaging_method.c_str());
 
     Device dev;
     ecckd_gmap* gmap = nullptr;

@@ -91,7 +91,8 @@ Scene read_lbl_fluxes(const std::string& path, const std::vector<int>& band_mapp
   if (s.is_sw) {
     std::vector<double> mu0_all = f.read("mu0");
     const int nsza_file = (int)mu0_all.size();
-    for (int c = 0; c < ncol_file; ++c) for (int k = 0; k < nsza; ++k) s.mu0.push_back(mu0_all.at(index_sza[k]));
+    if (nsza_file < 5) fail(ECCKD_PARAMETER_ERROR, "%s: %d solar zenith angles, the angles 0, 2 and 4 are used (lbl_fluxes.cpp:82)", path.c_str(), nsza_file);
+    for (int c = 0; c < ncol_file; ++c) for (int k = 0; k < nsza; ++k) s.mu0.push_back(mu0_all[index_sza[k]]);
     // columns x selected zenith angles of a (column, sza, ...) variable
     auto pick = [&](const std::vector<double>& a, size_t per) {
       std::vector<double> out;
@@ -110,6 +111,11 @@ Scene read_lbl_fluxes(const std::string& path, const std::vector<int>& band_mapp
       dn_name = "band_flux_dn_direct_sw"; up_name = "band_flux_up_sw"; w1_name = "band_wavenumber1_sw"; w2_name = "band_wavenumber2_sw";
       s.have_band = true;
     } else fail(ECCKD_PARAMETER_ERROR, "%s: no spectral or band fluxes", path.c_str());
+    {
+      const std::vector<size_t> fs = f.shape(dn_name);      // (column, mu0, half_level, band)
+      if (fs.size() != 4 || (int)fs[0] != ncol_file || (int)fs[1] != nsza_file || (int)fs[2] != nhl || f.shape(up_name) != fs)
+        fail(ECCKD_PARAMETER_ERROR, "%s: %s is not (column, mu0, half_level, band) on the file's grid", path.c_str(), dn_name.c_str());
+    }
     s.nband = (int)f.shape(dn_name).back();
     s.flux_dn = pick(f.read(dn_name), (size_t)nhl * s.nband);
     s.flux_up = pick(f.read(up_name), (size_t)nhl * s.nband);
@@ -119,6 +125,11 @@ Scene read_lbl_fluxes(const std::string& path, const std::vector<int>& band_mapp
       dn_name = "band_flux_dn_lw"; up_name = "band_flux_up_lw"; w1_name = "band_wavenumber1_lw"; w2_name = "band_wavenumber2_lw";
       s.have_band = true;
     } else fail(ECCKD_PARAMETER_ERROR, "%s: no spectral or band fluxes", path.c_str());
+    {
+      const std::vector<size_t> fs = f.shape(dn_name);      // (column, half_level, band)
+      if (fs.size() != 3 || (int)fs[0] != ncol_file || (int)fs[1] != nhl || f.shape(up_name) != fs)
+        fail(ECCKD_PARAMETER_ERROR, "%s: %s is not (column, half_level, band) on the file's grid", path.c_str(), dn_name.c_str());
+    }
     s.nband = (int)f.shape(dn_name).back();
     s.flux_dn = f.read(dn_name);
     s.flux_up = f.read(up_name);

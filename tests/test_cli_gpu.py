@@ -192,6 +192,22 @@ def _write_columns(path, gas, p1, t, wn, seed, scale, vmr, lo=0.0, hi=3260.0):
     w.close()
 
 
+def _write_columns_from(path, gas, p1, temps, wn, od, vmr):
+    """A spectral file with one column per temperature profile, all sharing the optical depth `od` (nlay, nwav)."""
+    ncol, nlay = len(temps), p1.size - 1
+    w = netcdf_file(str(path), "w", version=2)
+    for d, n in (("column", ncol), ("half_level", nlay + 1), ("level", nlay), ("wavenumber", wn.size)):
+        w.createDimension(d, n)
+    w.createVariable("pressure_hl", "d", ("column", "half_level"))[:] = np.tile(p1, (ncol, 1))
+    w.createVariable("temperature_hl", "d", ("column", "half_level"))[:] = np.stack(temps)
+    w.createVariable("wavenumber", "d", ("wavenumber",))[:] = wn
+    w.createVariable("mole_fraction_fl", "d", ("column", "level"))[:] = np.full((ncol, nlay), vmr)
+    w.createVariable("optical_depth", "f", ("column", "level", "wavenumber"))[:] = np.tile(np.asarray(od, dtype=np.float32)[None], (ncol, 1, 1))
+    w.createVariable("reference_surface_mole_fraction", "d", ())[...] = vmr
+    w.constituent_id = gas
+    w.close()
+
+
 def _same_files(a, b, rtol=0.0, skip=()):
     fa, fb = _nc(a), _nc(b)
     assert set(fa.variables) == set(fb.variables), set(fa.variables) ^ set(fb.variables)
@@ -623,3 +639,114 @@ def test_optimize_lut_shortwave(ctx, tmp_path):
     ncio.write_ckd_model(str(d / "py_sw.nc"), opt)
     _same_files(d / "opt_sw.nc", d / "py_sw.nc")
     assert any(not np.array_equal(a["molar_abs"], b["molar_abs"]) for a, b in zip(opt["gases"], raw["gases"]))
+
+
+def test_do_all_sw_with_the_tools(ctx, tmp_path):
+    """test/do_all_sw.sh with the binaries only: reorder_spectrum (ssi) -> find_g_points (total-transmission) ->
+    create_look_up_table (solar weights, Rayleigh coefficient) -> scale_lut -> optimize_lut -> run_ckd.  The line-by-line
+    direct-beam fluxes (external ckdmip_sw in the reference's scripts) come from the LBL stand-in.  Judged by the direct
+    flux profile of run_ckd against the line-by-line one at the reference zenith angle."""
+    import torch
+    from ecckd_amd import api
+    d = tmp_path
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=ctx.device)
+    nlay, nwav, lo, hi = 16, 8000, 250.0, 50000.0
+    p1 = syn.pressure_grid(nlay)
+    wn, dwn = syn.wavenumber_grid(nwav, lo, hi)
+    ssi = syn.solar_spectral_irradiance(wn, dwn)
+    w = netcdf_file(str(d / "ssi.nc"), "w", version=2)
+    w.createDimension("wavenumber", nwav)
+    w.createVariable("solar_spectral_irradiance", "d", ("wavenumber",))[:] = ssi
+    w.createVariable("wavenumber", "d", ("wavenumber",))[:] = wn
+    w.createVariable("total_solar_irradiance", "d", ())[...] = ssi.sum()
+    w.close()
+    base = {"h2o": (syn.optical_depth(np, p1, wn, syn.SEED_BASE + 81, nlines=60, column_scale=3.0, dtype="float32", lo=lo, hi=hi), 5e-3),
+            "o3": (syn.optical_depth(np, p1, wn, syn.SEED_BASE + 83, nlines=30, column_scale=0.8, dtype="float32", lo=lo, hi=hi), 1e-6)}
+    t0 = syn.temperature_profile(p1)
+    temps = [t0 - 20.0, t0, t0 + 20.0]
+    for g, (od, vmr) in base.items():
+        _write_columns_from(d / f"present_{g}.nc", g, p1, [t0], wn, od, vmr)
+        _write_columns_from(d / f"ideal_{g}.nc", g, p1, temps, wn, od, vmr)
+    _write_columns_from(d / "ideal_h2o_x4.nc", "h2o", p1, temps, wn, base["h2o"][0] * np.float32(4.0), base["h2o"][1] * 4.0)
+
+    # line-by-line direct fluxes: 3 columns x 5 zenith angles, 2 bands; no Rayleigh scattering in this toy atmosphere
+    b1, b2 = np.array([lo, 10000.0]), np.array([10000.0, hi])
+    ncol, mu0s = 3, np.array([0.9, 0.7, 0.5, 0.3, 0.1])
+    amount = {"h2o": np.array([0.7, 1.5, 3.0]), "o3": np.array([1.0, 2.0, 0.5])}
+    begin = [int(np.nonzero((wn >= a) & (wn < b + (b == hi)))[0][0]) for a, b in zip(b1, b2)]
+    end = [int(np.nonzero((wn >= a) & (wn < b + (b == hi)))[0][-1]) for a, b in zip(b1, b2)]
+    dn = np.empty((ncol, 5, nlay + 1, 2))
+    ods = [sum(base[g][0].astype(np.float64) * amount[g][c] for g in base) for c in range(ncol)]
+    for c in range(ncol):
+        for k, mu in enumerate(mu0s):
+            dn[c, k] = api.lbl_band_fluxes_sw(ctx, mu, dev(ssi), dev(ods[c]), begin, end)[0].T
+    hires = ssi[None, :] * 0.9 * np.exp(-np.concatenate([np.zeros((1, nwav)), np.cumsum(ods[0], axis=0)]) / 0.9)     # column 0, mu0 = 0.9
+    w = netcdf_file(str(d / "lbl_sw.nc"), "w", version=2)
+    for dim, n in (("column", ncol), ("mu0", 5), ("half_level", nlay + 1), ("level", nlay), ("gas", 2), ("band", 2), ("wavenumber", nwav)):
+        w.createDimension(dim, n)
+    vmr = np.stack([np.stack([np.full(nlay, base[g][1] * amount[g][c]) for g in ("h2o", "o3")]) for c in range(ncol)])
+    for name, dims, a in (("mu0", ("mu0",), mu0s), ("pressure_hl", ("column", "half_level"), np.tile(p1, (ncol, 1))),
+                          ("temperature_hl", ("column", "half_level"), np.tile(t0, (ncol, 1))), ("mole_fraction_fl", ("column", "gas", "level"), vmr),
+                          ("flux_dn_direct_sw", ("column", "mu0", "half_level"), dn.sum(-1)), ("flux_up_sw", ("column", "mu0", "half_level"), 0.0 * dn.sum(-1)),
+                          ("band_flux_dn_direct_sw", ("column", "mu0", "half_level", "band"), dn), ("band_flux_up_sw", ("column", "mu0", "half_level", "band"), 0.0 * dn),
+                          ("band_wavenumber1_sw", ("band",), b1), ("band_wavenumber2_sw", ("band",), b2)):
+        w.createVariable(name, "d", dims)[:] = a
+    w.constituent_id = "h2o o3"
+    w.close()
+    # the line-by-line file scale_lut reads (one profile, per-wavenumber direct flux); a training file must not carry a
+    # variable of that name with this shape - the tool says so instead of mis-reading it
+    w = netcdf_file(str(d / "lbl_hires.nc"), "w", version=2)
+    for dim, n in (("column", 1), ("mu0", 1), ("half_level", nlay + 1), ("level", nlay), ("gas", 2), ("wavenumber", nwav)):
+        w.createDimension(dim, n)
+    w.createVariable("mu0", "d", ("mu0",))[:] = [0.9]
+    w.createVariable("pressure_hl", "d", ("column", "half_level"))[:] = p1[None]
+    w.createVariable("temperature_hl", "d", ("column", "half_level"))[:] = t0[None]
+    w.createVariable("mole_fraction_fl", "d", ("column", "gas", "level"))[:] = vmr[:1]
+    w.createVariable("spectral_flux_dn_direct_sw", "d", ("column", "half_level", "wavenumber"))[:] = hires[None]
+    w.constituent_id = "h2o o3"
+    w.close()
+
+    ok = lambda r: (r.returncode == 0, r.stderr + r.stdout)
+    for g in base:
+        r = run_tool("reorder_spectrum", f"input=present_{g}.nc", f"output=order_{g}.nc", "ssi=ssi.nc", "wavenumber1=250 10000", "wavenumber2=10000 50000", cwd=d)
+        assert ok(r)[0], ok(r)[1]
+    (d / "g.cfg").write_text(
+        "ssi ssi.nc\nheating_rate_tolerance 0.06\nmax_iterations 30\naveraging_method total-transmission\ngases h2o o3\n"
+        "\\begin h2o\n input present_h2o.nc\n reordering_input order_h2o.nc\n background_input present_o3.nc\n\\end h2o\n"
+        "\\begin o3\n input present_o3.nc\n reordering_input order_o3.nc\n background_input present_h2o.nc\n\\end o3\n")
+    r = run_tool("find_g_points", "g.cfg", "output=gpoints.nc", cwd=d)
+    assert ok(r)[0], ok(r)[1]
+    (d / "lut.cfg").write_text(
+        "input gpoints.nc\noutput raw.nc\nssi ssi.nc\naveraging_method transmission-3\ngases h2o o3\n"      # create_lut_sw.sh:22
+        "\\begin h2o\n conc_dependence lut\n input \"ideal_h2o.nc ideal_h2o_x4.nc\"\n\\end h2o\n"
+        "\\begin o3\n conc_dependence linear\n input ideal_o3.nc\n\\end o3\n")
+    r = run_tool("create_look_up_table", "lut.cfg", cwd=d)
+    assert ok(r)[0], ok(r)[1]
+    r = run_tool("scale_lut", "input=raw.nc", "output=scaled.nc", "gpointfile=gpoints.nc", "lblfile=lbl_hires.nc", cwd=d)
+    assert ok(r)[0], ok(r)[1]
+    r = run_tool("optimize_lut", "input=scaled.nc", "output=x.nc", "training_input=lbl_hires.nc", cwd=d)
+    assert r.returncode == 147 and "solar zenith angles" in r.stderr, r.stderr            # not a training file
+    r = run_tool("optimize_lut", "input=scaled.nc", "output=ckd.nc", "training_input=lbl_sw.nc", "prior_error=2.0", "broadband_weight=0.4", "flux_weight=0.3",
+                 "flux_profile_weight=0.05", "max_iterations=80", "convergence_criterion=0", cwd=d)
+    assert ok(r)[0], ok(r)[1]
+    w = netcdf_file(str(d / "eval.nc"), "w", version=2)
+    for dim, n in (("column", ncol), ("half_level", nlay + 1), ("level", nlay)):
+        w.createDimension(dim, n)
+    w.createVariable("pressure_hl", "d", ("column", "half_level"))[:] = np.tile(p1, (ncol, 1))
+    w.createVariable("temperature_hl", "d", ("column", "half_level"))[:] = np.tile(t0, (ncol, 1))
+    for i, g in enumerate(("h2o", "o3")):
+        w.createVariable(g + "_mole_fraction_fl", "d", ("column", "level"))[:] = vmr[:, i, :]
+    w.close()
+    truth = dn[:, 2].sum(-1)                                    # mu0 = 0.5 = REFERENCE_COS_SZA, what run_ckd evaluates (:358)
+    rms = {}
+    for tag in ("raw", "scaled", "ckd"):
+        r = run_tool("run_ckd", f"ckd_model={tag}.nc", "input=eval.nc", f"output=flux_{tag}.nc", f"tsi={ssi.sum()}", cwd=d)
+        assert ok(r)[0], ok(r)[1]
+        f = _nc(d / f"flux_{tag}.nc")
+        got = f.variables["flux_dn_direct_sw"][...].astype(np.float64)
+        assert np.all(f.variables["rayleigh_optical_depth"][...] > 0)
+        f.close()
+        assert np.allclose(got[:, 0], 0.5 * ssi.sum(), rtol=1e-5)                   # top of atmosphere: mu0 * tsi
+        rms[tag] = float(np.sqrt(np.mean((got - truth) ** 2)))
+    print("direct-flux RMS error (W m-2), tools only:", rms)
+    assert np.isfinite(rms["raw"]) and rms["ckd"] < 0.9 * rms["raw"]
