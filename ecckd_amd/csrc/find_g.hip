@@ -806,10 +806,12 @@ k_rt_lw_bb_mirror(size_t n, long long chunk_pts, int nint, const Interval* __res
     const size_t ii = live ? (size_t)i : (size_t)p1;
     double a[H];       // optical depth -> transmittance
     double b[H + 1];   // Planck function -> source of the second sweep
+    __builtin_amdgcn_s_setprio(3);     // a wave that is about to issue its 55 loads goes ahead of the waves that are computing
 #pragma unroll
     for (int l = 0; l < H; ++l) a[l] = __builtin_nontemporal_load(&od0[(long long)l * row_step + (long long)ii]);
 #pragma unroll
     for (int l = 0; l <= H; ++l) b[l] = __builtin_nontemporal_load(&pl0[(long long)l * row_step + (long long)ii]);
+    __builtin_amdgcn_s_setprio(0);
 
     int slot = 0;
     auto push = [&](double flux) {
