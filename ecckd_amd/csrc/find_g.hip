@@ -316,6 +316,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   // layer's four row stores to complete and the kernel would run at one store latency per layer.
   OdT od_in[H];
   BgT bg_in[H];
+  __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int l = 0; l < H; ++l) od_in[l] = odc[half ? NLAY - 1 - l : l];
   if (bg_col) {   // uniform: one block of loads
@@ -325,6 +326,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
 #pragma unroll
     for (int l = 0; l < H; ++l) bg_in[l] = (BgT)0;
   }
+  __builtin_amdgcn_s_setprio(0);
   int lev_near = half ? NLAY : 0;
   double b_near = planck(lev_near);
   if (!REUSE && live) planck_hl[(size_t)lev_near * n + i] = b_near;
