@@ -813,7 +813,7 @@ k_rt_lw_bb_mirror(size_t n, long long chunk_pts, int nint, const Interval* __res
     for (int l = 0; l < H; ++l) a[l] = __builtin_nontemporal_load(&od0[(long long)l * row_step + (long long)ii]);
 #pragma unroll
     for (int l = 0; l <= H; ++l) b[l] = __builtin_nontemporal_load(&pl0[(long long)l * row_step + (long long)ii]);
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(1);     // first sweep: the partner wave waits for its result
 
     int slot = 0;
     auto push = [&](double flux) {
@@ -858,6 +858,7 @@ k_rt_lw_bb_mirror(size_t n, long long chunk_pts, int nint, const Interval* __res
     }
     // the flux that enters this half from the other side is the partner wave's result
     s_x[parity][wave][lane] = flux;
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     flux = s_x[parity][wave ^ 1][lane];
 #pragma unroll
