@@ -33,6 +33,16 @@
 namespace {
 
 constexpr int TILE = 256;          // points per tile sum
+// wave priorities of the K5c phases (s_setprio): measured choices, see DESIGN.md
+#ifndef ECCKD_PRIO_LOAD
+#define ECCKD_PRIO_LOAD 3
+#endif
+#ifndef ECCKD_PRIO_SWEEP1
+#define ECCKD_PRIO_SWEEP1 1
+#endif
+#ifndef ECCKD_PRIO_SWEEP2
+#define ECCKD_PRIO_SWEEP2 0
+#endif
 constexpr int RT_THREADS = 256;    // K5c block
 constexpr int PREP_THREADS = 256;  // K4 block
 
@@ -808,12 +818,12 @@ k_rt_lw_bb_mirror(size_t n, long long chunk_pts, int nint, const Interval* __res
     const size_t ii = live ? (size_t)i : (size_t)p1;
     double a[H];       // optical depth -> transmittance
     double b[H + 1];   // Planck function -> source of the second sweep
-    __builtin_amdgcn_s_setprio(3);     // a wave that is about to issue its 55 loads goes ahead of the waves that are computing
+    __builtin_amdgcn_s_setprio(ECCKD_PRIO_LOAD);     // a wave that is about to issue its 55 loads goes ahead of the waves that are computing
 #pragma unroll
     for (int l = 0; l < H; ++l) a[l] = __builtin_nontemporal_load(&od0[(long long)l * row_step + (long long)ii]);
 #pragma unroll
     for (int l = 0; l <= H; ++l) b[l] = __builtin_nontemporal_load(&pl0[(long long)l * row_step + (long long)ii]);
-    __builtin_amdgcn_s_setprio(1);     // first sweep: the partner wave waits for its result
+    __builtin_amdgcn_s_setprio(ECCKD_PRIO_SWEEP1);   // first sweep: the partner wave waits for its result
 
     int slot = 0;
     auto push = [&](double flux) {
@@ -858,7 +868,7 @@ k_rt_lw_bb_mirror(size_t n, long long chunk_pts, int nint, const Interval* __res
     }
     // the flux that enters this half from the other side is the partner wave's result
     s_x[parity][wave][lane] = flux;
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(ECCKD_PRIO_SWEEP2);
     __syncthreads();
     flux = s_x[parity][wave ^ 1][lane];
 #pragma unroll
