@@ -1247,9 +1247,11 @@ k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
     const bool live = i <= p1;
     const size_t ii = live ? (size_t)i : (size_t)p1;
     double tau[NLAY];
+    __builtin_amdgcn_s_setprio(3);     // as in the longwave kernel: the wave that is about to fetch its column goes first
 #pragma unroll
-    for (int l = 0; l < NLAY; ++l) tau[l] = bg_od[(size_t)l * n + ii];
+    for (int l = 0; l < NLAY; ++l) tau[l] = __builtin_nontemporal_load(&bg_od[(size_t)l * n + ii]);
     const double sv = ssi[ii];
+    __builtin_amdgcn_s_setprio(0);
     int slot = 0;
     auto push = [&](double v) {
       tile[(slot & 15) * ROW + lane] = live ? v : 0.0;
