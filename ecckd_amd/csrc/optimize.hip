@@ -1234,7 +1234,8 @@ static int opt_launch_forward(ecckd_opt* o) {
   ecckd_ctx* ctx = o->ctx;
   const int nlay = o->nlay, nhl = nlay + 1, ng = o->ng, nband = o->nband;
   const int ngpad = (ng + 63) / 64 * 64;
-  const int lgroups = std::max(1, 256 / ngpad);
+  static const int k8a_threads = [] { const char* e = std::getenv("ECCKD_K8A_THREADS"); const int v = e ? std::atoi(e) : 0; return v >= 64 && v <= 1024 ? v : 1024; }();
+  const int lgroups = std::max(1, k8a_threads / ngpad);
   const int threads = ngpad * lgroups;
   const size_t lds = ((size_t)nlay * ng + 2 * (size_t)nhl * ng + 4 * (size_t)nhl * nband + 16) * sizeof(double) +
                      ecckd_align_up((size_t)nlay * ng, 16);
