@@ -176,6 +176,11 @@ SIGNATURES = {
                                            C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p]),
     "ecckd_gather_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_invert_permutation_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "ecckd_calc_error_multi": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _c_double_p, _c_double_p,
+                                         _c_double_p]),
+    "ecckd_find_g_bands_ex": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _c_double_p, C.c_double,
+                                        C.c_int, C.c_void_p, C.POINTER(C.c_int), _c_double_p, _c_double_p, _c_int64_p, _c_int64_p,
+                                        C.c_int, C.POINTER(C.c_int), _c_double_p]),
     "ecckd_opt_set_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ecckd_cfg_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ecckd_cfg_from_args": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]),

@@ -426,6 +426,69 @@ class GasLW:
         return dict(status=st.value, bounds=b[:n + 1].copy(), error=e[:n].copy(), rank1=r1[:n].copy(),
                     rank2=r2[:n].copy(), comp_cost=cc.value)
 
+    def _band_options(self, keep, min_g_points=1, max_g_points=256, subbands=None, g_split=0.0, base_split=1.0, base_wn_bound=None,
+                      wavenumber=None, rank=None):
+        o = _lib.BandOptions()
+        o.min_g_points, o.max_g_points = int(min_g_points), int(max_g_points)
+        if subbands is not None:
+            i1 = np.ascontiguousarray(subbands[0], dtype=np.int64)
+            i2 = np.ascontiguousarray(subbands[1], dtype=np.int64)
+            keep += [i1, i2]
+            o.nsubband = i1.size
+            o.isubband1 = i1.ctypes.data_as(C.POINTER(C.c_int64))
+            o.isubband2 = i2.ctypes.data_as(C.POINTER(C.c_int64))
+            o.iupperindex = int(subbands[2])
+        o.g_split, o.base_split = float(g_split), float(base_split)
+        if base_wn_bound is not None:
+            bw = np.ascontiguousarray(base_wn_bound, dtype=np.float64)
+            keep.append(bw)
+            o.nbase_wn_bound = bw.size
+            o.base_wn_bound = bw.ctypes.data_as(C.POINTER(C.c_double))
+            if bw.size > 2:
+                o.d_wavenumber, o.d_rank, o.nwav = wavenumber.data_ptr(), rank.data_ptr(), rank.numel()
+        return o
+
+    def calc_error_multi(self, ibegin, npoints, bound1, bound2):
+        """Interval errors of several bands in one batch (ecckd_calc_error_multi): interval k is the fraction
+        [bound1[k], bound2[k]] of the band starting at sorted index ibegin[k] with npoints[k] points."""
+        ib = np.ascontiguousarray(ibegin, dtype=np.uint64)
+        npt = np.ascontiguousarray(npoints, dtype=np.uint64)
+        b1 = np.ascontiguousarray(bound1, dtype=np.float64)
+        b2 = np.ascontiguousarray(bound2, dtype=np.float64)
+        err = np.empty(b1.size)
+        check(self.lib.ecckd_calc_error_multi(self.handle, b1.size, ib.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                              npt.ctypes.data_as(C.POINTER(C.c_size_t)), _hptr(b1), _hptr(b2), _hptr(err)))
+        return err
+
+    def find_g_bands_ex(self, ibegin, iend, heating_rate_tolerance, tolerance_tolerance=0.02, max_iterations=60, options=None,
+                        capacity=1024):
+        """Every band of the gas at once (ecckd_find_g_bands_ex): the band searches run side by side and share their error
+        batches.  `options`: one dict of find_g_band_ex keyword options per band (or None).  -> list of result dicts."""
+        nband = len(ibegin)
+        ib = np.ascontiguousarray(ibegin, dtype=np.uint64)
+        ie = np.ascontiguousarray(iend, dtype=np.uint64)
+        tol = np.ascontiguousarray(np.broadcast_to(np.asarray(heating_rate_tolerance, dtype=np.float64), (nband,)))
+        keep = []
+        opts = (_lib.BandOptions * nband)()
+        for k in range(nband):
+            opts[k] = self._band_options(keep, **((options[k] if options else None) or {}))
+        b = np.zeros((nband, capacity + 1))
+        e = np.zeros((nband, capacity))
+        r1 = np.zeros((nband, capacity), dtype=np.int64)
+        r2 = np.zeros((nband, capacity), dtype=np.int64)
+        ng = np.zeros(nband, dtype=np.int32)
+        st = np.zeros(nband, dtype=np.int32)
+        cc = np.zeros(nband)
+        self.ctx.fence_from_torch()
+        check(self.lib.ecckd_find_g_bands_ex(self.handle, nband, ib.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                             ie.ctypes.data_as(C.POINTER(C.c_size_t)), _hptr(tol), float(tolerance_tolerance),
+                                             int(max_iterations), C.cast(opts, C.c_void_p), ng.ctypes.data_as(C.POINTER(C.c_int)),
+                                             _hptr(b), _hptr(e), r1.ctypes.data_as(C.POINTER(C.c_int64)),
+                                             r2.ctypes.data_as(C.POINTER(C.c_int64)), capacity, st.ctypes.data_as(C.POINTER(C.c_int)),
+                                             _hptr(cc)))
+        return [dict(status=int(st[k]), bounds=b[k, :ng[k] + 1].copy(), error=e[k, :ng[k]].copy(), rank1=r1[k, :ng[k]].copy(),
+                     rank2=r2[k, :ng[k]].copy(), comp_cost=float(cc[k])) for k in range(nband)]
+
     def median_sorting_variable(self, sorting_variable_sorted, ind1, ind2):
         """calc_median_sorting_variable (find_g_points.cpp:35-49) per g point; `sorting_variable_sorted` is a
         device tensor in this gas's sorted order."""

@@ -1913,8 +1913,17 @@ int ecckd_fit_optical_depth(ecckd_gas* g, size_t ibegin, size_t npoints, int n, 
 int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, const double* bound1,
                            const double* bound2, double* error) {
   ECCKD_REQUIRE(g && (n == 0 || (bound1 && bound2 && error)), "ecckd_calc_error_batch: NULL argument");
-  ECCKD_REQUIRE(npoints > 0 && ibegin + npoints <= g->n,
-                "ecckd_calc_error_batch: band [%zu,%zu) outside the spectrum (%zu points)", ibegin, ibegin + npoints, g->n);
+  if (n <= 0) return ECCKD_OK;
+  const std::vector<size_t> ib((size_t)n, ibegin), np((size_t)n, npoints);
+  return ecckd_calc_error_multi(g, n, ib.data(), np.data(), bound1, bound2, error);
+}
+
+// The same for intervals of DIFFERENT bands in one batch: interval k is the fraction [bound1[k], bound2[k]] of the band
+// that starts at sorted index ibegin[k] and has npoints[k] points.  One launch train for all of them - the band searches
+// of a gas are independent (find_g_points.cpp:1152), so their error evaluations can share the GPU (ecckd_find_g_bands_ex).
+int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const size_t* npoints_k, const double* bound1,
+                           const double* bound2, double* error) {
+  ECCKD_REQUIRE(g && (n == 0 || (ibegin_k && npoints_k && bound1 && bound2 && error)), "ecckd_calc_error_multi: NULL argument");
   if (n <= 0) return ECCKD_OK;
   ecckd_ctx* ctx = g->ctx;
   ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1924,6 +1933,9 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   std::vector<Interval> iv(n);
   long long total_pts = 0;
   for (int k = 0; k < n; ++k) {
+    const size_t ibegin = ibegin_k[k], npoints = npoints_k[k];
+    ECCKD_REQUIRE(npoints > 0 && ibegin + npoints <= g->n,
+                  "ecckd_calc_error_batch: band [%zu,%zu) outside the spectrum (%zu points)", ibegin, ibegin + npoints, g->n);
     const double b1 = bound1[k], b2 = bound2[k];
     long long i1 = (long long)std::ceil(b1 * (double)(npoints - 1));
     long long i2 = (long long)std::floor(b2 * (double)(npoints - 1));

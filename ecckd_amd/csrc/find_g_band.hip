@@ -9,8 +9,12 @@
 #include "partition_search.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -261,6 +265,81 @@ int ecckd_gas_median_sorting_variable(ecckd_gas* g, const double* d_sorting_vari
   return ECCKD_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Merges the error evaluations that several band searches (one host thread each) ask for at the same time into one
+// ecckd_calc_error_multi call.  A search hands in its batch and sleeps; the batch runs when EVERY search that is still
+// going has handed one in (so nothing else touches the gas meanwhile), on the thread that arrived last.
+class BandBatcher {
+ public:
+  BandBatcher(ecckd_gas* gas, int nsearch) : gas_(gas), active_(nsearch) {}
+
+  int evaluate(size_t ibegin, size_t npoints, int n, const double* b1, const double* b2, double* e) {
+    Request r{ibegin, npoints, n, b1, b2, e, {false}, ECCKD_OK, std::string()};
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      pending_.push_back(&r);
+      if ((int)pending_.size() == active_) run(lk);
+    }
+    // a batch takes a few hundred microseconds: yielding in a loop costs less than being put to sleep and woken up
+    while (!r.done.load(std::memory_order_acquire)) std::this_thread::yield();
+    if (r.rc != ECCKD_OK) ecckd::fail(r.rc, "%s", r.message.c_str());   // the message was recorded on the thread that ran the batch
+    return r.rc;
+  }
+
+  // a search is over (converged, failed, or gone on to its post-processing): the others no longer wait for it
+  void leave() {
+    std::unique_lock<std::mutex> lk(m_);
+    --active_;
+    if (active_ > 0 && (int)pending_.size() == active_) run(lk);
+  }
+
+ private:
+  struct Request {
+    size_t ibegin, npoints;
+    int n;
+    const double *b1, *b2;
+    double* e;
+    std::atomic<bool> done;
+    int rc;
+    std::string message;
+  };
+
+  void run(std::unique_lock<std::mutex>&) {   // called with the lock held; every other active search is asleep
+    std::vector<size_t> ib, np;
+    std::vector<double> b1, b2;
+    for (const Request* r : pending_)
+      for (int k = 0; k < r->n; ++k) { ib.push_back(r->ibegin); np.push_back(r->npoints); b1.push_back(r->b1[k]); b2.push_back(r->b2[k]); }
+    std::vector<double> err(b1.size());
+    const int rc = ecckd_calc_error_multi(gas_, (int)b1.size(), ib.data(), np.data(), b1.data(), b2.data(), err.data());
+    const std::string message = rc == ECCKD_OK ? std::string() : std::string(ecckd_last_error());
+    size_t off = 0;
+    for (Request* r : pending_) {
+      if (rc == ECCKD_OK) std::copy(err.begin() + off, err.begin() + off + r->n, r->e);
+      off += r->n;
+      r->rc = rc;
+      r->message = message;
+    }
+    std::vector<Request*> finished;
+    finished.swap(pending_);
+    for (Request* r : finished) r->done.store(true, std::memory_order_release);   // r may be gone right after this
+  }
+
+  ecckd_gas* gas_;
+  int active_;
+  std::mutex m_;
+  std::vector<Request*> pending_;
+};
+
+thread_local BandBatcher* tl_batcher = nullptr;
+std::mutex g_band_device_mutex;
+
+}  // namespace
+
+extern "C" {
+
 int ecckd_find_g_band_ex(ecckd_gas* g, size_t ibegin, size_t iend, double heating_rate_tolerance, double tolerance_tolerance,
                          int max_iterations, const ecckd_band_options* opt, int* ng, double* bounds, double* error,
                          int64_t* rank1, int64_t* rank2, int capacity, int* status, double* comp_cost) {
@@ -269,8 +348,15 @@ int ecckd_find_g_band_ex(ecckd_gas* g, size_t ibegin, size_t iend, double heatin
   const size_t npoints = iend - ibegin + 1;
   const double cost0 = g->total_comp_cost;
   int rc_eval = ECCKD_OK;
+  BandBatcher* const batcher = tl_batcher;    // set when this search is one of several running side by side
+  double local_cost = 0.0;
   ecckd::PartitionSearch ps([&](int n, const double* b1, const double* b2, double* e) {
-    rc_eval = ecckd_calc_error_batch(g, ibegin, npoints, n, b1, b2, e);
+    if (batcher) {
+      for (int k = 0; k < n; ++k) local_cost += b2[k] - b1[k];
+      rc_eval = batcher->evaluate(ibegin, npoints, n, b1, b2, e);
+    } else {
+      rc_eval = ecckd_calc_error_batch(g, ibegin, npoints, n, b1, b2, e);
+    }
     return rc_eval;
   });
   // CkdEquipartition::init_lw / init_sw (find_g_points.cpp:230-233, :256-261) + :1180-1181
@@ -358,8 +444,14 @@ int ecckd_find_g_band_ex(ecckd_gas* g, size_t ibegin, size_t iend, double heatin
       // band that starts at rank 0; any other band ends in the reference's :1335-1338 error
       if (ibegin != 0) return ecckd::fail(ECCKD_PARAMETER_ERROR, "Failed to account for all wavenumbers in split");
       std::vector<int64_t> count(nwavsplit);
-      ECCKD_CHECK(ecckd_regroup_rank_by_wavenumber_dev(g->ctx, opt->nwav, opt->d_wavenumber, opt->d_rank, 0, (size_t)ind2,
-                                                       nwavsplit, opt->base_wn_bound, count.data()));
+      {
+        // the other searches never touch the device themselves while this one is not waiting in the batcher, but two
+        // searches could get here together
+        std::unique_lock<std::mutex> device_lock(g_band_device_mutex, std::defer_lock);
+        if (batcher) device_lock.lock();
+        ECCKD_CHECK(ecckd_regroup_rank_by_wavenumber_dev(g->ctx, opt->nwav, opt->d_wavenumber, opt->d_rank, 0, (size_t)ind2,
+                                                         nwavsplit, opt->base_wn_bound, count.data()));
+      }
       iwav1[0] = 0;
       for (int q = 0; q < nwavsplit; ++q) {
         if (q > 0) iwav1[q] = iwav2[q - 1] + 1;
@@ -390,7 +482,7 @@ int ecckd_find_g_band_ex(ecckd_gas* g, size_t ibegin, size_t iend, double heatin
 
   *status = st;
   *ng = n;
-  if (comp_cost) *comp_cost = g->total_comp_cost - cost0;
+  if (comp_cost) *comp_cost = batcher ? local_cost : g->total_comp_cost - cost0;
   ECCKD_REQUIRE(n <= capacity, "ecckd_find_g_band_ex: %d g points exceed the caller's capacity %d", n, capacity);
   std::memcpy(bounds, b.data(), (size_t)(n + 1) * sizeof(double));
   std::memcpy(error, e.data(), (size_t)n * sizeof(double));
@@ -411,6 +503,44 @@ int ecckd_find_g_band(ecckd_gas* g, size_t ibegin, size_t iend, double heating_r
   opt.base_split = 1.0;
   return ecckd_find_g_band_ex(g, ibegin, iend, heating_rate_tolerance, tolerance_tolerance, max_iterations, &opt, ng,
                               bounds, error, nullptr, nullptr, capacity, status, comp_cost);
+}
+
+int ecckd_find_g_bands_ex(ecckd_gas* g, int nband, const size_t* ibegin, const size_t* iend, const double* heating_rate_tolerance,
+                          double tolerance_tolerance, int max_iterations, const ecckd_band_options* opt, int* ng, double* bounds,
+                          double* error, int64_t* rank1, int64_t* rank2, int capacity, int* status, double* comp_cost) {
+  ECCKD_REQUIRE(g && nband > 0 && ibegin && iend && heating_rate_tolerance && opt && ng && bounds && error && status && capacity > 0,
+                "ecckd_find_g_bands_ex: bad argument");
+  ECCKD_REQUIRE(!g->do_sw, "ecckd_find_g_bands_ex: longwave gases only (a shortwave gas holds one band albedo at a time)");
+  if (nband == 1)
+    return ecckd_find_g_band_ex(g, ibegin[0], iend[0], heating_rate_tolerance[0], tolerance_tolerance, max_iterations, &opt[0], ng,
+                                bounds, error, rank1, rank2, capacity, status, comp_cost);
+  BandBatcher batcher(g, nband);
+  std::vector<int> rc(nband, ECCKD_OK);
+  std::vector<std::string> message(nband);
+  std::vector<std::thread> threads;
+  threads.reserve(nband);
+  for (int b = 0; b < nband; ++b) {
+    threads.emplace_back([&, b] {
+      tl_batcher = &batcher;
+      struct Leave {   // whatever way the search ends, the others must stop waiting for it
+        BandBatcher& bb;
+        bool left = false;
+        void now() { if (!left) { left = true; bb.leave(); } }
+        ~Leave() { now(); }
+      } leave{batcher};
+      (void)hipSetDevice(g->ctx->device);
+      rc[b] = ecckd_find_g_band_ex(g, ibegin[b], iend[b], heating_rate_tolerance[b], tolerance_tolerance, max_iterations, &opt[b],
+                                   &ng[b], bounds + (size_t)b * (capacity + 1), error + (size_t)b * capacity,
+                                   rank1 ? rank1 + (size_t)b * capacity : nullptr, rank2 ? rank2 + (size_t)b * capacity : nullptr,
+                                   capacity, &status[b], comp_cost ? &comp_cost[b] : nullptr);
+      if (rc[b] != ECCKD_OK) message[b] = ecckd_last_error();
+      tl_batcher = nullptr;
+    });
+  }
+  for (std::thread& t : threads) t.join();
+  for (int b = 0; b < nband; ++b)
+    if (rc[b] != ECCKD_OK) return ecckd::fail(rc[b], "band %d: %s", b, message[b].c_str());
+  return ECCKD_OK;
 }
 
 }  // extern "C"

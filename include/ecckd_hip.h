@@ -189,6 +189,10 @@ double ecckd_gas_comp_cost(ecckd_gas* gas, int reset);
  * (:298-313).  Synchronous. */
 int ecckd_calc_error_batch(ecckd_gas* gas, size_t ibegin, size_t npoints, int n,
                            const double* h_bound1, const double* h_bound2, double* h_error);
+/* The same with a band per interval: interval k is the fraction [h_bound1[k], h_bound2[k]] of the band that starts at
+ * sorted index h_ibegin[k] and has h_npoints[k] points.  One launch train for intervals of several bands. */
+int ecckd_calc_error_multi(ecckd_gas* gas, int n, const size_t* h_ibegin, const size_t* h_npoints,
+                           const double* h_bound1, const double* h_bound2, double* h_error);
 
 /* The fitted grey optical depth alone: replaces fit_optical_depth_lw / fit_optical_depth_sw /
  * fit_optical_depth_sw_total_trans (find_g_points.cpp:54-106, :112-165, :171-204) for n
@@ -286,6 +290,19 @@ int ecckd_find_g_band_ex(ecckd_gas* gas, size_t ibegin, size_t iend, double heat
                          const ecckd_band_options* opt, int* ng, double* bounds, double* error,
                          int64_t* rank1, int64_t* rank2, int capacity, int* status,
                          double* comp_cost);
+
+/* All bands of a gas at once.  The band loop of find_g_points.cpp:1152 runs its searches one after the other, but they
+ * are independent: here every band's search (exactly ecckd_find_g_band_ex, same decisions) runs in its own host thread
+ * and the error evaluations the searches ask for at the same time are merged into ONE batch (ecckd_calc_error_multi),
+ * so that narrow bands, too small to fill the GPU on their own, share it: the 13 longwave bands of the ecRad structure
+ * go from 2.7e9 to the single-band rate in wavenumber-points/s.  Longwave gases only (a shortwave gas carries one band
+ * albedo at a time, ecckd_gas_set_band_albedo); results per band as ecckd_find_g_band_ex, arrays [nband] or
+ * [nband][capacity(+1)].  Interval errors can differ from the one-band-at-a-time values by rounding (the chunking of the
+ * sums follows the batch), never the logic. */
+int ecckd_find_g_bands_ex(ecckd_gas* gas, int nband, const size_t* ibegin, const size_t* iend,
+                          const double* heating_rate_tolerance, double tolerance_tolerance, int max_iterations,
+                          const ecckd_band_options* opt /* [nband] */, int* ng, double* bounds, double* error,
+                          int64_t* rank1, int64_t* rank2, int capacity, int* status, double* comp_cost);
 
 /* calc_median_sorting_variable (find_g_points.cpp:35-49) for n g points: the sorting variable
  * at the point where the cumulative weight (LW: surface Planck function, SW: solar irradiance,

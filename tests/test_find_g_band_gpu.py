@@ -280,3 +280,41 @@ def test_median_sorting_variable(ctx, oracle):
     want = np.array([oracle.median_sorting_variable(s["key_s"], s["surf_planck"], a, b) for a, b in zip(ind1, ind2)])
     assert np.array_equal(got, want)
     gas.close()
+
+
+def test_all_bands_at_once_match_one_band_at_a_time(ctx, oracle):
+    """ecckd_find_g_bands_ex: the 13 band searches of a gas side by side, their error batches merged
+    (ecckd_calc_error_multi), against the band loop of find_g_points.cpp:1152 run one band after the other: the same g
+    points - index boundaries, status, number - in every band; errors equal to rounding (the chunking follows the batch)."""
+    import torch
+    from ecckd_amd import api, synthetic as syn
+    from conftest import make_lw_case
+    nwav, nlay = 60000, 30
+    p, wn, dwn, od32 = make_lw_case(nwav, nlay=nlay, seed=91)
+    _, _, _, bg32 = make_lw_case(nwav, nlay=nlay, seed=191, column_scale=3.0)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=ctx.device)
+    b1, b2 = syn.LW_NARROW_BANDS
+    iband, begin, end = api.band_ranges(wn, b1, b2)
+    key, col = api.reorder_key_lw(ctx, p, api.idealised_temperature(p), dev(wn), dev(dwn), dev(od32), 0.5)
+    rank, _ = api.stable_argsort_bands(ctx, key, begin, end, want_ordered=False)
+    gas = api.GasLW(ctx, p, syn.temperature_profile(p), dev(wn), dev(dwn), rank, dev(od32), dev(bg32), "transmission", 0.02, 0.0)
+    nband = len(begin)
+    tol = np.where(np.arange(nband) % 2 == 0, 0.02, 0.05)
+    options = [dict(min_g_points=3) if k == 4 else (dict(max_g_points=2) if k == 7 else None) for k in range(nband)]
+    one_by_one = [gas.find_g_band_ex(int(begin[k]), int(end[k]), float(tol[k]), 0.02, 40, **(options[k] or {})) for k in range(nband)]
+    together = gas.find_g_bands_ex(begin, end, tol, 0.02, 40, options=options)
+    assert sum(len(r["error"]) for r in one_by_one) > 2 * nband
+    for k, (a, b) in enumerate(zip(one_by_one, together)):
+        assert a["status"] == b["status"] and np.array_equal(a["rank1"], b["rank1"]) and np.array_equal(a["rank2"], b["rank2"]), k
+        assert np.allclose(a["error"], b["error"], rtol=1e-10, atol=0) and np.allclose(a["bounds"], b["bounds"], rtol=0, atol=1e-12), k
+        assert b["comp_cost"] == pytest.approx(a["comp_cost"], rel=1e-9)
+    assert len(together[4]["error"]) >= 3 and len(together[7]["error"]) <= 2
+    # the merged batch itself: intervals of three bands in one call
+    ks = [0, 5, 12]
+    ib = np.repeat([begin[k] for k in ks], 2)
+    npt = np.repeat([end[k] - begin[k] + 1 for k in ks], 2)
+    lo, hi = np.tile([0.0, 0.4], 3), np.tile([0.4, 1.0], 3)
+    merged = gas.calc_error_multi(ib, npt, lo, hi)
+    single = np.concatenate([gas.calc_error_batch(int(begin[k]), int(end[k] - begin[k] + 1), [0.0, 0.4], [0.4, 1.0]) for k in ks])
+    assert np.allclose(merged, single, rtol=1e-10, atol=0)
+    gas.close()
