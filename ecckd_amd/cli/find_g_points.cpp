@@ -224,11 +224,13 @@ int main(int argc, char** argv) {
       GasResult res;
       res.molecule = gas_str;
       const int capacity = 1024;
+      // Options of every band first: longwave bands are then searched side by side (ecckd_find_g_bands_ex), shortwave bands
+      // one after the other because the gas carries one band albedo at a time.
+      std::vector<ecckd_band_options> opts(nband);
+      std::vector<std::vector<double>> wn_bounds(nband);
       for (int b = 0; b < nband; ++b) {
-        LOG("  Band %d: %g-%g cm-1\n", b, band_bound1[b], band_bound2[b]);
         if (ibegin[b] < 0) fail(ECCKD_PARAMETER_ERROR, "Band %d contains no wavenumbers", b);
-        if (do_sw) ck(ecckd_gas_set_band_albedo(gas, band_albedo[b]));
-        ecckd_band_options opt;
+        ecckd_band_options& opt = opts[b];
         std::memset(&opt, 0, sizeof opt);
         opt.min_g_points = min_g_points[b];
         opt.max_g_points = max_g_points[b];
@@ -240,7 +242,7 @@ int main(int argc, char** argv) {
           opt.g_split = g_split[b];
         }
         opt.base_split = base_split[b];
-        std::vector<double> wn_bound;
+        std::vector<double>& wn_bound = wn_bounds[b];
         std::vector<double> interior;
         for (double w : base_wavenumber_boundary) if (w > band_bound1[b] && w < band_bound2[b]) interior.push_back(w);
         if (base_split[b] != 1.0 || !interior.empty()) {   // :1268-1301
@@ -253,31 +255,47 @@ int main(int argc, char** argv) {
           opt.d_rank = d_rank.as<int32_t>();
           opt.nwav = nwav;
         }
-        int ng = 0, status = 0;
-        double comp_cost = 0.0;
-        std::vector<double> bounds(capacity + 1), error(capacity);
-        std::vector<int64_t> r1(capacity), r2(capacity);
-        ck(ecckd_find_g_band_ex(gas, (size_t)ibegin[b], (size_t)iend[b], tolerance[b], tolerance_tolerance, max_iterations, &opt, &ng,
-                                bounds.data(), error.data(), r1.data(), r2.data(), capacity, &status, &comp_cost));
-        LOG("    %s: %d g points, computational cost = %g\n", ecckd_partition_status_string(status), ng, comp_cost);
+      }
+      std::vector<int> ngs(nband, 0), statuses(nband, 0);
+      std::vector<double> comp_costs(nband, 0.0);
+      std::vector<double> bounds((size_t)nband * (capacity + 1)), error((size_t)nband * capacity);
+      std::vector<int64_t> r1((size_t)nband * capacity), r2((size_t)nband * capacity);
+      bool sequential_bands = false;                 // extension key: the reference's one-band-at-a-time order of evaluation
+      config.read(sequential_bands, "sequential_bands");
+      const bool side_by_side = !do_sw && nband > 1 && !sequential_bands;
+      if (side_by_side) {
+        std::vector<size_t> ib(ibegin.begin(), ibegin.end()), ie(iend.begin(), iend.end());
+        ck(ecckd_find_g_bands_ex(gas, nband, ib.data(), ie.data(), tolerance.data(), tolerance_tolerance, max_iterations, opts.data(),
+                                 ngs.data(), bounds.data(), error.data(), r1.data(), r2.data(), capacity, statuses.data(), comp_costs.data()));
+      }
+      for (int b = 0; b < nband; ++b) {
+        LOG("  Band %d: %g-%g cm-1\n", b, band_bound1[b], band_bound2[b]);
+        const size_t o = (size_t)b * capacity;
+        if (!side_by_side) {
+          if (do_sw) ck(ecckd_gas_set_band_albedo(gas, band_albedo[b]));
+          ck(ecckd_find_g_band_ex(gas, (size_t)ibegin[b], (size_t)iend[b], tolerance[b], tolerance_tolerance, max_iterations, &opts[b], &ngs[b],
+                                  &bounds[(size_t)b * (capacity + 1)], &error[o], &r1[o], &r2[o], capacity, &statuses[b], &comp_costs[b]));
+        }
+        const int ng = ngs[b];
+        LOG("    %s: %d g points, computational cost = %g\n", ecckd_partition_status_string(statuses[b]), ng, comp_costs[b]);
         std::vector<double> med(ng);
-        ck(ecckd_gas_median_sorting_variable(gas, d_sv_sorted.as<double>(), ng, r1.data(), r2.data(), med.data()));
+        ck(ecckd_gas_median_sorting_variable(gas, d_sv_sorted.as<double>(), ng, &r1[o], &r2[o], med.data()));
         res.n_g_points.push_back(ng);
         for (int k = 0; k < ng; ++k) {
           res.band_number.push_back(b);
-          res.rank1.push_back(r1[k]);
-          res.rank2.push_back(r2[k]);
-          res.error.push_back(error[k]);
+          res.rank1.push_back(r1[o + k]);
+          res.rank2.push_back(r2[o + k]);
+          res.error.push_back(error[o + k]);
           res.sorting_variable.push_back(med[k]);
-          LOG("    g point %d: ranks %lld-%lld, error %g K d-1\n", k, (long long)r1[k], (long long)r2[k], error[k]);
+          LOG("    g point %d: ranks %lld-%lld, error %g K d-1\n", k, (long long)r1[o + k], (long long)r2[o + k], error[o + k]);
         }
       }
       if (gas != first_lw_gas) ck(ecckd_gas_destroy(gas));
       // SingleGasData::store_g_points (single_gas_data.h:56-62) with the (possibly re-ranked) ranks
       const int ngp = (int)res.rank1.size();
-      std::vector<int32_t> r1(res.rank1.begin(), res.rank1.end()), r2(res.rank2.begin(), res.rank2.end());
+      std::vector<int32_t> gr1(res.rank1.begin(), res.rank1.end()), gr2(res.rank2.begin(), res.rank2.end());
       res.d_g_point.alloc(dev, nwav * sizeof(int32_t));
-      ck(ecckd_gas_g_point_dev(dev.ctx(), nwav, d_rank.as<int32_t>(), ngp, r1.data(), r2.data(), res.d_g_point.as<int32_t>()));
+      ck(ecckd_gas_g_point_dev(dev.ctx(), nwav, d_rank.as<int32_t>(), ngp, gr1.data(), gr2.data(), res.d_g_point.as<int32_t>()));
       ck(ecckd_synchronize(dev.ctx()));
       gases.push_back(std::move(res));
       LOG("\n");

@@ -308,6 +308,9 @@ class BandBatcher {
   };
 
   void run(std::unique_lock<std::mutex>&) {   // called with the lock held; every other active search is asleep
+    // the searches arrive in any order: the batch is laid out by band so that its sums (whose chunking follows the layout)
+    // and hence the errors are the same from run to run
+    std::sort(pending_.begin(), pending_.end(), [](const Request* a, const Request* b) { return a->ibegin < b->ibegin; });
     std::vector<size_t> ib, np;
     std::vector<double> b1, b2;
     for (const Request* r : pending_)

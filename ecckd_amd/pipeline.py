@@ -298,7 +298,7 @@ def reorder_spectrum(ctx, input_path, output_path, band_bound1, band_bound2, ipr
 
 def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, output_path=None, averaging_method="transmission",
                   flux_weight=0.02, min_pressure=0.0, tolerance_tolerance=0.02, max_iterations=60, iprofile=0, ssi=None,
-                  max_no_rayleigh_wavenumber=10000.0, reference_albedo=0.15, cos_sza=0.5):
+                  max_no_rayleigh_wavenumber=10000.0, reference_albedo=0.15, cos_sza=0.5, sequential_bands=False):
     """The main loop of find_g_points.cpp:655-1660 over classic files (shortwave when `ssi[nwav]` is given: solar weights,
     reference albedo 0.15 below max_no_rayleigh_wavenumber (:469, :522, :757-761, :921-923), REFERENCE_COS_SZA = 0.5,
     per-gas min_scaling / max_scaling (:661-667)): per gas the merged background, the gas
@@ -349,12 +349,20 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
         out = dict(name=spec["name"], n_g_points=[], band_number=[], rank1=[], rank2=[], error=[], sorting_variable=[])
         min_gp = np.broadcast_to(np.asarray(spec.get("min_g_points", 1)), (nband,))                   # per band, :733-754
         max_gp = np.broadcast_to(np.asarray(spec.get("max_g_points", 256)), (nband,))
-        for b in range(nband):
-            idx = np.nonzero(iband == b)[0]
-            if band_albedo is not None:
-                gas.set_band_albedo(band_albedo[b])                                                   # init_sw(..., band_albedo(jband), ...)
-            res = gas.find_g_band_ex(int(idx[0]), int(idx[-1]), float(tol[b]), tolerance_tolerance, max_iterations,
-                                     min_g_points=int(min_gp[b]), max_g_points=int(max_gp[b]))
+        band_idx = [np.nonzero(iband == b)[0] for b in range(nband)]
+        band_opts = [dict(min_g_points=int(min_gp[b]), max_g_points=int(max_gp[b])) for b in range(nband)]
+        if band_albedo is None and nband > 1 and not sequential_bands:
+            # longwave bands side by side, sharing their error batches (ecckd_find_g_bands_ex): same decisions per band
+            band_res = gas.find_g_bands_ex([int(i[0]) for i in band_idx], [int(i[-1]) for i in band_idx], tol, tolerance_tolerance,
+                                           max_iterations, band_opts)
+        else:
+            band_res = []
+            for b in range(nband):
+                if band_albedo is not None:
+                    gas.set_band_albedo(band_albedo[b])                                               # init_sw(..., band_albedo(jband), ...)
+                band_res.append(gas.find_g_band_ex(int(band_idx[b][0]), int(band_idx[b][-1]), float(tol[b]), tolerance_tolerance,
+                                                   max_iterations, **band_opts[b]))
+        for b, res in enumerate(band_res):
             n = len(res["error"])
             out["n_g_points"].append(n)
             out["band_number"] += [b] * n

@@ -295,7 +295,8 @@ int ecckd_find_g_band_ex(ecckd_gas* gas, size_t ibegin, size_t iend, double heat
  * are independent: here every band's search (exactly ecckd_find_g_band_ex, same decisions) runs in its own host thread
  * and the error evaluations the searches ask for at the same time are merged into ONE batch (ecckd_calc_error_multi),
  * so that narrow bands, too small to fill the GPU on their own, share it: the 13 longwave bands of the ecRad structure
- * go from 2.7e9 to the single-band rate in wavenumber-points/s.  Longwave gases only (a shortwave gas carries one band
+ * go from 3.0e9 to 3.65e9 wavenumber-points/s (one band of the same size on its own: 5.4e9; the tail of the searches,
+ * when only the widest bands are still refining, stays latency-bound).  Longwave gases only (a shortwave gas carries one band
  * albedo at a time, ecckd_gas_set_band_albedo); results per band as ecckd_find_g_band_ex, arrays [nband] or
  * [nband][capacity(+1)].  Interval errors can differ from the one-band-at-a-time values by rounding (the chunking of the
  * sums follows the batch), never the logic. */
