@@ -1211,8 +1211,12 @@ k_rt_sw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __
 // two different exponents per layer, no sources), level sums through the wave-private transposed LDS tile of the
 // longwave path.  Slots: 0 = sum of the solar irradiance, 1..NLAY = flux_dn below each layer, NLAY+1 = flux_up at the
 // surface, NLAY+2.. = flux_up above each layer going up.
-template <int NLAY>
-__global__ void __launch_bounds__(RT_THREADS, 3)
+// NFIT = 2 (total-transmission with min_scaling != max_scaling, find_g_points.cpp:374-386): the column is fetched once and
+// swept with both fitted optical depths, partial sums of the second fit nchunks * 2 NHL further on.
+// SAME: cos_sza == 0.5, so -tau / cos_sza == -2 tau exactly and the transmittance of the way down is the one of the way up
+// (radiative_transfer_sw.cpp:134-139 and :176-183): the last fit overwrites the column with it instead of evaluating it twice.
+template <int NLAY, int NFIT, bool SAME, int OCC = (NFIT == 1 ? 3 : 2)>
+__global__ void __launch_bounds__(RT_THREADS, OCC)
 k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv, double cos_sza, double albedo,
                 const double* __restrict__ ssi, const double* __restrict__ bg_od, const double* __restrict__ od_fit,
                 double* __restrict__ partial) {
@@ -1221,7 +1225,8 @@ k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
   constexpr int NCH = (NSLOT + 15) / 16;
   constexpr int ROW = 65;
   __shared__ double s_tile[4][16 * ROW];
-  __shared__ double s_out[4][NCH * 16];
+  __shared__ double s_out[NFIT][4][NCH * 16];
+  __shared__ double s_grey[NFIT][NLAY];   // the fitted optical depths: LDS broadcasts (as scalars they take 2 NLAY SGPRs per fit and spill)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long chunk = blockIdx.x;
   int lo = 0, hi = nint - 1;
@@ -1234,13 +1239,25 @@ k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
   const long long p0 = iv[k].i1 + c * chunk_pts;
   long long p1 = p0 + chunk_pts - 1;
   if (p1 > iv[k].i2) p1 = iv[k].i2;
-  const double* __restrict__ grey = od_fit + (size_t)k * NLAY;  // block-uniform -> scalar loads
+  for (int t = tid; t < NFIT * NLAY; t += RT_THREADS) {
+    const int f = t / NLAY, l = t - f * NLAY;
+    s_grey[f][l] = od_fit[((size_t)f * nint + k) * NLAY + l];
+  }
+  __syncthreads();
   double* tile = s_tile[wave];
   const int rr = lane & 15, qq = lane >> 4;
-  double acc[NCH];
+  double acc[NFIT][NCH];
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) acc[j] = 0.0;
+  for (int f = 0; f < NFIT; ++f) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) acc[f][j] = 0.0;
+  }
   const double minus_sec_sza = -1.0 / cos_sza;
+  // exp with its coefficients in scalar registers (fastmath.hpp).  A saturated interval fits an infinite optical depth
+  // (log(0), find_g_points.cpp:123-124): the argument is held at -800, where the result has already underflowed to 0,
+  // because exp_fast_s(-inf) would be inf - inf.
+  const ecckd::ExpConsts ek = ecckd::exp_consts();
+  auto trans = [&](double x) { return ecckd::exp_fast_s(fmax(x, -800.0), ek); };
   const bool reflect = albedo > 0.0;                 // :366-373: no upwelling without a reflecting surface
   for (long long base = p0; base <= p1; base += RT_THREADS) {
     const long long i = base + tid;
@@ -1250,56 +1267,85 @@ k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
     __builtin_amdgcn_s_setprio(3);     // as in the longwave kernel: the wave that is about to fetch its column goes first
 #pragma unroll
     for (int l = 0; l < NLAY; ++l) tau[l] = __builtin_nontemporal_load(&bg_od[(size_t)l * n + ii]);
-    const double sv = ssi[ii];
+    const double sv = live ? ssi[ii] : 0.0;   // a lane past the end carries zero flux through both sweeps: nothing else to mask
     __builtin_amdgcn_s_setprio(0);
-    int slot = 0;
-    auto push = [&](double v) {
-      tile[(slot & 15) * ROW + lane] = live ? v : 0.0;
-      if ((slot & 15) == 15 || slot == NSLOT - 1) {
-        const int ch = slot >> 4;
-        __builtin_amdgcn_wave_barrier();
-        double sum = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) sum += tile[rr * ROW + qq * 16 + j];
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        acc[ch] += sum;
-        __builtin_amdgcn_wave_barrier();
+    for (int f = 0; f < NFIT; ++f) {
+      const double* grey = s_grey[f];
+      int slot = 0;
+      auto push = [&](double v) {
+        tile[(slot & 15) * ROW + lane] = v;
+        if ((slot & 15) == 15 || slot == NSLOT - 1) {
+          const int ch = slot >> 4;
+          __builtin_amdgcn_wave_barrier();
+          double sum = 0.0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) sum += tile[rr * ROW + qq * 16 + j];
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+          acc[f][ch] += sum;
+          __builtin_amdgcn_wave_barrier();
+        }
+        ++slot;
+      };
+      push(sv);
+      double flux = cos_sza * sv;
+      const bool last = f == NFIT - 1;          // compile time after unrolling: the column is free to be overwritten
+      if (last && SAME) {
+#pragma unroll
+        for (int l = 0; l < NLAY; ++l) {
+          const double xd = -2.0 * (tau[l] + grey[l]);
+          tau[l] = trans(xd);
+          flux = flux * tau[l];
+          push(flux);
+        }
+      } else if (last) {
+#pragma unroll
+        for (int l = 0; l < NLAY; ++l) {
+          tau[l] += grey[l];
+          const double xd = minus_sec_sza * tau[l];
+          flux = flux * trans(xd);
+          push(flux);
+        }
+      } else {
+#pragma unroll
+        for (int l = 0; l < NLAY; ++l) {
+          const double xd = minus_sec_sza * (tau[l] + grey[l]);
+          flux = flux * trans(xd);
+          push(flux);
+        }
       }
-      ++slot;
-    };
-    push(sv);
-    double flux = cos_sza * sv;
-#pragma unroll
-    for (int l = 0; l < NLAY; ++l) {
-      tau[l] += grey[l];
-      // a saturated interval fits an infinite optical depth (log(0), find_g_points.cpp:123-124): exp(-inf) = 0
-      const double xd = minus_sec_sza * tau[l];
-      flux = flux * (xd < -745.0 ? 0.0 : ecckd::exp_fast(xd));
+      flux = reflect ? flux * albedo : 0.0;
       push(flux);
-    }
-    flux = reflect ? flux * albedo : 0.0;
-    push(flux);
 #pragma unroll
-    for (int l = NLAY - 1; l >= 0; --l) {
-      const double xu = -2.0 * tau[l];
-      if (reflect) flux = flux * (xu < -745.0 ? 0.0 : ecckd::exp_fast(xu));
-      push(flux);
-    }
-    if ((NSLOT & 15) != 0) {
+      for (int l = NLAY - 1; l >= 0; --l) {
+        if (last && SAME) {
+          if (reflect) flux = flux * tau[l];
+        } else {
+          const double xu = -2.0 * (last ? tau[l] : tau[l] + grey[l]);
+          if (reflect) flux = flux * trans(xu);
+        }
+        push(flux);
+      }
+      if ((NSLOT & 15) != 0) {
 #pragma unroll
-      for (int j = (NSLOT & 15); j < 16; ++j) tile[j * ROW + lane] = 0.0;
+        for (int j = (NSLOT & 15); j < 16; ++j) tile[j * ROW + lane] = 0.0;
+      }
     }
   }
   if (lane < 16) {
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) s_out[wave][j * 16 + lane] = acc[j];
+    for (int f = 0; f < NFIT; ++f) {
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) s_out[f][wave][j * 16 + lane] = acc[f][j];
+    }
   }
   __syncthreads();
-  for (int t = tid; t < 2 * NHL; t += RT_THREADS) {
+  for (int t = tid; t < NFIT * 2 * NHL; t += RT_THREADS) {
     // flux_dn level t = slot t; flux_up level u = slot NLAY + 1 + (NLAY - u)
-    const int sl = t < NHL ? t : NLAY + 1 + (NLAY - (t - NHL));
-    partial[(size_t)chunk * 2 * NHL + t] = ((s_out[0][sl] + s_out[1][sl]) + s_out[2][sl]) + s_out[3][sl];
+    const int f = t / (2 * NHL), tt = t - f * 2 * NHL;
+    const int sl = tt < NHL ? tt : NLAY + 1 + (NLAY - (tt - NHL));
+    partial[((size_t)f * gridDim.x + chunk) * 2 * NHL + tt] = ((s_out[f][0][sl] + s_out[f][1][sl]) + s_out[f][2][sl]) + s_out[f][3][sl];
   }
 }
 // K5d-SW: calc_cost_function_sw (calc_cost_function_sw.cpp:86-109): heating rate from the
@@ -1958,7 +2004,10 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   // mirror path: 3 resident blocks per CU (3 waves/SIMD) -> one wave of blocks; more chunks shorten K5c a
   // little but lengthen the ordered combine in K5d by more
   static const int rt_bpc = std::getenv("ECCKD_RT_BPC") ? std::max(1, std::atoi(std::getenv("ECCKD_RT_BPC"))) : 3;   // tuning knob
-  long long target_blocks = (long long)ctx->num_cu * (fast_path ? rt_bpc : 8);
+  // one round of resident blocks: the longwave and one-fit shortwave sweeps hold 3 blocks per CU, the two-fit shortwave sweep 2
+  static const int sw2_bpc = std::getenv("ECCKD_SW2_BPC") ? std::max(1, std::atoi(std::getenv("ECCKD_SW2_BPC"))) : 2;   // tuning knob
+  const bool sw_two_fits = g->do_sw && g->method == ECCKD_AVG_TOTAL_TRANSMISSION && fast_path;
+  long long target_blocks = (long long)ctx->num_cu * (sw_two_fits ? sw2_bpc : fast_path ? rt_bpc : 8);
   long long chunk_pts = (total_pts + target_blocks - 1) / target_blocks;
   chunk_pts = (chunk_pts + RT_THREADS - 1) / RT_THREADS * RT_THREADS;
   if (chunk_pts < RT_THREADS) chunk_pts = RT_THREADS;
@@ -1972,7 +2021,7 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   const size_t iv_bytes = ecckd_align_up((size_t)n * sizeof(Interval), 256);
   const size_t sums_bytes = ecckd_align_up((size_t)n * g->nrows * sizeof(double), 256);
   const size_t fit_bytes = ecckd_align_up((size_t)2 * n * nlay * sizeof(double), 256);
-  const size_t part_bytes = ecckd_align_up((size_t)nchunks * 2 * nhl * sizeof(double), 256);
+  const size_t part_bytes = ecckd_align_up((size_t)2 * nchunks * 2 * nhl * sizeof(double), 256);   // x2: both fits of the dual shortwave sweep
   const size_t err_bytes = ecckd_align_up((size_t)2 * n * sizeof(double), 256);
   ECCKD_CHECK(gas_ensure_work(g, iv_bytes + sums_bytes + fit_bytes + part_bytes + err_bytes, iv_bytes + err_bytes));
   char* w = (char*)g->work;
@@ -2005,17 +2054,32 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
     const size_t rt_lds_sw = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
     const size_t cost_lds_sw = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
     const int npass = is_tt ? 2 : 1;
+    // total-transmission evaluates the interval with the fit scaled by min_scaling and by max_scaling (:374-386; never equal
+    // in the reference: min <= 0.5, max >= 2.5, :666-667): one launch that fetches the column once and sweeps it with both
+    // fits (the compile-time-nlay kernels).  At the reference's cos_sza = 0.5 the direct and the reflected beam see the same
+    // transmittance exp(-2 tau), bit for bit: the kernels then keep it from the way down (SAME).
+    const bool dual = is_tt && (nlay == 54 || nlay == 30);
+    const size_t part_stride = (size_t)nchunks * 2 * nhl;
+    static const bool no_same = std::getenv("ECCKD_SW_NO_SAME") != nullptr;   // A/B knob
+    const bool same_exp = g->cos_sza == 0.5 && !no_same;
     for (int pass = 0; pass < npass; ++pass) {
-      if (nlay == 54)
-        hipLaunchKernelGGL(k_rt_sw_bb_fast<54>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, chunk_pts, n,
-                           d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, d_fit + (size_t)pass * n * nlay, d_part);
-      else if (nlay == 30)
-        hipLaunchKernelGGL(k_rt_sw_bb_fast<30>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, chunk_pts, n,
-                           d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, d_fit + (size_t)pass * n * nlay, d_part);
-      else
-        hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
-                           chunk_pts, n, d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od,
-                           d_fit + (size_t)pass * n * nlay, d_part);
+      const bool sweep = pass == 0 || !dual;
+      double* part = d_part + ((dual && pass == 1) ? part_stride : 0);
+      if (sweep) {
+#define ECCKD_SW_SWEEP(NL, NF, SM, FIT)                                                                                         \
+  hipLaunchKernelGGL((k_rt_sw_bb_fast<NL, NF, SM>), dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, chunk_pts, n, \
+                     d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, FIT, d_part)
+        const double* fit1 = d_fit + (size_t)pass * n * nlay;
+        if (nlay == 54 && dual) { if (same_exp) ECCKD_SW_SWEEP(54, 2, true, d_fit); else ECCKD_SW_SWEEP(54, 2, false, d_fit); }
+        else if (nlay == 30 && dual) { if (same_exp) ECCKD_SW_SWEEP(30, 2, true, d_fit); else ECCKD_SW_SWEEP(30, 2, false, d_fit); }
+        else if (nlay == 54) { if (same_exp) ECCKD_SW_SWEEP(54, 1, true, fit1); else ECCKD_SW_SWEEP(54, 1, false, fit1); }
+        else if (nlay == 30) { if (same_exp) ECCKD_SW_SWEEP(30, 1, true, fit1); else ECCKD_SW_SWEEP(30, 1, false, fit1); }
+#undef ECCKD_SW_SWEEP
+        else
+          hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
+                             chunk_pts, n, d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od,
+                             d_fit + (size_t)pass * n * nlay, d_part);
+      }
       int rH = R.H, rFDS = R.FDS, rFUT = R.FUT;
       if (is_tt) {
         rH = pass == 0 ? R.HL : R.HH;
@@ -2023,7 +2087,7 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
         rFUT = pass == 0 ? R.FUTL : R.FUTH;
       }
       hipLaunchKernelGGL(k_cost_sw, dim3(n), dim3(1024), cost_lds_sw, ctx->stream, nlay, R.total, rH, rFDS, rFUT,
-                         d_iv, nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight,
+                         d_iv, nchunks, part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight,
                          g->cos_sza, d_err + (size_t)pass * n);
     }
     ECCKD_HIP_CHECK(hipGetLastError());

@@ -2,6 +2,7 @@
 gas preparation, batched interval errors for every averaging method including
 total-transmission, against the CPU oracle.  Tolerances as in test_find_g_gpu.py."""
 import math
+import sys
 
 import numpy as np
 import pytest
@@ -131,6 +132,28 @@ def test_interval_errors_total_transmission(ctx, oracle, with_albedo, band_albed
     ref = np.array([eq.calc_error(x, y) for x, y in zip(b1, b2)])
     # absolute floor: errors are K/d differences of sums whose rounding noise is ~1e-12 K/d
     assert np.allclose(err, ref, rtol=ERR_RTOL, atol=1e-10)
+    gas.close()
+
+
+@pytest.mark.parametrize("nlay,method,mu0", [(54, "total-transmission", 0.5), (54, "total-transmission", 0.6),
+                                             (30, "total-transmission", 0.6), (20, "total-transmission", 0.5),
+                                             (54, "transmission", 0.5), (54, "transmission", 0.6), (30, "linear", 0.6)])
+def test_interval_errors_sweep_variants(ctx, oracle, monkeypatch, nlay, method, mu0):
+    """Every instantiation of the shortwave sweep: one or both fits per launch (total-transmission evaluates the fit scaled by
+    min_scaling and by max_scaling on one fetch of the column), the transmittance kept from the way down at the reference's
+    cos_sza = 0.5 or evaluated twice at any other, compile-time or run-time number of layers."""
+    monkeypatch.setattr(sys.modules[__name__], "MU0", mu0)
+    n = 9000
+    o = _sw_problem(oracle, n, nlay=nlay, seed=59, method=method)
+    gas = _make_gas(ctx, o, method, flux_weight=0.02)
+    gas.set_band_albedo(0.15)
+    eq = _oracle_eq(oracle, o, method, 0.02, 0.15)
+    b1 = np.array([0.0, 0.25, 0.6, 0.0])
+    b2 = np.array([0.25, 0.6, 1.0, 1.0])
+    err = gas.calc_error_batch(0, n, b1, b2)
+    ref = np.array([eq.calc_error(x, y) for x, y in zip(b1, b2)])
+    ok = np.isfinite(ref)
+    assert ok.sum() >= 3 and np.allclose(err[ok], ref[ok], rtol=ERR_RTOL, atol=1e-10)
     gas.close()
 
 

@@ -3,7 +3,7 @@ after the other as find_g_points does, against the single-band (FSCK) search of 
 import sys, time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from ecckd_amd import api, synthetic as syn
 
 nwav, nlay = int(sys.argv[1]) if len(sys.argv) > 1 else 7200000, 54
