@@ -1348,13 +1348,20 @@ k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
     partial[((size_t)f * gridDim.x + chunk) * 2 * NHL + tt] = ((s_out[f][0][sl] + s_out[f][1][sl]) + s_out[f][2][sl]) + s_out[f][3][sl];
   }
 }
+struct SwTruthRows { int rH[2], rFDS[2], rFUT[2]; };
+
 // K5d-SW: calc_cost_function_sw (calc_cost_function_sw.cpp:86-109): heating rate from the
 // direct beam only (:92), truth rows selected by (rH, rFDS, rFUT).
 __global__ void __launch_bounds__(1024)
-k_cost_sw(int nlay, int ntotal, int rH, int rFDS, int rFUT, const Interval* __restrict__ iv,
-          long long nchunks_total, const double* __restrict__ partial, const double* __restrict__ sums,
-          const double* __restrict__ conv, const double* __restrict__ layer_weight, double flux_weight,
-          double cos_sza, double* __restrict__ err) {
+k_cost_sw(int nlay, int ntotal, SwTruthRows rows, const Interval* __restrict__ iv,
+          long long nchunks_total, const double* __restrict__ partial_all, size_t partial_pass_stride,
+          const double* __restrict__ sums, const double* __restrict__ conv, const double* __restrict__ layer_weight,
+          double flux_weight, double cos_sza, double* __restrict__ err_all) {
+  // blockIdx.y: which of the (one or two) evaluations of the interval - its truth rows, its sweep's partial sums, its error slot
+  const int pass = blockIdx.y;
+  const int rH = rows.rH[pass], rFDS = rows.rFDS[pass], rFUT = rows.rFUT[pass];
+  const double* __restrict__ partial = partial_all + (size_t)pass * partial_pass_stride;
+  double* __restrict__ err = err_all + (size_t)pass * gridDim.x;
   extern __shared__ double s_mem[];
   const int nhl = nlay + 1;
   const int nv = 2 * nhl;
@@ -2029,7 +2036,7 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   double* d_sums = (double*)w; w += sums_bytes;
   double* d_fit = (double*)w; w += fit_bytes;
   double* d_part = (double*)w; w += part_bytes;
-  double* d_err = (double*)w;
+  (void)err_bytes;   // the errors are written into the pinned host buffer
   Interval* h_iv = (Interval*)g->pinned;
   double* h_err = (double*)((char*)g->pinned + iv_bytes);
   // the errors are written straight into the pinned host buffer by the last kernel (a few bytes over PCIe): no
@@ -2062,36 +2069,29 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
     const size_t part_stride = (size_t)nchunks * 2 * nhl;
     static const bool no_same = std::getenv("ECCKD_SW_NO_SAME") != nullptr;   // A/B knob
     const bool same_exp = g->cos_sza == 0.5 && !no_same;
-    for (int pass = 0; pass < npass; ++pass) {
-      const bool sweep = pass == 0 || !dual;
-      double* part = d_part + ((dual && pass == 1) ? part_stride : 0);
-      if (sweep) {
+    for (int pass = 0; pass < (dual ? 1 : npass); ++pass) {
+      double* part = d_part + (size_t)pass * part_stride;
 #define ECCKD_SW_SWEEP(NL, NF, SM, FIT)                                                                                         \
   hipLaunchKernelGGL((k_rt_sw_bb_fast<NL, NF, SM>), dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, chunk_pts, n, \
-                     d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, FIT, d_part)
-        const double* fit1 = d_fit + (size_t)pass * n * nlay;
-        if (nlay == 54 && dual) { if (same_exp) ECCKD_SW_SWEEP(54, 2, true, d_fit); else ECCKD_SW_SWEEP(54, 2, false, d_fit); }
-        else if (nlay == 30 && dual) { if (same_exp) ECCKD_SW_SWEEP(30, 2, true, d_fit); else ECCKD_SW_SWEEP(30, 2, false, d_fit); }
-        else if (nlay == 54) { if (same_exp) ECCKD_SW_SWEEP(54, 1, true, fit1); else ECCKD_SW_SWEEP(54, 1, false, fit1); }
-        else if (nlay == 30) { if (same_exp) ECCKD_SW_SWEEP(30, 1, true, fit1); else ECCKD_SW_SWEEP(30, 1, false, fit1); }
+                     d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, FIT, part)
+      const double* fit1 = d_fit + (size_t)pass * n * nlay;
+      if (nlay == 54 && dual) { if (same_exp) ECCKD_SW_SWEEP(54, 2, true, d_fit); else ECCKD_SW_SWEEP(54, 2, false, d_fit); }
+      else if (nlay == 30 && dual) { if (same_exp) ECCKD_SW_SWEEP(30, 2, true, d_fit); else ECCKD_SW_SWEEP(30, 2, false, d_fit); }
+      else if (nlay == 54) { if (same_exp) ECCKD_SW_SWEEP(54, 1, true, fit1); else ECCKD_SW_SWEEP(54, 1, false, fit1); }
+      else if (nlay == 30) { if (same_exp) ECCKD_SW_SWEEP(30, 1, true, fit1); else ECCKD_SW_SWEEP(30, 1, false, fit1); }
 #undef ECCKD_SW_SWEEP
-        else
-          hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
-                             chunk_pts, n, d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od,
-                             d_fit + (size_t)pass * n * nlay, d_part);
-      }
-      int rH = R.H, rFDS = R.FDS, rFUT = R.FUT;
-      if (is_tt) {
-        rH = pass == 0 ? R.HL : R.HH;
-        rFDS = pass == 0 ? R.FDSL : R.FDSH;
-        rFUT = pass == 0 ? R.FUTL : R.FUTH;
-      }
-      hipLaunchKernelGGL(k_cost_sw, dim3(n), dim3(1024), cost_lds_sw, ctx->stream, nlay, R.total, rH, rFDS, rFUT,
-                         d_iv, nchunks, part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight,
-                         g->cos_sza, d_err + (size_t)pass * n);
+      else
+        hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
+                           chunk_pts, n, d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, fit1, part);
     }
+    // both evaluations in one launch; the errors go straight into the pinned host buffer (a few bytes over PCIe)
+    SwTruthRows rows;
+    rows.rH[0] = is_tt ? R.HL : R.H;      rows.rH[1] = R.HH;
+    rows.rFDS[0] = is_tt ? R.FDSL : R.FDS; rows.rFDS[1] = R.FDSH;
+    rows.rFUT[0] = is_tt ? R.FUTL : R.FUT; rows.rFUT[1] = R.FUTH;
+    hipLaunchKernelGGL(k_cost_sw, dim3(n, npass), dim3(1024), cost_lds_sw, ctx->stream, nlay, R.total, rows, d_iv, nchunks,
+                       d_part, part_stride, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, g->cos_sza, h_err_dev);
     ECCKD_HIP_CHECK(hipGetLastError());
-    ECCKD_HIP_CHECK(hipMemcpyAsync(h_err, d_err, (size_t)npass * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < n; ++k) error[k] = is_tt ? 0.5 * (h_err[k] + h_err[n + k]) : h_err[k];  // :386
     return ECCKD_OK;
