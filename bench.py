@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lut-opt", action="store_true")
+    ap.add_argument("--no-sw", action="store_true")
     ap.add_argument("--lut-opt-iterations", type=int, default=40)
     # opt-in: the profile-sharded optimiser over ALL ranks (each rank trains on its own 8 x 50 profiles, one RCCL
     # all-reduce of [gradient, cost] per evaluation).  Off by default so that the driver's scaling runs time the
@@ -97,6 +98,43 @@ def cpu_baseline(nwav_s, nlay, seed, tol, tol_tol, max_it):
         raise RuntimeError("oracle/_ref not built")
     dt = time.perf_counter() - t0
     return nwav_s * (1.0 + eq.total_comp_cost), dt, len(e), eq.total_comp_cost, search
+
+
+def sw_find_g_bench(ctx, nwav=3_300_000, nlay=54):
+    """The shortwave twin of the step, reported beside the headline (N = 1 only): reorder key + sort + gas preparation +
+    search of ONE band of BASELINE configs[2]'s shape (nwav = 3.3e6 over 250-50000 cm-1, total-transmission as
+    test/find_g_points_sw.sh, scalings as the tool clamps them (find_g_points.cpp:666-667), reference albedo 0.15,
+    cos_sza 0.5).  Throughput = wavenumber-points x (1 + passes of the search) / time, as for the longwave metric."""
+    import torch
+    from ecckd_amd import api, synthetic as syn
+    dev = ctx.device
+    p = syn.pressure_grid(nlay)
+    wn_h, dwn_h = syn.wavenumber_grid(nwav, 250.0, 50000.0)
+    kw = dict(device=dev, lo=250.0, hi=50000.0)
+    od = syn.optical_depth(torch, p, wn_h, syn.SEED_BASE + 3, nlines=96, column_scale=5.0, **kw)
+    bg = syn.optical_depth(torch, p, wn_h, syn.SEED_BASE + 1003, nlines=24, column_scale=0.5, zero_fraction=0.0, **kw)
+    ssi = torch.as_tensor(syn.solar_spectral_irradiance(wn_h, dwn_h), device=dev)
+    alb = torch.full((nwav,), 0.15, dtype=torch.float64, device=dev)
+    key = torch.empty(nwav, dtype=torch.float64, device=dev)
+    col = torch.empty(nwav, dtype=torch.float64, device=dev)
+    rnk = torch.empty(nwav, dtype=torch.int32, device=dev)
+    out = None
+    for it in range(2):                                     # first pass warms the allocator
+        ctx.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        api.reorder_key_sw(ctx, p, od, 0.25, key=key, col_od=col)
+        api.stable_argsort_bands(ctx, key, [0], [nwav - 1], rank=rnk, want_ordered=False, sync=False)
+        gas = api.GasSW(ctx, p, ssi, rnk, od, bg, "total-transmission", flux_weight=0.02, albedo=alb)
+        gas.set_band_albedo(0.15)
+        st, b, e, cc = gas.find_g_band(0, nwav - 1, 0.02, 0.02, 60)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        gas.close()
+        out = {"value": nwav * (1.0 + cc) / dt, "unit": "wavenumber-points/s", "ms": dt * 1e3, "nwav": nwav, "nlay": nlay,
+               "ng": len(e), "n_pass": cc, "search_status": int(st),
+               "workload": "SW, one band 250-50000 cm-1 of configs[2]'s shape, total-transmission, albedo 0.15"}
+    del od, bg
+    return out
 
 
 def lut_opt_bench(ctx, iterations, sharded=False, rank=0, world=1):
@@ -292,6 +330,8 @@ def main():
             out["lut_opt"] = lut_sharded
         elif world == 1 and not args.no_lut_opt:
             out["lut_opt"] = lut_opt_bench(ctx, args.lut_opt_iterations)
+        if world == 1 and not args.no_sw:
+            out["sw_find_g"] = sw_find_g_bench(ctx)
         if world == 1 and not args.no_cpu:
             pts, cdt, cng, ccost, search = cpu_baseline(args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance,
                                                         args.tolerance_tolerance, args.max_iterations)

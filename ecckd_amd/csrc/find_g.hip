@@ -2015,9 +2015,21 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   static const int sw2_bpc = std::getenv("ECCKD_SW2_BPC") ? std::max(1, std::atoi(std::getenv("ECCKD_SW2_BPC"))) : 2;   // tuning knob
   const bool sw_two_fits = g->do_sw && g->method == ECCKD_AVG_TOTAL_TRANSMISSION && fast_path;
   long long target_blocks = (long long)ctx->num_cu * (sw_two_fits ? sw2_bpc : fast_path ? rt_bpc : 8);
+  // chunks are multiples of what one block iteration covers (the longwave mirror kernel: two wave pairs = 128 points).
+  // The smallest such chunk that still fits every interval's chunks into the resident blocks: one round, no straggler
+  // blocks from the intervals' partial last chunks.
+  static const bool chunk_old = std::getenv("ECCKD_RT_CHUNK_OLD") != nullptr;   // A/B knob
+  const long long gran = (!g->do_sw && fast_path && !chunk_old) ? RT_THREADS / 2 : RT_THREADS;
   long long chunk_pts = (total_pts + target_blocks - 1) / target_blocks;
-  chunk_pts = (chunk_pts + RT_THREADS - 1) / RT_THREADS * RT_THREADS;
-  if (chunk_pts < RT_THREADS) chunk_pts = RT_THREADS;
+  chunk_pts = (chunk_pts + gran - 1) / gran * gran;
+  if (chunk_pts < gran) chunk_pts = gran;
+  auto count_chunks = [&](long long c) {
+    long long m = 0;
+    for (int k = 0; k < n; ++k) m += (iv[k].i2 - iv[k].i1 + 1 + c - 1) / c;
+    return m;
+  };
+  if (!chunk_old && n < target_blocks)
+    while (count_chunks(chunk_pts) > target_blocks) chunk_pts += gran;
   long long nchunks = 0;
   for (int k = 0; k < n; ++k) {
     iv[k].chunk0 = nchunks;
