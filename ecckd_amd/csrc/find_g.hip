@@ -2007,7 +2007,8 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   for (int k = 0; k < n; ++k) g->total_comp_cost += bound2[k] - bound1[k];  // :320
 
   // chunking: aim at ~8 blocks per CU, chunks are multiples of the 256-point sub-tile
-  const bool fast_path = (nlay == 54 || nlay == 30);
+  // ECCKD_RT_GENERIC (read per call): the run-time-nlay sweeps instead of the compile-time ones, for cross-checks at full size
+  const bool fast_path = (nlay == 54 || nlay == 30) && std::getenv("ECCKD_RT_GENERIC") == nullptr;
   // mirror path: 3 resident blocks per CU (3 waves/SIMD) -> one wave of blocks; more chunks shorten K5c a
   // little but lengthen the ordered combine in K5d by more
   static const int rt_bpc = std::getenv("ECCKD_RT_BPC") ? std::max(1, std::atoi(std::getenv("ECCKD_RT_BPC"))) : 3;   // tuning knob
@@ -2077,7 +2078,7 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
     // in the reference: min <= 0.5, max >= 2.5, :666-667): one launch that fetches the column once and sweeps it with both
     // fits (the compile-time-nlay kernels).  At the reference's cos_sza = 0.5 the direct and the reflected beam see the same
     // transmittance exp(-2 tau), bit for bit: the kernels then keep it from the way down (SAME).
-    const bool dual = is_tt && (nlay == 54 || nlay == 30);
+    const bool dual = is_tt && fast_path;
     const size_t part_stride = (size_t)nchunks * 2 * nhl;
     static const bool no_same = std::getenv("ECCKD_SW_NO_SAME") != nullptr;   // A/B knob
     const bool same_exp = g->cos_sza == 0.5 && !no_same;
@@ -2087,14 +2088,14 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   hipLaunchKernelGGL((k_rt_sw_bb_fast<NL, NF, SM>), dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, chunk_pts, n, \
                      d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, FIT, part)
       const double* fit1 = d_fit + (size_t)pass * n * nlay;
-      if (nlay == 54 && dual) { if (same_exp) ECCKD_SW_SWEEP(54, 2, true, d_fit); else ECCKD_SW_SWEEP(54, 2, false, d_fit); }
+      if (!fast_path)
+        hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
+                           chunk_pts, n, d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, fit1, part);
+      else if (nlay == 54 && dual) { if (same_exp) ECCKD_SW_SWEEP(54, 2, true, d_fit); else ECCKD_SW_SWEEP(54, 2, false, d_fit); }
       else if (nlay == 30 && dual) { if (same_exp) ECCKD_SW_SWEEP(30, 2, true, d_fit); else ECCKD_SW_SWEEP(30, 2, false, d_fit); }
       else if (nlay == 54) { if (same_exp) ECCKD_SW_SWEEP(54, 1, true, fit1); else ECCKD_SW_SWEEP(54, 1, false, fit1); }
       else if (nlay == 30) { if (same_exp) ECCKD_SW_SWEEP(30, 1, true, fit1); else ECCKD_SW_SWEEP(30, 1, false, fit1); }
 #undef ECCKD_SW_SWEEP
-      else
-        hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
-                           chunk_pts, n, d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, fit1, part);
     }
     // both evaluations in one launch; the errors go straight into the pinned host buffer (a few bytes over PCIe)
     SwTruthRows rows;
@@ -2110,10 +2111,10 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   }
   const size_t rt_lds = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
-  if (nlay == 54) {
+  if (fast_path && nlay == 54) {
     hipLaunchKernelGGL(k_rt_lw_bb_mirror<54>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
                        chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
-  } else if (nlay == 30) {
+  } else if (fast_path && nlay == 30) {
     hipLaunchKernelGGL(k_rt_lw_bb_mirror<30>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
                        chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
   } else {

@@ -311,3 +311,48 @@ def test_full_size_find_g_against_oracle_slices(ctx, oracle):
     assert np.all(np.isfinite(e)) and np.all(e > 0) and cc > len(e) and e[:-1].max() <= 0.0161 * 1.0101
     assert np.allclose(gas.calc_error_batch(0, nwav, b[:-1], b[1:]), e, rtol=1e-12, atol=0)
     gas.close()
+
+
+@pytest.mark.parametrize("sw", [False, True])
+def test_full_size_compile_time_sweeps_match_run_time_sweeps(ctx, monkeypatch, sw):
+    """Size-independent cross-check at BASELINE sizes (LW nwav = 7.2e6, SW nwav = 3.3e6; nlay = 54): the compile-time-nlay
+    sweeps that the bench times (longwave mirror kernel; shortwave two-fit kernel with the transmittance kept from the way
+    down) against the run-time-nlay kernels (ECCKD_RT_GENERIC), which share no sweep code with them and are pinned against
+    the oracle at small sizes.  Same prepared gas, same intervals: the errors agree to rounding."""
+    from ecckd_amd import api, synthetic as syn
+    nlay = 54
+    dev = ctx.device
+    p = syn.pressure_grid(nlay)
+    if not sw:
+        nwav = 7_200_000
+        wn_h, dwn_h = syn.wavenumber_grid(nwav)
+        wn, dwn = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
+        od = syn.optical_depth(torch, p, wn, syn.SEED_BASE + 1, nlines=32, device=dev, chunk=1 << 20)
+        bg = syn.optical_depth(torch, p, wn, syn.SEED_BASE + 1001, nlines=24, column_scale=3.0, zero_fraction=0.0, device=dev, chunk=1 << 20)
+        key, col = api.reorder_key_lw(ctx, p, api.idealised_temperature(p), wn, dwn, od, 0.5)
+        rank, _ = api.stable_argsort_bands(ctx, key, [0], [nwav - 1], want_ordered=False)
+        gas = api.GasLW(ctx, p, syn.temperature_profile(p), wn, dwn, rank, od, bg, "transmission", flux_weight=0.02)
+    else:
+        nwav = 3_300_000
+        wn_h, dwn_h = syn.wavenumber_grid(nwav, 250.0, 50000.0)
+        kw = dict(device=dev, lo=250.0, hi=50000.0)
+        od = syn.optical_depth(torch, p, wn_h, syn.SEED_BASE + 3, nlines=96, column_scale=5.0, **kw)
+        bg = syn.optical_depth(torch, p, wn_h, syn.SEED_BASE + 1003, nlines=24, column_scale=0.5, zero_fraction=0.0, **kw)
+        ssi = torch.as_tensor(syn.solar_spectral_irradiance(wn_h, dwn_h), device=dev)
+        alb = torch.full((nwav,), 0.15, dtype=torch.float64, device=dev)
+        key, col = api.reorder_key_sw(ctx, p, od, 0.25)
+        rank, _ = api.stable_argsort_bands(ctx, key, [0], [nwav - 1], want_ordered=False)
+        gas = api.GasSW(ctx, p, ssi, rank, od, bg, "total-transmission", flux_weight=0.02, albedo=alb)
+        gas.set_band_albedo(0.15)
+    b1 = np.array([0.0, 0.0, 0.37, 0.62, 0.9, 0.999, 0.5])
+    b2 = np.array([1.0, 0.37, 0.62, 0.9, 0.999, 1.0, 0.5000004])
+    fast = gas.calc_error_batch(0, nwav, b1, b2)
+    monkeypatch.setenv("ECCKD_RT_GENERIC", "1")
+    generic = gas.calc_error_batch(0, nwav, b1, b2)
+    monkeypatch.delenv("ECCKD_RT_GENERIC")
+    again = gas.calc_error_batch(0, nwav, b1, b2)
+    gas.close()
+    assert np.all(np.isfinite(fast)) and np.all(fast > 0.0)
+    assert np.array_equal(fast, again)                        # the knob is read per call
+    assert np.allclose(fast, generic, rtol=1e-9, atol=1e-12)
+    assert not np.array_equal(fast, generic)                  # really two different sweeps (different summation order)
