@@ -177,7 +177,7 @@ SIGNATURES = {
     "ecckd_gather_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_invert_permutation_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ecckd_calc_error_multi": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _c_double_p, _c_double_p,
-                                         _c_double_p]),
+                                         _c_double_p, _c_double_p]),
     "ecckd_find_g_bands_ex": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _c_double_p, C.c_double,
                                         C.c_int, C.c_void_p, C.POINTER(C.c_int), _c_double_p, _c_double_p, _c_int64_p, _c_int64_p,
                                         C.c_int, C.POINTER(C.c_int), _c_double_p]),
@@ -213,7 +213,7 @@ class BandOptions(C.Structure):
                 ("isubband1", _c_int64_p), ("isubband2", _c_int64_p), ("iupperindex", C.c_int64),
                 ("g_split", C.c_double), ("base_split", C.c_double), ("nbase_wn_bound", C.c_int),
                 ("base_wn_bound", _c_double_p), ("d_wavenumber", C.c_void_p), ("d_rank", C.c_void_p),
-                ("nwav", C.c_size_t)]
+                ("nwav", C.c_size_t), ("band_albedo", C.c_double)]
 
 
 

@@ -427,9 +427,10 @@ class GasLW:
                     rank2=r2[:n].copy(), comp_cost=cc.value)
 
     def _band_options(self, keep, min_g_points=1, max_g_points=256, subbands=None, g_split=0.0, base_split=1.0, base_wn_bound=None,
-                      wavenumber=None, rank=None):
+                      wavenumber=None, rank=None, band_albedo=0.0):
         o = _lib.BandOptions()
         o.min_g_points, o.max_g_points = int(min_g_points), int(max_g_points)
+        o.band_albedo = float(band_albedo)            # find_g_bands_ex on a shortwave gas: this band's surface albedo
         if subbands is not None:
             i1 = np.ascontiguousarray(subbands[0], dtype=np.int64)
             i2 = np.ascontiguousarray(subbands[1], dtype=np.int64)
@@ -448,16 +449,19 @@ class GasLW:
                 o.d_wavenumber, o.d_rank, o.nwav = wavenumber.data_ptr(), rank.data_ptr(), rank.numel()
         return o
 
-    def calc_error_multi(self, ibegin, npoints, bound1, bound2):
+    def calc_error_multi(self, ibegin, npoints, bound1, bound2, band_albedo=None):
         """Interval errors of several bands in one batch (ecckd_calc_error_multi): interval k is the fraction
-        [bound1[k], bound2[k]] of the band starting at sorted index ibegin[k] with npoints[k] points."""
+        [bound1[k], bound2[k]] of the band starting at sorted index ibegin[k] with npoints[k] points; shortwave:
+        band_albedo[k] is the surface albedo of its band (None: the gas's band albedo)."""
+        alb = None if band_albedo is None else np.ascontiguousarray(band_albedo, dtype=np.float64)
         ib = np.ascontiguousarray(ibegin, dtype=np.uint64)
         npt = np.ascontiguousarray(npoints, dtype=np.uint64)
         b1 = np.ascontiguousarray(bound1, dtype=np.float64)
         b2 = np.ascontiguousarray(bound2, dtype=np.float64)
         err = np.empty(b1.size)
         check(self.lib.ecckd_calc_error_multi(self.handle, b1.size, ib.ctypes.data_as(C.POINTER(C.c_size_t)),
-                                              npt.ctypes.data_as(C.POINTER(C.c_size_t)), _hptr(b1), _hptr(b2), _hptr(err)))
+                                              npt.ctypes.data_as(C.POINTER(C.c_size_t)), _hptr(alb) if alb is not None else None,
+                                              _hptr(b1), _hptr(b2), _hptr(err)))
         return err
 
     def find_g_bands_ex(self, ibegin, iend, heating_rate_tolerance, tolerance_tolerance=0.02, max_iterations=60, options=None,

@@ -224,8 +224,8 @@ int main(int argc, char** argv) {
       GasResult res;
       res.molecule = gas_str;
       const int capacity = 1024;
-      // Options of every band first: longwave bands are then searched side by side (ecckd_find_g_bands_ex), shortwave bands
-      // one after the other because the gas carries one band albedo at a time.
+      // Options of every band first: the bands are then searched side by side (ecckd_find_g_bands_ex); a shortwave band brings
+      // its albedo (init_sw(..., band_albedo(jband), ...), :1177) with it.
       std::vector<ecckd_band_options> opts(nband);
       std::vector<std::vector<double>> wn_bounds(nband);
       for (int b = 0; b < nband; ++b) {
@@ -242,6 +242,7 @@ int main(int argc, char** argv) {
           opt.g_split = g_split[b];
         }
         opt.base_split = base_split[b];
+        opt.band_albedo = do_sw ? band_albedo[b] : 0.0;
         std::vector<double>& wn_bound = wn_bounds[b];
         std::vector<double> interior;
         for (double w : base_wavenumber_boundary) if (w > band_bound1[b] && w < band_bound2[b]) interior.push_back(w);
@@ -262,7 +263,7 @@ int main(int argc, char** argv) {
       std::vector<int64_t> r1((size_t)nband * capacity), r2((size_t)nband * capacity);
       bool sequential_bands = false;                 // extension key: the reference's one-band-at-a-time order of evaluation
       config.read(sequential_bands, "sequential_bands");
-      const bool side_by_side = !do_sw && nband > 1 && !sequential_bands;
+      const bool side_by_side = nband > 1 && !sequential_bands;
       if (side_by_side) {
         std::vector<size_t> ib(ibegin.begin(), ibegin.end()), ie(iend.begin(), iend.end());
         ck(ecckd_find_g_bands_ex(gas, nband, ib.data(), ie.data(), tolerance.data(), tolerance_tolerance, max_iterations, opts.data(),

@@ -448,6 +448,7 @@ struct Interval {
   long long i1, i2;      // inclusive global sorted indices
   long long chunk0;      // first RT chunk of this interval
   long long npoints;     // band length (for the logarithmic fit)
+  double albedo;         // shortwave: surface albedo of the interval's band
 };
 
 // this thread's share of sum_{i=i1..i2} row[i]: ragged head + whole tiles (from the tile sums) + ragged tail
@@ -1145,7 +1146,7 @@ k_fit_sw(int nlay, int method, RowMap R, int nint, double min_scaling, double ma
 // reference does, :128).  Same chunking and reduction order as the LW kernel.
 __global__ void __launch_bounds__(RT_THREADS)
 k_rt_sw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv,
-           double cos_sza, double albedo, const double* __restrict__ ssi, const double* __restrict__ bg_od,
+           double cos_sza, const double* __restrict__ ssi, const double* __restrict__ bg_od,
            const double* __restrict__ od_fit, double* __restrict__ partial) {
   extern __shared__ double s_mem[];  // [4][2*nhl] | [nlay]
   const int nhl = nlay + 1;
@@ -1159,6 +1160,7 @@ k_rt_sw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __
     if (iv[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
   }
   const int k = lo;
+  const double albedo = iv[k].albedo;
   const long long c = chunk - iv[k].chunk0;
   const long long p0 = iv[k].i1 + c * chunk_pts;
   long long p1 = p0 + chunk_pts - 1;
@@ -1217,7 +1219,7 @@ k_rt_sw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __
 // (radiative_transfer_sw.cpp:134-139 and :176-183): the last fit overwrites the column with it instead of evaluating it twice.
 template <int NLAY, int NFIT, bool SAME, int OCC = (NFIT == 1 ? 3 : 2)>
 __global__ void __launch_bounds__(RT_THREADS, OCC)
-k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv, double cos_sza, double albedo,
+k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv, double cos_sza,
                 const double* __restrict__ ssi, const double* __restrict__ bg_od, const double* __restrict__ od_fit,
                 double* __restrict__ partial) {
   constexpr int NHL = NLAY + 1;
@@ -1258,6 +1260,7 @@ k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
   // because exp_fast_s(-inf) would be inf - inf.
   const ecckd::ExpConsts ek = ecckd::exp_consts();
   auto trans = [&](double x) { return ecckd::exp_fast_s(fmax(x, -800.0), ek); };
+  const double albedo = iv[k].albedo;
   const bool reflect = albedo > 0.0;                 // :366-373: no upwelling without a reflecting surface
   for (long long base = p0; base <= p1; base += RT_THREADS) {
     const long long i = base + tid;
@@ -1935,6 +1938,7 @@ int ecckd_fit_optical_depth(ecckd_gas* g, size_t ibegin, size_t npoints, int n, 
     iv[k].i2 = (long long)ibegin + i2;
     iv[k].chunk0 = k;
     iv[k].npoints = (long long)npoints;
+    iv[k].albedo = 0.0;
   }
   const size_t iv_bytes = ecckd_align_up((size_t)n * sizeof(Interval), 256);
   const size_t sums_bytes = ecckd_align_up((size_t)n * g->nrows * sizeof(double), 256);
@@ -1968,14 +1972,14 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   ECCKD_REQUIRE(g && (n == 0 || (bound1 && bound2 && error)), "ecckd_calc_error_batch: NULL argument");
   if (n <= 0) return ECCKD_OK;
   const std::vector<size_t> ib((size_t)n, ibegin), np((size_t)n, npoints);
-  return ecckd_calc_error_multi(g, n, ib.data(), np.data(), bound1, bound2, error);
+  return ecckd_calc_error_multi(g, n, ib.data(), np.data(), nullptr, bound1, bound2, error);
 }
 
 // The same for intervals of DIFFERENT bands in one batch: interval k is the fraction [bound1[k], bound2[k]] of the band
 // that starts at sorted index ibegin[k] and has npoints[k] points.  One launch train for all of them - the band searches
 // of a gas are independent (find_g_points.cpp:1152), so their error evaluations can share the GPU (ecckd_find_g_bands_ex).
-int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const size_t* npoints_k, const double* bound1,
-                           const double* bound2, double* error) {
+int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const size_t* npoints_k, const double* albedo_k,
+                           const double* bound1, const double* bound2, double* error) {
   ECCKD_REQUIRE(g && (n == 0 || (ibegin_k && npoints_k && bound1 && bound2 && error)), "ecckd_calc_error_multi: NULL argument");
   if (n <= 0) return ECCKD_OK;
   ecckd_ctx* ctx = g->ctx;
@@ -2002,6 +2006,7 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
     iv[k].i1 = (long long)ibegin + i1;
     iv[k].i2 = (long long)ibegin + i2;
     iv[k].npoints = (long long)npoints;
+    iv[k].albedo = albedo_k ? albedo_k[k] : g->surf_albedo;
     total_pts += i2 - i1 + 1;
   }
   for (int k = 0; k < n; ++k) g->total_comp_cost += bound2[k] - bound1[k];  // :320
@@ -2086,11 +2091,11 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
       double* part = d_part + (size_t)pass * part_stride;
 #define ECCKD_SW_SWEEP(NL, NF, SM, FIT)                                                                                         \
   hipLaunchKernelGGL((k_rt_sw_bb_fast<NL, NF, SM>), dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, chunk_pts, n, \
-                     d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, FIT, part)
+                     d_iv, g->cos_sza, g->ssi, g->bg_od, FIT, part)
       const double* fit1 = d_fit + (size_t)pass * n * nlay;
       if (!fast_path)
         hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
-                           chunk_pts, n, d_iv, g->cos_sza, g->surf_albedo, g->ssi, g->bg_od, fit1, part);
+                           chunk_pts, n, d_iv, g->cos_sza, g->ssi, g->bg_od, fit1, part);
       else if (nlay == 54 && dual) { if (same_exp) ECCKD_SW_SWEEP(54, 2, true, d_fit); else ECCKD_SW_SWEEP(54, 2, false, d_fit); }
       else if (nlay == 30 && dual) { if (same_exp) ECCKD_SW_SWEEP(30, 2, true, d_fit); else ECCKD_SW_SWEEP(30, 2, false, d_fit); }
       else if (nlay == 54) { if (same_exp) ECCKD_SW_SWEEP(54, 1, true, fit1); else ECCKD_SW_SWEEP(54, 1, false, fit1); }

@@ -276,8 +276,8 @@ class BandBatcher {
  public:
   BandBatcher(ecckd_gas* gas, int nsearch) : gas_(gas), active_(nsearch) {}
 
-  int evaluate(size_t ibegin, size_t npoints, int n, const double* b1, const double* b2, double* e) {
-    Request r{ibegin, npoints, n, b1, b2, e, {false}, ECCKD_OK, std::string()};
+  int evaluate(size_t ibegin, size_t npoints, double albedo, int n, const double* b1, const double* b2, double* e) {
+    Request r{ibegin, npoints, albedo, n, b1, b2, e, {false}, ECCKD_OK, std::string()};
     {
       std::unique_lock<std::mutex> lk(m_);
       pending_.push_back(&r);
@@ -299,6 +299,7 @@ class BandBatcher {
  private:
   struct Request {
     size_t ibegin, npoints;
+    double albedo;      // shortwave: the band's surface albedo
     int n;
     const double *b1, *b2;
     double* e;
@@ -312,11 +313,13 @@ class BandBatcher {
     // and hence the errors are the same from run to run
     std::sort(pending_.begin(), pending_.end(), [](const Request* a, const Request* b) { return a->ibegin < b->ibegin; });
     std::vector<size_t> ib, np;
-    std::vector<double> b1, b2;
+    std::vector<double> b1, b2, alb;
     for (const Request* r : pending_)
-      for (int k = 0; k < r->n; ++k) { ib.push_back(r->ibegin); np.push_back(r->npoints); b1.push_back(r->b1[k]); b2.push_back(r->b2[k]); }
+      for (int k = 0; k < r->n; ++k) {
+        ib.push_back(r->ibegin); np.push_back(r->npoints); alb.push_back(r->albedo); b1.push_back(r->b1[k]); b2.push_back(r->b2[k]);
+      }
     std::vector<double> err(b1.size());
-    const int rc = ecckd_calc_error_multi(gas_, (int)b1.size(), ib.data(), np.data(), b1.data(), b2.data(), err.data());
+    const int rc = ecckd_calc_error_multi(gas_, (int)b1.size(), ib.data(), np.data(), alb.data(), b1.data(), b2.data(), err.data());
     const std::string message = rc == ECCKD_OK ? std::string() : std::string(ecckd_last_error());
     size_t off = 0;
     for (Request* r : pending_) {
@@ -356,7 +359,7 @@ int ecckd_find_g_band_ex(ecckd_gas* g, size_t ibegin, size_t iend, double heatin
   ecckd::PartitionSearch ps([&](int n, const double* b1, const double* b2, double* e) {
     if (batcher) {
       for (int k = 0; k < n; ++k) local_cost += b2[k] - b1[k];
-      rc_eval = batcher->evaluate(ibegin, npoints, n, b1, b2, e);
+      rc_eval = batcher->evaluate(ibegin, npoints, opt->band_albedo, n, b1, b2, e);
     } else {
       rc_eval = ecckd_calc_error_batch(g, ibegin, npoints, n, b1, b2, e);
     }
@@ -513,8 +516,7 @@ int ecckd_find_g_bands_ex(ecckd_gas* g, int nband, const size_t* ibegin, const s
                           double* error, int64_t* rank1, int64_t* rank2, int capacity, int* status, double* comp_cost) {
   ECCKD_REQUIRE(g && nband > 0 && ibegin && iend && heating_rate_tolerance && opt && ng && bounds && error && status && capacity > 0,
                 "ecckd_find_g_bands_ex: bad argument");
-  ECCKD_REQUIRE(!g->do_sw, "ecckd_find_g_bands_ex: longwave gases only (a shortwave gas holds one band albedo at a time)");
-  if (nband == 1)
+  if (nband == 1 && !g->do_sw)
     return ecckd_find_g_band_ex(g, ibegin[0], iend[0], heating_rate_tolerance[0], tolerance_tolerance, max_iterations, &opt[0], ng,
                                 bounds, error, rank1, rank2, capacity, status, comp_cost);
   BandBatcher batcher(g, nband);

@@ -351,10 +351,12 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
         max_gp = np.broadcast_to(np.asarray(spec.get("max_g_points", 256)), (nband,))
         band_idx = [np.nonzero(iband == b)[0] for b in range(nband)]
         band_opts = [dict(min_g_points=int(min_gp[b]), max_g_points=int(max_gp[b])) for b in range(nband)]
-        if band_albedo is None and nband > 1 and not sequential_bands:
-            # longwave bands side by side, sharing their error batches (ecckd_find_g_bands_ex): same decisions per band
+        if nband > 1 and not sequential_bands:
+            # bands side by side, sharing their error batches (ecckd_find_g_bands_ex): same decisions per band; a shortwave
+            # band brings its albedo (init_sw(..., band_albedo(jband), ...)) with it
+            side_opts = [dict(o, band_albedo=float(band_albedo[b])) if band_albedo is not None else o for b, o in enumerate(band_opts)]
             band_res = gas.find_g_bands_ex([int(i[0]) for i in band_idx], [int(i[-1]) for i in band_idx], tol, tolerance_tolerance,
-                                           max_iterations, band_opts)
+                                           max_iterations, side_opts)
         else:
             band_res = []
             for b in range(nband):

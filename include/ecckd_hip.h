@@ -190,9 +190,11 @@ double ecckd_gas_comp_cost(ecckd_gas* gas, int reset);
 int ecckd_calc_error_batch(ecckd_gas* gas, size_t ibegin, size_t npoints, int n,
                            const double* h_bound1, const double* h_bound2, double* h_error);
 /* The same with a band per interval: interval k is the fraction [h_bound1[k], h_bound2[k]] of the band that starts at
- * sorted index h_ibegin[k] and has h_npoints[k] points.  One launch train for intervals of several bands. */
+ * sorted index h_ibegin[k] and has h_npoints[k] points.  One launch train for intervals of several bands.
+ * h_band_albedo[k] (shortwave; NULL = the gas's band albedo for all): the surface albedo of interval k's band. */
 int ecckd_calc_error_multi(ecckd_gas* gas, int n, const size_t* h_ibegin, const size_t* h_npoints,
-                           const double* h_bound1, const double* h_bound2, double* h_error);
+                           const double* h_band_albedo, const double* h_bound1, const double* h_bound2,
+                           double* h_error);
 
 /* The fitted grey optical depth alone: replaces fit_optical_depth_lw / fit_optical_depth_sw /
  * fit_optical_depth_sw_total_trans (find_g_points.cpp:54-106, :112-165, :171-204) for n
@@ -284,6 +286,8 @@ typedef struct {
   const double* d_wavenumber;     /* [nwav] original order; needed if nwavsplit > 1 */
   int32_t* d_rank;                /* [nwav] original order, re-ranked in place if nwavsplit > 1 */
   size_t nwav;
+  double band_albedo;             /* ecckd_find_g_bands_ex on a shortwave gas: this band's surface albedo (init_sw's band_albedo(jband),
+                                   * find_g_points.cpp:1177); the one-band call uses ecckd_gas_set_band_albedo instead */
 } ecckd_band_options;
 int ecckd_find_g_band_ex(ecckd_gas* gas, size_t ibegin, size_t iend, double heating_rate_tolerance,
                          double tolerance_tolerance, int max_iterations,
@@ -296,10 +300,11 @@ int ecckd_find_g_band_ex(ecckd_gas* gas, size_t ibegin, size_t iend, double heat
  * and the error evaluations the searches ask for at the same time are merged into ONE batch (ecckd_calc_error_multi),
  * so that narrow bands, too small to fill the GPU on their own, share it: the 13 longwave bands of the ecRad structure
  * go from 3.0e9 to 3.65e9 wavenumber-points/s (one band of the same size on its own: 5.4e9; the tail of the searches,
- * when only the widest bands are still refining, stays latency-bound).  Longwave gases only (a shortwave gas carries one band
- * albedo at a time, ecckd_gas_set_band_albedo); results per band as ecckd_find_g_band_ex, arrays [nband] or
- * [nband][capacity(+1)].  Interval errors can differ from the one-band-at-a-time values by rounding (the chunking of the
- * sums follows the batch), never the logic. */
+ * when only the widest bands are still refining, stays latency-bound).  Shortwave gases too: every band brings its surface
+ * albedo in opt[b].band_albedo and the sweep takes it per interval (the gas's own band albedo, ecckd_gas_set_band_albedo,
+ * is neither used nor changed).  Results per band as ecckd_find_g_band_ex, arrays [nband] or [nband][capacity(+1)].
+ * Interval errors can differ from the one-band-at-a-time values by rounding (the chunking of the sums follows the batch),
+ * never the logic. */
 int ecckd_find_g_bands_ex(ecckd_gas* gas, int nband, const size_t* ibegin, const size_t* iend,
                           const double* heating_rate_tolerance, double tolerance_tolerance, int max_iterations,
                           const ecckd_band_options* opt /* [nband] */, int* ng, double* bounds, double* error,

@@ -57,3 +57,33 @@ def test_product_does_not_import_oracle():
             # no import, include, link or dlopen of anything under oracle/ (comments may cite it)
             for needle in ("pyoracle", "ecckd_oracle.h", "libecckd_oracle", "libequipartition_ref", "orc_"):
                 assert needle not in src, (f, needle)
+
+
+def test_struct_mirrors_match_the_header():
+    """Every ctypes mirror of a struct of include/ecckd_hip.h against the C compiler's layout: size and the offset of
+    every field (a field added to the header only, or in another order, shows up here and not as a wrong answer on the GPU)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    import tempfile
+    from ecckd_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mirrors = {"ecckd_band_options": _lib.BandOptions, "ecckd_opt_gas": _lib.OptGas, "ecckd_opt_model": _lib.OptModel,
+               "ecckd_opt_scene": _lib.OptScene, "ecckd_opt_config": _lib.OptConfig}
+    lines = []
+    for cname, cls in mirrors.items():
+        lines.append(f' printf("%zu", sizeof({cname}));\n')
+        lines += [f' printf(" %zu", offsetof({cname}, {name}));\n' for name, _ in cls._fields_]
+        lines.append(' printf("\\n");\n')
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "ecckd_hip.h"\nint main(void) {\n' + "".join(lines) + " return 0; }\n"
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "layout.c"), "w") as f:
+            f.write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), os.path.join(d, "layout.c"), "-o", os.path.join(d, "layout")])
+        rows = subprocess.check_output([os.path.join(d, "layout")]).decode().strip().split("\n")
+    for (cname, cls), row in zip(mirrors.items(), rows):
+        out = [int(x) for x in row.split()]
+        assert out[0] == C.sizeof(cls), cname
+        assert out[1:] == [getattr(cls, name).offset for name, _ in cls._fields_], cname

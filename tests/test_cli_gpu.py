@@ -176,6 +176,16 @@ def test_find_g_points_sw(ctx, tmp_path):
     assert np.allclose(v["solar_irradiance"][:], solar, rtol=1e-6)
     assert b"shortwave" in f.title
     f.close()
+    # the band loop one band after the other (the reference's order) finds the same g points
+    r = run_tool("find_g_points", "averaging_method=total-transmission", "sw.cfg", "output=gpoints_sw_seq.nc", "sequential_bands=1", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    fa, fs = _nc(d / "gpoints_sw.nc"), _nc(d / "gpoints_sw_seq.nc")
+    assert np.array_equal(fa.variables["g_point"][:], fs.variables["g_point"][:])
+    for g in ("h2o", "o3"):
+        for k in ("_rank1", "_rank2", "_n_g_points"):
+            assert np.array_equal(fa.variables[g + k][:], fs.variables[g + k][:]), (g, k)
+        assert np.allclose(fa.variables[g + "_error"][:], fs.variables[g + "_error"][:], rtol=1e-6)
+    fa.close(); fs.close()
 
 
 def test_exit_codes(tmp_path):

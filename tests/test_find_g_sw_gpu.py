@@ -205,3 +205,41 @@ def test_fit_optical_depth_sw_matches_oracle(ctx, oracle, method):
         # logs of order 1, so its absolute accuracy is that of the interval sums (~1e-14)
         assert np.allclose(fit[k][m], ref[m], rtol=1e-7, atol=1e-13)
     gas.close()
+
+
+def test_shortwave_bands_side_by_side_match_one_band_at_a_time(ctx, oracle):
+    """ecckd_find_g_bands_ex on a shortwave gas: four bands with their own surface albedos (0.15 below 10 000 cm-1, 0 above, as
+    find_g_points.cpp:757-761) searched side by side, the albedo travelling with every interval, against the band loop
+    (ecckd_gas_set_band_albedo + ecckd_find_g_band_ex per band): same g points, errors equal to rounding; the gas's own band
+    albedo is left alone."""
+    n = 32000
+    o = _sw_problem(oracle, n, nlay=30, seed=61, method="total-transmission")
+    gas = _make_gas(ctx, o, "total-transmission", flux_weight=0.02)
+    begin = np.array([0, 6000, 15000, 26000])
+    end = np.array([5999, 14999, 25999, n - 1])
+    albedo = [0.15, 0.0, 0.15, 0.0]
+    tol = [0.05, 0.03, 0.08, 0.05]
+    one_by_one = []
+    for k in range(4):
+        gas.set_band_albedo(albedo[k])
+        one_by_one.append(gas.find_g_band_ex(int(begin[k]), int(end[k]), tol[k], 0.02, 30, min_g_points=2))
+    gas.set_band_albedo(0.07)
+    options = [dict(min_g_points=2, band_albedo=albedo[k]) for k in range(4)]
+    together = gas.find_g_bands_ex(begin, end, tol, 0.02, 30, options=options)
+    assert sum(len(r["error"]) for r in one_by_one) >= 10
+    for k, (a, b) in enumerate(zip(one_by_one, together)):
+        assert a["status"] == b["status"] and np.array_equal(a["rank1"], b["rank1"]) and np.array_equal(a["rank2"], b["rank2"]), k
+        assert np.allclose(a["error"], b["error"], rtol=1e-9, atol=1e-12), k
+    # the albedo matters (else this test would not notice a mix-up) and the merged batch takes it per interval
+    ib, npt = np.repeat(begin[[0, 2]], 2), np.repeat((end - begin + 1)[[0, 2]], 2)
+    lo, hi = np.tile([0.0, 0.5], 2), np.tile([0.5, 1.0], 2)
+    merged = gas.calc_error_multi(ib, npt, lo, hi, band_albedo=[0.15, 0.15, 0.0, 0.0])
+    single = []
+    for k, a in ((0, 0.15), (2, 0.0)):
+        gas.set_band_albedo(a)
+        single.append(gas.calc_error_batch(int(begin[k]), int(end[k] - begin[k] + 1), [0.0, 0.5], [0.5, 1.0]))
+    assert np.allclose(merged, np.concatenate(single), rtol=1e-9, atol=1e-12)
+    gas.set_band_albedo(0.15)
+    with_albedo = gas.calc_error_batch(int(begin[2]), int(end[2] - begin[2] + 1), [0.0, 0.5], [0.5, 1.0])
+    assert not np.allclose(with_albedo, single[1], rtol=1e-6)
+    gas.close()
