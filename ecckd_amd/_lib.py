@@ -110,6 +110,7 @@ SIGNATURES = {
     "ecckd_opt_initial_state": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
     "ecckd_opt_cost_grad": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
     "ecckd_opt_forward": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
+    "ecckd_opt_forward_ex": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, _c_double_p, _c_double_p]),
     "ecckd_opt_coefficients": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, _c_double_p]),
     "ecckd_opt_minimize": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, _c_double_p, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), _c_double_p, _c_double_p]),

@@ -743,11 +743,13 @@ class Optimizer:
         check(self.lib.ecckd_opt_cost_grad(self.handle, _hptr(x), C.byref(J), _hptr(g) if want_grad else None))
         return (J.value, g) if want_grad else J.value
 
-    def forward(self, x):
+    def forward(self, x, unclamped=False):
+        """Total optical depths and CKD fluxes at state x; unclamped: without the clamp of negative optical depths (the
+        reference's "relative_to" evaluation, optimize_lut.cpp:229-234)."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         od = np.empty((self.ncol, self.nlay, self.ng))
         fl = np.empty((self.ncol, 2, self.nlay + 1, self.ng))
-        check(self.lib.ecckd_opt_forward(self.handle, _hptr(x), _hptr(od), _hptr(fl)))
+        check(self.lib.ecckd_opt_forward_ex(self.handle, _hptr(x), 1 if unclamped else 0, _hptr(od), _hptr(fl)))
         return od, fl
 
     def coefficients(self, x, gas, shape):

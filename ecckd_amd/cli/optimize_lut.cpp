@@ -292,6 +292,8 @@ int main(int argc, char** argv) {
     config.read(max_iterations, "max_iterations");
     config.read(oc.negative_od_penalty, "negative_od_penalty");
     if (config.exist("bounded_minimization")) config.read(is_bounded, "bounded_minimization");
+    bool remove_min_max = false;                                            // :243-244
+    if (config.exist("remove_min_max")) config.read(remove_min_max, "remove_min_max");
     if (rayleigh_prior_error > 0.0) fail(ECCKD_PARAMETER_ERROR, "rayleigh_prior_error > 0 (optimised Rayleigh scattering) is not supported by this tool");
     std::vector<int> band_mapping;
     if (config.exist("band_mapping")) config.read(band_mapping, "band_mapping");
@@ -372,7 +374,7 @@ int main(int argc, char** argv) {
       std::vector<double> x0(ecckd_opt_nx(ro));
       ck(ecckd_opt_initial_state(ro, x0.data(), nullptr, nullptr));
       rel_flux.resize((size_t)rel.ncol * 2 * (rel.nlay + 1) * model.ng);
-      ck(ecckd_opt_forward(ro, x0.data(), nullptr, rel_flux.data()));
+      ck(ecckd_opt_forward_ex(ro, x0.data(), 1 /* od = value(aod): no clamp, :231-234 */, nullptr, rel_flux.data()));
       ck(ecckd_opt_destroy(ro));
     }
 
@@ -417,6 +419,8 @@ int main(int argc, char** argv) {
     ck(ecckd_opt_destroy(opt));
     if (gp.gmap) ck(ecckd_gmap_destroy(gp.gmap));
 
+    if (remove_min_max)   // ckd_model.save_min_max(false), :308-310: the <gas>_molar_absorption_coeff_min / _max tables are not written
+      for (GasTable& t : model.gases) { t.min_molar_abs.clear(); t.max_molar_abs.clear(); }
     LOG("Writing %s\n", output.c_str());
     write_ckd(output, model, history_line(argc, argv), config.str());
     if (status >= 6) {   // :315-319

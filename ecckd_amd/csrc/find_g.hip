@@ -447,6 +447,9 @@ k_tile_sums(int nrows, size_t n, size_t ntiles, const double* const* __restrict_
 struct Interval {
   long long i1, i2;      // inclusive global sorted indices
   long long chunk0;      // first RT chunk of this interval
+  long long chunk_pts;   // points per RT chunk of THIS interval: a function of its length alone (interval_chunk_pts), so that the
+                         // order in which its points are summed - and with it every bit of its error - does not depend on what else
+                         // is evaluated in the same batch
   long long npoints;     // band length (for the logarithmic fit)
   double albedo;         // shortwave: surface albedo of the interval's band
 };
@@ -585,7 +588,7 @@ k_fit_lw(int nlay, int method, RowMap R, const Interval* __restrict__ iv,
 // The up sweep re-evaluates emissivity and factor exactly as the reference does
 // (:128-137) from re-loaded rows (second touch is served by L2/Infinity Cache).
 __global__ void __launch_bounds__(RT_THREADS)
-k_rt_lw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv,
+k_rt_lw_bb(int nlay, size_t n, int nint, const Interval* __restrict__ iv,
            const double* __restrict__ planck_hl, const double* __restrict__ bg_od,
            const double* __restrict__ od_fit, double* __restrict__ partial) {
   extern __shared__ double s_mem[];  // [4][2*nhl] accumulators | [nlay] grey od
@@ -602,6 +605,7 @@ k_rt_lw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __
     if (iv[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
   }
   const int k = lo;
+  const long long chunk_pts = iv[k].chunk_pts;
   const long long c = chunk - iv[k].chunk0;
   const long long p0 = iv[k].i1 + c * chunk_pts;
   long long p1 = p0 + chunk_pts - 1;
@@ -771,7 +775,7 @@ __device__ __forceinline__ void eps_fac_one(double od, double& eps, double& fac)
 // wave-private transposed LDS tile every 16 slots.
 template <int NLAY>
 __global__ void __launch_bounds__(RT_THREADS, 3)
-k_rt_lw_bb_mirror(size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv,
+k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
                   const double* __restrict__ planck_hl, const double* __restrict__ bg_od,
                   const double* __restrict__ od_fit, double* __restrict__ partial) {
   static_assert(NLAY % 2 == 0, "the column is split into two equal halves");
@@ -795,6 +799,7 @@ k_rt_lw_bb_mirror(size_t n, long long chunk_pts, int nint, const Interval* __res
     if (iv[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
   }
   const int k = lo;
+  const long long chunk_pts = iv[k].chunk_pts;
   const long long c = chunk - iv[k].chunk0;
   const long long p0 = iv[k].i1 + c * chunk_pts;
   long long p1 = p0 + chunk_pts - 1;
@@ -1145,7 +1150,7 @@ k_fit_sw(int nlay, int method, RowMap R, int nint, double min_scaling, double ma
 // { sum ssi, dn[1..nlay], up[0..nlay] } (dn[0] = cos_sza * sum ssi is formed in K5d as the
 // reference does, :128).  Same chunking and reduction order as the LW kernel.
 __global__ void __launch_bounds__(RT_THREADS)
-k_rt_sw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv,
+k_rt_sw_bb(int nlay, size_t n, int nint, const Interval* __restrict__ iv,
            double cos_sza, const double* __restrict__ ssi, const double* __restrict__ bg_od,
            const double* __restrict__ od_fit, double* __restrict__ partial) {
   extern __shared__ double s_mem[];  // [4][2*nhl] | [nlay]
@@ -1161,6 +1166,7 @@ k_rt_sw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __
   }
   const int k = lo;
   const double albedo = iv[k].albedo;
+  const long long chunk_pts = iv[k].chunk_pts;
   const long long c = chunk - iv[k].chunk0;
   const long long p0 = iv[k].i1 + c * chunk_pts;
   long long p1 = p0 + chunk_pts - 1;
@@ -1219,7 +1225,7 @@ k_rt_sw_bb(int nlay, size_t n, long long chunk_pts, int nint, const Interval* __
 // (radiative_transfer_sw.cpp:134-139 and :176-183): the last fit overwrites the column with it instead of evaluating it twice.
 template <int NLAY, int NFIT, bool SAME, int OCC = (NFIT == 1 ? 3 : 2)>
 __global__ void __launch_bounds__(RT_THREADS, OCC)
-k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restrict__ iv, double cos_sza,
+k_rt_sw_bb_fast(size_t n, int nint, const Interval* __restrict__ iv, double cos_sza,
                 const double* __restrict__ ssi, const double* __restrict__ bg_od, const double* __restrict__ od_fit,
                 double* __restrict__ partial) {
   constexpr int NHL = NLAY + 1;
@@ -1237,6 +1243,7 @@ k_rt_sw_bb_fast(size_t n, long long chunk_pts, int nint, const Interval* __restr
     if (iv[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
   }
   const int k = lo;
+  const long long chunk_pts = iv[k].chunk_pts;
   const long long c = chunk - iv[k].chunk0;
   const long long p0 = iv[k].i1 + c * chunk_pts;
   long long p1 = p0 + chunk_pts - 1;
@@ -1414,6 +1421,13 @@ k_cost_sw(int nlay, int ntotal, SwTruthRows rows, const Interval* __restrict__ i
     const double dtoa = up[0] - s[rFUT];
     err[k] = sqrt(hr_weight * hr_weight * ss + flux_weight * (dsurf * dsurf + dtoa * dtoa));
   }
+}
+
+// Chunk size of an interval of `len` points: the smallest multiple of `gran` that covers it with at most `blocks` chunks.
+long long interval_chunk_pts(long long len, long long blocks, long long gran) {
+  long long c = (len + blocks - 1) / blocks;
+  c = (c + gran - 1) / gran * gran;
+  return c < gran ? gran : c;
 }
 
 int gas_ensure_work(ecckd_gas* g, size_t dev_bytes, size_t pinned_bytes) {
@@ -1937,6 +1951,7 @@ int ecckd_fit_optical_depth(ecckd_gas* g, size_t ibegin, size_t npoints, int n, 
     iv[k].i1 = (long long)ibegin + i1;
     iv[k].i2 = (long long)ibegin + i2;
     iv[k].chunk0 = k;
+    iv[k].chunk_pts = 0;   // no sweep in this call
     iv[k].npoints = (long long)npoints;
     iv[k].albedo = 0.0;
   }
@@ -2011,36 +2026,29 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   }
   for (int k = 0; k < n; ++k) g->total_comp_cost += bound2[k] - bound1[k];  // :320
 
-  // chunking: aim at ~8 blocks per CU, chunks are multiples of the 256-point sub-tile
+  // Chunking.  Every interval is cut into chunks of ITS OWN size: the smallest multiple of what one block iteration covers
+  // (the longwave mirror kernel: two wave pairs = 128 points; the other sweeps: 256) with which the interval fills at most
+  // one round of resident blocks.  The chunk size - and with it the order in which the interval's points are added up, chunk
+  // by chunk in K5c and partial by partial in K5d - is a function of the interval's length alone, so an interval's error has
+  // the same bits whether it is evaluated alone, with its neighbours (calc_error_all, equipartition.h:98-116) or next to
+  // other bands' intervals (ecckd_calc_error_multi).  A batch of n intervals launches up to n rounds of small blocks; the
+  // hardware's block dispatcher balances them.
   // ECCKD_RT_GENERIC (read per call): the run-time-nlay sweeps instead of the compile-time ones, for cross-checks at full size
   const bool fast_path = (nlay == 54 || nlay == 30) && std::getenv("ECCKD_RT_GENERIC") == nullptr;
-  // mirror path: 3 resident blocks per CU (3 waves/SIMD) -> one wave of blocks; more chunks shorten K5c a
-  // little but lengthen the ordered combine in K5d by more
+  // mirror path: 3 resident blocks per CU (3 waves/SIMD); the two-fit shortwave sweep holds 2
   static const int rt_bpc = std::getenv("ECCKD_RT_BPC") ? std::max(1, std::atoi(std::getenv("ECCKD_RT_BPC"))) : 3;   // tuning knob
-  // one round of resident blocks: the longwave and one-fit shortwave sweeps hold 3 blocks per CU, the two-fit shortwave sweep 2
   static const int sw2_bpc = std::getenv("ECCKD_SW2_BPC") ? std::max(1, std::atoi(std::getenv("ECCKD_SW2_BPC"))) : 2;   // tuning knob
   const bool sw_two_fits = g->do_sw && g->method == ECCKD_AVG_TOTAL_TRANSMISSION && fast_path;
-  long long target_blocks = (long long)ctx->num_cu * (sw_two_fits ? sw2_bpc : fast_path ? rt_bpc : 8);
-  // chunks are multiples of what one block iteration covers (the longwave mirror kernel: two wave pairs = 128 points).
-  // The smallest such chunk that still fits every interval's chunks into the resident blocks: one round, no straggler
-  // blocks from the intervals' partial last chunks.
-  static const bool chunk_old = std::getenv("ECCKD_RT_CHUNK_OLD") != nullptr;   // A/B knob
-  const long long gran = (!g->do_sw && fast_path && !chunk_old) ? RT_THREADS / 2 : RT_THREADS;
-  long long chunk_pts = (total_pts + target_blocks - 1) / target_blocks;
-  chunk_pts = (chunk_pts + gran - 1) / gran * gran;
-  if (chunk_pts < gran) chunk_pts = gran;
-  auto count_chunks = [&](long long c) {
-    long long m = 0;
-    for (int k = 0; k < n; ++k) m += (iv[k].i2 - iv[k].i1 + 1 + c - 1) / c;
-    return m;
-  };
-  if (!chunk_old && n < target_blocks)
-    while (count_chunks(chunk_pts) > target_blocks) chunk_pts += gran;
+  const long long target_blocks = (long long)ctx->num_cu * (sw_two_fits ? sw2_bpc : fast_path ? rt_bpc : 8);
+  const long long gran = (!g->do_sw && fast_path) ? RT_THREADS / 2 : RT_THREADS;
   long long nchunks = 0;
   for (int k = 0; k < n; ++k) {
+    const long long len = iv[k].i2 - iv[k].i1 + 1;
+    iv[k].chunk_pts = interval_chunk_pts(len, target_blocks, gran);
     iv[k].chunk0 = nchunks;
-    nchunks += (iv[k].i2 - iv[k].i1 + 1 + chunk_pts - 1) / chunk_pts;
+    nchunks += (len + iv[k].chunk_pts - 1) / iv[k].chunk_pts;
   }
+  ECCKD_REQUIRE(nchunks < 0x7fffffffLL, "ecckd_calc_error_batch: %lld chunks in one batch", nchunks);
 
   // device work layout: intervals | sums[n][nrows] | od_fit[2][n][nlay] | partial[nchunks][2nhl] | err[2][n]
   const size_t iv_bytes = ecckd_align_up((size_t)n * sizeof(Interval), 256);
@@ -2090,12 +2098,12 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
     for (int pass = 0; pass < (dual ? 1 : npass); ++pass) {
       double* part = d_part + (size_t)pass * part_stride;
 #define ECCKD_SW_SWEEP(NL, NF, SM, FIT)                                                                                         \
-  hipLaunchKernelGGL((k_rt_sw_bb_fast<NL, NF, SM>), dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, chunk_pts, n, \
+  hipLaunchKernelGGL((k_rt_sw_bb_fast<NL, NF, SM>), dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, n, \
                      d_iv, g->cos_sza, g->ssi, g->bg_od, FIT, part)
       const double* fit1 = d_fit + (size_t)pass * n * nlay;
       if (!fast_path)
         hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
-                           chunk_pts, n, d_iv, g->cos_sza, g->ssi, g->bg_od, fit1, part);
+                           n, d_iv, g->cos_sza, g->ssi, g->bg_od, fit1, part);
       else if (nlay == 54 && dual) { if (same_exp) ECCKD_SW_SWEEP(54, 2, true, d_fit); else ECCKD_SW_SWEEP(54, 2, false, d_fit); }
       else if (nlay == 30 && dual) { if (same_exp) ECCKD_SW_SWEEP(30, 2, true, d_fit); else ECCKD_SW_SWEEP(30, 2, false, d_fit); }
       else if (nlay == 54) { if (same_exp) ECCKD_SW_SWEEP(54, 1, true, fit1); else ECCKD_SW_SWEEP(54, 1, false, fit1); }
@@ -2118,13 +2126,13 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
   if (fast_path && nlay == 54) {
     hipLaunchKernelGGL(k_rt_lw_bb_mirror<54>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
-                       chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+                       n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
   } else if (fast_path && nlay == 30) {
     hipLaunchKernelGGL(k_rt_lw_bb_mirror<30>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
-                       chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+                       n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
   } else {
     hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, ctx->stream, nlay, g->n,
-                       chunk_pts, n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+                       n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
   }
   if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
   const size_t cost_lds = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);

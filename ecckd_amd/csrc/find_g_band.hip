@@ -68,6 +68,9 @@ k_invert_perm(size_t n, const int32_t* __restrict__ perm, int32_t* __restrict__ 
 }
 
 // calc_median_sorting_variable (find_g_points.cpp:35-49), one block per g point.
+// The reference adds the weights one by one; here the total is a strided tree and the running sum is carried over
+// 16-point partial sums, so where the running sum comes within rounding of half the total the crossing can fall on the
+// neighbouring point (whose sorting variable differs from its neighbour's by the local spacing of the sorted keys).
 // Pass 1: total weight of [i1, i2] (fixed strided order + fixed tree).  Pass 2: walk the interval
 // in chunks of 256 x 16 points; an exclusive scan of the 256 per-thread partial sums locates the
 // thread whose 16 points contain the first crossing of half the total, and that thread walks them.
@@ -109,7 +112,10 @@ k_median_sorting(const long long* __restrict__ ind1, const long long* __restrict
     }
     __syncthreads();
     const double before = s_scan[tid], after = s_scan[tid + 1];
-    if (before < half && after >= half) {
+    // the first index at which the running sum reaches half the total lies in this thread's points: nothing before them
+    // had reached it.  The very first point may do so with nothing before it (an interval without weight: half == 0, the
+    // reference's loop stops at i1, :42-46).
+    if (after >= half && (before < half || (base == i1 && tid == 0))) {
       double cum = before;
       for (int q = 0; q < MED_PER; ++q) {
         const long long i = a + q;

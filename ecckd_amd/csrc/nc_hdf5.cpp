@@ -58,6 +58,8 @@ struct Api {
   hid_t (*H5Aget_space)(hid_t);
   herr_t (*H5Aread)(hid_t, hid_t, void*);
   herr_t (*H5Aclose)(hid_t);
+  herr_t (*H5get_libversion)(unsigned*, unsigned*, unsigned*);
+  herr_t (*H5free_memory)(void*) = nullptr;   // optional (1.8.13+): releases what the library allocated for variable-length strings
   hid_t* native_double = nullptr;   // H5T_NATIVE_DOUBLE_g
   hid_t* c_s1 = nullptr;            // H5T_C_S1_g
   std::string error;
@@ -90,7 +92,18 @@ Api* api() {
   LOAD(H5Sget_simple_extent_npoints); LOAD(H5Sselect_hyperslab); LOAD(H5Screate_simple); LOAD(H5Sclose); LOAD(H5Tget_class);
   LOAD(H5Tget_size); LOAD(H5Tget_sign); LOAD(H5Tis_variable_str); LOAD(H5Tcopy); LOAD(H5Tset_size); LOAD(H5Tclose);
   LOAD(H5Aexists_by_name); LOAD(H5Aopen_by_name); LOAD(H5Aget_type); LOAD(H5Aget_space); LOAD(H5Aread); LOAD(H5Aclose);
+  LOAD(H5get_libversion);
 #undef LOAD
+  a.H5free_memory = reinterpret_cast<decltype(a.H5free_memory)>(dlsym(a.lib, "H5free_memory"));
+  if (ok) {
+    // the ABI declared above (64-bit hid_t, H5P_DEFAULT = H5S_ALL = 0) is that of HDF5 1.10 and later; 1.8 has a 32-bit hid_t
+    unsigned maj = 0, min = 0, rel = 0;
+    if (a.H5get_libversion(&maj, &min, &rel) < 0 || maj < 1 || (maj == 1 && min < 10)) {
+      ok = false;
+      a.error = "HDF5 library version " + std::to_string(maj) + "." + std::to_string(min) + "." + std::to_string(rel) +
+                " is older than 1.10 (set ECCKD_HDF5_LIB to a newer one)";
+    }
+  }
   a.native_double = static_cast<hid_t*>(sym("H5T_NATIVE_DOUBLE_g"));
   a.c_s1 = static_cast<hid_t*>(sym("H5T_C_S1_g"));
   if (!ok) { dlclose(a.lib); a.lib = nullptr; return nullptr; }
@@ -241,7 +254,7 @@ int h5_read_att_text(H5File* h, const char* var, const char* att, int* exists, c
     const hid_t mt = a->H5Tcopy(*a->c_s1);
     a->H5Tset_size(mt, (size_t)-1 /* H5T_VARIABLE */);
     if (a->H5Aread(at, mt, &p) < 0) rc = fail(ECCKD_PROCESSING_ERROR, "%s: reading attribute \"%s\" failed", h->path.c_str(), att);
-    if (p) { text = p; std::free(p); }
+    if (p) { text = p; if (a->H5free_memory) a->H5free_memory(p); else std::free(p); }
     a->H5Tclose(mt);
   } else {                                         // NC_CHAR: fixed-length string (possibly an array of them)
     const size_t size = a->H5Tget_size(t);

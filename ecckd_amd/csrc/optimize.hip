@@ -190,6 +190,9 @@ __global__ void k_opt_forward_adjoint(
         s_clamp[l * ng + g] = 0;
       }
       if (od_out) od_out[(cell0 + l) * ng + g] = (keep_negative && s_clamp[l * ng + g]) ? tau_raw : tau;   // run_ckd mode: molecular absorption only (run_ckd.cpp:318-326)
+      // keep_negative == 2: the sweeps see the optical depth as it comes out of the look-up tables, negative cells included:
+      // the "relative_to" fluxes, od = value(aod) -> LblFluxes::calc_ckd_fluxes (optimize_lut.cpp:231-234), which has no clamp
+      if (keep_negative == 2) tau = tau_raw;
       tau += tau_ray;
       s_tau[l * ng + g] = tau;
     }
@@ -634,6 +637,9 @@ k_lb_direction(size_t n, LbSlots sl, LbCoef cf, const double* __restrict__ q, co
 #pragma unroll
     for (int k = 0; k < LB_M; ++k)
       if (k < sl.n) di += cf.cy[k] * Y[(size_t)sl.slot[k] * n + i] - cf.cs[k] * S[(size_t)sl.slot[k] * n + i];
+    // a variable held by an active bound (or pinned) does not move: without this the slope d.g of the Armijo test would
+    // count a decrease that the clamped trial point cannot deliver
+    if (q[i] == 0.0 && g[i] != 0.0) di = 0.0;
     d[i] = di;
     a += di * g[i];
     b += di * di;
@@ -1309,13 +1315,23 @@ int ecckd_opt_cost_grad(ecckd_opt* o, const double* h_x, double* J, double* h_gr
 // negative clamp) and the CKD fluxes [ncol][2][nlay+1][ng] (LblFluxes::calc_ckd_fluxes,
 // lbl_fluxes.cpp:443-471) at state h_x.
 int ecckd_opt_forward(ecckd_opt* o, const double* h_x, double* h_od, double* h_flux) {
+  return ecckd_opt_forward_ex(o, h_x, 0, h_od, h_flux);
+}
+
+// unclamped != 0: optical depths and fluxes WITHOUT the clamp of negative total optical depths at zero, as the reference
+// evaluates the "relative_to" scene (optimize_lut.cpp:229-234: calc_total_optical_depth -> value() -> calc_ckd_fluxes;
+// the clamp lives in calc_cost_function_and_gradient only, solve_adept.cpp:107-116).
+int ecckd_opt_forward_ex(ecckd_opt* o, const double* h_x, int unclamped, double* h_od, double* h_flux) {
   ECCKD_REQUIRE(o && h_x, "ecckd_opt_forward: NULL argument");
   ecckd_ctx* ctx = o->ctx;
   const size_t nod = o->ncell * o->ng, nfl = o->ncol * 2 * (o->nlay + 1) * o->ng;
   if (!o->d_od_out) ECCKD_HIP_CHECK(hipMalloc((void**)&o->d_od_out, nod * sizeof(double)));
   if (!o->d_flux_out) ECCKD_HIP_CHECK(hipMalloc((void**)&o->d_flux_out, nfl * sizeof(double)));
   double J;
+  const int saved_mode = o->eval_keep_negative;
+  if (unclamped) o->eval_keep_negative = 2;
   int rc = ecckd_opt_cost_grad(o, h_x, &J, nullptr);
+  o->eval_keep_negative = saved_mode;
   if (rc == ECCKD_OK) {
     if (h_od) rc = ecckd_d2h(ctx, h_od, o->d_od_out, nod * sizeof(double));
     if (rc == ECCKD_OK && h_flux) rc = ecckd_d2h(ctx, h_flux, o->d_flux_out, nfl * sizeof(double));
@@ -1485,7 +1501,9 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
       dg = h_step[2];
       if (!(dg < 0.0)) {
         // not a descent direction: drop the history, steepest descent on the projected gradient
-        if (restarted || npairs == 0) { ok = false; st = 0; break; }   // projected gradient is zero
+        // steepest descent on a non-zero projected gradient that is not a descent direction either: the gradient is not
+        // a number (MINIMIZER_STATUS_INVALID_GRADIENT) or no direction can be found (..._DIRECTION_FAILURE) - not "converged"
+        if (restarted || npairs == 0) { ok = false; st = (dg != dg) ? 7 : 4; break; }
         restarted = true;
         hist = 0;
         npairs = 0;

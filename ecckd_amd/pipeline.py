@@ -217,12 +217,15 @@ def iband_per_g(model, wavenumber1, wavenumber2):
 
 
 def optimize_lut(ctx, model, training_files, relative_to=None, band_mapping=None, gmap=None, max_iterations=3000,
-                 convergence_criterion=0.0, bounded=True, max_no_rayleigh_wavenumber=None, erythemal_weight=0.0, **cfg):
+                 convergence_criterion=0.0, bounded=True, max_no_rayleigh_wavenumber=None, erythemal_weight=0.0,
+                 remove_min_max=False, **cfg):
     """The driver of optimize_lut.cpp:60-330 on top of api.Optimizer: training scenes from LBL flux files
     (ncio.read_lbl_fluxes), optional "relative_to" file, bounded L-BFGS, optimised coefficients back into the model.
 
     model: dict from ncio.read_ckd_model (its `active` flags select the gases being optimised, optimize_lut.cpp:161).
     cfg:   flux_weight, flux_profile_weight, broadband_weight, spectral_boundary_weight, prior_error, ... (api.Optimizer).
+    remove_min_max: drop the min / max tables from the model that is returned (`ckd_model.save_min_max(false)`,
+           optimize_lut.cpp:243-244, :308-310), so that ncio.write_ckd_model leaves the _min / _max variables out.
     Returns (model with optimised molar_abs, result dict of Optimizer.minimize)."""
     names = [g["name"] for g in model["gases"]]
     is_sw = model.get("solar_irradiance") is not None
@@ -242,7 +245,7 @@ def optimize_lut(ctx, model, training_files, relative_to=None, band_mapping=None
         rel = load(relative_to)
         m0 = dict(model, iband_per_g=rel.get("iband_per_g", model["iband_per_g"]))
         ref_opt = api.Optimizer(ctx, m0, [_scene_for_optimizer(rel, is_sw)], **cfg)
-        _, fl = ref_opt.forward(ref_opt.initial_state())
+        _, fl = ref_opt.forward(ref_opt.initial_state(), unclamped=True)     # od = value(aod), no clamp (:231-234)
         ref_opt.close()
     scenes = []
     iband = None
@@ -265,6 +268,9 @@ def optimize_lut(ctx, model, training_files, relative_to=None, band_mapping=None
     out = dict(model, gases=[dict(g) for g in model["gases"]])
     for i, g in enumerate(out["gases"]):
         g["molar_abs"] = opt.coefficients(res["x"], i, np.asarray(g["molar_abs"]).shape)
+        if remove_min_max:
+            g.pop("min_molar_abs", None)
+            g.pop("max_molar_abs", None)
     opt.close()
     return out, res
 

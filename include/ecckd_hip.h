@@ -503,6 +503,10 @@ int ecckd_opt_cost_grad(ecckd_opt* opt, const double* h_x, double* J, double* h_
 /* total optical depth [ncol][nlay][ng] and CKD fluxes [ncol][2][nlay+1][ng] at state h_x
  * (calc_total_optical_depth, LblFluxes::calc_ckd_fluxes lbl_fluxes.cpp:443-471) */
 int ecckd_opt_forward(ecckd_opt* opt, const double* h_x, double* h_od, double* h_flux);
+/* the same with unclamped != 0: negative total optical depths are NOT set to zero before the radiative transfer - how the
+ * reference evaluates its "relative_to" scene (optimize_lut.cpp:229-234: od = value(aod) -> LblFluxes::calc_ckd_fluxes;
+ * the clamp belongs to the cost function alone, solve_adept.cpp:107-116) */
+int ecckd_opt_forward_ex(ecckd_opt* opt, const double* h_x, int unclamped, double* h_od, double* h_flux);
 int ecckd_opt_coefficients(ecckd_opt* opt, const double* h_x, int gas, double* h_molar_abs);
 /* status follows adept::MinimizerStatus: 0 success, 2 max iterations, 3 failed to converge,
  * >= 6 anomalous (optimize_lut.cpp:315-319 exits 1 for those) */

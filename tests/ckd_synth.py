@@ -73,9 +73,12 @@ class Oracle:
                               P(np.ascontiguousarray(m["planck_function"])), C.c_int(ng), C.c_int(T.size), P(T), P(out))
         return out
 
-    def fluxes(self, x, scene):
-        """CKD fluxes per g: (ncol, 2, nhl, ng), LblFluxes::calc_ckd_fluxes."""
-        od = np.maximum(self.optical_depth(x, scene), 0.0)
+    def fluxes(self, x, scene, unclamped=False):
+        """CKD fluxes per g: (ncol, 2, nhl, ng), LblFluxes::calc_ckd_fluxes.  unclamped: on the optical depths as they come
+        out of the tables (the "relative_to" evaluation, optimize_lut.cpp:229-234) instead of the cost function's clamped ones."""
+        od = self.optical_depth(x, scene)
+        if not unclamped:
+            od = np.maximum(od, 0.0)
         T = scene["temperature_hl"]
         ncol, nhl = T.shape
         ng = od.shape[2]

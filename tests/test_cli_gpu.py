@@ -369,6 +369,25 @@ def test_optimize_lut(ctx, tmp_path):
                                        temperature_corr=0.95, conc_corr=0.9, min_prior_error=-1.0, max_prior_error=-1.0)
     ncio.write_ckd_model(str(d / "py_rel.nc"), opt_rel, model_id="cli-test")
     _same_files(d / "opt_rel.nc", d / "py_rel.nc")
+    # remove_min_max=1 as the shipped scripts pass it (test/optimize_lut_lw.sh, optimize_lut.cpp:243-244, :308-310): the
+    # <gas>_molar_absorption_coeff_min / _max tables of the input are left out of the output, everything else is unchanged
+    f = _nc(d / "opt.nc")
+    assert "h2o_molar_absorption_coeff_min" in f.variables and "co2_molar_absorption_coeff_max" in f.variables
+    f.close()
+    r = run_tool("optimize_lut", "opt.cfg", "output=opt_nomm.nc", "remove_min_max=1", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    f = _nc(d / "opt_nomm.nc")
+    assert not [v for v in f.variables if v.endswith("_min") or v.endswith("_max")]
+    f.close()
+    stripped, _ = pipeline.optimize_lut(ctx, raw, paths, max_iterations=40, flux_weight=0.2, flux_profile_weight=0.05,
+                                        broadband_weight=0.4, prior_error=4.0, pressure_corr=0.95, temperature_corr=0.95,
+                                        conc_corr=0.9, min_prior_error=-1.0, max_prior_error=-1.0, remove_min_max=True)
+    ncio.write_ckd_model(str(d / "py_nomm.nc"), stripped, model_id="cli-test")
+    _same_files(d / "opt_nomm.nc", d / "py_nomm.nc")
+    fa, fb = _nc(d / "opt.nc"), _nc(d / "opt_nomm.nc")
+    for v in fb.variables:
+        assert np.array_equal(fa.variables[v][...], fb.variables[v][...]), v
+    fa.close(); fb.close()
     # exit codes
     r = run_tool("optimize_lut", "input=raw.nc", "output=x.nc", cwd=d)
     assert r.returncode == 147 and "training_input" in r.stderr

@@ -293,13 +293,14 @@ def test_full_size_find_g_against_oracle_slices(ctx, oracle):
     ref = np.array([eq.calc_error(x, y) for x, y in zip(b1, b2)])
     assert np.allclose(err, ref, rtol=ERR_RTOL, atol=1e-12)
 
-    # (c) the whole band: a repeated batch gives the same bits (fixed-order reductions, no atomics); the same intervals in
-    # other batches are split into chunks of another size, which moves the sums by rounding only
+    # (c) the whole band: an interval's error is a function of the interval alone (fixed-order reductions, no atomics, chunk
+    # size set by the interval's length): the same bits alone, with its neighbours, in another order, next to other intervals
     e_all = gas.calc_error_batch(0, nwav, [0.0, 0.3, 0.7], [0.3, 0.7, 1.0])
     assert np.array_equal(e_all, gas.calc_error_batch(0, nwav, [0.0, 0.3, 0.7], [0.3, 0.7, 1.0]))
     e_rev = gas.calc_error_batch(0, nwav, [0.7, 0.0, 0.3], [1.0, 0.3, 0.7])
     e_one = np.array([gas.calc_error_batch(0, nwav, [a], [b])[0] for a, b in ((0.0, 0.3), (0.3, 0.7), (0.7, 1.0))])
-    assert np.allclose(e_all, e_one, rtol=1e-12, atol=0) and np.allclose(e_all, e_rev[[1, 2, 0]], rtol=1e-12, atol=0)
+    e_mix = gas.calc_error_batch(0, nwav, [0.1, 0.3, 0.0, 0.0, 0.7, 0.95], [0.2, 0.7, 1.0, 0.3, 1.0, 0.96])
+    assert np.array_equal(e_all, e_one) and np.array_equal(e_all, e_rev[[1, 2, 0]]) and np.array_equal(e_all, e_mix[[3, 1, 4]])
     assert np.all(np.isfinite(e_all)) and np.all(e_all > 0)
 
     gas.close()
@@ -310,6 +311,35 @@ def test_full_size_find_g_against_oracle_slices(ctx, oracle):
     assert st == 0 and len(e) >= 4 and b[0] == 0.0 and b[-1] == 1.0 and np.all(np.diff(b) > 0)
     assert np.all(np.isfinite(e)) and np.all(e > 0) and cc > len(e) and e[:-1].max() <= 0.0161 * 1.0101
     assert np.allclose(gas.calc_error_batch(0, nwav, b[:-1], b[1:]), e, rtol=1e-12, atol=0)
+    gas.close()
+
+
+@pytest.mark.parametrize("nlay,method", [(54, "transmission"), (30, "logarithmic"), (12, "linear")])
+def test_interval_error_does_not_depend_on_the_batch(ctx, oracle, nlay, method):
+    """Equipartition::calc_error is a function of the interval (equipartition.h:95); the search evaluates the same interval
+    alone (next_bound_below / _above), with all its neighbours (calc_error_all, :98-116) and, here, side by side with other
+    bands' intervals (ecckd_calc_error_multi).  Every one of those evaluations must return the same bits, otherwise a search
+    run next to others could take other decisions than on its own.  54 / 30 layers: compile-time sweeps; 12: run-time."""
+    n = 150_000
+    o = _lw_problem(oracle, n, nlay=nlay, seed=27, method=method)
+    gas = _make_gas(ctx, o, method, flux_weight=0.02, od_dtype=np.float32 if nlay == 54 else np.float64)
+    rs = np.random.RandomState(11)
+    cuts = np.concatenate([[0.0], np.sort(rs.uniform(0, 1, 14)), [1.0]])
+    b1, b2 = cuts[:-1], cuts[1:]
+    together = gas.calc_error_batch(0, n, b1, b2)
+    alone = np.array([gas.calc_error_batch(0, n, [x], [y])[0] for x, y in zip(b1, b2)])
+    perm = rs.permutation(len(b1))
+    shuffled = gas.calc_error_batch(0, n, b1[perm], b2[perm])
+    assert np.array_equal(together, alone)
+    assert np.array_equal(together[perm], shuffled)
+    # the same intervals of a band that starts inside the spectrum, next to intervals of two other bands
+    ib, nb = 20_011, 90_000
+    e_band = gas.calc_error_batch(ib, nb, b1, b2)
+    ibegin = np.concatenate([[0, 0], np.full(len(b1), ib), [120_000]])
+    npts = np.concatenate([[15_000, 15_000], np.full(len(b1), nb), [30_000]])
+    e_multi = gas.calc_error_multi(ibegin, npts, np.concatenate([[0.0, 0.5], b1, [0.0]]), np.concatenate([[0.5, 1.0], b2, [1.0]]))
+    assert np.array_equal(e_band, e_multi[2:-1])
+    assert np.all(np.isfinite(e_multi)) and np.all(e_multi > 0)
     gas.close()
 
 

@@ -243,3 +243,29 @@ def test_shortwave_bands_side_by_side_match_one_band_at_a_time(ctx, oracle):
     with_albedo = gas.calc_error_batch(int(begin[2]), int(end[2] - begin[2] + 1), [0.0, 0.5], [0.5, 1.0])
     assert not np.allclose(with_albedo, single[1], rtol=1e-6)
     gas.close()
+
+
+@pytest.mark.parametrize("nlay,method", [(54, "total-transmission"), (30, "transmission"), (12, "total-transmission")])
+def test_interval_error_sw_does_not_depend_on_the_batch(ctx, oracle, nlay, method):
+    """Shortwave twin of test_find_g_gpu.py::test_interval_error_does_not_depend_on_the_batch: an interval's error has the
+    same bits alone, with its neighbours, in another order and next to another band's intervals (with another albedo)."""
+    n = 120_000
+    o = _sw_problem(oracle, n, nlay=nlay, seed=47, method=method)
+    gas = _make_gas(ctx, o, method)
+    gas.set_band_albedo(0.15)
+    rs = np.random.RandomState(13)
+    cuts = np.concatenate([[0.0], np.sort(rs.uniform(0, 1, 11)), [1.0]])
+    b1, b2 = cuts[:-1], cuts[1:]
+    together = gas.calc_error_batch(0, n, b1, b2)
+    alone = np.array([gas.calc_error_batch(0, n, [x], [y])[0] for x, y in zip(b1, b2)])
+    perm = rs.permutation(len(b1))
+    assert np.array_equal(together, alone)
+    assert np.array_equal(together[perm], gas.calc_error_batch(0, n, b1[perm], b2[perm]))
+    ib, nb = 10_007, 70_000
+    e_band = gas.calc_error_batch(ib, nb, b1, b2)
+    ibegin = np.concatenate([[0], np.full(len(b1), ib), [90_000]])
+    npts = np.concatenate([[9_000], np.full(len(b1), nb), [30_000]])
+    alb = np.concatenate([[0.0], np.full(len(b1), 0.15), [0.0]])
+    e_multi = gas.calc_error_multi(ibegin, npts, np.concatenate([[0.0], b1, [0.0]]), np.concatenate([[1.0], b2, [1.0]]), band_albedo=alb)
+    assert np.array_equal(e_band, e_multi[1:-1])
+    gas.close()

@@ -57,6 +57,30 @@ def test_forward_optical_depth_and_fluxes(ctx, oracle):
     opt.close()
 
 
+def test_forward_unclamped_for_relative_to(ctx, oracle):
+    """The "relative_to" fluxes (optimize_lut.cpp:229-234) come from od = value(aod) with NO clamp at zero: a cell whose
+    relative-linear gas sits far enough below its reference concentration keeps its negative optical depth through
+    radiative_transfer_lw.  ecckd_opt_forward_ex(unclamped) reproduces that; the default forward clamps as the cost does."""
+    model, scenes, cfg, orc = _problem(oracle, seed=3, ch4_low=True)
+    opt = _opt(ctx, model, scenes, cfg)
+    x = opt.initial_state()
+    sizes = np.cumsum([0] + orc.sizes)
+    x[sizes[3]:sizes[4]] += 9.0                                # strong relative-linear gas: (vmr - ref) * k < 0
+    od_ref = np.concatenate([orc.optical_depth(x, s) for s in scenes])
+    assert (od_ref < 0).sum() > 10
+    od_c, fl_c = opt.forward(x)
+    od_u, fl_u = opt.forward(x, unclamped=True)
+    assert np.allclose(od_u, od_ref, rtol=1e-12, atol=1e-300) and np.allclose(od_c, np.maximum(od_ref, 0.0), rtol=1e-12, atol=1e-300)
+    fl_ref_u = np.concatenate([orc.fluxes(x, s, unclamped=True) for s in scenes])
+    fl_ref_c = np.concatenate([orc.fluxes(x, s) for s in scenes])
+    assert np.allclose(fl_u, fl_ref_u, rtol=1e-10, atol=1e-300) and np.allclose(fl_c, fl_ref_c, rtol=1e-10, atol=1e-300)
+    assert not np.allclose(fl_u, fl_c, rtol=1e-6)
+    J1, _ = opt.cost_grad(x)                                   # the mode does not leak into the cost function
+    opt.forward(x, unclamped=True)
+    assert opt.cost_grad(x)[0] == J1
+    opt.close()
+
+
 @pytest.mark.parametrize("variant", ["base", "no_profile_term", "boundary", "negative_od", "power1"])
 def test_cost_and_gradient(ctx, oracle, variant):
     kw = {}
