@@ -82,6 +82,8 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_double,
                                       C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ecckd_planck_hl_sorted_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     "ecckd_gas_create_sw": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t,
                                       C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -290,6 +290,21 @@ class PartitionSearch:
         return st.value, b[:n + 1].copy(), err[:n].copy()
 
 
+def planck_hl_sorted(ctx, temperature_hl, wavenumber, d_wavenumber, rank, out=None):
+    """The Planck matrix (nlay+1, nwav) of the ordering `rank`, bit-identical to GasLW(...).view("planck_hl") for that
+    ordering and temperature profile (ecckd_planck_hl_sorted_dev): what a process that does not hold the FIRST gas passes
+    as planck_hl_reuse (find_g_points.cpp:529, :970-984).  Device tensors in, device tensor out."""
+    torch = _torch()
+    t = np.ascontiguousarray(temperature_hl, dtype=np.float64)
+    nwav = rank.numel()
+    if out is None:
+        out = torch.empty((t.size, nwav), dtype=torch.float64, device=ctx.device)
+    ctx.fence_from_torch()
+    check(ctx.lib.ecckd_planck_hl_sorted_dev(ctx.handle, t.size - 1, nwav, _hptr(t), _dptr(wavenumber), _dptr(d_wavenumber),
+                                             _dptr(rank), _dptr(out)))
+    return out
+
+
 class GasLW:
     """A prepared longwave gas (ecckd_gas_create_lw): find_g_points.cpp:872-1150 done once on
     the device, then batched interval errors (CkdEquipartition::calc_error, :291-405)."""

@@ -114,7 +114,8 @@ int ensure_pinned(ecckd_ctx* ctx, size_t bytes) {
     ctx->pinned_bytes = 0;
   }
   size_t want = ecckd_align_up(bytes * 2, 4096);
-  ECCKD_HIP_CHECK(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+  // host-coherent: results that a kernel writes here are visible to the host while the stream is still running (wait_for_slots)
+  ECCKD_HIP_CHECK(hipHostMalloc(&ctx->pinned, want, hipHostMallocMapped | hipHostMallocCoherent));
   ctx->pinned_bytes = want;
   return ECCKD_OK;
 }

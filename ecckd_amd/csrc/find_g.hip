@@ -25,10 +25,12 @@
 #include "partition_search.hpp"
 #include "fastmath.hpp"
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <immintrin.h>
 
 namespace {
 
@@ -90,6 +92,23 @@ __global__ void __launch_bounds__(256)
 k_check_perm(size_t n, const int32_t* __restrict__ ireorder, int* __restrict__ err) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && ireorder[i] < 0) atomicOr(err, 2);
+}
+
+// The Planck matrix of a gas's ordering alone: planck_hl[lev][i] for the wavenumber whose rank is i, evaluated exactly as
+// the preparation kernels do (same expression, same exp / division), so that a process which does not search the FIRST
+// gas can still hold the matrix the reference keeps from it for all later gases (find_g_points.cpp:529, :970-984).
+__global__ void __launch_bounds__(256)
+k_planck_sorted(int nhl, size_t n, const int32_t* __restrict__ ireorder, const double* __restrict__ hk,
+                const double* __restrict__ wn, const double* __restrict__ dwn, double* __restrict__ planck_hl) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t j = (size_t)ireorder[i];
+  const double w = wn[j], dw = dwn[j];
+  const double inv_cm_2_Hz = 100.0 * kLightC;
+  const double freq = w * inv_cm_2_Hz;
+  const double pref = (dw * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq);
+  for (int lev = 0; lev < nhl; ++lev)
+    planck_hl[(size_t)lev * n + i] = ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[lev]) - 1.0);
 }
 
 __device__ __forceinline__ double metric_of(int method, double od) {
@@ -454,6 +473,22 @@ struct Interval {
   double albedo;         // shortwave: surface albedo of the interval's band
 };
 
+// Small batches (most of a search: next_bound_below / _above evaluate ONE interval per call, equipartition.cpp:638-805)
+// hand their interval table to the first kernel of the train in its ARGUMENTS instead of a host-to-device copy in front of
+// it: one stream operation and one dependency gap less per batch.  The first kernel leaves the table in device memory for
+// the kernels behind it.
+constexpr int KARG_MAX = 8;
+struct IntervalArgs { Interval iv[KARG_MAX]; };
+
+__device__ __forceinline__ Interval interval_of(const IntervalArgs& ka, int use_ka, const Interval* __restrict__ iv, int k) {
+  if (!use_ka) return iv[k];
+  Interval me = ka.iv[0];
+#pragma unroll
+  for (int q = 1; q < KARG_MAX; ++q)
+    if (q == k) me = ka.iv[q];     // selects, not an indexed read: the argument block stays in scalar registers
+  return me;
+}
+
 // this thread's share of sum_{i=i1..i2} row[i]: ragged head + whole tiles (from the tile sums) + ragged tail
 __device__ __forceinline__ double interval_row_acc(const double* __restrict__ row, const double* __restrict__ trow,
                                                    long long i1, long long i2, int tid) {
@@ -479,13 +514,15 @@ __device__ __forceinline__ double interval_row_acc(const double* __restrict__ ro
 }
 
 __global__ void __launch_bounds__(256)
-k_interval_sums(int nrows, size_t ntiles, const Interval* __restrict__ iv,
+k_interval_sums(int nrows, size_t ntiles, const Interval* __restrict__ iv, IntervalArgs ka, int use_ka, Interval* __restrict__ iv_out,
                 const double* const* __restrict__ rows, const double* __restrict__ ts,
                 double* __restrict__ sums) {
   __shared__ double s4[4];
   const int r = blockIdx.x, k = blockIdx.y;
   const int tid = threadIdx.x;
-  const double acc = interval_row_acc(rows[r], ts + (size_t)r * ntiles, iv[k].i1, iv[k].i2, tid);
+  const Interval me = interval_of(ka, use_ka, iv, k);
+  if (use_ka && r == 0 && tid == 0) iv_out[k] = me;
+  const double acc = interval_row_acc(rows[r], ts + (size_t)r * ntiles, me.i1, me.i2, tid);
   const double s = block_sum_256(acc, s4);
   if (tid == 0) sums[(size_t)k * nrows + r] = s;
 }
@@ -511,12 +548,14 @@ __device__ __forceinline__ double fit_lw_layer(int method, double a, double b, d
 // logarithmic method, N+l), so the block that owns layer l adds up those rows and finishes the fit itself; the remaining
 // rows (heating rate, boundary fluxes) get one block each as before.  grid (nlay + rows from R.H on, nint), block 256.
 __global__ void __launch_bounds__(256)
-k_interval_sums_fit_lw(int nlay, int method, RowMap R, size_t ntiles, const Interval* __restrict__ iv,
-                       const double* const* __restrict__ rows, const double* __restrict__ ts,
+k_interval_sums_fit_lw(int nlay, int method, RowMap R, size_t ntiles, const Interval* __restrict__ iv, IntervalArgs ka, int use_ka,
+                       Interval* __restrict__ iv_out, const double* const* __restrict__ rows, const double* __restrict__ ts,
                        double* __restrict__ sums, double* __restrict__ od_fit) {
   __shared__ double s4[4];
   const int bx = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
-  const long long i1 = iv[k].i1, i2 = iv[k].i2;
+  const Interval me = interval_of(ka, use_ka, iv, k);
+  if (use_ka && bx == 0 && tid == 0) iv_out[k] = me;
+  const long long i1 = me.i1, i2 = me.i2;
   double* out = sums + (size_t)k * R.total;
   if (bx >= nlay) {
     const int r = R.H + (bx - nlay);
@@ -1423,6 +1462,48 @@ k_cost_sw(int nlay, int ntotal, SwTruthRows rows, const Interval* __restrict__ i
   }
 }
 
+// The errors of a batch arrive in pinned, host-coherent memory, written by the last kernel of the train.  Waiting for them
+// with hipStreamSynchronize costs a wake-up through the runtime per batch, and a search is hundreds of dependent batches
+// (equipartition.cpp:638-805: one interval per call); the host instead marks the slots as pending and watches them.
+// A pattern no result can have: the kernels end in sqrt(), whose only NaN is the canonical quiet one.
+constexpr unsigned long long kPendingBits = 0x7ff4dead5eed0001ULL;
+
+void mark_pending(double* h_slots, int count) {
+  volatile unsigned long long* s = reinterpret_cast<volatile unsigned long long*>(h_slots);
+  for (int k = 0; k < count; ++k) s[k] = kPendingBits;
+  std::atomic_thread_fence(std::memory_order_release);
+}
+
+int wait_for_slots(ecckd_ctx* ctx, const double* h_slots, int count) {
+  static const bool no_poll = std::getenv("ECCKD_NO_POLL") != nullptr;   // A/B knob: wait through the runtime
+  if (no_poll) {
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return ECCKD_OK;
+  }
+  const volatile unsigned long long* s = reinterpret_cast<const volatile unsigned long long*>(h_slots);
+  auto all_there = [&] {
+    for (int k = 0; k < count; ++k)
+      if (s[k] == kPendingBits) return false;
+    return true;
+  };
+  for (unsigned spins = 1;; ++spins) {
+    if (all_there()) break;
+    if ((spins & 0x3fff) == 0) {
+      // now and then: has the stream drained (or died) without delivering?  An idle stream has made all its writes visible.
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipSuccess) {
+        if (all_there()) break;
+        return ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION, "interval errors were not delivered by the device");
+      }
+      if (q != hipErrorNotReady)
+        return ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION, "device failure while waiting for interval errors: %s", hipGetErrorString(q));
+    }
+    _mm_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return ECCKD_OK;
+}
+
 // Chunk size of an interval of `len` points: the smallest multiple of `gran` that covers it with at most `blocks` chunks.
 long long interval_chunk_pts(long long len, long long blocks, long long gran) {
   long long c = (len + blocks - 1) / blocks;
@@ -1705,6 +1786,43 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
 }
 
 
+// planck_hl[nlay+1][nwav] in the order given by d_rank, bit-identical to the matrix ecckd_gas_create_lw builds for a gas
+// with that ordering and temperature profile (planck_function.cpp:22-54 on the reordered grid, find_g_points.cpp:970-979).
+int ecckd_planck_hl_sorted_dev(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_temperature_hl,
+                               const double* d_wavenumber, const double* d_d_wavenumber, const int32_t* d_rank,
+                               double* d_planck_hl) {
+  ECCKD_REQUIRE(ctx && h_temperature_hl && d_wavenumber && d_d_wavenumber && d_rank && d_planck_hl,
+                "ecckd_planck_hl_sorted_dev: NULL argument");
+  ECCKD_REQUIRE(nlay > 0 && nwav > 0 && nwav < (size_t)0x7fffffff, "ecckd_planck_hl_sorted_dev: bad size (nlay=%d, nwav=%zu)", nlay, nwav);
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const int nhl = nlay + 1;
+  std::vector<double> hk(nhl);
+  for (int i = 0; i < nhl; ++i) {
+    ECCKD_REQUIRE(h_temperature_hl[i] > 0.0, "ecckd_planck_hl_sorted_dev: temperature_hl must be positive");
+    hk[i] = (6.62606896e-34 / 1.3806504e-23) / h_temperature_hl[i];
+  }
+  const size_t hk_bytes = ecckd_align_up(nhl * sizeof(double), 256), flag_bytes = 256;
+  ECCKD_CHECK(ecckd::ensure_scratch(ctx, hk_bytes + flag_bytes + nwav * sizeof(int32_t)));
+  double* d_hk = (double*)ctx->scratch;
+  int* d_flag = (int*)((char*)ctx->scratch + hk_bytes);
+  int32_t* d_ireorder = (int32_t*)((char*)ctx->scratch + hk_bytes + flag_bytes);
+  ECCKD_HIP_CHECK(hipMemcpyAsync(d_hk, hk.data(), nhl * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ECCKD_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
+  ECCKD_HIP_CHECK(hipMemsetAsync(d_ireorder, 0xFF, nwav * sizeof(int32_t), ctx->stream));
+  const unsigned eblocks = (unsigned)((nwav + 255) / 256);
+  hipLaunchKernelGGL(k_invert_rank, dim3(eblocks), dim3(256), 0, ctx->stream, nwav, d_rank, d_ireorder, d_flag);
+  hipLaunchKernelGGL(k_check_perm, dim3(eblocks), dim3(256), 0, ctx->stream, nwav, d_ireorder, d_flag);
+  int flag = 0;
+  ECCKD_HIP_CHECK(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // also: hk is a local
+  ECCKD_REQUIRE(flag == 0, "ecckd_planck_hl_sorted_dev: rank is not a permutation of 0..nwav-1");
+  hipLaunchKernelGGL(k_planck_sorted, dim3(eblocks), dim3(256), 0, ctx->stream, nhl, nwav, d_ireorder, d_hk, d_wavenumber,
+                     d_d_wavenumber, d_planck_hl);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
+}
+
 // Shortwave gas (find_g_points.cpp do_sw branches of :872-1150).  d_albedo: per-wavenumber
 // surface albedo in ORIGINAL order (:921-923), used only for the up-welling of the two scaled
 // truth fields of the total-transmission method; NULL = direct beam only (:1027-1034).
@@ -1965,8 +2083,8 @@ int ecckd_fit_optical_depth(ecckd_gas* g, size_t ibegin, size_t npoints, int n, 
   double* d_fit = (double*)w;
   std::memcpy(g->pinned, iv.data(), (size_t)n * sizeof(Interval));
   ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, g->pinned, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv,
-                     (const double* const*)g->rows, g->tile_sums, d_sums);
+  hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv, IntervalArgs(), 0,
+                     d_iv, (const double* const*)g->rows, g->tile_sums, d_sums);
   if (g->do_sw) {
     // unscaled fit: scaling factors of 1
     hipLaunchKernelGGL(k_fit_sw, dim3(n), dim3(128), nlay * sizeof(double), ctx->stream, nlay, g->method, g->rm, n,
@@ -2069,14 +2187,24 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   // device-to-host copy in the stream
   double* h_err_dev = nullptr;
   ECCKD_HIP_CHECK(hipHostGetDevicePointer((void**)&h_err_dev, h_err, 0));
-  std::memcpy(h_iv, iv.data(), (size_t)n * sizeof(Interval));
-  ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, h_iv, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
+  const int nslots = (g->do_sw && g->method == ECCKD_AVG_TOTAL_TRANSMISSION) ? 2 * n : n;
+  mark_pending(h_err, nslots);
+  static const bool no_karg = std::getenv("ECCKD_NO_KARG") != nullptr;   // A/B knob: always copy the interval table
+  const int use_ka = (n <= KARG_MAX && !no_karg) ? 1 : 0;
+  IntervalArgs ka;
+  if (use_ka) {
+    for (int k = 0; k < KARG_MAX; ++k) ka.iv[k] = iv[k < n ? k : n - 1];
+  } else {
+    std::memset(&ka, 0, sizeof ka);
+    std::memcpy(h_iv, iv.data(), (size_t)n * sizeof(Interval));
+    ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, h_iv, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
+  }
 
   if (!g->do_sw)
     hipLaunchKernelGGL(k_interval_sums_fit_lw, dim3(nlay + (g->rm.total - g->rm.H), n), dim3(256), 0, ctx->stream, nlay, g->method,
-                       g->rm, g->ntiles, d_iv, (const double* const*)g->rows, g->tile_sums, d_sums, d_fit);
+                       g->rm, g->ntiles, d_iv, ka, use_ka, d_iv, (const double* const*)g->rows, g->tile_sums, d_sums, d_fit);
   else
-    hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv,
+    hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv, ka, use_ka, d_iv,
                        (const double* const*)g->rows, g->tile_sums, d_sums);
   if (g->do_sw) {
     // CkdEquipartition::calc_error, shortwave branches (find_g_points.cpp:341-402)
@@ -2118,7 +2246,7 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
     hipLaunchKernelGGL(k_cost_sw, dim3(n, npass), dim3(1024), cost_lds_sw, ctx->stream, nlay, R.total, rows, d_iv, nchunks,
                        d_part, part_stride, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, g->cos_sza, h_err_dev);
     ECCKD_HIP_CHECK(hipGetLastError());
-    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ECCKD_CHECK(wait_for_slots(ctx, h_err, nslots));
     for (int k = 0; k < n; ++k) error[k] = is_tt ? 0.5 * (h_err[k] + h_err[n + k]) : h_err[k];  // :386
     return ECCKD_OK;
   }
@@ -2139,10 +2267,11 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
   hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, ctx->stream, nlay, g->rm, d_iv,
                      nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, h_err_dev);
   ECCKD_HIP_CHECK(hipGetLastError());
-  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ECCKD_CHECK(wait_for_slots(ctx, h_err, nslots));
   std::memcpy(error, h_err, (size_t)n * sizeof(double));
   if (ctx->profile) {
     float ms = 0.f;
+    ECCKD_HIP_CHECK(hipEventSynchronize(ctx->pev1));    // long past: the cost kernel behind it has delivered
     ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1));
     ctx->stat_rt_lw.ms += ms;
     ctx->stat_rt_lw.units += (double)total_pts;

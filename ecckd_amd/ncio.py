@@ -125,8 +125,9 @@ class NcWriter:
             check(self.lib.ecckd_nc_close(h))
 
 
-def read_spectrum(path, iprofile=0):
-    """read_spectrum.cpp:20-87 for one column of a CKDMIP spectral file -> dict with the reference's names."""
+def read_spectrum(path, iprofile=0, optical_depth=True):
+    """read_spectrum.cpp:20-87 for one column of a CKDMIP spectral file -> dict with the reference's names.
+    optical_depth=False: the grids and profiles only (a process that needs the first gas's Planck matrix, not its spectrum)."""
     with NcFile(path) as f:
         out = {"ncol": f.var_info("pressure_hl")[1][0]}
         out["pressure_hl"] = f.read("pressure_hl", iprofile)
@@ -149,7 +150,8 @@ def read_spectrum(path, iprofile=0):
             out["vmr_fl"] = f.read("mole_fraction_fl", iprofile)
         else:
             out["vmr_fl"] = np.full(out["pressure_hl"].size - 1, -1.0)
-        out["optical_depth"] = f.read("optical_depth", iprofile)
+        if optical_depth:
+            out["optical_depth"] = f.read("optical_depth", iprofile)
     return out
 
 

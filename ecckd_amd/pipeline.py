@@ -304,7 +304,8 @@ def reorder_spectrum(ctx, input_path, output_path, band_bound1, band_bound2, ipr
 
 def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, output_path=None, averaging_method="transmission",
                   flux_weight=0.02, min_pressure=0.0, tolerance_tolerance=0.02, max_iterations=60, iprofile=0, ssi=None,
-                  max_no_rayleigh_wavenumber=10000.0, reference_albedo=0.15, cos_sza=0.5, sequential_bands=False):
+                  max_no_rayleigh_wavenumber=10000.0, reference_albedo=0.15, cos_sza=0.5, sequential_bands=False,
+                  rank=None, world_size=None, group=None):
     """The main loop of find_g_points.cpp:655-1660 over classic files (shortwave when `ssi[nwav]` is given: solar weights,
     reference albedo 0.15 below max_no_rayleigh_wavenumber (:469, :522, :757-761, :921-923), REFERENCE_COS_SZA = 0.5,
     per-gas min_scaling / max_scaling (:661-667)): per gas the merged background, the gas
@@ -312,15 +313,33 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
     g-point map and the g-points file.
 
     gases: list of dict(name, input=spectrum file, reordering_input=order file, background=[dict(path, scaling, conc), ...],
-                        min_g_points=1, max_g_points=256)."""
+                        min_g_points=1, max_g_points=256).
+
+    Several processes (one per GPU, torch.distributed initialised - RCCL on the GPU box - or explicit rank / world_size):
+    the (gas, band) searches are independent problems (:655, :1152) and are dealt to the processes as contiguous shares of
+    the task table (shard.deal_tasks); a process reads and prepares only the gases of which it searches a band.  Nothing is
+    exchanged while searching.  The per-band results (a few numbers per g point) are gathered on rank 0, which does what
+    follows the gas loop in the reference (:1452-1660: overlap, merged map, file); ONE all-reduce combines the final cost
+    (sum of the g points' errors) and the work counters.  Returns the result dict on rank 0, a summary elsewhere; both hold
+    `cost_sum` and `comp_cost_sum`, identical on every rank.  The g points do not depend on the number of processes."""
     import torch
+    from . import shard
     dev = ctx.device
     nband = len(band_bound1)
-    per_gas, gas_gp = [], []
-    wn = None
-    first_lw_gas = None
+    ngas = len(gases)
+    if rank is None or world_size is None:
+        rank, world_size = shard.world(group)
+    tasks = shard.task_table(range(ngas), nband)
+    mine = [tasks[t] for t in shard.deal_tasks(len(tasks), rank, world_size)]
+    my_bands = {}
+    for gi, b in mine:
+        my_bands.setdefault(gi, []).append(b)
     tol = np.broadcast_to(np.asarray(heating_rate_tolerance, dtype=np.float64), (nband,))           # :762-771
-    for spec in gases:
+    first_lw_gas = None
+    planck_first = None            # the first gas's Planck matrix where this process does not prepare the first gas itself
+    local = []                     # (gas index, band, result dict of the search, medians)
+    for gi in sorted(my_bands):
+        spec = gases[gi]
         s = ncio.read_spectrum(spec["input"], iprofile)
         order = ncio.read_order(spec["reordering_input"])
         wn, dwn = s["wavenumber_cm_1"], s["d_wavenumber_cm_1"]
@@ -334,11 +353,22 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
             bg = api.merge_spectrum(ctx, _to_device(b["optical_depth"], dev), sp, bg)
         if ssi is None:
             # the reference evaluates the Planck function once, on the FIRST gas's reordered grid, and keeps using that
-            # matrix for the later gases (find_g_points.cpp:529, :970-984): reproduced, the first gas stays alive
-            reuse = first_lw_gas.view_ptr("planck_hl")[0] if first_lw_gas is not None else None
+            # matrix for the later gases (find_g_points.cpp:529, :970-984): reproduced.  The process that prepares the first
+            # gas keeps it alive; any other builds the same matrix from the first gas's ordering file and profile
+            reuse = None
+            if gi > 0 and first_lw_gas is not None:
+                reuse = first_lw_gas.view_ptr("planck_hl")[0]
+            elif gi > 0:
+                if planck_first is None:
+                    s0 = ncio.read_spectrum(gases[0]["input"], iprofile, optical_depth=False)
+                    o0 = ncio.read_order(gases[0]["reordering_input"])
+                    planck_first = api.planck_hl_sorted(ctx, s0["temperature_hl"], torch.as_tensor(s0["wavenumber_cm_1"], device=dev),
+                                                        torch.as_tensor(s0["d_wavenumber_cm_1"], device=dev),
+                                                        torch.as_tensor(o0["rank"], device=dev))
+                reuse = planck_first.data_ptr()
             gas = api.GasLW(ctx, s["pressure_hl"], s["temperature_hl"], d_wn, d_dwn, d_rank, _to_device(s["optical_depth"], dev), bg,
                             averaging_method, flux_weight, min_pressure, planck_hl_reuse=reuse)
-            if first_lw_gas is None:
+            if gi == 0:
                 first_lw_gas = gas
             band_albedo = None
         else:
@@ -352,45 +382,79 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
                             torch.as_tensor(albedo, device=dev), spec.get("min_scaling", 1.0), spec.get("max_scaling", 1.0))
         sv_sorted = api.gather_f64(ctx, torch.as_tensor(order["sorting_variable"], device=dev), api.invert_permutation(ctx, d_rank))
         iband = order["band_number"]
-        out = dict(name=spec["name"], n_g_points=[], band_number=[], rank1=[], rank2=[], error=[], sorting_variable=[])
         min_gp = np.broadcast_to(np.asarray(spec.get("min_g_points", 1)), (nband,))                   # per band, :733-754
         max_gp = np.broadcast_to(np.asarray(spec.get("max_g_points", 256)), (nband,))
-        band_idx = [np.nonzero(iband == b)[0] for b in range(nband)]
-        band_opts = [dict(min_g_points=int(min_gp[b]), max_g_points=int(max_gp[b])) for b in range(nband)]
-        if nband > 1 and not sequential_bands:
+        bands = my_bands[gi]
+        band_idx = {b: np.nonzero(iband == b)[0] for b in bands}
+        band_opts = {b: dict(min_g_points=int(min_gp[b]), max_g_points=int(max_gp[b])) for b in bands}
+        if len(bands) > 1 and not sequential_bands:
             # bands side by side, sharing their error batches (ecckd_find_g_bands_ex): same decisions per band; a shortwave
             # band brings its albedo (init_sw(..., band_albedo(jband), ...)) with it
-            side_opts = [dict(o, band_albedo=float(band_albedo[b])) if band_albedo is not None else o for b, o in enumerate(band_opts)]
-            band_res = gas.find_g_bands_ex([int(i[0]) for i in band_idx], [int(i[-1]) for i in band_idx], tol, tolerance_tolerance,
-                                           max_iterations, side_opts)
+            side_opts = [dict(band_opts[b], band_albedo=float(band_albedo[b])) if band_albedo is not None else band_opts[b] for b in bands]
+            band_res = gas.find_g_bands_ex([int(band_idx[b][0]) for b in bands], [int(band_idx[b][-1]) for b in bands],
+                                           np.ascontiguousarray(tol[bands]), tolerance_tolerance, max_iterations, side_opts)
         else:
             band_res = []
-            for b in range(nband):
+            for b in bands:
                 if band_albedo is not None:
                     gas.set_band_albedo(band_albedo[b])                                               # init_sw(..., band_albedo(jband), ...)
                 band_res.append(gas.find_g_band_ex(int(band_idx[b][0]), int(band_idx[b][-1]), float(tol[b]), tolerance_tolerance,
                                                    max_iterations, **band_opts[b]))
-        for b, res in enumerate(band_res):
-            n = len(res["error"])
-            out["n_g_points"].append(n)
-            out["band_number"] += [b] * n
-            out["rank1"] += list(res["rank1"]); out["rank2"] += list(res["rank2"]); out["error"] += list(res["error"])
-            out["sorting_variable"] += list(gas.median_sorting_variable(sv_sorted, res["rank1"], res["rank2"]))
+        for b, res in zip(bands, band_res):
+            med = gas.median_sorting_variable(sv_sorted, res["rank1"], res["rank2"])
+            local.append((gi, b, dict(rank1=[int(v) for v in res["rank1"]], rank2=[int(v) for v in res["rank2"]],
+                                      error=[float(v) for v in res["error"]], status=int(res["status"]),
+                                      comp_cost=float(res["comp_cost"]), sorting_variable=[float(v) for v in med])))
         if gas is not first_lw_gas:
             gas.close()
-        gp = api.gas_g_point(ctx, d_rank, out["rank1"], out["rank2"])
+    if first_lw_gas is not None:
+        first_lw_gas.close()
+    planck_first = None
+    # ---- the only communication: the per-band results to rank 0, one all-reduce of the final cost and the work counter ----
+    cost_local = float(sum(sum(r["error"]) for _, _, r in local))
+    comp_local = float(sum(r["comp_cost"] for _, _, r in local))
+    gathered = shard.gather_to_root(local, group)
+    if world_size > 1:
+        _, comp_sum, cost_sum = shard.reduce_scalars(0.0, comp_local, cost_local, device=dev if _is_nccl(group) else None, group=group)
+    else:
+        comp_sum, cost_sum = comp_local, cost_local
+    if rank != 0:
+        return dict(rank=rank, tasks=mine, cost_sum=cost_sum, comp_cost_sum=comp_sum)
+    by_task = {(gi, b): r for part in gathered for gi, b, r in part}
+    if len(by_task) != len(tasks):
+        raise EcckdError(PROCESSING_ERROR, "find_g_points: %d of %d (gas, band) searches came back" % (len(by_task), len(tasks)))
+    # ---- what follows the gas loop (:1452-1660) ----
+    per_gas, gas_gp = [], []
+    wn = None
+    for gi, spec in enumerate(gases):
+        order = ncio.read_order(spec["reordering_input"])
+        wn = order["wavenumber"]
+        out = dict(name=spec["name"], n_g_points=[], band_number=[], rank1=[], rank2=[], error=[], sorting_variable=[],
+                   status=[], comp_cost=[])
+        for b in range(nband):
+            r = by_task[(gi, b)]
+            n = len(r["error"])
+            out["n_g_points"].append(n)
+            out["band_number"] += [b] * n
+            out["rank1"] += r["rank1"]; out["rank2"] += r["rank2"]; out["error"] += r["error"]
+            out["sorting_variable"] += r["sorting_variable"]
+            out["status"].append(r["status"]); out["comp_cost"].append(r["comp_cost"])
+        gp = api.gas_g_point(ctx, torch.as_tensor(order["rank"], device=dev), out["rank1"], out["rank2"])
         out["g_point"] = gp.cpu().numpy()
         gas_gp.append(gp)
         per_gas.append(out)
-    if first_lw_gas is not None:
-        first_lw_gas.close()
     ng, band_number, g_min, g_max = api.overlap_g_points([g["n_g_points"] for g in per_gas],
                                                          [np.asarray(g["sorting_variable"]) for g in per_gas])
     g_point, n_unassigned = api.merge_g_points(ctx, gas_gp, g_min, g_max)
     for k, g in enumerate(per_gas):
         g["g_min"], g["g_max"] = g_min[k], g_max[k]
     result = dict(ng=ng, band_number=band_number, g_point=g_point.cpu().numpy(), n_unassigned=n_unassigned, gases=per_gas,
-                  wavenumber=wn)
+                  wavenumber=wn, cost_sum=cost_sum, comp_cost_sum=comp_sum, rank=0, tasks=mine)
     if output_path is not None:
         ncio.write_g_points(output_path, band_bound1, band_bound2, band_number, per_gas, wn, result["g_point"])
     return result
+
+
+def _is_nccl(group=None):
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"

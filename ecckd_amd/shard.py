@@ -17,6 +17,42 @@ def shard_tasks(ntasks, rank, world_size):
     return list(range(rank, ntasks, world_size))
 
 
+def deal_tasks(ntasks, rank, world_size):
+    """Indices of the (gas, band) tasks owned by `rank` when the task table (gas outer, band inner, the order of the
+    reference's loops) is cut into `world_size` CONTIGUOUS shares whose sizes differ by at most one: a process then touches
+    as few gases as possible - it reads a gas's spectra only if it searches one of its bands - and the bands of a gas that
+    it does own are searched side by side in one launch train.  An interval's error does not depend on what else is in
+    its batch (ecckd_calc_error_multi), so every band ends at the same g points however the table is cut."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, extra = divmod(ntasks, world_size)
+    begin = rank * base + min(rank, extra)
+    return list(range(begin, begin + base + (1 if rank < extra else 0)))
+
+
+def world(group=None):
+    """(rank, world_size) of the torch.distributed job, (0, 1) when there is none."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 0, 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def gather_to_root(obj, group=None, dst=0):
+    """The ranks' picklable results on rank `dst`, in rank order (None elsewhere); [obj] without a job.  The only data
+    the (gas, band) searches hand back: a few numbers per g point."""
+    rank, ws = world(group)
+    if ws == 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * ws if rank == dst else None
+    dist.gather_object(obj, out, dst=dst, group=group)
+    return out
+
+
 def task_table(gases, nband):
     """[(gas, band), ...] in the order the reference loops (gas outer, band inner)."""
     return [(g, b) for g in gases for b in range(nband)]

@@ -157,6 +157,15 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav,
                         const void* d_od, int od_type, size_t src_stride,
                         int averaging_method, double flux_weight, double min_pressure,
                         const double* d_planck_hl_reuse, ecckd_gas** gas);
+
+/* The Planck matrix alone, d_planck_hl[nlay+1][nwav] in the order given by d_rank: bit-identical to the "planck_hl" view
+ * of a gas created with the same ordering and temperature profile.  The reference evaluates the matrix for the FIRST gas
+ * and reuses it for every later one (find_g_points.cpp:529, :970-984); a process that searches only later gases (the
+ * (gas, band) tasks are dealt to one process per GPU) builds it from the first gas's ordering file with this call and
+ * passes it as d_planck_hl_reuse. */
+int ecckd_planck_hl_sorted_dev(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_temperature_hl,
+                               const double* d_wavenumber, const double* d_d_wavenumber, const int32_t* d_rank,
+                               double* d_planck_hl);
 /* Shortwave twin (find_g_points.cpp do_sw branches: radiative_transfer_direct_sw :1003-1006,
  * the two scaled truth fields of the total-transmission method :1008-1034, :1060-1090).
  * d_ssi and d_albedo (NULL = direct beam only) are per-wavenumber arrays in ORIGINAL order;

@@ -33,7 +33,11 @@ def _worker(rank, world, port, q):
     cost = sum(0.01 * (t + 1) for t in mine)
     elapsed = 1.0 + 0.5 * rank
     out = shard.reduce_scalars(elapsed, passes, cost)
-    q.put((rank, mine, out))
+    # the driver's own dealing: contiguous shares of the table, results gathered on rank 0
+    dealt = [tasks[t] for t in shard.deal_tasks(len(tasks), rank, world)]
+    assert shard.world() == (rank, world)
+    gathered = shard.gather_to_root([(g, b, {"error": [0.5 * b]}) for g, b in dealt])
+    q.put((rank, mine, out, dealt, gathered))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,7 +60,13 @@ def test_two_rank_sharding_and_single_allreduce():
     assert set(res[0][1]).isdisjoint(res[1][1])
     exp_passes = sum(10.0 + (t % 7) for t in range(78))
     exp_cost = sum(0.01 * (t + 1) for t in range(78))
-    for _, _, (tmax, passes, cost) in res:
+    # contiguous dealing: 39 tasks each, rank 0 = composite, h2o, o3; rank 1 = co2, ch4, n2o; nothing twice, nothing missing
+    assert [len(r[3]) for r in res] == [39, 39]
+    assert {g for g, _ in res[0][3]} == {"composite", "h2o", "o3"} and {g for g, _ in res[1][3]} == {"co2", "ch4", "n2o"}
+    assert res[1][4] is None and len(res[0][4]) == 2
+    got = [(g, b) for part in res[0][4] for g, b, _ in part]
+    assert got == [(g, b) for g in ["composite", "h2o", "o3", "co2", "ch4", "n2o"] for b in range(13)]
+    for _, _, (tmax, passes, cost), _, _ in res:
         assert tmax == 1.5
         assert passes == exp_passes
         assert cost == pytest.approx(exp_cost, rel=1e-15)
@@ -154,3 +164,19 @@ def test_column_range_properties():
             assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard.shard_scene_columns(dict(pressure_hl=np.zeros((1, 3))), 1, 2)
+
+
+def test_deal_tasks_contiguous_and_complete():
+    from ecckd_amd import shard
+    for ntasks, world in ((104, 8), (78, 8), (9, 2), (3, 8), (13, 1), (0, 4)):
+        parts = [shard.deal_tasks(ntasks, r, world) for r in range(world)]
+        assert sum(parts, []) == list(range(ntasks))                              # every task once, table order kept
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    # 8 gases x 13 bands on 8 ranks: one gas per rank; 6 gases: a rank touches at most two gases
+    table = shard.task_table(range(8), 13)
+    assert all({table[t][0] for t in shard.deal_tasks(104, r, 8)} == {r} for r in range(8))
+    table = shard.task_table(range(6), 13)
+    assert all(len({table[t][0] for t in shard.deal_tasks(78, r, 8)}) <= 2 for r in range(8))
+    with pytest.raises(ValueError):
+        shard.deal_tasks(10, 3, 3)
+    assert shard.world() == (0, 1) and shard.gather_to_root("x") == ["x"]
