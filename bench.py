@@ -12,6 +12,15 @@ Metric = wavenumber-points/s = nwav * (1 + N_pass) / t, where N_pass is the refe
 work counter total_comp_cost = sum of (bound2 - bound1) over all calc_error calls
 (find_g_points.cpp:320).  Ranks process independent gases (weak scaling, no data-path
 collective); rank 0 prints ONE JSON line.
+
+--config 1 (default)  BASELINE configs[1], the configuration the metric is quoted on: as above.
+--config 3            BASELINE configs[3]: ONE find_g_points job over the 13 narrow longwave bands (test/config.h:141-142)
+                      and 8 gases incl. the CFCs at nwav = 7.2e6, its 104 (gas, band) searches dealt to the ranks
+                      (pipeline.find_g_points_resident: contiguous shares of the task table, results gathered on rank 0
+                      for the overlap of the gases' g points, one all-reduce of the final cost).  Strong scaling.
+--config 4            BASELINE configs[4]: optimize_lut, longwave and shortwave, 8 scenarios x 50 profiles (x 3 solar
+                      zenith angles in the shortwave), nx ~ 3e5, training profiles sharded over the ranks with one
+                      all-reduce of [gradient, cost] per evaluation.  Metric: L-BFGS iterations/s.
 """
 import argparse
 import json
@@ -46,18 +55,31 @@ def parse():
     # all-reduce of [gradient, cost] per evaluation).  Off by default so that the driver's scaling runs time the
     # headline metric only.
     ap.add_argument("--lut-dist", action="store_true")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4])
+    # synthetic spectra: "lines" = CKDMIP-like line list (>= 1e4 lines in vibration-rotation bands, synthetic.optical_depth_lines);
+    # "legacy" = the 32 isolated Lorentz lines of round 1
+    ap.add_argument("--spectra", default="lines", choices=["lines", "legacy"])
+    ap.add_argument("--nlines", type=int, default=12000)
+    ap.add_argument("--ngas", type=int, default=8)                       # config 3
+    ap.add_argument("--narrow-tolerance", type=float, default=0.013)     # narrow bands, test/do_all_lw.sh:46-60
     return ap.parse_args()
 
 
-def make_inputs(xp, nwav, nlay, seed, device=None):
+def make_inputs(xp, nwav, nlay, seed, device=None, spectra="lines", nlines=12000, column_scale=30.0):
     """Synthetic target gas + background (both FLOAT like the CKDMIP spectra files)."""
     from ecckd_amd import synthetic as syn
     p = syn.pressure_grid(nlay)
     wn_h, dwn_h = syn.wavenumber_grid(nwav)
-    kw = dict(device=device, chunk=1 << 20) if device is not None else {}
     wn = xp.as_tensor(wn_h, device=device) if device is not None else wn_h
-    od = syn.optical_depth(xp, p, wn, seed, nlines=32, **kw)
-    bg = syn.optical_depth(xp, p, wn, seed + 1000, nlines=24, column_scale=3.0, zero_fraction=0.0, **kw)
+    if spectra == "legacy":
+        kw = dict(device=device, chunk=1 << 20) if device is not None else {}
+        od = syn.optical_depth(xp, p, wn, seed, nlines=32, column_scale=column_scale, **kw)
+        bg = syn.optical_depth(xp, p, wn, seed + 1000, nlines=24, column_scale=3.0, zero_fraction=0.0, **kw)
+    else:
+        kw = dict(device=device) if device is not None else {}
+        od = syn.optical_depth_lines(xp, p, wn, seed, nlines=nlines, column_scale=column_scale, **kw)
+        bg = syn.optical_depth_lines(xp, p, wn, seed + 1000, nlines=max(nlines // 3, 1), column_scale=3.0, zero_fraction=0.0,
+                                     nclusters=5, **kw)
     return p, wn_h, dwn_h, od, bg
 
 
@@ -137,33 +159,124 @@ def sw_find_g_bench(ctx, nwav=3_300_000, nlay=54):
     return out
 
 
-def lut_opt_bench(ctx, iterations, sharded=False, rank=0, world=1):
+GAS_NAMES = ["composite", "h2o", "o3", "co2", "ch4", "n2o", "cfc11", "cfc12"]      # test/create_lut_lw.sh:143
+GAS_COLUMN_SCALE = [30.0, 100.0, 10.0, 50.0, 5.0, 5.0, 0.5, 0.5]
+
+
+def config3_bench(args, ctx, dist, rank, world):
+    """BASELINE configs[3]: one find_g_points job, 13 narrow longwave bands x `ngas` gases, nwav = 7.2e6, its (gas, band)
+    searches dealt to the ranks.  One step = for every gas this rank searches a band of: reorder (K1 key + K3 per-band sort),
+    gas preparation (K4), the side-by-side searches of its bands (K5); then the gather of the results on rank 0, the overlap
+    of the gases' g points and the merged g-point map there.  Strong scaling: the job is the same for every N."""
+    import torch
+    from ecckd_amd import api, pipeline, shard, synthetic as syn
+    dev = ctx.device
+    nwav, nlay, ngas = args.nwav, args.nlay, args.ngas
+    names = GAS_NAMES[:ngas]
+    b1, b2 = syn.LW_NARROW_BANDS
+    nband = len(b1)
+    p = syn.pressure_grid(nlay)
+    wn_h, dwn_h = syn.wavenumber_grid(nwav)
+    wn, dwn = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
+    _, begin, end = api.band_ranges(wn_h, b1, b2)
+    t_ideal, t_file = api.idealised_temperature(p), syn.temperature_profile(p)
+    tasks = shard.task_table(range(ngas), nband)
+    mine = [tasks[t] for t in shard.deal_tasks(len(tasks), rank, world)]
+    my_gases = sorted({g for g, _ in mine})
+    spectra = {}
+    for gi in my_gases:                                    # resident before the timed region (the tools read them from files)
+        _, _, _, od, bg = make_inputs(torch, nwav, nlay, syn.SEED_BASE + 301 + 17 * gi, device=dev, spectra=args.spectra,
+                                      nlines=args.nlines, column_scale=GAS_COLUMN_SCALE[gi % len(GAS_COLUMN_SCALE)])
+        spectra[gi] = (od, bg)
+
+    def reorder(od):
+        key, _ = api.reorder_key_lw(ctx, p, t_ideal, wn, dwn, od, 0.5)
+        rnk, _ = api.stable_argsort_bands(ctx, key, begin, end, want_ordered=False)
+        return key, rnk
+
+    first_order = None
+    if 0 not in my_gases and my_gases:
+        # stands for the first gas's ordering FILE, which a process that searches none of its bands reads for the shared
+        # Planck matrix (find_g_points.cpp:529, :970-984): made once, outside the timed region
+        _, _, _, od0, _ = make_inputs(torch, nwav, nlay, syn.SEED_BASE + 301, device=dev, spectra=args.spectra, nlines=args.nlines,
+                                      column_scale=GAS_COLUMN_SCALE[0])
+        first_order = dict(temperature_hl=t_file, wn=wn, dwn=dwn, rank=reorder(od0)[1])
+        del od0
+
+    def load_gas(gi):
+        od, bg = spectra[gi]
+        key, rnk = reorder(od)                            # the gas's reorder_spectrum step: part of the timed work
+        return dict(pressure_hl=p, temperature_hl=t_file, wn=wn, dwn=dwn, rank=rnk, od=od, bg=bg, sorting_variable=key,
+                    band_begin=begin, band_end=end, min_g_points=np.ones(nband, dtype=int), max_g_points=np.full(nband, 256))
+
+    out = {}
+
+    def step():
+        res = pipeline.find_g_points_resident(ctx, names, load_gas, nband, args.narrow_tolerance, (lambda: first_order),
+                                              "transmission", 0.0, 0.0, args.tolerance_tolerance, args.max_iterations,
+                                              rank=rank, world_size=world)
+        out.update(res)
+        return res["points"]
+
+    return step, out, dict(ngas=ngas, nband=nband, tasks=len(tasks), tasks_this_rank=len(mine), gases_this_rank=len(my_gases))
+
+
+def ckd_model_sw(model, seed=0):
+    """Shortwave variant of synthetic.ckd_model: solar irradiance and Rayleigh scattering per g point, no Planck table."""
+    m = dict(model, gases=[dict(g) for g in model["gases"]])
+    ng = m["planck_function"].shape[1]
+    rs = np.random.RandomState(seed + 99)
+    ssi = rs.uniform(0.5, 1.5, ng)
+    m["solar_irradiance"] = 1340.0 * ssi / ssi.sum()
+    m["rayleigh_molar_scattering"] = 10.0 ** rs.uniform(-7.0, -5.5, ng)
+    m["planck_function"] = None
+    m["temperature_planck"] = None
+    m["ng"] = ng
+    for g in m["gases"]:
+        for k in ("molar_abs", "min_molar_abs", "max_molar_abs"):
+            g[k] = g[k] * 0.002
+    return m
+
+
+def lut_opt_bench(ctx, iterations, sharded=False, rank=0, world=1, sw=False):
     """Second half of the headline metric: LUT-optimisation iterations/s (solve_adept.cpp:295-299 logs one
     line per L-BFGS iteration).  Synthetic CKD model with the shapes of configs[4]: ng = 64, 6 x 53 (T, p)
     grid, H2O look-up table with 12 mole fractions (nx ~ 3e5), 8 scenarios x 50 columns x 54 layers."""
     from ecckd_amd import api, synthetic as syn
     model = syn.ckd_model(ng=64, nt=6, np_=53, nband=13, seed=11, nconc=12)
     truth = syn.ckd_model(ng=64, nt=6, np_=53, nband=13, seed=11, nconc=12)
+    if sw:
+        model, truth = ckd_model_sw(model, 11), ckd_model_sw(truth, 11)
     rs = np.random.RandomState(12)
     for g in truth["gases"]:
         g["molar_abs"] = g["molar_abs"] * np.exp(0.25 * rs.normal(size=g["molar_abs"].shape))
     scenes = syn.ckd_scenes(model, nscene=8, ncol=50, nlay=54, seed=13 + 100 * rank)   # sharded: every rank its own profiles
-    cfg = dict(flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, prior_error=4.0, pressure_corr=0.95,
-               temperature_corr=0.95, conc_corr=0.95)       # test/optimize_lut_lw.sh:55 final pass
+    if not sw:
+        cfg = dict(flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, prior_error=4.0, pressure_corr=0.95,
+                   temperature_corr=0.95, conc_corr=0.95)       # test/optimize_lut_lw.sh:55 final pass
+    else:
+        cfg = dict(flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, prior_error=2.0, pressure_corr=0.8,
+                   temperature_corr=0.8, conc_corr=0.8)         # test/optimize_lut_sw.sh:75
+        mu0 = (1.0, 0.5, 0.1)                                   # three zenith angles per profile (lbl_fluxes.cpp:82)
+        rep = lambda a: np.ascontiguousarray(np.repeat(a, len(mu0), axis=0))
+        scenes = [dict(pressure_hl=rep(s["pressure_hl"]), temperature_hl=rep(s["temperature_hl"]), vmr_fl=rep(s["vmr_fl"]),
+                       gas_present=s["gas_present"], mu0=np.tile(np.asarray(mu0), s["pressure_hl"].shape[0]), tsi=1361.0,
+                       albedo=np.full(13, 0.15)) for s in scenes]
     ib = model["iband_per_g"]
     nhl = 55
+    ncs = scenes[0]["pressure_hl"].shape[0]                   # columns per scene: 50, or 150 with the zenith angles
     for s in scenes:                                         # placeholders, replaced by the truth model's fluxes
-        s["flux_dn"] = np.zeros((50, nhl, 13))
-        s["flux_up"] = np.zeros((50, nhl, 13))
+        s["flux_dn"] = np.zeros((ncs, nhl, 13))
+        s["flux_up"] = np.zeros((ncs, nhl, 13))
     t_opt = api.Optimizer(ctx, truth, scenes, **cfg)
     _, fl = t_opt.forward(t_opt.initial_state())
     t_opt.close()
     band = np.stack([fl[..., ib == b].sum(-1) for b in range(13)], axis=-1)   # (ncol, 2, nhl, nband)
     c0 = 0
     for s in scenes:
-        s["flux_dn"] = np.ascontiguousarray(band[c0:c0 + 50, 0])
-        s["flux_up"] = np.ascontiguousarray(band[c0:c0 + 50, 1])
-        c0 += 50
+        s["flux_dn"] = np.ascontiguousarray(band[c0:c0 + ncs, 0])
+        s["flux_up"] = np.ascontiguousarray(band[c0:c0 + ncs, 1])
+        c0 += ncs
     opt = api.Optimizer(ctx, model, scenes, **cfg)
     if sharded:
         opt.set_allreduce()
@@ -178,13 +291,199 @@ def lut_opt_bench(ctx, iterations, sharded=False, rank=0, world=1):
         opt.cost_grad(x0)
     dt_eval = (time.perf_counter() - t1) / 20
     out = {"iters_per_s": res["iterations"] / dt, "iterations": res["iterations"], "nx": opt.nx,
-           "cells": world * 8 * 50 * 54 * 64, "cost_grad_ms": dt_eval * 1e3, "J0": J0, "J_final": res["cost"],
-           "status": res["status"]}
+           "cells": world * 8 * ncs * 54 * 64, "cost_grad_ms": dt_eval * 1e3, "J0": J0, "J_final": res["cost"],
+           "status": res["status"], "region": "shortwave" if sw else "longwave", "profiles_per_rank": 8 * ncs}
     if sharded:
         out["ranks"] = world
         out["allreduce_bytes_per_evaluation"] = (opt.nx + 1) * 8
     opt.close()
     return out
+
+
+def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
+    """configs[1] (default; weak scaling: every rank its own single-gas, single-band job) and configs[3] (one 13-band,
+    8-gas job dealt to the ranks; strong scaling): warm-up, K timed steps between barriers, ONE all-reduce of
+    [elapsed, points, final cost], the JSON line on rank 0."""
+    import torch
+    from ecckd_amd import api, synthetic as syn
+    dev = ctx.device
+    nwav, nlay = args.nwav, args.nlay
+    info = {}
+    extra = {}
+    if args.config == 3:
+        step3, info, extra = config3_bench(args, ctx, dist, rank, world)
+        od = None
+        def step():
+            return step3() / nwav             # passes over a 7.2e6-point spectrum done by this rank
+    else:
+        # each rank owns a different synthetic gas: independent (gas, band) shards, SURVEY.md 8e
+        p, wn_h, dwn_h, od, bg = make_inputs(torch, nwav, nlay, syn.SEED_BASE + 1 + 17 * rank, device=dev, spectra=args.spectra,
+                                             nlines=args.nlines)
+        wn = torch.as_tensor(wn_h, device=dev)
+        dwn = torch.as_tensor(dwn_h, device=dev)
+        t_ideal = api.idealised_temperature(p)
+        t_file = syn.temperature_profile(p)
+        key = torch.empty(nwav, dtype=torch.float64, device=dev)
+        col = torch.empty(nwav, dtype=torch.float64, device=dev)
+        rnk = torch.empty(nwav, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+        def step():
+            api.reorder_key_lw(ctx, p, t_ideal, wn, dwn, od, 0.5, key=key, col_od=col)
+            api.stable_argsort_bands(ctx, key, [0], [nwav - 1], rank=rnk, want_ordered=False, sync=False)
+            gas = api.GasLW(ctx, p, t_file, wn, dwn, rnk, od, bg, "transmission", flux_weight=0.0)
+            st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance,
+                                           args.max_iterations)
+            gas.close()
+            info.update(ng=len(e), status=st, comp_cost=cc, cost_sum=float(np.sum(e)))
+            return 1.0 + cc  # passes over the spectrum in this step
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    passes = 0.0
+    for _ in range(args.steps):
+        passes += step()
+    barrier()
+    dt = time.perf_counter() - t0
+    rt_calls, rt_ms, rt_pts = ctx.profile_get("k_rt_lw_bb")
+    k1_calls, k1_ms, k1_pts = ctx.profile_get("k_reorder_key_lw")
+    # the single collective of the path: max elapsed, total passes, total final cost (RCCL over xGMI)
+    from ecckd_amd import shard
+    dt, passes, total_cost = shard.reduce_scalars(dt, passes, info.get("cost_sum", 0.0), device=dev)
+
+    # What a caller that hands over HOST buffers pays on top (the tools do: spectra come from NetCDF files): the FLOAT
+    # target and background spectra of one step over PCIe from pinned memory.  Reported beside `value`, never as `value`.
+    h2d_ms = None
+    out = None
+    if rank == 0 and world == 1 and args.config == 1:
+        try:
+            host = torch.empty((nlay, nwav), dtype=torch.float32).pin_memory()
+            host.copy_(od.cpu() if od.dtype == torch.float32 else od.float().cpu())
+            dst = torch.empty_like(od if od.dtype == torch.float32 else od.float())
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):                       # target + background
+                dst.copy_(host, non_blocking=True)
+            torch.cuda.synchronize()
+            h2d_ms = (time.perf_counter() - t1) * 1e3
+            del host, dst
+        except RuntimeError:
+            h2d_ms = None
+
+    lut_sharded = None
+    if args.lut_dist and use_dist and not args.no_lut_opt:
+        lut_sharded = lut_opt_bench(ctx, args.lut_opt_iterations, sharded=True, rank=rank, world=world)
+
+    if rank == 0:
+        points = nwav * passes
+        # dominant kernel: K5c k_rt_lw_bb.  Algorithmic bytes per point and pass (SURVEY 8d, B5):
+        # planck (nlay+1) + background optical depth (nlay) rows of f64 = (2*nlay+1)*8 B.
+        rt_bytes_per_pt = (2 * nlay + 1) * 8
+        rt_gbs = rt_pts * rt_bytes_per_pt / (rt_ms * 1e-3) / 1e9 if rt_ms > 0 else 0.0
+        k1_bytes_per_pt = nlay * 4 + 32                  # FLOAT optical depths
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+        # WRITE_SIZE collected separately; 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md section HBM),
+        # scaled to this run's points per launch
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_k_rt_lw_bb.json")
+        if os.path.exists(tpath) and rt_calls:
+            with open(tpath) as f:
+                traffic = json.load(f)["corrected_bytes_per_point"] * rt_pts / rt_calls
+        out = {
+            "metric": "wavenumber-points/s (LW reorder+find_g)",
+            "value": points / dt,
+            "unit": "wavenumber-points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak" if args.config == 1 else "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": ({"workload": "configs[1]: LW FSCK (1 band 0-3260 cm-1), 1 synthetic gas + background per "
+                                    "rank, nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging transmission"
+                                    % (nwav, nlay, args.tolerance),
+                        "n_pass_per_step": (passes / args.steps / world) - 1.0, "ng": info.get("ng"),
+                        "search_status": info.get("status"), "final_cost_sum_K_per_day": total_cost}
+                       if args.config == 1 else
+                       {"workload": "configs[3]: ONE find_g_points job, 13 narrow LW bands (test/config.h:141-142) x %d gases "
+                                    "(%s), nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging transmission; the %d "
+                                    "(gas, band) searches dealt to the ranks in contiguous shares, results gathered on "
+                                    "rank 0 (overlap of the gases' g points, merged g-point map)"
+                                    % (extra["ngas"], " ".join(GAS_NAMES[:extra["ngas"]]), nwav, nlay, args.narrow_tolerance,
+                                       extra["tasks"]),
+                        "passes_over_the_spectrum_per_step": passes / args.steps, "ng_merged": info.get("ng"),
+                        "ng_per_gas": [int(sum(g["n_g_points"])) for g in info.get("gases", [])],
+                        "searches_not_converged": int(sum(st != 0 for g in info.get("gases", []) for st in g["status"])),
+                        "n_unassigned": info.get("n_unassigned"), "final_cost_sum_K_per_day": total_cost,
+                        "tasks_on_rank_0": extra["tasks_this_rank"]}),
+            "spectra": {"generator": args.spectra, "lines_per_gas": args.nlines if args.spectra == "lines" else 32},
+            "search": {"error_batches_per_step": rt_calls / max(args.steps, 1),
+                       "points_per_batch": rt_pts / max(rt_calls, 1)},
+            "roofline": {"bound": "hbm", "kernel": "k_rt_lw_bb", "achieved": rt_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": rt_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": rt_bytes_per_pt * rt_pts / max(rt_calls, 1),
+                         "launches": rt_calls, "avg_launch_ms": rt_ms / max(rt_calls, 1),
+                         "algorithmic_bytes_per_point": rt_bytes_per_pt,
+                         "points_per_launch": rt_pts / max(rt_calls, 1),
+                         "share_of_step_time": rt_ms * 1e-3 / dt,
+                         "k_reorder_key_lw": {"avg_launch_ms": k1_ms / max(k1_calls, 1),
+                                              "achieved": k1_pts * k1_bytes_per_pt / max(k1_ms * 1e-3, 1e-12) / 1e9,
+                                              "algorithmic_bytes_per_point": k1_bytes_per_pt}},
+        }
+        if h2d_ms is not None:
+            step_ms = dt * 1e3 / args.steps
+            out["pcie_inclusive"] = {"h2d_ms_per_step": h2d_ms, "bytes_per_step": 2 * nlay * nwav * 4,
+                                     "value": points / (dt + args.steps * h2d_ms * 1e-3), "unit": "wavenumber-points/s",
+                                     "note": "FLOAT target + background spectra uploaded from pinned host memory, not overlapped"}
+        if lut_sharded is not None:
+            out["lut_opt"] = lut_sharded
+        elif world == 1 and not args.no_lut_opt and args.config == 1:
+            out["lut_opt"] = lut_opt_bench(ctx, args.lut_opt_iterations)
+        if world == 1 and not args.no_sw and args.config == 1:
+            out["sw_find_g"] = sw_find_g_bench(ctx)
+        if world == 1 and not args.no_cpu and args.config == 1:
+            pts, cdt, cng, ccost, search = cpu_baseline(args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance,
+                                                        args.tolerance_tolerance, args.max_iterations)
+            out["cpu_baseline"] = {"value": pts / cdt, "unit": "wavenumber-points/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+                                   "sample": "oracle reorder + gas prep + %s over oracle calc_error, nwav=%d "
+                                             "(same generator, ng=%d, N_pass=%.1f, %.1f s)"
+                                             % (search, args.cpu_sample, cng, ccost, cdt)}
+    return out
+
+
+def config4_main(args, ctx, dist, rank, world, barrier):
+    """BASELINE configs[4]: optimize_lut on the shapes of the LW + SW training (8 scenarios x 50 profiles, x 3 zenith
+    angles in the shortwave; ng = 64, 6 x 53 (T, p) grid, 12 H2O mole fractions: nx ~ 3e5), the training profiles sharded
+    over the ranks: every rank holds its own 8 x 50 profiles (weak scaling in the profiles) and ONE all-reduce of
+    [gradient, cost] per evaluation keeps the ranks' L-BFGS states identical.  A step = `--lut-opt-iterations` L-BFGS
+    iterations of the longwave problem followed by as many of the shortwave one."""
+    sharded = dist is not None
+    res = {}
+    t = {}
+    for name, sw in (("longwave", False), ("shortwave", True)):
+        barrier()
+        t0 = time.perf_counter()
+        res[name] = lut_opt_bench(ctx, args.lut_opt_iterations, sharded=sharded, rank=rank, world=world, sw=sw)
+        barrier()
+        t[name] = time.perf_counter() - t0
+    if rank != 0:
+        return None
+    its = sum(r["iterations"] for r in res.values())
+    secs = sum(r["iterations"] / r["iters_per_s"] for r in res.values())
+    return {"metric": "LUT-opt iterations/s", "value": its / secs, "unit": "iterations/s", "n_gpus": world, "steps": 1, "warmup": 0,
+            "ms_per_step": secs * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[4]: optimize_lut LW then SW, 8 scenarios x 50 profiles per rank (x 3 solar zenith "
+                                   "angles in the SW), ng=64, nx=%d, profile-sharded with one all-reduce of [gradient, cost] "
+                                   "per evaluation" % res["longwave"]["nx"],
+                       "iterations_per_region": args.lut_opt_iterations},
+            "roofline": None, "cpu_baseline": None, "longwave": res["longwave"], "shortwave": res["shortwave"],
+            "setup_inclusive_seconds": t}
 
 
 def main():
@@ -211,27 +510,7 @@ def main():
     ctx = api.Context(local_rank)
     dev = ctx.device
     nwav, nlay = args.nwav, args.nlay
-    # each rank owns a different synthetic gas: independent (gas, band) shards, SURVEY.md 8e
-    p, wn_h, dwn_h, od, bg = make_inputs(torch, nwav, nlay, syn.SEED_BASE + 1 + 17 * rank, device=dev)
-    wn = torch.as_tensor(wn_h, device=dev)
-    dwn = torch.as_tensor(dwn_h, device=dev)
-    t_ideal = api.idealised_temperature(p)
-    t_file = syn.temperature_profile(p)
-    key = torch.empty(nwav, dtype=torch.float64, device=dev)
-    col = torch.empty(nwav, dtype=torch.float64, device=dev)
-    rnk = torch.empty(nwav, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-    info = {}
-
-    def step():
-        api.reorder_key_lw(ctx, p, t_ideal, wn, dwn, od, 0.5, key=key, col_od=col)
-        api.stable_argsort_bands(ctx, key, [0], [nwav - 1], rank=rnk, want_ordered=False, sync=False)
-        gas = api.GasLW(ctx, p, t_file, wn, dwn, rnk, od, bg, "transmission", flux_weight=0.0)
-        st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance,
-                                       args.max_iterations)
-        gas.close()
-        info.update(ng=len(e), status=st, comp_cost=cc, cost=float(np.sum(e)))
-        return 1.0 + cc  # passes over the spectrum in this step
+    out = None
 
     def barrier():
         ctx.synchronize()
@@ -239,106 +518,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.profile_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    passes = 0.0
-    for _ in range(args.steps):
-        passes += step()
-    barrier()
-    dt = time.perf_counter() - t0
-    rt_calls, rt_ms, rt_pts = ctx.profile_get("k_rt_lw_bb")
-    k1_calls, k1_ms, k1_pts = ctx.profile_get("k_reorder_key_lw")
-    # the single collective of the path: max elapsed, total passes, total final cost (RCCL over xGMI)
-    from ecckd_amd import shard
-    dt, passes, total_cost = shard.reduce_scalars(dt, passes, info.get("cost", 0.0), device=dev)
-
-    # What a caller that hands over HOST buffers pays on top (the tools do: spectra come from NetCDF files): the FLOAT
-    # target and background spectra of one step over PCIe from pinned memory.  Reported beside `value`, never as `value`.
-    h2d_ms = None
-    if rank == 0 and world == 1:
-        try:
-            host = torch.empty((nlay, nwav), dtype=torch.float32).pin_memory()
-            host.copy_(od.cpu() if od.dtype == torch.float32 else od.float().cpu())
-            dst = torch.empty_like(od if od.dtype == torch.float32 else od.float())
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(2):                       # target + background
-                dst.copy_(host, non_blocking=True)
-            torch.cuda.synchronize()
-            h2d_ms = (time.perf_counter() - t1) * 1e3
-            del host, dst
-        except RuntimeError:
-            h2d_ms = None
-
-    lut_sharded = None
-    if args.lut_dist and use_dist and not args.no_lut_opt:
-        lut_sharded = lut_opt_bench(ctx, args.lut_opt_iterations, sharded=True, rank=rank, world=world)
-
-    if rank == 0:
-        points = nwav * passes
-        # dominant kernel: K5c k_rt_lw_bb.  Algorithmic bytes per point and pass:
-        # planck (nlay+1) + background optical depth (nlay) rows of f64 = (2*nlay+1)*8 B.
-        rt_bytes_per_pt = (2 * nlay + 1) * 8
-        rt_gbs = rt_pts * rt_bytes_per_pt / (rt_ms * 1e-3) / 1e9 if rt_ms > 0 else 0.0
-        k1_bytes_per_pt = nlay * od.element_size() + 32
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-        # WRITE_SIZE collected separately; 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md section HBM),
-        # scaled to this run's points per launch
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_k_rt_lw_bb.json")
-        if os.path.exists(tpath) and rt_calls:
-            with open(tpath) as f:
-                traffic = json.load(f)["corrected_bytes_per_point"] * rt_pts / rt_calls
-        out = {
-            "metric": "wavenumber-points/s (LW reorder+find_g)",
-            "value": points / dt,
-            "unit": "wavenumber-points/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: LW FSCK (1 band 0-3260 cm-1), 1 synthetic gas + background per "
-                                   "rank, nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging transmission"
-                                   % (nwav, nlay, args.tolerance),
-                       "n_pass_per_step": (passes / args.steps / world) - 1.0, "ng": info.get("ng"),
-                       "search_status": info.get("status"), "final_cost_sum_K_per_day": total_cost},
-            "roofline": {"bound": "hbm", "kernel": "k_rt_lw_bb", "achieved": rt_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": rt_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": rt_bytes_per_pt * rt_pts / max(rt_calls, 1),
-                         "launches": rt_calls, "avg_launch_ms": rt_ms / max(rt_calls, 1),
-                         "algorithmic_bytes_per_point": rt_bytes_per_pt,
-                         "points_per_launch": rt_pts / max(rt_calls, 1),
-                         "share_of_step_time": rt_ms * 1e-3 / dt,
-                         "k_reorder_key_lw": {"avg_launch_ms": k1_ms / max(k1_calls, 1),
-                                              "achieved": k1_pts * k1_bytes_per_pt / max(k1_ms * 1e-3, 1e-12) / 1e9,
-                                              "algorithmic_bytes_per_point": k1_bytes_per_pt}},
-        }
-        if h2d_ms is not None:
-            step_ms = dt * 1e3 / args.steps
-            out["pcie_inclusive"] = {"h2d_ms_per_step": h2d_ms, "bytes_per_step": 2 * nlay * nwav * 4,
-                                     "value": points / (dt + args.steps * h2d_ms * 1e-3), "unit": "wavenumber-points/s",
-                                     "note": "FLOAT target + background spectra uploaded from pinned host memory, not overlapped"}
-        if lut_sharded is not None:
-            out["lut_opt"] = lut_sharded
-        elif world == 1 and not args.no_lut_opt:
-            out["lut_opt"] = lut_opt_bench(ctx, args.lut_opt_iterations)
-        if world == 1 and not args.no_sw:
-            out["sw_find_g"] = sw_find_g_bench(ctx)
-        if world == 1 and not args.no_cpu:
-            pts, cdt, cng, ccost, search = cpu_baseline(args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance,
-                                                        args.tolerance_tolerance, args.max_iterations)
-            out["cpu_baseline"] = {"value": pts / cdt, "unit": "wavenumber-points/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
-                                   "sample": "oracle reorder + gas prep + %s over oracle calc_error, nwav=%d "
-                                             "(same generator, ng=%d, N_pass=%.1f, %.1f s)"
-                                             % (search, args.cpu_sample, cng, ccost, cdt)}
+    if args.config == 4:
+        out = config4_main(args, ctx, dist, rank, world, barrier)
+    else:
+        out = find_g_main(args, ctx, dist, rank, world, barrier, use_dist)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

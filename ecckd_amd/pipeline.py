@@ -6,7 +6,7 @@ create_look_up_table : src/ecckd/create_look_up_table.cpp:60-606 (without the ba
 import numpy as np
 
 from . import api, ncio
-from ._lib import EcckdError, PARAMETER_ERROR
+from ._lib import EcckdError, PARAMETER_ERROR, PROCESSING_ERROR
 
 
 def _to_device(od, dev):
@@ -302,6 +302,98 @@ def reorder_spectrum(ctx, input_path, output_path, band_bound1, band_bound2, ipr
     return dict(spectrum=s, key=key, column_optical_depth=col, band_number=iband, rank=rank)
 
 
+def _search_gas(ctx, g, bands, tol, tolerance_tolerance, max_iterations, averaging_method, flux_weight, min_pressure,
+                sequential_bands, planck_reuse=None, sw=None):
+    """One gas of the loop find_g_points.cpp:655-1450 with everything already on the device: gas preparation (:872-1150),
+    the searches of `bands` (:1152-1414, side by side unless sequential_bands) and the median sorting variable of every
+    g point (:1404-1409).
+
+    g:  dict(pressure_hl, temperature_hl (host), wn, dwn, rank (int32), od, bg (or None), sorting_variable: device tensors in
+        ORIGINAL wavenumber order; band_begin[nband], band_end[nband]: first / last sorted index of every band;
+        min_g_points[nband], max_g_points[nband]; shortwave: min_scaling, max_scaling)
+    sw: None (longwave; planck_reuse = device pointer of the first gas's Planck matrix or None) or
+        dict(ssi, albedo: device tensors, band_albedo[nband], cos_sza).
+    Returns (gas handle - the caller closes it -, [(band, dict(rank1, rank2, error, status, comp_cost, sorting_variable))])."""
+    if sw is None:
+        gas = api.GasLW(ctx, g["pressure_hl"], g["temperature_hl"], g["wn"], g["dwn"], g["rank"], g["od"], g.get("bg"),
+                        averaging_method, flux_weight, min_pressure, planck_hl_reuse=planck_reuse)
+        band_albedo = None
+    else:
+        gas = api.GasSW(ctx, g["pressure_hl"], sw["ssi"], g["rank"], g["od"], g.get("bg"), averaging_method, flux_weight,
+                        min_pressure, sw["cos_sza"], sw["albedo"], g.get("min_scaling", 1.0), g.get("max_scaling", 1.0))
+        band_albedo = sw["band_albedo"]
+    sv_sorted = api.gather_f64(ctx, g["sorting_variable"], api.invert_permutation(ctx, g["rank"]))
+    begin, end = g["band_begin"], g["band_end"]
+    opts = [dict(min_g_points=int(g["min_g_points"][b]), max_g_points=int(g["max_g_points"][b])) for b in bands]
+    if len(bands) > 1 and not sequential_bands:
+        # bands side by side, sharing their error batches (ecckd_find_g_bands_ex): same decisions per band; a shortwave
+        # band brings its albedo (init_sw(..., band_albedo(jband), ...)) with it
+        side = [dict(o, band_albedo=float(band_albedo[b])) if band_albedo is not None else o for b, o in zip(bands, opts)]
+        band_res = gas.find_g_bands_ex([int(begin[b]) for b in bands], [int(end[b]) for b in bands],
+                                       np.ascontiguousarray(np.asarray(tol)[bands]), tolerance_tolerance, max_iterations, side)
+    else:
+        band_res = []
+        for b, o in zip(bands, opts):
+            if band_albedo is not None:
+                gas.set_band_albedo(band_albedo[b])                                                   # init_sw(..., band_albedo(jband), ...)
+            band_res.append(gas.find_g_band_ex(int(begin[b]), int(end[b]), float(tol[b]), tolerance_tolerance, max_iterations, **o))
+    out = []
+    for b, res in zip(bands, band_res):
+        med = gas.median_sorting_variable(sv_sorted, res["rank1"], res["rank2"])
+        out.append((b, dict(rank1=[int(v) for v in res["rank1"]], rank2=[int(v) for v in res["rank2"]],
+                            error=[float(v) for v in res["error"]], status=int(res["status"]),
+                            comp_cost=float(res["comp_cost"]), sorting_variable=[float(v) for v in med])))
+    return gas, out
+
+
+def _deal(ngas, nband, rank, world_size, group):
+    from . import shard
+    if rank is None or world_size is None:
+        rank, world_size = shard.world(group)
+    tasks = shard.task_table(range(ngas), nband)
+    mine = [tasks[t] for t in shard.deal_tasks(len(tasks), rank, world_size)]
+    my_bands = {}
+    for gi, b in mine:
+        my_bands.setdefault(gi, []).append(b)
+    return rank, world_size, tasks, mine, my_bands
+
+
+def _collect(local, ntasks, rank, world_size, group, dev):
+    """The only communication of a sharded find_g_points: the per-band results to rank 0, ONE all-reduce of the final cost
+    (sum of the g points' errors) and of the work counter."""
+    from . import shard
+    cost_local = float(sum(sum(r["error"]) for _, _, r in local))
+    comp_local = float(sum(r["comp_cost"] for _, _, r in local))
+    gathered = shard.gather_to_root(local, group)
+    if world_size > 1:
+        _, comp_sum, cost_sum = shard.reduce_scalars(0.0, comp_local, cost_local, device=dev if _is_nccl(group) else None, group=group)
+    else:
+        comp_sum, cost_sum = comp_local, cost_local
+    by_task = None
+    if rank == 0:
+        by_task = {(gi, b): r for part in gathered for gi, b, r in part}
+        if len(by_task) != ntasks:
+            raise EcckdError(PROCESSING_ERROR, "find_g_points: %d of %d (gas, band) searches came back" % (len(by_task), ntasks))
+    return by_task, cost_sum, comp_sum
+
+
+def _per_gas_tables(names, nband, by_task):
+    """SingleGasData of every gas (single_gas_data.h:24-80) from the per-band results, bands in order."""
+    per_gas = []
+    for gi, name in enumerate(names):
+        out = dict(name=name, n_g_points=[], band_number=[], rank1=[], rank2=[], error=[], sorting_variable=[], status=[], comp_cost=[])
+        for b in range(nband):
+            r = by_task[(gi, b)]
+            n = len(r["error"])
+            out["n_g_points"].append(n)
+            out["band_number"] += [b] * n
+            out["rank1"] += r["rank1"]; out["rank2"] += r["rank2"]; out["error"] += r["error"]
+            out["sorting_variable"] += r["sorting_variable"]
+            out["status"].append(r["status"]); out["comp_cost"].append(r["comp_cost"])
+        per_gas.append(out)
+    return per_gas
+
+
 def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, output_path=None, averaging_method="transmission",
                   flux_weight=0.02, min_pressure=0.0, tolerance_tolerance=0.02, max_iterations=60, iprofile=0, ssi=None,
                   max_no_rayleigh_wavenumber=10000.0, reference_albedo=0.15, cos_sza=0.5, sequential_bands=False,
@@ -323,39 +415,39 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
     (sum of the g points' errors) and the work counters.  Returns the result dict on rank 0, a summary elsewhere; both hold
     `cost_sum` and `comp_cost_sum`, identical on every rank.  The g points do not depend on the number of processes."""
     import torch
-    from . import shard
     dev = ctx.device
     nband = len(band_bound1)
     ngas = len(gases)
-    if rank is None or world_size is None:
-        rank, world_size = shard.world(group)
-    tasks = shard.task_table(range(ngas), nband)
-    mine = [tasks[t] for t in shard.deal_tasks(len(tasks), rank, world_size)]
-    my_bands = {}
-    for gi, b in mine:
-        my_bands.setdefault(gi, []).append(b)
+    rank, world_size, tasks, mine, my_bands = _deal(ngas, nband, rank, world_size, group)
     tol = np.broadcast_to(np.asarray(heating_rate_tolerance, dtype=np.float64), (nband,))           # :762-771
     first_lw_gas = None
     planck_first = None            # the first gas's Planck matrix where this process does not prepare the first gas itself
-    local = []                     # (gas index, band, result dict of the search, medians)
+    local = []                     # (gas index, band, result of the search)
     for gi in sorted(my_bands):
         spec = gases[gi]
         s = ncio.read_spectrum(spec["input"], iprofile)
         order = ncio.read_order(spec["reordering_input"])
-        wn, dwn = s["wavenumber_cm_1"], s["d_wavenumber_cm_1"]
-        d_wn, d_dwn = torch.as_tensor(wn, device=dev), torch.as_tensor(dwn, device=dev)
-        d_rank = torch.as_tensor(order["rank"], device=dev)
+        wn = s["wavenumber_cm_1"]
         bg = None
         for item in spec.get("background", []):                                                       # read_merged_spectrum (:891)
             b = ncio.read_spectrum(item["path"], iprofile)
             sp, _ = api.merge_scaling(b["pressure_hl"], item.get("scaling", -1.0), item.get("conc", -1.0),
                                       b["reference_surface_vmr"], b["vmr_fl"])
             bg = api.merge_spectrum(ctx, _to_device(b["optical_depth"], dev), sp, bg)
+        iband = order["band_number"]
+        idx = [np.nonzero(iband == b)[0] for b in range(nband)]
+        g = dict(pressure_hl=s["pressure_hl"], temperature_hl=s["temperature_hl"], wn=torch.as_tensor(wn, device=dev),
+                 dwn=torch.as_tensor(s["d_wavenumber_cm_1"], device=dev), rank=torch.as_tensor(order["rank"], device=dev),
+                 od=_to_device(s["optical_depth"], dev), bg=bg, sorting_variable=torch.as_tensor(order["sorting_variable"], device=dev),
+                 band_begin=[int(i[0]) if i.size else -1 for i in idx], band_end=[int(i[-1]) if i.size else -1 for i in idx],
+                 min_g_points=np.broadcast_to(np.asarray(spec.get("min_g_points", 1)), (nband,)),       # per band, :733-754
+                 max_g_points=np.broadcast_to(np.asarray(spec.get("max_g_points", 256)), (nband,)),
+                 min_scaling=spec.get("min_scaling", 1.0), max_scaling=spec.get("max_scaling", 1.0))
+        sw = reuse = None
         if ssi is None:
             # the reference evaluates the Planck function once, on the FIRST gas's reordered grid, and keeps using that
             # matrix for the later gases (find_g_points.cpp:529, :970-984): reproduced.  The process that prepares the first
             # gas keeps it alive; any other builds the same matrix from the first gas's ordering file and profile
-            reuse = None
             if gi > 0 and first_lw_gas is not None:
                 reuse = first_lw_gas.view_ptr("planck_hl")[0]
             elif gi > 0:
@@ -366,83 +458,36 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
                                                         torch.as_tensor(s0["d_wavenumber_cm_1"], device=dev),
                                                         torch.as_tensor(o0["rank"], device=dev))
                 reuse = planck_first.data_ptr()
-            gas = api.GasLW(ctx, s["pressure_hl"], s["temperature_hl"], d_wn, d_dwn, d_rank, _to_device(s["optical_depth"], dev), bg,
-                            averaging_method, flux_weight, min_pressure, planck_hl_reuse=reuse)
-            if gi == 0:
-                first_lw_gas = gas
-            band_albedo = None
         else:
             b2 = np.asarray(band_bound2, dtype=np.float64)
             no_ray = b2 <= max_no_rayleigh_wavenumber
-            band_albedo = np.where(no_ray, reference_albedo, 0.0)                                     # :756-760
             wn_limit = b2[no_ray].max() if no_ray.any() else 0.0                                      # :761
-            albedo = np.where(wn < wn_limit, reference_albedo, 0.0)                                   # :921-923
-            gas = api.GasSW(ctx, s["pressure_hl"], torch.as_tensor(np.asarray(ssi, dtype=np.float64), device=dev), d_rank,
-                            _to_device(s["optical_depth"], dev), bg, averaging_method, flux_weight, min_pressure, cos_sza,
-                            torch.as_tensor(albedo, device=dev), spec.get("min_scaling", 1.0), spec.get("max_scaling", 1.0))
-        sv_sorted = api.gather_f64(ctx, torch.as_tensor(order["sorting_variable"], device=dev), api.invert_permutation(ctx, d_rank))
-        iband = order["band_number"]
-        min_gp = np.broadcast_to(np.asarray(spec.get("min_g_points", 1)), (nband,))                   # per band, :733-754
-        max_gp = np.broadcast_to(np.asarray(spec.get("max_g_points", 256)), (nband,))
-        bands = my_bands[gi]
-        band_idx = {b: np.nonzero(iband == b)[0] for b in bands}
-        band_opts = {b: dict(min_g_points=int(min_gp[b]), max_g_points=int(max_gp[b])) for b in bands}
-        if len(bands) > 1 and not sequential_bands:
-            # bands side by side, sharing their error batches (ecckd_find_g_bands_ex): same decisions per band; a shortwave
-            # band brings its albedo (init_sw(..., band_albedo(jband), ...)) with it
-            side_opts = [dict(band_opts[b], band_albedo=float(band_albedo[b])) if band_albedo is not None else band_opts[b] for b in bands]
-            band_res = gas.find_g_bands_ex([int(band_idx[b][0]) for b in bands], [int(band_idx[b][-1]) for b in bands],
-                                           np.ascontiguousarray(tol[bands]), tolerance_tolerance, max_iterations, side_opts)
+            sw = dict(ssi=torch.as_tensor(np.asarray(ssi, dtype=np.float64), device=dev), cos_sza=cos_sza,
+                      band_albedo=np.where(no_ray, reference_albedo, 0.0),                            # :756-760
+                      albedo=torch.as_tensor(np.where(wn < wn_limit, reference_albedo, 0.0), device=dev))   # :921-923
+        gas, res = _search_gas(ctx, g, my_bands[gi], tol, tolerance_tolerance, max_iterations, averaging_method, flux_weight,
+                               min_pressure, sequential_bands, reuse, sw)
+        local += [(gi, b, r) for b, r in res]
+        if ssi is None and gi == 0:
+            first_lw_gas = gas
         else:
-            band_res = []
-            for b in bands:
-                if band_albedo is not None:
-                    gas.set_band_albedo(band_albedo[b])                                               # init_sw(..., band_albedo(jband), ...)
-                band_res.append(gas.find_g_band_ex(int(band_idx[b][0]), int(band_idx[b][-1]), float(tol[b]), tolerance_tolerance,
-                                                   max_iterations, **band_opts[b]))
-        for b, res in zip(bands, band_res):
-            med = gas.median_sorting_variable(sv_sorted, res["rank1"], res["rank2"])
-            local.append((gi, b, dict(rank1=[int(v) for v in res["rank1"]], rank2=[int(v) for v in res["rank2"]],
-                                      error=[float(v) for v in res["error"]], status=int(res["status"]),
-                                      comp_cost=float(res["comp_cost"]), sorting_variable=[float(v) for v in med])))
-        if gas is not first_lw_gas:
             gas.close()
     if first_lw_gas is not None:
         first_lw_gas.close()
     planck_first = None
-    # ---- the only communication: the per-band results to rank 0, one all-reduce of the final cost and the work counter ----
-    cost_local = float(sum(sum(r["error"]) for _, _, r in local))
-    comp_local = float(sum(r["comp_cost"] for _, _, r in local))
-    gathered = shard.gather_to_root(local, group)
-    if world_size > 1:
-        _, comp_sum, cost_sum = shard.reduce_scalars(0.0, comp_local, cost_local, device=dev if _is_nccl(group) else None, group=group)
-    else:
-        comp_sum, cost_sum = comp_local, cost_local
+    by_task, cost_sum, comp_sum = _collect(local, len(tasks), rank, world_size, group, dev)
     if rank != 0:
         return dict(rank=rank, tasks=mine, cost_sum=cost_sum, comp_cost_sum=comp_sum)
-    by_task = {(gi, b): r for part in gathered for gi, b, r in part}
-    if len(by_task) != len(tasks):
-        raise EcckdError(PROCESSING_ERROR, "find_g_points: %d of %d (gas, band) searches came back" % (len(by_task), len(tasks)))
     # ---- what follows the gas loop (:1452-1660) ----
-    per_gas, gas_gp = [], []
+    per_gas = _per_gas_tables([spec["name"] for spec in gases], nband, by_task)
+    gas_gp = []
     wn = None
-    for gi, spec in enumerate(gases):
+    for spec, out in zip(gases, per_gas):
         order = ncio.read_order(spec["reordering_input"])
         wn = order["wavenumber"]
-        out = dict(name=spec["name"], n_g_points=[], band_number=[], rank1=[], rank2=[], error=[], sorting_variable=[],
-                   status=[], comp_cost=[])
-        for b in range(nband):
-            r = by_task[(gi, b)]
-            n = len(r["error"])
-            out["n_g_points"].append(n)
-            out["band_number"] += [b] * n
-            out["rank1"] += r["rank1"]; out["rank2"] += r["rank2"]; out["error"] += r["error"]
-            out["sorting_variable"] += r["sorting_variable"]
-            out["status"].append(r["status"]); out["comp_cost"].append(r["comp_cost"])
         gp = api.gas_g_point(ctx, torch.as_tensor(order["rank"], device=dev), out["rank1"], out["rank2"])
         out["g_point"] = gp.cpu().numpy()
         gas_gp.append(gp)
-        per_gas.append(out)
     ng, band_number, g_min, g_max = api.overlap_g_points([g["n_g_points"] for g in per_gas],
                                                          [np.asarray(g["sorting_variable"]) for g in per_gas])
     g_point, n_unassigned = api.merge_g_points(ctx, gas_gp, g_min, g_max)
@@ -453,6 +498,108 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
     if output_path is not None:
         ncio.write_g_points(output_path, band_bound1, band_bound2, band_number, per_gas, wn, result["g_point"])
     return result
+
+
+def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, first_gas_order=None, averaging_method="transmission",
+                           flux_weight=0.02, min_pressure=0.0, tolerance_tolerance=0.02, max_iterations=60,
+                           sequential_bands=False, rank=None, world_size=None, group=None, merged_map=True):
+    """find_g_points on spectra that are already resident in HBM (bench.py, the full-size tests): the same dealing of the
+    (gas, band) tasks, the same per-gas work (_search_gas) and the same collection as find_g_points, with `load_gas(gi)`
+    handing over the device tensors of gas gi (the dict _search_gas takes; the call may do the gas's reorder_spectrum step,
+    K1 + K3, itself) instead of reading files.  Longwave only.
+
+    first_gas_order: callable -> dict(temperature_hl, wn, dwn, rank) of the FIRST gas for a process that searches none of
+    its bands (what the file driver reads from the first gas's ordering file), for the shared Planck matrix.
+    merged_map: every gas's per-wavenumber g points travel to rank 0 (one reduce per gas; each wavenumber is set by exactly
+    one process), which forms the merged g-point map (:1459-1475).
+    -> rank 0: dict(ng, band_number, gases, g_point (device), n_unassigned, cost_sum, comp_cost_sum, points);
+       others: dict(cost_sum, comp_cost_sum, points).  `points`: wavenumber points x (1 + passes) this process worked through."""
+    import torch
+    dev = ctx.device
+    ngas = len(names)
+    rank, world_size, tasks, mine, my_bands = _deal(ngas, nband, rank, world_size, group)
+    tol = np.broadcast_to(np.asarray(heating_rate_tolerance, dtype=np.float64), (nband,))
+    first_lw_gas = None
+    planck_first = None
+    local, maps = [], {}
+    points = 0.0
+    nwav = None
+    for gi in sorted(my_bands):
+        g = load_gas(gi)
+        nwav = g["rank"].numel()
+        reuse = None
+        if gi > 0 and first_lw_gas is not None:
+            reuse = first_lw_gas.view_ptr("planck_hl")[0]
+        elif gi > 0:
+            if planck_first is None:
+                o0 = first_gas_order()
+                planck_first = api.planck_hl_sorted(ctx, o0["temperature_hl"], o0["wn"], o0["dwn"], o0["rank"])
+            reuse = planck_first.data_ptr()
+        gas, res = _search_gas(ctx, g, my_bands[gi], tol, tolerance_tolerance, max_iterations, averaging_method, flux_weight,
+                               min_pressure, sequential_bands, reuse, None)
+        for b, r in res:
+            r["index_range"] = (int(g["band_begin"][b]), int(g["band_end"][b]))
+            points += (g["band_end"][b] - g["band_begin"][b] + 1) * (1.0 + r["comp_cost"])
+        local += [(gi, b, r) for b, r in res]
+        if merged_map:
+            # this process's bands of the gas: g point of every wavenumber counted from the band's first (-1 elsewhere)
+            gp = torch.full((nwav,), -1, dtype=torch.int32, device=dev)
+            for b, r in res:
+                sl = slice(int(g["band_begin"][b]), int(g["band_end"][b]) + 1)      # a band's members are contiguous in wavenumber
+                gp[sl] = api.gas_g_point(ctx, g["rank"][sl].contiguous(), r["rank1"], r["rank2"])
+            maps[gi] = gp
+        if gi == 0:
+            first_lw_gas = gas
+        else:
+            gas.close()
+    if first_lw_gas is not None:
+        first_lw_gas.close()
+    planck_first = None
+    by_task, cost_sum, comp_sum = _collect(local, len(tasks), rank, world_size, group, dev)
+    gas_gp = []
+    if merged_map:
+        if nwav is None:
+            nwav = first_gas_order()["rank"].numel()
+        for gi in range(ngas):
+            gp = maps.get(gi)
+            if gp is None:
+                gp = torch.full((nwav,), -1, dtype=torch.int32, device=dev)
+            gas_gp.append(_max_to_root(gp, world_size, group))
+    if rank != 0:
+        return dict(rank=rank, tasks=mine, cost_sum=cost_sum, comp_cost_sum=comp_sum, points=points)
+    per_gas = _per_gas_tables(names, nband, by_task)
+    ng, band_number, g_min, g_max = api.overlap_g_points([g["n_g_points"] for g in per_gas],
+                                                         [np.asarray(g["sorting_variable"]) for g in per_gas])
+    result = dict(ng=ng, band_number=band_number, gases=per_gas, cost_sum=cost_sum, comp_cost_sum=comp_sum, rank=0, tasks=mine,
+                  points=points)
+    for k, g in enumerate(per_gas):
+        g["g_min"], g["g_max"] = g_min[k], g_max[k]
+    if merged_map:
+        # the gathered maps count a band's g points from 0: add the number of g points of the gas's earlier bands
+        # (SingleGasData::store_g_points numbers them through the bands, single_gas_data.h:56-62)
+        for gi, (gp, out) in enumerate(zip(gas_gp, per_gas)):
+            first = np.concatenate([[0], np.cumsum(out["n_g_points"])[:-1]])
+            for b in range(nband):
+                i0, i1 = by_task[(gi, b)]["index_range"]
+                if first[b]:
+                    sl = gp[i0:i1 + 1]
+                    sl += torch.where(sl >= 0, int(first[b]), 0).to(sl.dtype)
+        result["g_point"], result["n_unassigned"] = api.merge_g_points(ctx, gas_gp, g_min, g_max)
+        result["gas_g_point"] = gas_gp
+    return result
+
+
+def _max_to_root(t, world_size, group=None):
+    """Element-wise maximum over the processes on rank 0 (one reduce; gloo works on a host copy)."""
+    if world_size == 1:
+        return t
+    import torch.distributed as dist
+    if _is_nccl(group):
+        dist.reduce(t, dst=0, op=dist.ReduceOp.MAX, group=group)
+        return t
+    h = t.cpu()
+    dist.reduce(h, dst=0, op=dist.ReduceOp.MAX, group=group)
+    return h.to(t.device)
 
 
 def _is_nccl(group=None):

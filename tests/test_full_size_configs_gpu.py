@@ -1,0 +1,194 @@
+"""BASELINE configs[3] and configs[4] at full size (the oracle cannot run them whole in seconds; it replays windows).
+
+configs[3]: one find_g_points job over the 13 narrow longwave bands at nwav = 7.2e6, nlay = 54 (three gases here, eight in
+bench.py --config 3), through the resident-data driver that bench.py and the sharded runs use.  Checked: (a) oracle replay
+of the interval errors of one narrow band deep inside the spectrum, from the device's own prepared rows; (b) every
+wavenumber is assigned to exactly one merged g point, the per-gas maps are those of the g points' rank ranges;
+(c) searching the bands one at a time (the reference's order of evaluation) ends at the same g points as side by side;
+(d) the shares of a two-process deal, run one after the other here, give the same per-band results as the whole job.
+
+configs[4]: the LW and the SW optimize_lut problems at nx ~ 3e5, 8 scenarios x 50 profiles (x 3 zenith angles): cost at
+the initial state against the CPU oracle (oracle_ckd.c), gradient against central differences of the device cost, and the
+bounded L-BFGS lowers the cost."""
+import numpy as np
+import pytest
+import torch
+
+from ecckd_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+ERR_RTOL = 1e-9
+
+
+class _DevView:
+    def __init__(self, ptr, rows, cols):
+        self.__cuda_array_interface__ = {"shape": (rows, cols), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def test_config3_thirteen_bands_full_size(ctx, oracle):
+    from ecckd_amd import api, pipeline, shard
+    nwav, nlay, names = 7_200_000, 54, ["composite", "h2o", "o3"]
+    scales = [30.0, 100.0, 10.0]
+    dev = ctx.device
+    p = syn.pressure_grid(nlay)
+    wn_h, dwn_h = syn.wavenumber_grid(nwav)
+    wn, dwn = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
+    b1, b2 = syn.LW_NARROW_BANDS
+    nband = len(b1)
+    _, begin, end = api.band_ranges(wn_h, b1, b2)
+    t_ideal, t_file = api.idealised_temperature(p), syn.temperature_profile(p)
+    spectra, orders = {}, {}
+    for gi in range(len(names)):
+        od = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 301 + 17 * gi, column_scale=scales[gi], device=dev)
+        bg = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 1301 + 17 * gi, nlines=4000, column_scale=3.0, zero_fraction=0.0,
+                                     nclusters=5, device=dev)
+        spectra[gi] = (od, bg)
+
+    def load_gas(gi):
+        od, bg = spectra[gi]
+        if gi not in orders:
+            key, _ = api.reorder_key_lw(ctx, p, t_ideal, wn, dwn, od, 0.5)
+            rnk, _ = api.stable_argsort_bands(ctx, key, begin, end, want_ordered=False)
+            orders[gi] = (key, rnk)
+        key, rnk = orders[gi]
+        return dict(pressure_hl=p, temperature_hl=t_file, wn=wn, dwn=dwn, rank=rnk, od=od, bg=bg, sorting_variable=key,
+                    band_begin=begin, band_end=end, min_g_points=np.ones(nband, dtype=int), max_g_points=np.full(nband, 256))
+
+    first_order = lambda: dict(temperature_hl=t_file, wn=wn, dwn=dwn, rank=load_gas(0)["rank"])
+    kw = dict(averaging_method="transmission", flux_weight=0.0, min_pressure=0.0, tolerance_tolerance=0.01, max_iterations=60)
+    res = pipeline.find_g_points_resident(ctx, names, load_gas, nband, 0.013, first_order, **kw)
+    assert res["n_unassigned"] == 0 and res["ng"] >= nband
+    gp = res["g_point"].cpu().numpy()
+    assert gp.min() == 0 and gp.max() == res["ng"] - 1 and np.unique(gp).size == res["ng"]
+    # a merged g point lies in ONE band: its wavenumbers are those of that band
+    for ig in (0, res["ng"] // 2, res["ng"] - 1):
+        b = res["band_number"][ig]
+        idx = np.nonzero(gp == ig)[0]
+        assert idx.min() >= begin[b] and idx.max() <= end[b]
+    for gi, g in enumerate(res["gases"]):
+        assert len(g["n_g_points"]) == nband and all(n >= 1 for n in g["n_g_points"])
+        rnk = orders[gi][1].cpu().numpy()
+        ggp = res["gas_g_point"][gi].cpu().numpy()
+        k = len(g["rank1"]) // 2                                           # store_g_points (single_gas_data.h:56-62), one g point
+        assert np.array_equal(np.nonzero(ggp == k)[0], np.nonzero((rnk >= g["rank1"][k]) & (rnk <= g["rank2"][k]))[0])
+        e = np.array(g["error"])
+        assert np.all(np.isfinite(e)) and np.all(e > 0)
+    assert res["cost_sum"] == pytest.approx(sum(sum(g["error"]) for g in res["gases"]), rel=1e-13)
+
+    # (a) oracle replay of a narrow band (band 3: 630-700 cm-1, ~155 000 points) of the second gas, from its prepared rows
+    od, bg = spectra[1]
+    key, rnk = orders[1]
+    planck_first = api.planck_hl_sorted(ctx, t_file, wn, dwn, orders[0][1])
+    gas = api.GasLW(ctx, p, t_file, wn, dwn, rnk, od, bg, "transmission", 0.0, 0.0, planck_hl_reuse=planck_first.data_ptr())
+    i0, i1 = int(begin[3]), int(end[3])
+    n = i1 - i0 + 1
+    view = lambda name: torch.as_tensor(_DevView(*gas.view_ptr(name)), device=dev)
+    sl = slice(i0, i1 + 1)
+    ireorder = api.invert_permutation(ctx, rnk).long()
+    od_s = od[:, ireorder[sl]].double().cpu().numpy()
+    pl = planck_first[:, sl].cpu().numpy()
+    eq = oracle.CkdEquipartitionLW("transmission", 0.0, oracle.layer_weight(p, 0.0), p, np.ones(n), pl[-1],
+                                   view("flux_dn_surf")[0, sl].cpu().numpy(), view("flux_up_toa")[0, sl].cpu().numpy(), pl,
+                                   view("bg_optical_depth")[:, sl].cpu().numpy(), oracle.metric("transmission", od_s),
+                                   view("hr")[:, sl].cpu().numpy())
+    g1 = res["gases"][1]
+    first = int(np.sum(g1["n_g_points"][:3]))
+    ng3 = g1["n_g_points"][3]
+    r1, r2 = np.array(g1["rank1"][first:first + ng3]), np.array(g1["rank2"][first:first + ng3])
+    b_lo, b_hi = (r1 - i0 - 0.25) / (n - 1), (r2 - i0 + 0.25) / (n - 1)   # ceil / floor (find_g_points.cpp:282-287) land on r1, r2
+    err = gas.calc_error_batch(i0, n, b_lo, b_hi)
+    pick = sorted({0, ng3 // 2, ng3 - 1})                    # the oracle walks ~1e5 points x 54 layers per interval
+    ref = np.array([eq.calc_error(b_lo[k], b_hi[k]) for k in pick])
+    assert np.allclose(err[pick], ref, rtol=ERR_RTOL, atol=1e-12)
+    # the errors the search reported are those of its final intervals (same rank ranges -> same bits)
+    assert np.array_equal(err, g1["error"][first:first + ng3])
+    gas.close()
+
+    # (c) one band at a time == side by side
+    seq = pipeline.find_g_points_resident(ctx, names, load_gas, nband, 0.013, first_order, sequential_bands=True, merged_map=False, **kw)
+    for a, b in zip(seq["gases"], res["gases"]):
+        assert a["rank1"] == b["rank1"] and a["rank2"] == b["rank2"] and a["error"] == b["error"] and a["status"] == b["status"]
+
+    # (d) the shares of a two-process deal give the same searches (each share run here on its own, without the gather)
+    tasks = shard.task_table(range(len(names)), nband)
+    for r in range(2):
+        mine = [tasks[t] for t in shard.deal_tasks(len(tasks), r, 2)]
+        by_gas = {}
+        for gi, b in mine:
+            by_gas.setdefault(gi, []).append(b)
+        for gi, bands in by_gas.items():
+            g = load_gas(gi)
+            reuse = None if gi == 0 else api.planck_hl_sorted(ctx, t_file, wn, dwn, orders[0][1])
+            gas, out = pipeline._search_gas(ctx, g, bands, np.full(nband, 0.013), 0.01, 60, "transmission", 0.0, 0.0, False,
+                                            reuse.data_ptr() if reuse is not None else None, None)
+            gas.close()
+            ref_g = res["gases"][gi]
+            firsts = np.concatenate([[0], np.cumsum(ref_g["n_g_points"])])
+            for b, rr in out:
+                assert rr["rank1"] == ref_g["rank1"][firsts[b]:firsts[b + 1]] and rr["error"] == ref_g["error"][firsts[b]:firsts[b + 1]]
+
+
+def _lut_problem(sw):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    model = syn.ckd_model(ng=64, nt=6, np_=53, nband=13, seed=11, nconc=12)
+    truth = syn.ckd_model(ng=64, nt=6, np_=53, nband=13, seed=11, nconc=12)
+    if sw:
+        model, truth = bench.ckd_model_sw(model, 11), bench.ckd_model_sw(truth, 11)
+    rs = np.random.RandomState(12)
+    for g in truth["gases"]:
+        g["molar_abs"] = g["molar_abs"] * np.exp(0.25 * rs.normal(size=g["molar_abs"].shape))
+    scenes = syn.ckd_scenes(model, nscene=8, ncol=50, nlay=54, seed=13)
+    return model, truth, scenes
+
+
+@pytest.mark.parametrize("sw", [False, True])
+def test_config4_optimize_lut_full_size(ctx, oracle, sw):
+    import ckd_synth
+    from ecckd_amd import api
+    model, truth, scenes = _lut_problem(sw)
+    if not sw:
+        cfg = dict(flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, spectral_boundary_weight=0.0,
+                   negative_od_penalty=1.0e4, pressure_weight_power=0.5, prior_error=4.0, pressure_corr=0.95,
+                   temperature_corr=0.95, conc_corr=0.95, cap_relative_linear=0.0)
+    else:
+        cfg = dict(flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, spectral_boundary_weight=0.0,
+                   negative_od_penalty=1.0e4, pressure_weight_power=0.5, prior_error=2.0, pressure_corr=0.8,
+                   temperature_corr=0.8, conc_corr=0.8, cap_relative_linear=0.0)
+        scenes = ckd_synth.make_scenes_sw(model, np.full(13, 0.15), mu0=(1.0, 0.5, 0.1), nscene=8, ncol=50, nlay=54, seed=13)
+    ib, nband = model["iband_per_g"], 13
+    ncs = scenes[0]["pressure_hl"].shape[0]
+    assert ncs == (150 if sw else 50)
+    for s in scenes:
+        s["flux_dn"] = np.zeros((ncs, 55, nband)); s["flux_up"] = np.zeros((ncs, 55, nband))
+    t_opt = api.Optimizer(ctx, truth, scenes, **cfg)
+    _, fl = t_opt.forward(t_opt.initial_state())
+    t_opt.close()
+    band = np.stack([fl[..., ib == b].sum(-1) for b in range(nband)], axis=-1)
+    for k, s in enumerate(scenes):
+        s["flux_dn"] = np.ascontiguousarray(band[k * ncs:(k + 1) * ncs, 0])
+        s["flux_up"] = np.ascontiguousarray(band[k * ncs:(k + 1) * ncs, 1])
+    opt = api.Optimizer(ctx, model, scenes, **cfg)
+    assert 2.9e5 < opt.nx < 3.3e5
+    x0 = opt.initial_state()
+    J0, g0 = opt.cost_grad(x0)
+    # cost at the common starting point against the CPU oracle: two scenes of the eight (the oracle is a per-profile C call)
+    sub = [scenes[0], scenes[5]]
+    orc = (ckd_synth.OracleSW if sw else ckd_synth.Oracle)(oracle, model, sub, cfg)
+    opt_sub = api.Optimizer(ctx, model, sub, **cfg)
+    J_sub, _ = opt_sub.cost_grad(x0)
+    opt_sub.close()
+    assert J_sub == pytest.approx(orc.cost_rt(x0) + orc.cost_prior(x0, cfg["prior_error"])[0], rel=1e-10)
+    # gradient against central differences of the device cost
+    rs = np.random.RandomState(3)
+    free = np.nonzero(x0 > -1.0e20)[0]
+    big = free[np.argsort(-np.abs(g0[free]))[:200]]
+    for i in rs.choice(big, 6, replace=False):
+        e = np.zeros_like(x0); e[i] = 1e-5
+        fd = (opt.cost_grad(x0 + e, False) - opt.cost_grad(x0 - e, False)) / 2e-5
+        assert g0[i] == pytest.approx(fd, rel=2e-5, abs=1e-7 * np.abs(g0).max())
+    res = opt.minimize(max_iterations=25, convergence_criterion=0.0, bounded=True)
+    assert res["status"] in (0, 2) and res["cost"] < 0.8 * J0
+    opt.close()
