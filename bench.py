@@ -334,9 +334,12 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
             gas = api.GasLW(ctx, p, t_file, wn, dwn, rnk, od, bg, "transmission", flux_weight=0.0)
             st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance,
                                            args.max_iterations)
+            info.update(ng=len(e), status=st, comp_cost=cc, cost_sum=float(np.sum(e)), eval_stats=gas.eval_stats())
             gas.close()
-            info.update(ng=len(e), status=st, comp_cost=cc, cost_sum=float(np.sum(e)))
-            return 1.0 + cc  # passes over the spectrum in this step
+            # passes over the spectrum in this step: the reorder pass + what the search actually swept on the device.  (The
+            # reference's counter total_comp_cost counts every interval the search asks for; the library answers an
+            # interval it has evaluated before from its memo, so fewer points are swept than the counter says.)
+            return 1.0 + info["eval_stats"]["points_evaluated"] / nwav
     for _ in range(args.warmup):
         step()
     ctx.profile_enable(True)
@@ -407,7 +410,10 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
             "config": ({"workload": "configs[1]: LW FSCK (1 band 0-3260 cm-1), 1 synthetic gas + background per "
                                     "rank, nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging transmission"
                                     % (nwav, nlay, args.tolerance),
-                        "n_pass_per_step": (passes / args.steps / world) - 1.0, "ng": info.get("ng"),
+                        "n_pass_per_step": (passes / args.steps / world) - 1.0,
+                        "n_pass_reference_counter": info.get("comp_cost"), "ng": info.get("ng"),
+                        "interval_requests": info.get("eval_stats", {}).get("requests"),
+                        "interval_requests_answered_from_memo": info.get("eval_stats", {}).get("memo_hits"),
                         "search_status": info.get("status"), "final_cost_sum_K_per_day": total_cost}
                        if args.config == 1 else
                        {"workload": "configs[3]: ONE find_g_points job, 13 narrow LW bands (test/config.h:141-142) x %d gases "

@@ -370,6 +370,13 @@ class GasLW:
     def comp_cost(self, reset=False):
         return float(self.lib.ecckd_gas_comp_cost(self.handle, int(reset)))
 
+    def eval_stats(self):
+        """What the memo of interval errors saved (ecckd_gas_eval_stats): dict(requests, memo_hits, points_requested,
+        points_evaluated)."""
+        rq, hit, pr, pe = C.c_longlong(), C.c_longlong(), C.c_double(), C.c_double()
+        check(self.lib.ecckd_gas_eval_stats(self.handle, C.byref(rq), C.byref(hit), C.byref(pr), C.byref(pe)))
+        return dict(requests=rq.value, memo_hits=hit.value, points_requested=pr.value, points_evaluated=pe.value)
+
     def calc_error_batch(self, ibegin, npoints, bound1, bound2):
         b1 = np.ascontiguousarray(bound1, dtype=np.float64)
         b2 = np.ascontiguousarray(bound2, dtype=np.float64)

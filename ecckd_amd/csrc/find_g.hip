@@ -2108,41 +2108,13 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   return ecckd_calc_error_multi(g, n, ib.data(), np.data(), nullptr, bound1, bound2, error);
 }
 
-// The same for intervals of DIFFERENT bands in one batch: interval k is the fraction [bound1[k], bound2[k]] of the band
-// that starts at sorted index ibegin[k] and has npoints[k] points.  One launch train for all of them - the band searches
-// of a gas are independent (find_g_points.cpp:1152), so their error evaluations can share the GPU (ecckd_find_g_bands_ex).
-int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const size_t* npoints_k, const double* albedo_k,
-                           const double* bound1, const double* bound2, double* error) {
-  ECCKD_REQUIRE(g && (n == 0 || (ibegin_k && npoints_k && bound1 && bound2 && error)), "ecckd_calc_error_multi: NULL argument");
-  if (n <= 0) return ECCKD_OK;
+// Errors of the intervals iv[0..n) (first / last sorted index and albedo filled in) on the device -> error[0..n).
+static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error) {
+  const int n = (int)iv.size();
   ecckd_ctx* ctx = g->ctx;
-  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
   const int nlay = g->nlay, nhl = nlay + 1;
-
-  // index mapping and error paths of CkdEquipartition::calc_error (find_g_points.cpp:282-320)
-  std::vector<Interval> iv(n);
   long long total_pts = 0;
-  for (int k = 0; k < n; ++k) {
-    const size_t ibegin = ibegin_k[k], npoints = npoints_k[k];
-    ECCKD_REQUIRE(npoints > 0 && ibegin + npoints <= g->n,
-                  "ecckd_calc_error_batch: band [%zu,%zu) outside the spectrum (%zu points)", ibegin, ibegin + npoints, g->n);
-    const double b1 = bound1[k], b2 = bound2[k];
-    long long i1 = (long long)std::ceil(b1 * (double)(npoints - 1));
-    long long i2 = (long long)std::floor(b2 * (double)(npoints - 1));
-    if (i1 < 0 || i2 >= (long long)npoints || !(b1 == b1) || !(b2 == b2))
-      return ecckd::fail(ECCKD_PROCESSING_ERROR,
-                         "requested bounds %.17g-%.17g corresponding to indices %lld-%lld outside valid range 0-%zu",
-                         b1, b2, i1, i2, npoints - 1);
-    if (b2 < b1) return ecckd::fail(ECCKD_PROCESSING_ERROR, "requested bounds out of order: %.17g-%.17g", b1, b2);
-    if (i2 + 1 < i1) return ecckd::fail(ECCKD_PROCESSING_ERROR, "requested indices out of order: %lld-%lld", i1, i2);
-    if (i2 < i1) i2 = i1;
-    iv[k].i1 = (long long)ibegin + i1;
-    iv[k].i2 = (long long)ibegin + i2;
-    iv[k].npoints = (long long)npoints;
-    iv[k].albedo = albedo_k ? albedo_k[k] : g->surf_albedo;
-    total_pts += i2 - i1 + 1;
-  }
-  for (int k = 0; k < n; ++k) g->total_comp_cost += bound2[k] - bound1[k];  // :320
+  for (int k = 0; k < n; ++k) total_pts += iv[k].i2 - iv[k].i1 + 1;
 
   // Chunking.  Every interval is cut into chunks of ITS OWN size: the smallest multiple of what one block iteration covers
   // (the longwave mirror kernel: two wave pairs = 128 points; the other sweeps: 256) with which the interval fills at most
@@ -2277,6 +2249,94 @@ int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const si
     ctx->stat_rt_lw.units += (double)total_pts;
     ctx->stat_rt_lw.calls += 1;
   }
+  return ECCKD_OK;
+}
+
+// The same for intervals of DIFFERENT bands in one batch: interval k is the fraction [bound1[k], bound2[k]] of the band
+// that starts at sorted index ibegin[k] and has npoints[k] points.  One launch train for all of them - the band searches
+// of a gas are independent (find_g_points.cpp:1152), so their error evaluations can share the GPU (ecckd_find_g_bands_ex).
+int ecckd_calc_error_multi(ecckd_gas* g, int n, const size_t* ibegin_k, const size_t* npoints_k, const double* albedo_k,
+                           const double* bound1, const double* bound2, double* error) {
+  ECCKD_REQUIRE(g && (n == 0 || (ibegin_k && npoints_k && bound1 && bound2 && error)), "ecckd_calc_error_multi: NULL argument");
+  if (n <= 0) return ECCKD_OK;
+  ecckd_ctx* ctx = g->ctx;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+
+  // index mapping and error paths of CkdEquipartition::calc_error (find_g_points.cpp:282-320)
+  std::vector<Interval> iv(n);
+  for (int k = 0; k < n; ++k) {
+    const size_t ibegin = ibegin_k[k], npoints = npoints_k[k];
+    ECCKD_REQUIRE(npoints > 0 && ibegin + npoints <= g->n,
+                  "ecckd_calc_error_batch: band [%zu,%zu) outside the spectrum (%zu points)", ibegin, ibegin + npoints, g->n);
+    const double b1 = bound1[k], b2 = bound2[k];
+    long long i1 = (long long)std::ceil(b1 * (double)(npoints - 1));
+    long long i2 = (long long)std::floor(b2 * (double)(npoints - 1));
+    if (i1 < 0 || i2 >= (long long)npoints || !(b1 == b1) || !(b2 == b2))
+      return ecckd::fail(ECCKD_PROCESSING_ERROR,
+                         "requested bounds %.17g-%.17g corresponding to indices %lld-%lld outside valid range 0-%zu",
+                         b1, b2, i1, i2, npoints - 1);
+    if (b2 < b1) return ecckd::fail(ECCKD_PROCESSING_ERROR, "requested bounds out of order: %.17g-%.17g", b1, b2);
+    if (i2 + 1 < i1) return ecckd::fail(ECCKD_PROCESSING_ERROR, "requested indices out of order: %lld-%lld", i1, i2);
+    if (i2 < i1) i2 = i1;
+    iv[k].i1 = (long long)ibegin + i1;
+    iv[k].i2 = (long long)ibegin + i2;
+    iv[k].chunk0 = 0;
+    iv[k].chunk_pts = 0;
+    iv[k].npoints = (long long)npoints;
+    iv[k].albedo = albedo_k ? albedo_k[k] : g->surf_albedo;
+  }
+  for (int k = 0; k < n; ++k) g->total_comp_cost += bound2[k] - bound1[k];  // :320: the reference's counter counts every request
+
+  // The memo: only intervals not seen before (and once each) go to the device.  ECCKD_NO_ERROR_MEMO (read per call): every
+  // request is evaluated, as the reference does - for cross-checks.
+  const bool use_memo = std::getenv("ECCKD_NO_ERROR_MEMO") == nullptr;
+  if (g->error_memo.size() > (size_t)4000000) g->error_memo.clear();
+  std::vector<Interval> todo;
+  std::vector<int> slot(n, -1);            // index into todo, or -1: served from the memo
+  std::unordered_map<IntervalKey, int, IntervalKeyHash> in_batch;
+  for (int k = 0; k < n; ++k) {
+    IntervalKey key;
+    key.i1 = iv[k].i1; key.i2 = iv[k].i2;
+    std::memcpy(&key.albedo_bits, &iv[k].albedo, sizeof(double));
+    if (!g->do_sw) key.albedo_bits = 0;
+    const double len = (double)(iv[k].i2 - iv[k].i1 + 1);
+    g->memo_requests += 1;
+    g->points_requested += len;
+    if (use_memo) {
+      auto hit = g->error_memo.find(key);
+      if (hit != g->error_memo.end()) { error[k] = hit->second; g->memo_hits += 1; continue; }
+      auto dup = in_batch.find(key);
+      if (dup != in_batch.end()) { slot[k] = dup->second; g->memo_hits += 1; continue; }
+      in_batch.emplace(key, (int)todo.size());
+    }
+    slot[k] = (int)todo.size();
+    todo.push_back(iv[k]);
+    g->points_evaluated += len;
+  }
+  if (todo.empty()) return ECCKD_OK;
+  std::vector<double> fresh(todo.size());
+  ECCKD_CHECK(eval_intervals(g, todo, fresh.data()));
+  for (int k = 0; k < n; ++k)
+    if (slot[k] >= 0) error[k] = fresh[slot[k]];
+  if (use_memo)
+    for (size_t t = 0; t < todo.size(); ++t) {
+      IntervalKey key;
+      key.i1 = todo[t].i1; key.i2 = todo[t].i2;
+      std::memcpy(&key.albedo_bits, &todo[t].albedo, sizeof(double));
+      if (!g->do_sw) key.albedo_bits = 0;
+      g->error_memo.emplace(key, fresh[t]);
+    }
+  return ECCKD_OK;
+}
+
+// What the memo of interval errors saved: intervals asked for / found in the memo, wavenumber points asked for (what the
+// reference would have swept) / actually swept on the device.
+int ecckd_gas_eval_stats(ecckd_gas* gas, long long* requests, long long* memo_hits, double* points_requested, double* points_evaluated) {
+  ECCKD_REQUIRE(gas, "ecckd_gas_eval_stats: NULL handle");
+  if (requests) *requests = gas->memo_requests;
+  if (memo_hits) *memo_hits = gas->memo_hits;
+  if (points_requested) *points_requested = gas->points_requested;
+  if (points_evaluated) *points_evaluated = gas->points_evaluated;
   return ECCKD_OK;
 }
 

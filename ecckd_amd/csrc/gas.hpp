@@ -2,6 +2,8 @@
 #pragma once
 #include "common.hpp"
 #include <cstdint>
+#include <cstring>
+#include <unordered_map>
 #include <vector>
 
 // Row table of a gas: which summable per-point rows exist and where (indices into
@@ -20,6 +22,25 @@ struct RowMap {
   int total = 0;
 };
 
+// An interval's error is a function of the interval alone (its first and last sorted index and, in the shortwave, the
+// surface albedo of its band): the partition search asks for the same interval again and again - calc_error_all
+// re-evaluates every interval of a partition of which one bound has moved (equipartition.h:98-116), line_search and the
+// pairwise shuffles come back to bounds they have seen (equipartition.cpp:162-196, :499-531) - and gets the same bits
+// from the memo as from the device.
+struct IntervalKey {
+  long long i1, i2;
+  unsigned long long albedo_bits;
+  bool operator==(const IntervalKey& o) const { return i1 == o.i1 && i2 == o.i2 && albedo_bits == o.albedo_bits; }
+};
+struct IntervalKeyHash {
+  size_t operator()(const IntervalKey& k) const {
+    unsigned long long h = (unsigned long long)k.i1 * 0x9E3779B97F4A7C15ULL;
+    h ^= (unsigned long long)k.i2 + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2);
+    h ^= k.albedo_bits + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2);
+    return (size_t)h;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // opaque handle
 struct ecckd_gas {
@@ -30,6 +51,10 @@ struct ecckd_gas {
   size_t n = 0;  // wavenumbers (sorted order)
   double flux_weight = 0.0;
   double total_comp_cost = 0.0;
+  // memo of interval errors and its counters: intervals asked for / found in the memo, points asked for / swept on the device
+  std::unordered_map<IntervalKey, double, IntervalKeyHash> error_memo;
+  long long memo_requests = 0, memo_hits = 0;
+  double points_requested = 0.0, points_evaluated = 0.0;
   // device arrays, all in sorted order
   double* planck_hl = nullptr;  // [nlay+1][n]
   bool owns_planck = true;

@@ -513,7 +513,8 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
     merged_map: every gas's per-wavenumber g points travel to rank 0 (one reduce per gas; each wavenumber is set by exactly
     one process), which forms the merged g-point map (:1459-1475).
     -> rank 0: dict(ng, band_number, gases, g_point (device), n_unassigned, cost_sum, comp_cost_sum, points);
-       others: dict(cost_sum, comp_cost_sum, points).  `points`: wavenumber points x (1 + passes) this process worked through."""
+       others: dict(cost_sum, comp_cost_sum, points).  `points`: wavenumber points this process worked through: one pass over its bands (reorder, preparation) + the points
+    its searches swept on the device (an interval asked for twice is swept once: the memo of interval errors)."""
     import torch
     dev = ctx.device
     ngas = len(names)
@@ -539,7 +540,8 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
                                min_pressure, sequential_bands, reuse, None)
         for b, r in res:
             r["index_range"] = (int(g["band_begin"][b]), int(g["band_end"][b]))
-            points += (g["band_end"][b] - g["band_begin"][b] + 1) * (1.0 + r["comp_cost"])
+            points += g["band_end"][b] - g["band_begin"][b] + 1            # the reorder / preparation pass over the band
+        points += gas.eval_stats()["points_evaluated"]                       # what the searches swept on the device
         local += [(gi, b, r) for b, r in res]
         if merged_map:
             # this process's bands of the gas: g point of every wavenumber counted from the band's first (-1 elsewhere)

@@ -205,6 +205,15 @@ int ecckd_calc_error_multi(ecckd_gas* gas, int n, const size_t* h_ibegin, const 
                            const double* h_band_albedo, const double* h_bound1, const double* h_bound2,
                            double* h_error);
 
+/* An interval's error depends on the interval alone (its bits are the same in any batch), so the library keeps a memo per
+ * gas: an interval the search has asked for before - calc_error_all re-evaluates every interval of a partition of which
+ * one bound has moved (equipartition.h:98-116) - is answered from it.  The reference's work counter (ecckd_gas_comp_cost,
+ * find_g_points.cpp:320) counts every request all the same.  This call reports what the memo saved: intervals asked for /
+ * answered from the memo, wavenumber points asked for / actually swept on the device.  Environment ECCKD_NO_ERROR_MEMO
+ * (read per call) switches the memo off. */
+int ecckd_gas_eval_stats(ecckd_gas* gas, long long* requests, long long* memo_hits, double* points_requested,
+                         double* points_evaluated);
+
 /* The fitted grey optical depth alone: replaces fit_optical_depth_lw / fit_optical_depth_sw /
  * fit_optical_depth_sw_total_trans (find_g_points.cpp:54-106, :112-165, :171-204) for n
  * intervals; h_od_fit[n][nlay]. */

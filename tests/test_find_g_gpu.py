@@ -17,6 +17,13 @@ from conftest import make_lw_case
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _every_request_on_the_device(monkeypatch):
+    """These tests compare evaluations of the same interval with each other (other batches, other sweep kernels): the memo
+    of interval errors would answer the second one without running it."""
+    monkeypatch.setenv("ECCKD_NO_ERROR_MEMO", "1")
+
 ERR_RTOL = 1e-9
 
 
@@ -341,6 +348,39 @@ def test_interval_error_does_not_depend_on_the_batch(ctx, oracle, nlay, method):
     assert np.array_equal(e_band, e_multi[2:-1])
     assert np.all(np.isfinite(e_multi)) and np.all(e_multi > 0)
     gas.close()
+
+
+def test_memo_of_interval_errors(ctx, oracle, monkeypatch):
+    """The memo answers an interval the search has already asked for (calc_error_all re-evaluates whole partitions of which
+    one bound moved, equipartition.h:98-116) with the bits the device gave: the search takes the same decisions, the
+    reference's work counter counts every request, and fewer points are swept."""
+    n = 60_000
+    o = _lw_problem(oracle, n, nlay=30, seed=29)
+    monkeypatch.delenv("ECCKD_NO_ERROR_MEMO")
+    gas = _make_gas(ctx, o, "transmission", flux_weight=0.02)
+    b1, b2 = np.array([0.0, 0.25, 0.25, 0.6]), np.array([0.25, 0.6, 0.6, 1.0])
+    e1 = gas.calc_error_batch(0, n, b1, b2)
+    st = gas.eval_stats()
+    assert st["requests"] == 4 and st["memo_hits"] == 1 and e1[1] == e1[2]              # a duplicate inside one batch
+    e2 = gas.calc_error_batch(0, n, b1[[3, 0]], b2[[3, 0]])
+    st = gas.eval_stats()
+    assert np.array_equal(e2, e1[[3, 0]]) and st["memo_hits"] == 3 and st["points_evaluated"] < st["points_requested"]
+    assert gas.comp_cost() == pytest.approx(float(np.sum(b2 - b1) + (b2 - b1)[[3, 0]].sum()), rel=1e-14)   # every request counted
+    monkeypatch.setenv("ECCKD_NO_ERROR_MEMO", "1")
+    assert np.array_equal(gas.calc_error_batch(0, n, b1, b2), e1)                       # the device gives the memo's bits
+    monkeypatch.delenv("ECCKD_NO_ERROR_MEMO")
+    res_memo = gas.find_g_band(0, n - 1, 0.05, 0.02, 40)
+    st_memo = gas.eval_stats()
+    gas.close()
+    monkeypatch.setenv("ECCKD_NO_ERROR_MEMO", "1")
+    gas = _make_gas(ctx, o, "transmission", flux_weight=0.02)
+    res_dev = gas.find_g_band(0, n - 1, 0.05, 0.02, 40)
+    st_dev = gas.eval_stats()
+    gas.close()
+    assert res_memo[0] == res_dev[0] and np.array_equal(res_memo[1], res_dev[1]) and np.array_equal(res_memo[2], res_dev[2])
+    assert res_memo[3] == res_dev[3]                                                    # total_comp_cost, find_g_points.cpp:320
+    assert st_dev["memo_hits"] == 0 and st_dev["points_evaluated"] == st_dev["points_requested"]
+    assert st_memo["points_evaluated"] < st_dev["points_evaluated"]
 
 
 @pytest.mark.parametrize("sw", [False, True])

@@ -12,6 +12,13 @@ from conftest import make_lw_case
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _every_request_on_the_device(monkeypatch):
+    """These tests compare evaluations of the same interval with each other (other batches, other sweep kernels): the memo
+    of interval errors would answer the second one without running it."""
+    monkeypatch.setenv("ECCKD_NO_ERROR_MEMO", "1")
+
 ERR_RTOL = 1e-9
 MU0 = 0.5
 
