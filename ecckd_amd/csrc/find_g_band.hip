@@ -16,6 +16,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <immintrin.h>
 
 namespace {
 
@@ -67,69 +68,127 @@ k_invert_perm(size_t n, const int32_t* __restrict__ perm, int32_t* __restrict__ 
   inv[r] = (int32_t)i;
 }
 
-// calc_median_sorting_variable (find_g_points.cpp:35-49), one block per g point.
-// The reference adds the weights one by one; here the total is a strided tree and the running sum is carried over
-// 16-point partial sums, so where the running sum comes within rounding of half the total the crossing can fall on the
-// neighbouring point (whose sorting variable differs from its neighbour's by the local spacing of the sorted keys).
-// Pass 1: total weight of [i1, i2] (fixed strided order + fixed tree).  Pass 2: walk the interval
-// in chunks of 256 x 16 points; an exclusive scan of the 256 per-thread partial sums locates the
-// thread whose 16 points contain the first crossing of half the total, and that thread walks them.
-constexpr int MED_PER = 16;
+// calc_median_sorting_variable (find_g_points.cpp:35-49): the sorting variable at the first index of [i1, i2] where the
+// running sum of the weights reaches half their total (the reference's loop ends at i2 - 1 and falls through to i2).
+// Two kernels: 256-point tile sums of the weight row, once per call; then one block per g point adds the ragged head, the
+// whole tiles and the ragged tail for the total, and finds the crossing top-down - head, tile (a block-wide scan over the
+// tile sums, then a walk through the one segment that holds the crossing), point inside that tile, tail.  The reference
+// adds the weights one by one; here sums are formed by tile and by scan, so where the running sum comes within rounding
+// of half the total the crossing can fall on the neighbouring point (whose sorting variable differs from its
+// neighbour's by the local spacing of the sorted keys).
+constexpr int MED_TILE = 256;
+
 __global__ void __launch_bounds__(256)
-k_median_sorting(const long long* __restrict__ ind1, const long long* __restrict__ ind2,
-                 const double* __restrict__ weight, const double* __restrict__ sv, double* __restrict__ out) {
-  __shared__ double s_part[256];
-  __shared__ double s_scan[257];
-  __shared__ long long s_found;
-  __shared__ double s_carry;
-  const int k = blockIdx.x, tid = threadIdx.x;
-  const long long i1 = ind1[k], i2 = ind2[k];
-  double acc = 0.0;
-  for (long long i = i1 + tid; i <= i2; i += 256) acc += weight[i];
-  s_part[tid] = acc;
+k_median_tile_sums(size_t n, const double* __restrict__ weight, double* __restrict__ ts) {
+  __shared__ double s[256];
+  const size_t i = (size_t)blockIdx.x * MED_TILE + threadIdx.x;
+  s[threadIdx.x] = i < n ? weight[i] : 0.0;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) s_part[tid] += s_part[tid + off];
+    if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
     __syncthreads();
   }
-  const double half = 0.5 * s_part[0];
-  if (tid == 0) { s_found = -1; s_carry = 0.0; }
+  if (threadIdx.x == 0) ts[blockIdx.x] = s[0];
+}
+
+// inclusive scan of one value per thread over the 256 threads of the block (Hillis-Steele, fixed order); the scanned
+// values stay in s[] until the next call: s[t-1] is thread t's exclusive value, s[255] the total
+__device__ __forceinline__ void block_scan_256(double v, double* s) {
+  const int t = threadIdx.x;
   __syncthreads();
-  // the reference loop runs iind = i1 .. i2-1 and falls through to i2 (:42-47)
-  for (long long base = i1; base < i2; base += 256 * MED_PER) {
-    const long long a = base + (long long)tid * MED_PER;
-    double part = 0.0;
-    for (int q = 0; q < MED_PER; ++q) {
-      const long long i = a + q;
-      if (i < i2) part += weight[i];
-    }
-    s_part[tid] = part;
+  s[t] = v;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const double add = t >= off ? s[t - off] : 0.0;
     __syncthreads();
-    if (tid == 0) {
-      double run = s_carry;
-      for (int t = 0; t < 256; ++t) { s_scan[t] = run; run += s_part[t]; }
-      s_scan[256] = run;
-    }
+    s[t] += add;
     __syncthreads();
-    const double before = s_scan[tid], after = s_scan[tid + 1];
-    // the first index at which the running sum reaches half the total lies in this thread's points: nothing before them
-    // had reached it.  The very first point may do so with nothing before it (an interval without weight: half == 0, the
-    // reference's loop stops at i1, :42-46).
-    if (after >= half && (before < half || (base == i1 && tid == 0))) {
-      double cum = before;
-      for (int q = 0; q < MED_PER; ++q) {
-        const long long i = a + q;
-        if (i >= i2) break;
-        cum += weight[i];
-        if (cum >= half) { s_found = i; break; }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_median_sorting(const long long* __restrict__ ind1, const long long* __restrict__ ind2, const double* __restrict__ weight,
+                 const double* __restrict__ ts, const double* __restrict__ sv, double* __restrict__ out) {
+  __shared__ double s_scan[256];
+  __shared__ long long s_found;     // smallest index at which the running sum has reached half the total, or LLONG_MAX
+  __shared__ long long s_tile;
+  __shared__ double s_before;
+  const long long NONE = 0x7fffffffffffffffLL;
+  const int tid = threadIdx.x;
+  const int k = blockIdx.x;
+  const long long i1 = ind1[k], i2 = ind2[k];
+  const long long last = i2 - 1;                         // the loop of :42-47 looks at i1 .. i2-1
+  const long long t1 = (i1 + MED_TILE - 1) / MED_TILE;   // first whole tile
+  const long long t2 = (i2 + 1) / MED_TILE;              // one past the last whole tile
+  const bool tiles = t1 < t2;
+  const long long head_end = tiles ? t1 * MED_TILE : i2 + 1;   // exclusive; without a whole tile everything is "head"
+  const long long seg = tiles ? (t2 - t1 + 255) / 256 : 0;     // whole tiles per thread, contiguous
+  const long long ta = t1 + (long long)tid * seg, tb = tiles ? (ta + seg < t2 ? ta + seg : t2) : ta;
+  // ---- total weight of [i1, i2]: head points, whole tiles, tail points ----
+  double part = 0.0;
+  for (long long i = i1 + tid; i < head_end; i += 256) part += weight[i];
+  block_scan_256(part, s_scan);
+  double total = s_scan[255];
+  double seg_sum = 0.0;
+  for (long long t = ta; t < tb; ++t) seg_sum += ts[t];
+  if (tiles) {
+    block_scan_256(seg_sum, s_scan);
+    total += s_scan[255];
+    const long long tail0 = t2 * MED_TILE;
+    block_scan_256((tail0 + tid <= i2) ? weight[tail0 + tid] : 0.0, s_scan);
+    total += s_scan[255];
+  }
+  const double half = 0.5 * total;
+  if (tid == 0) { s_found = NONE; s_tile = -1; }
+  __syncthreads();
+  // ---- the crossing, top-down.  `carry` = running sum in front of what is being looked at; a thread's exclusive value is
+  //      its neighbour's inclusive one, so exactly one element is the first to reach half ----
+  double carry = 0.0;
+  for (long long base = i1; base < head_end; base += 256) {       // head: rounds of 256 points
+    const long long i = base + tid;
+    const bool in = i < head_end && i <= last;
+    block_scan_256(in ? weight[i] : 0.0, s_scan);
+    const double before = carry + (tid ? s_scan[tid - 1] : 0.0), inc = carry + s_scan[tid];
+    // the very first point may reach half with nothing before it (an interval without weight: half == 0, the reference
+    // stops at i1)
+    if (in && inc >= half && (before < half || i == i1)) atomicMin(&s_found, i);
+    carry += s_scan[255];
+    __syncthreads();
+    if (s_found != NONE) break;
+  }
+  if (tiles && s_found == NONE) {
+    block_scan_256(seg_sum, s_scan);                               // which thread's run of tiles
+    const double before = carry + (tid ? s_scan[tid - 1] : 0.0), inc = carry + s_scan[tid];
+    const double all_tiles = s_scan[255];
+    if (ta < tb && inc >= half && before < half) {
+      double cum = before;                                         // which tile of the run: walk it
+      for (long long t = ta; t < tb; ++t) {
+        const double next = cum + ts[t];
+        if (next >= half || t == tb - 1) { s_tile = t; s_before = cum; break; }
+        cum = next;
       }
     }
     __syncthreads();
-    if (s_found >= 0) break;
-    if (tid == 0) s_carry = s_scan[256];
-    __syncthreads();
+    if (s_tile >= 0) {                                             // which point of that tile
+      const long long i = s_tile * MED_TILE + tid;
+      const bool in = i <= last;
+      block_scan_256(in ? weight[i] : 0.0, s_scan);
+      const double b0 = s_before + (tid ? s_scan[tid - 1] : 0.0), inc2 = s_before + s_scan[tid];
+      if (in && inc2 >= half && b0 < half) atomicMin(&s_found, i);
+      __syncthreads();
+      // (the tile's own sum said "reached", the scan of its points rounds differently: the tile's last point then)
+      if (tid == 0 && s_found == NONE) s_found = (s_tile + 1) * MED_TILE - 1 <= last ? (s_tile + 1) * MED_TILE - 1 : NONE;
+    } else {                                                       // tail
+      const long long i = t2 * MED_TILE + tid;
+      const bool in = i <= last;
+      block_scan_256(in ? weight[i] : 0.0, s_scan);
+      const double base3 = carry + all_tiles;
+      const double b0 = base3 + (tid ? s_scan[tid - 1] : 0.0), inc3 = base3 + s_scan[tid];
+      if (in && inc3 >= half && b0 < half) atomicMin(&s_found, i);
+    }
   }
-  if (tid == 0) out[k] = sv[s_found >= 0 ? s_found : i2];
+  __syncthreads();
+  if (tid == 0) out[k] = sv[s_found != NONE ? s_found : i2];
 }
 
 struct DevBuf {
@@ -256,15 +315,18 @@ int ecckd_gas_median_sorting_variable(ecckd_gas* g, const double* d_sorting_vari
                   (long long)h_ind1[k], (long long)h_ind2[k]);
   // weight: surface Planck function (LW, :1405) or reordered solar irradiance (SW, :1408)
   const double* weight = g->do_sw ? g->ssi : g->planck_hl + (size_t)g->nlay * g->n;
-  DevBuf buf;
-  ECCKD_HIP_CHECK(hipMalloc(&buf.p, (size_t)n * (2 * sizeof(long long) + sizeof(double))));
-  long long* d_i1 = (long long*)buf.p;
+  const size_t ntiles = (g->n + MED_TILE - 1) / MED_TILE;
+  const size_t ts_bytes = ecckd_align_up(ntiles * sizeof(double), 256), idx_bytes = ecckd_align_up((size_t)n * 2 * sizeof(long long), 256);
+  ECCKD_CHECK(ecckd::ensure_scratch(ctx, ts_bytes + idx_bytes + (size_t)n * sizeof(double)));
+  double* d_ts = (double*)ctx->scratch;
+  long long* d_i1 = (long long*)((char*)ctx->scratch + ts_bytes);
   long long* d_i2 = d_i1 + n;
-  double* d_out = (double*)(d_i2 + n);
+  double* d_out = (double*)((char*)ctx->scratch + ts_bytes + idx_bytes);
   std::vector<long long> tmp(2 * (size_t)n);
   for (int k = 0; k < n; ++k) { tmp[k] = h_ind1[k]; tmp[n + k] = h_ind2[k]; }
   ECCKD_HIP_CHECK(hipMemcpyAsync(d_i1, tmp.data(), tmp.size() * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_median_sorting, dim3(n), dim3(256), 0, ctx->stream, d_i1, d_i2, weight, d_sorting_variable_sorted, d_out);
+  hipLaunchKernelGGL(k_median_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, g->n, weight, d_ts);
+  hipLaunchKernelGGL(k_median_sorting, dim3(n), dim3(256), 0, ctx->stream, d_i1, d_i2, weight, d_ts, d_sorting_variable_sorted, d_out);
   ECCKD_HIP_CHECK(hipGetLastError());
   ECCKD_HIP_CHECK(hipMemcpyAsync(h_median, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -276,76 +338,89 @@ int ecckd_gas_median_sorting_variable(ecckd_gas* g, const double* d_sorting_vari
 namespace {
 
 // Merges the error evaluations that several band searches (one host thread each) ask for at the same time into one
-// ecckd_calc_error_multi call.  A search hands in its batch and sleeps; the batch runs when EVERY search that is still
-// going has handed one in (so nothing else touches the gas meanwhile), on the thread that arrived last.
+// ecckd_calc_error_multi call.  A search posts its batch in its own slot and spins on it; the thread that started the
+// searches (ecckd_find_g_bands_ex) watches the slots and runs the merged batch when EVERY search that is still going has
+// posted one.  Only that thread talks to the device: a thread's first HIP call costs milliseconds of per-thread set-up,
+// which with one fresh thread per band and gas used to be most of a narrow-band job's wall time.
 class BandBatcher {
  public:
-  BandBatcher(ecckd_gas* gas, int nsearch) : gas_(gas), active_(nsearch) {}
+  BandBatcher(ecckd_gas* gas, int nsearch) : gas_(gas), slots_(nsearch), active_(nsearch) {}
 
-  int evaluate(size_t ibegin, size_t npoints, double albedo, int n, const double* b1, const double* b2, double* e) {
-    Request r{ibegin, npoints, albedo, n, b1, b2, e, {false}, ECCKD_OK, std::string()};
-    {
-      std::unique_lock<std::mutex> lk(m_);
-      pending_.push_back(&r);
-      if ((int)pending_.size() == active_) run(lk);
-    }
-    // a batch takes a few hundred microseconds: yielding in a loop costs less than being put to sleep and woken up
-    while (!r.done.load(std::memory_order_acquire)) std::this_thread::yield();
-    if (r.rc != ECCKD_OK) ecckd::fail(r.rc, "%s", r.message.c_str());   // the message was recorded on the thread that ran the batch
-    return r.rc;
+  // called by search `id`: post the request, wait for its errors
+  int evaluate(int id, size_t ibegin, size_t npoints, double albedo, int n, const double* b1, const double* b2, double* e) {
+    Slot& s = slots_[id];
+    s.ibegin = ibegin; s.npoints = npoints; s.albedo = albedo; s.n = n; s.b1 = b1; s.b2 = b2; s.e = e;
+    s.state.store(PENDING, std::memory_order_release);
+    while (s.state.load(std::memory_order_acquire) != DONE) _mm_pause();
+    s.state.store(IDLE, std::memory_order_relaxed);
+    if (s.rc != ECCKD_OK) ecckd::fail(s.rc, "%s", s.message.c_str());   // the message was recorded on the thread that ran the batch
+    return s.rc;
   }
 
-  // a search is over (converged, failed, or gone on to its post-processing): the others no longer wait for it
-  void leave() {
-    std::unique_lock<std::mutex> lk(m_);
-    --active_;
-    if (active_ > 0 && (int)pending_.size() == active_) run(lk);
+  // search `id` is over (converged, failed, or gone on to its post-processing): the others no longer wait for it
+  void leave(int id) {
+    slots_[id].state.store(LEFT, std::memory_order_release);
+    active_.fetch_sub(1, std::memory_order_acq_rel);
+  }
+
+  // on the starting thread: serve batches until every search has left
+  void serve() {
+    std::vector<size_t> ib, np;
+    std::vector<double> b1, b2, alb, err;
+    std::vector<int> who;
+    while (active_.load(std::memory_order_acquire) > 0) {
+      // a round is complete when no search is between two requests
+      bool complete = true;
+      who.clear();
+      for (size_t i = 0; i < slots_.size(); ++i) {
+        const int st = slots_[i].state.load(std::memory_order_acquire);
+        if (st == PENDING) who.push_back((int)i);
+        else if (st != LEFT) { complete = false; break; }
+      }
+      if (!complete || who.empty()) { _mm_pause(); continue; }
+      // laid out by band (slot order = band order): the batch is the same from run to run
+      ib.clear(); np.clear(); b1.clear(); b2.clear(); alb.clear();
+      for (int i : who) {
+        const Slot& s = slots_[i];
+        for (int k = 0; k < s.n; ++k) {
+          ib.push_back(s.ibegin); np.push_back(s.npoints); alb.push_back(s.albedo); b1.push_back(s.b1[k]); b2.push_back(s.b2[k]);
+        }
+      }
+      err.resize(b1.size());
+      const int rc = ecckd_calc_error_multi(gas_, (int)b1.size(), ib.data(), np.data(), alb.data(), b1.data(), b2.data(), err.data());
+      const std::string message = rc == ECCKD_OK ? std::string() : std::string(ecckd_last_error());
+      size_t off = 0;
+      for (int i : who) {
+        Slot& s = slots_[i];
+        if (rc == ECCKD_OK) std::copy(err.begin() + off, err.begin() + off + s.n, s.e);
+        off += s.n;
+        s.rc = rc;
+        s.message = message;
+        s.state.store(DONE, std::memory_order_release);
+      }
+    }
   }
 
  private:
-  struct Request {
-    size_t ibegin, npoints;
-    double albedo;      // shortwave: the band's surface albedo
-    int n;
-    const double *b1, *b2;
-    double* e;
-    std::atomic<bool> done;
-    int rc;
+  enum { IDLE = 0, PENDING = 1, DONE = 2, LEFT = 3 };
+  struct Slot {
+    std::atomic<int> state{IDLE};
+    size_t ibegin = 0, npoints = 0;
+    double albedo = 0.0;      // shortwave: the band's surface albedo
+    int n = 0;
+    const double *b1 = nullptr, *b2 = nullptr;
+    double* e = nullptr;
+    int rc = ECCKD_OK;
     std::string message;
   };
 
-  void run(std::unique_lock<std::mutex>&) {   // called with the lock held; every other active search is asleep
-    // the searches arrive in any order: the batch is laid out by band so that its sums (whose chunking follows the layout)
-    // and hence the errors are the same from run to run
-    std::sort(pending_.begin(), pending_.end(), [](const Request* a, const Request* b) { return a->ibegin < b->ibegin; });
-    std::vector<size_t> ib, np;
-    std::vector<double> b1, b2, alb;
-    for (const Request* r : pending_)
-      for (int k = 0; k < r->n; ++k) {
-        ib.push_back(r->ibegin); np.push_back(r->npoints); alb.push_back(r->albedo); b1.push_back(r->b1[k]); b2.push_back(r->b2[k]);
-      }
-    std::vector<double> err(b1.size());
-    const int rc = ecckd_calc_error_multi(gas_, (int)b1.size(), ib.data(), np.data(), alb.data(), b1.data(), b2.data(), err.data());
-    const std::string message = rc == ECCKD_OK ? std::string() : std::string(ecckd_last_error());
-    size_t off = 0;
-    for (Request* r : pending_) {
-      if (rc == ECCKD_OK) std::copy(err.begin() + off, err.begin() + off + r->n, r->e);
-      off += r->n;
-      r->rc = rc;
-      r->message = message;
-    }
-    std::vector<Request*> finished;
-    finished.swap(pending_);
-    for (Request* r : finished) r->done.store(true, std::memory_order_release);   // r may be gone right after this
-  }
-
   ecckd_gas* gas_;
-  int active_;
-  std::mutex m_;
-  std::vector<Request*> pending_;
+  std::vector<Slot> slots_;
+  std::atomic<int> active_;
 };
 
-thread_local BandBatcher* tl_batcher = nullptr;
+struct BatcherRef { BandBatcher* batcher; int id; };
+thread_local BatcherRef tl_batcher = {nullptr, -1};
 std::mutex g_band_device_mutex;
 
 }  // namespace
@@ -360,12 +435,13 @@ int ecckd_find_g_band_ex(ecckd_gas* g, size_t ibegin, size_t iend, double heatin
   const size_t npoints = iend - ibegin + 1;
   const double cost0 = g->total_comp_cost;
   int rc_eval = ECCKD_OK;
-  BandBatcher* const batcher = tl_batcher;    // set when this search is one of several running side by side
+  BandBatcher* const batcher = tl_batcher.batcher;    // set when this search is one of several running side by side
+  const int batcher_id = tl_batcher.id;
   double local_cost = 0.0;
   ecckd::PartitionSearch ps([&](int n, const double* b1, const double* b2, double* e) {
     if (batcher) {
       for (int k = 0; k < n; ++k) local_cost += b2[k] - b1[k];
-      rc_eval = batcher->evaluate(ibegin, npoints, opt->band_albedo, n, b1, b2, e);
+      rc_eval = batcher->evaluate(batcher_id, ibegin, npoints, opt->band_albedo, n, b1, b2, e);
     } else {
       rc_eval = ecckd_calc_error_batch(g, ibegin, npoints, n, b1, b2, e);
     }
@@ -532,22 +608,21 @@ int ecckd_find_g_bands_ex(ecckd_gas* g, int nband, const size_t* ibegin, const s
   threads.reserve(nband);
   for (int b = 0; b < nband; ++b) {
     threads.emplace_back([&, b] {
-      tl_batcher = &batcher;
+      tl_batcher = {&batcher, b};
       struct Leave {   // whatever way the search ends, the others must stop waiting for it
         BandBatcher& bb;
-        bool left = false;
-        void now() { if (!left) { left = true; bb.leave(); } }
-        ~Leave() { now(); }
-      } leave{batcher};
-      (void)hipSetDevice(g->ctx->device);
+        int id;
+        ~Leave() { bb.leave(id); }
+      } leave{batcher, b};
       rc[b] = ecckd_find_g_band_ex(g, ibegin[b], iend[b], heating_rate_tolerance[b], tolerance_tolerance, max_iterations, &opt[b],
                                    &ng[b], bounds + (size_t)b * (capacity + 1), error + (size_t)b * capacity,
                                    rank1 ? rank1 + (size_t)b * capacity : nullptr, rank2 ? rank2 + (size_t)b * capacity : nullptr,
                                    capacity, &status[b], comp_cost ? &comp_cost[b] : nullptr);
       if (rc[b] != ECCKD_OK) message[b] = ecckd_last_error();
-      tl_batcher = nullptr;
+      tl_batcher = {nullptr, -1};
     });
   }
+  batcher.serve();
   for (std::thread& t : threads) t.join();
   for (int b = 0; b < nband; ++b)
     if (rc[b] != ECCKD_OK) return ecckd::fail(rc[b], "band %d: %s", b, message[b].c_str());

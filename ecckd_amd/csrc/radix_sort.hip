@@ -17,6 +17,7 @@
 // Algorithmic traffic per pass: 8 B (histogram) + 12 B read + 12 B written.
 #include "common.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -35,6 +36,37 @@ __device__ __forceinline__ unsigned long long key_to_sortable(double k) {
   return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// Several bands in ONE sort: the spectrum is cut into segments (bands, and the gaps between them) that are contiguous in
+// the input; after the eight passes over the key a ninth pass sorts by segment number, which - the sort being stable -
+// puts every band's points, ordered by key, back into the band's own index range.  Points of a gap carry the key 0 and
+// therefore keep their places.  The segment of an element is looked up from its original index (the payload).
+constexpr int MAX_SEG = 120;
+struct SegTable {
+  int n;                         // number of segments
+  unsigned begin[MAX_SEG];       // first index of segment q (begin[0] = 0)
+  unsigned char is_band[MAX_SEG];
+};
+
+__device__ __forceinline__ unsigned seg_of(const SegTable& st, unsigned j) {
+  unsigned q = 0;
+  for (int t = 1; t < st.n; ++t) q += (st.begin[t] <= j) ? 1u : 0u;
+  return q;
+}
+
+// digit of an element in the pass `shift`: eight bits of the key, or (shift == 64) its segment
+__device__ __forceinline__ unsigned digit_of(unsigned long long key, unsigned idx, int shift, const SegTable& st) {
+  return shift < 64 ? (unsigned)(key >> shift) & (RADIX - 1) : seg_of(st, idx);
+}
+
+__global__ void __launch_bounds__(256)
+k_sort_prepare_segments(size_t n, const double* __restrict__ key, SegTable st, unsigned long long* __restrict__ skey,
+                        unsigned* __restrict__ sidx) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  skey[i] = st.is_band[seg_of(st, (unsigned)i)] ? key_to_sortable(key[i]) : 0ull;
+  sidx[i] = (unsigned)i;
+}
+
 __global__ void __launch_bounds__(256)
 k_sort_prepare(size_t off, size_t n, const double* __restrict__ key,
                unsigned long long* __restrict__ skey, unsigned* __restrict__ sidx) {
@@ -46,7 +78,7 @@ k_sort_prepare(size_t off, size_t n, const double* __restrict__ key,
 
 // (1) tile histogram -> tile_hist[digit * ntiles + tile]
 __global__ void __launch_bounds__(SORT_THREADS)
-k_sort_hist(size_t n, int shift, const unsigned long long* __restrict__ skey,
+k_sort_hist(size_t n, int shift, const unsigned long long* __restrict__ skey, const unsigned* __restrict__ sidx, SegTable st,
             unsigned* __restrict__ tile_hist, unsigned ntiles) {
   __shared__ unsigned s_hist[RADIX];
   const int tid = threadIdx.x;
@@ -57,7 +89,7 @@ k_sort_hist(size_t n, int shift, const unsigned long long* __restrict__ skey,
   for (int it = 0; it < SORT_ITEMS; ++it) {
     size_t i = base + (size_t)it * SORT_THREADS + tid;
     if (i < n) {
-      unsigned d = (unsigned)(skey[i] >> shift) & (RADIX - 1);
+      unsigned d = digit_of(skey[i], shift < 64 ? 0u : sidx[i], shift, st);
       atomicAdd(&s_hist[d], 1u);
     }
   }
@@ -107,7 +139,7 @@ __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_scatter(size_t n, int shift, const unsigned long long* __restrict__ skey_in,
                const unsigned* __restrict__ sidx_in, unsigned long long* __restrict__ skey_out,
                unsigned* __restrict__ sidx_out, const unsigned* __restrict__ tile_offs,
-               unsigned ntiles, const unsigned* __restrict__ digit_total) {
+               unsigned ntiles, const unsigned* __restrict__ digit_total, SegTable st) {
   __shared__ unsigned s_cnt[SORT_WAVES][RADIX];  // per-wave digit counts, then running offsets
   __shared__ unsigned s_dig[RADIX];              // exclusive scan of the digit totals
   const int tid = threadIdx.x;
@@ -141,7 +173,7 @@ k_sort_scatter(size_t n, int shift, const unsigned long long* __restrict__ skey_
     bool valid = i < n;
     k[c] = valid ? skey_in[i] : ~0ull;
     v[c] = valid ? sidx_in[i] : 0u;
-    if (valid) atomicAdd(&s_cnt[wave][(unsigned)(k[c] >> shift) & (RADIX - 1)], 1u);
+    if (valid) atomicAdd(&s_cnt[wave][digit_of(k[c], v[c], shift, st)], 1u);
   }
   __syncthreads();
   // thread `tid` owns digit `tid`: turn counts into per-wave start offsets
@@ -161,7 +193,7 @@ k_sort_scatter(size_t n, int shift, const unsigned long long* __restrict__ skey_
   for (int c = 0; c < SORT_ITEMS; ++c) {
     size_t i = wave_base + (size_t)c * 64 + lane;
     bool valid = i < n;
-    unsigned d = (unsigned)(k[c] >> shift) & (RADIX - 1);
+    unsigned d = digit_of(k[c], v[c], shift, st);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < RADIX_BITS; ++b) {
@@ -244,6 +276,57 @@ extern "C" int ecckd_stable_argsort_bands_dev(ecckd_ctx* ctx, size_t nwav, const
   unsigned* hist = (unsigned*)p;
   unsigned* digit_total = (unsigned*)(p + hist_bytes - 1024);
 
+  SegTable none;
+  std::memset(&none, 0, sizeof none);
+  // several bands, ascending and disjoint (reorder_spectrum.cpp:277-289 builds them so): one nine-pass sort of the whole
+  // spectrum instead of one eight-pass sort per band
+  bool one_sort = nband > 1 && 2 * nband + 1 <= MAX_SEG && std::getenv("ECCKD_SORT_PER_BAND") == nullptr;
+  long long prev_end = -1;
+  for (int b = 0; b < nband && one_sort; ++b) {
+    if (h_band_end[b] < h_band_begin[b]) continue;
+    if (h_band_begin[b] <= prev_end) one_sort = false;
+    prev_end = h_band_end[b];
+  }
+  if (one_sort) {
+    SegTable st;
+    std::memset(&st, 0, sizeof st);
+    long long pos = 0;
+    auto add = [&](long long begin, bool band) { st.begin[st.n] = (unsigned)begin; st.is_band[st.n] = band ? 1 : 0; ++st.n; };
+    for (int b = 0; b < nband; ++b) {
+      if (h_band_end[b] < h_band_begin[b]) continue;
+      if (h_band_begin[b] > pos) add(pos, false);
+      add(h_band_begin[b], true);
+      pos = h_band_end[b] + 1;
+    }
+    if (pos < (long long)nwav) add(pos, false);
+    const size_t n = nwav;
+    const unsigned ntiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+    const unsigned eblocks = (unsigned)((n + 255) / 256);
+    const size_t kb = ecckd_align_up(n * sizeof(unsigned long long), 256), ib = ecckd_align_up(n * sizeof(unsigned), 256);
+    const size_t hb = ecckd_align_up((size_t)RADIX * ntiles * sizeof(unsigned), 256) + 1024;
+    ECCKD_CHECK(ecckd::ensure_scratch(ctx, 2 * kb + 2 * ib + hb));
+    char* q = (char*)ctx->scratch;
+    unsigned long long* ks[2] = {(unsigned long long*)q, (unsigned long long*)(q + kb)};
+    q += 2 * kb;
+    unsigned* is[2] = {(unsigned*)q, (unsigned*)(q + ib)};
+    q += 2 * ib;
+    unsigned* hs = (unsigned*)q;
+    unsigned* dt = (unsigned*)(q + hb - 1024);
+    hipLaunchKernelGGL(k_sort_prepare_segments, dim3(eblocks), dim3(256), 0, ctx->stream, n, d_key, st, ks[0], is[0]);
+    int cur = 0;
+    for (int pass = 0; pass <= 64 / RADIX_BITS; ++pass) {
+      const int shift = pass * RADIX_BITS;      // the last one, 64: by segment
+      hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, ks[cur], is[cur], st, hs, ntiles);
+      hipLaunchKernelGGL(k_sort_scan_rows, dim3(RADIX), dim3(256), 0, ctx->stream, hs, ntiles, dt);
+      hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, ks[cur], is[cur], ks[cur ^ 1],
+                         is[cur ^ 1], hs, ntiles, dt, st);
+      cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_sort_finish, dim3(eblocks), dim3(256), 0, ctx->stream, (size_t)0, n, is[cur], d_rank, d_ordered_index);
+    ECCKD_HIP_CHECK(hipGetLastError());
+    return ECCKD_OK;
+  }
+
   for (int b = 0; b < nband; ++b) {
     if (h_band_end[b] < h_band_begin[b]) continue;
     const size_t off = (size_t)h_band_begin[b];
@@ -254,11 +337,11 @@ extern "C" int ecckd_stable_argsort_bands_dev(ecckd_ctx* ctx, size_t nwav, const
     int cur = 0;
     for (int pass = 0; pass < 64 / RADIX_BITS; ++pass) {
       const int shift = pass * RADIX_BITS;
-      hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, keys[cur],
+      hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, keys[cur], idxs[cur], none,
                          hist, ntiles);
       hipLaunchKernelGGL(k_sort_scan_rows, dim3(RADIX), dim3(256), 0, ctx->stream, hist, ntiles, digit_total);
       hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift,
-                         keys[cur], idxs[cur], keys[cur ^ 1], idxs[cur ^ 1], hist, ntiles, digit_total);
+                         keys[cur], idxs[cur], keys[cur ^ 1], idxs[cur ^ 1], hist, ntiles, digit_total, none);
       cur ^= 1;
     }
     hipLaunchKernelGGL(k_sort_finish, dim3(eblocks), dim3(256), 0, ctx->stream, off, n, idxs[cur], d_rank,

@@ -378,7 +378,7 @@ def test_memo_of_interval_errors(ctx, oracle, monkeypatch):
     st_dev = gas.eval_stats()
     gas.close()
     assert res_memo[0] == res_dev[0] and np.array_equal(res_memo[1], res_dev[1]) and np.array_equal(res_memo[2], res_dev[2])
-    assert res_memo[3] == res_dev[3]                                                    # total_comp_cost, find_g_points.cpp:320
+    assert res_memo[3] == pytest.approx(res_dev[3], rel=1e-12)                          # total_comp_cost (find_g_points.cpp:320): same requests
     assert st_dev["memo_hits"] == 0 and st_dev["points_evaluated"] == st_dev["points_requested"]
     assert st_memo["points_evaluated"] < st_dev["points_evaluated"]
 

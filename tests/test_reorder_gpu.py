@@ -138,6 +138,32 @@ def test_sort_bands_and_outside_points(ctx, oracle):
     assert outside.any() and np.array_equal(orank[outside], np.nonzero(outside)[0])
 
 
+def test_sort_of_several_bands_in_one_go_matches_band_by_band(ctx, monkeypatch):
+    """Several bands are sorted by ONE nine-pass sort (eight passes over the key, one over the segment number); the
+    band-by-band path (ECCKD_SORT_PER_BAND) and numpy's stable argsort per band give the same permutation - with gaps
+    between bands, points outside every band, ties, NaN and -0.0."""
+    from ecckd_amd import api
+    n = 70_001
+    rs = np.random.RandomState(3)
+    key = rs.normal(size=n)
+    key[rs.uniform(size=n) < 0.2] = 0.25
+    key[rs.uniform(size=n) < 0.02] = -0.0
+    key[rs.uniform(size=n) < 0.02] = 0.0
+    key[[5000, 30000, 30001]] = np.nan
+    bb = np.array([100, 9000, 9001 + 4096, 40000, 69990])           # gap below, two adjacent bands, gaps, a tiny last band
+    be = np.array([8999, 9000 + 4096, 31000, 65000, 70000])
+    d_key = _dev(ctx, key)
+    rank, oi = api.stable_argsort_bands(ctx, d_key, bb, be)
+    monkeypatch.setenv("ECCKD_SORT_PER_BAND", "1")
+    rank_b, oi_b = api.stable_argsort_bands(ctx, d_key, bb, be)
+    assert torch.equal(rank, rank_b) and torch.equal(oi, oi_b)
+    expect = np.arange(n)
+    skey = np.where(key == 0.0, 0.0, key)
+    for a, b in zip(bb, be):
+        expect[a:b + 1] = a + np.argsort(skey[a:b + 1], kind="stable")      # NaN last, as numpy sorts it too
+    assert np.array_equal(oi.cpu().numpy(), expect)
+
+
 def test_sort_all_ties_is_identity(ctx):
     from ecckd_amd import api
     n = 10000
