@@ -426,6 +426,7 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                         "ng_per_gas": [int(sum(g["n_g_points"])) for g in info.get("gases", [])],
                         "searches_not_converged": int(sum(st != 0 for g in info.get("gases", []) for st in g["status"])),
                         "n_unassigned": info.get("n_unassigned"), "final_cost_sum_K_per_day": total_cost,
+                        "phase_ms_last_step_rank_0": {k: round(v * 1e3, 2) for k, v in info.get("phase_seconds", {}).items()},
                         "tasks_on_rank_0": extra["tasks_this_rank"]}),
             "spectra": {"generator": args.spectra, "lines_per_gas": args.nlines if args.spectra == "lines" else 32},
             "search": {"error_batches_per_step": rt_calls / max(args.steps, 1),

@@ -314,6 +314,9 @@ def _search_gas(ctx, g, bands, tol, tolerance_tolerance, max_iterations, averagi
     sw: None (longwave; planck_reuse = device pointer of the first gas's Planck matrix or None) or
         dict(ssi, albedo: device tensors, band_albedo[nband], cos_sza).
     Returns (gas handle - the caller closes it -, [(band, dict(rank1, rank2, error, status, comp_cost, sorting_variable))])."""
+    import time
+    timing = g.setdefault("timing", {})
+    t0 = time.perf_counter()
     if sw is None:
         gas = api.GasLW(ctx, g["pressure_hl"], g["temperature_hl"], g["wn"], g["dwn"], g["rank"], g["od"], g.get("bg"),
                         averaging_method, flux_weight, min_pressure, planck_hl_reuse=planck_reuse)
@@ -323,6 +326,9 @@ def _search_gas(ctx, g, bands, tol, tolerance_tolerance, max_iterations, averagi
                         min_pressure, sw["cos_sza"], sw["albedo"], g.get("min_scaling", 1.0), g.get("max_scaling", 1.0))
         band_albedo = sw["band_albedo"]
     sv_sorted = api.gather_f64(ctx, g["sorting_variable"], api.invert_permutation(ctx, g["rank"]))
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    timing["preparation"] = timing.get("preparation", 0.0) + t1 - t0
     begin, end = g["band_begin"], g["band_end"]
     opts = [dict(min_g_points=int(g["min_g_points"][b]), max_g_points=int(g["max_g_points"][b])) for b in bands]
     if len(bands) > 1 and not sequential_bands:
@@ -337,12 +343,22 @@ def _search_gas(ctx, g, bands, tol, tolerance_tolerance, max_iterations, averagi
             if band_albedo is not None:
                 gas.set_band_albedo(band_albedo[b])                                                   # init_sw(..., band_albedo(jband), ...)
             band_res.append(gas.find_g_band_ex(int(begin[b]), int(end[b]), float(tol[b]), tolerance_tolerance, max_iterations, **o))
+    t2 = time.perf_counter()
+    timing["search"] = timing.get("search", 0.0) + t2 - t1
+    # the median sorting variable of every g point of these bands in one call
+    r1_all = np.concatenate([np.asarray(res["rank1"], dtype=np.int64) for res in band_res])
+    r2_all = np.concatenate([np.asarray(res["rank2"], dtype=np.int64) for res in band_res])
+    med_all = gas.median_sorting_variable(sv_sorted, r1_all, r2_all)
     out = []
+    k0 = 0
     for b, res in zip(bands, band_res):
-        med = gas.median_sorting_variable(sv_sorted, res["rank1"], res["rank2"])
+        n = len(res["rank1"])
+        med = med_all[k0:k0 + n]
+        k0 += n
         out.append((b, dict(rank1=[int(v) for v in res["rank1"]], rank2=[int(v) for v in res["rank2"]],
                             error=[float(v) for v in res["error"]], status=int(res["status"]),
                             comp_cost=float(res["comp_cost"]), sorting_variable=[float(v) for v in med])))
+    timing["medians"] = timing.get("medians", 0.0) + time.perf_counter() - t2
     return gas, out
 
 
@@ -522,11 +538,16 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
     tol = np.broadcast_to(np.asarray(heating_rate_tolerance, dtype=np.float64), (nband,))
     first_lw_gas = None
     planck_first = None
+    import time
     local, maps = [], {}
     points = 0.0
     nwav = None
+    phase = {"reorder": 0.0, "preparation": 0.0, "search": 0.0, "medians": 0.0, "maps": 0.0, "collect": 0.0}
     for gi in sorted(my_bands):
+        tl = time.perf_counter()
         g = load_gas(gi)
+        ctx.synchronize()
+        phase["reorder"] += time.perf_counter() - tl
         nwav = g["rank"].numel()
         reuse = None
         if gi > 0 and first_lw_gas is not None:
@@ -543,6 +564,9 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
             points += g["band_end"][b] - g["band_begin"][b] + 1            # the reorder / preparation pass over the band
         points += gas.eval_stats()["points_evaluated"]                       # what the searches swept on the device
         local += [(gi, b, r) for b, r in res]
+        for k in ("preparation", "search", "medians"):
+            phase[k] += g["timing"].get(k, 0.0)
+        tm = time.perf_counter()
         if merged_map:
             # this process's bands of the gas: g point of every wavenumber counted from the band's first (-1 elsewhere)
             gp = torch.full((nwav,), -1, dtype=torch.int32, device=dev)
@@ -554,9 +578,11 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
             first_lw_gas = gas
         else:
             gas.close()
+        phase["maps"] += time.perf_counter() - tm
     if first_lw_gas is not None:
         first_lw_gas.close()
     planck_first = None
+    tc = time.perf_counter()
     by_task, cost_sum, comp_sum = _collect(local, len(tasks), rank, world_size, group, dev)
     gas_gp = []
     if merged_map:
@@ -568,12 +594,13 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
                 gp = torch.full((nwav,), -1, dtype=torch.int32, device=dev)
             gas_gp.append(_max_to_root(gp, world_size, group))
     if rank != 0:
-        return dict(rank=rank, tasks=mine, cost_sum=cost_sum, comp_cost_sum=comp_sum, points=points)
+        phase["collect"] = time.perf_counter() - tc
+        return dict(rank=rank, tasks=mine, cost_sum=cost_sum, comp_cost_sum=comp_sum, points=points, phase_seconds=phase)
     per_gas = _per_gas_tables(names, nband, by_task)
     ng, band_number, g_min, g_max = api.overlap_g_points([g["n_g_points"] for g in per_gas],
                                                          [np.asarray(g["sorting_variable"]) for g in per_gas])
     result = dict(ng=ng, band_number=band_number, gases=per_gas, cost_sum=cost_sum, comp_cost_sum=comp_sum, rank=0, tasks=mine,
-                  points=points)
+                  points=points, phase_seconds=phase)
     for k, g in enumerate(per_gas):
         g["g_min"], g["g_max"] = g_min[k], g_max[k]
     if merged_map:
@@ -588,6 +615,7 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
                     sl += torch.where(sl >= 0, int(first[b]), 0).to(sl.dtype)
         result["g_point"], result["n_unassigned"] = api.merge_g_points(ctx, gas_gp, g_min, g_max)
         result["gas_g_point"] = gas_gp
+    phase["collect"] = time.perf_counter() - tc
     return result
 
 
