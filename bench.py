@@ -33,6 +33,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+K1_VALU_PER_POINT = 677.0e6 * 64 / 7.2e6   # SQ_INSTS_VALU (wave instructions) per launch of 7.2e6 points, profiles/r01_pmc_k_rt_lw_bb_mirror.md
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -46,7 +47,7 @@ def parse():
     ap.add_argument("--tolerance", type=float, default=0.0161)   # fsck, test/do_all_lw.sh:59-60
     ap.add_argument("--tolerance-tolerance", type=float, default=0.01)  # test/find_g_points_lw.sh
     ap.add_argument("--max-iterations", type=int, default=60)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 15)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lut-opt", action="store_true")
     ap.add_argument("--no-sw", action="store_true")
@@ -83,43 +84,50 @@ def make_inputs(xp, nwav, nlay, seed, device=None, spectra="lines", nlines=12000
     return p, wn_h, dwn_h, od, bg
 
 
-def cpu_baseline(nwav_s, nlay, seed, tol, tol_tol, max_it):
-    """The oracle ("port") on the host with OpenMP at the reference's own sites (planck_function.cpp:50 over
-    levels, equipartition.h:101 over the intervals of calc_error_all, as find_g_points.cpp:231 enables it):
-    reorder + gas prep + the reference-built partition search (oracle/_ref) over the oracle's calc_error."""
+def cpu_baseline(args, nwav_s, nlay, seed, tol, tol_tol, max_it, device):
+    """The oracle ("port") on the host cores: reorder_spectrum -> find_g_points for one gas of the same generator at
+    `nwav_s` points, in C end to end (oracle/oracle_chain.c: restated pieces composed as the reference's main() functions
+    do, the partition search by the REFERENCE's own Equipartition built into oracle/_ref, a C callback for calc_error - no
+    Python inside), OpenMP at the reference's sites (planck_function.cpp:50, equipartition.h:101 as find_g_points.cpp:231
+    enables it).  The sample spectrum is generated on the device and handed to the host."""
+    import ctypes as C
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as o
     from ecckd_amd import synthetic as syn
-    p, wn, dwn, od32, bg32 = make_inputs(np, nwav_s, nlay, seed)
-    od, bg = od32.astype(np.float64), bg32.astype(np.float64)
-    t_hl = syn.temperature_profile(p)
-    t0 = time.perf_counter()
-    key, col, _ = o.reorder_key(p, o.idealised_temperature(p), wn, dwn, od, None, 0.5)
-    _, oi, rank = o.stable_argsort_bands(wn, key, [0.0], [3260.0])
-    ireorder = np.empty(nwav_s, dtype=np.int64)
-    ireorder[rank] = np.arange(nwav_s)
-    od_s, bg_s = od[:, ireorder], bg[:, ireorder]
-    planck = o.planck_function(t_hl, wn[ireorder], dwn[ireorder])
-    fdn, fup = o.radiative_transfer_lw(planck, bg_s + od_s, np.ones(nwav_s), planck[-1])
-    hr = o.heating_rate(p, fdn, fup)
-    eq = o.CkdEquipartitionLW("transmission", 0.0, o.layer_weight(p, 0.0), p, np.ones(nwav_s), planck[-1],
-                              fdn[-1].copy(), fup[0].copy(), planck, bg_s, o.metric("transmission", od_s), hr)
-    if o.ref_lib() is not None:
-        ref = o.RefEquipartition(eq.calc_error, resolution=1.0 / nwav_s, partition_tolerance=tol_tol,
-                                 partition_max_iterations=max_it, parallel=True)
-        devnull = os.open(os.devnull, os.O_WRONLY)
-        saved = os.dup(1)
-        os.dup2(devnull, 1)  # the reference search prints progress to stdout
-        try:
-            st, b, e = ref.equipartition_e(tol)
-        finally:
-            os.dup2(saved, 1)
-            os.close(devnull)
-        search = "reference equipartition.cpp (oracle/_ref)"
-    else:
+    p, wn, dwn, od, bg = make_inputs(torch, nwav_s, nlay, seed, device=device, spectra=args.spectra, nlines=args.nlines)
+    od32 = np.ascontiguousarray(od.cpu().numpy(), dtype=np.float32)
+    bg32 = np.ascontiguousarray(bg.cpu().numpy(), dtype=np.float32)
+    del od, bg
+    t_hl = np.ascontiguousarray(syn.temperature_profile(p))
+    L = o.lib()
+    ref = os.path.join(ROOT, "oracle", "_ref", "libequipartition_ref.so")
+    if not os.path.exists(ref):
         raise RuntimeError("oracle/_ref not built")
-    dt = time.perf_counter() - t0
-    return nwav_s * (1.0 + eq.total_comp_cost), dt, len(e), eq.total_comp_cost, search
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    b1, b2, tolv = np.array([0.0]), np.array([3260.0]), np.array([float(tol)])
+    ng, st = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
+    cc, secs = np.zeros(1), np.zeros(3)
+    rank = np.zeros(nwav_s, dtype=np.int32)
+    L.orc_find_g_lw_chain.restype = C.c_int
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(1)
+    os.dup2(devnull, 1)  # the reference search prints progress to stdout
+    try:
+        t0 = time.perf_counter()
+        rc = L.orc_find_g_lw_chain(ref.encode(), C.c_int(nlay), C.c_size_t(nwav_s), P(np.ascontiguousarray(p)), P(t_hl), P(wn), P(dwn),
+                                   od32.ctypes.data_as(C.POINTER(C.c_float)), bg32.ctypes.data_as(C.POINTER(C.c_float)),
+                                   C.c_double(0.5), C.c_int(1), P(b1), P(b2), C.c_int(1), C.c_double(0.0), C.c_double(0.0), P(tolv),
+                                   C.c_double(tol_tol), C.c_int(max_it), C.c_int(1), ng.ctypes.data_as(C.POINTER(C.c_int)), P(cc),
+                                   st.ctypes.data_as(C.POINTER(C.c_int)), P(secs), rank.ctypes.data_as(C.POINTER(C.c_int32)))
+        dt = time.perf_counter() - t0
+    finally:
+        os.dup2(saved, 1)
+        os.close(devnull)
+    if rc:
+        raise RuntimeError("orc_find_g_lw_chain failed with code %d" % rc)
+    return dict(points=nwav_s * (1.0 + cc[0]), seconds=float(secs.sum()), wall=dt, ng=int(ng[0]), n_pass=float(cc[0]),
+                status=int(st[0]), stage_seconds=dict(reorder=secs[0], preparation=secs[1], search=secs[2]))
 
 
 def sw_find_g_bench(ctx, nwav=3_300_000, nlay=54):
@@ -438,9 +446,16 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                          "algorithmic_bytes_per_point": rt_bytes_per_pt,
                          "points_per_launch": rt_pts / max(rt_calls, 1),
                          "share_of_step_time": rt_ms * 1e-3 / dt,
-                         "k_reorder_key_lw": {"avg_launch_ms": k1_ms / max(k1_calls, 1),
-                                              "achieved": k1_pts * k1_bytes_per_pt / max(k1_ms * 1e-3, 1e-12) / 1e9,
-                                              "algorithmic_bytes_per_point": k1_bytes_per_pt}},
+                         # K1 is bound by fp64 vector issue, not by HBM: ~94 VALU instructions per layer and point (2 exp, 2
+                         # divisions; rocprofv3 SQ_INSTS_VALU, profiles/) at 4 cycles per wave64 fp64 instruction
+                         "k_reorder_key_lw": {"bound": "fp64 issue", "avg_launch_ms": k1_ms / max(k1_calls, 1),
+                                              "hbm_achieved_GBs": k1_pts * k1_bytes_per_pt / max(k1_ms * 1e-3, 1e-12) / 1e9,
+                                              "algorithmic_bytes_per_point": k1_bytes_per_pt,
+                                              "valu_instructions_per_point": K1_VALU_PER_POINT,
+                                              "issue_floor_ms": K1_VALU_PER_POINT * (k1_pts / max(k1_calls, 1)) / 64.0 * 4.0
+                                                                / (256 * 4 * 2.4e9) * 1e3,
+                                              "frac_of_fp64_issue_roof": (K1_VALU_PER_POINT * (k1_pts / max(k1_calls, 1)) / 64.0 * 4.0
+                                                                          / (256 * 4 * 2.4e9) * 1e3) / max(k1_ms / max(k1_calls, 1), 1e-12)}},
         }
         if h2d_ms is not None:
             step_ms = dt * 1e3 / args.steps
@@ -454,12 +469,18 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
         if world == 1 and not args.no_sw and args.config == 1:
             out["sw_find_g"] = sw_find_g_bench(ctx)
         if world == 1 and not args.no_cpu and args.config == 1:
-            pts, cdt, cng, ccost, search = cpu_baseline(args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance,
-                                                        args.tolerance_tolerance, args.max_iterations)
-            out["cpu_baseline"] = {"value": pts / cdt, "unit": "wavenumber-points/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
-                                   "sample": "oracle reorder + gas prep + %s over oracle calc_error, nwav=%d "
-                                             "(same generator, ng=%d, N_pass=%.1f, %.1f s)"
-                                             % (search, args.cpu_sample, cng, ccost, cdt)}
+            cb = cpu_baseline(args, args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance, args.tolerance_tolerance,
+                              args.max_iterations, dev)
+            out["cpu_baseline"] = {"value": cb["points"] / cb["seconds"], "unit": "wavenumber-points/s",
+                                   "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+                                   "sample": "oracle/oracle_chain.c (C end to end: reorder + gas preparation + the reference's "
+                                             "equipartition.cpp from oracle/_ref over the oracle's calc_error, OpenMP at the "
+                                             "reference's sites), same generator at nwav=%d: ng=%d, N_pass=%.1f (every request "
+                                             "swept, as the reference does), search status %d, %.1f s (reorder %.2f, "
+                                             "preparation %.2f, search %.2f)"
+                                             % (args.cpu_sample, cb["ng"], cb["n_pass"], cb["status"], cb["seconds"],
+                                                cb["stage_seconds"]["reorder"], cb["stage_seconds"]["preparation"],
+                                                cb["stage_seconds"]["search"])}
     return out
 
 

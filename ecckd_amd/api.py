@@ -749,6 +749,18 @@ class Optimizer:
             add_prior = dist.get_rank(group) == 0
         check(self.lib.ecckd_opt_set_allreduce(self.handle, C.cast(fn, C.c_void_p), None, int(bool(add_prior))))
 
+    def set_progress(self, fn):
+        """fn(iteration, cost, gradient_norm) once per L-BFGS iteration (report_progress, solve_adept.cpp:295-299); also
+        starts the activity timers read by timings()."""
+        self._progress = _lib.PROGRESS_FN(lambda it, cost, gnorm, _user: fn(it, cost, gnorm)) if fn is not None else None
+        check(self.lib.ecckd_opt_set_progress(self.handle, C.cast(self._progress, C.c_void_p) if fn is not None else None, None))
+
+    def timings(self):
+        """Seconds in the reference's three activities (solve_adept.cpp:216-218): dict(minimizer, a_priori, radiative_transfer)."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(self.lib.ecckd_opt_timings(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return {"minimizer": a.value, "a-priori": b.value, "radiative transfer": c.value}
+
     def initial_state(self, bounds=False):
         x = np.empty(self.nx)
         if not bounds:

@@ -409,6 +409,11 @@ int main(int argc, char** argv) {
     std::vector<double> x(nx);
     int status = 0, niter = 0;
     double J = 0.0, gnorm = 0.0;
+    // report_progress (solve_adept.cpp:295-299) and the Timer of :214-231, whose table goes to stderr when it is destroyed
+    ck(ecckd_opt_set_progress(opt, [](int it, double cost, double gn, void*) {
+      LOG("Iteration %d: cost function = %g, gradient norm = %g\n", it, cost, gn);
+    }, nullptr));
+    LOG(is_bounded ? "  Minimization is bounded\n" : "  Minimization is unbounded\n");
     ck(ecckd_opt_minimize(opt, max_iterations, convergence_criterion, is_bounded ? 1 : 0, x.data(), &status, &niter, &J, &gnorm));
     static const char* const status_str[] = {"Converged", "Initial state", "Maximum iterations reached", "Failed to converge",
                                              "Direction-finding failure", "Bound reached", "Invalid cost function", "Invalid gradient",
@@ -416,6 +421,12 @@ int main(int argc, char** argv) {
     LOG("Minimizer status: %s after %d iterations, cost function %g, gradient norm %g\n",
         status >= 0 && status < 9 ? status_str[status] : "unknown", niter, J, gnorm);
     for (size_t i = 0; i < model.gases.size(); ++i) ck(ecckd_opt_coefficients(opt, x.data(), (int)i, model.gases[i].molar_abs.data()));
+    {
+      double t_min = 0.0, t_prior = 0.0, t_rt = 0.0;   // Timer::print (Timer.h:59-69)
+      ck(ecckd_opt_timings(opt, &t_min, &t_prior, &t_rt));
+      std::fprintf(stderr, "3 activities:\n%10g s: minimizer\n%10g s: a-priori\n%10g s: radiative transfer\n%10g s: Total\n", t_min, t_prior,
+                   t_rt, t_min + t_prior + t_rt);
+    }
     ck(ecckd_opt_destroy(opt));
     if (gp.gmap) ck(ecckd_gmap_destroy(gp.gmap));
 

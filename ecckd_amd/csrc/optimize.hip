@@ -30,6 +30,7 @@
 // The dominant costs are launch latency and ~50 MB of traffic per iteration;
 // the metric is iterations per second.
 #include "common.hpp"
+#include <chrono>
 #include "fastmath.hpp"
 
 #include <algorithm>
@@ -765,6 +766,11 @@ struct ecckd_opt {
   bool add_prior = true;     // exactly one rank contributes the prior term
   // timing
   long long n_eval = 0;
+  // progress line and activity timers of solve_adept.cpp (:216-218 "minimizer", "a-priori", "radiative transfer"; :295-299)
+  ecckd_progress_fn progress_fn = nullptr;
+  void* progress_user = nullptr;
+  hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
+  double t_rt = 0.0, t_prior = 0.0, t_minimizer = 0.0;
 };
 
 namespace {
@@ -789,6 +795,8 @@ void opt_free(ecckd_opt* o) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (o->h_pin) (void)hipHostFree(o->h_pin);
+  for (hipEvent_t e : o->tev)
+    if (e) (void)hipEventDestroy(e);
   delete o;
 }
 
@@ -1208,6 +1216,25 @@ size_t ecckd_opt_nx(ecckd_opt* o) { return o ? o->nx : 0; }
 // Initial state and log-space bounds, solve_adept.cpp:335-353.  h_x_min/h_x_max may be NULL;
 // unbounded elements get -/+ infinity.  Returns the gas order of the state in h_gas_order
 // (user gas indices of the active gases, in state order) if not NULL.
+int ecckd_opt_set_progress(ecckd_opt* o, ecckd_progress_fn fn, void* user) {
+  ECCKD_REQUIRE(o, "ecckd_opt_set_progress: NULL handle");
+  o->progress_fn = fn;
+  o->progress_user = user;
+  if (!o->tev[0]) {
+    ECCKD_HIP_CHECK(hipSetDevice(o->ctx->device));
+    for (int k = 0; k < 3; ++k) ECCKD_HIP_CHECK(hipEventCreate(&o->tev[k]));
+  }
+  return ECCKD_OK;
+}
+
+int ecckd_opt_timings(ecckd_opt* o, double* minimizer_s, double* a_priori_s, double* radiative_transfer_s) {
+  ECCKD_REQUIRE(o, "ecckd_opt_timings: NULL handle");
+  if (minimizer_s) *minimizer_s = o->t_minimizer;
+  if (a_priori_s) *a_priori_s = o->t_prior;
+  if (radiative_transfer_s) *radiative_transfer_s = o->t_rt;
+  return ECCKD_OK;
+}
+
 int ecckd_opt_set_allreduce(ecckd_opt* o, ecckd_allreduce_fn fn, void* user, int add_prior) {
   ECCKD_REQUIRE(o, "ecckd_opt_set_allreduce: NULL argument");
   o->reduce_fn = fn;
@@ -1266,16 +1293,29 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
   const int ngpad = (ng + 63) / 64 * 64;
   const int lgroups = std::max(1, 256 / ngpad);
   const int threads = ngpad * lgroups;
+  const bool timed = o->tev[0] != nullptr;
+  if (timed) ECCKD_HIP_CHECK(hipEventRecord(o->tev[0], ctx->stream));
   ECCKD_CHECK(opt_launch_forward(o));
+  if (timed) ECCKD_HIP_CHECK(hipEventRecord(o->tev[1], ctx->stream));
   hipLaunchKernelGGL(k_opt_gradient, dim3((unsigned)o->nnode_active), dim3(threads),
                      ((size_t)lgroups * ngpad + 16) * sizeof(double), ctx->stream, o->nnode_active, ng, ngpad, d_x, o->d_xprior,
                      o->d_k, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_dtau, o->d_node_gas, o->d_node_ic,
                      o->d_node_it, o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2,
                      prior ? 1 : 0, d_grad, o->d_jb);
   ECCKD_HIP_CHECK(hipGetLastError());
+  if (timed) ECCKD_HIP_CHECK(hipEventRecord(o->tev[2], ctx->stream));
   ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jcol, o->d_jcol, o->ncol * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jb, o->d_jb, o->nnode_active * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (timed) {
+    // "radiative transfer": look-up, penalty, two sweeps, cost and their adjoint; "a-priori": the gradient kernel, which
+    // gathers the adjoint back onto the coefficients and adds the prior term (the reference times the prior alone there)
+    float ms = 0.f;
+    ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, o->tev[0], o->tev[1]));
+    o->t_rt += 1e-3 * ms;
+    ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, o->tev[1], o->tev[2]));
+    o->t_prior += 1e-3 * ms;
+  }
   double j = 0.0;
   for (size_t c = 0; c < o->ncol; ++c) j += o->h_jcol[c];  // scene/profile order, as the reference accumulates (:157)
   double jb = 0.0;
@@ -1415,6 +1455,8 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   bool pending = false;   // a pair has been written to `pend_slot`; its dots are read with the next direction
   int pend_slot = 0;
 
+  const auto wall0 = std::chrono::steady_clock::now();
+  const double dev0 = o->t_rt + o->t_prior;
   double J = 0.0;
   ECCKD_CHECK(opt_cost_grad_dev(o, x, g, &J));
   int st = 2, it = 0;
@@ -1451,6 +1493,7 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
       pending = false;
     }
     gnorm = std::sqrt(h_rb[0]);
+    if (o->progress_fn) o->progress_fn(it, J, gnorm, o->progress_user);   // report_progress, solve_adept.cpp:295-299
     if (!(gnorm == gnorm)) { st = 7; break; }
     if (gnorm <= convergence_criterion) { st = 0; break; }
     if (it == max_iterations) { st = 2; break; }
@@ -1554,6 +1597,7 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   }
   ECCKD_HIP_CHECK(hipMemcpyAsync(h_x, x, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  o->t_minimizer += std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() - (o->t_rt + o->t_prior - dev0);
   *status = st;
   if (n_iterations) *n_iterations = it;
   if (J_final) *J_final = J;

@@ -544,6 +544,15 @@ int ecckd_opt_minimize(ecckd_opt* opt, int max_iterations, double convergence_cr
 typedef int (*ecckd_allreduce_fn)(void* d_buf, size_t count, void* stream, void* user);
 int ecckd_opt_set_allreduce(ecckd_opt* opt, ecckd_allreduce_fn fn, void* user, int add_prior);
 
+/* The minimizer's progress line and the three timed activities of the reference (solve_adept.cpp:216-218 "minimizer",
+ * "a-priori", "radiative transfer"; report_progress :295-299 "Iteration n: cost function = ..., gradient norm = ...").
+ * fn is called once per L-BFGS iteration of ecckd_opt_minimize, on the calling thread.  Setting it also starts the
+ * activity timers (HIP events around the kernels: "radiative transfer" = look-up + sweeps + cost + their adjoint,
+ * "a-priori" = the gradient kernel that carries the prior term, "minimizer" = the rest of ecckd_opt_minimize). */
+typedef void (*ecckd_progress_fn)(int iteration, double cost, double gradient_norm, void* user);
+int ecckd_opt_set_progress(ecckd_opt* opt, ecckd_progress_fn fn, void* user);
+int ecckd_opt_timings(ecckd_opt* opt, double* minimizer_s, double* a_priori_s, double* radiative_transfer_s);
+
 /* ---- run_ckd -------------------------------------------------------
  * Replaces the compute part of run_ckd.cpp:27-373 for the profiles of one scene (flux arrays
  * of the scene are ignored; mu0 and tsi are used for a shortwave model, run_ckd.cpp:92,:358

@@ -187,6 +187,15 @@ double orc_ckd_calc_error(orc_ckd_equipartition* eq, double bound1, double bound
 double orc_median_sorting_variable(const double* sorting_variable,
                                    const double* weight, size_t i1, size_t i2);
 
+/* ---- the chain reorder_spectrum -> find_g_points for one longwave gas, in C end to end (oracle_chain.c): what bench.py
+ * times as `cpu_baseline`.  refep_path: oracle/_ref/libequipartition_ref.so (the reference's own Equipartition). */
+int orc_find_g_lw_chain(const char* refep_path, int nlay, size_t nwav, const double* pressure_hl,
+                        const double* temperature_hl, const double* wn, const double* dwn, const float* od32,
+                        const float* bg32, double threshold_optical_depth, int nband, const double* band_bound1,
+                        const double* band_bound2, int method, double flux_weight, double min_pressure,
+                        const double* tolerance, double tolerance_tolerance, int max_iterations, int parallel,
+                        int* ng, double* comp_cost, int* status, double* seconds, int32_t* rank);
+
 #ifdef __cplusplus
 }
 #endif

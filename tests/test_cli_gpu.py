@@ -351,6 +351,10 @@ def test_optimize_lut(ctx, tmp_path):
     r = run_tool("optimize_lut", "opt.cfg", cwd=d)
     assert r.returncode == 0, r.stderr + r.stdout
     assert "Optimizing coefficients of: composite h2o co2 ch4" in r.stdout and "Minimizer status" in r.stdout
+    # the reference's progress line per iteration (solve_adept.cpp:295-299) and its three timed activities (:216-218)
+    its = [l for l in r.stdout.splitlines() if l.startswith("Iteration ") and "cost function = " in l and "gradient norm = " in l]
+    assert len(its) >= 40 and its[0].startswith("Iteration 0:")
+    assert all(k in r.stderr for k in ("3 activities:", "s: minimizer", "s: a-priori", "s: radiative transfer", "s: Total"))
     raw = ncio.read_ckd_model(str(d / "raw.nc"), active_gases=["composite", "h2o", "co2", "ch4"])
     opt_model, res = pipeline.optimize_lut(ctx, raw, paths, max_iterations=40, flux_weight=0.2, flux_profile_weight=0.05,
                                            broadband_weight=0.4, prior_error=4.0, pressure_corr=0.95, temperature_corr=0.95,
