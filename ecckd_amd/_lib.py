@@ -113,6 +113,7 @@ SIGNATURES = {
     "ecckd_opt_initial_state": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
     "ecckd_opt_cost_grad": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
     "ecckd_opt_forward": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
+    "ecckd_opt_set_evaluator": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_opt_set_progress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_opt_timings": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
     "ecckd_opt_forward_ex": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, _c_double_p, _c_double_p]),
@@ -256,6 +257,7 @@ class OptConfig(C.Structure):
 
 
 ERROR_FN = C.CFUNCTYPE(C.c_int, C.c_int, _c_double_p, _c_double_p, _c_double_p, C.c_void_p)
+EVALUATOR_FN = C.CFUNCTYPE(C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)   # ecckd_evaluator_fn
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_double, C.c_double, C.c_void_p)                 # ecckd_progress_fn
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)   # ecckd_allreduce_fn
 

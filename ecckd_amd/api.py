@@ -749,6 +749,29 @@ class Optimizer:
             add_prior = dist.get_rank(group) == 0
         check(self.lib.ecckd_opt_set_allreduce(self.handle, C.cast(fn, C.c_void_p), None, int(bool(add_prior))))
 
+    def set_evaluator(self, fn):
+        """Run minimize() over fn(x) -> (J, gradient) (numpy, on the host) instead of the device's cost function
+        (ecckd_opt_set_evaluator); None restores the device evaluation."""
+        if fn is None:
+            self._evaluator = None
+            check(self.lib.ecckd_opt_set_evaluator(self.handle, None, None))
+            return
+
+        def cb(nx, px, pj, pg, _user):
+            try:
+                x = np.ctypeslib.as_array(px, shape=(nx,)).copy()
+                J, g = fn(x)
+                pj[0] = float(J)
+                np.ctypeslib.as_array(pg, shape=(nx,))[:] = g
+                return 0
+            except Exception as exc:                        # never let an exception cross the C boundary
+                import sys
+                print(f"ecckd evaluator callback failed: {exc!r}", file=sys.stderr)
+                return 1
+
+        self._evaluator = _lib.EVALUATOR_FN(cb)
+        check(self.lib.ecckd_opt_set_evaluator(self.handle, C.cast(self._evaluator, C.c_void_p), None))
+
     def set_progress(self, fn):
         """fn(iteration, cost, gradient_norm) once per L-BFGS iteration (report_progress, solve_adept.cpp:295-299); also
         starts the activity timers read by timings()."""

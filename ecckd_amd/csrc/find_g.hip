@@ -489,40 +489,59 @@ __device__ __forceinline__ Interval interval_of(const IntervalArgs& ka, int use_
   return me;
 }
 
-// this thread's share of sum_{i=i1..i2} row[i]: ragged head + whole tiles (from the tile sums) + ragged tail
+// this thread's share of sum_{i=i1..i2} row[i]: ragged head points, whole 256-point tiles up to the next 65 536-point
+// super tile, whole super tiles, the tiles behind them, ragged tail points - at most one value of each kind per thread
+// (the sums of tiles and super tiles were formed once per gas), so the sums of an interval cost a handful of loads
+// however long it is.  trow / srow: the row's tile and super-tile sums.
+constexpr int SUPER = 256;                     // tiles per super tile
 __device__ __forceinline__ double interval_row_acc(const double* __restrict__ row, const double* __restrict__ trow,
-                                                   long long i1, long long i2, int tid) {
+                                                   const double* __restrict__ srow, long long i1, long long i2, int tid) {
   const long long t1 = (i1 + TILE - 1) / TILE;   // first whole tile
   const long long t2 = (i2 + 1) / TILE;          // one past the last whole tile
   double acc = 0.0;
   if (t1 >= t2) {
     // no whole tile inside: at most 2*TILE-2 raw points
     for (long long i = i1 + tid; i <= i2; i += 256) acc += row[i];
-  } else {
-    const long long head_end = t1 * TILE;  // exclusive
-    if (i1 + tid < head_end) acc += row[i1 + tid];
-    long long t = t1 + tid;
-    for (; t + 768 < t2; t += 1024) {   // four tile sums at a time, added in tile order
-      const double q0 = trow[t], q1 = trow[t + 256], q2 = trow[t + 512], q3 = trow[t + 768];
-      acc += q0; acc += q1; acc += q2; acc += q3;
-    }
-    for (; t < t2; t += 256) acc += trow[t];
-    const long long tail = t2 * TILE + tid;
-    if (tail <= i2) acc += row[tail];
+    return acc;
   }
+  const long long head_end = t1 * TILE;  // exclusive
+  if (i1 + tid < head_end) acc += row[i1 + tid];
+  const long long s1 = (t1 + SUPER - 1) / SUPER;  // first whole super tile
+  const long long s2 = t2 / SUPER;                // one past the last whole super tile
+  if (s1 >= s2) {
+    // no whole super tile inside: at most 2*SUPER-2 tiles
+    for (long long t = t1 + tid; t < t2; t += 256) acc += trow[t];
+  } else {
+    if (t1 + tid < s1 * SUPER) acc += trow[t1 + tid];
+    for (long long q = s1 + tid; q < s2; q += 256) acc += srow[q];
+    if (s2 * SUPER + tid < t2) acc += trow[s2 * SUPER + tid];
+  }
+  const long long tail = t2 * TILE + tid;
+  if (tail <= i2) acc += row[tail];
   return acc;
 }
 
+// super-tile sums of every row: SS[r][q] = sum of the row's tile sums q*SUPER .. q*SUPER+SUPER-1, grid (nsuper, nrows)
 __global__ void __launch_bounds__(256)
-k_interval_sums(int nrows, size_t ntiles, const Interval* __restrict__ iv, IntervalArgs ka, int use_ka, Interval* __restrict__ iv_out,
-                const double* const* __restrict__ rows, const double* __restrict__ ts,
-                double* __restrict__ sums) {
+k_super_sums(size_t ntiles, size_t nsuper, const double* __restrict__ ts, double* __restrict__ ss) {
+  __shared__ double s4[4];
+  const size_t q = blockIdx.x, r = blockIdx.y;
+  const size_t t = q * SUPER + threadIdx.x;
+  const double v = t < ntiles ? ts[r * ntiles + t] : 0.0;
+  const double sum = block_sum_256(v, s4);
+  if (threadIdx.x == 0) ss[r * nsuper + q] = sum;
+}
+
+__global__ void __launch_bounds__(256)
+k_interval_sums(int nrows, size_t ntiles, size_t nsuper, const Interval* __restrict__ iv, IntervalArgs ka, int use_ka,
+                Interval* __restrict__ iv_out, const double* const* __restrict__ rows, const double* __restrict__ ts,
+                const double* __restrict__ ss, double* __restrict__ sums) {
   __shared__ double s4[4];
   const int r = blockIdx.x, k = blockIdx.y;
   const int tid = threadIdx.x;
   const Interval me = interval_of(ka, use_ka, iv, k);
   if (use_ka && r == 0 && tid == 0) iv_out[k] = me;
-  const double acc = interval_row_acc(rows[r], ts + (size_t)r * ntiles, me.i1, me.i2, tid);
+  const double acc = interval_row_acc(rows[r], ts + (size_t)r * ntiles, ss + (size_t)r * nsuper, me.i1, me.i2, tid);
   const double s = block_sum_256(acc, s4);
   if (tid == 0) sums[(size_t)k * nrows + r] = s;
 }
@@ -548,9 +567,10 @@ __device__ __forceinline__ double fit_lw_layer(int method, double a, double b, d
 // logarithmic method, N+l), so the block that owns layer l adds up those rows and finishes the fit itself; the remaining
 // rows (heating rate, boundary fluxes) get one block each as before.  grid (nlay + rows from R.H on, nint), block 256.
 __global__ void __launch_bounds__(256)
-k_interval_sums_fit_lw(int nlay, int method, RowMap R, size_t ntiles, const Interval* __restrict__ iv, IntervalArgs ka, int use_ka,
-                       Interval* __restrict__ iv_out, const double* const* __restrict__ rows, const double* __restrict__ ts,
-                       double* __restrict__ sums, double* __restrict__ od_fit) {
+k_interval_sums_fit_lw(int nlay, int method, RowMap R, size_t ntiles, size_t nsuper, const Interval* __restrict__ iv, IntervalArgs ka,
+                       int use_ka, Interval* __restrict__ iv_out, const double* const* __restrict__ rows,
+                       const double* __restrict__ ts, const double* __restrict__ ss, double* __restrict__ sums,
+                       double* __restrict__ od_fit) {
   __shared__ double s4[4];
   const int bx = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
   const Interval me = interval_of(ka, use_ka, iv, k);
@@ -559,16 +579,16 @@ k_interval_sums_fit_lw(int nlay, int method, RowMap R, size_t ntiles, const Inte
   double* out = sums + (size_t)k * R.total;
   if (bx >= nlay) {
     const int r = R.H + (bx - nlay);
-    const double s = block_sum_256(interval_row_acc(rows[r], ts + (size_t)r * ntiles, i1, i2, tid), s4);
+    const double s = block_sum_256(interval_row_acc(rows[r], ts + (size_t)r * ntiles, ss + (size_t)r * nsuper, i1, i2, tid), s4);
     if (tid == 0) out[r] = s;
     return;
   }
   const int l = bx;
   const bool is_log = method == ECCKD_AVG_LOGARITHMIC;
-  const double a = block_sum_256(interval_row_acc(rows[R.A + l], ts + (size_t)(R.A + l) * ntiles, i1, i2, tid), s4);
-  const double b = block_sum_256(interval_row_acc(rows[R.B + l], ts + (size_t)(R.B + l) * ntiles, i1, i2, tid), s4);
+  const double a = block_sum_256(interval_row_acc(rows[R.A + l], ts + (size_t)(R.A + l) * ntiles, ss + (size_t)(R.A + l) * nsuper, i1, i2, tid), s4);
+  const double b = block_sum_256(interval_row_acc(rows[R.B + l], ts + (size_t)(R.B + l) * ntiles, ss + (size_t)(R.B + l) * nsuper, i1, i2, tid), s4);
   double nnz = 0.0;
-  if (is_log) nnz = block_sum_256(interval_row_acc(rows[R.N + l], ts + (size_t)(R.N + l) * ntiles, i1, i2, tid), s4);
+  if (is_log) nnz = block_sum_256(interval_row_acc(rows[R.N + l], ts + (size_t)(R.N + l) * ntiles, ss + (size_t)(R.N + l) * nsuper, i1, i2, tid), s4);
   if (tid == 0) {
     out[R.A + l] = a;
     out[R.B + l] = b;
@@ -973,6 +993,13 @@ k_cost_lw(int nlay, RowMap R, const Interval* __restrict__ iv, long long nchunks
     double a = 0.0;
     // four chunks at a time: independent loads in flight together, added in chunk order
     long long c = c0 + g;
+    for (; c + 56 < c1; c += 64) {      // eight chunks at a time: independent loads in flight together, added in chunk order
+      double q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = partial[(size_t)(c + 8 * u) * nv + v];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += q[u];
+    }
     for (; c + 24 < c1; c += 32) {
       const double p0 = partial[(size_t)c * nv + v], p1 = partial[(size_t)(c + 8) * nv + v];
       const double p2 = partial[(size_t)(c + 16) * nv + v], p3 = partial[(size_t)(c + 24) * nv + v];
@@ -1426,6 +1453,13 @@ k_cost_sw(int nlay, int ntotal, SwTruthRows rows, const Interval* __restrict__ i
     double a = 0.0;
     // four chunks at a time: independent loads in flight together, added in chunk order
     long long c = c0 + g;
+    for (; c + 56 < c1; c += 64) {      // eight chunks at a time: independent loads in flight together, added in chunk order
+      double q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = partial[(size_t)(c + 8 * u) * nv + v];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += q[u];
+    }
     for (; c + 24 < c1; c += 32) {
       const double p0 = partial[(size_t)c * nv + v], p1 = partial[(size_t)(c + 8) * nv + v];
       const double p2 = partial[(size_t)(c + 16) * nv + v], p3 = partial[(size_t)(c + 24) * nv + v];
@@ -1538,7 +1572,7 @@ void gas_free(ecckd_gas* g) {
   if (g->owns_planck) fr(g->planck_hl);
   fr(g->ssi); fr(g->tf); fr(g->tg); fr(g->hr_low); fr(g->hr_high); fr(g->fx);
   fr(g->bg_od); fr(g->w1); fr(g->w2); fr(g->cnt); fr(g->hr); fr(g->fds); fr(g->fut);
-  fr(g->wn_sorted); fr(g->dwn_sorted); fr(g->ireorder); fr((void*)g->rows); fr(g->tile_sums);
+  fr(g->wn_sorted); fr(g->dwn_sorted); fr(g->ireorder); fr((void*)g->rows); fr(g->tile_sums); fr(g->super_sums);
   fr(g->lev); fr(g->work);
   delete g;
 }
@@ -1773,6 +1807,11 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
                        (const double* const*)g->rows, g->tile_sums);
   }
   GTRY(hipGetLastError());
+  g->nsuper = (g->ntiles + SUPER - 1) / SUPER;
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->super_sums, (size_t)g->nrows * g->nsuper * sizeof(double)));
+  hipLaunchKernelGGL(k_super_sums, dim3((unsigned)g->nsuper, (unsigned)g->nrows), dim3(256), 0, ctx->stream, g->ntiles, g->nsuper,
+                     (const double*)g->tile_sums, g->super_sums);
+  GTRY(hipGetLastError());
   int flag = 0;
   GTRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GTRY(hipStreamSynchronize(ctx->stream));
@@ -1992,6 +2031,11 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)g->ntiles), dim3(TILE), 0, ctx->stream, g->nrows, nwav, g->ntiles,
                      (const double* const*)g->rows, g->tile_sums);
   GTRY(hipGetLastError());
+  g->nsuper = (g->ntiles + SUPER - 1) / SUPER;
+  GTRY(ecckd::dev_malloc(ctx, (void**)&g->super_sums, (size_t)g->nrows * g->nsuper * sizeof(double)));
+  hipLaunchKernelGGL(k_super_sums, dim3((unsigned)g->nsuper, (unsigned)g->nrows), dim3(256), 0, ctx->stream, g->ntiles, g->nsuper,
+                     (const double*)g->tile_sums, g->super_sums);
+  GTRY(hipGetLastError());
   GTRY(hipStreamSynchronize(ctx->stream));
 #undef GTRY
   *out = g;
@@ -2083,8 +2127,8 @@ int ecckd_fit_optical_depth(ecckd_gas* g, size_t ibegin, size_t npoints, int n, 
   double* d_fit = (double*)w;
   std::memcpy(g->pinned, iv.data(), (size_t)n * sizeof(Interval));
   ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, g->pinned, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv, IntervalArgs(), 0,
-                     d_iv, (const double* const*)g->rows, g->tile_sums, d_sums);
+  hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, g->nsuper, d_iv, IntervalArgs(), 0,
+                     d_iv, (const double* const*)g->rows, g->tile_sums, g->super_sums, d_sums);
   if (g->do_sw) {
     // unscaled fit: scaling factors of 1
     hipLaunchKernelGGL(k_fit_sw, dim3(n), dim3(128), nlay * sizeof(double), ctx->stream, nlay, g->method, g->rm, n,
@@ -2174,10 +2218,11 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
 
   if (!g->do_sw)
     hipLaunchKernelGGL(k_interval_sums_fit_lw, dim3(nlay + (g->rm.total - g->rm.H), n), dim3(256), 0, ctx->stream, nlay, g->method,
-                       g->rm, g->ntiles, d_iv, ka, use_ka, d_iv, (const double* const*)g->rows, g->tile_sums, d_sums, d_fit);
+                       g->rm, g->ntiles, g->nsuper, d_iv, ka, use_ka, d_iv, (const double* const*)g->rows, g->tile_sums, g->super_sums,
+                       d_sums, d_fit);
   else
-    hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, d_iv, ka, use_ka, d_iv,
-                       (const double* const*)g->rows, g->tile_sums, d_sums);
+    hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, g->nsuper, d_iv, ka, use_ka,
+                       d_iv, (const double* const*)g->rows, g->tile_sums, g->super_sums, d_sums);
   if (g->do_sw) {
     // CkdEquipartition::calc_error, shortwave branches (find_g_points.cpp:341-402)
     const bool is_tt = g->method == ECCKD_AVG_TOTAL_TRANSMISSION;

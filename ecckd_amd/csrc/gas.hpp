@@ -82,8 +82,10 @@ struct ecckd_gas {
   RowMap rm;
   int nrows = 0;
   const double** rows = nullptr;  // device array of nrows row pointers
-  double* tile_sums = nullptr;    // [nrows][ntiles]
+  double* tile_sums = nullptr;    // [nrows][ntiles]   sums over 256 points
   size_t ntiles = 0;
+  double* super_sums = nullptr;   // [nrows][nsuper]   sums over 256 tiles
+  size_t nsuper = 0;
   // per-level constants on device: conv[nlay] | layer_weight[nlay]
   double* lev = nullptr;
   std::vector<double> h_pressure_hl;

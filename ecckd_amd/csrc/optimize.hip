@@ -767,6 +767,9 @@ struct ecckd_opt {
   // timing
   long long n_eval = 0;
   // progress line and activity timers of solve_adept.cpp (:216-218 "minimizer", "a-priori", "radiative transfer"; :295-299)
+  ecckd_evaluator_fn eval_fn = nullptr;    // cost / gradient supplied by the caller instead of the device kernels
+  void* eval_user = nullptr;
+  std::vector<double> eval_x, eval_g;
   ecckd_progress_fn progress_fn = nullptr;
   void* progress_user = nullptr;
   hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
@@ -1216,6 +1219,13 @@ size_t ecckd_opt_nx(ecckd_opt* o) { return o ? o->nx : 0; }
 // Initial state and log-space bounds, solve_adept.cpp:335-353.  h_x_min/h_x_max may be NULL;
 // unbounded elements get -/+ infinity.  Returns the gas order of the state in h_gas_order
 // (user gas indices of the active gases, in state order) if not NULL.
+int ecckd_opt_set_evaluator(ecckd_opt* o, ecckd_evaluator_fn fn, void* user) {
+  ECCKD_REQUIRE(o, "ecckd_opt_set_evaluator: NULL handle");
+  o->eval_fn = fn;
+  o->eval_user = user;
+  return ECCKD_OK;
+}
+
 int ecckd_opt_set_progress(ecckd_opt* o, ecckd_progress_fn fn, void* user) {
   ECCKD_REQUIRE(o, "ecckd_opt_set_progress: NULL handle");
   o->progress_fn = fn;
@@ -1286,6 +1296,19 @@ static int opt_launch_forward(ecckd_opt* o) {
 
 static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, double* J) {
   ecckd_ctx* ctx = o->ctx;
+  if (o->eval_fn && o->d_od_out == nullptr) {
+    // the caller's cost function and gradient in place of the device's: the minimizer itself is unchanged
+    o->eval_x.resize(o->nx);
+    o->eval_g.assign(o->nx, 0.0);
+    ECCKD_HIP_CHECK(hipMemcpyAsync(o->eval_x.data(), d_x, o->nx * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int rc = o->eval_fn(o->nx, o->eval_x.data(), J, o->eval_g.data(), o->eval_user);
+    if (rc != 0) return ecckd::fail(ECCKD_PROCESSING_ERROR, "ecckd_opt: the cost-function callback failed (%d)", rc);
+    ECCKD_HIP_CHECK(hipMemcpyAsync(d_grad, o->eval_g.data(), o->nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    o->n_eval++;
+    return ECCKD_OK;
+  }
   const bool reduce = o->reduce_fn != nullptr && o->d_od_out == nullptr;   // not for the diagnostic forward pass
   const bool prior = o->have_prior && (!reduce || o->add_prior);
   hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, d_x, o->d_k);

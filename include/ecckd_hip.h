@@ -544,6 +544,14 @@ int ecckd_opt_minimize(ecckd_opt* opt, int max_iterations, double convergence_cr
 typedef int (*ecckd_allreduce_fn)(void* d_buf, size_t count, void* stream, void* user);
 int ecckd_opt_set_allreduce(ecckd_opt* opt, ecckd_allreduce_fn fn, void* user, int add_prior);
 
+/* ecckd_opt_minimize over a cost function and gradient supplied by the caller (host arrays) instead of the library's
+ * kernels: the L-BFGS iteration, its bounds and its line search stay exactly the library's.  With the reference's own
+ * CkdOptimizable::calc_cost_function_gradient (solve_adept.cpp:240-292) behind fn this runs the library's minimizer over
+ * the reference's cost function; the parity tests put the CPU oracle there and compare the two trajectories.
+ * fn returns 0, or non-zero to abort (PROCESSING_ERROR).  fn == NULL restores the device evaluation. */
+typedef int (*ecckd_evaluator_fn)(size_t nx, const double* h_x, double* J, double* h_grad, void* user);
+int ecckd_opt_set_evaluator(ecckd_opt* opt, ecckd_evaluator_fn fn, void* user);
+
 /* The minimizer's progress line and the three timed activities of the reference (solve_adept.cpp:216-218 "minimizer",
  * "a-priori", "radiative transfer"; report_progress :295-299 "Iteration n: cost function = ..., gradient norm = ...").
  * fn is called once per L-BFGS iteration of ecckd_opt_minimize, on the calling thread.  Setting it also starts the

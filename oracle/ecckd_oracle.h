@@ -187,6 +187,22 @@ double orc_ckd_calc_error(orc_ckd_equipartition* eq, double bound1, double bound
 double orc_median_sorting_variable(const double* sorting_variable,
                                    const double* weight, size_t i1, size_t i2);
 
+/* ---- reverse mode by hand of the longwave optimize_lut forward model (oracle_adjoint.c): the gradient the reference gets
+ * from Adept's tape (solve_adept.cpp:91, :201-203).  d_od / d_molar_abs are ACCUMULATED into. */
+double orc_calc_cost_function_ckd_lw_ad(int nlay, int ng, int nband, const double* pressure_hl, const double* planck_hl,
+                                        const double* surf_emiss_orig, const double* surf_planck,
+                                        const double* optical_depth, const double* flux_dn, const double* flux_up,
+                                        const double* hr, const double* spectral_flux_dn_surf,
+                                        const double* spectral_flux_up_toa, double flux_weight,
+                                        double flux_profile_weight, double broadband_weight,
+                                        double spectral_boundary_weight, const double* layer_weight,
+                                        const double* relative_ckd_flux_dn, const double* relative_ckd_flux_up,
+                                        const int* band_mapping, double* d_od);
+int orc_ckd_optical_depth_ad(int ng, int nt, int np, const double* log_pressure, const double* temperature,
+                             int conc_dependence, int nconc, const double* vmr_lut, double reference_vmr, int ncol, int nlay,
+                             const double* pressure_hl, const double* temperature_fl, const double* vmr_fl,
+                             const double* d_od, double* d_molar_abs);
+
 /* ---- the chain reorder_spectrum -> find_g_points for one longwave gas, in C end to end (oracle_chain.c): what bench.py
  * times as `cpu_baseline`.  refep_path: oracle/_ref/libequipartition_ref.so (the reference's own Equipartition). */
 int orc_find_g_lw_chain(const char* refep_path, int nlay, size_t nwav, const double* pressure_hl,

@@ -132,6 +132,73 @@ class Oracle:
                     ib.ctypes.data_as(C.POINTER(C.c_int)))
         return J
 
+    def cost_grad_rt(self, x):
+        """cost_rt and its gradient with respect to x = ln k by the oracle's hand-written reverse mode (oracle_adjoint.c):
+        per profile dJ/d(optical depth), the penalty of negative optical depths and the clamp (solve_adept.cpp:107-116),
+        the transpose of the look-up-table interpolation, then dJ/dx = dJ/dk * k (solve_adept.cpp:276-283)."""
+        cfg, P, L, m = self.cfg, self.o._p, self.L, self.m
+        L.orc_calc_cost_function_ckd_lw_ad.restype = C.c_double
+        nband = m["nband"]
+        ib = np.ascontiguousarray(m["iband_per_g"], dtype=np.int32)
+        nt, np_ = m["temperature"].shape
+        ks = self.coeffs(x)
+        dk = [np.zeros_like(np.ascontiguousarray(k, dtype=np.float64)) for k in ks]
+        J = 0.0
+        for scene in self.scenes:
+            od = self.optical_depth(x, scene)
+            neg = od < 0.0
+            p, T, vmr = (np.ascontiguousarray(scene[k]) for k in ("pressure_hl", "temperature_hl", "vmr_fl"))
+            ncol, nhl = p.shape
+            nlay, ng = nhl - 1, od.shape[2]
+            d_od = np.zeros_like(od)
+            if neg.any():
+                J += cfg["negative_od_penalty"] * np.sum(od[neg] ** 2)
+            odc = np.where(neg, 0.0, od)
+            for c in range(ncol):
+                pw = cfg["pressure_weight_power"]
+                lw = (np.sqrt(p[c, 1:]) - np.sqrt(p[c, :-1])) if pw == 0.5 else (p[c, 1:] ** pw - p[c, :-1] ** pw)
+                lw = np.ascontiguousarray(lw / lw.sum())
+                pl = self.planck(T[c])
+                fd, fu = np.ascontiguousarray(scene["flux_dn"][c]), np.ascontiguousarray(scene["flux_up"][c])
+                hr = np.ascontiguousarray(self.o.heating_rate(p[c], fd, fu))
+                sfd, sfu = scene.get("spectral_flux_dn_surf"), scene.get("spectral_flux_up_toa")
+                rd, ru = scene.get("relative_flux_dn"), scene.get("relative_flux_up")
+                dc = np.zeros((nlay, ng))
+                J += L.orc_calc_cost_function_ckd_lw_ad(
+                    C.c_int(nlay), C.c_int(ng), C.c_int(nband), P(np.ascontiguousarray(p[c])), P(pl), P(np.ones(nband)),
+                    P(np.ascontiguousarray(pl[-1])), P(np.ascontiguousarray(odc[c])), P(fd), P(fu), P(hr),
+                    P(np.ascontiguousarray(sfd[c])) if sfd is not None else None,
+                    P(np.ascontiguousarray(sfu[c])) if sfu is not None else None, C.c_double(cfg["flux_weight"]),
+                    C.c_double(cfg["flux_profile_weight"]), C.c_double(cfg["broadband_weight"]),
+                    C.c_double(cfg["spectral_boundary_weight"]), P(lw),
+                    P(np.ascontiguousarray(rd[c])) if rd is not None else None,
+                    P(np.ascontiguousarray(ru[c])) if ru is not None else None, ib.ctypes.data_as(C.POINTER(C.c_int)), P(dc))
+                d_od[c] = dc
+            # the clamped cells pass nothing on but the penalty's derivative (:110-113)
+            d_od = np.where(neg, 2.0 * cfg["negative_od_penalty"] * od, d_od)
+            d_od = np.ascontiguousarray(d_od)
+            t_fl = np.ascontiguousarray((T[:, :-1] * p[:, :-1] + T[:, 1:] * p[:, 1:]) / (p[:, :-1] + p[:, 1:]))
+            for i, g in enumerate(m["gases"]):
+                present = scene.get("gas_present") is None or scene["gas_present"][i]
+                if not present and g["conc"] != "none":
+                    continue
+                v = np.ascontiguousarray(vmr[:, i, :]) if (present and g["conc"] != "none") else None
+                vl = np.ascontiguousarray(g["vmr"]) if g.get("vmr") is not None else None
+                rc = L.orc_ckd_optical_depth_ad(C.c_int(ng), C.c_int(nt), C.c_int(np_), P(np.ascontiguousarray(m["log_pressure"])),
+                                                P(np.ascontiguousarray(m["temperature"])), C.c_int(CONC[g["conc"]]),
+                                                C.c_int(dk[i].shape[0] if g["conc"] == "lut" else 1), P(vl),
+                                                C.c_double(g.get("reference_vmr", 0.0)), C.c_int(ncol), C.c_int(nlay), P(p), P(t_fl),
+                                                P(v), P(d_od), P(dk[i]))
+                assert rc == 0
+        grad = np.zeros_like(x)
+        off = 0
+        for i, n in zip(self.active, self.sizes):
+            xx = x[off:off + n]
+            kk = np.asarray(ks[i]).ravel()
+            grad[off:off + n] = np.where(xx > -1.0e20, dk[i].ravel() * kk, 0.0)
+            off += n
+        return J, grad
+
     def prior_matrices(self):
         """Dense inverse covariance per active gas exactly as create_error_covariances builds it
         (ckd_model.cpp:693-713, :760-780): pow(corr, |index difference|), LAPACK inverse, < 1e-6 zeroed."""

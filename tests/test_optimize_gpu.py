@@ -131,6 +131,70 @@ def test_cost_and_gradient(ctx, oracle, variant):
     opt.close()
 
 
+@pytest.mark.parametrize("variant", ["base", "boundary", "negative_od"])
+def test_gradient_matches_the_oracles_reverse_mode(ctx, oracle, variant):
+    """Device adjoint against the oracle's hand-written reverse mode (oracle/oracle_adjoint.c, itself pinned to central
+    differences in tests/test_oracle_adjoint.py): two independent derivations of dJ/dx, compared element by element."""
+    kw = dict(boundary=True, spectral_boundary_weight=0.3) if variant == "boundary" else dict(ch4_low=True) if variant == "negative_od" else {}
+    model, scenes, cfg, orc = _problem(oracle, seed=5, **kw)
+    opt = _opt(ctx, model, scenes, dict(cfg, prior_error=1.0e30))       # the radiative-transfer part of the cost alone
+    rs = np.random.RandomState(4)
+    x0 = opt.initial_state()
+    free = x0 > -1.0e20
+    x = x0 + np.where(free, 0.2 * rs.normal(size=x0.size), 0.0)
+    if variant == "negative_od":
+        sizes = np.cumsum([0] + orc.sizes)
+        x[sizes[3]:sizes[4]] += 9.0
+    J, g = opt.cost_grad(x)
+    J_ref, g_ref = orc.cost_grad_rt(x)
+    assert J == pytest.approx(J_ref, rel=1e-10)
+    assert np.allclose(g, g_ref, rtol=1e-8, atol=1e-11 * np.abs(g_ref).max())
+    opt.close()
+
+
+def test_same_minimizer_over_device_and_oracle_cost_functions(ctx, oracle):
+    """The library's L-BFGS run twice from the same state: over the device's cost function / gradient, and over the CPU
+    oracle's (ecckd_opt_set_evaluator: forward cost of oracle_ckd.c, reverse mode of oracle_adjoint.c, dense-inverse prior).
+    Same minimizer, two independent implementations of J and dJ/dx: the trajectories stay together, and the optimised
+    models give the same heating rates (RMS difference, weighted as plot/calc_hr_error.m:1-23, far below 1e-6 K/day)."""
+    model, scenes, cfg, orc = _problem(oracle, seed=7)
+    opt = _opt(ctx, model, scenes, cfg)
+    niter = 15
+    hist_dev, hist_cpu = [], []
+    opt.set_progress(lambda it, cost, gnorm: hist_dev.append((it, cost, gnorm)))
+    res_dev = opt.minimize(max_iterations=niter, convergence_criterion=0.0, bounded=True)
+
+    def cpu_cost_grad(x):
+        J, g = orc.cost_grad_rt(x)
+        Jb, gb = orc.cost_prior(x, cfg["prior_error"])
+        g = g + gb
+        g[np.abs(g) < 1.0e-80] = 0.0                                     # solve_adept.cpp:286
+        return J + Jb, np.where(x > -1.0e20, g, 0.0)
+
+    opt.set_evaluator(cpu_cost_grad)
+    opt.set_progress(lambda it, cost, gnorm: hist_cpu.append((it, cost, gnorm)))
+    res_cpu = opt.minimize(max_iterations=niter, convergence_criterion=0.0, bounded=True)
+    opt.set_evaluator(None)
+    assert res_dev["iterations"] == res_cpu["iterations"] == niter and res_dev["status"] == res_cpu["status"]
+    assert len(hist_dev) == len(hist_cpu) and hist_dev[-1][1] < 0.7 * hist_dev[0][1]
+    for (i1, c1, g1), (i2, c2, g2) in zip(hist_dev, hist_cpu):
+        assert i1 == i2 and c1 == pytest.approx(c2, rel=1e-7) and g1 == pytest.approx(g2, rel=1e-5)
+    moved = np.abs(res_dev["x"] - opt.initial_state()) > 0
+    assert np.allclose(res_dev["x"][moved], res_cpu["x"][moved], rtol=0, atol=1e-6)
+    # heating rates of the two optimised models on the training profiles
+    _, fl_dev = opt.forward(res_dev["x"])
+    _, fl_cpu = opt.forward(res_cpu["x"])
+    p = np.concatenate([s["pressure_hl"] for s in scenes])
+    conv = -(9.80665 / 1004.0) / np.diff(p, axis=1) * 86400.0
+    net = lambda fl: (fl[:, 0] - fl[:, 1]).sum(-1)                        # broadband net flux (ncol, nhl), down - up
+    hr_dev, hr_cpu = conv * np.diff(net(fl_dev), axis=1), conv * np.diff(net(fl_cpu), axis=1)
+    w = np.diff(p ** (1.0 / 3.0), axis=1)                                # calc_hr_error.m:12-22: d(p^(1/3)), normalised per profile
+    w = w / w.sum(axis=1, keepdims=True)
+    rmse = np.sqrt(np.sum(w * (hr_dev - hr_cpu) ** 2) / p.shape[0])
+    assert rmse < 1.0e-6, rmse
+    opt.close()
+
+
 def test_prior_matches_dense_inverse(ctx, oracle):
     """K9 Kronecker-tridiagonal stencil == the reference's dense inv(B) product, incl. the 1e-6 zeroing."""
     for corr in (dict(pressure_corr=0.95, temperature_corr=0.95, conc_corr=0.95),
