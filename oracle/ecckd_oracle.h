@@ -212,6 +212,15 @@ int orc_find_g_lw_chain(const char* refep_path, int nlay, size_t nwav, const dou
                         const double* tolerance, double tolerance_tolerance, int max_iterations, int parallel,
                         int* ng, double* comp_cost, int* status, double* seconds, int32_t* rank);
 
+int orc_find_g_lw_chain_ex(const char* refep_path, int nlay, size_t nwav, const double* pressure_hl,
+                           const double* temperature_hl, const double* wn, const double* dwn, const float* od32,
+                           const float* bg32, double threshold_optical_depth, int nband, const double* band_bound1,
+                           const double* band_bound2, int method, double flux_weight, double min_pressure,
+                           const double* tolerance, double tolerance_tolerance, int max_iterations, int parallel,
+                           int* ng, double* comp_cost, int* status, double* seconds, int32_t* rank, int capacity,
+                           int64_t* rank1, int64_t* rank2, double* error_out, double* median_out, double* key_out,
+                           double* planck_io, int planck_mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,15 @@ static double now_s(void) {
   return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 
+int orc_find_g_lw_chain_ex(const char* refep_path, int nlay, size_t nwav, const double* pressure_hl,
+                           const double* temperature_hl, const double* wn, const double* dwn, const float* od32,
+                           const float* bg32, double threshold_optical_depth, int nband, const double* band_bound1,
+                           const double* band_bound2, int method, double flux_weight, double min_pressure,
+                           const double* tolerance, double tolerance_tolerance, int max_iterations, int parallel,
+                           int* ng, double* comp_cost, int* status, double* seconds, int32_t* rank, int capacity,
+                           int64_t* rank1, int64_t* rank2, double* error_out, double* median_out, double* key_out,
+                           double* planck_io, int planck_mode);
+
 /* One gas, longwave.  Inputs in ORIGINAL wavenumber order, FLOAT optical depths as in the CKDMIP files (widened to double
  * as DataFile::read does, DataFileEngineNetcdf.cpp:593-599).  Outputs: ng[nband], comp_cost[nband], status[nband],
  * seconds[3] = {reorder, preparation, search}, rank[nwav].  Returns 0, or a non-zero code. */
@@ -78,6 +87,25 @@ int orc_find_g_lw_chain(const char* refep_path, int nlay, size_t nwav, const dou
                         const double* band_bound2, int method, double flux_weight, double min_pressure,
                         const double* tolerance, double tolerance_tolerance, int max_iterations, int parallel,
                         int* ng, double* comp_cost, int* status, double* seconds, int32_t* rank) {
+  return orc_find_g_lw_chain_ex(refep_path, nlay, nwav, pressure_hl, temperature_hl, wn, dwn, od32, bg32, threshold_optical_depth,
+                                nband, band_bound1, band_bound2, method, flux_weight, min_pressure, tolerance, tolerance_tolerance,
+                                max_iterations, parallel, ng, comp_cost, status, seconds, rank, 0, NULL, NULL, NULL, NULL, NULL, NULL, 0);
+}
+
+/* The same with the per-g-point results the rest of find_g_points needs (:1396-1409): rank1 / rank2 (first and last sorted
+ * index), error and Planck-weighted median sorting variable of every g point, bands one after the other (capacity entries);
+ * key_out[nwav] = the sorting variable (what write_order stores).  planck_mode: 0 = the Planck matrix of this gas's own
+ * ordering; 1 = the same, and copied to planck_io[(nlay+1)*nwav] (the FIRST gas of a find_g_points run); 2 = planck_io is
+ * used INSTEAD - the reference evaluates the matrix for the first gas only and keeps it for the later ones
+ * (find_g_points.cpp:529, :970-984). */
+int orc_find_g_lw_chain_ex(const char* refep_path, int nlay, size_t nwav, const double* pressure_hl,
+                           const double* temperature_hl, const double* wn, const double* dwn, const float* od32,
+                           const float* bg32, double threshold_optical_depth, int nband, const double* band_bound1,
+                           const double* band_bound2, int method, double flux_weight, double min_pressure,
+                           const double* tolerance, double tolerance_tolerance, int max_iterations, int parallel,
+                           int* ng, double* comp_cost, int* status, double* seconds, int32_t* rank, int capacity,
+                           int64_t* rank1, int64_t* rank2, double* error_out, double* median_out, double* key_out,
+                           double* planck_io, int planck_mode) {
   refep_api ep;
   if (load_refep(refep_path, &ep)) return 10;
   const size_t nhl = (size_t)nlay + 1;
@@ -124,7 +152,9 @@ int orc_find_g_lw_chain(const char* refep_path, int nlay, size_t nwav, const dou
       bg_s[(size_t)l * nwav + i] = bg[(size_t)l * nwav + j];
       tot_s[(size_t)l * nwav + i] = bg[(size_t)l * nwav + j] + od[(size_t)l * nwav + j];
     }
-  orc_planck_function((int)nhl, temperature_hl, nwav, wn_s, dwn_s, planck);                       /* :970-979 */
+  if (planck_mode == 2 && planck_io) memcpy(planck, planck_io, nhl * nwav * sizeof(double));
+  else orc_planck_function((int)nhl, temperature_hl, nwav, wn_s, dwn_s, planck);                  /* :970-979 */
+  if (planck_mode == 1 && planck_io) memcpy(planck_io, planck, nhl * nwav * sizeof(double));
   orc_radiative_transfer_lw(nlay, nwav, planck, tot_s, ones, planck + (size_t)nlay * nwav, fdn, fup);   /* :993-995 */
   orc_heating_rate(nlay, nwav, pressure_hl, fdn, fup, hr);                                       /* :1041 */
   memcpy(fds, fdn + (size_t)nlay * nwav, nwav * sizeof(double));                                 /* :1044-1053 */
@@ -135,6 +165,13 @@ int orc_find_g_lw_chain(const char* refep_path, int nlay, size_t nwav, const dou
   seconds[1] = t2 - t1;
 
   /* ---- the bands (:1152-1266) ---- */
+  int nout = 0;
+  double* key_s = NULL;
+  if (key_out) {
+    memcpy(key_out, key, nwav * sizeof(double));
+    key_s = (double*)malloc(nwav * sizeof(double));
+    for (size_t i = 0; i < nwav; ++i) key_s[i] = key[ordered[i]];
+  }
   for (int b = 0; b < nband; ++b) {
     long first = -1, last = -1;
     for (size_t i = 0; i < nwav; ++i)
@@ -163,10 +200,21 @@ int orc_find_g_lw_chain(const char* refep_path, int nlay, size_t nwav, const dou
     ng[b] = n;
     comp_cost[b] = c.comp_cost;
     if (c.failed) rc = 20 + c.failed;
+    if (rank1 && status[b] >= 0) {
+      const double np1 = (double)(c.eq.npoints - 1);
+      for (int k = 0; k < n && nout < capacity; ++k, ++nout) {
+        rank1[nout] = (int64_t)ceil(bounds[k] * np1) + first;                 /* :1397-1398 */
+        rank2[nout] = (int64_t)floor(bounds[k + 1] * np1) + first;
+        error_out[nout] = err[k];
+        if (median_out && key_s)
+          median_out[nout] = orc_median_sorting_variable(key_s, planck + (size_t)nlay * nwav, (size_t)rank1[nout], (size_t)rank2[nout]);
+      }
+    }
     free(bounds); free(err);
     ep.destroy(h);
   }
   seconds[2] = now_s() - t2;
+  free(key_s);
 
 done:
   free(od); free(bg); free(key); free(col); free(iband); free(ordered); free(t_ideal); free(od_s); free(bg_s); free(tot_s);
