@@ -78,6 +78,10 @@ SIGNATURES = {
                                          _c_double_p, C.c_void_p, C.c_int, _c_double_p, C.c_double,
                                          C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
                                          _c_int16_p, _c_int32_p]),
+    "ecckd_reorder_spectrum_od_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, _c_double_p,
+                                                _c_double_p, C.c_void_p, C.c_int, _c_double_p, C.c_double,
+                                                C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
+                                                _c_int16_p, _c_int32_p]),
     "ecckd_gas_create_lw": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, _c_double_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_double,
@@ -165,6 +169,7 @@ SIGNATURES = {
     "ecckd_nc_inq_var": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_size_t), C.c_int]),
     "ecckd_nc_read_double": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong, _c_double_p, C.c_size_t]),
+    "ecckd_nc_read_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_longlong, C.c_int, C.c_void_p, C.c_size_t]),
     "ecckd_nc_read_att_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "ecckd_nc_read_att_double": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), _c_double_p, C.c_size_t]),
     "ecckd_nc_create": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),

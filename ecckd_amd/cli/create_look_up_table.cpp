@@ -212,13 +212,11 @@ int main(int argc, char** argv) {
           } else {
             const std::string path = paths.find(files[iconc]);
             LOG("  Reading temperature profile %d from %s\n", iprofile, path.c_str());
-            first = read_spectrum(path, iprofile);
+            first = read_spectrum(path, iprofile, false);
             ref_vmr = first.reference_surface_vmr;
             if (gas.conc == CONC_LUT && ref_vmr < 0.0)
               fail(ECCKD_PARAMETER_ERROR, "Invalid reference_surface_vmr for constructing VMR-dependent look-up table");
-            od = upload_od(dev, first.optical_depth, first.od_is_float);
-            first.optical_depth.clear();
-            first.optical_depth.shrink_to_fit();
+            od = read_od_dev(dev, NcIn(path), iprofile, first.nlay, first.nwav);
             d_od = od.buf.ptr();
             od_type = od.type;
           }

@@ -26,7 +26,9 @@ int main(int argc, char** argv) {
 
     SearchPath paths;
     LOG("Reading %s\n", input.c_str());
-    Spectrum s = read_spectrum(paths.find(input), iprofile);
+    Device dev;
+    Spectrum s = read_spectrum(paths.find(input), iprofile, false);
+    DevOd d_od = read_od_dev(dev, NcIn(paths.find(input)), iprofile, s.nlay, s.nwav);   // file -> pinned buffers -> HBM, decoded there
     std::string molecule = s.molecule;
     config.read(molecule, "molecule");
     LOG("%d layers\n%zu spectral points\n", s.nlay, s.nwav);
@@ -54,19 +56,13 @@ int main(int argc, char** argv) {
     else LOG("Splitting the spectrum into %d bands\n", nband);
     LOG(do_sw ? "Sorting by peak heating\n" : "Sorting by peak cooling\n");
 
-    Device dev;
     std::vector<double> key(s.nwav), col(s.nwav);
     std::vector<int16_t> iband(s.nwav);
     std::vector<int32_t> rank(s.nwav);
-    std::vector<float> od32;
-    const void* od = s.optical_depth.data();
-    if (s.od_is_float) {   // FLOAT in the file: ship half the bytes, same values
-      od32.assign(s.optical_depth.begin(), s.optical_depth.end());
-      od = od32.data();
-    }
-    ck(ecckd_reorder_spectrum(dev.ctx(), s.nlay, s.nwav, s.pressure_hl.data(), s.wavenumber_cm_1.data(), s.d_wavenumber_cm_1.data(), od,
-                              s.od_is_float ? ECCKD_F32 : ECCKD_F64, do_sw ? ssi.data() : nullptr, threshold_optical_depth, nband,
-                              band_bound1.data(), band_bound2.data(), key.data(), col.data(), iband.data(), rank.data()));
+    ck(ecckd_reorder_spectrum_od_dev(dev.ctx(), s.nlay, s.nwav, s.pressure_hl.data(), s.wavenumber_cm_1.data(),
+                                     s.d_wavenumber_cm_1.data(), d_od.buf.ptr(), d_od.type, do_sw ? ssi.data() : nullptr,
+                                     threshold_optical_depth, nband, band_bound1.data(), band_bound2.data(), key.data(), col.data(),
+                                     iband.data(), rank.data()));
     // the file stores the bounds clamped to the range of the data (:268-273), membership used the unclamped ones
     std::vector<double> clamp1 = band_bound1, clamp2 = band_bound2;
     clamp1.front() = std::max(s.wavenumber_cm_1.front(), band_bound1.front());

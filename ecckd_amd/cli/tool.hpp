@@ -228,6 +228,7 @@ class NcIn {
     return true;
   }
   const std::string& path() const { return path_; }
+  ecckd_nc* handle() const { return f_; }
 
  private:
   std::string path_;
@@ -410,6 +411,23 @@ inline DevOd upload_od(const Device& d, const std::vector<double>& od, bool as_f
   return out;
 }
 
+// optical_depth of one profile straight from the file into device memory (ecckd_nc_read_dev: the bytes are streamed through
+// pinned buffers and decoded on the device; FLOAT stays FLOAT), instead of file -> doubles on the host -> floats -> upload
+inline DevOd read_od_dev(const Device& d, const NcIn& f, int iprofile, int nlay, size_t nwav) {
+  std::vector<size_t> sh;
+  int type = 0;
+  if (!f.exist("optical_depth", &sh, &type)) fail(ECCKD_PARAMETER_ERROR, "Variable \"optical_depth\" not found in %s", f.path().c_str());
+  size_t n = 1;
+  for (size_t k = 1; k < sh.size(); ++k) n *= sh[k];
+  if (sh.size() != 3 || n != (size_t)nlay * nwav)
+    fail(ECCKD_PARAMETER_ERROR, "optical_depth in %s is not (column, level, wavenumber)", f.path().c_str());
+  DevOd out;
+  out.type = type == NC_FLOAT_T ? ECCKD_F32 : ECCKD_F64;
+  out.buf.alloc(d, n * (size_t)out.type);
+  ck(ecckd_nc_read_dev(d.ctx(), f.handle(), "optical_depth", iprofile, out.type, out.buf.ptr(), n));
+  return out;
+}
+
 // ---- read_merged_spectrum (read_merged_spectrum.cpp:20-185): keys <prefix>input / scaling / conc ----
 struct Merged {
   Spectrum first;            // grid, pressures, temperatures of the first file (optical_depth released)
@@ -445,19 +463,16 @@ inline Merged read_merged_spectrum(const Device& dev, const Config& config, cons
     const std::string path = paths.find(files[ibg]);
     LOG("  Reading %s\n", path.c_str());
     Spectrum s;
+    DevOd od;
     if (ibg == 0) {
-      s = read_spectrum(path, iprofile);
+      s = read_spectrum(path, iprofile, false);
       m.molecules = s.molecule;
+      od = read_od_dev(dev, NcIn(path), iprofile, s.nlay, s.nwav);
     } else {
       NcIn f(path);
-      int type = 0;
-      f.exist("optical_depth", nullptr, &type);
-      s.od_is_float = type == NC_FLOAT_T;
-      s.optical_depth = f.read("optical_depth", iprofile);
       s.nlay = m.first.nlay;
       s.nwav = m.first.nwav;
-      if (s.optical_depth.size() != (size_t)s.nlay * s.nwav)
-        fail(ECCKD_PARAMETER_ERROR, "%s: optical_depth does not match the grid of the first spectrum", path.c_str());
+      od = read_od_dev(dev, f, iprofile, s.nlay, s.nwav);
       read_od_meta(f, iprofile, s.nlay, s.reference_surface_vmr, s.vmr_fl, s.molecule);
       if (s.molecule.empty())
         fail(ECCKD_PARAMETER_ERROR, "Found neither \"constituent_id\" nor \"molecules\" amongst the global attributes");
@@ -479,20 +494,15 @@ inline Merged read_merged_spectrum(const Device& dev, const Config& config, cons
     else if (!unscaled) LOG("    Scaling by %g\n", profile[0]);
     m.vmr_fl.push_back(vmr_out);
     if (files.size() == 1 && unscaled) {
-      m.single = upload_od(dev, s.optical_depth, s.od_is_float);
+      m.single = std::move(od);
       m.is_single = true;
     } else {
       if (ibg == 0) m.d_od.alloc(dev, (size_t)s.nlay * s.nwav * sizeof(double));
-      DevOd od = upload_od(dev, s.optical_depth, s.od_is_float);
       ck(ecckd_merge_spectrum_dev(dev.ctx(), s.nlay, s.nwav, od.buf.ptr(), od.type, s.nwav, profile.data(), ibg == 0 ? 1 : 0,
                                   m.d_od.as<double>(), s.nwav));
       ck(ecckd_synchronize(dev.ctx()));
     }
-    if (ibg == 0) {
-      s.optical_depth.clear();
-      s.optical_depth.shrink_to_fit();
-      m.first = std::move(s);
-    }
+    if (ibg == 0) m.first = std::move(s);
   }
   return m;
 }

@@ -39,6 +39,8 @@ struct ecckd_ctx {
   // resident rows each) does not pay hipMalloc / hipFree - page-table set-up that costs hundreds of
   // milliseconds on some hosts - inside the sweep.  Everything runs on `stream`, so reuse is ordered.
   void* cache_impl = nullptr;
+  // streaming file reader (nc_stream.hip): copy stream, pinned and device staging buffers, created on first use
+  void* stream_impl = nullptr;
 };
 
 namespace ecckd {
@@ -55,6 +57,7 @@ void dev_release(ecckd_ctx* ctx, void* p);          // back to the cache (or hip
 void dev_cache_trim(ecckd_ctx* ctx);                // hipFree every cached block
 void dev_cache_delete(ecckd_ctx* ctx);
 int ensure_pinned(ecckd_ctx* ctx, size_t bytes);
+void streamer_delete(ecckd_ctx* ctx);               // nc_stream.hip
 
 }  // namespace ecckd
 

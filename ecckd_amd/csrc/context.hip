@@ -164,6 +164,7 @@ int ecckd_destroy(ecckd_ctx* ctx) {
   if (!ctx) return ECCKD_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  ecckd::streamer_delete(ctx);
   ecckd::dev_cache_trim(ctx);
   ecckd::dev_cache_delete(ctx);
   if (ctx->scratch) (void)hipFree(ctx->scratch);

@@ -15,6 +15,7 @@
 // like DataFile::read(M, "v", j) (:582-590).
 #include "common.hpp"
 #include "nc_hdf5.hpp"
+#include "nc_classic.hpp"
 
 #include <algorithm>
 #include <cctype>
@@ -342,6 +343,35 @@ int ecckd_nc_inq_var(ecckd_nc* f, const char* name, int* exists, int* nc_type, i
   }
   return ECCKD_OK;
 }
+
+}  // extern "C" (reopened below)
+
+namespace ecckd {
+int nc_locate_slice(ecckd_nc* f, const char* name, long long slice, NcSlice* out) {
+  ECCKD_REQUIRE(f && name && out && !f->writing, "nc_locate_slice: bad argument");
+  *out = NcSlice();
+  if (f->h5) return ECCKD_OK;                 // not contiguous: the caller reads through the HDF5 layer
+  const Var* v = f->find(name);
+  if (!v) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: no variable \"%s\"", f->path.c_str(), name);
+  std::vector<uint64_t> sh;
+  f->shape_of(*v, sh);
+  uint64_t per_slice = 1;
+  for (size_t k = 1; k < sh.size(); ++k) per_slice *= sh[k];
+  const uint64_t nslice = sh.empty() ? 1 : sh[0];
+  if (slice >= 0)
+    ECCKD_REQUIRE(!sh.empty() && (uint64_t)slice < nslice, "%s: slice %lld of \"%s\" outside 0..%llu", f->path.c_str(), slice, name,
+                  (unsigned long long)nslice);
+  out->nc_type = v->type;
+  out->count = slice >= 0 ? per_slice : per_slice * nslice;
+  if (v->record) return ECCKD_OK;              // interleaved with the other record variables
+  out->fd = fileno(f->fp);
+  out->offset = v->begin + (slice >= 0 ? (uint64_t)slice * per_slice * type_size(v->type) : 0);
+  out->contiguous = true;
+  return ECCKD_OK;
+}
+}  // namespace ecckd
+
+extern "C" {
 
 int ecckd_nc_read_double(ecckd_nc* f, const char* name, long long slice, double* out, size_t capacity) {
   ECCKD_REQUIRE(f && name && out && !f->writing, "ecckd_nc_read_double: bad argument");

@@ -59,6 +59,24 @@ class NcFile:
     def exist(self, name):
         return self.var_info(name) is not None
 
+    def read_dev(self, ctx, name, index=None, dtype=None):
+        """The variable (or index `index` of its slowest dimension) as a tensor in device memory (ecckd_nc_read_dev: the file's
+        bytes go through pinned buffers and are decoded on the device).  dtype: torch.float32 / float64; default: FLOAT stays
+        float32, everything else float64."""
+        import torch
+        info = self.var_info(name)
+        if info is None:
+            raise EcckdError(_lib.PARAMETER_ERROR, f'variable "{name}" not found')
+        t, shape = info
+        shape = shape[1:] if index is not None else shape
+        if dtype is None:
+            dtype = torch.float32 if t == 5 else torch.float64
+        out = torch.empty(shape, dtype=dtype, device=ctx.device)
+        ctx.fence_from_torch()
+        check(self.lib.ecckd_nc_read_dev(ctx.handle, self.handle, _b(name), -1 if index is None else int(index),
+                                         4 if dtype == torch.float32 else 8, C.c_void_p(out.data_ptr()), out.numel()))
+        return out
+
     def read(self, name, index=None):
         """The variable as float64 (every external type is converted, DataFileEngineNetcdf.cpp:593-599);
         `index` selects one entry of the slowest dimension (:582-590)."""

@@ -135,6 +135,15 @@ int ecckd_reorder_spectrum(ecckd_ctx* ctx, int nlay, size_t nwav,
                            const double* h_band_bound2,
                            double* h_key, double* h_col_od, int16_t* h_iband,
                            int32_t* h_rank);
+/* the same with the optical depths already in device memory (ecckd_nc_read_dev) */
+int ecckd_reorder_spectrum_od_dev(ecckd_ctx* ctx, int nlay, size_t nwav,
+                           const double* h_pressure_hl, const double* h_wavenumber,
+                           const double* h_d_wavenumber, const void* d_od, int od_type,
+                           const double* h_ssi, double threshold_optical_depth,
+                           int nband, const double* h_band_bound1,
+                           const double* h_band_bound2,
+                           double* h_key, double* h_col_od, int16_t* h_iband,
+                           int32_t* h_rank);
 
 /* ---- find_g_points: gas preparation (K4) -------------------------------------
  * Replaces find_g_points.cpp:872-1150 for one gas: invert the rank from the order
@@ -381,6 +390,13 @@ int ecckd_nc_inq_dim(ecckd_nc* file, const char* name, size_t* length);
 int ecckd_nc_inq_var(ecckd_nc* file, const char* name, int* exists, int* nc_type, int* ndims, size_t* shape,
                      int shape_capacity);
 int ecckd_nc_read_double(ecckd_nc* file, const char* name, long long slice, double* out, size_t capacity);
+/* One index of the slowest dimension (slice >= 0) or the whole variable straight into device memory as FLOAT (out_type 4)
+ * or DOUBLE (8): replaces DataFile::read -> nc_get_vara_double -> element-wise copy (DataFileEngineNetcdf.cpp:593-608) for
+ * the spectra.  A contiguous FLOAT / DOUBLE variable of a classic file is streamed - reader threads fill pinned buffers,
+ * a copy stream ships them, a kernel decodes the big-endian values on the device, reading overlaps shipping; anything
+ * else (NetCDF-4, record variables, integer types) is read on the host and uploaded once.  capacity in elements. */
+int ecckd_nc_read_dev(ecckd_ctx* ctx, ecckd_nc* file, const char* name, long long slice, int out_type, void* d_out,
+                      size_t capacity);
 int ecckd_nc_read_att_text(ecckd_nc* file, const char* var, const char* att, int* exists, char* out, size_t capacity);
 int ecckd_nc_read_att_double(ecckd_nc* file, const char* var, const char* att, int* nelems, double* out, size_t capacity);
 /* writing: define, ecckd_nc_enddef (picks CDF-1 / CDF-2 / CDF-5 from the sizes), then whole variables */

@@ -1,0 +1,41 @@
+"""ecckd_nc_read_dev: a variable of a NetCDF file straight into device memory (pinned chunks, copy stream, decoding on the
+device) against the element-wise host reader (nc_get_vara_double semantics, DataFileEngineNetcdf.cpp:593-608): FLOAT and
+DOUBLE variables larger than several chunks, one slice and the whole variable, widening and narrowing, the fallbacks
+(integer type, record variable) and the tools' use of it (tests/test_cli_gpu.py runs them on files)."""
+import numpy as np
+import pytest
+import torch
+from scipy.io import netcdf_file
+
+pytestmark = pytest.mark.gpu
+
+
+def test_streamed_read_matches_host_reader(ctx, tmp_path, monkeypatch):
+    from ecckd_amd import ncio
+    rs = np.random.RandomState(1)
+    ncol, nlay, nwav = 2, 3, 2_000_003            # 24 MB per FLOAT slice: two 16-MB chunks, the second one ragged
+    od = (rs.standard_normal((ncol, nlay, nwav)) * 1e3).astype(np.float32)
+    od[0, 0, :5] = [0.0, -0.0, np.float32(1e-40), np.inf, -1.5]
+    wn = np.cumsum(rs.uniform(0.1, 1.0, nwav))
+    path = tmp_path / "s.nc"
+    w = netcdf_file(str(path), "w", version=2)
+    for d, n in (("column", ncol), ("level", nlay), ("wavenumber", nwav)):
+        w.createDimension(d, n)
+    w.createVariable("optical_depth", "f", ("column", "level", "wavenumber"))[:] = od
+    w.createVariable("wavenumber", "d", ("wavenumber",))[:] = wn
+    w.createVariable("count", "i", ("level",))[:] = [3, -7, 2**31 - 1]
+    w.close()
+    with ncio.NcFile(path) as f:
+        for idx in (0, 1):
+            got = f.read_dev(ctx, "optical_depth", idx)
+            assert got.dtype == torch.float32 and got.shape == (nlay, nwav)
+            assert np.array_equal(got.cpu().numpy().view(np.uint32), od[idx].view(np.uint32))          # bit for bit, -0.0 and denormals too
+            wide = f.read_dev(ctx, "optical_depth", idx, dtype=torch.float64)
+            assert np.array_equal(wide.cpu().numpy(), f.read("optical_depth", idx))
+        whole = f.read_dev(ctx, "optical_depth")
+        assert whole.shape == (ncol, nlay, nwav) and np.array_equal(whole.cpu().numpy().view(np.uint32), od.view(np.uint32))
+        assert np.array_equal(f.read_dev(ctx, "wavenumber").cpu().numpy(), wn)
+        assert np.array_equal(f.read_dev(ctx, "wavenumber", dtype=torch.float32).cpu().numpy(), wn.astype(np.float32))
+        assert np.array_equal(f.read_dev(ctx, "count").cpu().numpy(), [3.0, -7.0, 2.0**31 - 1])           # integer type: host path
+        monkeypatch.setenv("ECCKD_NO_STREAMED_READ", "1")                                               # the fallback gives the same
+        assert np.array_equal(f.read_dev(ctx, "optical_depth", 1).cpu().numpy().view(np.uint32), od[1].view(np.uint32))
