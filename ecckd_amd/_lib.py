@@ -179,6 +179,7 @@ SIGNATURES = {
     "ecckd_nc_put_att_double": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, _c_double_p]),
     "ecckd_nc_enddef": (C.c_int, [C.c_void_p]),
     "ecckd_nc_write_double": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p, C.c_size_t]),
+    "ecckd_nc_write_slice_double": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, _c_double_p, C.c_size_t]),
     "ecckd_write_order_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, _c_double_p, _c_double_p,
                                          C.c_size_t, _c_double_p, _c_double_p, _c_int16_p, _c_int32_p, _c_double_p,
                                          _c_double_p]),

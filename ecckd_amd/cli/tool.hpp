@@ -267,6 +267,9 @@ class NcOut {
   }
   void end_define() { ck(ecckd_nc_enddef(f_)); }
   void write(const std::string& name, const std::vector<double>& v) { ck(ecckd_nc_write_double(f_, name.c_str(), v.data(), v.size())); }
+  void write_slice(const std::string& name, size_t slice, const std::vector<double>& v) {
+    ck(ecckd_nc_write_slice_double(f_, name.c_str(), slice, v.data(), v.size()));
+  }
   template <class T>
   void write_as_double(const std::string& name, const std::vector<T>& v) {
     std::vector<double> d(v.begin(), v.end());

@@ -573,6 +573,31 @@ int ecckd_nc_write_double(ecckd_nc* f, const char* name, const double* data, siz
   return ECCKD_OK;
 }
 
+// one index of the slowest dimension of a (fixed-size) variable: what lets a tool write a (column, level, wavenumber)
+// matrix column by column without holding all columns
+int ecckd_nc_write_slice_double(ecckd_nc* f, const char* name, size_t slice, const double* data, size_t count) {
+  ECCKD_REQUIRE(f && f->writing && !f->defining && name && data, "ecckd_nc_write_slice_double: bad argument or still in define mode");
+  const Var* v = f->find(name);
+  if (!v) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: no variable \"%s\"", f->path.c_str(), name);
+  ECCKD_REQUIRE(!v->dimids.empty() && !v->record, "ecckd_nc_write_slice_double: \"%s\" is a scalar or a record variable", name);
+  uint64_t per = 1;
+  for (size_t k = 1; k < v->dimids.size(); ++k) per *= f->dims[v->dimids[k]].len;
+  ECCKD_REQUIRE(slice < f->dims[v->dimids[0]].len && count == per, "ecckd_nc_write_slice_double: \"%s\" slice %zu / %zu values do not fit",
+                name, slice, count);
+  const size_t ts = type_size(v->type);
+  if (fseeko(f->fp, (off_t)(v->begin + (uint64_t)slice * per * ts), SEEK_SET) != 0)
+    return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: seek failed", f->path.c_str());
+  std::vector<unsigned char> buf((size_t)std::min<uint64_t>(per, (uint64_t)1 << 20) * ts);
+  size_t i = 0;
+  while (i < count) {
+    const size_t n = std::min(count - i, buf.size() / ts);
+    for (size_t k = 0; k < n; ++k) encode(buf.data() + k * ts, v->type, data[i + k]);
+    if (std::fwrite(buf.data(), ts, n, f->fp) != n) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: short write of \"%s\"", f->path.c_str(), name);
+    i += n;
+  }
+  return ECCKD_OK;
+}
+
 
 // write_order (write_order.cpp:24-143): the reordering file that find_g_points and create_look_up_table read.
 // Same variable names, external types, long_name / units / comment attributes and global attributes

@@ -66,7 +66,7 @@ class NcFile:
         import torch
         info = self.var_info(name)
         if info is None:
-XX
+            raise _lib.EcckdError(_lib.PARAMETER_ERROR, f'variable "{name}" not found')
         t, shape = info
         shape = shape[1:] if index is not None else shape
         if dtype is None:

@@ -407,6 +407,8 @@ int ecckd_nc_put_att_text(ecckd_nc* file, const char* var, const char* att, cons
 int ecckd_nc_put_att_double(ecckd_nc* file, const char* var, const char* att, int nc_type, int n, const double* values);
 int ecckd_nc_enddef(ecckd_nc* file);
 int ecckd_nc_write_double(ecckd_nc* file, const char* name, const double* data, size_t count);
+/* one index of the slowest dimension of a fixed-size variable (count = the elements below that dimension) */
+int ecckd_nc_write_slice_double(ecckd_nc* file, const char* name, size_t slice, const double* data, size_t count);
 /* write_order (write_order.cpp:24-143): same variables, external types and attributes; `history` is the
  * line OutputDataFile::append_history would add (may be NULL); column_optical_depth may be NULL (:88). */
 int ecckd_write_order_file(const char* path, const char* molecule, const char* config_str, const char* history, int nband,
