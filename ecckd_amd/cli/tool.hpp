@@ -4,6 +4,7 @@
 // NetCDF files in and out, exit code 0 or one of src/include/EsaExitCodes.h.  Everything here sits ABOVE the
 // C ABI of include/ecckd_hip.h - the tools never touch HIP themselves.
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -48,7 +49,16 @@ inline void set_log_level(const std::string& s) {
   else if (s == "info" || s == "2") log_level() = 2;
   else log_level() = 3;
 }
-#define LOG(...) do { if (tool::log_level() >= 2) { std::printf(__VA_ARGS__); std::fflush(stdout); } } while (0)
+// ECCKD_LOG_TIMES=1: every LOG line starts with the seconds since the tool started (where does the wall time go?)
+inline double seconds_since_start() {
+  static const std::clock_t unused = std::clock();
+  (void)unused;
+  static const auto t0 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+inline bool log_times() { static const bool on = std::getenv("ECCKD_LOG_TIMES") != nullptr; return on; }
+#define LOG(...) do { if (tool::log_level() >= 2) { if (tool::log_times()) std::printf("[%8.3f] ", tool::seconds_since_start()); \
+                                                    std::printf(__VA_ARGS__); std::fflush(stdout); } } while (0)
 #define WARN(...) do { if (tool::log_level() >= 1) { std::fprintf(stderr, "*** Warning: "); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } } while (0)
 
 // ---- configuration (DataFile config(argc, argv)) ----

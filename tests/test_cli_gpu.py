@@ -799,3 +799,80 @@ def test_do_all_sw_with_the_tools(ctx, tmp_path):
         rms[tag] = float(np.sqrt(np.mean((got - truth) ** 2)))
     print("direct-flux RMS error (W m-2), tools only:", rms)
     assert np.isfinite(rms["raw"]) and rms["ckd"] < 0.9 * rms["raw"]
+
+
+def test_ckdmip_lw_stand_in(ctx, tmp_path):
+    """bin/ckdmip_lw, the stand-in for the external CKDMIP tool of the reference's scripts: --merge-only
+    (test/merge_well_mixed_lw.sh:28-63) against the library's merge, the line-by-line band fluxes
+    (test/run_lw_lbl_evaluation.sh:286-323) against ecckd_lbl_band_fluxes_lw and through LblFluxes::read's mirror, and the
+    flux evaluation of a CKD model's optical depths (test/run_ckd_lw.sh:133-137) against run_ckd's own fluxes."""
+    import torch
+    from ecckd_amd import api, ncio
+    from test_pipeline_gpu import make_do_all_inputs
+    d = tmp_path
+    inp = make_do_all_inputs(ctx, d)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=ctx.device)
+    nlay, wn = inp["nlay"], inp["wn"]
+    # ---- merge-only: h2o as it is + co2 scaled to 8e-4 at the surface (its file says 4e-4) ----
+    r = run_tool("ckdmip_lw", "--merge-only", "ideal_h2o.nc", "--conc", "8e-4", "ideal_co2.nc", "--output", "merged.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    for col in (0, 2):
+        m = ncio.read_spectrum(d / "merged.nc", col)
+        h, c = ncio.read_spectrum(d / "ideal_h2o.nc", col), ncio.read_spectrum(d / "ideal_co2.nc", col)
+        want = (h["optical_depth"] + 2.0 * c["optical_depth"]).astype(np.float32)
+        assert np.allclose(m["optical_depth"], want, rtol=2e-7, atol=0) and np.array_equal(m["wavenumber_cm_1"], wn)
+        assert np.allclose(m["temperature_hl"], h["temperature_hl"], rtol=1e-6) and m["molecule"] == "composite"
+    # ---- line-by-line band fluxes of the three idealised columns, co2 at a constant 6e-4, h2o scaled by 0.5 ----
+    (d / "lw.nam").write_text("&longwave_config\noptical_depth_name = \"optical_depth\",\nnspectralstride = 1,\nnangle = 0, ! classic\n"
+                              "do_write_spectral_boundary_fluxes = false,\nband_wavenumber1(1:2) = 0, 1300,\n"
+                              "band_wavenumber2(1:2) = 1300, 3260,\niverbose = 3\n/\n")
+    r = run_tool("ckdmip_lw", "--config", "lw.nam", "--scenario", "test-1", "--scale", "0.5", "ideal_h2o.nc", "--const", "6e-4", "ideal_co2.nc",
+                 "--output", "lbl_tool.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    f = _nc(d / "lbl_tool.nc")
+    assert f.scenario == b"test-1" and f.constituent_id == b"h2o co2"
+    begin = [int(np.nonzero((wn >= a) & (wn < b + (b == 3260.0)))[0][0]) for a, b in zip(*inp["bands"])]
+    end = [int(np.nonzero((wn >= a) & (wn < b + (b == 3260.0)))[0][-1]) for a, b in zip(*inp["bands"])]
+    dwn = ncio.read_spectrum(d / "ideal_h2o.nc")["d_wavenumber_cm_1"]
+    for col in range(3):
+        h, c = ncio.read_spectrum(d / "ideal_h2o.nc", col), ncio.read_spectrum(d / "ideal_co2.nc", col)
+        od = 0.5 * h["optical_depth"] + (6e-4 / c["vmr_fl"])[:, None] * c["optical_depth"]
+        dn, up = api.lbl_band_fluxes_lw(ctx, h["temperature_hl"], dev(wn), dev(dwn), dev(od), begin, end)
+        assert np.allclose(f.variables["band_flux_dn_lw"][col], dn.T, rtol=3e-7, atol=1e-30)
+        assert np.allclose(f.variables["band_flux_up_lw"][col], up.T, rtol=3e-7)
+        assert np.allclose(f.variables["flux_up_lw"][col], up.sum(0), rtol=3e-7)
+        assert np.allclose(f.variables["mole_fraction_fl"][col], np.stack([0.5 * h["vmr_fl"], np.full(nlay, 6e-4)]), rtol=2e-7)
+    f.close()
+    s = ncio.read_lbl_fluxes(d / "lbl_tool.nc", ["h2o", "co2"], ctx=ctx)           # what optimize_lut reads (lbl_fluxes.cpp:52-397)
+    assert s["have_band_fluxes"] and s["flux_dn"].shape == (3, nlay + 1, 2) and np.array_equal(s["band_wavenumber2"], [1300.0, 3260.0])
+    # ---- errors: an angle quadrature is refused, so is a namelist without bands ----
+    (d / "bad.nam").write_text("&longwave_config\nnangle = 4,\nband_wavenumber1(1:1) = 0,\nband_wavenumber2(1:1) = 3260\n/\n")
+    r = run_tool("ckdmip_lw", "--config", "bad.nam", "ideal_h2o.nc", "--output", "x.nc", cwd=d)
+    assert r.returncode == 147 and "nangle" in r.stderr
+    r = run_tool("ckdmip_lw", "ideal_h2o.nc", "--output", "x.nc", cwd=d)
+    assert r.returncode == 147 and "band_wavenumber1" in r.stderr
+    # ---- --ckd: fluxes from the optical depths run_ckd wrote ----
+    from test_pipeline_gpu import make_optimize_files
+    e = tmp_path / "ckd"
+    e.mkdir()
+    model, truth, scenes, paths, ib, names = make_optimize_files(ctx, e)
+    sc = scenes[0]
+    ncol, nhl = sc["pressure_hl"].shape
+    w = netcdf_file(str(e / "conc.nc"), "w", version=2)
+    for dim, n in (("column", ncol), ("half_level", nhl), ("level", nhl - 1)):
+        w.createDimension(dim, n)
+    w.createVariable("pressure_hl", "d", ("column", "half_level"))[:] = sc["pressure_hl"]
+    w.createVariable("temperature_hl", "d", ("column", "half_level"))[:] = sc["temperature_hl"]
+    for i, g in enumerate(model["gases"]):
+        if g["conc"] != "none":
+            w.createVariable(names[i] + "_mole_fraction_fl", "d", ("column", "level"))[:] = sc["vmr_fl"][:, i, :]
+    w.close()
+    r = run_tool("run_ckd", "ckd_model=raw.nc", "input=conc.nc", "output=od.nc", cwd=e)
+    assert r.returncode == 0, r.stderr + r.stdout
+    r = run_tool("ckdmip_lw", "--scenario", "present", "--ckd", "od.nc", "--output", "fluxes.nc", cwd=e)
+    assert r.returncode == 0, r.stderr + r.stdout
+    a, b = _nc(e / "od.nc"), _nc(e / "fluxes.nc")
+    for k in ("flux_dn_lw", "flux_up_lw"):          # run_ckd's own fluxes come from the unrounded optical depths: FLOAT agreement
+        assert np.allclose(b.variables[k][...], a.variables[k][...], rtol=2e-5, atol=1e-4), k
+    assert b.variables["spectral_flux_dn_lw"].shape == a.variables["optical_depth"].shape[:1] + (nhl, a.variables["optical_depth"].shape[2])
+    a.close(); b.close()
