@@ -394,16 +394,27 @@ int ecckd_nc_read_double(ecckd_nc* f, const char* name, long long slice, double*
   ECCKD_REQUIRE(total <= capacity, "ecckd_nc_read_double: \"%s\" needs %llu values, buffer holds %zu", name,
                 (unsigned long long)total, capacity);
   const size_t ts = type_size(v->type);
-  std::vector<unsigned char> buf((size_t)std::min<uint64_t>(per_slice, (uint64_t)1 << 20) * ts);
   size_t o = 0;
-  for (uint64_t s = s0; s < s1; ++s) {
-    const uint64_t off = v->record ? v->begin + s * f->recsize : v->begin + s * per_slice * ts;
+  // a fixed-size variable lies in one piece: the requested slices are one contiguous run (a 1-D variable is "slices" of
+  // ONE element each - seeking to every one of them made reading a 4e6-point grid take seconds); a record variable is
+  // interleaved with the others record by record
+  const uint64_t nrun = v->record ? (s1 - s0) : 1;
+  const uint64_t run_elems = v->record ? per_slice : total;
+  std::vector<unsigned char> buf((size_t)std::min<uint64_t>(std::max<uint64_t>(run_elems, 1), (uint64_t)1 << 20) * ts);
+  for (uint64_t r = 0; r < nrun; ++r) {
+    const uint64_t off = v->record ? v->begin + (s0 + r) * f->recsize : v->begin + s0 * per_slice * ts;
     if (fseeko(f->fp, (off_t)off, SEEK_SET) != 0) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: seek failed", f->path.c_str());
-    uint64_t left = per_slice;
+    uint64_t left = run_elems;
     while (left > 0) {
       const size_t n = (size_t)std::min<uint64_t>(left, buf.size() / ts);
       if (fread(buf.data(), ts, n, f->fp) != n) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: short read of \"%s\"", f->path.c_str(), name);
-      for (size_t i = 0; i < n; ++i) out[o++] = decode(buf.data() + i * ts, v->type);
+      if (v->type == NC_DOUBLE) {
+        for (size_t i = 0; i < n; ++i) { uint64_t u; std::memcpy(&u, buf.data() + i * 8, 8); u = __builtin_bswap64(u); std::memcpy(&out[o++], &u, 8); }
+      } else if (v->type == NC_FLOAT) {
+        for (size_t i = 0; i < n; ++i) { uint32_t u; std::memcpy(&u, buf.data() + i * 4, 4); u = __builtin_bswap32(u); float x; std::memcpy(&x, &u, 4); out[o++] = (double)x; }
+      } else {
+        for (size_t i = 0; i < n; ++i) out[o++] = decode(buf.data() + i * ts, v->type);
+      }
       left -= n;
     }
   }
