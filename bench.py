@@ -33,7 +33,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-K1_VALU_PER_POINT = 677.0e6 * 64 / 7.2e6   # SQ_INSTS_VALU (wave instructions) per launch of 7.2e6 points, profiles/r01_pmc_k_rt_lw_bb_mirror.md
+K1_VALU_PER_POINT = 574.259e6 * 64 / 7.2e6   # SQ_INSTS_VALU (wave instructions) per launch of 7.2e6 points, profiles/r02_pmc_find_g_kernels.md
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
