@@ -347,6 +347,8 @@ int ecckd_nc_inq_var(ecckd_nc* f, const char* name, int* exists, int* nc_type, i
 }  // extern "C" (reopened below)
 
 namespace ecckd {
+H5File* nc_h5_handle(ecckd_nc* f) { return f ? f->h5 : nullptr; }
+
 int nc_locate_slice(ecckd_nc* f, const char* name, long long slice, NcSlice* out) {
   ECCKD_REQUIRE(f && name && out && !f->writing, "nc_locate_slice: bad argument");
   *out = NcSlice();
@@ -375,7 +377,12 @@ extern "C" {
 
 int ecckd_nc_read_double(ecckd_nc* f, const char* name, long long slice, double* out, size_t capacity) {
   ECCKD_REQUIRE(f && name && out && !f->writing, "ecckd_nc_read_double: bad argument");
-  if (f->h5) return ecckd::h5_read_double(f->h5, name, slice, out, capacity);
+  if (f->h5) {
+    bool handled = false;        // big chunked FLOAT / DOUBLE variables: the chunks inflated by worker threads
+    ECCKD_CHECK(ecckd::h5_read_real_parallel(f->h5, name, slice, 8, out, capacity, &handled));
+    if (handled) return ECCKD_OK;
+    return ecckd::h5_read_double(f->h5, name, slice, out, capacity);
+  }
   const Var* v = f->find(name);
   if (!v) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: no variable \"%s\"", f->path.c_str(), name);
   std::vector<uint64_t> sh;

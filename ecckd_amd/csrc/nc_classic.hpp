@@ -17,4 +17,8 @@ struct NcSlice {
 // Where one index of the slowest dimension (slice >= 0) or the whole variable (slice < 0) lies in the file.
 int nc_locate_slice(ecckd_nc* f, const char* name, long long slice, NcSlice* out);
 
+struct H5File;
+// the HDF5 backend of a NetCDF-4 file opened for reading, or NULL for a classic file
+H5File* nc_h5_handle(ecckd_nc* f);
+
 }  // namespace ecckd

@@ -20,6 +20,11 @@
 #include "common.hpp"
 #include "nc_hdf5.hpp"
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
 namespace {
 
 typedef int64_t hid_t;
@@ -59,6 +64,17 @@ struct Api {
   herr_t (*H5Aread)(hid_t, hid_t, void*);
   herr_t (*H5Aclose)(hid_t);
   herr_t (*H5get_libversion)(unsigned*, unsigned*, unsigned*);
+  // optional (1.10.3+ / 1.10.5+): raw chunk access for the parallel inflate path
+  hid_t (*H5Dget_create_plist)(hid_t) = nullptr;
+  int (*H5Pget_layout)(hid_t) = nullptr;
+  int (*H5Pget_chunk)(hid_t, int, hsize_t*) = nullptr;
+  int (*H5Pget_nfilters)(hid_t) = nullptr;
+  int (*H5Pget_filter2)(hid_t, unsigned, unsigned*, size_t*, unsigned*, size_t, char*, unsigned*) = nullptr;
+  herr_t (*H5Pclose)(hid_t) = nullptr;
+  herr_t (*H5Dread_chunk)(hid_t, hid_t, const hsize_t*, unsigned*, void*) = nullptr;
+  herr_t (*H5Dget_chunk_storage_size)(hid_t, const hsize_t*, hsize_t*) = nullptr;
+  int (*H5Tget_order)(hid_t) = nullptr;
+  int (*z_uncompress)(unsigned char*, unsigned long*, const unsigned char*, unsigned long) = nullptr;   // zlib, loaded beside
   herr_t (*H5free_memory)(void*) = nullptr;   // optional (1.8.13+): releases what the library allocated for variable-length strings
   hid_t* native_double = nullptr;   // H5T_NATIVE_DOUBLE_g
   hid_t* c_s1 = nullptr;            // H5T_C_S1_g
@@ -95,6 +111,16 @@ Api* api() {
   LOAD(H5get_libversion);
 #undef LOAD
   a.H5free_memory = reinterpret_cast<decltype(a.H5free_memory)>(dlsym(a.lib, "H5free_memory"));
+#define OPT(f) a.f = reinterpret_cast<decltype(a.f)>(dlsym(a.lib, #f))
+  OPT(H5Dget_create_plist); OPT(H5Pget_layout); OPT(H5Pget_chunk); OPT(H5Pget_nfilters); OPT(H5Pget_filter2); OPT(H5Pclose);
+  OPT(H5Dread_chunk); OPT(H5Dget_chunk_storage_size); OPT(H5Tget_order);
+#undef OPT
+  for (const char* zn : {"libz.so.1", "libz.so", "/opt/conda/lib/libz.so.1"}) {
+    if (void* z = dlopen(zn, RTLD_NOW | RTLD_LOCAL)) {
+      a.z_uncompress = reinterpret_cast<decltype(a.z_uncompress)>(dlsym(z, "uncompress"));
+      if (a.z_uncompress) break;
+    }
+  }
   if (ok) {
     // the ABI declared above (64-bit hid_t, H5P_DEFAULT = H5S_ALL = 0) is that of HDF5 1.10 and later; 1.8 has a 32-bit hid_t
     unsigned maj = 0, min = 0, rel = 0;
@@ -227,6 +253,137 @@ int h5_read_double(H5File* h, const char* name, long long slice, double* out, si
     rc = fail(ECCKD_PROCESSING_ERROR, "%s: reading \"%s\" failed (missing filter plug-in?)", h->path.c_str(), name);
   if (mem > 0) a->H5Sclose(mem);
   a->H5Sclose(sp); a->H5Dclose(d);
+  return rc;
+}
+
+// One slice (or all) of a chunked FLOAT / DOUBLE variable with the shuffle + deflate filters of NetCDF-4
+// (OutputDataFile.cpp:350-359 writes them so; the CKDMIP spectra are stored that way): the calling thread pulls the RAW chunks
+// out of the file (H5Dread_chunk: no filter pipeline, the library is not thread-safe), worker threads inflate, unshuffle and
+// place them - the HDF5 library would do all of that on the one calling thread.  *handled = false: the layout is not
+// one this path takes apart (contiguous, other filters, big-endian, missing chunks, old library); the caller falls back to H5Dread.
+int h5_read_real_parallel(H5File* h, const char* name, long long slice, int out_type, void* out, size_t capacity, bool* handled) {
+  Api* a = h->a;
+  *handled = false;
+  if (!a->H5Dread_chunk || !a->H5Dget_chunk_storage_size || !a->H5Dget_create_plist || !a->H5Pget_layout || !a->H5Pget_chunk ||
+      !a->H5Pget_nfilters || !a->H5Pget_filter2 || !a->H5Pclose || !a->H5Tget_order || !a->z_uncompress ||
+      std::getenv("ECCKD_NO_PARALLEL_INFLATE"))
+    return ECCKD_OK;
+  if (a->H5Lexists(h->file, name, 0) <= 0) return ECCKD_OK;
+  const hid_t d = a->H5Dopen2(h->file, name, 0);
+  if (d < 0) return ECCKD_OK;
+  const hid_t sp = a->H5Dget_space(d), t = a->H5Dget_type(d), pl = a->H5Dget_create_plist(d);
+  const int nd = a->H5Sget_simple_extent_ndims(sp);
+  hsize_t dims[32] = {}, cdims[32] = {};
+  if (nd > 0) a->H5Sget_simple_extent_dims(sp, dims, nullptr);
+  const size_t ts = a->H5Tget_size(t);
+  bool ok = nd >= 1 && nd <= 8 && a->H5Tget_class(t) == 1 && (ts == 4 || ts == 8) && a->H5Tget_order(t) == 0 /* little-endian */ &&
+            a->H5Pget_layout(pl) == 2 /* H5D_CHUNKED */ && a->H5Pget_chunk(pl, nd, cdims) == nd;
+  // filter pipeline: [shuffle,] deflate  (ids 2, 1), in that order
+  int i_shuffle = -1, i_deflate = -1;
+  if (ok) {
+    const int nf = a->H5Pget_nfilters(pl);
+    for (int i = 0; i < nf && ok; ++i) {
+      unsigned flags = 0, cfg = 0, cd[8];
+      size_t ncd = 8;
+      char fname[8];
+      const int id = a->H5Pget_filter2(pl, (unsigned)i, &flags, &ncd, cd, sizeof fname, fname, &cfg);
+      if (id == 2 && i_shuffle < 0 && i_deflate < 0) i_shuffle = i;
+      else if (id == 1 && i_deflate < 0) i_deflate = i;
+      else ok = false;
+    }
+    ok = ok && i_deflate >= 0;
+  }
+  hsize_t lo[8] = {}, hi[8] = {};          // requested box [lo, hi) in dataset coordinates
+  size_t total = 1;
+  if (ok) {
+    for (int k = 0; k < nd; ++k) { lo[k] = 0; hi[k] = dims[k]; }
+    if (slice >= 0) {
+      if ((hsize_t)slice >= dims[0]) ok = false;
+      else { lo[0] = (hsize_t)slice; hi[0] = lo[0] + 1; }
+    }
+    for (int k = 0; k < nd; ++k) total *= (size_t)(hi[k] - lo[k]);
+    ok = ok && total <= capacity && total > 0;
+  }
+  int rc = ECCKD_OK;
+  if (ok) {
+    // chunks that intersect the box
+    hsize_t c0[8], c1[8];
+    size_t nchunks = 1, chunk_elems = 1;
+    for (int k = 0; k < nd; ++k) {
+      c0[k] = lo[k] / cdims[k];
+      c1[k] = (hi[k] - 1) / cdims[k];
+      nchunks *= (size_t)(c1[k] - c0[k] + 1);
+      chunk_elems *= (size_t)cdims[k];
+    }
+    struct Job { hsize_t off[8]; std::vector<unsigned char> raw; unsigned mask; };
+    const unsigned nworkers = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<Job> jobs(nchunks);
+    std::atomic<size_t> produced{0}, next{0};
+    std::atomic<int> bad{0};
+    const size_t out_ts = (size_t)out_type;
+    auto worker = [&]() {
+      std::vector<unsigned char> plain(chunk_elems * ts), unshuf(chunk_elems * ts);
+      for (;;) {
+        const size_t j = next.fetch_add(1);
+        if (j >= nchunks) return;
+        while (produced.load(std::memory_order_acquire) <= j && !bad.load()) std::this_thread::yield();
+        if (bad.load()) return;
+        Job& job = jobs[j];
+        const unsigned char* data = job.raw.data();
+        if (!(job.mask & (1u << i_deflate))) {
+          unsigned long n = (unsigned long)plain.size();
+          if (a->z_uncompress(plain.data(), &n, job.raw.data(), (unsigned long)job.raw.size()) != 0 || n != plain.size()) { bad.store(1); return; }
+          data = plain.data();
+        } else if (job.raw.size() != plain.size()) { bad.store(1); return; }
+        if (i_shuffle >= 0 && !(job.mask & (1u << i_shuffle))) {       // byte b of element e sits at b * nelems + e
+          for (size_t b = 0; b < ts; ++b) {
+            const unsigned char* src = data + b * chunk_elems;
+            for (size_t e = 0; e < chunk_elems; ++e) unshuf[e * ts + b] = src[e];
+          }
+          data = unshuf.data();
+        }
+        // copy the part of the chunk that lies in the box, innermost dimension contiguous
+        hsize_t b0[8], b1[8];
+        for (int k = 0; k < nd; ++k) { b0[k] = std::max(lo[k], job.off[k]); b1[k] = std::min(hi[k], job.off[k] + cdims[k]); }
+        const size_t run = (size_t)(b1[nd - 1] - b0[nd - 1]);
+        hsize_t idx[8];
+        for (int k = 0; k < nd; ++k) idx[k] = b0[k];
+        for (;;) {
+          size_t src_e = 0, dst_e = 0;
+          for (int k = 0; k < nd; ++k) { src_e = src_e * (size_t)cdims[k] + (size_t)(idx[k] - job.off[k]); dst_e = dst_e * (size_t)(hi[k] - lo[k]) + (size_t)(idx[k] - lo[k]); }
+          if (ts == 4 && out_ts == 4) std::memcpy((float*)out + dst_e, data + src_e * 4, run * 4);
+          else if (ts == 8 && out_ts == 8) std::memcpy((double*)out + dst_e, data + src_e * 8, run * 8);
+          else if (ts == 4) { const float* sf = (const float*)(data + src_e * 4); for (size_t e = 0; e < run; ++e) ((double*)out)[dst_e + e] = (double)sf[e]; }
+          else { const double* sd = (const double*)(data + src_e * 8); for (size_t e = 0; e < run; ++e) ((float*)out)[dst_e + e] = (float)sd[e]; }
+          int k = nd - 2;
+          for (; k >= 0; --k) { if (++idx[k] < b1[k]) break; idx[k] = b0[k]; }
+          if (k < 0) break;
+        }
+        std::vector<unsigned char>().swap(job.raw);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nworkers; ++w) pool.emplace_back(worker);
+    // producer: raw chunks in row-major chunk order
+    hsize_t ci[8];
+    for (int k = 0; k < nd; ++k) ci[k] = c0[k];
+    for (size_t j = 0; j < nchunks && !bad.load(); ++j) {
+      Job& job = jobs[j];
+      for (int k = 0; k < nd; ++k) job.off[k] = ci[k] * cdims[k];
+      hsize_t bytes = 0;
+      if (a->H5Dget_chunk_storage_size(d, job.off, &bytes) < 0 || bytes == 0) { bad.store(2); break; }   // an unwritten chunk: leave it to H5Dread (fill value)
+      job.raw.resize((size_t)bytes);
+      job.mask = 0;
+      if (a->H5Dread_chunk(d, 0, job.off, &job.mask, job.raw.data()) < 0) { bad.store(3); break; }
+      produced.store(j + 1, std::memory_order_release);
+      for (int k = nd - 1; k >= 0; --k) { if (++ci[k] <= c1[k]) break; ci[k] = c0[k]; }
+    }
+    if (bad.load()) produced.store(nchunks, std::memory_order_release);
+    for (std::thread& th : pool) th.join();
+    if (bad.load() == 1 || bad.load() == 3) rc = fail(ECCKD_PROCESSING_ERROR, "%s: a chunk of \"%s\" could not be read or inflated", h->path.c_str(), name);
+    else if (bad.load() == 0) *handled = true;
+  }
+  a->H5Pclose(pl); a->H5Tclose(t); a->H5Sclose(sp); a->H5Dclose(d);
   return rc;
 }
 

@@ -10,6 +10,7 @@
 // record variables, integer types) go through the element-wise host path and one upload.
 #include "common.hpp"
 #include "nc_classic.hpp"
+#include "nc_hdf5.hpp"
 
 #include <atomic>
 #include <cstring>
@@ -109,6 +110,13 @@ int ecckd_nc_read_dev(ecckd_ctx* ctx, ecckd_nc* file, const char* name, long lon
     size_t n = 1;
     for (int k = (slice >= 0 ? 1 : 0); k < nd; ++k) n *= sh[k];
     ECCKD_REQUIRE(n <= capacity, "ecckd_nc_read_dev: \"%s\" needs %zu values, buffer holds %zu", name, n, capacity);
+    if (ecckd::H5File* h5 = ecckd::nc_h5_handle(file)) {
+      // NetCDF-4: raw chunks pulled by this thread, inflated / unshuffled by worker threads straight into the output type
+      bool handled = false;
+      std::vector<unsigned char> typed(n * (size_t)out_type);
+      ECCKD_CHECK(ecckd::h5_read_real_parallel(h5, name, slice, out_type, typed.data(), n, &handled));
+      if (handled) return ecckd_h2d(ctx, d_out, typed.data(), typed.size());
+    }
     std::vector<double> host(n);
     ECCKD_CHECK(ecckd_nc_read_double(file, name, slice, host.data(), n));
     if (out_type == ECCKD_F64) return ecckd_h2d(ctx, d_out, host.data(), n * sizeof(double));

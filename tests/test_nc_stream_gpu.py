@@ -39,3 +39,21 @@ def test_streamed_read_matches_host_reader(ctx, tmp_path, monkeypatch):
         assert np.array_equal(f.read_dev(ctx, "count").cpu().numpy(), [3.0, -7.0, 2.0**31 - 1])           # integer type: host path
         monkeypatch.setenv("ECCKD_NO_STREAMED_READ", "1")                                               # the fallback gives the same
         assert np.array_equal(f.read_dev(ctx, "optical_depth", 1).cpu().numpy().view(np.uint32), od[1].view(np.uint32))
+
+
+def test_netcdf4_variable_to_device(ctx, tmp_path):
+    """A NetCDF-4 (HDF5) spectrum read straight to the device: the chunks are inflated by worker threads into the requested
+    type (FLOAT stays FLOAT) and uploaded once."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import h5_fixture as h5
+    from ecckd_amd import ncio
+    if not h5.available():
+        pytest.skip("no HDF5 shared library with the deflate filter in this environment")
+    rs = np.random.RandomState(2)
+    od = (rs.standard_normal((2, 9, 70_001)) * 5).astype(np.float32)
+    h5.write(tmp_path / "s.h5", {"optical_depth": (od, "f4", (1, 9, 8192), None)})
+    with ncio.NcFile(tmp_path / "s.h5") as f:
+        got = f.read_dev(ctx, "optical_depth", 1)
+        assert got.dtype == torch.float32 and np.array_equal(got.cpu().numpy().view(np.uint32), od[1].view(np.uint32))
+        assert np.array_equal(f.read_dev(ctx, "optical_depth", 0, dtype=torch.float64).cpu().numpy(), od[0].astype(np.float64))

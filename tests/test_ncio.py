@@ -355,3 +355,31 @@ def test_netcdf4_spectrum_is_read_through_hdf5(tmp_path, vlen):
     with pytest.raises(Exception):
         with ncio.NcFile(path) as f:
             f.read("no_such_variable")
+
+
+def test_netcdf4_chunks_are_inflated_in_parallel(tmp_path, monkeypatch):
+    """Chunked + shuffled + deflated FLOAT / DOUBLE variables are taken apart outside the HDF5 library (raw chunks pulled by the
+    caller, inflated / unshuffled / placed by worker threads, csrc/nc_hdf5.cpp::h5_read_real_parallel): chunk shapes that do not
+    divide the variable, chunks spanning several slices, DOUBLE storage, a 1-D variable - same values as the library's own
+    H5Dread path (ECCKD_NO_PARALLEL_INFLATE)."""
+    sys.path.insert(0, os.path.dirname(__file__))
+    import h5_fixture as h5
+    from ecckd_amd import ncio
+    if not h5.available():
+        pytest.skip("no HDF5 shared library with the deflate filter in this environment")
+    rs = np.random.RandomState(0)
+    od = (rs.standard_normal((3, 17, 50_003)) * 10).astype(np.float32)
+    od[1, 3, :7] = [0.0, -0.0, np.float32(1e-42), np.inf, -np.inf, 1.0, -1.0]
+    x64 = rs.standard_normal((4, 5, 3001))
+    path = tmp_path / "chunky.h5"
+    h5.write(path, {"optical_depth": (od, "f4", (2, 5, 4096), None), "x64": (x64, "f8", (1, 2, 777), None),
+                    "flat": (od[0, 0], "f4", (1000,), None)})
+    for no_parallel in (False, True):
+        if no_parallel:
+            monkeypatch.setenv("ECCKD_NO_PARALLEL_INFLATE", "1")
+        with ncio.NcFile(path) as f:
+            for k in range(3):
+                assert np.array_equal(f.read("optical_depth", k).view(np.uint64), od[k].astype(np.float64).view(np.uint64)), k
+            assert np.array_equal(f.read("optical_depth"), od.astype(np.float64))
+            assert np.array_equal(f.read("x64", 3), x64[3]) and np.array_equal(f.read("x64"), x64)
+            assert np.array_equal(f.read("flat"), od[0, 0].astype(np.float64))
