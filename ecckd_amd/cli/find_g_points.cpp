@@ -10,6 +10,15 @@
 // min_scaling, max_scaling, g_split + subband_wavenumber_boundary, base_split, base_wavenumber_boundary,
 // min_g_points, max_g_points.
 // All nwav-sized work runs on the GPU through include/ecckd_hip.h; this file is the driver around it.
+//
+// Several processes, one per GPU (RANK / WORLD_SIZE / LOCAL_RANK from the launcher, e.g. torchrun --no-python): the (gas, band)
+// searches are independent problems (:655, :1152); every process takes a contiguous share of the task table, reads and prepares
+// only the gases of which it searches a band, and leaves its per-band results (a few numbers per g point and the band's slice
+// of the - possibly re-ranked - rank) in "<output>.part<rank>"; rank 0 collects the parts, does what follows the gas loop
+// (:1452-1660) and prints the final cost (sum of the g points' errors).  The g-points file does not depend on WORLD_SIZE.
+#include <fstream>
+#include <thread>
+#include <unistd.h>
 #include <algorithm>
 #include <cctype>
 
@@ -28,6 +37,65 @@ struct GasResult {   // SingleGasData (single_gas_data.h:24-80)
   std::vector<int> g_min, g_max;      // per merged g point
   DevBuf d_g_point;                   // int32 [nwav]
 };
+
+// what one (gas, band) search hands back
+struct BandResult {
+  int gas = 0, band = 0, ng = 0, status = 0;
+  double comp_cost = 0.0;
+  int64_t ibegin = 0, iend = -1;
+  std::vector<int64_t> rank1, rank2;
+  std::vector<double> error, median;
+  std::vector<int32_t> rank_slice;     // rank of the wavenumbers ibegin..iend after the search (sub-band / base-split re-ranking)
+};
+
+template <class T> void put(std::ofstream& f, const T& v) { f.write(reinterpret_cast<const char*>(&v), sizeof v); }
+template <class T> void put_vec(std::ofstream& f, const std::vector<T>& v) {
+  const uint64_t n = v.size();
+  put(f, n);
+  if (n) f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(n * sizeof(T)));
+}
+template <class T> bool get(std::ifstream& f, T& v) { return (bool)f.read(reinterpret_cast<char*>(&v), sizeof v); }
+template <class T> bool get_vec(std::ifstream& f, std::vector<T>& v) {
+  uint64_t n = 0;
+  if (!get(f, n) || n > ((uint64_t)1 << 33)) return false;
+  v.resize((size_t)n);
+  return n == 0 || (bool)f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(n * sizeof(T)));
+}
+
+void write_part(const std::string& path, const std::vector<BandResult>& res) {
+  const std::string tmp = path + ".tmp";
+  {
+    std::ofstream f(tmp, std::ios::binary);
+    if (!f) fail(ECCKD_PROCESSING_ERROR, "Cannot write %s", tmp.c_str());
+    const uint64_t magic = 0x45434b4450415254ull, n = res.size();   // "ECKDPART"
+    put(f, magic); put(f, n);
+    for (const BandResult& r : res) {
+      put(f, r.gas); put(f, r.band); put(f, r.ng); put(f, r.status); put(f, r.comp_cost); put(f, r.ibegin); put(f, r.iend);
+      put_vec(f, r.rank1); put_vec(f, r.rank2); put_vec(f, r.error); put_vec(f, r.median); put_vec(f, r.rank_slice);
+    }
+    if (!f) fail(ECCKD_PROCESSING_ERROR, "Short write of %s", tmp.c_str());
+  }
+  if (std::rename(tmp.c_str(), path.c_str()) != 0) fail(ECCKD_PROCESSING_ERROR, "Cannot rename %s", tmp.c_str());   // complete or absent
+}
+
+std::vector<BandResult> read_part(const std::string& path, double timeout_s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  while (access(path.c_str(), R_OK) != 0) {
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+      fail(ECCKD_PROCESSING_ERROR, "Timed out waiting for %s (did the process of that rank fail?)", path.c_str());
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  }
+  std::ifstream f(path, std::ios::binary);
+  uint64_t magic = 0, n = 0;
+  if (!get(f, magic) || magic != 0x45434b4450415254ull || !get(f, n)) fail(ECCKD_PROCESSING_ERROR, "%s is not a find_g_points part file", path.c_str());
+  std::vector<BandResult> res((size_t)n);
+  for (BandResult& r : res) {
+    const bool ok = get(f, r.gas) && get(f, r.band) && get(f, r.ng) && get(f, r.status) && get(f, r.comp_cost) && get(f, r.ibegin) && get(f, r.iend) &&
+                    get_vec(f, r.rank1) && get_vec(f, r.rank2) && get_vec(f, r.error) && get_vec(f, r.median) && get_vec(f, r.rank_slice);
+    if (!ok) fail(ECCKD_PROCESSING_ERROR, "%s is truncated", path.c_str());
+  }
+  return res;
+}
 
 template <class T>
 std::vector<T> per_band(const Config& config, const std::string& gas, const char* key, int nband, T fill, bool* present = nullptr) {
@@ -79,14 +147,85 @@ int main(int argc, char** argv) {
     if (method < 0) fail(ECCKD_PARAMETER_ERROR, "Averaging method \"%s\" not understood", averaging_method.c_str());
 
     Device dev;
-    std::vector<GasResult> gases;
+    const int world = std::max(1, env_int("WORLD_SIZE", 1)), my_rank = env_int("RANK", 0);
+    if (my_rank < 0 || my_rank >= world) fail(ECCKD_PARAMETER_ERROR, "RANK=%d outside WORLD_SIZE=%d", my_rank, world);
+    const std::vector<std::string> gas_list = config.read_list("gases");
+    const int ngas = (int)gas_list.size();
+    if (ngas == 0) fail(ECCKD_PARAMETER_ERROR, "No gases specified in \"gases\"");
+    if (world > 1) {
+      LOG("Process %d of %d: the (gas, band) searches are dealt in contiguous shares\n", my_rank, world);
+      std::remove((output + ".part" + std::to_string(my_rank)).c_str());   // never a stale part of an earlier run
+    }
+    std::vector<BandResult> results;                     // the searches of this process
+    std::vector<std::vector<int32_t>> order_rank(ngas);  // process 0: the rank of every gas as its ordering file has it
     std::vector<double> band_bound1, band_bound2, wavenumber;
     int nband = 0;
     size_t nwav = 0;
     ecckd_gas* first_lw_gas = nullptr;
     const double* d_planck_first = nullptr;
+    DevBuf d_planck_rebuilt;
 
-    for (const std::string& gas_str : config.read_list("gases")) {
+    // the ordering file of a gas (:669-683) and the sub-bands of the optically thin part of `bands` (:788-870), which re-rank
+    // d_rank before anything is reordered
+    struct Ordering {
+      std::vector<int32_t> rank;
+      std::vector<int> iband;
+      std::vector<double> sorting_variable, subband_wavenumber_boundary, g_split;
+      std::vector<int64_t> ibegin, iend;   // first / last index of every band: the members of a band are contiguous in rank
+      bool have_g_split = false;
+      int nsb = 1;
+      std::vector<int> nsubband;
+      std::vector<int64_t> iupperindex, isubband1, isubband2;
+      DevBuf d_rank, d_wn;
+    };
+    auto read_ordering = [&](const std::string& gas_str, Ordering& o) {
+      const char* scope = gas_str.c_str();
+      std::string reordering_input;
+      if (!config.read(reordering_input, "reordering_input", scope)) fail(ECCKD_PARAMETER_ERROR, "No reordering_input found");
+      LOG("Reading %s\n", reordering_input.c_str());
+      {
+        NcIn f(paths.find(reordering_input));
+        std::vector<double> r = f.read("rank"), b = f.read("band_number");
+        o.rank.assign(r.begin(), r.end());
+        o.iband.assign(b.begin(), b.end());
+        band_bound1 = f.read("wavenumber1_band");
+        band_bound2 = f.read("wavenumber2_band");
+        o.sorting_variable = f.read("sorting_variable");
+        wavenumber = f.read("wavenumber");
+      }
+      nband = (int)band_bound1.size();
+      nwav = o.rank.size();
+      o.g_split = per_band<double>(config, gas_str, "g_split", nband, -1.0, &o.have_g_split);
+      if (o.have_g_split && !config.read(o.subband_wavenumber_boundary, "subband_wavenumber_boundary", scope))
+        fail(ECCKD_PARAMETER_ERROR, "g_split must be accompanied by subband_wavenumber_boundary");
+      o.ibegin.assign(nband, -1);
+      o.iend.assign(nband, -1);
+      for (size_t i = 0; i < nwav; ++i) {
+        const int b = o.iband[i];
+        if (b < 0 || b >= nband) continue;
+        if (o.ibegin[b] < 0) o.ibegin[b] = (int64_t)i;
+        o.iend[b] = (int64_t)i;
+      }
+      o.nsb = (int)o.subband_wavenumber_boundary.size() + 1;
+      o.nsubband.assign(nband, 0);
+      o.iupperindex.assign(nband, -1);
+      o.isubband1.assign((size_t)nband * o.nsb, -1);
+      o.isubband2.assign((size_t)nband * o.nsb, -1);
+    };
+    auto subband_setup = [&](Ordering& o, const std::vector<char>& bands) {
+      o.d_rank.upload(dev, o.rank);
+      o.d_wn.upload(dev, wavenumber);
+      if (!o.have_g_split) return;
+      for (int b = 0; b < nband; ++b)
+        if (bands[b] && o.g_split[b] > 0.0 && o.ibegin[b] >= 0)
+          ck(ecckd_subband_setup_dev(dev.ctx(), nwav, o.d_wn.as<double>(), o.d_rank.as<int32_t>(), o.ibegin[b], o.iend[b], o.g_split[b],
+                                     band_bound1[b], band_bound2[b], (int)o.subband_wavenumber_boundary.size(),
+                                     o.subband_wavenumber_boundary.data(), &o.nsubband[b], &o.isubband1[(size_t)b * o.nsb],
+                                     &o.isubband2[(size_t)b * o.nsb], &o.iupperindex[b]));
+    };
+
+    for (int gi = 0; gi < ngas; ++gi) {
+      const std::string& gas_str = gas_list[gi];
       std::string Gas = gas_str;
       std::transform(Gas.begin(), Gas.end(), Gas.begin(), ::toupper);
       LOG("*** FINDING G POINTS FOR %s\n", Gas.c_str());
@@ -98,35 +237,32 @@ int main(int argc, char** argv) {
       max_scaling = std::max(2.5, max_scaling);
 
       // ---- ordering (:669-683) ----
-      std::string reordering_input;
-      if (!config.read(reordering_input, "reordering_input", scope)) fail(ECCKD_PARAMETER_ERROR, "No reordering_input found");
-      LOG("Reading %s\n", reordering_input.c_str());
-      std::vector<int32_t> rank;
-      std::vector<int> iband;
-      std::vector<double> sorting_variable;
-      {
-        NcIn f(paths.find(reordering_input));
-        std::vector<double> r = f.read("rank"), b = f.read("band_number");
-        rank.assign(r.begin(), r.end());
-        iband.assign(b.begin(), b.end());
-        band_bound1 = f.read("wavenumber1_band");
-        band_bound2 = f.read("wavenumber2_band");
-        sorting_variable = f.read("sorting_variable");
-        wavenumber = f.read("wavenumber");
+      Ordering ord;
+      read_ordering(gas_str, ord);
+      if (my_rank == 0) order_rank[gi] = ord.rank;
+
+      // ---- the bands of this gas that fall to this process ----
+      int task_begin = 0, task_end = 0;
+      deal_tasks(ngas * nband, my_rank, world, task_begin, task_end);
+      std::vector<int> mine;
+      std::vector<char> is_mine(nband, 0);
+      for (int b = 0; b < nband; ++b)
+        if (gi * nband + b >= task_begin && gi * nband + b < task_end) {
+          mine.push_back(b);
+          is_mine[b] = 1;
+        }
+      if (mine.empty()) {
+        LOG("  (searched by other processes)\n\n");
+        continue;
       }
-      nband = (int)band_bound1.size();
-      nwav = rank.size();
+      const int nmine = (int)mine.size();
 
       // ---- band-specific configuration (:687-771) ----
-      std::vector<double> base_wavenumber_boundary, subband_wavenumber_boundary;
+      std::vector<double> base_wavenumber_boundary;
       config.read(base_wavenumber_boundary, "base_wavenumber_boundary", scope);
-      bool have_g_split = false;
-      std::vector<double> g_split = per_band<double>(config, gas_str, "g_split", nband, -1.0, &have_g_split);
-      if (have_g_split && !config.read(subband_wavenumber_boundary, "subband_wavenumber_boundary", scope))
-        fail(ECCKD_PARAMETER_ERROR, "g_split must be accompanied by subband_wavenumber_boundary");
       bool have_base_split = false;
       std::vector<double> base_split = per_band<double>(config, gas_str, "base_split", nband, 1.0, &have_base_split);
-      if (have_base_split && have_g_split) fail(ECCKD_PARAMETER_ERROR, "Cannot use both g_split and base_split");
+      if (have_base_split && ord.have_g_split) fail(ECCKD_PARAMETER_ERROR, "Cannot use both g_split and base_split");
       std::vector<int> min_g_points = per_band<int>(config, gas_str, "min_g_points", nband, 1);
       std::vector<int> max_g_points = per_band<int>(config, gas_str, "max_g_points", nband, 256);
       std::vector<double> band_albedo(nband, 0.0);
@@ -141,31 +277,14 @@ int main(int argc, char** argv) {
       else if (tolerance_in.size() == 1) tolerance.assign(nband, tolerance_in[0]);
       else fail(ECCKD_PARAMETER_ERROR, "heating_rate_tolerance must have either one element or one per band (%d)", nband);
 
-      // first / last sorted index of every band: the members of a band are contiguous in rank
-      std::vector<int64_t> ibegin(nband, -1), iend(nband, -1);
-      for (size_t i = 0; i < nwav; ++i) {
-        const int b = iband[i];
-        if (b < 0 || b >= nband) continue;
-        if (ibegin[b] < 0) ibegin[b] = (int64_t)i;
-        iend[b] = (int64_t)i;
-      }
-
-      DevBuf d_rank, d_wn, d_dwn;
-      d_rank.upload(dev, rank);
-      d_wn.upload(dev, wavenumber);
-
-      // ---- sub-bands of the optically thin part of a band (:788-870): re-ranks d_rank before anything is reordered ----
-      std::vector<int> nsubband(nband, 0);
-      std::vector<int64_t> iupperindex(nband, -1);
-      const int nsb = (int)subband_wavenumber_boundary.size() + 1;
-      std::vector<int64_t> isubband1((size_t)nband * nsb, -1), isubband2((size_t)nband * nsb, -1);
-      if (have_g_split)
-        for (int b = 0; b < nband; ++b)
-          if (g_split[b] > 0.0 && ibegin[b] >= 0)
-            ck(ecckd_subband_setup_dev(dev.ctx(), nwav, d_wn.as<double>(), d_rank.as<int32_t>(), ibegin[b], iend[b], g_split[b],
-                                       band_bound1[b], band_bound2[b], (int)subband_wavenumber_boundary.size(),
-                                       subband_wavenumber_boundary.data(), &nsubband[b], &isubband1[(size_t)b * nsb],
-                                       &isubband2[(size_t)b * nsb], &iupperindex[b]));
+      // ---- sub-bands (:788-870).  The first longwave gas lends its Planck matrix to the later ones, whichever process searches
+      // them: its ordering is prepared in every band, so that the matrix does not depend on how the tasks were dealt ----
+      subband_setup(ord, (gi == 0 && !do_sw) ? std::vector<char>(nband, 1) : is_mine);
+      DevBuf& d_rank = ord.d_rank;
+      DevBuf& d_wn = ord.d_wn;
+      DevBuf d_dwn;
+      const std::vector<int>& nsubband = ord.nsubband;
+      const int nsb = ord.nsb;
 
       // ---- background and target optical depths (:872-915) ----
       Merged bg;
@@ -189,12 +308,36 @@ int main(int argc, char** argv) {
       DevBuf d_ssi, d_albedo;
       if (!do_sw) {
         if (s.temperature_hl.empty()) fail(ECCKD_PARAMETER_ERROR, "temperature_hl missing from the spectrum of %s", gas_str.c_str());
+        if (gi > 0 && !d_planck_first) {
+          // The reference evaluates the Planck function once, on the FIRST gas's reordered grid (:529, :970-984).  This process
+          // does not search the first gas: the matrix is rebuilt from that gas's ordering file and temperatures, bit for bit.
+          const std::string first = gas_list[0];
+          std::vector<double> bb1 = band_bound1, bb2 = band_bound2, wn_now = wavenumber;
+          Ordering o0;
+          read_ordering(first, o0);
+          subband_setup(o0, std::vector<char>(nband, 1));
+          const std::vector<std::string> files0 = config.read_list(first + ".input");
+          if (files0.empty()) fail(ECCKD_PARAMETER_ERROR, "%s.input not found", first.c_str());
+          const Spectrum s0 = read_spectrum(paths.find(files0[0]), iprofile, false);
+          if (s0.nwav != nwav || s0.nlay != s.nlay || s0.temperature_hl.empty())
+            fail(ECCKD_PARAMETER_ERROR, "The spectrum of %s does not match that of %s", first.c_str(), gas_str.c_str());
+          DevBuf d_wn0, d_dwn0;
+          d_wn0.upload(dev, s0.wavenumber_cm_1);
+          d_dwn0.upload(dev, s0.d_wavenumber_cm_1);
+          d_planck_rebuilt.alloc(dev, (size_t)(s0.nlay + 1) * nwav * sizeof(double));
+          ck(ecckd_planck_hl_sorted_dev(dev.ctx(), s0.nlay, nwav, s0.temperature_hl.data(), d_wn0.as<double>(), d_dwn0.as<double>(),
+                                        o0.d_rank.as<int32_t>(), d_planck_rebuilt.as<double>()));
+          ck(ecckd_synchronize(dev.ctx()));
+          d_planck_first = d_planck_rebuilt.as<double>();
+          band_bound1 = bb1; band_bound2 = bb2; wavenumber = wn_now;
+          nband = (int)band_bound1.size();
+          nwav = ord.rank.size();
+        }
         ck(ecckd_gas_create_lw(dev.ctx(), s.nlay, nwav, s.pressure_hl.data(), s.temperature_hl.data(), d_wn.as<double>(),
                                d_dwn.as<double>(), d_rank.as<int32_t>(), have_bg ? bg.od_ptr() : nullptr, have_bg ? bg.od_type() : 0,
                                target.od_ptr(), target.od_type(), nwav, method, flux_weight, min_pressure, d_planck_first, &gas));
-        if (!first_lw_gas) {
-          // The reference evaluates the Planck function once, on the FIRST gas's reordered grid, and keeps using
-          // that matrix for the later gases (:529, :970-984).  Reproduced: the first gas stays alive and lends it.
+        if (gi == 0) {
+          // the first gas stays alive and lends its matrix
           first_lw_gas = gas;
           size_t rows = 0, cols = 0;
           ck(ecckd_gas_view(gas, "planck_hl", &d_planck_first, &rows, &cols));
@@ -215,35 +358,39 @@ int main(int argc, char** argv) {
 
       // sorting variable in sorted order (:781): sorted[r] = orig[ireorder[r]]
       DevBuf d_ireorder(dev, nwav * sizeof(int32_t)), d_sv, d_sv_sorted(dev, nwav * sizeof(double));
-      d_sv.upload(dev, sorting_variable);
+      d_sv.upload(dev, ord.sorting_variable);
       ck(ecckd_invert_permutation_dev(dev.ctx(), nwav, d_rank.as<int32_t>(), d_ireorder.as<int32_t>()));
       ck(ecckd_gather_f64_dev(dev.ctx(), nwav, d_sv.as<double>(), d_ireorder.as<int32_t>(), d_sv_sorted.as<double>()));
       ck(ecckd_synchronize(dev.ctx()));
 
       // ---- the bands (:1152-1414) ----
-      GasResult res;
-      res.molecule = gas_str;
       const int capacity = 1024;
       // Options of every band first: the bands are then searched side by side (ecckd_find_g_bands_ex); a shortwave band brings
       // its albedo (init_sw(..., band_albedo(jband), ...), :1177) with it.
-      std::vector<ecckd_band_options> opts(nband);
-      std::vector<std::vector<double>> wn_bounds(nband);
-      for (int b = 0; b < nband; ++b) {
-        if (ibegin[b] < 0) fail(ECCKD_PARAMETER_ERROR, "Band %d contains no wavenumbers", b);
-        ecckd_band_options& opt = opts[b];
+      std::vector<ecckd_band_options> opts(nmine);
+      std::vector<std::vector<double>> wn_bounds(nmine);
+      std::vector<size_t> ib(nmine), ie(nmine);
+      std::vector<double> tol(nmine);
+      for (int m = 0; m < nmine; ++m) {
+        const int b = mine[m];
+        if (ord.ibegin[b] < 0) fail(ECCKD_PARAMETER_ERROR, "Band %d contains no wavenumbers", b);
+        ib[m] = (size_t)ord.ibegin[b];
+        ie[m] = (size_t)ord.iend[b];
+        tol[m] = tolerance[b];
+        ecckd_band_options& opt = opts[m];
         std::memset(&opt, 0, sizeof opt);
         opt.min_g_points = min_g_points[b];
         opt.max_g_points = max_g_points[b];
         if (nsubband[b] > 1) {
           opt.nsubband = nsubband[b];
-          opt.isubband1 = &isubband1[(size_t)b * nsb];
-          opt.isubband2 = &isubband2[(size_t)b * nsb];
-          opt.iupperindex = iupperindex[b];
-          opt.g_split = g_split[b];
+          opt.isubband1 = &ord.isubband1[(size_t)b * nsb];
+          opt.isubband2 = &ord.isubband2[(size_t)b * nsb];
+          opt.iupperindex = ord.iupperindex[b];
+          opt.g_split = ord.g_split[b];
         }
         opt.base_split = base_split[b];
         opt.band_albedo = do_sw ? band_albedo[b] : 0.0;
-        std::vector<double>& wn_bound = wn_bounds[b];
+        std::vector<double>& wn_bound = wn_bounds[m];
         std::vector<double> interior;
         for (double w : base_wavenumber_boundary) if (w > band_bound1[b] && w < band_bound2[b]) interior.push_back(w);
         if (base_split[b] != 1.0 || !interior.empty()) {   // :1268-1301
@@ -257,53 +404,108 @@ int main(int argc, char** argv) {
           opt.nwav = nwav;
         }
       }
-      std::vector<int> ngs(nband, 0), statuses(nband, 0);
-      std::vector<double> comp_costs(nband, 0.0);
-      std::vector<double> bounds((size_t)nband * (capacity + 1)), error((size_t)nband * capacity);
-      std::vector<int64_t> r1((size_t)nband * capacity), r2((size_t)nband * capacity);
+      std::vector<int> ngs(nmine, 0), statuses(nmine, 0);
+      std::vector<double> comp_costs(nmine, 0.0);
+      std::vector<double> bounds((size_t)nmine * (capacity + 1)), error((size_t)nmine * capacity);
+      std::vector<int64_t> r1((size_t)nmine * capacity), r2((size_t)nmine * capacity);
       bool sequential_bands = false;                 // extension key: the reference's one-band-at-a-time order of evaluation
       config.read(sequential_bands, "sequential_bands");
-      const bool side_by_side = nband > 1 && !sequential_bands;
-      if (side_by_side) {
-        std::vector<size_t> ib(ibegin.begin(), ibegin.end()), ie(iend.begin(), iend.end());
-        ck(ecckd_find_g_bands_ex(gas, nband, ib.data(), ie.data(), tolerance.data(), tolerance_tolerance, max_iterations, opts.data(),
+      const bool side_by_side = nmine > 1 && !sequential_bands;
+      if (side_by_side)
+        ck(ecckd_find_g_bands_ex(gas, nmine, ib.data(), ie.data(), tol.data(), tolerance_tolerance, max_iterations, opts.data(),
                                  ngs.data(), bounds.data(), error.data(), r1.data(), r2.data(), capacity, statuses.data(), comp_costs.data()));
-      }
-      for (int b = 0; b < nband; ++b) {
+      for (int m = 0; m < nmine; ++m) {
+        const int b = mine[m];
         LOG("  Band %d: %g-%g cm-1\n", b, band_bound1[b], band_bound2[b]);
-        const size_t o = (size_t)b * capacity;
+        const size_t o = (size_t)m * capacity;
         if (!side_by_side) {
           if (do_sw) ck(ecckd_gas_set_band_albedo(gas, band_albedo[b]));
-          ck(ecckd_find_g_band_ex(gas, (size_t)ibegin[b], (size_t)iend[b], tolerance[b], tolerance_tolerance, max_iterations, &opts[b], &ngs[b],
-                                  &bounds[(size_t)b * (capacity + 1)], &error[o], &r1[o], &r2[o], capacity, &statuses[b], &comp_costs[b]));
+          ck(ecckd_find_g_band_ex(gas, ib[m], ie[m], tol[m], tolerance_tolerance, max_iterations, &opts[m], &ngs[m],
+                                  &bounds[(size_t)m * (capacity + 1)], &error[o], &r1[o], &r2[o], capacity, &statuses[m], &comp_costs[m]));
         }
-        const int ng = ngs[b];
-        LOG("    %s: %d g points, computational cost = %g\n", ecckd_partition_status_string(statuses[b]), ng, comp_costs[b]);
-        std::vector<double> med(ng);
-        ck(ecckd_gas_median_sorting_variable(gas, d_sv_sorted.as<double>(), ng, &r1[o], &r2[o], med.data()));
-        res.n_g_points.push_back(ng);
-        for (int k = 0; k < ng; ++k) {
-          res.band_number.push_back(b);
-          res.rank1.push_back(r1[o + k]);
-          res.rank2.push_back(r2[o + k]);
-          res.error.push_back(error[o + k]);
-          res.sorting_variable.push_back(med[k]);
+        const int ng = ngs[m];
+        LOG("    %s: %d g points, computational cost = %g\n", ecckd_partition_status_string(statuses[m]), ng, comp_costs[m]);
+        BandResult br;
+        br.gas = gi; br.band = b; br.ng = ng; br.status = statuses[m]; br.comp_cost = comp_costs[m];
+        br.ibegin = ord.ibegin[b]; br.iend = ord.iend[b];
+        br.median.resize(ng);
+        ck(ecckd_gas_median_sorting_variable(gas, d_sv_sorted.as<double>(), ng, &r1[o], &r2[o], br.median.data()));
+        br.rank1.assign(r1.begin() + o, r1.begin() + o + ng);
+        br.rank2.assign(r2.begin() + o, r2.begin() + o + ng);
+        br.error.assign(error.begin() + o, error.begin() + o + ng);
+        for (int k = 0; k < ng; ++k)
           LOG("    g point %d: ranks %lld-%lld, error %g K d-1\n", k, (long long)r1[o + k], (long long)r2[o + k], error[o + k]);
-        }
+        results.push_back(std::move(br));
+      }
+      // the ranks of these bands as the searches left them (sub-bands and base splits re-rank inside a band)
+      ck(ecckd_synchronize(dev.ctx()));
+      for (size_t k = results.size() - (size_t)nmine; k < results.size(); ++k) {
+        BandResult& br = results[k];
+        br.rank_slice.resize((size_t)(br.iend - br.ibegin + 1));
+        ck(ecckd_d2h(dev.ctx(), br.rank_slice.data(), d_rank.as<int32_t>() + br.ibegin, br.rank_slice.size() * sizeof(int32_t)));
       }
       if (gas != first_lw_gas) ck(ecckd_gas_destroy(gas));
-      // SingleGasData::store_g_points (single_gas_data.h:56-62) with the (possibly re-ranked) ranks
-      const int ngp = (int)res.rank1.size();
-      std::vector<int32_t> gr1(res.rank1.begin(), res.rank1.end()), gr2(res.rank2.begin(), res.rank2.end());
-      res.d_g_point.alloc(dev, nwav * sizeof(int32_t));
-      ck(ecckd_gas_g_point_dev(dev.ctx(), nwav, d_rank.as<int32_t>(), ngp, gr1.data(), gr2.data(), res.d_g_point.as<int32_t>()));
-      ck(ecckd_synchronize(dev.ctx()));
-      gases.push_back(std::move(res));
       LOG("\n");
     }
     if (first_lw_gas) ck(ecckd_gas_destroy(first_lw_gas));
-    const int ngas = (int)gases.size();
-    if (ngas == 0) fail(ECCKD_PARAMETER_ERROR, "No gases specified in \"gases\"");
+    d_planck_rebuilt.release();
+
+    // ---- several processes: the others leave their searches for process 0 ----
+    double my_cost = 0.0;
+    for (const BandResult& r : results) for (double e : r.error) my_cost += e;
+    if (world > 1) LOG("Process %d: %zu searches, sum of the g points' errors %.17g K d-1\n", my_rank, results.size(), my_cost);
+    if (my_rank != 0) {
+      write_part(output + ".part" + std::to_string(my_rank), results);
+      return 0;
+    }
+    double part_timeout = 3600.0;                      // extension key: how long process 0 waits for the others, in seconds
+    config.read(part_timeout, "part_timeout");
+    for (int r = 1; r < world; ++r) {
+      const std::string path = output + ".part" + std::to_string(r);
+      std::vector<BandResult> part = read_part(path, part_timeout);
+      for (BandResult& br : part) results.push_back(std::move(br));
+      std::remove(path.c_str());
+    }
+    std::vector<const BandResult*> by_task((size_t)ngas * nband, nullptr);
+    for (const BandResult& br : results) {
+      if (br.gas < 0 || br.gas >= ngas || br.band < 0 || br.band >= nband || by_task[(size_t)br.gas * nband + br.band])
+        fail(ECCKD_PROCESSING_ERROR, "Search of gas %d, band %d reported twice or out of range", br.gas, br.band);
+      by_task[(size_t)br.gas * nband + br.band] = &br;
+    }
+    double final_cost = 0.0;
+    std::vector<GasResult> gases(ngas);
+    for (int gi = 0; gi < ngas; ++gi) {
+      GasResult& res = gases[gi];
+      res.molecule = gas_list[gi];
+      std::vector<int32_t>& rank = order_rank[gi];
+      for (int b = 0; b < nband; ++b) {
+        const BandResult* br = by_task[(size_t)gi * nband + b];
+        if (!br) fail(ECCKD_PROCESSING_ERROR, "No process searched band %d of %s", b, gas_list[gi].c_str());
+        if (br->ibegin < 0 || br->iend >= (int64_t)nwav || (int64_t)br->rank_slice.size() != br->iend - br->ibegin + 1)
+          fail(ECCKD_PROCESSING_ERROR, "Rank slice of band %d of %s does not fit", b, gas_list[gi].c_str());
+        std::copy(br->rank_slice.begin(), br->rank_slice.end(), rank.begin() + br->ibegin);
+        res.n_g_points.push_back(br->ng);
+        for (int k = 0; k < br->ng; ++k) {
+          res.band_number.push_back(b);
+          res.rank1.push_back(br->rank1[k]);
+          res.rank2.push_back(br->rank2[k]);
+          res.error.push_back(br->error[k]);
+          res.sorting_variable.push_back(br->median[k]);
+          final_cost += br->error[k];
+        }
+      }
+      // SingleGasData::store_g_points (single_gas_data.h:56-62) with the (possibly re-ranked) ranks
+      const int ngp = (int)res.rank1.size();
+      std::vector<int32_t> gr1(res.rank1.begin(), res.rank1.end()), gr2(res.rank2.begin(), res.rank2.end());
+      DevBuf d_rank;
+      d_rank.upload(dev, rank);
+      res.d_g_point.alloc(dev, nwav * sizeof(int32_t));
+      ck(ecckd_gas_g_point_dev(dev.ctx(), nwav, d_rank.as<int32_t>(), ngp, gr1.data(), gr2.data(), res.d_g_point.as<int32_t>()));
+      ck(ecckd_synchronize(dev.ctx()));
+      std::vector<int32_t>().swap(rank);
+    }
+    results.clear();
+    if (world > 1) LOG("Final cost (sum of the g points' errors over all processes): %.17g K d-1\n", final_cost);
 
     // ---- spectral overlap of the gases (:1452-1483) ----
     LOG("*** COMPUTING SPECTRAL OVERLAP OF GASES\n");

@@ -4,6 +4,7 @@
 // NetCDF files in and out, exit code 0 or one of src/include/EsaExitCodes.h.  Everything here sits ABOVE the
 // C ABI of include/ecckd_hip.h - the tools never touch HIP themselves.
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -356,8 +357,10 @@ inline Spectrum read_spectrum(const std::string& path, int iprofile, bool want_o
 class Device {
  public:
   Device() {
+    // one process per GPU: ECCKD_DEVICE, else the LOCAL_RANK a launcher (torchrun --no-python, mpirun wrappers) hands out
     int dev = 0;
     if (const char* e = std::getenv("ECCKD_DEVICE")) dev = std::atoi(e);
+    else if (const char* l = std::getenv("LOCAL_RANK")) dev = std::atoi(l);
     ck(ecckd_init(dev, &ctx_));
   }
   ~Device() { if (ctx_) ecckd_destroy(ctx_); }
@@ -518,6 +521,19 @@ inline Merged read_merged_spectrum(const Device& dev, const Config& config, cons
     if (ibg == 0) m.first = std::move(s);
   }
   return m;
+}
+
+// ---- several processes (one per GPU): RANK / WORLD_SIZE of the launcher; contiguous shares of a task table ----
+inline int env_int(const char* name, int fallback) {
+  const char* e = std::getenv(name);
+  return e && *e ? std::atoi(e) : fallback;
+}
+// tasks [begin, end) of `rank` when `ntasks` are cut into `world` contiguous shares whose sizes differ by at most one
+// (ecckd_amd/shard.py::deal_tasks)
+inline void deal_tasks(int ntasks, int rank, int world, int& begin, int& end) {
+  const int base = ntasks / world, extra = ntasks % world;
+  begin = rank * base + std::min(rank, extra);
+  end = begin + base + (rank < extra ? 1 : 0);
 }
 
 // ---- main wrapper: exit codes like THROW(code) (Logging.h:115-117) ----

@@ -133,6 +133,52 @@ def test_reorder_and_find_g_points_lw(ctx, tmp_path):
     fa.close(); fs.close(); fg.close()
 
 
+def _run_ranks(world, *args, cwd=None):
+    """`world` find_g_points processes as a launcher (torchrun --no-python, one per GPU) would start them; here they share GPU 0."""
+    exe = os.path.join(BIN, "find_g_points")
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), ECCKD_DEVICE="0")
+        procs.append(subprocess.Popen([exe, *[str(a) for a in args]], cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err + out
+    return [o for o, _ in outs]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_find_g_points_several_processes(ctx, tmp_path, world):
+    """The (gas, band) searches dealt to `world` processes: the g-points file is the one a single process writes, whatever the
+    share of each - including the process that searches only the second gas and rebuilds the first gas's Planck matrix (with
+    that gas's sub-band re-ranking), and the bands whose rank the search changed (g_split; only in the second band: the first band's
+    lower bound, a FLOAT in the ordering file, lies above the first wavenumber of this grid, which ends the reference's sub-band
+    set-up - and this one - with "Failed to account for all wavenumbers in split")."""
+    d = tmp_path
+    _make_lw_files(d)
+    os.symlink(d / "h2o.nc", d / "co2_bg_is_h2o.nc")
+    for g in ("h2o", "co2"):
+        r = run_tool("reorder_spectrum", f"input={d}/{g}.nc", f"output={d}/order_{g}.nc", "wavenumber1=0 1300", "wavenumber2=1300 3260")
+        assert r.returncode == 0, r.stderr
+    cfg = LW_CFG.format(d=d).replace("  background_input \"co2.nc\"\n",
+                                     "  background_input \"co2.nc\"\n  g_split 0 0.7\n  subband_wavenumber_boundary 2000 2600\n")
+    assert "g_split" in cfg
+    (d / "find_g.cfg").write_text(cfg)
+    r = run_tool("find_g_points", d / "find_g.cfg", f"output={d}/one.nc", cwd="/")
+    assert r.returncode == 0, r.stderr + r.stdout
+    outs = _run_ranks(world, d / "find_g.cfg", f"output={d}/many.nc", "part_timeout=300", cwd="/")
+    _same_files(d / "one.nc", d / "many.nc")
+    assert not [f for f in os.listdir(d) if ".part" in f]                   # the parts are collected and removed
+    assert "Final cost" in outs[0] and "COMPUTING SPECTRAL OVERLAP" in outs[0]
+    assert all("COMPUTING SPECTRAL OVERLAP" not in o for o in outs[1:])
+    f = _nc(d / "one.nc")
+    total = float(np.sum(f.variables["h2o_error"][:].astype(np.float64)) + np.sum(f.variables["co2_error"][:].astype(np.float64)))
+    f.close()
+    final = float(outs[0].split("Final cost")[1].split(":")[1].split()[0])
+    assert final == pytest.approx(total, rel=1e-6)                           # the file holds FLOAT errors
+    if world == 3:
+        assert "(searched by other processes)" in outs[1]                    # process 1 searches co2 only
+
+
 def test_find_g_points_sw(ctx, tmp_path):
     from ecckd_amd import pipeline
     d = tmp_path
