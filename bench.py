@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nwav", type=int, default=7_200_000)
+    ap.add_argument("--nwav", type=int, default=None)           # 7.2e6 (longwave); 3.3e6 for --config 2 (shortwave)
     ap.add_argument("--nlay", type=int, default=54)
     ap.add_argument("--tolerance", type=float, default=0.0161)   # fsck, test/do_all_lw.sh:59-60
     ap.add_argument("--tolerance-tolerance", type=float, default=0.01)  # test/find_g_points_lw.sh
@@ -56,14 +56,18 @@ def parse():
     # all-reduce of [gradient, cost] per evaluation).  Off by default so that the driver's scaling runs time the
     # headline metric only.
     ap.add_argument("--lut-dist", action="store_true")
-    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4])
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4])
     # synthetic spectra: "lines" = CKDMIP-like line list (>= 1e4 lines in vibration-rotation bands, synthetic.optical_depth_lines);
     # "legacy" = the 32 isolated Lorentz lines of round 1
     ap.add_argument("--spectra", default="lines", choices=["lines", "legacy"])
     ap.add_argument("--nlines", type=int, default=12000)
     ap.add_argument("--ngas", type=int, default=8)                       # config 3
     ap.add_argument("--narrow-tolerance", type=float, default=0.013)     # narrow bands, test/do_all_lw.sh:46-60
-    return ap.parse_args()
+    ap.add_argument("--sw-tolerance", type=float, default=0.05)          # config 2 (test/do_all_sw.sh: heating_rate_tolerance per model)
+    args = ap.parse_args()
+    if args.nwav is None:
+        args.nwav = 3_300_000 if args.config == 2 else 7_200_000
+    return args
 
 
 def make_inputs(xp, nwav, nlay, seed, device=None, spectra="lines", nlines=12000, column_scale=30.0):
@@ -229,6 +233,64 @@ def config3_bench(args, ctx, dist, rank, world):
     return step, out, dict(ngas=ngas, nband=nband, tasks=len(tasks), tasks_this_rank=len(mine), gases_this_rank=len(my_gases))
 
 
+SW_GAS_NAMES = ["h2o", "o3", "co2"]
+SW_COLUMN_SCALE = [5.0, 1.5, 3.0]
+
+
+def config2_bench(args, ctx, dist, rank, world):
+    """BASELINE configs[2]: one SHORTWAVE find_g_points job, 32 bands (equal width in log wavenumber over 250-50000 cm-1) x
+    H2O + O3 + CO2 at nwav = 3.3e6, total-transmission averaging with the tool's scaling clamps (find_g_points.cpp:666-667),
+    reference albedo 0.15 in the bands below 10 000 cm-1 (:756-760, :921-923), cos_sza 0.5; the 96 (gas, band) searches dealt
+    to the ranks as in configs[3].  One step = reorder (K2 key + K3 per-band sort) + gas preparation + the side-by-side
+    searches of every gas this rank has a band of, then gather / overlap / merged map on rank 0."""
+    import torch
+    from ecckd_amd import api, pipeline, shard, synthetic as syn
+    dev = ctx.device
+    nwav, nlay, nband, lo, hi = args.nwav, args.nlay, 32, 250.0, 50000.0
+    names = SW_GAS_NAMES
+    ngas = len(names)
+    p = syn.pressure_grid(nlay)
+    wn_h, dwn_h = syn.wavenumber_grid(nwav, lo, hi)
+    wn, dwn = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
+    edges = np.geomspace(lo, hi, nband + 1)
+    b1, b2 = edges[:-1], edges[1:].copy()
+    b2[-1] = hi + 1.0
+    _, begin, end = api.band_ranges(wn_h, b1, b2)
+    band_albedo = np.where(b2 <= 10000.0, 0.15, 0.0)
+    sw = dict(ssi=torch.as_tensor(syn.solar_spectral_irradiance(wn_h, dwn_h), device=dev), cos_sza=0.5, band_albedo=band_albedo,
+              albedo=torch.as_tensor(np.where(wn_h < b2[band_albedo > 0].max(), 0.15, 0.0), device=dev))
+    tasks = shard.task_table(range(ngas), nband)
+    mine = [tasks[t] for t in shard.deal_tasks(len(tasks), rank, world)]
+    my_gases = sorted({g for g, _ in mine})
+    spectra = {}
+    for gi in my_gases:
+        od = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 501 + 17 * gi, nlines=args.nlines, column_scale=SW_COLUMN_SCALE[gi],
+                                     device=dev, lo=lo, hi=hi)
+        bg = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 1501 + 17 * gi, nlines=max(args.nlines // 3, 1), column_scale=0.5,
+                                     zero_fraction=0.0, nclusters=5, device=dev, lo=lo, hi=hi)
+        spectra[gi] = (od, bg)
+    rank0 = torch.zeros(nwav, dtype=torch.int32, device=dev)       # a process without tasks only asks for the number of points
+
+    def load_gas(gi):
+        od, bg = spectra[gi]
+        key, _ = api.reorder_key_sw(ctx, p, od, 0.25)            # the gas's reorder_spectrum step: part of the timed work
+        rnk, _ = api.stable_argsort_bands(ctx, key, begin, end, want_ordered=False)
+        return dict(pressure_hl=p, temperature_hl=None, wn=wn, dwn=dwn, rank=rnk, od=od, bg=bg, sorting_variable=key,
+                    band_begin=begin, band_end=end, min_g_points=np.ones(nband, dtype=int), max_g_points=np.full(nband, 256),
+                    min_scaling=0.5, max_scaling=2.5)
+
+    out = {}
+
+    def step():
+        res = pipeline.find_g_points_resident(ctx, names, load_gas, nband, args.sw_tolerance, (lambda: dict(rank=rank0)),
+                                              "total-transmission", 0.02, 0.0, 0.02, args.max_iterations,
+                                              rank=rank, world_size=world, sw=sw)
+        out.update(res)
+        return res["points"]
+
+    return step, out, dict(ngas=ngas, nband=nband, tasks=len(tasks), tasks_this_rank=len(mine), gases_this_rank=len(my_gases))
+
+
 def ckd_model_sw(model, seed=0):
     """Shortwave variant of synthetic.ckd_model: solar irradiance and Rayleigh scattering per g point, no Planck table."""
     m = dict(model, gases=[dict(g) for g in model["gases"]])
@@ -318,11 +380,11 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
     nwav, nlay = args.nwav, args.nlay
     info = {}
     extra = {}
-    if args.config == 3:
-        step3, info, extra = config3_bench(args, ctx, dist, rank, world)
+    if args.config in (2, 3):
+        step3, info, extra = (config3_bench if args.config == 3 else config2_bench)(args, ctx, dist, rank, world)
         od = None
         def step():
-            return step3() / nwav             # passes over a 7.2e6-point spectrum done by this rank
+            return step3() / nwav             # passes over the nwav-point spectrum done by this rank
     else:
         # each rank owns a different synthetic gas: independent (gas, band) shards, SURVEY.md 8e
         p, wn_h, dwn_h, od, bg = make_inputs(torch, nwav, nlay, syn.SEED_BASE + 1 + 17 * rank, device=dev, spectra=args.spectra,
@@ -440,7 +502,7 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
             with open(tpath) as f:
                 traffic = json.load(f)["corrected_bytes_per_point"] * rt_pts / rt_calls
         out = {
-            "metric": "wavenumber-points/s (LW reorder+find_g)",
+            "metric": "wavenumber-points/s (LW reorder+find_g)" if args.config != 2 else "wavenumber-points/s (SW reorder+find_g)",
             "value": points / dt,
             "unit": "wavenumber-points/s",
             "n_gpus": world,
@@ -461,12 +523,17 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                         "interval_requests_answered_from_memo": info.get("eval_stats", {}).get("memo_hits"),
                         "search_status": info.get("status"), "final_cost_sum_K_per_day": total_cost}
                        if args.config == 1 else
-                       {"workload": "configs[3]: ONE find_g_points job, 13 narrow LW bands (test/config.h:141-142) x %d gases "
-                                    "(%s), nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging transmission; the %d "
-                                    "(gas, band) searches dealt to the ranks in contiguous shares, results gathered on "
-                                    "rank 0 (overlap of the gases' g points, merged g-point map)"
-                                    % (extra["ngas"], " ".join(GAS_NAMES[:extra["ngas"]]), nwav, nlay, args.narrow_tolerance,
-                                       extra["tasks"]),
+                       {"workload": ("configs[3]: ONE find_g_points job, 13 narrow LW bands (test/config.h:141-142) x %d gases "
+                                     "(%s), nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging transmission; the %d "
+                                     "(gas, band) searches dealt to the ranks in contiguous shares, results gathered on "
+                                     "rank 0 (overlap of the gases' g points, merged g-point map)"
+                                     % (extra["ngas"], " ".join(GAS_NAMES[:extra["ngas"]]), nwav, nlay, args.narrow_tolerance,
+                                        extra["tasks"])) if args.config == 3 else
+                                    ("configs[2]: ONE shortwave find_g_points job, 32 bands (log-spaced, 250-50000 cm-1) x %d gases "
+                                     "(%s), nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging total-transmission, albedo 0.15 "
+                                     "below 10000 cm-1; the %d (gas, band) searches dealt to the ranks in contiguous shares, "
+                                     "results gathered on rank 0" % (extra["ngas"], " ".join(SW_GAS_NAMES), nwav, nlay,
+                                                                     args.sw_tolerance, extra["tasks"])),
                         "passes_over_the_spectrum_per_step": passes / args.steps, "ng_merged": info.get("ng"),
                         "ng_per_gas": [int(sum(g["n_g_points"])) for g in info.get("gases", [])],
                         "searches_not_converged": int(sum(st != 0 for g in info.get("gases", []) for st in g["status"])),
@@ -494,6 +561,11 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                                               "frac_of_fp64_issue_roof": (K1_VALU_PER_POINT * (k1_pts / max(k1_calls, 1)) / 64.0 * 4.0
                                                                           / (256 * 4 * 2.4e9) * 1e3) / max(k1_ms / max(k1_calls, 1), 1e-12)}},
         }
+        if args.config == 2:
+            # the shortwave sweep (k_rt_sw_bb) has no event slot in the library; its roofline figures
+            # are the rocprofv3 ones in profiles/ (fp64-VALU-bound, traffic = algorithmic bytes)
+            out["roofline"] = {"bound": "hbm", "kernel": "k_rt_sw (not instrumented in this leg; see profiles/r01_pmc_k_rt_sw_bb_fast.md)",
+                               "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         if h2d_ms is not None:
             step_ms = dt * 1e3 / args.steps
             out["pcie_inclusive"] = {"h2d_ms_per_step": h2d_ms, "bytes_per_step": 2 * nlay * nwav * 4,

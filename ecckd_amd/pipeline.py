@@ -518,11 +518,13 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
 
 def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, first_gas_order=None, averaging_method="transmission",
                            flux_weight=0.02, min_pressure=0.0, tolerance_tolerance=0.02, max_iterations=60,
-                           sequential_bands=False, rank=None, world_size=None, group=None, merged_map=True):
+                           sequential_bands=False, rank=None, world_size=None, group=None, merged_map=True, sw=None):
     """find_g_points on spectra that are already resident in HBM (bench.py, the full-size tests): the same dealing of the
     (gas, band) tasks, the same per-gas work (_search_gas) and the same collection as find_g_points, with `load_gas(gi)`
     handing over the device tensors of gas gi (the dict _search_gas takes; the call may do the gas's reorder_spectrum step,
-    K1 + K3, itself) instead of reading files.  Longwave only.
+    K1 + K3, itself) instead of reading files.  Longwave unless `sw` is given: dict(ssi, albedo: device tensors,
+    band_albedo[nband], cos_sza) as _search_gas takes it (no shared Planck matrix then; first_gas_order is only asked for the
+    number of wavenumbers by a process without tasks).
 
     first_gas_order: callable -> dict(temperature_hl, wn, dwn, rank) of the FIRST gas for a process that searches none of
     its bands (what the file driver reads from the first gas's ordering file), for the shared Planck matrix.
@@ -550,7 +552,9 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
         phase["reorder"] += time.perf_counter() - tl
         nwav = g["rank"].numel()
         reuse = None
-        if gi > 0 and first_lw_gas is not None:
+        if sw is not None:
+            pass
+        elif gi > 0 and first_lw_gas is not None:
             reuse = first_lw_gas.view_ptr("planck_hl")[0]
         elif gi > 0:
             if planck_first is None:
@@ -558,7 +562,7 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
                 planck_first = api.planck_hl_sorted(ctx, o0["temperature_hl"], o0["wn"], o0["dwn"], o0["rank"])
             reuse = planck_first.data_ptr()
         gas, res = _search_gas(ctx, g, my_bands[gi], tol, tolerance_tolerance, max_iterations, averaging_method, flux_weight,
-                               min_pressure, sequential_bands, reuse, None)
+                               min_pressure, sequential_bands, reuse, sw)
         for b, r in res:
             r["index_range"] = (int(g["band_begin"][b]), int(g["band_end"][b]))
             points += g["band_end"][b] - g["band_begin"][b] + 1            # the reorder / preparation pass over the band
@@ -574,7 +578,7 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
                 sl = slice(int(g["band_begin"][b]), int(g["band_end"][b]) + 1)      # a band's members are contiguous in wavenumber
                 gp[sl] = api.gas_g_point(ctx, g["rank"][sl].contiguous(), r["rank1"], r["rank2"])
             maps[gi] = gp
-        if gi == 0:
+        if gi == 0 and sw is None:
             first_lw_gas = gas
         else:
             gas.close()

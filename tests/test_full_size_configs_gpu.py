@@ -1,4 +1,4 @@
-"""BASELINE configs[3] and configs[4] at full size (the oracle cannot run them whole in seconds; it replays windows).
+"""BASELINE configs[2], configs[3] and configs[4] at full size (the oracle cannot run them whole in seconds; it replays windows).
 
 configs[3]: one find_g_points job over the 13 narrow longwave bands at nwav = 7.2e6, nlay = 54 (three gases here, eight in
 bench.py --config 3), through the resident-data driver that bench.py and the sharded runs use.  Checked: (a) oracle replay
@@ -6,6 +6,10 @@ of the interval errors of one narrow band deep inside the spectrum, from the dev
 wavenumber is assigned to exactly one merged g point, the per-gas maps are those of the g points' rank ranges;
 (c) searching the bands one at a time (the reference's order of evaluation) ends at the same g points as side by side;
 (d) the shares of a two-process deal, run one after the other here, give the same per-band results as the whole job.
+
+configs[2]: one shortwave find_g_points job over 32 bands (equal width in log wavenumber, 250-50000 cm-1) at nwav = 3.3e6,
+nlay = 54, three gases, total-transmission averaging, the reference albedo below 10 000 cm-1: the same driver and the same
+checks (a)-(d), the oracle being the shortwave evaluator (oracle CkdEquipartitionSW) with the band's albedo.
 
 configs[4]: the LW and the SW optimize_lut problems at nx ~ 3e5, 8 scenarios x 50 profiles (x 3 zenith angles): cost at
 the initial state against the CPU oracle (oracle_ckd.c), gradient against central differences of the device cost, and the
@@ -127,6 +131,123 @@ def test_config3_thirteen_bands_full_size(ctx, oracle):
             firsts = np.concatenate([[0], np.cumsum(ref_g["n_g_points"])])
             for b, rr in out:
                 assert rr["rank1"] == ref_g["rank1"][firsts[b]:firsts[b + 1]] and rr["error"] == ref_g["error"][firsts[b]:firsts[b + 1]]
+
+
+def test_config2_thirty_two_sw_bands_full_size(ctx, oracle):
+    from ecckd_amd import api, pipeline, shard
+    nwav, nlay, nband, names = 3_300_000, 54, 32, ["h2o", "o3", "co2"]
+    lo, hi, mu0, method = 250.0, 50000.0, 0.5, "total-transmission"
+    scales = [5.0, 1.5, 3.0]
+    dev = ctx.device
+    p = syn.pressure_grid(nlay)
+    wn_h, dwn_h = syn.wavenumber_grid(nwav, lo, hi)
+    wn, dwn = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
+    edges = np.geomspace(lo, hi, nband + 1)
+    b1, b2 = edges[:-1], edges[1:].copy()
+    b2[-1] = hi + 1.0
+    _, begin, end = api.band_ranges(wn_h, b1, b2)
+    band_albedo = np.where(b2 <= 10000.0, 0.15, 0.0)                                              # find_g_points.cpp:756-760
+    ssi_h = syn.solar_spectral_irradiance(wn_h, dwn_h)
+    sw = dict(ssi=torch.as_tensor(ssi_h, device=dev), cos_sza=mu0, band_albedo=band_albedo,
+              albedo=torch.as_tensor(np.where(wn_h < b2[band_albedo > 0].max(), 0.15, 0.0), device=dev))   # :921-923
+    spectra, orders = {}, {}
+    for gi in range(len(names)):
+        od = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 501 + 17 * gi, column_scale=scales[gi], device=dev, lo=lo, hi=hi)
+        bg = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 1501 + 17 * gi, nlines=4000, column_scale=0.5, zero_fraction=0.0,
+                                     nclusters=5, device=dev, lo=lo, hi=hi)
+        spectra[gi] = (od, bg)
+
+    def load_gas(gi):
+        od, bg = spectra[gi]
+        if gi not in orders:
+            key, _ = api.reorder_key_sw(ctx, p, od, 0.25)
+            rnk, _ = api.stable_argsort_bands(ctx, key, begin, end, want_ordered=False)
+            orders[gi] = (key, rnk)
+        key, rnk = orders[gi]
+        return dict(pressure_hl=p, temperature_hl=None, wn=wn, dwn=dwn, rank=rnk, od=od, bg=bg, sorting_variable=key,
+                    band_begin=begin, band_end=end, min_g_points=np.ones(nband, dtype=int), max_g_points=np.full(nband, 256),
+                    min_scaling=0.5, max_scaling=2.5)                                            # after the clamps of :666-667
+
+    first_order = lambda: dict(rank=load_gas(0)["rank"])
+    tol = 0.05
+    kw = dict(averaging_method=method, flux_weight=0.02, min_pressure=0.0, tolerance_tolerance=0.02, max_iterations=60, sw=sw)
+    res = pipeline.find_g_points_resident(ctx, names, load_gas, nband, tol, first_order, **kw)
+    assert res["n_unassigned"] == 0 and res["ng"] >= nband
+    gp = res["g_point"].cpu().numpy()
+    assert gp.min() == 0 and gp.max() == res["ng"] - 1 and np.unique(gp).size == res["ng"]
+    for ig in (0, res["ng"] // 2, res["ng"] - 1):
+        b = res["band_number"][ig]
+        idx = np.nonzero(gp == ig)[0]
+        assert idx.min() >= begin[b] and idx.max() <= end[b]
+    # solar irradiance of every merged g point (:1620-1633): all of it is accounted for, no g point without sunlight
+    solar = np.bincount(gp, weights=ssi_h, minlength=res["ng"])
+    assert solar.min() > 0.0 and solar.sum() == pytest.approx(ssi_h.sum(), rel=1e-12)
+    for gi, g in enumerate(res["gases"]):
+        assert len(g["n_g_points"]) == nband and all(n >= 1 for n in g["n_g_points"])
+        rnk = orders[gi][1].cpu().numpy()
+        ggp = res["gas_g_point"][gi].cpu().numpy()
+        k = len(g["rank1"]) // 2
+        assert np.array_equal(np.nonzero(ggp == k)[0], np.nonzero((rnk >= g["rank1"][k]) & (rnk <= g["rank2"][k]))[0])
+        e = np.array(g["error"])
+        assert np.all(np.isfinite(e)) and np.all(e >= 0)
+    assert res["cost_sum"] == pytest.approx(sum(sum(g["error"]) for g in res["gases"]), rel=1e-13)
+
+    # (a) oracle replay of two bands of the first gas - one below 10 000 cm-1 (albedo 0.15), one above (direct beam only) -
+    # from the device's own prepared rows
+    od, bg = spectra[0]
+    key, rnk = orders[0]
+    gas = api.GasSW(ctx, p, sw["ssi"], rnk, od, bg, method, 0.02, 0.0, mu0, sw["albedo"], 0.5, 2.5)
+    view = lambda name: torch.as_tensor(_DevView(*gas.view_ptr(name)), device=dev)
+    ireorder = api.invert_permutation(ctx, rnk).long()
+    g0 = res["gases"][0]
+    firsts = np.concatenate([[0], np.cumsum(g0["n_g_points"])])
+    # the two most finely divided bands, one on either side of the albedo limit, that the oracle still walks in seconds
+    width = np.asarray(end) - np.asarray(begin) + 1
+    pick_band = lambda mask: int(max((b for b in range(nband) if mask[b] and width[b] <= 130_000), key=lambda b: g0["n_g_points"][b]))
+    for band in (pick_band(band_albedo > 0), pick_band(band_albedo == 0)):
+        i0, i1 = int(begin[band]), int(end[band])
+        n = i1 - i0 + 1
+        sl = slice(i0, i1 + 1)
+        od_s = od[:, ireorder[sl]].double().cpu().numpy()
+        fx = view("flux_extras")[:, sl].cpu().numpy()
+        extras = dict(min_scaling=0.5, max_scaling=2.5, hr_low=view("hr_low")[:, sl].cpu().numpy(), hr_high=view("hr_high")[:, sl].cpu().numpy(),
+                      flux_dn_surf_low=fx[0], flux_up_toa_low=fx[1], flux_dn_surf_high=fx[2], flux_up_toa_high=fx[3])
+        eq = oracle.CkdEquipartitionSW(method, 0.02, oracle.layer_weight(p, 0.0), mu0, p, view("ssi")[0, sl].cpu().numpy(),
+                                       float(band_albedo[band]), view("flux_dn_surf")[0, sl].cpu().numpy(),
+                                       view("flux_up_toa")[0, sl].cpu().numpy(), view("bg_optical_depth")[:, sl].cpu().numpy(),
+                                       oracle.metric(method, od_s), view("hr")[:, sl].cpu().numpy(), extras)
+        ngb = g0["n_g_points"][band]
+        r1 = np.array(g0["rank1"][firsts[band]:firsts[band] + ngb])
+        r2 = np.array(g0["rank2"][firsts[band]:firsts[band] + ngb])
+        b_lo, b_hi = (r1 - i0 - 0.25) / (n - 1), (r2 - i0 + 0.25) / (n - 1)
+        gas.set_band_albedo(float(band_albedo[band]))
+        err = gas.calc_error_batch(i0, n, b_lo, b_hi)
+        pick = sorted({0, ngb // 2, ngb - 1})
+        ref = np.array([eq.calc_error(b_lo[k], b_hi[k]) for k in pick])
+        assert np.allclose(err[pick], ref, rtol=ERR_RTOL, atol=1e-10), (band, err[pick], ref)
+        assert np.array_equal(err, g0["error"][firsts[band]:firsts[band] + ngb])              # same rank ranges -> same bits
+    gas.close()
+
+    # (c) one band at a time == side by side
+    seq = pipeline.find_g_points_resident(ctx, names, load_gas, nband, tol, first_order, sequential_bands=True, merged_map=False, **kw)
+    for a, b in zip(seq["gases"], res["gases"]):
+        assert a["rank1"] == b["rank1"] and a["rank2"] == b["rank2"] and a["error"] == b["error"] and a["status"] == b["status"]
+
+    # (d) the shares of a three-process deal give the same searches (3 x 32 tasks: every process a whole gas... shifted by a third)
+    tasks = shard.task_table(range(len(names)), nband)
+    for world in (2, 5):
+        for r in range(world):
+            mine = [tasks[t] for t in shard.deal_tasks(len(tasks), r, world)]
+            by_gas = {}
+            for gi, b in mine:
+                by_gas.setdefault(gi, []).append(b)
+            for gi, bands in by_gas.items():
+                gas, out = pipeline._search_gas(ctx, load_gas(gi), bands, np.full(nband, tol), 0.02, 60, method, 0.02, 0.0, False, None, sw)
+                gas.close()
+                ref_g = res["gases"][gi]
+                fg = np.concatenate([[0], np.cumsum(ref_g["n_g_points"])])
+                for b, rr in out:
+                    assert rr["rank1"] == ref_g["rank1"][fg[b]:fg[b + 1]] and rr["error"] == ref_g["error"][fg[b]:fg[b + 1]]
 
 
 def _lut_problem(sw):
