@@ -134,19 +134,22 @@ def cpu_baseline(args, nwav_s, nlay, seed, tol, tol_tol, max_it, device):
                 status=int(st[0]), stage_seconds=dict(reorder=secs[0], preparation=secs[1], search=secs[2]))
 
 
-def sw_find_g_bench(ctx, nwav=3_300_000, nlay=54):
+def sw_find_g_bench(ctx, nwav=3_300_000, nlay=54, tol=0.047, nlines=12000):
     """The shortwave twin of the step, reported beside the headline (N = 1 only): reorder key + sort + gas preparation +
-    search of ONE band of BASELINE configs[2]'s shape (nwav = 3.3e6 over 250-50000 cm-1, total-transmission as
-    test/find_g_points_sw.sh, scalings as the tool clamps them (find_g_points.cpp:666-667), reference albedo 0.15,
-    cos_sza 0.5).  Throughput = wavenumber-points x (1 + passes of the search) / time, as for the longwave metric."""
+    search of ONE band of BASELINE configs[2]'s shape (nwav = 3.3e6 over 250-50000 cm-1, CKDMIP-like line spectra,
+    total-transmission as test/find_g_points_sw.sh with its tolerance_tolerance 0.01, the fsck tolerance of
+    test/do_all_sw.sh:54, scalings as the tool clamps them (find_g_points.cpp:666-667), reference albedo 0.15, cos_sza 0.5).
+    Throughput = wavenumber-points x (1 + passes swept by the search) / time, as for the longwave metric."""
     import torch
     from ecckd_amd import api, synthetic as syn
     dev = ctx.device
+    lo, hi = 250.0, 50000.0
     p = syn.pressure_grid(nlay)
-    wn_h, dwn_h = syn.wavenumber_grid(nwav, 250.0, 50000.0)
-    kw = dict(device=dev, lo=250.0, hi=50000.0)
-    od = syn.optical_depth(torch, p, wn_h, syn.SEED_BASE + 3, nlines=96, column_scale=5.0, **kw)
-    bg = syn.optical_depth(torch, p, wn_h, syn.SEED_BASE + 1003, nlines=24, column_scale=0.5, zero_fraction=0.0, **kw)
+    wn_h, dwn_h = syn.wavenumber_grid(nwav, lo, hi)
+    wn = torch.as_tensor(wn_h, device=dev)
+    od = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 501, nlines=nlines, column_scale=5.0, device=dev, lo=lo, hi=hi)
+    bg = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 1501, nlines=max(nlines // 3, 1), column_scale=0.5, zero_fraction=0.0,
+                                 nclusters=5, device=dev, lo=lo, hi=hi)
     ssi = torch.as_tensor(syn.solar_spectral_irradiance(wn_h, dwn_h), device=dev)
     alb = torch.full((nwav,), 0.15, dtype=torch.float64, device=dev)
     key = torch.empty(nwav, dtype=torch.float64, device=dev)
@@ -158,15 +161,16 @@ def sw_find_g_bench(ctx, nwav=3_300_000, nlay=54):
         t0 = time.perf_counter()
         api.reorder_key_sw(ctx, p, od, 0.25, key=key, col_od=col)
         api.stable_argsort_bands(ctx, key, [0], [nwav - 1], rank=rnk, want_ordered=False, sync=False)
-        gas = api.GasSW(ctx, p, ssi, rnk, od, bg, "total-transmission", flux_weight=0.02, albedo=alb)
+        gas = api.GasSW(ctx, p, ssi, rnk, od, bg, "total-transmission", 0.02, 0.0, 0.5, alb, 0.5, 2.5)
         gas.set_band_albedo(0.15)
-        st, b, e, cc = gas.find_g_band(0, nwav - 1, 0.02, 0.02, 60)
+        st, b, e, cc = gas.find_g_band(0, nwav - 1, tol, 0.01, 60)
         ctx.synchronize()
         dt = time.perf_counter() - t0
+        swept = gas.eval_stats()["points_evaluated"] / nwav
         gas.close()
-        out = {"value": nwav * (1.0 + cc) / dt, "unit": "wavenumber-points/s", "ms": dt * 1e3, "nwav": nwav, "nlay": nlay,
-               "ng": len(e), "n_pass": cc, "search_status": int(st),
-               "workload": "SW, one band 250-50000 cm-1 of configs[2]'s shape, total-transmission, albedo 0.15"}
+        out = {"value": nwav * (1.0 + swept) / dt, "unit": "wavenumber-points/s", "ms": dt * 1e3, "nwav": nwav, "nlay": nlay,
+               "ng": len(e), "n_pass": swept, "n_pass_reference_counter": cc, "search_status": int(st), "tolerance": tol,
+               "workload": "SW, one band 250-50000 cm-1 of configs[2]'s shape, line spectra, total-transmission, albedo 0.15"}
     del od, bg
     return out
 
