@@ -89,6 +89,8 @@ class Context:
         torch.cuda.current_stream(self.device).synchronize()
 
     def profile_enable(self, on=True):
+        """on = True / 1: HIP events around every launch of the dominant kernels; on = N > 1: around every N-th launch of the
+        sweep kernel (profile_get("k_rt_lw_bb.all") then counts all launches)."""
         check(self.lib.ecckd_profile_enable(self.handle, int(on)))
 
     def profile_get(self, kernel):

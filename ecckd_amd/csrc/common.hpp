@@ -29,8 +29,10 @@ struct ecckd_ctx {
   size_t pinned_bytes = 0;
   // optional per-kernel timing of the dominant kernels (HIP events on `stream`)
   bool profile = false;
+  int profile_stride = 1;        // the sweep kernel: every profile_stride-th launch is timed (ecckd_profile_enable(ctx, stride))
+  long long profile_seq = 0;
   hipEvent_t pev0 = nullptr, pev1 = nullptr;
-  struct KernelStat { double ms = 0.0; double units = 0.0; long long calls = 0; };
+  struct KernelStat { double ms = 0.0; double units = 0.0; long long calls = 0; double all_units = 0.0; long long all_calls = 0; };
   KernelStat stat_rt_lw;     // k_rt_lw_bb: units = wavenumber points processed
   KernelStat stat_key_lw;    // k_reorder_key_lw: units = wavenumber points
   KernelStat stat_sort;      // whole K3 pass sequence: units = keys sorted

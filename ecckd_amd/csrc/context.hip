@@ -231,6 +231,8 @@ int ecckd_profile_enable(ecckd_ctx* ctx, int on) {
     ECCKD_HIP_CHECK(hipEventCreate(&ctx->pev1));
   }
   ctx->profile = on != 0;
+  ctx->profile_stride = on > 1 ? on : 1;
+  ctx->profile_seq = 0;
   ctx->stat_rt_lw = ecckd_ctx::KernelStat();
   ctx->stat_key_lw = ecckd_ctx::KernelStat();
   ctx->stat_sort = ecckd_ctx::KernelStat();
@@ -243,6 +245,12 @@ int ecckd_profile_get(ecckd_ctx* ctx, const char* kernel, long long* calls, doub
   if (!strcmp(kernel, "k_rt_lw_bb")) st = &ctx->stat_rt_lw;
   else if (!strcmp(kernel, "k_reorder_key_lw")) st = &ctx->stat_key_lw;
   else if (!strcmp(kernel, "radix_sort")) st = &ctx->stat_sort;
+  if (!strcmp(kernel, "k_rt_lw_bb.all")) {     // every launch since profile_enable, timed or not (ms = 0)
+    if (calls) *calls = ctx->stat_rt_lw.all_calls;
+    if (ms) *ms = 0.0;
+    if (units) *units = ctx->stat_rt_lw.all_units;
+    return ECCKD_OK;
+  }
   if (!st) return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_profile_get: unknown kernel \"%s\"", kernel);
   if (calls) *calls = st->calls;
   if (ms) *ms = st->ms;

@@ -27,6 +27,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -69,6 +70,20 @@ __device__ __forceinline__ double block_sum_256(double v, double* s4) {
   if (lane == 0) s4[wave] = v;
   __syncthreads();
   return ((s4[0] + s4[1]) + s4[2]) + s4[3];
+}
+
+// two (or three) block sums behind ONE pair of barriers; every sum is formed exactly as block_sum_256 forms it
+__device__ __forceinline__ void block_sum_256_x3(double& a, double& b, double& c, double (*s4)[4]) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  c = wave_sum(c);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { s4[0][wave] = a; s4[1][wave] = b; s4[2][wave] = c; }
+  __syncthreads();
+  a = ((s4[0][0] + s4[0][1]) + s4[0][2]) + s4[0][3];
+  b = ((s4[1][0] + s4[1][1]) + s4[1][2]) + s4[1][3];
+  c = ((s4[2][0] + s4[2][1]) + s4[2][2]) + s4[2][3];
 }
 
 }  // namespace
@@ -473,19 +488,26 @@ struct Interval {
   double albedo;         // shortwave: surface albedo of the interval's band
 };
 
-// Small batches (most of a search: next_bound_below / _above evaluate ONE interval per call, equipartition.cpp:638-805)
-// hand their interval table to the first kernel of the train in its ARGUMENTS instead of a host-to-device copy in front of
-// it: one stream operation and one dependency gap less per batch.  The first kernel leaves the table in device memory for
+// Batches of up to KARG_MAX intervals (nearly all of a search: next_bound_below / _above evaluate ONE interval per call,
+// equipartition.cpp:638-805; calc_error_all a partition of a few dozen) hand their interval table to the first kernel of the
+// train in its ARGUMENTS instead of a host-to-device copy in front of it (a blit kernel of ~18 us): one stream operation and
+// one dependency gap less per batch.  The first kernel leaves the table in device memory for
 // the kernels behind it.
-constexpr int KARG_MAX = 8;
+constexpr int KARG_MAX = 64;     // 3 KB of the 4 KB argument segment
 struct IntervalArgs { Interval iv[KARG_MAX]; };
 
-__device__ __forceinline__ Interval interval_of(const IntervalArgs& ka, int use_ka, const Interval* __restrict__ iv, int k) {
+// The argument table is read where it lies, in the kernel-argument segment, with scalar loads at a block-uniform offset:
+// IntervalArgs MUST be the kernel's FIRST parameter (offset 0 of the segment).  Indexing the by-value struct itself makes the
+// compiler copy it to scratch (392 bytes per lane: every wave launch then waits for a scratch slot and the kernel's time
+// grows by ~2.3 us per interval of the batch).
+__device__ __forceinline__ Interval interval_of(int use_ka, const Interval* __restrict__ iv, int k) {
   if (!use_ka) return iv[k];
-  Interval me = ka.iv[0];
-#pragma unroll
-  for (int q = 1; q < KARG_MAX; ++q)
-    if (q == k) me = ka.iv[q];     // selects, not an indexed read: the argument block stays in scalar registers
+  typedef const __attribute__((address_space(4))) long long* karg_ptr;
+  karg_ptr q = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + (size_t)k * (sizeof(Interval) / sizeof(long long));
+  static_assert(sizeof(Interval) == 6 * sizeof(long long), "Interval is six 8-byte fields");
+  Interval me;
+  me.i1 = q[0]; me.i2 = q[1]; me.chunk0 = q[2]; me.chunk_pts = q[3]; me.npoints = q[4];
+  me.albedo = __longlong_as_double(q[5]);
   return me;
 }
 
@@ -533,13 +555,14 @@ k_super_sums(size_t ntiles, size_t nsuper, const double* __restrict__ ts, double
 }
 
 __global__ void __launch_bounds__(256)
-k_interval_sums(int nrows, size_t ntiles, size_t nsuper, const Interval* __restrict__ iv, IntervalArgs ka, int use_ka,
+k_interval_sums(IntervalArgs ka, int nrows, size_t ntiles, size_t nsuper, const Interval* __restrict__ iv, int use_ka,
                 Interval* __restrict__ iv_out, const double* const* __restrict__ rows, const double* __restrict__ ts,
                 const double* __restrict__ ss, double* __restrict__ sums) {
   __shared__ double s4[4];
   const int r = blockIdx.x, k = blockIdx.y;
   const int tid = threadIdx.x;
-  const Interval me = interval_of(ka, use_ka, iv, k);
+  (void)ka;
+  const Interval me = interval_of(use_ka, iv, k);
   if (use_ka && r == 0 && tid == 0) iv_out[k] = me;
   const double acc = interval_row_acc(rows[r], ts + (size_t)r * ntiles, ss + (size_t)r * nsuper, me.i1, me.i2, tid);
   const double s = block_sum_256(acc, s4);
@@ -567,13 +590,14 @@ __device__ __forceinline__ double fit_lw_layer(int method, double a, double b, d
 // logarithmic method, N+l), so the block that owns layer l adds up those rows and finishes the fit itself; the remaining
 // rows (heating rate, boundary fluxes) get one block each as before.  grid (nlay + rows from R.H on, nint), block 256.
 __global__ void __launch_bounds__(256)
-k_interval_sums_fit_lw(int nlay, int method, RowMap R, size_t ntiles, size_t nsuper, const Interval* __restrict__ iv, IntervalArgs ka,
+k_interval_sums_fit_lw(IntervalArgs ka, int nlay, int method, RowMap R, size_t ntiles, size_t nsuper, const Interval* __restrict__ iv,
                        int use_ka, Interval* __restrict__ iv_out, const double* const* __restrict__ rows,
                        const double* __restrict__ ts, const double* __restrict__ ss, double* __restrict__ sums,
                        double* __restrict__ od_fit) {
   __shared__ double s4[4];
   const int bx = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
-  const Interval me = interval_of(ka, use_ka, iv, k);
+  (void)ka;
+  const Interval me = interval_of(use_ka, iv, k);
   if (use_ka && bx == 0 && tid == 0) iv_out[k] = me;
   const long long i1 = me.i1, i2 = me.i2;
   double* out = sums + (size_t)k * R.total;
@@ -585,10 +609,13 @@ k_interval_sums_fit_lw(int nlay, int method, RowMap R, size_t ntiles, size_t nsu
   }
   const int l = bx;
   const bool is_log = method == ECCKD_AVG_LOGARITHMIC;
-  const double a = block_sum_256(interval_row_acc(rows[R.A + l], ts + (size_t)(R.A + l) * ntiles, ss + (size_t)(R.A + l) * nsuper, i1, i2, tid), s4);
-  const double b = block_sum_256(interval_row_acc(rows[R.B + l], ts + (size_t)(R.B + l) * ntiles, ss + (size_t)(R.B + l) * nsuper, i1, i2, tid), s4);
+  // the loads of the two (three) rows go out together: one memory round trip and one pair of barriers instead of two (three)
+  __shared__ double s43[3][4];
+  double a = interval_row_acc(rows[R.A + l], ts + (size_t)(R.A + l) * ntiles, ss + (size_t)(R.A + l) * nsuper, i1, i2, tid);
+  double b = interval_row_acc(rows[R.B + l], ts + (size_t)(R.B + l) * ntiles, ss + (size_t)(R.B + l) * nsuper, i1, i2, tid);
   double nnz = 0.0;
-  if (is_log) nnz = block_sum_256(interval_row_acc(rows[R.N + l], ts + (size_t)(R.N + l) * ntiles, ss + (size_t)(R.N + l) * nsuper, i1, i2, tid), s4);
+  if (is_log) nnz = interval_row_acc(rows[R.N + l], ts + (size_t)(R.N + l) * ntiles, ss + (size_t)(R.N + l) * nsuper, i1, i2, tid);
+  block_sum_256_x3(a, b, nnz, s43);
   if (tid == 0) {
     out[R.A + l] = a;
     out[R.B + l] = b;
@@ -971,6 +998,8 @@ k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
   }
 }
 
+constexpr int COST_GROUPS = 64;    // K5d: groups of 32 chunks per interval it has room for (2 048 chunks)
+
 // K5d: combine chunk partials of each interval in order, heating rate, cost
 // (calc_cost_function_lw.cpp:100-109).  grid nint, block 1024 = 8 groups x 128.
 __global__ void __launch_bounds__(1024)
@@ -978,40 +1007,41 @@ k_cost_lw(int nlay, RowMap R, const Interval* __restrict__ iv, long long nchunks
           const double* __restrict__ partial, const double* __restrict__ sums,
           const double* __restrict__ conv, const double* __restrict__ layer_weight,
           double flux_weight, double* __restrict__ err) {
-  extern __shared__ double s_mem[];  // [8][2*nhl] | [2*nhl] | [nlay]
+  extern __shared__ double s_mem[];  // [COST_GROUPS][2*nhl] | [2*nhl] | [nlay]
   const int nhl = nlay + 1;
   const int nv = 2 * nhl;
   double* s_grp = s_mem;
-  double* s_flux = s_mem + 8 * nv;
+  double* s_flux = s_mem + COST_GROUPS * nv;
   double* s_term = s_flux + nv;
   const int k = blockIdx.x;
   const long long c0 = iv[k].chunk0;
   const long long c1 = (k + 1 < (int)gridDim.x) ? iv[k + 1].chunk0 : nchunks_total;
   const int tid = threadIdx.x;
+  // The interval's chunks are added up in groups of 32 consecutive chunks (each group from 0.0 in chunk order), the groups
+  // then in ascending order: a function of the interval's chunk count alone.  Thread group g (128 threads: one per flux
+  // value) takes the chunk groups g, g + 8, ...; sixteen loads are in flight together.
   const int g = tid >> 7, t = tid & 127;
-  for (int v = t; v < nv; v += 128) {
-    double a = 0.0;
-    // four chunks at a time: independent loads in flight together, added in chunk order
-    long long c = c0 + g;
-    for (; c + 56 < c1; c += 64) {      // eight chunks at a time: independent loads in flight together, added in chunk order
-      double q[8];
+  const long long ncg = (c1 - c0 + 31) / 32;
+  for (long long cg = g; cg < ncg; cg += 8) {
+    const long long cb = c0 + cg * 32;
+    const int cnt = (int)((c1 - cb) < 32 ? (c1 - cb) : 32);
+    if (t < nv) {
+      double a = 0.0;
+#pragma unroll 1
+      for (int h = 0; h < 32; h += 16) {               // sixteen loads in flight, added in chunk order
+        double q[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) q[u] = partial[(size_t)(c + 8 * u) * nv + v];
+        for (int u = 0; u < 16; ++u) q[u] = h + u < cnt ? partial[(size_t)(cb + h + u) * nv + t] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a += q[u];
+        for (int u = 0; u < 16; ++u) a += q[u];        // + 0.0 behind the last chunk of a short group changes nothing
+      }
+      s_grp[(size_t)cg * nv + t] = a;
     }
-    for (; c + 24 < c1; c += 32) {
-      const double p0 = partial[(size_t)c * nv + v], p1 = partial[(size_t)(c + 8) * nv + v];
-      const double p2 = partial[(size_t)(c + 16) * nv + v], p3 = partial[(size_t)(c + 24) * nv + v];
-      a += p0; a += p1; a += p2; a += p3;
-    }
-    for (; c < c1; c += 8) a += partial[(size_t)c * nv + v];
-    s_grp[g * nv + v] = a;
   }
   __syncthreads();
   for (int v = tid; v < nv; v += 1024) {
     double a = 0.0;
-    for (int gg = 0; gg < 8; ++gg) a += s_grp[gg * nv + v];
+    for (long long cg = 0; cg < ncg; ++cg) a += s_grp[(size_t)cg * nv + v];
     s_flux[v] = a;
   }
   __syncthreads();
@@ -1442,36 +1472,37 @@ k_cost_sw(int nlay, int ntotal, SwTruthRows rows, const Interval* __restrict__ i
   const int nhl = nlay + 1;
   const int nv = 2 * nhl;
   double* s_grp = s_mem;
-  double* s_flux = s_mem + 8 * nv;
+  double* s_flux = s_mem + COST_GROUPS * nv;
   double* s_term = s_flux + nv;
   const int k = blockIdx.x;
   const long long c0 = iv[k].chunk0;
   const long long c1 = (k + 1 < (int)gridDim.x) ? iv[k + 1].chunk0 : nchunks_total;
   const int tid = threadIdx.x;
+  // The interval's chunks are added up in groups of 32 consecutive chunks (each group from 0.0 in chunk order), the groups
+  // then in ascending order: a function of the interval's chunk count alone.  Thread group g (128 threads: one per flux
+  // value) takes the chunk groups g, g + 8, ...; sixteen loads are in flight together.
   const int g = tid >> 7, t = tid & 127;
-  for (int v = t; v < nv; v += 128) {
-    double a = 0.0;
-    // four chunks at a time: independent loads in flight together, added in chunk order
-    long long c = c0 + g;
-    for (; c + 56 < c1; c += 64) {      // eight chunks at a time: independent loads in flight together, added in chunk order
-      double q[8];
+  const long long ncg = (c1 - c0 + 31) / 32;
+  for (long long cg = g; cg < ncg; cg += 8) {
+    const long long cb = c0 + cg * 32;
+    const int cnt = (int)((c1 - cb) < 32 ? (c1 - cb) : 32);
+    if (t < nv) {
+      double a = 0.0;
+#pragma unroll 1
+      for (int h = 0; h < 32; h += 16) {               // sixteen loads in flight, added in chunk order
+        double q[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) q[u] = partial[(size_t)(c + 8 * u) * nv + v];
+        for (int u = 0; u < 16; ++u) q[u] = h + u < cnt ? partial[(size_t)(cb + h + u) * nv + t] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a += q[u];
+        for (int u = 0; u < 16; ++u) a += q[u];        // + 0.0 behind the last chunk of a short group changes nothing
+      }
+      s_grp[(size_t)cg * nv + t] = a;
     }
-    for (; c + 24 < c1; c += 32) {
-      const double p0 = partial[(size_t)c * nv + v], p1 = partial[(size_t)(c + 8) * nv + v];
-      const double p2 = partial[(size_t)(c + 16) * nv + v], p3 = partial[(size_t)(c + 24) * nv + v];
-      a += p0; a += p1; a += p2; a += p3;
-    }
-    for (; c < c1; c += 8) a += partial[(size_t)c * nv + v];
-    s_grp[g * nv + v] = a;
   }
   __syncthreads();
   for (int v = tid; v < nv; v += 1024) {
     double a = 0.0;
-    for (int gg = 0; gg < 8; ++gg) a += s_grp[gg * nv + v];
+    for (long long cg = 0; cg < ncg; ++cg) a += s_grp[(size_t)cg * nv + v];
     s_flux[v] = a;
   }
   __syncthreads();
@@ -2127,7 +2158,7 @@ int ecckd_fit_optical_depth(ecckd_gas* g, size_t ibegin, size_t npoints, int n, 
   double* d_fit = (double*)w;
   std::memcpy(g->pinned, iv.data(), (size_t)n * sizeof(Interval));
   ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, g->pinned, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, g->nsuper, d_iv, IntervalArgs(), 0,
+  hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, IntervalArgs(), g->nrows, g->ntiles, g->nsuper, d_iv, 0,
                      d_iv, (const double* const*)g->rows, g->tile_sums, g->super_sums, d_sums);
   if (g->do_sw) {
     // unscaled fit: scaling factors of 1
@@ -2201,8 +2232,11 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
   double* h_err = (double*)((char*)g->pinned + iv_bytes);
   // the errors are written straight into the pinned host buffer by the last kernel (a few bytes over PCIe): no
   // device-to-host copy in the stream
-  double* h_err_dev = nullptr;
-  ECCKD_HIP_CHECK(hipHostGetDevicePointer((void**)&h_err_dev, h_err, 0));
+  if (g->pinned_dev_of != g->pinned) {        // the device alias of the pinned buffer, looked up once per (re)allocation
+    ECCKD_HIP_CHECK(hipHostGetDevicePointer((void**)&g->pinned_dev, g->pinned, 0));
+    g->pinned_dev_of = g->pinned;
+  }
+  double* h_err_dev = (double*)((char*)g->pinned_dev + iv_bytes);
   const int nslots = (g->do_sw && g->method == ECCKD_AVG_TOTAL_TRANSMISSION) ? 2 * n : n;
   mark_pending(h_err, nslots);
   static const bool no_karg = std::getenv("ECCKD_NO_KARG") != nullptr;   // A/B knob: always copy the interval table
@@ -2217,11 +2251,11 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
   }
 
   if (!g->do_sw)
-    hipLaunchKernelGGL(k_interval_sums_fit_lw, dim3(nlay + (g->rm.total - g->rm.H), n), dim3(256), 0, ctx->stream, nlay, g->method,
-                       g->rm, g->ntiles, g->nsuper, d_iv, ka, use_ka, d_iv, (const double* const*)g->rows, g->tile_sums, g->super_sums,
+    hipLaunchKernelGGL(k_interval_sums_fit_lw, dim3(nlay + (g->rm.total - g->rm.H), n), dim3(256), 0, ctx->stream, ka, nlay, g->method,
+                       g->rm, g->ntiles, g->nsuper, d_iv, use_ka, d_iv, (const double* const*)g->rows, g->tile_sums, g->super_sums,
                        d_sums, d_fit);
   else
-    hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, g->nrows, g->ntiles, g->nsuper, d_iv, ka, use_ka,
+    hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, ka, g->nrows, g->ntiles, g->nsuper, d_iv, use_ka,
                        d_iv, (const double* const*)g->rows, g->tile_sums, g->super_sums, d_sums);
   if (g->do_sw) {
     // CkdEquipartition::calc_error, shortwave branches (find_g_points.cpp:341-402)
@@ -2230,7 +2264,9 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
     hipLaunchKernelGGL(k_fit_sw, dim3(n), dim3(128), nlay * sizeof(double), ctx->stream, nlay, g->method, R, n,
                        g->min_scaling, g->max_scaling, d_iv, d_sums, d_fit);
     const size_t rt_lds_sw = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
-    const size_t cost_lds_sw = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
+    const size_t cost_lds_sw = (size_t)(COST_GROUPS * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
+    ECCKD_REQUIRE(target_blocks <= 32 * COST_GROUPS && cost_lds_sw <= 64 * 1024, "ecckd_calc_error_batch: %lld chunks per interval / %d layers exceed the cost kernel's room",
+                  target_blocks, nlay);
     const int npass = is_tt ? 2 : 1;
     // total-transmission evaluates the interval with the fit scaled by min_scaling and by max_scaling (:374-386; never equal
     // in the reference: min <= 0.5, max >= 2.5, :666-667): one launch that fetches the column once and sweeps it with both
@@ -2268,7 +2304,9 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
     return ECCKD_OK;
   }
   const size_t rt_lds = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
-  if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
+  const bool timed = ctx->profile && (ctx->profile_seq++ % ctx->profile_stride) == 0;
+  if (ctx->profile) { ctx->stat_rt_lw.all_calls += 1; ctx->stat_rt_lw.all_units += (double)total_pts; }
+  if (timed) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
   if (fast_path && nlay == 54) {
     hipLaunchKernelGGL(k_rt_lw_bb_mirror<54>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
                        n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
@@ -2279,20 +2317,25 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
     hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, ctx->stream, nlay, g->n,
                        n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
   }
-  if (ctx->profile) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
-  const size_t cost_lds = (size_t)(8 * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
+  if (timed) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
+  const size_t cost_lds = (size_t)(COST_GROUPS * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
+  ECCKD_REQUIRE(target_blocks <= 32 * COST_GROUPS && cost_lds <= 64 * 1024, "ecckd_calc_error_batch: %lld chunks per interval / %d layers exceed the cost kernel's room",
+                target_blocks, nlay);
   hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, ctx->stream, nlay, g->rm, d_iv,
                      nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, h_err_dev);
   ECCKD_HIP_CHECK(hipGetLastError());
   ECCKD_CHECK(wait_for_slots(ctx, h_err, nslots));
   std::memcpy(error, h_err, (size_t)n * sizeof(double));
-  if (ctx->profile) {
+  if (timed) {
     float ms = 0.f;
     ECCKD_HIP_CHECK(hipEventSynchronize(ctx->pev1));    // long past: the cost kernel behind it has delivered
     ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1));
     ctx->stat_rt_lw.ms += ms;
     ctx->stat_rt_lw.units += (double)total_pts;
     ctx->stat_rt_lw.calls += 1;
+    // ECCKD_SWEEP_LOG=<file>: one line per sweep launch (intervals, points, chunks, ms) for tools/sweep_sizes.py
+    static FILE* sweep_log = std::getenv("ECCKD_SWEEP_LOG") ? std::fopen(std::getenv("ECCKD_SWEEP_LOG"), "a") : nullptr;
+    if (sweep_log) std::fprintf(sweep_log, "%d %lld %lld %.6f\n", n, total_pts, nchunks, (double)ms);
   }
   return ECCKD_OK;
 }

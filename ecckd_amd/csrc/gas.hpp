@@ -95,5 +95,7 @@ struct ecckd_gas {
   size_t work_bytes = 0;
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  void* pinned_dev = nullptr;      // device alias of `pinned` (hipHostGetDevicePointer), valid while pinned_dev_of == pinned
+  void* pinned_dev_of = nullptr;
 };
 

@@ -76,7 +76,9 @@ int ecckd_h2d(ecckd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int ecckd_d2h(ecckd_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 /* per-kernel timing of the dominant kernels with HIP events on the context's stream:
  * kernel = "k_rt_lw_bb" | "k_reorder_key_lw"; units = wavenumber points processed.
- * Enabling resets the counters. */
+ * Enabling resets the counters.  on = 1: every launch is timed; on = N > 1: every N-th launch of the sweep kernel (the
+ * two event records and the event query cost several microseconds per batch of a search: a sample keeps them out of the
+ * way); "k_rt_lw_bb.all" then gives the number of launches and points of ALL launches (ms = 0). */
 int ecckd_profile_enable(ecckd_ctx* ctx, int on);
 int ecckd_profile_get(ecckd_ctx* ctx, const char* kernel, long long* calls, double* ms, double* units);
 /* timing on the context's stream (hipEvent pair): begin .. end -> milliseconds */
