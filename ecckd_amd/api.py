@@ -1104,3 +1104,21 @@ def merge_g_points(ctx, gas_g_points, g_min, g_max):
     check(ctx.lib.ecckd_merge_g_points_dev(ctx.handle, n, ngas, ptrs, ng, ng, ip(gmin), ip(gmax), _dptr(out),
                                            C.byref(cnt)))
     return out, cnt.value
+
+
+def inflate(ctx, streams, out_bytes):
+    """zlib streams (bytes objects) inflated on the device (ecckd_inflate) -> (list of bytes, status array); out_bytes[s] =
+    the number of bytes stream s must inflate to."""
+    n = len(streams)
+    raw = b"".join(streams)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in streams])
+    want = np.ascontiguousarray(out_bytes, dtype=np.uint64)
+    buf = np.frombuffer(raw, dtype=np.uint8) if raw else np.zeros(1, dtype=np.uint8)
+    out = np.zeros(max(int(want.sum()), 1), dtype=np.uint8)
+    status = np.zeros(max(n, 1), dtype=np.int32)
+    check(ctx.lib.ecckd_inflate(ctx.handle, n, buf.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.POINTER(C.c_ulonglong)),
+                                want.ctypes.data_as(C.POINTER(C.c_ulonglong)), out.ctypes.data_as(C.c_void_p),
+                                status.ctypes.data_as(C.POINTER(C.c_int))))
+    ends = np.concatenate([[0], np.cumsum(want)]).astype(np.int64)
+    return [out[ends[k]:ends[k + 1]].tobytes() for k in range(n)], status[:n]

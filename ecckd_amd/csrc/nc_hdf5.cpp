@@ -22,6 +22,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <thread>
 #include <vector>
 
@@ -362,6 +364,7 @@ int h5_read_real_parallel(H5File* h, const char* name, long long slice, int out_
         std::vector<unsigned char>().swap(job.raw);
       }
     };
+    const auto t_start = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
     for (unsigned w = 0; w < nworkers; ++w) pool.emplace_back(worker);
     // producer: raw chunks in row-major chunk order
@@ -379,12 +382,136 @@ int h5_read_real_parallel(H5File* h, const char* name, long long slice, int out_
       for (int k = nd - 1; k >= 0; --k) { if (++ci[k] <= c1[k]) break; ci[k] = c0[k]; }
     }
     if (bad.load()) produced.store(nchunks, std::memory_order_release);
+    const auto t_read = std::chrono::steady_clock::now();
     for (std::thread& th : pool) th.join();
+    if (std::getenv("ECCKD_H5_TIMES"))
+      std::fprintf(stderr, "%s \"%s\": %zu chunks, raw chunks read in %.1f ms, inflated and placed by %u threads %.1f ms later\n", h->path.c_str(), name,
+                   nchunks, 1e3 * std::chrono::duration<double>(t_read - t_start).count(), nworkers,
+                   1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read).count());
     if (bad.load() == 1 || bad.load() == 3) rc = fail(ECCKD_PROCESSING_ERROR, "%s: a chunk of \"%s\" could not be read or inflated", h->path.c_str(), name);
     else if (bad.load() == 0) *handled = true;
   }
   a->H5Pclose(pl); a->H5Tclose(t); a->H5Sclose(sp); a->H5Dclose(d);
   return rc;
+}
+
+// ---- the same raw chunks for a consumer that inflates them elsewhere (nc_stream.hip: on the device) ----
+struct H5ChunkReader {
+  H5File* h = nullptr;
+  hid_t d = -1, sp = -1, t = -1, pl = -1;
+  H5ChunkPlan plan;
+  hsize_t c0[8] = {}, c1[8] = {}, ci[8] = {};
+  size_t next = 0;
+  hsize_t off[8] = {};
+  int i_shuffle = -1, i_deflate = -1;
+};
+
+void h5_chunks_close(H5ChunkReader* r) {
+  if (!r) return;
+  Api* a = r->h->a;
+  if (r->pl >= 0) a->H5Pclose(r->pl);
+  if (r->t >= 0) a->H5Tclose(r->t);
+  if (r->sp >= 0) a->H5Sclose(r->sp);
+  if (r->d >= 0) a->H5Dclose(r->d);
+  delete r;
+}
+
+// *out = nullptr (and ECCKD_OK) if the variable's layout is not [shuffle,] deflate over little-endian FLOAT / DOUBLE chunks
+int h5_chunks_open(H5File* h, const char* name, long long slice, size_t capacity, H5ChunkReader** out, H5ChunkPlan* plan) {
+  Api* a = h->a;
+  *out = nullptr;
+  if (!a->H5Dread_chunk || !a->H5Dget_chunk_storage_size || !a->H5Dget_create_plist || !a->H5Pget_layout || !a->H5Pget_chunk ||
+      !a->H5Pget_nfilters || !a->H5Pget_filter2 || !a->H5Pclose || !a->H5Tget_order)
+    return ECCKD_OK;
+  if (a->H5Lexists(h->file, name, 0) <= 0) return ECCKD_OK;
+  H5ChunkReader* r = new H5ChunkReader;
+  r->h = h;
+  r->d = a->H5Dopen2(h->file, name, 0);
+  if (r->d < 0) { delete r; return ECCKD_OK; }
+  r->sp = a->H5Dget_space(r->d); r->t = a->H5Dget_type(r->d); r->pl = a->H5Dget_create_plist(r->d);
+  H5ChunkPlan& P = r->plan;
+  P = H5ChunkPlan();
+  const int nd = a->H5Sget_simple_extent_ndims(r->sp);
+  hsize_t dims[32] = {}, cdims[32] = {};
+  if (nd > 0) a->H5Sget_simple_extent_dims(r->sp, dims, nullptr);
+  const size_t ts = a->H5Tget_size(r->t);
+  bool ok = nd >= 1 && nd <= 8 && a->H5Tget_class(r->t) == 1 && (ts == 4 || ts == 8) && a->H5Tget_order(r->t) == 0 &&
+            a->H5Pget_layout(r->pl) == 2 && a->H5Pget_chunk(r->pl, nd, cdims) == nd;
+  if (ok) {
+    const int nf = a->H5Pget_nfilters(r->pl);
+    for (int i = 0; i < nf && ok; ++i) {
+      unsigned flags = 0, cfg = 0, cd[8];
+      size_t ncd = 8;
+      char fname[8];
+      const int id = a->H5Pget_filter2(r->pl, (unsigned)i, &flags, &ncd, cd, sizeof fname, fname, &cfg);
+      if (id == 2 && r->i_shuffle < 0 && r->i_deflate < 0) r->i_shuffle = i;
+      else if (id == 1 && r->i_deflate < 0) r->i_deflate = i;
+      else ok = false;
+    }
+    ok = ok && r->i_deflate >= 0;
+  }
+  if (ok) {
+    P.nd = nd; P.ts = ts; P.shuffle = r->i_shuffle >= 0 ? 1 : 0;
+    P.total = 1; P.nchunks = 1; P.chunk_elems = 1;
+    for (int k = 0; k < nd; ++k) { P.dims[k] = dims[k]; P.cdims[k] = cdims[k]; P.lo[k] = 0; P.hi[k] = dims[k]; }
+    if (slice >= 0) {
+      if ((hsize_t)slice >= dims[0]) ok = false;
+      else { P.lo[0] = (unsigned long long)slice; P.hi[0] = P.lo[0] + 1; }
+    }
+  }
+  if (ok) {
+    for (int k = 0; k < nd; ++k) {
+      P.total *= (size_t)(P.hi[k] - P.lo[k]);
+      r->c0[k] = P.lo[k] / cdims[k];
+      r->c1[k] = (P.hi[k] - 1) / cdims[k];
+      r->ci[k] = r->c0[k];
+      P.nchunks *= (size_t)(r->c1[k] - r->c0[k] + 1);
+      P.chunk_elems *= (size_t)cdims[k];
+    }
+    ok = P.total > 0 && P.total <= capacity;
+  }
+  if (!ok) { h5_chunks_close(r); return ECCKD_OK; }
+  *plan = P;
+  *out = r;
+  return ECCKD_OK;
+}
+
+// the next chunk (row-major chunk order): its origin in dataset coordinates and its stored size; *bytes = 0 behind the last
+// chunk or for a chunk that was never written (the caller then leaves the variable to the HDF5 library, which knows the
+// fill value)
+int h5_chunks_next(H5ChunkReader* r, unsigned long long* off, size_t* bytes, int* unwritten) {
+  Api* a = r->h->a;
+  *bytes = 0;
+  *unwritten = 0;
+  if (r->next >= r->plan.nchunks) return ECCKD_OK;
+  for (int k = 0; k < r->plan.nd; ++k) { r->off[k] = r->ci[k] * r->plan.cdims[k]; off[k] = r->off[k]; }
+  hsize_t n = 0;
+  if (a->H5Dget_chunk_storage_size(r->d, r->off, &n) < 0 || n == 0) { *unwritten = 1; return ECCKD_OK; }
+  *bytes = (size_t)n;
+  return ECCKD_OK;
+}
+
+// zlib's uncompress as loaded beside the HDF5 library (thread-safe); false if there is none or the stream is not dst_len bytes
+bool h5_inflate_host(H5File* h, void* dst, size_t dst_len, const void* src, size_t src_len) {
+  Api* a = h->a;
+  if (!a->z_uncompress) return false;
+  unsigned long n = (unsigned long)dst_len;
+  return a->z_uncompress((unsigned char*)dst, &n, (const unsigned char*)src, (unsigned long)src_len) == 0 && n == dst_len;
+}
+bool h5_has_zlib(H5File* h) { return h->a->z_uncompress != nullptr; }
+
+// the bytes of the chunk h5_chunks_next announced, as stored (no filter is undone); *deflated / *shuffled: which filters were
+// applied to this chunk
+int h5_chunks_read(H5ChunkReader* r, void* dst, int* deflated, int* shuffled) {
+  Api* a = r->h->a;
+  unsigned mask = 0;
+  if (a->H5Dread_chunk(r->d, 0, r->off, &mask, dst) < 0)
+    return fail(ECCKD_PROCESSING_ERROR, "%s: a chunk could not be read", r->h->path.c_str());
+  *deflated = !(mask & (1u << r->i_deflate));
+  *shuffled = r->i_shuffle >= 0 && !(mask & (1u << r->i_shuffle));
+  ++r->next;
+  for (int k = r->plan.nd - 1; k >= 0; --k) { if (++r->ci[k] <= r->c1[k]) break; r->ci[k] = r->c0[k]; }
+  return ECCKD_OK;
 }
 
 static hid_t open_att(H5File* h, const char* var, const char* att) {

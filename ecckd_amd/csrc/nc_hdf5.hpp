@@ -14,6 +14,20 @@ int h5_read_double(H5File* h, const char* name, long long slice, double* out, si
 // FLOAT / DOUBLE variable (one slice or all) as float (out_type 4) or double (8) with the chunks inflated by worker threads;
 // *handled = false if the variable's layout is not one this path takes apart (the caller then uses h5_read_double)
 int h5_read_real_parallel(H5File* h, const char* name, long long slice, int out_type, void* out, size_t capacity, bool* handled);
+// The raw (still filtered) chunks of such a variable, for a consumer that inflates them itself (nc_stream.hip: on the device).
+struct H5ChunkPlan {
+  int nd = 0, shuffle = 0;
+  size_t ts = 0;                       // bytes per stored value (4 or 8, little-endian IEEE)
+  unsigned long long dims[8] = {}, cdims[8] = {}, lo[8] = {}, hi[8] = {};   // dataset shape, chunk shape, requested box [lo, hi)
+  size_t nchunks = 0, chunk_elems = 0, total = 0;                            // chunks that meet the box, values per chunk, values in the box
+};
+struct H5ChunkReader;
+int h5_chunks_open(H5File* h, const char* name, long long slice, size_t capacity, H5ChunkReader** out, H5ChunkPlan* plan);
+int h5_chunks_next(H5ChunkReader* r, unsigned long long* off, size_t* bytes, int* unwritten);
+int h5_chunks_read(H5ChunkReader* r, void* dst, int* deflated, int* shuffled);
+void h5_chunks_close(H5ChunkReader* r);
+bool h5_has_zlib(H5File* h);
+bool h5_inflate_host(H5File* h, void* dst, size_t dst_len, const void* src, size_t src_len);
 int h5_read_att_text(H5File* h, const char* var, const char* att, int* exists, char* out, size_t capacity);
 int h5_read_att_double(H5File* h, const char* var, const char* att, int* nelems, double* out, size_t capacity);
 

@@ -399,6 +399,14 @@ int ecckd_nc_read_double(ecckd_nc* file, const char* name, long long slice, doub
  * else (NetCDF-4, record variables, integer types) is read on the host and uploaded once.  capacity in elements. */
 int ecckd_nc_read_dev(ecckd_ctx* ctx, ecckd_nc* file, const char* name, long long slice, int out_type, void* d_out,
                       size_t capacity);
+/* zlib streams (RFC 1950 / 1951: what HDF5's deflate filter leaves in a chunk) inflated on the device, one wavefront per
+ * stream - the NetCDF-4 spectra are read this way by ecckd_nc_read_dev (the reference leaves it to the HDF5 library on the
+ * reading thread, DataFileEngineNetcdf.cpp:593-608).  Host-pointer form: stream s is h_in[h_in_off[s] .. h_in_off[s + 1]) and
+ * must inflate to exactly h_out_bytes[s] bytes, written one stream after the other to h_out; h_status[s] = 0, or 1 bad
+ * header, 2 bad block, 3 bad code, 4 distance too far back, 5 more output than expected, 6 less, 7 input exhausted.
+ * The Adler-32 trailer is not verified. */
+int ecckd_inflate(ecckd_ctx* ctx, int nstreams, const void* h_in, const unsigned long long* h_in_off,
+                  const unsigned long long* h_out_bytes, void* h_out, int* h_status);
 int ecckd_nc_read_att_text(ecckd_nc* file, const char* var, const char* att, int* exists, char* out, size_t capacity);
 int ecckd_nc_read_att_double(ecckd_nc* file, const char* var, const char* att, int* nelems, double* out, size_t capacity);
 /* writing: define, ecckd_nc_enddef (picks CDF-1 / CDF-2 / CDF-5 from the sizes), then whole variables */

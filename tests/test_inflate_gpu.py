@@ -1,0 +1,89 @@
+"""zlib / DEFLATE streams inflated on the device (csrc/inflate.hip, the NetCDF-4 read path of ecckd_nc_read_dev) against
+Python's zlib (the library HDF5's deflate filter uses): bit-exact for stored, fixed-Huffman and dynamic-Huffman blocks,
+matches at every distance up to the 32 KB window, run-length matches (distance < length), long codes, many streams of
+different sizes in one launch, and damaged streams reported per stream."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _shuffled_floats(n, seed):
+    """what a NetCDF-4 chunk of a spectrum looks like behind the shuffle filter: byte planes of smooth positive floats"""
+    rs = np.random.RandomState(seed)
+    v = np.exp(np.cumsum(rs.normal(0.0, 0.05, n))).astype("<f4") * 1e-3
+    v[rs.uniform(size=n) < 0.05] = 0.0
+    return v.view(np.uint8).reshape(n, 4).T.copy().tobytes()
+
+
+def _cases():
+    rs = np.random.RandomState(7)
+    cases = {
+        "empty": b"",
+        "one byte": b"x",
+        "text": b"the quick brown fox jumps over the lazy dog. " * 400,
+        "zeros": bytes(200_000),
+        "random": rs.bytes(70_000),                                     # incompressible: stored blocks at any level
+        "run lengths": b"".join(bytes([k % 251]) * (1 + 37 * k % 300) for k in range(2000)),
+        "far matches": (lambda a: a + rs.bytes(32768 - 300 - 17) + a[:250] + rs.bytes(5000) + a)(rs.bytes(300)),
+        "shuffled floats": _shuffled_floats(262_144, 3),
+        "skewed alphabet": bytes(np.minimum(rs.geometric(0.08, 150_000), 255).astype(np.uint8)),   # code lengths beyond the 10-bit table
+    }
+    return cases
+
+
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+def test_inflate_matches_zlib(ctx, level):
+    from ecckd_amd import api
+    cases = _cases()
+    names = list(cases)
+    streams = [zlib.compress(cases[k], level) for k in names]
+    out, status = api.inflate(ctx, streams, [len(cases[k]) for k in names])
+    assert list(status) == [0] * len(names), dict(zip(names, status))
+    for k, got in zip(names, out):
+        assert got == cases[k], k
+
+
+def test_fixed_huffman_and_raw_strategies(ctx):
+    from ecckd_amd import api
+    data = _cases()
+    streams, want = [], []
+    for strategy in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+        for k in ("text", "shuffled floats", "run lengths", "skewed alphabet"):
+            c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, strategy)
+            streams.append(c.compress(data[k]) + c.flush())
+            want.append(data[k])
+    out, status = api.inflate(ctx, streams, [len(w) for w in want])
+    assert not status.any()
+    assert out == want
+
+
+def test_many_streams_of_many_sizes(ctx):
+    from ecckd_amd import api
+    rs = np.random.RandomState(11)
+    want = [_shuffled_floats(int(n), 100 + i) for i, n in enumerate(rs.randint(1, 40_000, 700))]
+    streams = [zlib.compress(w, int(rs.randint(1, 10))) for w in want]
+    # several flush points inside a stream: empty stored blocks and block boundaries in odd places
+    c = zlib.compressobj(6)
+    pieces = [c.compress(want[0][:1000]), c.flush(zlib.Z_SYNC_FLUSH), c.compress(want[0][1000:]), c.flush(zlib.Z_FULL_FLUSH), c.flush()]
+    streams[0] = b"".join(pieces)
+    out, status = api.inflate(ctx, streams, [len(w) for w in want])
+    assert not status.any()
+    assert out == want
+
+
+def test_damaged_streams_are_reported(ctx):
+    from ecckd_amd import api
+    good = b"spectral intervals " * 3000
+    z = zlib.compress(good, 6)
+    bad_header = bytes([z[0] ^ 0x0f]) + z[1:]
+    truncated = z[:len(z) // 2]
+    streams = [z, bad_header, truncated, z, z]
+    out, status = api.inflate(ctx, streams, [len(good), len(good), len(good), len(good) - 5, len(good) + 5])
+    assert status[0] == 0 and out[0] == good
+    assert status[1] == 1                       # bad header
+    assert status[2] != 0                       # input exhausted / bad code in the padding
+    assert status[3] == 5                       # more output than expected
+    assert status[4] == 6                       # less

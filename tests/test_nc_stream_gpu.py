@@ -57,3 +57,41 @@ def test_netcdf4_variable_to_device(ctx, tmp_path):
         got = f.read_dev(ctx, "optical_depth", 1)
         assert got.dtype == torch.float32 and np.array_equal(got.cpu().numpy().view(np.uint32), od[1].view(np.uint32))
         assert np.array_equal(f.read_dev(ctx, "optical_depth", 0, dtype=torch.float64).cpu().numpy(), od[0].astype(np.float64))
+
+
+@pytest.mark.parametrize("mode", ["device inflate", "host inflate", "host only"])
+def test_netcdf4_chunks_to_the_device(ctx, tmp_path, monkeypatch, mode):
+    """The NetCDF-4 read path: raw chunks inflated by worker threads into pinned slots (default) or on the device
+    (ECCKD_GPU_INFLATE=1: csrc/inflate.hip, one wavefront per chunk), then unshuffled, converted and placed by k_place_chunks;
+    or everything on the host and one upload (ECCKD_NO_DEVICE_PLACE=1).  Chunk shapes that do not divide the variable, chunks
+    spanning several slices, DOUBLE storage, a 1-D variable, special values, both output types: the same bits every way."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import h5_fixture as h5
+    from ecckd_amd import ncio
+    if not h5.available():
+        pytest.skip("no HDF5 shared library with the deflate filter in this environment")
+    if mode == "device inflate":
+        monkeypatch.setenv("ECCKD_GPU_INFLATE", "1")
+    elif mode == "host only":
+        monkeypatch.setenv("ECCKD_NO_DEVICE_PLACE", "1")
+    rs = np.random.RandomState(0)
+    od = np.exp(np.cumsum(rs.normal(0, 0.05, (3, 17, 50_003)), axis=-1)).astype(np.float32)
+    od[1, 3, :7] = [0.0, -0.0, np.float32(1e-42), np.inf, -np.inf, 1.0, -1.0]
+    od[2, :, 1000:30_000] = 0.0                                                           # long runs: matches at distance 1
+    x64 = rs.standard_normal((4, 5, 3001))
+    noise = rs.standard_normal((2, 3, 20_000)).astype(np.float32)                       # incompressible mantissas
+    path = tmp_path / "chunky.h5"
+    h5.write(path, {"optical_depth": (od, "f4", (2, 5, 4096), None), "x64": (x64, "f8", (1, 2, 777), None),
+                    "flat": (od[0, 0], "f4", (1000,), None), "noise": (noise, "f4", (1, 1, 20_000), None)})
+    with ncio.NcFile(path) as f:
+        for k in range(3):
+            got = f.read_dev(ctx, "optical_depth", k)
+            assert got.dtype == torch.float32 and np.array_equal(got.cpu().numpy().view(np.uint32), od[k].view(np.uint32)), k
+        assert np.array_equal(f.read_dev(ctx, "optical_depth", dtype=torch.float64).cpu().numpy().view(np.uint64),
+                              od.astype(np.float64).view(np.uint64))
+        assert np.array_equal(f.read_dev(ctx, "x64", 3).cpu().numpy(), x64[3])
+        assert np.array_equal(f.read_dev(ctx, "x64").cpu().numpy(), x64)
+        assert np.array_equal(f.read_dev(ctx, "x64", 1, dtype=torch.float32).cpu().numpy(), x64[1].astype(np.float32))
+        assert np.array_equal(f.read_dev(ctx, "flat").cpu().numpy(), od[0, 0])
+        assert np.array_equal(f.read_dev(ctx, "noise", 1).cpu().numpy(), noise[1])
