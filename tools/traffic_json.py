@@ -19,7 +19,9 @@ pat, fetch_csv, write_csv, bench = sys.argv[1:5]
 fetch_kb, nf = avg(fetch_csv, pat, "FETCH_SIZE")
 write_kb, nw = avg(write_csv, pat, "WRITE_SIZE")
 line = json.loads(open(bench).read().strip().splitlines()[-1])
-ppl = line["roofline"]["points_per_launch"]
+# mean points per launch over ALL launches (the counters are averaged over all of them; roofline.points_per_launch is the mean
+# of the launches timed with events, every N-th one)
+ppl = line.get("search", {}).get("points_per_batch") or line["roofline"]["points_per_launch"]
 corrected = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
 print(json.dumps({
     "kernel": pat, "launches_fetch_pass": nf, "launches_write_pass": nw, "points_per_launch": ppl, "fetch_kb": fetch_kb,
