@@ -27,6 +27,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -2183,8 +2184,25 @@ int ecckd_calc_error_batch(ecckd_gas* g, size_t ibegin, size_t npoints, int n, c
   return ecckd_calc_error_multi(g, n, ib.data(), np.data(), nullptr, bound1, bound2, error);
 }
 
+// ECCKD_TURNAROUND_LOG=1: where the host's time between two batches of a search goes (printed when the process ends)
+struct TurnaroundLog {
+  bool on = std::getenv("ECCKD_TURNAROUND_LOG") != nullptr;
+  std::chrono::steady_clock::time_point seen;
+  bool have_seen = false;
+  double to_entry = 0, to_first = 0, to_last = 0, wait = 0;
+  long long n = 0;
+  ~TurnaroundLog() {
+    if (on && n)
+      std::fprintf(stderr, "search batches %lld: errors seen -> next evaluation entered %.2f us, -> first launch issued %.2f us, -> last launch "
+                           "issued %.2f us, waiting for the errors %.2f us\n", n, 1e6 * to_entry / n, 1e6 * to_first / n, 1e6 * to_last / n, 1e6 * wait / n);
+  }
+};
+static TurnaroundLog g_turn;
+
 // Errors of the intervals iv[0..n) (first / last sorted index and albedo filled in) on the device -> error[0..n).
 static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error) {
+  const auto t_entry = g_turn.on ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+  std::chrono::steady_clock::time_point t_first, t_last;
   const int n = (int)iv.size();
   ecckd_ctx* ctx = g->ctx;
   const int nlay = g->nlay, nhl = nlay + 1;
@@ -2303,6 +2321,7 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
     for (int k = 0; k < n; ++k) error[k] = is_tt ? 0.5 * (h_err[k] + h_err[n + k]) : h_err[k];  // :386
     return ECCKD_OK;
   }
+  if (g_turn.on) t_first = std::chrono::steady_clock::now();
   const size_t rt_lds = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
   const bool timed = ctx->profile && (ctx->profile_seq++ % ctx->profile_stride) == 0;
   if (ctx->profile) { ctx->stat_rt_lw.all_calls += 1; ctx->stat_rt_lw.all_units += (double)total_pts; }
@@ -2324,7 +2343,20 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
   hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, ctx->stream, nlay, g->rm, d_iv,
                      nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, h_err_dev);
   ECCKD_HIP_CHECK(hipGetLastError());
+  if (g_turn.on) t_last = std::chrono::steady_clock::now();
   ECCKD_CHECK(wait_for_slots(ctx, h_err, nslots));
+  if (g_turn.on) {
+    const auto now = std::chrono::steady_clock::now();
+    if (g_turn.have_seen && std::chrono::duration<double>(t_entry - g_turn.seen).count() < 500e-6) {   // not the pause between two searches
+      g_turn.to_entry += std::chrono::duration<double>(t_entry - g_turn.seen).count();
+      g_turn.to_first += std::chrono::duration<double>(t_first - g_turn.seen).count();
+      g_turn.to_last += std::chrono::duration<double>(t_last - g_turn.seen).count();
+      g_turn.wait += std::chrono::duration<double>(now - t_last).count();
+      g_turn.n += 1;
+    }
+    g_turn.seen = now;
+    g_turn.have_seen = true;
+  }
   std::memcpy(error, h_err, (size_t)n * sizeof(double));
   if (timed) {
     float ms = 0.f;
