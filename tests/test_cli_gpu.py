@@ -922,3 +922,89 @@ def test_ckdmip_lw_stand_in(ctx, tmp_path):
         assert np.allclose(b.variables[k][...], a.variables[k][...], rtol=2e-5, atol=1e-4), k
     assert b.variables["spectral_flux_dn_lw"].shape == a.variables["optical_depth"].shape[:1] + (nhl, a.variables["optical_depth"].shape[2])
     a.close(); b.close()
+
+
+def test_ckdmip_sw_stand_in(ctx, tmp_path):
+    """bin/ckdmip_sw, the stand-in for the external CKDMIP shortwave tool of the reference's scripts: --merge-only
+    (test/merge_well_mixed_sw.sh:35-81), the line-by-line band fluxes for every zenith angle of the namelist
+    (test/run_sw_lbl_evaluation.sh) against ecckd_lbl_band_fluxes_sw and through LblFluxes::read's mirror (five angles of which
+    the reference keeps three, lbl_fluxes.cpp:88), and the flux evaluation of a CKD model's optical depths
+    (test/run_ckd_sw.sh:125-128) against the closed form."""
+    import torch
+    from ecckd_amd import api, ncio
+    d = tmp_path
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=ctx.device)
+    nlay, nwav, lo, hi = 16, 8000, 250.0, 50000.0
+    p1 = syn.pressure_grid(nlay)
+    wn, dwn = syn.wavenumber_grid(nwav, lo, hi)
+    ssi = syn.solar_spectral_irradiance(wn, dwn)
+    w = netcdf_file(str(d / "ssi.nc"), "w", version=2)
+    w.createDimension("wavenumber", nwav)
+    w.createVariable("solar_spectral_irradiance", "d", ("wavenumber",))[:] = ssi
+    w.close()
+    t0 = syn.temperature_profile(p1)
+    base = {"h2o": (syn.optical_depth(np, p1, wn, syn.SEED_BASE + 81, nlines=60, column_scale=3.0, dtype="float32", lo=lo, hi=hi), 5e-3),
+            "o3": (syn.optical_depth(np, p1, wn, syn.SEED_BASE + 83, nlines=30, column_scale=0.8, dtype="float32", lo=lo, hi=hi), 1e-6)}
+    for g, (od, vmr) in base.items():
+        _write_columns_from(d / f"ideal_{g}.nc", g, p1, [t0 - 20.0, t0, t0 + 20.0], wn, od, vmr)
+    # ---- merge-only ----
+    r = run_tool("ckdmip_sw", "--merge-only", "ideal_h2o.nc", "--scale", "2", "ideal_o3.nc", "--output", "merged.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    m = ncio.read_spectrum(d / "merged.nc", 1)
+    assert np.allclose(m["optical_depth"], (base["h2o"][0] + 2.0 * base["o3"][0]).astype(np.float32), rtol=2e-7) and m["molecule"] == "composite"
+    # ---- line-by-line band fluxes: 3 columns x 5 zenith angles, 2 bands ----
+    (d / "sw.nam").write_text("&shortwave_config\noptical_depth_name = \"optical_depth\",\nsurf_albedo = 0.15,\nuse_mu0_dimension = true,\n"
+                              "cos_solar_zenith_angle(1:5) = 0.1, 0.3, 0.5, 0.7, 0.9,\nnspectralstride = 1,\n"
+                              "band_wavenumber1(1:2) = 250, 10000,\nband_wavenumber2(1:2) = 10000, 50000,\niverbose = 3\n/\n")
+    r = run_tool("ckdmip_sw", "--config", "sw.nam", "--scenario", "present", "--ssi", "ssi.nc", "ideal_h2o.nc", "--scale", "0.5", "ideal_o3.nc",
+                 "--output", "lbl_sw_tool.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    f = _nc(d / "lbl_sw_tool.nc")
+    mu0s = np.array([0.1, 0.3, 0.5, 0.7, 0.9])
+    assert np.allclose(f.variables["mu0"][:], mu0s) and f.constituent_id == b"h2o o3" and f.scenario == b"present"
+    b1, b2 = np.array([lo, 10000.0]), np.array([10000.0, hi])
+    begin = [int(np.nonzero((wn >= a) & (wn < b + (b == hi)))[0][0]) for a, b in zip(b1, b2)]
+    end = [int(np.nonzero((wn >= a) & (wn < b + (b == hi)))[0][-1]) for a, b in zip(b1, b2)]
+    od = base["h2o"][0].astype(np.float64) + 0.5 * base["o3"][0].astype(np.float64)
+    alb = dev(np.full(nwav, 0.15))
+    for k, mu in enumerate(mu0s):
+        dn, up = api.lbl_band_fluxes_sw(ctx, mu, dev(ssi), dev(od), begin, end, albedo=alb)
+        for col in range(3):                       # the three columns share the optical depths (only the temperatures differ)
+            assert np.allclose(f.variables["band_flux_dn_direct_sw"][col, k], dn.T, rtol=3e-7, atol=1e-30)
+            assert np.allclose(f.variables["band_flux_up_sw"][col, k], up.T, rtol=3e-7, atol=1e-30)
+            assert np.allclose(f.variables["flux_dn_direct_sw"][col, k], dn.sum(0), rtol=3e-7)
+        assert f.variables["flux_dn_direct_sw"][0, k, 0] == pytest.approx(mu * ssi.sum(), rel=1e-6)        # top of atmosphere
+        assert np.all(up[:, -1] <= 0.15 * dn[:, -1] * (1 + 1e-12))
+    assert np.allclose(f.variables["mole_fraction_fl"][1], np.stack([np.full(nlay, 5e-3), np.full(nlay, 0.5e-6)]), rtol=2e-7)
+    f.close()
+    s = ncio.read_lbl_fluxes(d / "lbl_sw_tool.nc", ["h2o", "o3"], ctx=ctx)           # what optimize_lut reads (lbl_fluxes.cpp:52-133)
+    assert s["is_sw"] and s["have_band_fluxes"] and s["flux_dn"].shape == (9, nlay + 1, 2)      # 3 columns x the angles 0, 2, 4
+    assert np.allclose(s["mu0"], np.tile([0.1, 0.5, 0.9], 3)) and s["tsi"] == pytest.approx(ssi.sum(), rel=1e-6)
+    # ---- errors ----
+    r = run_tool("ckdmip_sw", "--config", "sw.nam", "ideal_h2o.nc", "--output", "x.nc", cwd=d)
+    assert r.returncode == 147 and "--ssi" in r.stderr
+    # ---- --ckd: direct beam and reflected flux on g-point optical depths (the file run_ckd writes for a shortwave model) ----
+    rs = np.random.RandomState(5)
+    ncol, ng = 2, 7
+    odg = rs.uniform(0.0, 0.4, (ncol, nlay, ng))
+    ray = rs.uniform(0.0, 0.05, (ncol, nlay, ng))
+    inc = rs.uniform(10.0, 300.0, (ncol, ng))
+    w = netcdf_file(str(d / "od_sw.nc"), "w", version=2)
+    for dim, n in (("column", ncol), ("half_level", nlay + 1), ("level", nlay), ("g_point", ng)):
+        w.createDimension(dim, n)
+    w.createVariable("pressure_hl", "d", ("column", "half_level"))[:] = np.tile(p1, (ncol, 1))
+    w.createVariable("optical_depth", "d", ("column", "level", "g_point"))[:] = odg
+    w.createVariable("rayleigh_optical_depth", "d", ("column", "level", "g_point"))[:] = ray
+    w.createVariable("incoming_sw", "d", ("column", "g_point"))[:] = inc
+    w.close()
+    r = run_tool("ckdmip_sw", "--config", "sw.nam", "--ckd", "od_sw.nc", "--output", "fluxes_sw.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    f = _nc(d / "fluxes_sw.nc")
+    tau = np.concatenate([np.zeros((ncol, 1, ng)), np.cumsum(odg + ray, axis=1)], axis=1)                # to the top of every half level
+    for k, mu in enumerate(mu0s):
+        dn = mu * inc[:, None, :] * np.exp(-tau / mu)
+        up = 0.15 * dn[:, -1:, :] * np.exp(-2.0 * (tau[:, -1:, :] - tau))
+        assert np.allclose(f.variables["spectral_flux_dn_direct_sw"][:, k], dn, rtol=3e-6)
+        assert np.allclose(f.variables["spectral_flux_up_sw"][:, k], up, rtol=3e-6)
+        assert np.allclose(f.variables["flux_up_sw"][:, k], up.sum(-1), rtol=3e-6)
+    f.close()
