@@ -222,6 +222,9 @@ def test_find_g_points_sw(ctx, tmp_path):
     assert np.allclose(v["solar_irradiance"][:], solar, rtol=1e-6)
     assert b"shortwave" in f.title
     f.close()
+    # two processes (the four (gas, band) searches dealt two and two): the same file
+    _run_ranks(2, "averaging_method=total-transmission", "sw.cfg", "output=gpoints_sw_2.nc", "part_timeout=300", cwd=d)
+    _same_files(d / "gpoints_sw.nc", d / "gpoints_sw_2.nc")
     # the band loop one band after the other (the reference's order) finds the same g points
     r = run_tool("find_g_points", "averaging_method=total-transmission", "sw.cfg", "output=gpoints_sw_seq.nc", "sequential_bands=1", cwd=d)
     assert r.returncode == 0, r.stderr + r.stdout
