@@ -7,7 +7,8 @@ two restatements by different routes (C in double, here in multi-precision Pytho
 Rows: a2 planck_function, a3 radiative_transfer_lw, a4 radiative_transfer_lw_bb, a5 the shortwave pair, a6 heating_rate,
 a7 the longwave sorting key, a10-a12 fit_optical_depth_lw (all five averaging methods, with the reference's level shift
 in the logarithmic one) + calc_cost_function_lw through CkdEquipartition::calc_error's index mapping, a15 the g-point
-averages of create_look_up_table."""
+averages of create_look_up_table, a17 / a21 the CKD model's optical depths and Planck look-up, a18 the optimiser's cost function
+(longwave and shortwave)."""
 import math
 
 import mpmath as mp
@@ -697,3 +698,84 @@ def test_ckd_optical_depth_planck_and_cost_a17_a18(oracle):
     want = _cost_ckd_lw_mp(M(p[c]), M(pl), M(od_c), M(fd_true), M(fu_true), M(hr_true), M(sfd), M(sfu), cfg, M(lw), M(rel_dn), M(rel_up),
                            list(ib), nband)
     assert got == pytest.approx(float(want), rel=1e-10)
+
+
+def _cost_ckd_sw_mp(mu0, p, ssi, albedo_band, od, flux_dn, flux_up, hr, sfd, sbw, cfg, lw, rel_dn, rel_up, band_of_g, nband):
+    """calc_cost_function_ckd_sw, calc_cost_function_sw.cpp:116-277: direct beam (and, unless every band's albedo is <= 0, the
+    surface-reflected flux with the band's albedo), band sums, heating rate from the DOWNWELLING flux alone (:198), twenty-fold
+    weight on the upwelling flux at the top (:215), broadband upwelling terms only if every band has a positive albedo
+    (:249, :261), per-g boundary weights on the surface flux (:269-272)."""
+    nlay, ng = len(od), len(od[0])
+    dn = [[mu0 * s for s in ssi]]
+    for l in range(nlay):
+        dn.append([dn[l][g] * mp.exp(-od[l][g] / mu0) for g in range(ng)])
+    up = [[mp.mpf(0)] * ng for _ in range(nlay + 1)]
+    if not all(a <= 0 for a in albedo_band):
+        up[nlay] = [dn[nlay][g] * albedo_band[band_of_g[g]] for g in range(ng)]
+        for l in range(nlay - 1, -1, -1):
+            up[l] = [up[l + 1][g] * mp.exp(-2 * od[l][g]) for g in range(ng)]
+    if rel_dn is not None:
+        dn = [[dn[i][g] - rel_dn[i][g] for g in range(ng)] for i in range(nlay + 1)]
+        up = [[up[i][g] - rel_up[i][g] for g in range(ng)] for i in range(nlay + 1)]
+    bdn = [[mp.fsum(dn[i][g] for g in range(ng) if band_of_g[g] == b) for b in range(nband)] for i in range(nlay + 1)]
+    bup = [[mp.fsum(up[i][g] for g in range(ng) if band_of_g[g] == b) for b in range(nband)] for i in range(nlay + 1)]
+    hrf = heating_rate_mp(p, bdn)
+    w = mp.mpf(3600 * 24)
+    fw, fpw, bw = (mp.mpf(cfg[k]) for k in ("flux_weight", "flux_profile_weight", "broadband_weight"))
+    iw = [fpw * mp.mpf("0.5") * (lw[l] + lw[l + 1]) for l in range(nlay - 1)]
+    cost = mp.mpf(0)
+    for b in range(nband):
+        cost += w * w * mp.fsum(lw[l] * (hrf[l][b] - hr[l][b]) ** 2 for l in range(nlay)) \
+            + fw * ((bdn[nlay][b] - flux_dn[nlay][b]) ** 2 + 20 * (bup[0][b] - flux_up[0][b]) ** 2)
+        if fpw > 0:
+            cost += mp.fsum(iw[i - 1] * ((bdn[i][b] - flux_dn[i][b]) ** 2 + (bup[i][b] - flux_up[i][b]) ** 2) for i in range(1, nlay))
+    all_pos = all(a > 0 for a in albedo_band)
+    if bw > 0:
+        cost = cost * (1 - bw) / nband + bw * w * w * mp.fsum(lw[l] * mp.fsum(hrf[l][b] - hr[l][b] for b in range(nband)) ** 2 for l in range(nlay))
+        cost += bw * fw * mp.fsum(bdn[nlay][b] - flux_dn[nlay][b] for b in range(nband)) ** 2
+        if all_pos:
+            cost += bw * fw * mp.fsum(bup[0][b] - flux_up[0][b] for b in range(nband)) ** 2
+        if fpw > 0:
+            cost += bw * mp.fsum(iw[i - 1] * mp.fsum(bdn[i][b] - flux_dn[i][b] for b in range(nband)) ** 2 for i in range(1, nlay))
+            if all_pos:
+                cost += bw * mp.fsum(iw[i - 1] * mp.fsum(bup[i][b] - flux_up[i][b] for b in range(nband)) ** 2 for i in range(1, nlay))
+    if sbw is not None and sfd is not None:
+        cost += mp.fsum(sbw[g] * (dn[nlay][g] - sfd[g]) ** 2 for g in range(ng))
+    return cost
+
+
+@pytest.mark.parametrize("albedo_case", ["all positive", "one band without", "none"])
+def test_ckd_cost_shortwave_a18(oracle, albedo_case):
+    import ctypes as C
+    rs = np.random.RandomState(31)
+    nlay, ng, nband, mu0 = 6, 7, 3, 0.6
+    p = np.sort(rs.uniform(100.0, 1.0e5, nlay + 1))
+    od = 10.0 ** rs.uniform(-2.5, 0.0, (nlay, ng))
+    ssi = rs.uniform(20.0, 300.0, ng)
+    ib = np.array([0, 0, 1, 1, 1, 2, 2])
+    albedo = {"all positive": [0.15, 0.1, 0.2], "one band without": [0.15, 0.0, 0.2], "none": [0.0, 0.0, 0.0]}[albedo_case]
+    albedo = np.array(albedo)
+    band = lambda a: np.stack([a[:, ib == b].sum(-1) for b in range(nband)], axis=-1)
+    if np.all(albedo <= 0):
+        d, u = oracle.radiative_transfer_direct_sw(mu0, ssi, od), np.zeros((nlay + 1, ng))
+    else:
+        d, u = oracle.radiative_transfer_norayleigh_sw(mu0, ssi, od, albedo[ib])
+    fd_true = band(d) * (1 + 0.02 * rs.standard_normal((nlay + 1, nband)))
+    fu_true = band(u) * (1 + 0.02 * rs.standard_normal((nlay + 1, nband))) + 0.01
+    hr_true = oracle.heating_rate(p, fd_true, None)
+    rel_dn, rel_up = 0.05 * d * rs.uniform(0.5, 1.5, d.shape), 0.05 * u * rs.uniform(0.5, 1.5, u.shape)
+    sfd, sbw = d[-1] * rs.uniform(0.9, 1.1, ng), rs.uniform(0.0, 0.05, ng)
+    lw = np.sqrt(p[1:]) - np.sqrt(p[:-1])
+    lw /= lw.sum()
+    cfg = dict(flux_weight=0.2, flux_profile_weight=0.3, broadband_weight=0.4)
+    P, cc = oracle._p, np.ascontiguousarray
+    L = oracle.lib()
+    L.orc_calc_cost_function_ckd_sw.restype = C.c_double
+    got = L.orc_calc_cost_function_ckd_sw(
+        C.c_int(nlay), C.c_int(ng), C.c_int(nband), C.c_double(mu0), P(cc(p)), P(cc(ssi)), P(cc(albedo)), P(cc(od)), P(cc(fd_true)),
+        P(cc(fu_true)), P(cc(hr_true)), P(cc(sfd)), C.c_double(cfg["flux_weight"]), C.c_double(cfg["flux_profile_weight"]),
+        C.c_double(cfg["broadband_weight"]), P(cc(sbw)), P(cc(lw)), P(cc(rel_dn)), P(cc(rel_up)),
+        cc(ib, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int)))
+    want = _cost_ckd_sw_mp(mp.mpf(mu0), M(p), M(ssi), M(albedo), M(od), M(fd_true), M(fu_true), M(hr_true), M(sfd), M(sbw), cfg, M(lw),
+                           M(rel_dn), M(rel_up), list(ib), nband)
+    assert got == pytest.approx(float(want), rel=1e-11)
