@@ -29,7 +29,8 @@ typedef unsigned long long u64;
 constexpr int WINDOW = 32768;
 constexpr int IN_BYTES = 1024;       // two halves of 512 bytes
 constexpr int LIT_BITS = 10, DIST_BITS = 8;
-constexpr size_t IN_SLACK = 2048;    // bytes behind a stream that must be readable (zero or anything)
+constexpr size_t IN_SLACK = 2048;    // bytes behind a stream that must be readable (zero or anything): fetches end below
+                                     // round_up(in_bytes, 512) + 1024
 
 struct StreamDesc {
   u64 in_off, in_bytes;    // zlib stream in the input buffer; in_off is a multiple of 16
@@ -64,7 +65,7 @@ struct Lds {
   Huff<DIST_BITS, 32> dist;
   Huff<7, 19> cl;
   u64 st_buf;      // the bit reader and the output position while a rare, out-of-line step runs (save_state / load_state)
-  u32 st_cnt, st_ipos, st_opos, st_pad;
+  u32 st_cnt, st_ipos, st_opos, st_limit;
   u8 len[384];     // code lengths: [0, 19) the code-length code's, [32, 32 + 286 + 30) the block's (fixed block: [0, 318))
 };
 
@@ -150,12 +151,14 @@ struct Bits {
   u64 buf;
   u32 cnt;
   u32 ipos;
+  u32 limit;      // no input is fetched from byte `limit` on (a multiple of 512 behind the stream's end, inside the slack): a damaged
+                  // stream whose codes keep consuming the zero padding is fed zeros until it runs into one of the decoder's checks
 };
 
 __device__ __forceinline__ void refill(Lds& L, Bits& b, const u8* src, int lane) {
   if (b.cnt <= 32) {
-    if ((b.ipos & 511u) == 0) fetch_half(L, src, b.ipos + 512, lane);
-    const u32 w = uni(L.in[(b.ipos >> 2) & (IN_BYTES / 4 - 1)]);
+    if ((b.ipos & 511u) == 0 && b.ipos + 512 < b.limit) fetch_half(L, src, b.ipos + 512, lane);
+    const u32 w = b.ipos < b.limit ? uni(L.in[(b.ipos >> 2) & (IN_BYTES / 4 - 1)]) : 0u;
     b.buf |= (u64)w << b.cnt;
     b.cnt += 32;
     b.ipos += 4;
@@ -165,7 +168,7 @@ __device__ __forceinline__ void refill(Lds& L, Bits& b, const u8* src, int lane)
 // The rare steps run out of line; handing them the bit reader by reference would pin it in scratch memory for the whole kernel,
 // so it travels through LDS instead.
 __device__ __forceinline__ void save_state(Lds& L, const Bits& b, u32 opos, int lane) {
-  if (lane == 0) { L.st_buf = b.buf; L.st_cnt = b.cnt; L.st_ipos = b.ipos; L.st_opos = opos; }
+  if (lane == 0) { L.st_buf = b.buf; L.st_cnt = b.cnt; L.st_ipos = b.ipos; L.st_opos = opos; L.st_limit = b.limit; }
   __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ void load_state(Lds& L, Bits& b, u32& opos) {
@@ -174,14 +177,15 @@ __device__ __forceinline__ void load_state(Lds& L, Bits& b, u32& opos) {
   b.buf = ((u64)hi << 32) | lo;
   b.cnt = uni(L.st_cnt);
   b.ipos = uni(L.st_ipos);
+  b.limit = uni(L.st_limit);
   opos = uni(L.st_opos);
 }
 
 // continue reading at byte `at` (behind a stored block)
 __device__ __forceinline__ void reposition(Lds& L, Bits& b, const u8* src, u32 at, int lane) {
   const u32 word = at & ~3u;
-  fetch_half(L, src, word & ~511u, lane);
-  if (word & 511u) fetch_half(L, src, (word & ~511u) + 512, lane);   // else refill() fetches it when it takes the first word
+  if ((word & ~511u) < b.limit) fetch_half(L, src, word & ~511u, lane);
+  if ((word & 511u) && (word & ~511u) + 512 < b.limit) fetch_half(L, src, (word & ~511u) + 512, lane);   // else refill() fetches it with the first word
   b.buf = 0; b.cnt = 0; b.ipos = word;
   refill(L, b, src, lane);
   const u32 drop = 8 * (at & 3u);
@@ -313,6 +317,7 @@ k_inflate(int nstreams, const u8* __restrict__ in, const StreamDesc* __restrict_
 
   Bits b;
   b.buf = 0; b.cnt = 0; b.ipos = 0;
+  b.limit = ((in_bytes + 511u) & ~511u) + 512u;        // < in_bytes + IN_SLACK: every fetch stays inside the stream's slack
   fetch_half(L, src, 0, lane);
   refill(L, b, src, lane);
   // RFC 1950: CMF (method 8, window <= 32 KB), FLG (check bits, no preset dictionary)

@@ -87,3 +87,46 @@ def test_damaged_streams_are_reported(ctx):
     assert status[2] != 0                       # input exhausted / bad code in the padding
     assert status[3] == 5                       # more output than expected
     assert status[4] == 6                       # less
+
+
+def test_corrupted_streams_never_run_away(ctx):
+    """Bit flips, truncations and garbage: every stream of the launch comes back with a verdict - output is never written
+    beyond the expected size and input never fetched beyond the stream's slack, whatever the codes say (a stream whose
+    damaged codes keep consuming input is fed zeros behind its end until a check stops it).  Where zlib still accepts the
+    damaged stream, the bytes are zlib's; the Adler-32 trailer is not verified here, so a stream that only zlib's checksum
+    rejects may pass."""
+    from ecckd_amd import api
+    rs = np.random.RandomState(13)
+    base = [_shuffled_floats(20_000, 50), b"abcdefgh" * 4000, rs.bytes(9000), bytes(30_000)]
+    streams, want_len, expect = [], [], []
+    for k in range(240):
+        raw = base[k % len(base)]
+        z = bytearray(zlib.compress(raw, [1, 6, 9][k % 3]))
+        kind = k % 4
+        if kind == 0:                                   # flip a few bits somewhere behind the header
+            for _ in range(1 + k % 3):
+                pos = rs.randint(2, len(z))
+                z[pos] ^= 1 << rs.randint(8)
+        elif kind == 1:                                 # cut the stream short
+            z = z[:rs.randint(2, len(z))]
+        elif kind == 2:                                 # garbage with a valid header
+            z = bytearray(b"\x78\x9c") + bytearray(rs.bytes(rs.randint(1, 3000)))
+        else:                                           # a one-bit code that would produce output for ever: all-zero payload
+            z = bytearray(b"\x78\x9c") + bytearray(rs.randint(1, 600))
+        n = len(raw) if k % 5 else len(raw) + rs.randint(-50, 50)
+        streams.append(bytes(z))
+        want_len.append(max(n, 0))
+        try:
+            good = zlib.decompress(bytes(z))
+        except zlib.error:
+            good = None
+        expect.append(good)
+    out, status = api.inflate(ctx, streams, want_len)
+    nbad = 0
+    for k in range(len(streams)):
+        if expect[k] is not None and len(expect[k]) == want_len[k]:
+            assert status[k] == 0 and out[k] == expect[k], k
+        elif expect[k] is not None:
+            assert status[k] in (5, 6), (k, status[k])          # a valid stream of another length
+        nbad += status[k] != 0
+    assert nbad > 150
