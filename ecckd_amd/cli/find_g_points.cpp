@@ -147,6 +147,7 @@ int main(int argc, char** argv) {
     if (method < 0) fail(ECCKD_PARAMETER_ERROR, "Averaging method \"%s\" not understood", averaging_method.c_str());
 
     Device dev;
+    dev.enable_od_cache();       // a gas's spectrum is the target once and part of the other gases' backgrounds: read once
     const int world = std::max(1, env_int("WORLD_SIZE", 1)), my_rank = env_int("RANK", 0);
     if (my_rank < 0 || my_rank >= world) fail(ECCKD_PARAMETER_ERROR, "RANK=%d outside WORLD_SIZE=%d", my_rank, world);
     const std::vector<std::string> gas_list = config.read_list("gases");

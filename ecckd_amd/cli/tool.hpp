@@ -5,6 +5,8 @@
 // C ABI of include/ecckd_hip.h - the tools never touch HIP themselves.
 #pragma once
 #include <algorithm>
+#include <climits>
+#include <map>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -363,13 +365,40 @@ class Device {
     else if (const char* l = std::getenv("LOCAL_RANK")) dev = std::atoi(l);
     ck(ecckd_init(dev, &ctx_));
   }
-  ~Device() { if (ctx_) ecckd_destroy(ctx_); }
+  ~Device() {
+    for (auto& kv : od_cache_) ecckd_dev_free(ctx_, kv.second.ptr);
+    if (ctx_) ecckd_destroy(ctx_);
+  }
   Device(const Device&) = delete;
   Device& operator=(const Device&) = delete;
   ecckd_ctx* ctx() const { return ctx_; }
 
+  // Optical-depth slices that stay on the device for the life of the process, keyed by file and profile: find_g_points reads
+  // the spectrum of every gas once as the target and once more in the background of every other gas (the reference reads
+  // the files again each time, read_merged_spectrum.cpp:63-100).  ECCKD_OD_CACHE_GB: the budget (default 64, 0 = off);
+  // slices beyond it are read as before and owned by their reader.
+  struct CachedOd { void* ptr; size_t bytes; int type; };
+  const CachedOd* od_cache_find(const std::string& key) const {
+    auto it = od_cache_.find(key);
+    return it == od_cache_.end() ? nullptr : &it->second;
+  }
+  void enable_od_cache() { od_cache_on_ = true; }     // for a tool that reads the same slices again (find_g_points)
+  bool od_cache_room(size_t bytes) const {
+    if (!od_cache_on_) return false;
+    double gb = 64.0;
+    if (const char* e = std::getenv("ECCKD_OD_CACHE_GB")) gb = std::atof(e);
+    return (double)(od_cache_bytes_ + bytes) <= gb * 1073741824.0;
+  }
+  void od_cache_put(const std::string& key, void* ptr, size_t bytes, int type) const {
+    od_cache_[key] = CachedOd{ptr, bytes, type};
+    od_cache_bytes_ += bytes;
+  }
+
  private:
   ecckd_ctx* ctx_ = nullptr;
+  mutable std::map<std::string, CachedOd> od_cache_;
+  mutable size_t od_cache_bytes_ = 0;
+  bool od_cache_on_ = false;
 };
 
 class DevBuf {
@@ -379,18 +408,26 @@ class DevBuf {
   ~DevBuf() { release(); }
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : ctx_(o.ctx_), p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; }
+  DevBuf(DevBuf&& o) noexcept : ctx_(o.ctx_), p_(o.p_), bytes_(o.bytes_), owned_(o.owned_) { o.p_ = nullptr; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); ctx_ = o.ctx_; p_ = o.p_; bytes_ = o.bytes_; o.p_ = nullptr; }
+    if (this != &o) { release(); ctx_ = o.ctx_; p_ = o.p_; bytes_ = o.bytes_; owned_ = o.owned_; o.p_ = nullptr; }
     return *this;
+  }
+  // a view of memory that something else owns (the Device's cache of optical-depth slices): release() only forgets it
+  static DevBuf view(ecckd_ctx* ctx, void* p, size_t bytes) {
+    DevBuf b;
+    b.ctx_ = ctx; b.p_ = p; b.bytes_ = bytes; b.owned_ = false;
+    return b;
   }
   void alloc(const Device& d, size_t bytes) {
     release();
     ctx_ = d.ctx();
     bytes_ = bytes;
+    owned_ = true;
     ck(ecckd_dev_alloc(ctx_, bytes ? bytes : 8, &p_));
   }
-  void release() { if (p_) { ecckd_dev_free(ctx_, p_); p_ = nullptr; } }
+  void release() { if (p_ && owned_) ecckd_dev_free(ctx_, p_); p_ = nullptr; owned_ = true; }
+  size_t bytes() const { return bytes_; }
   template <class T> void upload(const Device& d, const std::vector<T>& v) {
     alloc(d, v.size() * sizeof(T));
     if (!v.empty()) ck(ecckd_h2d(ctx_, p_, v.data(), v.size() * sizeof(T)));
@@ -408,6 +445,7 @@ class DevBuf {
   ecckd_ctx* ctx_ = nullptr;
   void* p_ = nullptr;
   size_t bytes_ = 0;
+  bool owned_ = true;
 };
 
 // optical depth to the device: FLOAT as stored when the file holds FLOAT, DOUBLE otherwise
@@ -439,7 +477,26 @@ inline DevOd read_od_dev(const Device& d, const NcIn& f, int iprofile, int nlay,
     fail(ECCKD_PARAMETER_ERROR, "optical_depth in %s is not (column, level, wavenumber)", f.path().c_str());
   DevOd out;
   out.type = type == NC_FLOAT_T ? ECCKD_F32 : ECCKD_F64;
-  out.buf.alloc(d, n * (size_t)out.type);
+  const size_t bytes = n * (size_t)out.type;
+  char resolved[PATH_MAX];
+  const std::string key = std::string(realpath(f.path().c_str(), resolved) ? resolved : f.path().c_str()) + "#" + std::to_string(iprofile);
+  if (const Device::CachedOd* hit = d.od_cache_find(key)) {
+    if (hit->bytes == bytes && hit->type == out.type) {
+      LOG("    (optical depths already on the device)\n");
+      out.buf = DevBuf::view(d.ctx(), hit->ptr, bytes);
+      return out;
+    }
+  }
+  if (d.od_cache_room(bytes)) {
+    void* p = nullptr;
+    ck(ecckd_dev_alloc(d.ctx(), bytes, &p));
+    const int rc = ecckd_nc_read_dev(d.ctx(), f.handle(), "optical_depth", iprofile, out.type, p, n);
+    if (rc != ECCKD_OK) { ecckd_dev_free(d.ctx(), p); ck(rc); }
+    d.od_cache_put(key, p, bytes, out.type);
+    out.buf = DevBuf::view(d.ctx(), p, bytes);
+    return out;
+  }
+  out.buf.alloc(d, bytes);
   ck(ecckd_nc_read_dev(d.ctx(), f.handle(), "optical_depth", iprofile, out.type, out.buf.ptr(), n));
   return out;
 }
