@@ -1076,7 +1076,27 @@ k_cost_lw(int nlay, RowMap R, const Interval* __restrict__ iv, long long nchunks
 // for the total-transmission method the per-point direct fluxes that
 // fit_optical_depth_sw_total_trans sums (:171-204) plus the two scaled "truth" fields
 // (:1011-1034, :1060-1090).  One thread per sorted wavenumber.
-template <typename BgT, typename OdT>
+// the sums of up to sixteen rows over a wave's 64 points: `tile` is the wave's [16][65] LDS tile (slot, point), `rows` the
+// table row of every slot.  Out of line: the preparation kernel calls it from every one of its pushes.
+__device__ __noinline__ void sw_flush_row_sums(const double* tile, const int* rows, double* __restrict__ wave_part, size_t nw,
+                                               size_t wid, int count, int lane) {
+  const int rr = lane & 15, qq = lane >> 4;
+  __builtin_amdgcn_wave_barrier();
+  double sum = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) sum += tile[rr * 65 + qq * 16 + q];
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  if (qq == 0 && rr < count && wid < nw) wave_part[(size_t)rows[rr] * nw + wid] = sum;
+  __builtin_amdgcn_wave_barrier();
+}
+
+// COLS: bg_src / od_src are the rank-scattered columns [n][nlay] (k_scatter_columns), read contiguously per point, instead of
+// the (level, wavenumber) matrices gathered through ireorder (108 random 4-byte reads per point).  wave_part != NULL: the sums
+// over each wave's 64 points of every row of the table (RowMap R) are formed while the values are in registers - sixteen
+// rows at a time through a wave-private transposed LDS tile, as in k_gas_prep_lw_mirror - and k_combine_wave_sums turns
+// them into the tile sums that k_tile_sums otherwise makes by reading all rows again.
+template <typename BgT, typename OdT, bool COLS>
 __global__ void __launch_bounds__(PREP_THREADS)
 k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza, double min_scaling,
               double max_scaling, const int32_t* __restrict__ ireorder, const double* __restrict__ conv,
@@ -1086,69 +1106,114 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
               double* __restrict__ w2, double* __restrict__ cnt, double* __restrict__ hr,
               double* __restrict__ fds, double* __restrict__ fut, double* __restrict__ tf,
               double* __restrict__ tg, double* __restrict__ hr_low, double* __restrict__ hr_high,
-              double* __restrict__ fx) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+              double* __restrict__ fx, RowMap R, double* __restrict__ wave_part, size_t nw) {
+  constexpr int ROWW = 65;
+  __shared__ double s_sum[COLS ? 4 : 1][COLS ? 16 * ROWW : 1];
+  __shared__ int s_row[COLS ? 4 : 1][16];
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i0 < n;
+  if (!COLS && !live) return;
+  const size_t i = live ? i0 : n - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t wid = (size_t)blockIdx.x * 4 + wave;
+  int slot = 0;
+  auto flush = [&](int count) { sw_flush_row_sums(s_sum[COLS ? wave : 0], s_row[COLS ? wave : 0], wave_part, nw, wid, count, lane); };
+  auto push = [&](int row, double v) {
+    if (!COLS || !wave_part) return;
+    s_sum[COLS ? wave : 0][(slot & 15) * ROWW + lane] = live ? v : 0.0;
+    s_row[COLS ? wave : 0][slot & 15] = row;
+    if ((slot & 15) == 15) flush(16);
+    ++slot;
+  };
   const size_t j = (size_t)ireorder[i];
   const bool is_log = method == ECCKD_AVG_LOGARITHMIC;
   const bool is_tt = method == ECCKD_AVG_TOTAL_TRANSMISSION;
   const double s = ssi_src[j];
-  ssi_s[i] = s;
+  if (live) ssi_s[i] = s;
   const double minus_sec_sza = -1.0 / cos_sza;
   double flux = cos_sza * s;
   double fl_low = flux, fl_high = flux;
   double tfv = s, tgv = s;  // :178-179 start from ssi, not cos_sza*ssi
   // inputs are fetched eight layers at a time, ahead of that chunk's stores: a load issued after a store waits for the
   // store to complete on this hardware, so one load per layer would cost one store latency per layer
-  constexpr int CH = 8;
-  for (int l0 = 0; l0 < nlay; l0 += CH) {
-  double bgv[CH], odv[CH];
+  // and the NEXT chunk's inputs are requested before this chunk's stores are issued, so that the wait for them (which includes
+  // the stores of the chunk before) overlaps this chunk's arithmetic
+  constexpr int CH = 9;
+  BgT bgn[CH];
+  OdT odn[CH];
+  auto fetch = [&](int l0) {
 #pragma unroll
-  for (int q = 0; q < CH; ++q) {
-    const int lq = l0 + q < nlay ? l0 + q : nlay - 1;
-    bgv[q] = bg_src ? (double)bg_src[(size_t)lq * src_stride + j] : 0.0;
-    odv[q] = (double)od_src[(size_t)lq * src_stride + j];
-  }
+    for (int q = 0; q < CH; ++q) {
+      const int lq = l0 + q < nlay ? l0 + q : nlay - 1;
+      bgn[q] = bg_src ? bg_src[COLS ? i * (size_t)nlay + lq : (size_t)lq * src_stride + j] : (BgT)0;
+      odn[q] = od_src[COLS ? i * (size_t)nlay + lq : (size_t)lq * src_stride + j];
+    }
+  };
+  fetch(0);
+  for (int l0 = 0; l0 < nlay; l0 += CH) {
+  BgT bgv[CH];
+  OdT odv[CH];
+#pragma unroll
+  for (int q = 0; q < CH; ++q) { bgv[q] = bgn[q]; odv[q] = odn[q]; }
+  if (l0 + CH < nlay) fetch(l0 + CH);
 #pragma unroll
   for (int q = 0; q < CH; ++q) {
     const int l = l0 + q;
     if (l >= nlay) break;
-    const double bg = bgv[q];
-    const double od = odv[q];
+    const double bg = (double)bgv[q];
+    const double od = (double)odv[q];
     const size_t o = (size_t)l * n + i;
-    bg_od[o] = bg;
-    const double flux_next = flux * exp(minus_sec_sza * (bg + od));
-    hr[o] = conv[l] * (flux_next - flux);
+    if (live) __builtin_nontemporal_store(bg, &bg_od[o]);      // written once, read by later kernels: streaming stores
+    const double flux_next = flux * ecckd::exp_fast(minus_sec_sza * (bg + od));
+    const double hrv = conv[l] * (flux_next - flux);
+    if (live) __builtin_nontemporal_store(hrv, &hr[o]);
+    push(R.H + l, hrv);
     flux = flux_next;
-    const double m = metric_of(method, od);
+    double m = od;                       // find_g_points.cpp:1119-1150: linear, logarithmic, total-transmission
+    if (method == ECCKD_AVG_TRANSMISSION) m = 1.0 - ecckd::exp_fast(-od * kD);
+    else if (method == ECCKD_AVG_TRANSMISSION_2) m = 1.0 - ecckd::exp_fast(-od * kD * 2.0);
+    else if (method == ECCKD_AVG_SQUARE_ROOT) m = sqrt(od);
     if (!is_log) {
-      w1[o] = m * s;
+      const double a = m * s;
+      if (live) __builtin_nontemporal_store(a, &w1[o]);
+      push(R.A + l, a);
+      push(R.B + l, s);
     } else {
       const bool pos = m > 0.0;
-      w1[o] = pos ? log(m) * s : 0.0;
-      w2[o] = pos ? s : 0.0;
-      cnt[o] = pos ? 1.0 : 0.0;
+      const double a = pos ? log(m) * s : 0.0, b = pos ? s : 0.0, c = pos ? 1.0 : 0.0;
+      if (live) { __builtin_nontemporal_store(a, &w1[o]); __builtin_nontemporal_store(b, &w2[o]); __builtin_nontemporal_store(c, &cnt[o]); }
+      push(R.A + l, a);
+      push(R.B + l, b);
+      push(R.N + l, c);
     }
     if (is_tt) {
       // :191-192
-      tgv *= exp(-2.0 * bg);
-      tfv *= exp(-2.0 * (bg + od));
-      tg[o] = tgv;
-      tf[o] = tfv;
-      const double lo_next = fl_low * exp(minus_sec_sza * (bg + min_scaling * od));
-      hr_low[o] = conv[l] * (lo_next - fl_low);
+      tgv *= ecckd::exp_fast(-2.0 * bg);
+      tfv *= ecckd::exp_fast(-2.0 * (bg + od));
+      const double lo_next = fl_low * ecckd::exp_fast(minus_sec_sza * (bg + min_scaling * od));
+      const double hl = conv[l] * (lo_next - fl_low);
       fl_low = lo_next;
-      const double hi_next = fl_high * exp(minus_sec_sza * (bg + max_scaling * od));
-      hr_high[o] = conv[l] * (hi_next - fl_high);
+      const double hi_next = fl_high * ecckd::exp_fast(minus_sec_sza * (bg + max_scaling * od));
+      const double hh = conv[l] * (hi_next - fl_high);
       fl_high = hi_next;
+      if (live) {
+        __builtin_nontemporal_store(tgv, &tg[o]); __builtin_nontemporal_store(tfv, &tf[o]);
+        __builtin_nontemporal_store(hl, &hr_low[o]); __builtin_nontemporal_store(hh, &hr_high[o]);
+      }
+      push(R.TG + l, tgv);
+      push(R.TF + l, tfv);
+      push(R.HL + l, hl);
+      push(R.HH + l, hh);
     }
   }
   }
-  fds[i] = flux;
-  fut[i] = 0.0;  // find_g_points.cpp:1047-1050: no upwelling in the base truth
+  if (live) {
+    fds[i] = flux;
+    fut[i] = 0.0;  // find_g_points.cpp:1047-1050: no upwelling in the base truth
+  }
+  push(R.FDS, flux);
+  push(R.FUT, 0.0);
   if (is_tt) {
-    fx[i] = fl_low;
-    fx[2 * n + i] = fl_high;
     double up_low = 0.0, up_high = 0.0;
     if (albedo_src) {
       // radiative_transfer_norayleigh_sw (radiative_transfer_sw.cpp:72-76), two-stream secant 2
@@ -1156,15 +1221,24 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
       up_low = fl_low * alb;
       up_high = fl_high * alb;
       for (int l = nlay - 1; l >= 0; --l) {
-        const double bg = bg_src ? (double)bg_src[(size_t)l * src_stride + j] : 0.0;
-        const double od = (double)od_src[(size_t)l * src_stride + j];
-        up_low = up_low * exp(-2.0 * (bg + min_scaling * od));
-        up_high = up_high * exp(-2.0 * (bg + max_scaling * od));
+        const double bg = bg_src ? (double)bg_src[COLS ? i * (size_t)nlay + l : (size_t)l * src_stride + j] : 0.0;
+        const double od = (double)od_src[COLS ? i * (size_t)nlay + l : (size_t)l * src_stride + j];
+        up_low = up_low * ecckd::exp_fast(-2.0 * (bg + min_scaling * od));
+        up_high = up_high * ecckd::exp_fast(-2.0 * (bg + max_scaling * od));
       }
     }
-    fx[n + i] = up_low;
-    fx[3 * n + i] = up_high;
+    if (live) {
+      fx[i] = fl_low;
+      fx[2 * n + i] = fl_high;
+      fx[n + i] = up_low;
+      fx[3 * n + i] = up_high;
+    }
+    push(R.FDSL, fl_low);
+    push(R.FUTL, up_low);
+    push(R.FDSH, fl_high);
+    push(R.FUTH, up_high);
   }
+  if (COLS && wave_part && (slot & 15)) flush(slot & 15);
 }
 
 // K5b-SW: fit_optical_depth_sw (find_g_points.cpp:112-165) and
@@ -2002,20 +2076,6 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
       return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_gas_create_sw: rank is not a permutation of 0..nwav-1");
     }
   }
-  const unsigned pblocks = (unsigned)((nwav + PREP_THREADS - 1) / PREP_THREADS);
-#define LAUNCH_PREP_SW(BG, OD)                                                                                  \
-  hipLaunchKernelGGL((k_gas_prep_sw<BG, OD>), dim3(pblocks), dim3(PREP_THREADS), 0, ctx->stream, nlay, nwav,    \
-                     src_stride, averaging_method, cos_sza, min_scaling, max_scaling, g->ireorder,              \
-                     g->lev + nhl, d_ssi, d_albedo, (const BG*)d_bg_od, (const OD*)d_od, g->ssi, g->bg_od,      \
-                     g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut, g->tf, g->tg, g->hr_low, g->hr_high, g->fx)
-  const bool bg32 = d_bg_od && bg_type == ECCKD_F32;
-  if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP_SW(float, float);
-  else if (bg32) LAUNCH_PREP_SW(float, double);
-  else if (od_type == ECCKD_F32) LAUNCH_PREP_SW(double, float);
-  else LAUNCH_PREP_SW(double, double);
-#undef LAUNCH_PREP_SW
-  GTRY(hipGetLastError());
-
   RowMap R;
   int next = 0;
   R.A = next; next += nlay;
@@ -2034,6 +2094,53 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   R.total = next;
   g->rm = R;
   g->nrows = R.total;
+
+  const unsigned pblocks = (unsigned)((nwav + PREP_THREADS - 1) / PREP_THREADS);
+  const bool bg32 = d_bg_od && bg_type == ECCKD_F32;
+  // 54 layers of FLOAT optical depths (the CKDMIP spectra): the columns are scattered into rank order first, read
+  // contiguously by the preparation, and the row sums are taken from registers (ECCKD_SW_PREP_GATHER: the gathering path)
+  const bool cols = nlay == 54 && od_type == ECCKD_F32 && std::getenv("ECCKD_SW_PREP_GATHER") == nullptr;
+  void *od_col = nullptr, *bg_col = nullptr, *wave_part = nullptr;
+  auto drop_temps = [&]() {
+    if (od_col) ecckd::dev_release(ctx, od_col);
+    if (bg_col) ecckd::dev_release(ctx, bg_col);
+    if (wave_part) ecckd::dev_release(ctx, wave_part);
+    od_col = bg_col = wave_part = nullptr;
+  };
+  const size_t nw64 = (nwav + 63) / 64;
+#define LAUNCH_PREP_SW(BG, OD, COLS, BGP, ODP, WP)                                                                \
+  hipLaunchKernelGGL((k_gas_prep_sw<BG, OD, COLS>), dim3(pblocks), dim3(PREP_THREADS), 0, ctx->stream, nlay, nwav, \
+                     src_stride, averaging_method, cos_sza, min_scaling, max_scaling, g->ireorder,                 \
+                     g->lev + nhl, d_ssi, d_albedo, (const BG*)(BGP), (const OD*)(ODP), g->ssi, g->bg_od,          \
+                     g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut, g->tf, g->tg, g->hr_low, g->hr_high, g->fx, R,   \
+                     (double*)(WP), nw64)
+  if (cols) {
+    const unsigned tblocks = (unsigned)((nwav + 63) / 64);
+    int rc2 = ecckd::dev_malloc(ctx, &od_col, (size_t)nwav * 54 * sizeof(float));
+    if (rc2 == ECCKD_OK && d_bg_od) rc2 = ecckd::dev_malloc(ctx, &bg_col, (size_t)nwav * 54 * (bg32 ? sizeof(float) : sizeof(double)));
+    if (rc2 == ECCKD_OK) rc2 = ecckd::dev_malloc(ctx, &wave_part, (size_t)g->nrows * nw64 * sizeof(double));
+    if (rc2 != ECCKD_OK) { drop_temps(); gas_free(g); return rc2; }
+    hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
+                       (const float*)d_od, (float*)od_col);
+    if (d_bg_od && bg32)
+      hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
+                         (const float*)d_bg_od, (float*)bg_col);
+    else if (d_bg_od)
+      hipLaunchKernelGGL((k_scatter_columns<54, double>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
+                         (const double*)d_bg_od, (double*)bg_col);
+    if (bg32 || !d_bg_od) LAUNCH_PREP_SW(float, float, true, bg_col, od_col, wave_part);
+    else LAUNCH_PREP_SW(double, float, true, bg_col, od_col, wave_part);
+  }
+  else if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP_SW(float, float, false, d_bg_od, d_od, nullptr);
+  else if (bg32) LAUNCH_PREP_SW(float, double, false, d_bg_od, d_od, nullptr);
+  else if (od_type == ECCKD_F32) LAUNCH_PREP_SW(double, float, false, d_bg_od, d_od, nullptr);
+  else LAUNCH_PREP_SW(double, double, false, d_bg_od, d_od, nullptr);
+#undef LAUNCH_PREP_SW
+  {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); drop_temps(); GTRY(e); }
+  }
+
   std::vector<const double*> rows(g->nrows);
   for (int l = 0; l < nlay; ++l) {
     rows[R.A + l] = g->w1 + (size_t)l * nwav;
@@ -2059,10 +2166,23 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   GTRY(hipMemcpyAsync((void*)g->rows, rows.data(), rows.size() * sizeof(double*), hipMemcpyHostToDevice, ctx->stream));
   GTRY(hipStreamSynchronize(ctx->stream));
   g->ntiles = (nwav + TILE - 1) / TILE;
-  GTRY(ecckd::dev_malloc(ctx, (void**)&g->tile_sums, (size_t)g->nrows * g->ntiles * sizeof(double)));
-  hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)g->ntiles), dim3(TILE), 0, ctx->stream, g->nrows, nwav, g->ntiles,
-                     (const double* const*)g->rows, g->tile_sums);
-  GTRY(hipGetLastError());
+  {
+    const int rc3 = ecckd::dev_malloc(ctx, (void**)&g->tile_sums, (size_t)g->nrows * g->ntiles * sizeof(double));
+    if (rc3 != ECCKD_OK) { (void)hipStreamSynchronize(ctx->stream); drop_temps(); gas_free(g); return rc3; }
+  }
+  if (wave_part) {
+    hipLaunchKernelGGL(k_combine_wave_sums, dim3((unsigned)((g->ntiles + 255) / 256), (unsigned)g->nrows), dim3(256), 0, ctx->stream,
+                       g->nrows, nw64, g->ntiles, (const double*)wave_part, g->tile_sums);
+  } else {
+    hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)g->ntiles), dim3(TILE), 0, ctx->stream, g->nrows, nwav, g->ntiles,
+                       (const double* const*)g->rows, g->tile_sums);
+  }
+  {
+    const hipError_t e = hipGetLastError();
+    (void)hipStreamSynchronize(ctx->stream);
+    drop_temps();
+    GTRY(e);
+  }
   g->nsuper = (g->ntiles + SUPER - 1) / SUPER;
   GTRY(ecckd::dev_malloc(ctx, (void**)&g->super_sums, (size_t)g->nrows * g->nsuper * sizeof(double)));
   hipLaunchKernelGGL(k_super_sums, dim3((unsigned)g->nsuper, (unsigned)g->nrows), dim3(256), 0, ctx->stream, g->ntiles, g->nsuper,
