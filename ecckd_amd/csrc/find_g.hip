@@ -1076,16 +1076,19 @@ k_cost_lw(int nlay, RowMap R, const Interval* __restrict__ iv, long long nchunks
 // for the total-transmission method the per-point direct fluxes that
 // fit_optical_depth_sw_total_trans sums (:171-204) plus the two scaled "truth" fields
 // (:1011-1034, :1060-1090).  One thread per sorted wavenumber.
-// the sums of up to sixteen rows over a wave's 64 points: `tile` is the wave's [16][65] LDS tile (slot, point), `rows` the
-// table row of every slot.  Out of line: the preparation kernel calls it from every one of its pushes.
-__device__ __noinline__ void sw_flush_row_sums(const double* tile, const int* rows, double* __restrict__ wave_part, size_t nw,
-                                               size_t wid, int count, int lane) {
-  const int rr = lane & 15, qq = lane >> 4;
+// the sums of up to SW_TILE_ROWS rows over a wave's 64 points: `tile` is the wave's [SW_TILE_ROWS][65] LDS tile (slot, point),
+// `rows` the table row of every slot.  Inlined at its few call sites (one per three layers): a call would start with a wait for
+// every store the wave has in flight.
+constexpr int SW_TILE_ROWS = 24, SW_TILE_W = 65;
+__device__ __forceinline__ void sw_flush_row_sums(const double* tile, const int* rows, double* __restrict__ wave_part, size_t nw,
+                                                  size_t wid, int count, int lane) {
+  const int rr = lane & 31, qq = lane >> 5;
   __builtin_amdgcn_wave_barrier();
   double sum = 0.0;
+  if (rr < count) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) sum += tile[rr * 65 + qq * 16 + q];
-  sum += __shfl_xor(sum, 16, 64);
+    for (int q = 0; q < 32; ++q) sum += tile[rr * SW_TILE_W + qq * 32 + q];
+  }
   sum += __shfl_xor(sum, 32, 64);
   if (qq == 0 && rr < count && wid < nw) wave_part[(size_t)rows[rr] * nw + wid] = sum;
   __builtin_amdgcn_wave_barrier();
@@ -1107,9 +1110,9 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
               double* __restrict__ fds, double* __restrict__ fut, double* __restrict__ tf,
               double* __restrict__ tg, double* __restrict__ hr_low, double* __restrict__ hr_high,
               double* __restrict__ fx, RowMap R, double* __restrict__ wave_part, size_t nw) {
-  constexpr int ROWW = 65;
-  __shared__ double s_sum[COLS ? 4 : 1][COLS ? 16 * ROWW : 1];
-  __shared__ int s_row[COLS ? 4 : 1][16];
+  constexpr int ROWW = SW_TILE_W;
+  __shared__ double s_sum[COLS ? 4 : 1][COLS ? SW_TILE_ROWS * ROWW : 1];
+  __shared__ int s_row[COLS ? 4 : 1][SW_TILE_ROWS];
   const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i0 < n;
   if (!COLS && !live) return;
@@ -1117,12 +1120,16 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t wid = (size_t)blockIdx.x * 4 + wave;
   int slot = 0;
-  auto flush = [&](int count) { sw_flush_row_sums(s_sum[COLS ? wave : 0], s_row[COLS ? wave : 0], wave_part, nw, wid, count, lane); };
+  // at most seven rows a layer, flushed every three layers
+  auto flush = [&]() {
+    if (!COLS || !wave_part) return;
+    sw_flush_row_sums(s_sum[COLS ? wave : 0], s_row[COLS ? wave : 0], wave_part, nw, wid, slot, lane);
+    slot = 0;
+  };
   auto push = [&](int row, double v) {
     if (!COLS || !wave_part) return;
-    s_sum[COLS ? wave : 0][(slot & 15) * ROWW + lane] = live ? v : 0.0;
-    s_row[COLS ? wave : 0][slot & 15] = row;
-    if ((slot & 15) == 15) flush(16);
+    s_sum[COLS ? wave : 0][slot * ROWW + lane] = live ? v : 0.0;
+    s_row[COLS ? wave : 0][slot] = row;
     ++slot;
   };
   const size_t j = (size_t)ireorder[i];
@@ -1141,11 +1148,20 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
   constexpr int CH = 9;
   BgT bgn[CH];
   OdT odn[CH];
+  // no background: the loads still happen (from the target's own array, same shape, when its elements are at least as wide)
+  // and their values are dropped - a branch round each load would put a full wait behind it
+  const bool has_bg = bg_src != nullptr;
+  constexpr bool BG_ALIAS = sizeof(BgT) <= sizeof(OdT);
+  const BgT* __restrict__ bsrc = (has_bg || !BG_ALIAS) ? bg_src : reinterpret_cast<const BgT*>(od_src);
+  auto load_bg = [&](size_t at) -> BgT {
+    if (BG_ALIAS) { const BgT v = bsrc[at]; return has_bg ? v : (BgT)0; }
+    return has_bg ? bg_src[at] : (BgT)0;
+  };
   auto fetch = [&](int l0) {
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
       const int lq = l0 + q < nlay ? l0 + q : nlay - 1;
-      bgn[q] = bg_src ? bg_src[COLS ? i * (size_t)nlay + lq : (size_t)lq * src_stride + j] : (BgT)0;
+      bgn[q] = load_bg(COLS ? i * (size_t)nlay + lq : (size_t)lq * src_stride + j);
       odn[q] = od_src[COLS ? i * (size_t)nlay + lq : (size_t)lq * src_stride + j];
     }
   };
@@ -1205,7 +1221,9 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
       push(R.HL + l, hl);
       push(R.HH + l, hh);
     }
+    if (q % 3 == 2) flush();
   }
+  flush();
   }
   if (live) {
     fds[i] = flux;
@@ -1220,11 +1238,29 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
       const double alb = albedo_src[j];
       up_low = fl_low * alb;
       up_high = fl_high * alb;
-      for (int l = nlay - 1; l >= 0; --l) {
-        const double bg = bg_src ? (double)bg_src[COLS ? i * (size_t)nlay + l : (size_t)l * src_stride + j] : 0.0;
-        const double od = (double)od_src[COLS ? i * (size_t)nlay + l : (size_t)l * src_stride + j];
-        up_low = up_low * ecckd::exp_fast(-2.0 * (bg + min_scaling * od));
-        up_high = up_high * ecckd::exp_fast(-2.0 * (bg + max_scaling * od));
+      if (COLS) {
+        // the column once more (54 layers, host-checked), fetched as a whole: a load inside the loop would wait for the row
+        // stores above and then cost one memory latency per layer
+        constexpr int NL = 54;
+        BgT ub[NL];
+        OdT uo[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          ub[l] = load_bg(i * (size_t)NL + l);
+          uo[l] = od_src[i * (size_t)NL + l];
+        }
+#pragma unroll
+        for (int l = NL - 1; l >= 0; --l) {
+          up_low = up_low * ecckd::exp_fast(-2.0 * ((double)ub[l] + min_scaling * (double)uo[l]));
+          up_high = up_high * ecckd::exp_fast(-2.0 * ((double)ub[l] + max_scaling * (double)uo[l]));
+        }
+      } else {
+        for (int l = nlay - 1; l >= 0; --l) {
+          const double bg = (double)load_bg((size_t)l * src_stride + j);
+          const double od = (double)od_src[(size_t)l * src_stride + j];
+          up_low = up_low * ecckd::exp_fast(-2.0 * (bg + min_scaling * od));
+          up_high = up_high * ecckd::exp_fast(-2.0 * (bg + max_scaling * od));
+        }
       }
     }
     if (live) {
@@ -1238,7 +1274,7 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
     push(R.FDSH, fl_high);
     push(R.FUTH, up_high);
   }
-  if (COLS && wave_part && (slot & 15)) flush(slot & 15);
+  flush();
 }
 
 // K5b-SW: fit_optical_depth_sw (find_g_points.cpp:112-165) and
