@@ -1122,12 +1122,12 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
   int slot = 0;
   // at most seven rows a layer, flushed every three layers
   auto flush = [&]() {
-    if (!COLS || !wave_part) return;
+    if (!COLS) return;   // COLS comes with wave_part (ecckd_gas_create_sw)
     sw_flush_row_sums(s_sum[COLS ? wave : 0], s_row[COLS ? wave : 0], wave_part, nw, wid, slot, lane);
     slot = 0;
   };
   auto push = [&](int row, double v) {
-    if (!COLS || !wave_part) return;
+    if (!COLS) return;
     s_sum[COLS ? wave : 0][slot * ROWW + lane] = live ? v : 0.0;
     s_row[COLS ? wave : 0][slot] = row;
     ++slot;
@@ -1179,10 +1179,12 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
     const double bg = (double)bgv[q];
     const double od = (double)odv[q];
     const size_t o = (size_t)l * n + i;
-    if (live) __builtin_nontemporal_store(bg, &bg_od[o]);      // written once, read by later kernels: streaming stores
+    // the row stores are unconditional (a lane past the end repeats point n-1: same values to the same addresses), so that the
+    // compiler can count them and the wait for the next chunk's inputs need not drain them
+    __builtin_nontemporal_store(bg, &bg_od[o]);      // written once, read by later kernels: streaming stores
     const double flux_next = flux * ecckd::exp_fast(minus_sec_sza * (bg + od));
     const double hrv = conv[l] * (flux_next - flux);
-    if (live) __builtin_nontemporal_store(hrv, &hr[o]);
+    __builtin_nontemporal_store(hrv, &hr[o]);
     push(R.H + l, hrv);
     flux = flux_next;
     double m = od;                       // find_g_points.cpp:1119-1150: linear, logarithmic, total-transmission
@@ -1191,13 +1193,13 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
     else if (method == ECCKD_AVG_SQUARE_ROOT) m = sqrt(od);
     if (!is_log) {
       const double a = m * s;
-      if (live) __builtin_nontemporal_store(a, &w1[o]);
+      __builtin_nontemporal_store(a, &w1[o]);
       push(R.A + l, a);
       push(R.B + l, s);
     } else {
       const bool pos = m > 0.0;
       const double a = pos ? log(m) * s : 0.0, b = pos ? s : 0.0, c = pos ? 1.0 : 0.0;
-      if (live) { __builtin_nontemporal_store(a, &w1[o]); __builtin_nontemporal_store(b, &w2[o]); __builtin_nontemporal_store(c, &cnt[o]); }
+      { __builtin_nontemporal_store(a, &w1[o]); __builtin_nontemporal_store(b, &w2[o]); __builtin_nontemporal_store(c, &cnt[o]); }
       push(R.A + l, a);
       push(R.B + l, b);
       push(R.N + l, c);
@@ -1212,7 +1214,7 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
       const double hi_next = fl_high * ecckd::exp_fast(minus_sec_sza * (bg + max_scaling * od));
       const double hh = conv[l] * (hi_next - fl_high);
       fl_high = hi_next;
-      if (live) {
+      {
         __builtin_nontemporal_store(tgv, &tg[o]); __builtin_nontemporal_store(tfv, &tf[o]);
         __builtin_nontemporal_store(hl, &hr_low[o]); __builtin_nontemporal_store(hh, &hr_high[o]);
       }
@@ -1258,6 +1260,199 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
         for (int l = nlay - 1; l >= 0; --l) {
           const double bg = (double)load_bg((size_t)l * src_stride + j);
           const double od = (double)od_src[(size_t)l * src_stride + j];
+          up_low = up_low * ecckd::exp_fast(-2.0 * (bg + min_scaling * od));
+          up_high = up_high * ecckd::exp_fast(-2.0 * (bg + max_scaling * od));
+        }
+      }
+    }
+    if (live) {
+      fx[i] = fl_low;
+      fx[2 * n + i] = fl_high;
+      fx[n + i] = up_low;
+      fx[3 * n + i] = up_high;
+    }
+    push(R.FDSL, fl_low);
+    push(R.FUTL, up_low);
+    push(R.FDSH, fl_high);
+    push(R.FUTH, up_high);
+  }
+  flush();
+}
+
+// K4-SW, staged form (54 layers, FLOAT optical depths: the CKDMIP spectra).  The same arithmetic as k_gas_prep_sw, with the
+// inputs brought in differently: k_scatter_column_halves leaves each point's column at its rank as two runs of 27 layers,
+// [2][npad][27], so that the 27-layer block of a wave's 64 points is one contiguous 6912-byte piece.  The wave copies it into
+// LDS with full-width loads (seven per lane) and every lane reads its own column back from there.  Reading the columns
+// straight from memory, one 4-byte element per lane and layer at a stride of 216 bytes, took 64 cache lines per load
+// instruction and more time than the arithmetic and the row stores together (ablation).  The upward
+// sweep of the total-transmission truths starts on the half that is still staged and fetches the other once more.
+// Row sums: the (at most seven) values a layer adds to the table go through a wave-private [8][65] tile, summed per layer.
+constexpr int SWS_H = 27, SWS_TR = 8, SWS_TW = 65;
+template <int NLAY, typename SrcT>
+__global__ void __launch_bounds__(256)
+k_scatter_column_halves(size_t n, size_t npad, size_t src_stride, const int32_t* __restrict__ rank, const SrcT* __restrict__ src,
+                        SrcT* __restrict__ dst) {
+  constexpr int HP = NLAY / 2;
+  __shared__ SrcT s_tile[NLAY][65];
+  const size_t j0 = (size_t)blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int l = wave; l < NLAY; l += 4) {
+    const size_t j = j0 + lane;
+    s_tile[l][lane] = (j < n) ? src[(size_t)l * src_stride + j] : (SrcT)0;
+  }
+  __syncthreads();
+  for (int p = wave; p < 64; p += 4) {
+    const size_t j = j0 + p;
+    if (j >= n) break;
+    const size_t r = (size_t)rank[j];
+    if (lane < NLAY) dst[((size_t)(lane / HP) * npad + r) * HP + lane % HP] = s_tile[lane][p];
+  }
+}
+
+__global__ void __launch_bounds__(PREP_THREADS)
+k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double min_scaling, double max_scaling,
+                     const int32_t* __restrict__ ireorder, const double* __restrict__ conv,
+                     const double* __restrict__ ssi_src, const double* __restrict__ albedo_src,
+                     const float* __restrict__ bg_half, const float* __restrict__ od_half,
+                     double* __restrict__ ssi_s, double* __restrict__ bg_od, double* __restrict__ w1,
+                     double* __restrict__ w2, double* __restrict__ cnt, double* __restrict__ hr,
+                     double* __restrict__ fds, double* __restrict__ fut, double* __restrict__ tf,
+                     double* __restrict__ tg, double* __restrict__ hr_low, double* __restrict__ hr_high,
+                     double* __restrict__ fx, RowMap R, double* __restrict__ wave_part, size_t nw) {
+  constexpr int H = SWS_H;
+  __shared__ __attribute__((aligned(16))) float s_od[4][64 * H];
+  __shared__ __attribute__((aligned(16))) float s_bg[4][64 * H];
+  __shared__ double s_sum[4][SWS_TR * SWS_TW];
+  __shared__ int s_row[4][SWS_TR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t wid = (size_t)blockIdx.x * 4 + wave;
+  if (wid * 64 >= n) return;   // a whole wave past the end (no block-wide barrier below)
+  const size_t i0 = wid * 64 + lane;
+  const bool live = i0 < n;
+  const size_t i = live ? i0 : n - 1;
+  const bool has_bg = bg_half != nullptr;
+  float* const my_od = s_od[wave];
+  float* const my_bg = s_bg[wave];
+  double* const my_sum = s_sum[wave];
+  int* const my_row = s_row[wave];
+
+  // this wave's 64 x 27 block of half h: 432 float4, contiguous and 256-byte aligned (npad is a multiple of 64)
+  auto stage = [&](int h) {
+    constexpr int NV = 64 * H / 4, NIT = (NV + 63) / 64;
+    const float4* so = reinterpret_cast<const float4*>(od_half + ((size_t)h * npad + wid * 64) * H);
+    const float4* sb = reinterpret_cast<const float4*>((has_bg ? bg_half : od_half) + ((size_t)h * npad + wid * 64) * H);
+    __builtin_amdgcn_wave_barrier();   // the lanes are done with the half staged before
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) {
+      const int at = t * 64 + lane;
+      if (at < NV) {
+        const float4 vo = so[at], vb = sb[at];
+        reinterpret_cast<float4*>(my_od)[at] = vo;
+        reinterpret_cast<float4*>(my_bg)[at] = vb;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  int slot = 0;
+  auto push = [&](int row, double v) {
+    my_sum[slot * SWS_TW + lane] = live ? v : 0.0;
+    my_row[slot] = row;
+    ++slot;
+  };
+  // the sums of the pushed rows over the wave's 64 points: lane (r, q) adds eight points of row r, three exchanges add the eighths
+  auto flush = [&]() {
+    const int rr = lane & 7, qq = lane >> 3;
+    __builtin_amdgcn_wave_barrier();
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum += my_sum[rr * SWS_TW + qq * 8 + q];
+    sum += __shfl_xor(sum, 8, 64);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (qq == 0 && rr < slot) wave_part[(size_t)my_row[rr] * nw + wid] = sum;
+    __builtin_amdgcn_wave_barrier();
+    slot = 0;
+  };
+
+  const size_t j = (size_t)ireorder[i];
+  const bool is_log = method == ECCKD_AVG_LOGARITHMIC;
+  const bool is_tt = method == ECCKD_AVG_TOTAL_TRANSMISSION;
+  const double s = ssi_src[j];
+  if (live) ssi_s[i] = s;
+  const double minus_sec_sza = -1.0 / cos_sza;
+  double flux = cos_sza * s;
+  double fl_low = flux, fl_high = flux;
+  double tfv = s, tgv = s;  // :178-179 start from ssi, not cos_sza*ssi
+  for (int h = 0; h < 2; ++h) {
+    stage(h);
+    for (int k = 0; k < H; ++k) {
+      const int l = h * H + k;
+      const double bg = has_bg ? (double)my_bg[lane * H + k] : 0.0;
+      const double od = (double)my_od[lane * H + k];
+      const size_t o = (size_t)l * n + i;
+      if (live) __builtin_nontemporal_store(bg, &bg_od[o]);      // written once, read by later kernels: streaming stores
+      const double flux_next = flux * ecckd::exp_fast(minus_sec_sza * (bg + od));
+      const double hrv = conv[l] * (flux_next - flux);
+      if (live) __builtin_nontemporal_store(hrv, &hr[o]);
+      push(R.H + l, hrv);
+      flux = flux_next;
+      double m = od;                       // find_g_points.cpp:1119-1150: linear, logarithmic, total-transmission
+      if (method == ECCKD_AVG_TRANSMISSION) m = 1.0 - ecckd::exp_fast(-od * kD);
+      else if (method == ECCKD_AVG_TRANSMISSION_2) m = 1.0 - ecckd::exp_fast(-od * kD * 2.0);
+      else if (method == ECCKD_AVG_SQUARE_ROOT) m = sqrt(od);
+      if (!is_log) {
+        const double a = m * s;
+        if (live) __builtin_nontemporal_store(a, &w1[o]);
+        push(R.A + l, a);
+        push(R.B + l, s);
+      } else {
+        const bool pos = m > 0.0;
+        const double a = pos ? log(m) * s : 0.0, b = pos ? s : 0.0, c = pos ? 1.0 : 0.0;
+        if (live) { __builtin_nontemporal_store(a, &w1[o]); __builtin_nontemporal_store(b, &w2[o]); __builtin_nontemporal_store(c, &cnt[o]); }
+        push(R.A + l, a);
+        push(R.B + l, b);
+        push(R.N + l, c);
+      }
+      if (is_tt) {
+        // :191-192
+        tgv *= ecckd::exp_fast(-2.0 * bg);
+        tfv *= ecckd::exp_fast(-2.0 * (bg + od));
+        const double lo_next = fl_low * ecckd::exp_fast(minus_sec_sza * (bg + min_scaling * od));
+        const double hl = conv[l] * (lo_next - fl_low);
+        fl_low = lo_next;
+        const double hi_next = fl_high * ecckd::exp_fast(minus_sec_sza * (bg + max_scaling * od));
+        const double hh = conv[l] * (hi_next - fl_high);
+        fl_high = hi_next;
+        if (live) {
+          __builtin_nontemporal_store(tgv, &tg[o]); __builtin_nontemporal_store(tfv, &tf[o]);
+          __builtin_nontemporal_store(hl, &hr_low[o]); __builtin_nontemporal_store(hh, &hr_high[o]);
+        }
+        push(R.TG + l, tgv);
+        push(R.TF + l, tfv);
+        push(R.HL + l, hl);
+        push(R.HH + l, hh);
+      }
+      flush();
+    }
+  }
+  if (live) {
+    fds[i] = flux;
+    fut[i] = 0.0;  // find_g_points.cpp:1047-1050: no upwelling in the base truth
+  }
+  push(R.FDS, flux);
+  push(R.FUT, 0.0);
+  if (is_tt) {
+    double up_low = 0.0, up_high = 0.0;
+    if (albedo_src) {
+      // radiative_transfer_norayleigh_sw (radiative_transfer_sw.cpp:72-76), two-stream secant 2; the lower half is still staged
+      const double alb = albedo_src[j];
+      up_low = fl_low * alb;
+      up_high = fl_high * alb;
+      for (int h = 1; h >= 0; --h) {
+        if (h == 0) stage(0);
+        for (int k = H - 1; k >= 0; --k) {
+          const double bg = has_bg ? (double)my_bg[lane * H + k] : 0.0;
+          const double od = (double)my_od[lane * H + k];
           up_low = up_low * ecckd::exp_fast(-2.0 * (bg + min_scaling * od));
           up_high = up_high * ecckd::exp_fast(-2.0 * (bg + max_scaling * od));
         }
@@ -2152,20 +2347,29 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
                      (double*)(WP), nw64)
   if (cols) {
     const unsigned tblocks = (unsigned)((nwav + 63) / 64);
-    int rc2 = ecckd::dev_malloc(ctx, &od_col, (size_t)nwav * 54 * sizeof(float));
-    if (rc2 == ECCKD_OK && d_bg_od) rc2 = ecckd::dev_malloc(ctx, &bg_col, (size_t)nwav * 54 * (bg32 ? sizeof(float) : sizeof(double)));
+    const bool staged = bg32 || !d_bg_od;   // FLOAT background as well: the staged kernel (columns as two 27-layer runs)
+    const size_t npad = nw64 * 64;
+    int rc2 = ecckd::dev_malloc(ctx, &od_col, (staged ? npad : (size_t)nwav) * 54 * sizeof(float));
+    if (rc2 == ECCKD_OK && d_bg_od) rc2 = ecckd::dev_malloc(ctx, &bg_col, (staged ? npad : (size_t)nwav) * 54 * (bg32 ? sizeof(float) : sizeof(double)));
     if (rc2 == ECCKD_OK) rc2 = ecckd::dev_malloc(ctx, &wave_part, (size_t)g->nrows * nw64 * sizeof(double));
     if (rc2 != ECCKD_OK) { drop_temps(); gas_free(g); return rc2; }
-    hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
-                       (const float*)d_od, (float*)od_col);
-    if (d_bg_od && bg32)
+    if (staged) {
+      hipLaunchKernelGGL((k_scatter_column_halves<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride, d_rank,
+                         (const float*)d_od, (float*)od_col);
+      if (d_bg_od)
+        hipLaunchKernelGGL((k_scatter_column_halves<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride,
+                           d_rank, (const float*)d_bg_od, (float*)bg_col);
+      hipLaunchKernelGGL(k_gas_prep_sw_staged, dim3(pblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav, npad, averaging_method, cos_sza,
+                         min_scaling, max_scaling, g->ireorder, g->lev + nhl, d_ssi, d_albedo, (const float*)bg_col,
+                         (const float*)od_col, g->ssi, g->bg_od, g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut, g->tf, g->tg,
+                         g->hr_low, g->hr_high, g->fx, R, (double*)wave_part, nw64);
+    } else {
       hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
-                         (const float*)d_bg_od, (float*)bg_col);
-    else if (d_bg_od)
+                         (const float*)d_od, (float*)od_col);
       hipLaunchKernelGGL((k_scatter_columns<54, double>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
                          (const double*)d_bg_od, (double*)bg_col);
-    if (bg32 || !d_bg_od) LAUNCH_PREP_SW(float, float, true, bg_col, od_col, wave_part);
-    else LAUNCH_PREP_SW(double, float, true, bg_col, od_col, wave_part);
+      LAUNCH_PREP_SW(double, float, true, bg_col, od_col, wave_part);
+    }
   }
   else if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP_SW(float, float, false, d_bg_od, d_od, nullptr);
   else if (bg32) LAUNCH_PREP_SW(float, double, false, d_bg_od, d_od, nullptr);
