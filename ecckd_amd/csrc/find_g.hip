@@ -1280,19 +1280,20 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
 }
 
 // K4-SW, staged form (54 layers, FLOAT optical depths: the CKDMIP spectra).  The same arithmetic as k_gas_prep_sw, with the
-// inputs brought in differently: k_scatter_column_halves leaves each point's column at its rank as two runs of 27 layers,
-// [2][npad][27], so that the 27-layer block of a wave's 64 points is one contiguous 6912-byte piece.  The wave copies it into
-// LDS with full-width loads (seven per lane) and every lane reads its own column back from there.  Reading the columns
+// inputs brought in differently: k_scatter_column_halves leaves each point's column at its rank as PARTS runs of H = 54 / PARTS
+// layers, [PARTS][npad][H], so that the H-layer block of a wave's 64 points is one contiguous, 256-byte aligned piece.  The wave
+// copies it into LDS with full-width loads and every lane reads its own column back from there.  Reading the columns
 // straight from memory, one 4-byte element per lane and layer at a stride of 216 bytes, took 64 cache lines per load
 // instruction and more time than the arithmetic and the row stores together (ablation).  The upward
-// sweep of the total-transmission truths starts on the half that is still staged and fetches the other once more.
-// Row sums: the (at most seven) values a layer adds to the table go through a wave-private [8][65] tile, summed per layer.
-constexpr int SWS_H = 27, SWS_TR = 8, SWS_TW = 65;
-template <int NLAY, typename SrcT>
+// sweep of the total-transmission truths starts on the part that is still staged and fetches the others once more.
+// Row sums: the (at most seven) values a layer adds to the table go through a wave-private [7][65] tile, summed per layer.
+// Three parts of 18 layers: 51 KB of LDS per block, three blocks (three waves per SIMD) per compute unit.
+constexpr int SWS_TR = 7, SWS_TW = 65, SW_STAGE_PARTS = 3;
+template <int NLAY, typename SrcT, int PARTS>
 __global__ void __launch_bounds__(256)
 k_scatter_column_halves(size_t n, size_t npad, size_t src_stride, const int32_t* __restrict__ rank, const SrcT* __restrict__ src,
                         SrcT* __restrict__ dst) {
-  constexpr int HP = NLAY / 2;
+  constexpr int HP = NLAY / PARTS;
   __shared__ SrcT s_tile[NLAY][65];
   const size_t j0 = (size_t)blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1309,7 +1310,8 @@ k_scatter_column_halves(size_t n, size_t npad, size_t src_stride, const int32_t*
   }
 }
 
-__global__ void __launch_bounds__(PREP_THREADS)
+template <int PARTS>
+__global__ void __launch_bounds__(PREP_THREADS, PARTS)
 k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double min_scaling, double max_scaling,
                      const int32_t* __restrict__ ireorder, const double* __restrict__ conv,
                      const double* __restrict__ ssi_src, const double* __restrict__ albedo_src,
@@ -1319,7 +1321,8 @@ k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double m
                      double* __restrict__ fds, double* __restrict__ fut, double* __restrict__ tf,
                      double* __restrict__ tg, double* __restrict__ hr_low, double* __restrict__ hr_high,
                      double* __restrict__ fx, RowMap R, double* __restrict__ wave_part, size_t nw) {
-  constexpr int H = SWS_H;
+  constexpr int H = 54 / PARTS;
+  static_assert(H * PARTS == 54 && (64 * H) % 4 == 0, "whole parts, whole float4s");
   __shared__ __attribute__((aligned(16))) float s_od[4][64 * H];
   __shared__ __attribute__((aligned(16))) float s_bg[4][64 * H];
   __shared__ double s_sum[4][SWS_TR * SWS_TW];
@@ -1336,12 +1339,12 @@ k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double m
   double* const my_sum = s_sum[wave];
   int* const my_row = s_row[wave];
 
-  // this wave's 64 x 27 block of half h: 432 float4, contiguous and 256-byte aligned (npad is a multiple of 64)
+  // this wave's 64 x H block of part h: contiguous and 256-byte aligned (npad is a multiple of 64)
   auto stage = [&](int h) {
     constexpr int NV = 64 * H / 4, NIT = (NV + 63) / 64;
     const float4* so = reinterpret_cast<const float4*>(od_half + ((size_t)h * npad + wid * 64) * H);
     const float4* sb = reinterpret_cast<const float4*>((has_bg ? bg_half : od_half) + ((size_t)h * npad + wid * 64) * H);
-    __builtin_amdgcn_wave_barrier();   // the lanes are done with the half staged before
+    __builtin_amdgcn_wave_barrier();   // the lanes are done with the part staged before
 #pragma unroll
     for (int t = 0; t < NIT; ++t) {
       const int at = t * 64 + lane;
@@ -1365,7 +1368,7 @@ k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double m
     __builtin_amdgcn_wave_barrier();
     double sum = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) sum += my_sum[rr * SWS_TW + qq * 8 + q];
+    for (int q = 0; q < 8; ++q) sum += rr < slot ? my_sum[rr * SWS_TW + qq * 8 + q] : 0.0;
     sum += __shfl_xor(sum, 8, 64);
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
@@ -1383,8 +1386,9 @@ k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double m
   double flux = cos_sza * s;
   double fl_low = flux, fl_high = flux;
   double tfv = s, tgv = s;  // :178-179 start from ssi, not cos_sza*ssi
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < PARTS; ++h) {
     stage(h);
+#pragma unroll 2
     for (int k = 0; k < H; ++k) {
       const int l = h * H + k;
       const double bg = has_bg ? (double)my_bg[lane * H + k] : 0.0;
@@ -1444,12 +1448,13 @@ k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double m
   if (is_tt) {
     double up_low = 0.0, up_high = 0.0;
     if (albedo_src) {
-      // radiative_transfer_norayleigh_sw (radiative_transfer_sw.cpp:72-76), two-stream secant 2; the lower half is still staged
+      // radiative_transfer_norayleigh_sw (radiative_transfer_sw.cpp:72-76), two-stream secant 2; the lowest part is still staged
       const double alb = albedo_src[j];
       up_low = fl_low * alb;
       up_high = fl_high * alb;
-      for (int h = 1; h >= 0; --h) {
-        if (h == 0) stage(0);
+      for (int h = PARTS - 1; h >= 0; --h) {
+        if (h != PARTS - 1) stage(h);
+#pragma unroll 3
         for (int k = H - 1; k >= 0; --k) {
           const double bg = has_bg ? (double)my_bg[lane * H + k] : 0.0;
           const double od = (double)my_od[lane * H + k];
@@ -2347,19 +2352,19 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
                      (double*)(WP), nw64)
   if (cols) {
     const unsigned tblocks = (unsigned)((nwav + 63) / 64);
-    const bool staged = bg32 || !d_bg_od;   // FLOAT background as well: the staged kernel (columns as two 27-layer runs)
+    const bool staged = bg32 || !d_bg_od;   // FLOAT background as well: the staged kernel (columns in runs of 18 layers)
     const size_t npad = nw64 * 64;
     int rc2 = ecckd::dev_malloc(ctx, &od_col, (staged ? npad : (size_t)nwav) * 54 * sizeof(float));
     if (rc2 == ECCKD_OK && d_bg_od) rc2 = ecckd::dev_malloc(ctx, &bg_col, (staged ? npad : (size_t)nwav) * 54 * (bg32 ? sizeof(float) : sizeof(double)));
     if (rc2 == ECCKD_OK) rc2 = ecckd::dev_malloc(ctx, &wave_part, (size_t)g->nrows * nw64 * sizeof(double));
     if (rc2 != ECCKD_OK) { drop_temps(); gas_free(g); return rc2; }
     if (staged) {
-      hipLaunchKernelGGL((k_scatter_column_halves<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride, d_rank,
+      hipLaunchKernelGGL((k_scatter_column_halves<54, float, SW_STAGE_PARTS>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride, d_rank,
                          (const float*)d_od, (float*)od_col);
       if (d_bg_od)
-        hipLaunchKernelGGL((k_scatter_column_halves<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride,
+        hipLaunchKernelGGL((k_scatter_column_halves<54, float, SW_STAGE_PARTS>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride,
                            d_rank, (const float*)d_bg_od, (float*)bg_col);
-      hipLaunchKernelGGL(k_gas_prep_sw_staged, dim3(pblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav, npad, averaging_method, cos_sza,
+      hipLaunchKernelGGL((k_gas_prep_sw_staged<SW_STAGE_PARTS>), dim3(pblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav, npad, averaging_method, cos_sza,
                          min_scaling, max_scaling, g->ireorder, g->lev + nhl, d_ssi, d_albedo, (const float*)bg_col,
                          (const float*)od_col, g->ssi, g->bg_od, g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut, g->tf, g->tg,
                          g->hr_low, g->hr_high, g->fx, R, (double*)wave_part, nw64);
