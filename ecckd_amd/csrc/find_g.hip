@@ -272,6 +272,30 @@ k_scatter_columns(size_t n, size_t src_stride, const int32_t* __restrict__ rank,
   }
 }
 
+// The same scatter with each column left as PARTS runs of NLAY / PARTS layers, dst[PARTS][npad][NLAY / PARTS] (npad: n rounded
+// up to whole waves): the block of one run for 64 consecutive ranks is contiguous, which is what the preparation kernels copy
+// into LDS.
+template <int NLAY, typename SrcT, int PARTS>
+__global__ void __launch_bounds__(256)
+k_scatter_column_halves(size_t n, size_t npad, size_t src_stride, const int32_t* __restrict__ rank, const SrcT* __restrict__ src,
+                        SrcT* __restrict__ dst) {
+  constexpr int HP = NLAY / PARTS;
+  __shared__ SrcT s_tile[NLAY][65];
+  const size_t j0 = (size_t)blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int l = wave; l < NLAY; l += 4) {
+    const size_t j = j0 + lane;
+    s_tile[l][lane] = (j < n) ? src[(size_t)l * src_stride + j] : (SrcT)0;
+  }
+  __syncthreads();
+  for (int p = wave; p < 64; p += 4) {
+    const size_t j = j0 + p;
+    if (j >= n) break;
+    const size_t r = (size_t)rank[j];
+    if (lane < NLAY) dst[((size_t)(lane / HP) * npad + r) * HP + lane % HP] = s_tile[lane][p];
+  }
+}
+
 // K4 mirror path (same idea as K5c's, see k_rt_lw_bb_mirror): a pair of waves shares 64 points, the even
 // wave prepares the upper NLAY/2 layers top-down (first sweep = downwelling from the top of the
 // atmosphere), the odd wave the lower NLAY/2 layers bottom-up (first sweep = upwelling from the surface,
@@ -294,6 +318,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
                      size_t nw) {
   static_assert(NLAY % 2 == 0 && PREP_THREADS == 256, "two wave pairs per block, equal halves");
   constexpr int H = NLAY / 2;
+  constexpr bool STAGED = sizeof(BgT) == 4 && sizeof(OdT) == 4;   // the columns arrive in two runs of H layers, see below
   __shared__ double s_x[4][64];
   // Row sums over the wave's 64 points, formed while the values are still in registers (they used to be re-read from
   // HBM by k_tile_sums: 1 312 B per point).  Sixteen rows at a time go through a wave-private transposed LDS tile: lane
@@ -313,8 +338,8 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   const double inv_cm_2_Hz = 100.0 * kLightC;
   const double freq = w * inv_cm_2_Hz;
   const double pref = (dw * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq);
-  const BgT* bgc = bg_col ? bg_col + ii * NLAY : nullptr;
-  const OdT* odc = od_col + ii * NLAY;
+  const BgT* bgc = bg_col && !STAGED ? bg_col + ii * NLAY : nullptr;
+  const OdT* odc = od_col + (STAGED ? 0 : ii * NLAY);
   const size_t wid = (size_t)blockIdx.x * 2 + pair;          // index of this pair's 64 points among the 64-point groups
   double* sum_tile = s_sum[wave];
   const int rr = lane & 15, qq = lane >> 4;
@@ -362,14 +387,47 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   OdT od_in[H];
   BgT bg_in[H];
   __builtin_amdgcn_s_setprio(3);
+  if (STAGED) {
+    // FLOAT background: both inputs come as [2][npad][H] (k_scatter_column_halves), this wave's 64 x H block is one contiguous
+    // piece.  It is copied into LDS (the row-sum tile, idle until the first push) with full-width loads and each lane takes
+    // its column from there: read straight from memory a column costs 64 cache lines per load instruction.
+    float* st = reinterpret_cast<float*>(sum_tile);
+    constexpr int NV = 16 * H;                                // float4s in the block
+    static_assert(NV * 16 <= 16 * ROWW * 8, "the block fits the tile");
+    const size_t widc = wid < nw ? wid : nw - 1;              // a pair past the end repeats the last point, as ii does
+    const int lc = live ? lane : (int)((n - 1) - widc * 64);
+    const size_t blk = ((size_t)half * (nw * 64) + widc * 64) * H;
+    auto fill = [&](const float* col) {
 #pragma unroll
-  for (int l = 0; l < H; ++l) od_in[l] = odc[half ? NLAY - 1 - l : l];
-  if (bg_col) {   // uniform: one block of loads
+      for (int t = 0; t < (NV + 63) / 64; ++t) {
+        const int at = t * 64 + lane;
+        if (at < NV) reinterpret_cast<float4*>(st)[at] = reinterpret_cast<const float4*>(col + blk)[at];
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    fill(reinterpret_cast<const float*>(od_col));
 #pragma unroll
-    for (int l = 0; l < H; ++l) bg_in[l] = bgc[half ? NLAY - 1 - l : l];
+    for (int l = 0; l < H; ++l) od_in[l] = (OdT)st[lc * H + (half ? H - 1 - l : l)];
+    __builtin_amdgcn_wave_barrier();
+    if (bg_col) {
+      fill(reinterpret_cast<const float*>(bg_col));
+#pragma unroll
+      for (int l = 0; l < H; ++l) bg_in[l] = (BgT)st[lc * H + (half ? H - 1 - l : l)];
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int l = 0; l < H; ++l) bg_in[l] = (BgT)0;
+    }
   } else {
 #pragma unroll
-    for (int l = 0; l < H; ++l) bg_in[l] = (BgT)0;
+    for (int l = 0; l < H; ++l) od_in[l] = odc[half ? NLAY - 1 - l : l];
+    if (bg_col) {   // uniform: one block of loads
+#pragma unroll
+      for (int l = 0; l < H; ++l) bg_in[l] = bgc[half ? NLAY - 1 - l : l];
+    } else {
+#pragma unroll
+      for (int l = 0; l < H; ++l) bg_in[l] = (BgT)0;
+    }
   }
   __builtin_amdgcn_s_setprio(0);
   int lev_near = half ? NLAY : 0;
@@ -1289,27 +1347,6 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
 // Row sums: the (at most seven) values a layer adds to the table go through a wave-private [7][65] tile, summed per layer.
 // Three parts of 18 layers: 51 KB of LDS per block, three blocks (three waves per SIMD) per compute unit.
 constexpr int SWS_TR = 7, SWS_TW = 65, SW_STAGE_PARTS = 3;
-template <int NLAY, typename SrcT, int PARTS>
-__global__ void __launch_bounds__(256)
-k_scatter_column_halves(size_t n, size_t npad, size_t src_stride, const int32_t* __restrict__ rank, const SrcT* __restrict__ src,
-                        SrcT* __restrict__ dst) {
-  constexpr int HP = NLAY / PARTS;
-  __shared__ SrcT s_tile[NLAY][65];
-  const size_t j0 = (size_t)blockIdx.x * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int l = wave; l < NLAY; l += 4) {
-    const size_t j = j0 + lane;
-    s_tile[l][lane] = (j < n) ? src[(size_t)l * src_stride + j] : (SrcT)0;
-  }
-  __syncthreads();
-  for (int p = wave; p < 64; p += 4) {
-    const size_t j = j0 + p;
-    if (j >= n) break;
-    const size_t r = (size_t)rank[j];
-    if (lane < NLAY) dst[((size_t)(lane / HP) * npad + r) * HP + lane % HP] = s_tile[lane][p];
-  }
-}
-
 template <int PARTS>
 __global__ void __launch_bounds__(PREP_THREADS, PARTS)
 k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double min_scaling, double max_scaling,
@@ -2075,20 +2112,26 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   size_t nw64 = 0;
   if (fast) {
     const size_t bg_elem = bg32 ? sizeof(float) : sizeof(double);
-    GTRY(ecckd::dev_malloc(ctx, &od_col_v, (size_t)nwav * 54 * sizeof(float)));
-    if (d_bg_od) GTRY(ecckd::dev_malloc(ctx, &bg_col, (size_t)nwav * 54 * bg_elem));
+    nw64 = (nwav + 63) / 64;
+    const bool staged = bg32 || !d_bg_od;      // all FLOAT: the columns in two runs of 27 layers, staged through LDS by K4
+    const size_t ncol = staged ? nw64 * 64 : (size_t)nwav;
+    GTRY(ecckd::dev_malloc(ctx, &od_col_v, ncol * 54 * sizeof(float)));
+    if (d_bg_od) GTRY(ecckd::dev_malloc(ctx, &bg_col, ncol * 54 * bg_elem));
     float* od_col = (float*)od_col_v;
     const unsigned tblocks = (unsigned)((nwav + 63) / 64);
-    hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
-                       (const float*)d_od, od_col);
-    if (d_bg_od && bg32)
+    if (staged) {
+      hipLaunchKernelGGL((k_scatter_column_halves<54, float, 2>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, ncol, src_stride,
+                         d_rank, (const float*)d_od, od_col);
+      if (d_bg_od)
+        hipLaunchKernelGGL((k_scatter_column_halves<54, float, 2>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, ncol, src_stride,
+                           d_rank, (const float*)d_bg_od, (float*)bg_col);
+    } else {
       hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
-                         (const float*)d_bg_od, (float*)bg_col);
-    else if (d_bg_od)
+                         (const float*)d_od, od_col);
       hipLaunchKernelGGL((k_scatter_columns<54, double>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
                          (const double*)d_bg_od, (double*)bg_col);
+    }
     const unsigned fblocks = (unsigned)((nwav + 127) / 128);
-    nw64 = (nwav + 63) / 64;
     GTRY(ecckd::dev_malloc(ctx, &wave_part_v, (size_t)(3 * 54 + 2) * nw64 * sizeof(double)));
     double* wave_part = (double*)wave_part_v;
 #define LAUNCH_MIRROR(BG, REUSE)                                                                                              \
