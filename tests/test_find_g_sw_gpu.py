@@ -28,13 +28,17 @@ def _dev(ctx, a):
 
 
 def _sw_problem(oracle, nwav, nlay=30, seed=41, method="total-transmission", min_scaling=0.5, max_scaling=2.5,
-                with_albedo=True):
+                with_albedo=True, bg_kind="double"):
     from ecckd_amd import synthetic as syn
     lo, hi = 250.0, 50000.0
     p, wn, dwn, od32 = make_lw_case(nwav, nlay=nlay, seed=seed, lo=lo, hi=hi, column_scale=5.0)
     od = od32.astype(np.float64)
     _, _, _, bg32 = make_lw_case(nwav, nlay=nlay, seed=seed + 100, lo=lo, hi=hi, column_scale=0.5)
     bg = bg32.astype(np.float64) * 0.5 + 1e-5
+    if bg_kind == "float":
+        bg = bg.astype(np.float32).astype(np.float64)       # a FLOAT background file: the oracle sees the same values
+    elif bg_kind == "none":
+        bg = np.zeros_like(bg)
     ssi = syn.solar_spectral_irradiance(wn, dwn)
     key, col, st = oracle.reorder_key(p, None, wn, dwn, od, ssi, 0.25)
     assert st == 0
@@ -96,6 +100,58 @@ def test_gas_prep_sw_matches_oracle(ctx, oracle):
         assert np.allclose(fx[row], ex[name], rtol=1e-12, atol=1e-300), name
     assert (ex["flux_up_toa_low"] > 0).any()
     gas.close()
+
+
+@pytest.mark.parametrize("bg_kind", ["none", "float", "double"])
+@pytest.mark.parametrize("method,with_albedo", [("total-transmission", True), ("total-transmission", False),
+                                                ("transmission", True), ("logarithmic", True)])
+def test_gas_prep_sw_fast_path_54_layers(ctx, oracle, bg_kind, method, with_albedo, n=9001):
+    """The 54-layer FLOAT-spectrum preparations: all FLOAT (or no background) takes k_scatter_column_halves +
+    k_gas_prep_sw_staged (columns staged through LDS in runs of 18 layers), a DOUBLE (merged) background the column-reading
+    kernel.  A number of points that fills neither the last wave nor the last block; the prepared arrays against the oracle,
+    and interval errors (which go through the per-wave row sums formed inside the preparation)."""
+    from ecckd_amd import api
+    o = _sw_problem(oracle, n, nlay=54, seed=61, method=method, with_albedo=with_albedo, bg_kind=bg_kind)
+    od32 = o["od"].astype(np.float32)
+    assert np.array_equal(od32.astype(np.float64), o["od"])
+    bg = None if bg_kind == "none" else o["bg"].astype(np.float32) if bg_kind == "float" else o["bg"]
+    ex = o["extras"] or {}
+    gas = api.GasSW(ctx, o["p"], _dev(ctx, o["ssi"]), _dev(ctx, o["rank"].astype(np.int32)), _dev(ctx, od32),
+                    _dev(ctx, bg) if bg is not None else None, method, 0.02, 0.0, MU0,
+                    _dev(ctx, o["albedo"]) if o["albedo"] is not None else None,
+                    ex.get("min_scaling", 1.0), ex.get("max_scaling", 1.0))
+    assert np.array_equal(gas.view("ssi")[0], o["ssi_s"])
+    assert np.array_equal(gas.view("bg_optical_depth"), o["bg_s"])
+    conv = (9.80665 / 1004.0) / np.diff(o["p"])
+    tol = lambda ref: 1e-12 * np.abs(ref).max(axis=0, keepdims=True) + 1e-14 * conv[:, None] * MU0 * o["ssi_s"][None, :]
+    assert np.all(np.abs(gas.view("hr") - o["hr"]) <= tol(o["hr"]))
+    assert np.allclose(gas.view("flux_dn_surf")[0], o["fds"], rtol=1e-12, atol=1e-300)
+    if method == "total-transmission":
+        assert np.all(np.abs(gas.view("hr_low") - ex["hr_low"]) <= tol(ex["hr_low"]))
+        assert np.all(np.abs(gas.view("hr_high") - ex["hr_high"]) <= tol(ex["hr_high"]))
+        fx = gas.view("flux_extras")
+        for row, name in enumerate(["flux_dn_surf_low", "flux_up_toa_low", "flux_dn_surf_high", "flux_up_toa_high"]):
+            assert np.allclose(fx[row], ex[name], rtol=1e-12, atol=1e-300), name
+        assert (ex["flux_up_toa_low"] > 0).any() == with_albedo
+    if n < 1000:
+        gas.close()
+        return
+    gas.set_band_albedo(0.15)
+    eq = _oracle_eq(oracle, o, method, 0.02, 0.15)
+    b1 = np.array([0.0, 0.25, 0.6, 0.0, 0.993])
+    b2 = np.array([0.25, 0.6, 1.0, 1.0, 1.0])
+    err = gas.calc_error_batch(0, n, b1, b2)
+    ref = np.array([eq.calc_error(x, y) for x, y in zip(b1, b2)])
+    assert np.array_equal(np.isnan(err), np.isnan(ref))
+    ok = np.isfinite(ref)
+    assert ok.sum() >= 3 and np.allclose(err[ok], ref[ok], rtol=ERR_RTOL, atol=1e-10)
+    gas.close()
+
+
+@pytest.mark.parametrize("bg_kind", ["none", "float"])
+def test_gas_prep_sw_staged_less_than_a_wave(ctx, oracle, bg_kind):
+    """41 points: one partly filled wave, three idle ones in the only block."""
+    test_gas_prep_sw_fast_path_54_layers(ctx, oracle, bg_kind, "total-transmission", True, n=41)
 
 
 @pytest.mark.parametrize("method", ["linear", "transmission", "transmission-2", "square-root", "logarithmic"])
