@@ -247,34 +247,11 @@ k_gas_prep_lw(int nlay, size_t n, size_t src_stride, int method,
 }
 
 
-// K4 fast path, step 1: transposing scatter.  src is (layer, wavenumber) in ORIGINAL order;
-// dst[rank[j]][NLAY] holds the column of wavenumber j at its SORTED position, contiguous.
-// Reads are coalesced rows through an LDS tile; each point's NLAY values leave as one
-// contiguous wave store.  This replaces 2*NLAY random 4-byte gathers per point (64-byte sectors
-// for 4 useful bytes) by one contiguous NLAY*4-byte segment.
-template <int NLAY, typename SrcT>
-__global__ void __launch_bounds__(256)
-k_scatter_columns(size_t n, size_t src_stride, const int32_t* __restrict__ rank, const SrcT* __restrict__ src,
-                  SrcT* __restrict__ dst) {
-  __shared__ SrcT s_tile[NLAY][65];
-  const size_t j0 = (size_t)blockIdx.x * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int l = wave; l < NLAY; l += 4) {
-    const size_t j = j0 + lane;
-    s_tile[l][lane] = (j < n) ? src[(size_t)l * src_stride + j] : (SrcT)0;
-  }
-  __syncthreads();
-  for (int p = wave; p < 64; p += 4) {
-    const size_t j = j0 + p;
-    if (j >= n) break;
-    const size_t r = (size_t)rank[j];
-    if (lane < NLAY) dst[r * NLAY + lane] = s_tile[lane][p];
-  }
-}
-
-// The same scatter with each column left as PARTS runs of NLAY / PARTS layers, dst[PARTS][npad][NLAY / PARTS] (npad: n rounded
-// up to whole waves): the block of one run for 64 consecutive ranks is contiguous, which is what the preparation kernels copy
-// into LDS.
+// K4 fast path, step 1: transposing scatter.  src is (layer, wavenumber) in ORIGINAL order; the column of wavenumber j goes to
+// its SORTED position rank[j], as PARTS runs of NLAY / PARTS layers: dst[PARTS][npad][NLAY / PARTS] (npad: n rounded up to whole
+// waves).  Reads are coalesced rows through an LDS tile, each point's values leave as one wave store of PARTS contiguous
+// segments.  The block of one run for 64 consecutive ranks is contiguous: that is what the preparation kernels copy into LDS
+// (instead of 2*NLAY random 4-byte gathers per point, or NLAY-element columns read at a stride of NLAY*4 bytes).
 template <int NLAY, typename SrcT, int PARTS>
 __global__ void __launch_bounds__(256)
 k_scatter_column_halves(size_t n, size_t npad, size_t src_stride, const int32_t* __restrict__ rank, const SrcT* __restrict__ src,
@@ -318,7 +295,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
                      size_t nw) {
   static_assert(NLAY % 2 == 0 && PREP_THREADS == 256, "two wave pairs per block, equal halves");
   constexpr int H = NLAY / 2;
-  constexpr bool STAGED = sizeof(BgT) == 4 && sizeof(OdT) == 4;   // the columns arrive in two runs of H layers, see below
+  constexpr bool STAGED = sizeof(OdT) == 4;   // the columns arrive in two runs of H layers, see below (always, on this path)
   __shared__ double s_x[4][64];
   // Row sums over the wave's 64 points, formed while the values are still in registers (they used to be re-read from
   // HBM by k_tile_sums: 1 312 B per point).  Sixteen rows at a time go through a wave-private transposed LDS tile: lane
@@ -388,7 +365,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   BgT bg_in[H];
   __builtin_amdgcn_s_setprio(3);
   if (STAGED) {
-    // FLOAT background: both inputs come as [2][npad][H] (k_scatter_column_halves), this wave's 64 x H block is one contiguous
+    // Both inputs come as [2][npad][H] (k_scatter_column_halves), this wave's 64 x H block of each is one contiguous
     // piece.  It is copied into LDS (the row-sum tile, idle until the first push) with full-width loads and each lane takes
     // its column from there: read straight from memory a column costs 64 cache lines per load instruction.
     float* st = reinterpret_cast<float*>(sum_tile);
@@ -409,11 +386,29 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
 #pragma unroll
     for (int l = 0; l < H; ++l) od_in[l] = (OdT)st[lc * H + (half ? H - 1 - l : l)];
     __builtin_amdgcn_wave_barrier();
-    if (bg_col) {
+    if (bg_col && sizeof(BgT) == 4) {
       fill(reinterpret_cast<const float*>(bg_col));
 #pragma unroll
       for (int l = 0; l < H; ++l) bg_in[l] = (BgT)st[lc * H + (half ? H - 1 - l : l)];
       __builtin_amdgcn_wave_barrier();
+    } else if (bg_col) {
+      // DOUBLE (merged) background: the block is twice the tile, so it comes in two pieces of 32 points
+      const double* colb = reinterpret_cast<const double*>(bg_col) + blk;
+      const double* std_ = reinterpret_cast<const double*>(sum_tile);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int t = 0; t < (NV + 63) / 64; ++t) {
+          const int at = t * 64 + lane;
+          if (at < NV) reinterpret_cast<double2*>(sum_tile)[at] = reinterpret_cast<const double2*>(colb + (size_t)r * 32 * H)[at];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if ((lc >> 5) == r) {
+#pragma unroll
+          for (int l = 0; l < H; ++l) bg_in[l] = (BgT)std_[(lc & 31) * H + (half ? H - 1 - l : l)];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     } else {
 #pragma unroll
       for (int l = 0; l < H; ++l) bg_in[l] = (BgT)0;
@@ -1134,30 +1129,10 @@ k_cost_lw(int nlay, RowMap R, const Interval* __restrict__ iv, long long nchunks
 // for the total-transmission method the per-point direct fluxes that
 // fit_optical_depth_sw_total_trans sums (:171-204) plus the two scaled "truth" fields
 // (:1011-1034, :1060-1090).  One thread per sorted wavenumber.
-// the sums of up to SW_TILE_ROWS rows over a wave's 64 points: `tile` is the wave's [SW_TILE_ROWS][65] LDS tile (slot, point),
-// `rows` the table row of every slot.  Inlined at its few call sites (one per three layers): a call would start with a wait for
-// every store the wave has in flight.
-constexpr int SW_TILE_ROWS = 24, SW_TILE_W = 65;
-__device__ __forceinline__ void sw_flush_row_sums(const double* tile, const int* rows, double* __restrict__ wave_part, size_t nw,
-                                                  size_t wid, int count, int lane) {
-  const int rr = lane & 31, qq = lane >> 5;
-  __builtin_amdgcn_wave_barrier();
-  double sum = 0.0;
-  if (rr < count) {
-#pragma unroll
-    for (int q = 0; q < 32; ++q) sum += tile[rr * SW_TILE_W + qq * 32 + q];
-  }
-  sum += __shfl_xor(sum, 32, 64);
-  if (qq == 0 && rr < count && wid < nw) wave_part[(size_t)rows[rr] * nw + wid] = sum;
-  __builtin_amdgcn_wave_barrier();
-}
-
-// COLS: bg_src / od_src are the rank-scattered columns [n][nlay] (k_scatter_columns), read contiguously per point, instead of
-// the (level, wavenumber) matrices gathered through ireorder (108 random 4-byte reads per point).  wave_part != NULL: the sums
-// over each wave's 64 points of every row of the table (RowMap R) are formed while the values are in registers - sixteen
-// rows at a time through a wave-private transposed LDS tile, as in k_gas_prep_lw_mirror - and k_combine_wave_sums turns
-// them into the tile sums that k_tile_sums otherwise makes by reading all rows again.
-template <typename BgT, typename OdT, bool COLS>
+// This is the general form (any number of layers, FLOAT or DOUBLE spectra): the (level, wavenumber) matrices are gathered
+// through ireorder, the tile sums of the rows are made afterwards by k_tile_sums.  54 layers of FLOAT optical depths take
+// k_gas_prep_sw_staged below.
+template <typename BgT, typename OdT>
 __global__ void __launch_bounds__(PREP_THREADS)
 k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza, double min_scaling,
               double max_scaling, const int32_t* __restrict__ ireorder, const double* __restrict__ conv,
@@ -1167,42 +1142,21 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
               double* __restrict__ w2, double* __restrict__ cnt, double* __restrict__ hr,
               double* __restrict__ fds, double* __restrict__ fut, double* __restrict__ tf,
               double* __restrict__ tg, double* __restrict__ hr_low, double* __restrict__ hr_high,
-              double* __restrict__ fx, RowMap R, double* __restrict__ wave_part, size_t nw) {
-  constexpr int ROWW = SW_TILE_W;
-  __shared__ double s_sum[COLS ? 4 : 1][COLS ? SW_TILE_ROWS * ROWW : 1];
-  __shared__ int s_row[COLS ? 4 : 1][SW_TILE_ROWS];
-  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i0 < n;
-  if (!COLS && !live) return;
-  const size_t i = live ? i0 : n - 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t wid = (size_t)blockIdx.x * 4 + wave;
-  int slot = 0;
-  // at most seven rows a layer, flushed every three layers
-  auto flush = [&]() {
-    if (!COLS) return;   // COLS comes with wave_part (ecckd_gas_create_sw)
-    sw_flush_row_sums(s_sum[COLS ? wave : 0], s_row[COLS ? wave : 0], wave_part, nw, wid, slot, lane);
-    slot = 0;
-  };
-  auto push = [&](int row, double v) {
-    if (!COLS) return;
-    s_sum[COLS ? wave : 0][slot * ROWW + lane] = live ? v : 0.0;
-    s_row[COLS ? wave : 0][slot] = row;
-    ++slot;
-  };
+              double* __restrict__ fx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
   const size_t j = (size_t)ireorder[i];
   const bool is_log = method == ECCKD_AVG_LOGARITHMIC;
   const bool is_tt = method == ECCKD_AVG_TOTAL_TRANSMISSION;
   const double s = ssi_src[j];
-  if (live) ssi_s[i] = s;
+  ssi_s[i] = s;
   const double minus_sec_sza = -1.0 / cos_sza;
   double flux = cos_sza * s;
   double fl_low = flux, fl_high = flux;
   double tfv = s, tgv = s;  // :178-179 start from ssi, not cos_sza*ssi
-  // inputs are fetched eight layers at a time, ahead of that chunk's stores: a load issued after a store waits for the
-  // store to complete on this hardware, so one load per layer would cost one store latency per layer
-  // and the NEXT chunk's inputs are requested before this chunk's stores are issued, so that the wait for them (which includes
-  // the stores of the chunk before) overlaps this chunk's arithmetic
+  // inputs are fetched nine layers at a time and one chunk ahead: a load issued after a store waits for that store on this
+  // hardware (one counter, in order), so one load per layer would cost one store latency per layer; requested before the
+  // chunk's own stores, the wait for them overlaps the chunk's arithmetic
   constexpr int CH = 9;
   BgT bgn[CH];
   OdT odn[CH];
@@ -1219,8 +1173,8 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
       const int lq = l0 + q < nlay ? l0 + q : nlay - 1;
-      bgn[q] = load_bg(COLS ? i * (size_t)nlay + lq : (size_t)lq * src_stride + j);
-      odn[q] = od_src[COLS ? i * (size_t)nlay + lq : (size_t)lq * src_stride + j];
+      bgn[q] = load_bg((size_t)lq * src_stride + j);
+      odn[q] = od_src[(size_t)lq * src_stride + j];
     }
   };
   fetch(0);
@@ -1233,17 +1187,14 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
 #pragma unroll
   for (int q = 0; q < CH; ++q) {
     const int l = l0 + q;
-    if (l >= nlay) break;
+    if (l >= nlay) continue;
     const double bg = (double)bgv[q];
     const double od = (double)odv[q];
     const size_t o = (size_t)l * n + i;
-    // the row stores are unconditional (a lane past the end repeats point n-1: same values to the same addresses), so that the
-    // compiler can count them and the wait for the next chunk's inputs need not drain them
     __builtin_nontemporal_store(bg, &bg_od[o]);      // written once, read by later kernels: streaming stores
     const double flux_next = flux * ecckd::exp_fast(minus_sec_sza * (bg + od));
     const double hrv = conv[l] * (flux_next - flux);
     __builtin_nontemporal_store(hrv, &hr[o]);
-    push(R.H + l, hrv);
     flux = flux_next;
     double m = od;                       // find_g_points.cpp:1119-1150: linear, logarithmic, total-transmission
     if (method == ECCKD_AVG_TRANSMISSION) m = 1.0 - ecckd::exp_fast(-od * kD);
@@ -1252,15 +1203,10 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
     if (!is_log) {
       const double a = m * s;
       __builtin_nontemporal_store(a, &w1[o]);
-      push(R.A + l, a);
-      push(R.B + l, s);
     } else {
       const bool pos = m > 0.0;
       const double a = pos ? log(m) * s : 0.0, b = pos ? s : 0.0, c = pos ? 1.0 : 0.0;
-      { __builtin_nontemporal_store(a, &w1[o]); __builtin_nontemporal_store(b, &w2[o]); __builtin_nontemporal_store(c, &cnt[o]); }
-      push(R.A + l, a);
-      push(R.B + l, b);
-      push(R.N + l, c);
+      __builtin_nontemporal_store(a, &w1[o]); __builtin_nontemporal_store(b, &w2[o]); __builtin_nontemporal_store(c, &cnt[o]);
     }
     if (is_tt) {
       // :191-192
@@ -1272,25 +1218,13 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
       const double hi_next = fl_high * ecckd::exp_fast(minus_sec_sza * (bg + max_scaling * od));
       const double hh = conv[l] * (hi_next - fl_high);
       fl_high = hi_next;
-      {
-        __builtin_nontemporal_store(tgv, &tg[o]); __builtin_nontemporal_store(tfv, &tf[o]);
-        __builtin_nontemporal_store(hl, &hr_low[o]); __builtin_nontemporal_store(hh, &hr_high[o]);
-      }
-      push(R.TG + l, tgv);
-      push(R.TF + l, tfv);
-      push(R.HL + l, hl);
-      push(R.HH + l, hh);
+      __builtin_nontemporal_store(tgv, &tg[o]); __builtin_nontemporal_store(tfv, &tf[o]);
+      __builtin_nontemporal_store(hl, &hr_low[o]); __builtin_nontemporal_store(hh, &hr_high[o]);
     }
-    if (q % 3 == 2) flush();
   }
-  flush();
   }
-  if (live) {
-    fds[i] = flux;
-    fut[i] = 0.0;  // find_g_points.cpp:1047-1050: no upwelling in the base truth
-  }
-  push(R.FDS, flux);
-  push(R.FUT, 0.0);
+  fds[i] = flux;
+  fut[i] = 0.0;  // find_g_points.cpp:1047-1050: no upwelling in the base truth
   if (is_tt) {
     double up_low = 0.0, up_high = 0.0;
     if (albedo_src) {
@@ -1298,43 +1232,18 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
       const double alb = albedo_src[j];
       up_low = fl_low * alb;
       up_high = fl_high * alb;
-      if (COLS) {
-        // the column once more (54 layers, host-checked), fetched as a whole: a load inside the loop would wait for the row
-        // stores above and then cost one memory latency per layer
-        constexpr int NL = 54;
-        BgT ub[NL];
-        OdT uo[NL];
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-          ub[l] = load_bg(i * (size_t)NL + l);
-          uo[l] = od_src[i * (size_t)NL + l];
-        }
-#pragma unroll
-        for (int l = NL - 1; l >= 0; --l) {
-          up_low = up_low * ecckd::exp_fast(-2.0 * ((double)ub[l] + min_scaling * (double)uo[l]));
-          up_high = up_high * ecckd::exp_fast(-2.0 * ((double)ub[l] + max_scaling * (double)uo[l]));
-        }
-      } else {
-        for (int l = nlay - 1; l >= 0; --l) {
-          const double bg = (double)load_bg((size_t)l * src_stride + j);
-          const double od = (double)od_src[(size_t)l * src_stride + j];
-          up_low = up_low * ecckd::exp_fast(-2.0 * (bg + min_scaling * od));
-          up_high = up_high * ecckd::exp_fast(-2.0 * (bg + max_scaling * od));
-        }
+      for (int l = nlay - 1; l >= 0; --l) {
+        const double bg = (double)load_bg((size_t)l * src_stride + j);
+        const double od = (double)od_src[(size_t)l * src_stride + j];
+        up_low = up_low * ecckd::exp_fast(-2.0 * (bg + min_scaling * od));
+        up_high = up_high * ecckd::exp_fast(-2.0 * (bg + max_scaling * od));
       }
     }
-    if (live) {
-      fx[i] = fl_low;
-      fx[2 * n + i] = fl_high;
-      fx[n + i] = up_low;
-      fx[3 * n + i] = up_high;
-    }
-    push(R.FDSL, fl_low);
-    push(R.FUTL, up_low);
-    push(R.FDSH, fl_high);
-    push(R.FUTH, up_high);
+    fx[i] = fl_low;
+    fx[2 * n + i] = fl_high;
+    fx[n + i] = up_low;
+    fx[3 * n + i] = up_high;
   }
-  flush();
 }
 
 // K4-SW, staged form (54 layers, FLOAT optical depths: the CKDMIP spectra).  The same arithmetic as k_gas_prep_sw, with the
@@ -1347,12 +1256,12 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
 // Row sums: the (at most seven) values a layer adds to the table go through a wave-private [7][65] tile, summed per layer.
 // Three parts of 18 layers: 51 KB of LDS per block, three blocks (three waves per SIMD) per compute unit.
 constexpr int SWS_TR = 7, SWS_TW = 65, SW_STAGE_PARTS = 3;
-template <int PARTS>
-__global__ void __launch_bounds__(PREP_THREADS, PARTS)
+template <int PARTS, typename BgT>
+__global__ void __launch_bounds__(PREP_THREADS, sizeof(BgT) == 4 ? PARTS : 2)
 k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double min_scaling, double max_scaling,
                      const int32_t* __restrict__ ireorder, const double* __restrict__ conv,
                      const double* __restrict__ ssi_src, const double* __restrict__ albedo_src,
-                     const float* __restrict__ bg_half, const float* __restrict__ od_half,
+                     const BgT* __restrict__ bg_half, const float* __restrict__ od_half,
                      double* __restrict__ ssi_s, double* __restrict__ bg_od, double* __restrict__ w1,
                      double* __restrict__ w2, double* __restrict__ cnt, double* __restrict__ hr,
                      double* __restrict__ fds, double* __restrict__ fut, double* __restrict__ tf,
@@ -1361,7 +1270,7 @@ k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double m
   constexpr int H = 54 / PARTS;
   static_assert(H * PARTS == 54 && (64 * H) % 4 == 0, "whole parts, whole float4s");
   __shared__ __attribute__((aligned(16))) float s_od[4][64 * H];
-  __shared__ __attribute__((aligned(16))) float s_bg[4][64 * H];
+  __shared__ __attribute__((aligned(16))) BgT s_bg[4][64 * H];     // a DOUBLE (merged) background: 70 KB per block, two blocks per CU
   __shared__ double s_sum[4][SWS_TR * SWS_TW];
   __shared__ int s_row[4][SWS_TR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1372,23 +1281,27 @@ k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double m
   const size_t i = live ? i0 : n - 1;
   const bool has_bg = bg_half != nullptr;
   float* const my_od = s_od[wave];
-  float* const my_bg = s_bg[wave];
+  BgT* const my_bg = s_bg[wave];
   double* const my_sum = s_sum[wave];
   int* const my_row = s_row[wave];
 
   // this wave's 64 x H block of part h: contiguous and 256-byte aligned (npad is a multiple of 64)
   auto stage = [&](int h) {
     constexpr int NV = 64 * H / 4, NIT = (NV + 63) / 64;
+    constexpr int NVB = NV * (int)(sizeof(BgT) / 4), NITB = (NVB + 63) / 64;
     const float4* so = reinterpret_cast<const float4*>(od_half + ((size_t)h * npad + wid * 64) * H);
-    const float4* sb = reinterpret_cast<const float4*>((has_bg ? bg_half : od_half) + ((size_t)h * npad + wid * 64) * H);
+    const float4* sb = reinterpret_cast<const float4*>(bg_half + ((size_t)h * npad + wid * 64) * H);
     __builtin_amdgcn_wave_barrier();   // the lanes are done with the part staged before
 #pragma unroll
     for (int t = 0; t < NIT; ++t) {
       const int at = t * 64 + lane;
-      if (at < NV) {
-        const float4 vo = so[at], vb = sb[at];
-        reinterpret_cast<float4*>(my_od)[at] = vo;
-        reinterpret_cast<float4*>(my_bg)[at] = vb;
+      if (at < NV) reinterpret_cast<float4*>(my_od)[at] = so[at];
+    }
+    if (has_bg) {
+#pragma unroll
+      for (int t = 0; t < NITB; ++t) {
+        const int at = t * 64 + lane;
+        if (at < NVB) reinterpret_cast<float4*>(my_bg)[at] = sb[at];
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -2113,24 +2026,19 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   if (fast) {
     const size_t bg_elem = bg32 ? sizeof(float) : sizeof(double);
     nw64 = (nwav + 63) / 64;
-    const bool staged = bg32 || !d_bg_od;      // all FLOAT: the columns in two runs of 27 layers, staged through LDS by K4
-    const size_t ncol = staged ? nw64 * 64 : (size_t)nwav;
+    const size_t ncol = nw64 * 64;             // the columns in two runs of 27 layers, [2][ncol][27], staged through LDS by K4
     GTRY(ecckd::dev_malloc(ctx, &od_col_v, ncol * 54 * sizeof(float)));
     if (d_bg_od) GTRY(ecckd::dev_malloc(ctx, &bg_col, ncol * 54 * bg_elem));
     float* od_col = (float*)od_col_v;
     const unsigned tblocks = (unsigned)((nwav + 63) / 64);
-    if (staged) {
+    hipLaunchKernelGGL((k_scatter_column_halves<54, float, 2>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, ncol, src_stride,
+                       d_rank, (const float*)d_od, od_col);
+    if (d_bg_od && bg32)
       hipLaunchKernelGGL((k_scatter_column_halves<54, float, 2>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, ncol, src_stride,
-                         d_rank, (const float*)d_od, od_col);
-      if (d_bg_od)
-        hipLaunchKernelGGL((k_scatter_column_halves<54, float, 2>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, ncol, src_stride,
-                           d_rank, (const float*)d_bg_od, (float*)bg_col);
-    } else {
-      hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
-                         (const float*)d_od, od_col);
-      hipLaunchKernelGGL((k_scatter_columns<54, double>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
-                         (const double*)d_bg_od, (double*)bg_col);
-    }
+                         d_rank, (const float*)d_bg_od, (float*)bg_col);
+    else if (d_bg_od)
+      hipLaunchKernelGGL((k_scatter_column_halves<54, double, 2>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, ncol, src_stride,
+                         d_rank, (const double*)d_bg_od, (double*)bg_col);
     const unsigned fblocks = (unsigned)((nwav + 127) / 128);
     GTRY(ecckd::dev_malloc(ctx, &wave_part_v, (size_t)(3 * 54 + 2) * nw64 * sizeof(double)));
     double* wave_part = (double*)wave_part_v;
@@ -2376,8 +2284,8 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
 
   const unsigned pblocks = (unsigned)((nwav + PREP_THREADS - 1) / PREP_THREADS);
   const bool bg32 = d_bg_od && bg_type == ECCKD_F32;
-  // 54 layers of FLOAT optical depths (the CKDMIP spectra): the columns are scattered into rank order first, read
-  // contiguously by the preparation, and the row sums are taken from registers (ECCKD_SW_PREP_GATHER: the gathering path)
+  // 54 layers of FLOAT optical depths (the CKDMIP spectra): the columns are scattered into rank order first, staged through
+  // LDS by the preparation, and the row sums are taken from registers (ECCKD_SW_PREP_GATHER: the general, gathering kernel)
   const bool cols = nlay == 54 && od_type == ECCKD_F32 && std::getenv("ECCKD_SW_PREP_GATHER") == nullptr;
   void *od_col = nullptr, *bg_col = nullptr, *wave_part = nullptr;
   auto drop_temps = [&]() {
@@ -2387,42 +2295,38 @@ int ecckd_gas_create_sw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
     od_col = bg_col = wave_part = nullptr;
   };
   const size_t nw64 = (nwav + 63) / 64;
-#define LAUNCH_PREP_SW(BG, OD, COLS, BGP, ODP, WP)                                                                \
-  hipLaunchKernelGGL((k_gas_prep_sw<BG, OD, COLS>), dim3(pblocks), dim3(PREP_THREADS), 0, ctx->stream, nlay, nwav, \
+#define LAUNCH_PREP_SW(BG, OD, BGP, ODP)                                                                          \
+  hipLaunchKernelGGL((k_gas_prep_sw<BG, OD>), dim3(pblocks), dim3(PREP_THREADS), 0, ctx->stream, nlay, nwav,       \
                      src_stride, averaging_method, cos_sza, min_scaling, max_scaling, g->ireorder,                 \
                      g->lev + nhl, d_ssi, d_albedo, (const BG*)(BGP), (const OD*)(ODP), g->ssi, g->bg_od,          \
-                     g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut, g->tf, g->tg, g->hr_low, g->hr_high, g->fx, R,   \
-                     (double*)(WP), nw64)
+                     g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut, g->tf, g->tg, g->hr_low, g->hr_high, g->fx)
   if (cols) {
     const unsigned tblocks = (unsigned)((nwav + 63) / 64);
-    const bool staged = bg32 || !d_bg_od;   // FLOAT background as well: the staged kernel (columns in runs of 18 layers)
-    const size_t npad = nw64 * 64;
-    int rc2 = ecckd::dev_malloc(ctx, &od_col, (staged ? npad : (size_t)nwav) * 54 * sizeof(float));
-    if (rc2 == ECCKD_OK && d_bg_od) rc2 = ecckd::dev_malloc(ctx, &bg_col, (staged ? npad : (size_t)nwav) * 54 * (bg32 ? sizeof(float) : sizeof(double)));
+    const size_t npad = nw64 * 64;          // the columns in runs of 18 layers, [3][npad][18], staged through LDS by the kernel
+    int rc2 = ecckd::dev_malloc(ctx, &od_col, npad * 54 * sizeof(float));
+    if (rc2 == ECCKD_OK && d_bg_od) rc2 = ecckd::dev_malloc(ctx, &bg_col, npad * 54 * (bg32 ? sizeof(float) : sizeof(double)));
     if (rc2 == ECCKD_OK) rc2 = ecckd::dev_malloc(ctx, &wave_part, (size_t)g->nrows * nw64 * sizeof(double));
     if (rc2 != ECCKD_OK) { drop_temps(); gas_free(g); return rc2; }
-    if (staged) {
-      hipLaunchKernelGGL((k_scatter_column_halves<54, float, SW_STAGE_PARTS>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride, d_rank,
-                         (const float*)d_od, (float*)od_col);
-      if (d_bg_od)
-        hipLaunchKernelGGL((k_scatter_column_halves<54, float, SW_STAGE_PARTS>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride,
-                           d_rank, (const float*)d_bg_od, (float*)bg_col);
-      hipLaunchKernelGGL((k_gas_prep_sw_staged<SW_STAGE_PARTS>), dim3(pblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav, npad, averaging_method, cos_sza,
-                         min_scaling, max_scaling, g->ireorder, g->lev + nhl, d_ssi, d_albedo, (const float*)bg_col,
-                         (const float*)od_col, g->ssi, g->bg_od, g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut, g->tf, g->tg,
-                         g->hr_low, g->hr_high, g->fx, R, (double*)wave_part, nw64);
-    } else {
-      hipLaunchKernelGGL((k_scatter_columns<54, float>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
-                         (const float*)d_od, (float*)od_col);
-      hipLaunchKernelGGL((k_scatter_columns<54, double>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, src_stride, d_rank,
-                         (const double*)d_bg_od, (double*)bg_col);
-      LAUNCH_PREP_SW(double, float, true, bg_col, od_col, wave_part);
-    }
+    hipLaunchKernelGGL((k_scatter_column_halves<54, float, SW_STAGE_PARTS>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride, d_rank,
+                       (const float*)d_od, (float*)od_col);
+    if (d_bg_od && bg32)
+      hipLaunchKernelGGL((k_scatter_column_halves<54, float, SW_STAGE_PARTS>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride,
+                         d_rank, (const float*)d_bg_od, (float*)bg_col);
+    else if (d_bg_od)
+      hipLaunchKernelGGL((k_scatter_column_halves<54, double, SW_STAGE_PARTS>), dim3(tblocks), dim3(256), 0, ctx->stream, nwav, npad, src_stride,
+                         d_rank, (const double*)d_bg_od, (double*)bg_col);
+#define LAUNCH_PREP_SW_STAGED(BG)                                                                                                     \
+  hipLaunchKernelGGL((k_gas_prep_sw_staged<SW_STAGE_PARTS, BG>), dim3(pblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav, npad,        \
+                     averaging_method, cos_sza, min_scaling, max_scaling, g->ireorder, g->lev + nhl, d_ssi, d_albedo, (const BG*)bg_col, \
+                     (const float*)od_col, g->ssi, g->bg_od, g->w1, g->w2, g->cnt, g->hr, g->fds, g->fut, g->tf, g->tg, g->hr_low,      \
+                     g->hr_high, g->fx, R, (double*)wave_part, nw64)
+    if (bg32 || !d_bg_od) LAUNCH_PREP_SW_STAGED(float); else LAUNCH_PREP_SW_STAGED(double);
+#undef LAUNCH_PREP_SW_STAGED
   }
-  else if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP_SW(float, float, false, d_bg_od, d_od, nullptr);
-  else if (bg32) LAUNCH_PREP_SW(float, double, false, d_bg_od, d_od, nullptr);
-  else if (od_type == ECCKD_F32) LAUNCH_PREP_SW(double, float, false, d_bg_od, d_od, nullptr);
-  else LAUNCH_PREP_SW(double, double, false, d_bg_od, d_od, nullptr);
+  else if (bg32 && od_type == ECCKD_F32) LAUNCH_PREP_SW(float, float, d_bg_od, d_od);
+  else if (bg32) LAUNCH_PREP_SW(float, double, d_bg_od, d_od);
+  else if (od_type == ECCKD_F32) LAUNCH_PREP_SW(double, float, d_bg_od, d_od);
+  else LAUNCH_PREP_SW(double, double, d_bg_od, d_od);
 #undef LAUNCH_PREP_SW
   {
     const hipError_t e = hipGetLastError();

@@ -200,8 +200,7 @@ def test_find_g_band_min_max_g_points(ctx, oracle):
 @pytest.mark.parametrize("bg_kind", ["none", "float", "double"])
 @pytest.mark.parametrize("reuse", [False, True])
 def test_gas_prep_fast_path_54_layers(ctx, oracle, bg_kind, reuse, n):
-    """The 54-layer FLOAT-spectrum preparation (k_scatter_column_halves / k_scatter_columns + k_gas_prep_lw_mirror, the inputs
-    staged through LDS when the background is FLOAT or absent) in every instantiation the
+    """The 54-layer FLOAT-spectrum preparation (k_scatter_column_halves + k_gas_prep_lw_mirror, the inputs staged through LDS) in every instantiation the
     find_g_points driver reaches: no / FLOAT / DOUBLE (merged) background, own Planck matrix or the one of an earlier
     gas (find_g_points.cpp:970-984 keeps the first gas's matrix although the later gases are ordered differently)."""
     from ecckd_amd import api
