@@ -1143,6 +1143,8 @@ k_gas_prep_sw(int nlay, size_t n, size_t src_stride, int method, double cos_sza,
               double* __restrict__ fds, double* __restrict__ fut, double* __restrict__ tf,
               double* __restrict__ tg, double* __restrict__ hr_low, double* __restrict__ hr_high,
               double* __restrict__ fx) {
+  // no contraction of a * b + c beyond the explicit fma of exp_fast: this kernel and the staged one then give the same bits
+#pragma clang fp contract(off)
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const size_t j = (size_t)ireorder[i];
@@ -1267,6 +1269,7 @@ k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double m
                      double* __restrict__ fds, double* __restrict__ fut, double* __restrict__ tf,
                      double* __restrict__ tg, double* __restrict__ hr_low, double* __restrict__ hr_high,
                      double* __restrict__ fx, RowMap R, double* __restrict__ wave_part, size_t nw) {
+#pragma clang fp contract(off)
   constexpr int H = 54 / PARTS;
   static_assert(H * PARTS == 54 && (64 * H) % 4 == 0, "whole parts, whole float4s");
   __shared__ __attribute__((aligned(16))) float s_od[4][64 * H];

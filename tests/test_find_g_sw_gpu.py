@@ -148,6 +148,35 @@ def test_gas_prep_sw_fast_path_54_layers(ctx, oracle, bg_kind, method, with_albe
     gas.close()
 
 
+@pytest.mark.parametrize("bg_kind", ["none", "float", "double"])
+def test_gas_prep_sw_staged_and_gathering_kernels_agree(ctx, oracle, monkeypatch, bg_kind):
+    """The same arithmetic per point in both preparation kernels: every prepared array bit for bit; the interval errors (row sums
+    formed per wave inside the staged kernel, per 256-point tile by k_tile_sums after the other) to rounding."""
+    from ecckd_amd import api
+    n = 20011
+    o = _sw_problem(oracle, n, nlay=54, seed=67, bg_kind=bg_kind)
+    od32 = o["od"].astype(np.float32)
+    bg = None if bg_kind == "none" else o["bg"].astype(np.float32) if bg_kind == "float" else o["bg"]
+    ex = o["extras"]
+
+    def make():
+        g = api.GasSW(ctx, o["p"], _dev(ctx, o["ssi"]), _dev(ctx, o["rank"].astype(np.int32)), _dev(ctx, od32),
+                      _dev(ctx, bg) if bg is not None else None, "total-transmission", 0.02, 0.0, MU0, _dev(ctx, o["albedo"]),
+                      ex["min_scaling"], ex["max_scaling"])
+        g.set_band_albedo(0.15)
+        return g
+    staged = make()
+    monkeypatch.setenv("ECCKD_SW_PREP_GATHER", "1")
+    gathered = make()
+    for name in ("ssi", "bg_optical_depth", "weighted_metric", "hr", "flux_dn_surf", "flux_up_toa", "hr_low", "hr_high", "flux_extras"):
+        assert np.array_equal(staged.view(name), gathered.view(name)), name
+    b1 = np.array([0.0, 0.2, 0.55, 0.0])
+    b2 = np.array([0.2, 0.55, 1.0, 1.0])
+    assert np.allclose(staged.calc_error_batch(0, n, b1, b2), gathered.calc_error_batch(0, n, b1, b2), rtol=1e-9, atol=1e-12)
+    staged.close()
+    gathered.close()
+
+
 @pytest.mark.parametrize("bg_kind", ["none", "float"])
 def test_gas_prep_sw_staged_less_than_a_wave(ctx, oracle, bg_kind):
     """41 points: one partly filled wave, three idle ones in the only block."""
