@@ -264,12 +264,17 @@ k_scatter_column_halves(size_t n, size_t npad, size_t src_stride, const int32_t*
     const size_t j = j0 + lane;
     s_tile[l][lane] = (j < n) ? src[(size_t)l * src_stride + j] : (SrcT)0;
   }
+  // the ranks of the tile's 64 points: one coalesced load per wave, handed out lane by lane below (a load per point inside the
+  // loop made every store wait for its own memory latency)
+  const int my_rank = j0 + lane < n ? rank[j0 + lane] : -1;
   __syncthreads();
+  const size_t part = (size_t)(lane / HP) * npad;
+  const int within = lane % HP;
+#pragma unroll 4
   for (int p = wave; p < 64; p += 4) {
-    const size_t j = j0 + p;
-    if (j >= n) break;
-    const size_t r = (size_t)rank[j];
-    if (lane < NLAY) dst[((size_t)(lane / HP) * npad + r) * HP + lane % HP] = s_tile[lane][p];
+    const int r = __shfl(my_rank, p, 64);
+    if (r < 0) break;
+    if (lane < NLAY) dst[(part + (size_t)r) * HP + within] = s_tile[lane][p];
   }
 }
 
