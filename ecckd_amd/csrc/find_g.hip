@@ -307,7 +307,10 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   // (rr, qq) adds the 16 points qq*16.. of row rr in index order, the four quarters are combined by two xor-shuffles.
   constexpr int ROWW = 65;
   constexpr int NPUSH = 3 * H + 1;                 // w1 and Planck row per layer, heating rate per layer, boundary flux
-  __shared__ double s_sum[4][16 * ROWW];
+  __shared__ double s_sum[4][8 * ROWW];
+  // the first sweep's fluxes at the wave's H + 1 levels, [level][lane]: 56 registers that the kernel does not have (it spilled 120
+  // bytes per lane with them); before the sweep the block holds the staged inputs
+  __shared__ __attribute__((aligned(16))) double s_f1[4][(H + 1) * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = wave & 1, pair = wave >> 1;
@@ -324,7 +327,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
   const OdT* odc = od_col + (STAGED ? 0 : ii * NLAY);
   const size_t wid = (size_t)blockIdx.x * 2 + pair;          // index of this pair's 64 points among the 64-point groups
   double* sum_tile = s_sum[wave];
-  const int rr = lane & 15, qq = lane >> 4;
+  const int rr = lane & 7, qq = lane >> 3;
   int slot = 0;
   // rows of the table ecckd_gas_create_lw builds: A = w1 (0..NLAY), B = planck_hl(l+1) (NLAY..), H = hr (2 NLAY..), then the two boundary rows
   auto row_of_slot = [&](int sl) -> int {
@@ -333,13 +336,14 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     return 3 * NLAY + (half ? 0 : 1);
   };
   auto push = [&](double v) {
-    sum_tile[(slot & 15) * ROWW + lane] = live ? v : 0.0;
-    if ((slot & 15) == 15 || slot == NPUSH - 1) {
-      const int base = slot & ~15, count = slot - base + 1;
+    sum_tile[(slot & 7) * ROWW + lane] = live ? v : 0.0;
+    if ((slot & 7) == 7 || slot == NPUSH - 1) {
+      const int base = slot & ~7, count = slot - base + 1;
       __builtin_amdgcn_wave_barrier();
       double sum = 0.0;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) sum += sum_tile[rr * ROWW + qq * 16 + j];
+      for (int j = 0; j < 8; ++j) sum += sum_tile[rr * ROWW + qq * 8 + j];
+      sum += __shfl_xor(sum, 8, 64);
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
       if (wave_part && qq == 0 && rr < count && wid < nw) wave_part[(size_t)row_of_slot(base + rr) * nw + wid] = sum;
@@ -362,7 +366,8 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     return ecckd::div_fast(pref, ecckd::exp_fast_s(freq * hk[level], ek) - 1.0);
   };
   // local layer l is layer l (even wave) or NLAY-1-l (odd wave); its near level is where the first sweep enters
-  double ee[H], s2[H], f1[H + 1];
+  double ee[H], s2[H];
+  double* const f1 = s_f1[wave] + lane;     // f1[level * 64]
   // All inputs of this wave's half column are fetched BEFORE the first store: on this hardware the counter a load
   // waits on also counts the stores issued before it, so a load inside the layer loop would wait for the previous
   // layer's four row stores to complete and the kernel would run at one store latency per layer.
@@ -373,9 +378,9 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     // Both inputs come as [2][npad][H] (k_scatter_column_halves), this wave's 64 x H block of each is one contiguous
     // piece.  It is copied into LDS (the row-sum tile, idle until the first push) with full-width loads and each lane takes
     // its column from there: read straight from memory a column costs 64 cache lines per load instruction.
-    float* st = reinterpret_cast<float*>(sum_tile);
+    float* st = reinterpret_cast<float*>(s_f1[wave]);
     constexpr int NV = 16 * H;                                // float4s in the block
-    static_assert(NV * 16 <= 16 * ROWW * 8, "the block fits the tile");
+    static_assert(NV * 16 * 2 <= (H + 1) * 64 * 8, "a DOUBLE block fits too");
     const size_t widc = wid < nw ? wid : nw - 1;              // a pair past the end repeats the last point, as ii does
     const int lc = live ? lane : (int)((n - 1) - widc * 64);
     const size_t blk = ((size_t)half * (nw * 64) + widc * 64) * H;
@@ -397,23 +402,18 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
       for (int l = 0; l < H; ++l) bg_in[l] = (BgT)st[lc * H + (half ? H - 1 - l : l)];
       __builtin_amdgcn_wave_barrier();
     } else if (bg_col) {
-      // DOUBLE (merged) background: the block is twice the tile, so it comes in two pieces of 32 points
+      // DOUBLE (merged) background: the same with 16-byte pairs of doubles
       const double* colb = reinterpret_cast<const double*>(bg_col) + blk;
-      const double* std_ = reinterpret_cast<const double*>(sum_tile);
+      double* std_ = s_f1[wave];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-#pragma unroll
-        for (int t = 0; t < (NV + 63) / 64; ++t) {
-          const int at = t * 64 + lane;
-          if (at < NV) reinterpret_cast<double2*>(sum_tile)[at] = reinterpret_cast<const double2*>(colb + (size_t)r * 32 * H)[at];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if ((lc >> 5) == r) {
-#pragma unroll
-          for (int l = 0; l < H; ++l) bg_in[l] = (BgT)std_[(lc & 31) * H + (half ? H - 1 - l : l)];
-        }
-        __builtin_amdgcn_wave_barrier();
+      for (int t = 0; t < (2 * NV + 63) / 64; ++t) {
+        const int at = t * 64 + lane;
+        if (at < 2 * NV) reinterpret_cast<double2*>(std_)[at] = reinterpret_cast<const double2*>(colb)[at];
       }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int l = 0; l < H; ++l) bg_in[l] = (BgT)std_[lc * H + (half ? H - 1 - l : l)];
+      __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll
       for (int l = 0; l < H; ++l) bg_in[l] = (BgT)0;
@@ -449,7 +449,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     const double next = flux * (1.0 - eps) + b_near * emf + b_far * fac;
     ee[l] = eps;
     s2[l] = b_far * emf + b_near * fac;
-    f1[l + 1] = next;
+    f1[(l + 1) * 64] = next;
     double m;
     switch (method) {
       case ECCKD_AVG_TRANSMISSION: m = 1.0 - ecckd::exp_fast_s(-od * kD, ek); break;
@@ -477,8 +477,9 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     const int L = half ? NLAY - 1 - l : l;
     const double next = flux * (1.0 - ee[l]) + s2[l];
     // conv * (dn(L+1) - dn(L) - up(L+1) + up(L)), left to right
-    const double net = half ? (next - flux) - f1[l] + f1[l + 1]        // second sweep is downwelling: flux = dn(L), next = dn(L+1)
-                            : (f1[l + 1] - f1[l]) - flux + next;       // second sweep is upwelling:   flux = up(L+1), next = up(L)
+    const double f1a = f1[l * 64], f1b = f1[(l + 1) * 64];
+    const double net = half ? (next - flux) - f1a + f1b        // second sweep is downwelling: flux = dn(L), next = dn(L+1)
+                            : (f1b - f1a) - flux + next;       // second sweep is upwelling:   flux = up(L+1), next = up(L)
     const double hrv = conv[L] * net;
     if (live) __builtin_nontemporal_store(hrv, &hr[(size_t)L * n + i]);
     push(hrv);
