@@ -572,11 +572,20 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
             phase[k] += g["timing"].get(k, 0.0)
         tm = time.perf_counter()
         if merged_map:
-            # this process's bands of the gas: g point of every wavenumber counted from the band's first (-1 elsewhere)
-            gp = torch.full((nwav,), -1, dtype=torch.int32, device=dev)
-            for b, r in res:
-                sl = slice(int(g["band_begin"][b]), int(g["band_end"][b]) + 1)      # a band's members are contiguous in wavenumber
-                gp[sl] = api.gas_g_point(ctx, g["rank"][sl].contiguous(), r["rank1"], r["rank2"])
+            # this process's bands of the gas: (band << 16) + g point of every wavenumber counted from the band's first (-1
+            # elsewhere).  One launch over the spectrum with the bands' rank ranges one after the other (a band's ranks lie in its
+            # own index range, so no other band's wavenumbers fall into them), then from that running count to band and count
+            # within the band - what the root can renumber once it knows every band's number of g points.
+            if res:
+                r1 = np.concatenate([np.asarray(r["rank1"], dtype=np.int64) for _, r in res])
+                r2 = np.concatenate([np.asarray(r["rank2"], dtype=np.int64) for _, r in res])
+                assert nband < 32768 and all(len(r["rank1"]) < 65536 for _, r in res)
+                within = np.concatenate([(b << 16) + np.arange(len(r["rank1"]), dtype=np.int32) for b, r in res]).astype(np.int32)
+                gp = api.gas_g_point(ctx, g["rank"], r1, r2)
+                tbl = torch.as_tensor(within, device=dev)
+                gp = torch.where(gp >= 0, tbl[gp.clamp(min=0).long()], gp)
+            else:
+                gp = torch.full((nwav,), -1, dtype=torch.int32, device=dev)
             maps[gi] = gp
         if gi == 0 and sw is None:
             first_lw_gas = gas
@@ -608,15 +617,12 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
     for k, g in enumerate(per_gas):
         g["g_min"], g["g_max"] = g_min[k], g_max[k]
     if merged_map:
-        # the gathered maps count a band's g points from 0: add the number of g points of the gas's earlier bands
-        # (SingleGasData::store_g_points numbers them through the bands, single_gas_data.h:56-62)
+        # the gathered maps hold (band << 16) + the g point counted from the band's first: add the number of g points of the gas's
+        # earlier bands (SingleGasData::store_g_points numbers them through the bands, single_gas_data.h:56-62)
         for gi, (gp, out) in enumerate(zip(gas_gp, per_gas)):
-            first = np.concatenate([[0], np.cumsum(out["n_g_points"])[:-1]])
-            for b in range(nband):
-                i0, i1 = by_task[(gi, b)]["index_range"]
-                if first[b]:
-                    sl = gp[i0:i1 + 1]
-                    sl += torch.where(sl >= 0, int(first[b]), 0).to(sl.dtype)
+            first = torch.as_tensor(np.concatenate([[0], np.cumsum(out["n_g_points"])[:-1]]).astype(np.int32), device=gp.device)
+            renumbered = first[(gp >> 16).clamp(min=0).long()] + (gp & 0xffff)
+            gas_gp[gi] = torch.where(gp >= 0, renumbered, gp)
         result["g_point"], result["n_unassigned"] = api.merge_g_points(ctx, gas_gp, g_min, g_max)
         result["gas_g_point"] = gas_gp
     phase["collect"] = time.perf_counter() - tc
