@@ -232,7 +232,7 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
           out.write_slice("spectral_flux_dn_direct_sw", c, dn_all); out.write_slice("spectral_flux_up_sw", c, up_all);
         }
         out.close();
-        return 0;
+        return done(0);
       }
       if (!f.exist("planck_hl")) fail(ECCKD_PARAMETER_ERROR, "%s holds no planck_hl: not a longwave optical-depth file", ckd_file.c_str());
       NcOut out(output);
@@ -257,7 +257,7 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
         out.write_slice("spectral_flux_dn_lw", c, dn); out.write_slice("spectral_flux_up_lw", c, up);
       }
       out.close();
-      return 0;
+      return done(0);
     }
 
     if (gases.empty()) fail(ECCKD_PARAMETER_ERROR, "No spectrum files given");
@@ -425,7 +425,7 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
       LOG("  column %d done\n", c + 1);
     }
     out.close();
-    return 0;
+    return done(0);
   } catch (const Fatal& f) {
     std::fprintf(stderr, "*** Error: %s\n", f.msg.c_str());
     return f.code ? f.code : 1;

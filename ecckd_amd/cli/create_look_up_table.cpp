@@ -292,6 +292,6 @@ int main(int argc, char** argv) {
 
     LOG("Writing %s\n", output.c_str());
     write_ckd(output, model, history_line(argc, argv), config.str());
-    return 0;
+    return done(0);
   });
 }

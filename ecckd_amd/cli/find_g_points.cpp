@@ -457,7 +457,7 @@ int main(int argc, char** argv) {
     if (world > 1) LOG("Process %d: %zu searches, sum of the g points' errors %.17g K d-1\n", my_rank, results.size(), my_cost);
     if (my_rank != 0) {
       write_part(output + ".part" + std::to_string(my_rank), results);
-      return 0;
+      return done(0);
     }
     double part_timeout = 3600.0;                      // extension key: how long process 0 waits for the others, in seconds
     config.read(part_timeout, "part_timeout");
@@ -601,6 +601,6 @@ int main(int argc, char** argv) {
     file.write("wavenumber", wavenumber);
     file.write_as_double("g_point", g_point);
     file.close();
-    return 0;
+    return done(0);
   });
 }

@@ -438,6 +438,6 @@ int main(int argc, char** argv) {
       std::fprintf(stderr, "*** Error: minimizer returned an anomalous status\n");
       return 1;
     }
-    return 0;
+    return done(0);
   });
 }

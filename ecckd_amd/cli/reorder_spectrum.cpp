@@ -74,6 +74,6 @@ int main(int argc, char** argv) {
     ck(ecckd_write_order_file(output.c_str(), molecule.c_str(), config.str().c_str(), history.c_str(), nband, clamp1.data(),
                               clamp2.data(), s.nwav, s.wavenumber_cm_1.data(), s.d_wavenumber_cm_1.data(), iband.data(),
                               rank.data(), col.data(), key.data()));
-    return 0;
+    return done(0);
   });
 }

@@ -169,6 +169,6 @@ int main(int argc, char** argv) {
       }
     }
     file.close();
-    return 0;
+    return done(0);
   });
 }
