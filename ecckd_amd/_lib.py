@@ -172,6 +172,7 @@ SIGNATURES = {
     "ecckd_nc_read_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_longlong, C.c_int, C.c_void_p, C.c_size_t]),
     "ecckd_inflate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_void_p,
                                 C.POINTER(C.c_int)]),
+    "ecckd_inflate_host": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "ecckd_nc_read_att_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "ecckd_nc_read_att_double": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), _c_double_p, C.c_size_t]),
     "ecckd_nc_create": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),

@@ -270,7 +270,6 @@ k_scatter_column_halves(size_t n, size_t npad, size_t src_stride, const int32_t*
   __syncthreads();
   const size_t part = (size_t)(lane / HP) * npad;
   const int within = lane % HP;
-#pragma unroll 4
   for (int p = wave; p < 64; p += 4) {
     const int r = __shfl(my_rank, p, 64);
     if (r < 0) break;

@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "nc_hdf5.hpp"
+#include "fast_inflate.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -75,6 +76,7 @@ struct Api {
   herr_t (*H5Pclose)(hid_t) = nullptr;
   herr_t (*H5Dread_chunk)(hid_t, hid_t, const hsize_t*, unsigned*, void*) = nullptr;
   herr_t (*H5Dget_chunk_storage_size)(hid_t, const hsize_t*, hsize_t*) = nullptr;
+  herr_t (*H5Dget_chunk_info_by_coord)(hid_t, const hsize_t*, unsigned*, unsigned long long* /* haddr_t */, hsize_t*) = nullptr;   // 1.10.5 on
   int (*H5Tget_order)(hid_t) = nullptr;
   int (*z_uncompress)(unsigned char*, unsigned long*, const unsigned char*, unsigned long) = nullptr;   // zlib, loaded beside
   herr_t (*H5free_memory)(void*) = nullptr;   // optional (1.8.13+): releases what the library allocated for variable-length strings
@@ -115,7 +117,7 @@ Api* api() {
   a.H5free_memory = reinterpret_cast<decltype(a.H5free_memory)>(dlsym(a.lib, "H5free_memory"));
 #define OPT(f) a.f = reinterpret_cast<decltype(a.f)>(dlsym(a.lib, #f))
   OPT(H5Dget_create_plist); OPT(H5Pget_layout); OPT(H5Pget_chunk); OPT(H5Pget_nfilters); OPT(H5Pget_filter2); OPT(H5Pclose);
-  OPT(H5Dread_chunk); OPT(H5Dget_chunk_storage_size); OPT(H5Tget_order);
+  OPT(H5Dread_chunk); OPT(H5Dget_chunk_storage_size); OPT(H5Tget_order); OPT(H5Dget_chunk_info_by_coord);
 #undef OPT
   for (const char* zn : {"libz.so.1", "libz.so", "/opt/conda/lib/libz.so.1"}) {
     if (void* z = dlopen(zn, RTLD_NOW | RTLD_LOCAL)) {
@@ -494,6 +496,10 @@ int h5_chunks_next(H5ChunkReader* r, unsigned long long* off, size_t* bytes, int
 // zlib's uncompress as loaded beside the HDF5 library (thread-safe); false if there is none or the stream is not dst_len bytes
 bool h5_inflate_host(H5File* h, void* dst, size_t dst_len, const void* src, size_t src_len) {
   Api* a = h->a;
+  // the in-tree decoder first (fast_inflate.cpp: ~3x zlib on shuffled FLOATs; ECCKD_ZLIB_INFLATE: zlib alone); whatever it
+  // does not take or does not pass its checks goes to zlib
+  const bool zlib_only = std::getenv("ECCKD_ZLIB_INFLATE") != nullptr;   // (per call: probes and tests switch it)
+  if (!zlib_only && fast_inflate_zlib(dst, dst_len, src, src_len)) return true;
   if (!a->z_uncompress) return false;
   unsigned long n = (unsigned long)dst_len;
   return a->z_uncompress((unsigned char*)dst, &n, (const unsigned char*)src, (unsigned long)src_len) == 0 && n == dst_len;
@@ -513,6 +519,24 @@ int h5_chunks_read(H5ChunkReader* r, void* dst, int* deflated, int* shuffled) {
   for (int k = r->plan.nd - 1; k >= 0; --k) { if (++r->ci[k] <= r->c1[k]) break; r->ci[k] = r->c0[k]; }
   return ECCKD_OK;
 }
+
+// where the chunk h5_chunks_next announced lies in the file (instead of its bytes: the caller reads them itself, from any
+// thread); *addr = ~0 if the library cannot tell (before 1.10.5) or the chunk has no address.  Advances like h5_chunks_read.
+int h5_chunks_locate(H5ChunkReader* r, unsigned long long* addr, int* deflated, int* shuffled) {
+  Api* a = r->h->a;
+  *addr = ~0ull;
+  unsigned mask = 0;
+  unsigned long long at = ~0ull;
+  hsize_t size = 0;
+  if (a->H5Dget_chunk_info_by_coord && a->H5Dget_chunk_info_by_coord(r->d, r->off, &mask, &at, &size) >= 0 && size > 0) *addr = at;
+  *deflated = !(mask & (1u << r->i_deflate));
+  *shuffled = r->i_shuffle >= 0 && !(mask & (1u << r->i_shuffle));
+  ++r->next;
+  for (int k = r->plan.nd - 1; k >= 0; --k) { if (++r->ci[k] <= r->c1[k]) break; r->ci[k] = r->c0[k]; }
+  return ECCKD_OK;
+}
+bool h5_can_locate(H5File* h) { return h->a->H5Dget_chunk_info_by_coord != nullptr; }
+const char* h5_path(H5File* h) { return h->path.c_str(); }
 
 static hid_t open_att(H5File* h, const char* var, const char* att) {
   Api* a = h->a;

@@ -407,6 +407,10 @@ int ecckd_nc_read_dev(ecckd_ctx* ctx, ecckd_nc* file, const char* name, long lon
  * The Adler-32 trailer is not verified. */
 int ecckd_inflate(ecckd_ctx* ctx, int nstreams, const void* h_in, const unsigned long long* h_in_off,
                   const unsigned long long* h_out_bytes, void* h_out, int* h_status);
+/* One zlib stream inflated on the calling thread by the in-tree decoder the worker threads of ecckd_nc_read_dev use before
+ * they fall back to zlib (csrc/fast_inflate.cpp; no device involved).  *ok = 1: the stream inflates to exactly out_bytes
+ * bytes with the right Adler-32 and out holds them; 0: not taken or a check failed. */
+int ecckd_inflate_host(const void* in, size_t in_bytes, void* out, size_t out_bytes, int* ok);
 int ecckd_nc_read_att_text(ecckd_nc* file, const char* var, const char* att, int* exists, char* out, size_t capacity);
 int ecckd_nc_read_att_double(ecckd_nc* file, const char* var, const char* att, int* nelems, double* out, size_t capacity);
 /* writing: define, ecckd_nc_enddef (picks CDF-1 / CDF-2 / CDF-5 from the sizes), then whole variables */

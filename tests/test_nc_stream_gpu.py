@@ -59,9 +59,11 @@ def test_netcdf4_variable_to_device(ctx, tmp_path):
         assert np.array_equal(f.read_dev(ctx, "optical_depth", 0, dtype=torch.float64).cpu().numpy(), od[0].astype(np.float64))
 
 
-@pytest.mark.parametrize("mode", ["device inflate", "host inflate", "host only"])
+@pytest.mark.parametrize("mode", ["device inflate", "host inflate", "host inflate, serial read", "host inflate, zlib", "host only"])
 def test_netcdf4_chunks_to_the_device(ctx, tmp_path, monkeypatch, mode):
-    """The NetCDF-4 read path: raw chunks inflated by worker threads into pinned slots (default) or on the device
+    """The NetCDF-4 read path: raw chunks read (pread at the addresses the library reports; ECCKD_H5_SERIAL_READ=1: by the calling
+    thread through the library) and inflated by worker threads (csrc/fast_inflate.cpp, then zlib for what it refuses;
+    ECCKD_ZLIB_INFLATE=1: zlib alone) into pinned slots (default) or on the device
     (ECCKD_GPU_INFLATE=1: csrc/inflate.hip, one wavefront per chunk), then unshuffled, converted and placed by k_place_chunks;
     or everything on the host and one upload (ECCKD_NO_DEVICE_PLACE=1).  Chunk shapes that do not divide the variable, chunks
     spanning several slices, DOUBLE storage, a 1-D variable, special values, both output types: the same bits every way."""
@@ -75,6 +77,10 @@ def test_netcdf4_chunks_to_the_device(ctx, tmp_path, monkeypatch, mode):
         monkeypatch.setenv("ECCKD_GPU_INFLATE", "1")
     elif mode == "host only":
         monkeypatch.setenv("ECCKD_NO_DEVICE_PLACE", "1")
+    elif mode == "host inflate, serial read":
+        monkeypatch.setenv("ECCKD_H5_SERIAL_READ", "1")
+    elif mode == "host inflate, zlib":
+        monkeypatch.setenv("ECCKD_ZLIB_INFLATE", "1")
     rs = np.random.RandomState(0)
     od = np.exp(np.cumsum(rs.normal(0, 0.05, (3, 17, 50_003)), axis=-1)).astype(np.float32)
     od[1, 3, :7] = [0.0, -0.0, np.float32(1e-42), np.inf, -np.inf, 1.0, -1.0]

@@ -22,10 +22,13 @@ h5.write(path, {"optical_depth": (od[None], "f4", (1, 1, cpts), None)})
 print(f"file written in {time.perf_counter() - t0:.1f} s: {os.path.getsize(path) / 1e6:.0f} MB for {od.nbytes / 1e6:.0f} MB", flush=True)
 ctx = api.Context(0)
 import torch
-for label, env in (("worker threads inflate, device places (default)", {}), ("device inflates and places", {"ECCKD_GPU_INFLATE": "1"}),
+for label, env in (("worker threads read and inflate, device places (default)", {}),
+                   ("the same with zlib instead of the in-tree decoder", {"ECCKD_ZLIB_INFLATE": "1"}),
+                   ("calling thread reads the raw chunks, worker threads inflate with zlib (the path before)", {"ECCKD_H5_SERIAL_READ": "1", "ECCKD_ZLIB_INFLATE": "1"}),
+                   ("device inflates and places", {"ECCKD_GPU_INFLATE": "1"}),
                    ("worker threads inflate and place, one upload", {"ECCKD_NO_DEVICE_PLACE": "1"}),
                    ("HDF5 library alone", {"ECCKD_NO_PARALLEL_INFLATE": "1"})):
-    for k in ("ECCKD_NO_PARALLEL_INFLATE", "ECCKD_GPU_INFLATE", "ECCKD_NO_DEVICE_PLACE"):
+    for k in ("ECCKD_NO_PARALLEL_INFLATE", "ECCKD_GPU_INFLATE", "ECCKD_NO_DEVICE_PLACE", "ECCKD_H5_SERIAL_READ", "ECCKD_ZLIB_INFLATE"):
         os.environ.pop(k, None)
     os.environ.update(env)
     os.environ["ECCKD_H5_TIMES"] = "1"
