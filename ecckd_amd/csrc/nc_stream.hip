@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <thread>
 #include <fcntl.h>
@@ -367,6 +368,7 @@ static int read_h5_dev(ecckd_ctx* ctx, H5File* h5, const char* name, long long s
         std::this_thread::yield();
       }
     };
+    const auto t_begin = std::chrono::steady_clock::now();
     for (size_t j = 0; j < n && rc == ECCKD_OK && !stop.load(); ++j) {
       size_t bytes = 0;
       int unwritten = 0;
@@ -416,6 +418,7 @@ static int read_h5_dev(ecckd_ctx* ctx, H5File* h5, const char* name, long long s
       state[j].store(1, std::memory_order_release);
       rc = ship_ready(false);
     }
+    const auto t_walked = std::chrono::steady_clock::now();
     if (rc != ECCKD_OK || fallback) stop.store(1);
     if (!stop.load()) rc = ship_ready(true);
     const bool inflate_failed = stop.load() && rc == ECCKD_OK && !fallback;
@@ -423,6 +426,12 @@ static int read_h5_dev(ecckd_ctx* ctx, H5File* h5, const char* name, long long s
     for (std::thread& th : pool) th.join();
     (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    if (std::getenv("ECCKD_H5_TIMES")) {
+      const auto t_end = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "%s \"%s\": %zu chunks, %s by the calling thread in %.1f ms, all inflated and shipped %.1f ms later (%u threads)\n",
+                   h5_path(h5), name, n, fd >= 0 ? "located" : "read", std::chrono::duration<double, std::milli>(t_walked - t_begin).count(),
+                   std::chrono::duration<double, std::milli>(t_end - t_walked).count(), nworkers);
+    }
     if (rc != ECCKD_OK) return rc;
     if (inflate_failed) return fail(ECCKD_PROCESSING_ERROR, "a chunk of \"%s\" could not be inflated", name);
   }
