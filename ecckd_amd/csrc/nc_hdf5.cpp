@@ -521,8 +521,9 @@ int h5_chunks_read(H5ChunkReader* r, void* dst, int* deflated, int* shuffled) {
 }
 
 // where the chunk h5_chunks_next announced lies in the file (instead of its bytes: the caller reads them itself, from any
-// thread); *addr = ~0 if the library cannot tell (before 1.10.5) or the chunk has no address.  Advances like h5_chunks_read.
-int h5_chunks_locate(H5ChunkReader* r, unsigned long long* addr, int* deflated, int* shuffled) {
+// thread); *addr = ~0 if the library cannot tell (before 1.10.5) or the chunk has no address.  advance: on to the next chunk, like
+// h5_chunks_read (false: the same chunk can still be read through the library).
+int h5_chunks_locate(H5ChunkReader* r, unsigned long long* addr, int* deflated, int* shuffled, bool advance) {
   Api* a = r->h->a;
   *addr = ~0ull;
   unsigned mask = 0;
@@ -531,6 +532,7 @@ int h5_chunks_locate(H5ChunkReader* r, unsigned long long* addr, int* deflated, 
   if (a->H5Dget_chunk_info_by_coord && a->H5Dget_chunk_info_by_coord(r->d, r->off, &mask, &at, &size) >= 0 && size > 0) *addr = at;
   *deflated = !(mask & (1u << r->i_deflate));
   *shuffled = r->i_shuffle >= 0 && !(mask & (1u << r->i_shuffle));
+  if (!advance) return ECCKD_OK;
   ++r->next;
   for (int k = r->plan.nd - 1; k >= 0; --k) { if (++r->ci[k] <= r->c1[k]) break; r->ci[k] = r->c0[k]; }
   return ECCKD_OK;

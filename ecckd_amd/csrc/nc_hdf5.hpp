@@ -26,7 +26,7 @@ int h5_chunks_open(H5File* h, const char* name, long long slice, size_t capacity
 int h5_chunks_next(H5ChunkReader* r, unsigned long long* off, size_t* bytes, int* unwritten);
 int h5_chunks_read(H5ChunkReader* r, void* dst, int* deflated, int* shuffled);
 // the address of the chunk in the file instead of its bytes (~0: unknown), for readers that pread it themselves
-int h5_chunks_locate(H5ChunkReader* r, unsigned long long* addr, int* deflated, int* shuffled);
+int h5_chunks_locate(H5ChunkReader* r, unsigned long long* addr, int* deflated, int* shuffled, bool advance = true);
 bool h5_can_locate(H5File* h);
 const char* h5_path(H5File* h);
 void h5_chunks_close(H5ChunkReader* r);

@@ -384,33 +384,24 @@ static int read_h5_dev(ecckd_ctx* ctx, H5File* h5, const char* name, long long s
       } else {
         // the first chunk through the library, and - where chunks can be located - once more with pread: the same bytes, or
         // the addresses are not file offsets (a user block) and every chunk goes through the library
+        unsigned long long a0 = ~0ull;
+        if (fd >= 0) {
+          int d0 = 0, s0 = 0;
+          rc = h5_chunks_locate(rd, &a0, &d0, &s0, false);
+          if (rc != ECCKD_OK) break;
+        }
         jobs[j].raw.resize(bytes);
         rc = h5_chunks_read(rd, jobs[j].raw.data(), &deflated, &shuffled);
         if (rc != ECCKD_OK) break;
         if (fd >= 0) {
-          bool same = false;
-          if (n > 1) {
-            // look the same chunk up again: step the reader back is not offered, so ask for the address by hand
-            H5ChunkReader* probe = nullptr;
-            H5ChunkPlan P2;
-            if (h5_chunks_open(h5, name, slice, capacity, &probe, &P2) == ECCKD_OK && probe) {
-              unsigned long long o2[8]; size_t b2 = 0; int u2 = 0, d2 = 0, s2 = 0;
-              unsigned long long a2 = ~0ull;
-              if (h5_chunks_next(probe, o2, &b2, &u2) == ECCKD_OK && !u2 && b2 == bytes && h5_chunks_locate(probe, &a2, &d2, &s2) == ECCKD_OK &&
-                  a2 != ~0ull) {
-                std::vector<unsigned char> again(bytes);
-                size_t got = 0;
-                while (got < bytes) {
-                  const ssize_t k = pread(fd, again.data() + got, bytes - got, (off_t)(a2 + got));
-                  if (k <= 0) break;
-                  got += (size_t)k;
-                }
-                same = got == bytes && std::memcmp(again.data(), jobs[j].raw.data(), bytes) == 0;
-              }
-              h5_chunks_close(probe);
-            }
+          std::vector<unsigned char> again(bytes);
+          size_t got = 0;
+          while (a0 != ~0ull && got < bytes) {
+            const ssize_t k = pread(fd, again.data() + got, bytes - got, (off_t)(a0 + got));
+            if (k <= 0) break;
+            got += (size_t)k;
           }
-          if (!same) { close(fd); fd = -1; }
+          if (got != bytes || std::memcmp(again.data(), jobs[j].raw.data(), bytes) != 0) { close(fd); fd = -1; }
         }
       }
       if (!deflated) { fallback = true; break; }
