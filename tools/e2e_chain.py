@@ -121,7 +121,32 @@ def hr_rms_difference(p1, hr_a, hr_b):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def gpu_chain(d, inp):
+def write_netcdf4_spectra(d):
+    """The five spectra once more as NetCDF-4 (*.h5: chunks of 1 x 1 x 262 144 FLOATs, shuffle + deflate 2), what the CKDMIP files
+    and the reference's scripts use; written through the HDF5 library (tests/h5_fixture.py), not timed."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import h5_fixture as h5
+    from scipy.io import netcdf_file
+    if not h5.available():
+        return False
+    for name in [f"present_{g}" for g in GASES] + [f"ideal_{g}" for g in GASES] + ["ideal_h2o_x4"]:
+        f = netcdf_file(os.path.join(d, name + ".nc"), "r", mmap=False)
+        v = {k: f.variables[k][...] for k in ("pressure_hl", "temperature_hl", "wavenumber", "mole_fraction_fl", "optical_depth",
+                                               "reference_surface_mole_fraction")}
+        gas = f.constituent_id.decode() if isinstance(f.constituent_id, bytes) else f.constituent_id
+        f.close()
+        nwav = v["wavenumber"].size
+        h5.write(os.path.join(d, name + ".h5"), {
+            "pressure_hl": (v["pressure_hl"], "f8", None, None), "temperature_hl": (v["temperature_hl"], "f8", None, None),
+            "wavenumber": (v["wavenumber"], "f8", (min(nwav, 262144),), None), "mole_fraction_fl": (v["mole_fraction_fl"], "f8", None, None),
+            "reference_surface_mole_fraction": (float(v["reference_surface_mole_fraction"]), "f8", None, None),
+            "optical_depth": (v["optical_depth"], "f4", (1, 1, min(nwav, 262144)), None)}, {"constituent_id": gas})
+    return True
+
+
+def gpu_chain(d, inp, ext="nc"):
+    """ext: the spectra the tools read are the classic files (nc) or their NetCDF-4 twins (h5); everything the tools write is
+    classic either way."""
     from scipy.io import netcdf_file
     bindir = os.path.join(ROOT, "bin")
     secs = {}
@@ -135,18 +160,18 @@ def gpu_chain(d, inp):
         return r
 
     for g in GASES:
-        run("reorder_spectrum", "reorder_spectrum", f"input=present_{g}.nc", f"output=order_{g}.nc", "wavenumber1=0 1300", "wavenumber2=1300 3260")
+        run("reorder_spectrum", "reorder_spectrum", f"input=present_{g}.{ext}", f"output=order_{g}.nc", "wavenumber1=0 1300", "wavenumber2=1300 3260")
     with open(os.path.join(d, "find_g.cfg"), "w") as f:
         f.write("heating_rate_tolerance %g\nmax_iterations %d\ntolerance_tolerance %g\nflux_weight %g\naveraging_method transmission\n"
                 "gases h2o co2\n"
-                "\\begin h2o\n input present_h2o.nc\n reordering_input order_h2o.nc\n background_input present_co2.nc\n\\end h2o\n"
-                "\\begin co2\n input present_co2.nc\n reordering_input order_co2.nc\n background_input present_h2o.nc\n\\end co2\n"
-                % (FIND_G["heating_rate_tolerance"], FIND_G["max_iterations"], FIND_G["tolerance_tolerance"], FIND_G["flux_weight"]))
+                "\\begin h2o\n input present_h2o.%s\n reordering_input order_h2o.nc\n background_input present_co2.%s\n\\end h2o\n"
+                "\\begin co2\n input present_co2.%s\n reordering_input order_co2.nc\n background_input present_h2o.%s\n\\end co2\n"
+                % (FIND_G["heating_rate_tolerance"], FIND_G["max_iterations"], FIND_G["tolerance_tolerance"], FIND_G["flux_weight"], ext, ext, ext, ext))
     run("find_g_points", "find_g_points", "find_g.cfg", "output=gpoints.nc")
     with open(os.path.join(d, "lut.cfg"), "w") as f:
         f.write("input gpoints.nc\noutput raw_ckd.nc\ngases h2o co2\n"
-                "\\begin h2o\n conc_dependence lut\n input \"ideal_h2o.nc ideal_h2o_x4.nc\"\n\\end h2o\n"
-                "\\begin co2\n conc_dependence linear\n input ideal_co2.nc\n\\end co2\n")
+                "\\begin h2o\n conc_dependence lut\n input \"ideal_h2o.%s ideal_h2o_x4.%s\"\n\\end h2o\n"
+                "\\begin co2\n conc_dependence linear\n input ideal_co2.%s\n\\end co2\n" % (ext, ext, ext))
     run("create_look_up_table", "create_look_up_table", "lut.cfg")
     r = run("optimize_lut", "optimize_lut", "input=raw_ckd.nc", "output=ckd.nc", "training_input=lbl.nc", *[f"{k}={v}" for k, v in OPT.items()])
     its = [l for l in r.stdout.splitlines() if l.startswith("Iteration ")]
@@ -310,15 +335,16 @@ def main():
     ap.add_argument("--nlay", type=int, default=30)
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--netcdf4", action="store_true", help="run the tools a second time on NetCDF-4 twins of the spectra")
     args = ap.parse_args()
     ncores = min(16, len(os.sched_getaffinity(0)))
     os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
     from ecckd_amd import api, ncio
-    res = run(args.nwav, args.nlay, args.workdir)
+    res = run(args.nwav, args.nlay, args.workdir, netcdf4=args.netcdf4)
     print(json.dumps(res) if args.json else json.dumps(res, indent=1))
 
 
-def run(nwav=1 << 15, nlay=30, workdir=None):
+def run(nwav=1 << 15, nlay=30, workdir=None, netcdf4=False):
     from ecckd_amd import api, ncio
     d = workdir or tempfile.mkdtemp(prefix="ecckd_e2e_")
     os.makedirs(d, exist_ok=True)
@@ -326,6 +352,12 @@ def run(nwav=1 << 15, nlay=30, workdir=None):
     with api.Context(0) as ctx:
         inp = make_inputs(ctx, d, nwav, nlay)
         g_secs, g_out = gpu_chain(d, inp)
+        gpoints_classic = ncio.read_g_points(os.path.join(d, "gpoints.nc"))["g_point"]
+        h5_secs = h5_same = None
+        if netcdf4 and write_netcdf4_spectra(d):
+            h5_secs, _ = gpu_chain(d, inp, ext="h5")
+            h5_same = bool(np.array_equal(ncio.read_g_points(os.path.join(d, "gpoints.nc"))["g_point"], gpoints_classic))
+            g_secs2, g_out = gpu_chain(d, inp)               # the files the comparison below reads are the classic run's again
         c_secs, c_out = cpu_chain(ctx, d, inp, ncores)
     gpf = ncio.read_g_points(os.path.join(d, "gpoints.nc"))
     same_g = bool(np.array_equal(gpf["g_point"], c_out["g_point"]))
@@ -368,6 +400,9 @@ def run(nwav=1 << 15, nlay=30, workdir=None):
                     "evaluation profiles; find_g_points tolerance %g K/d, optimize_lut %d iterations"
                     % (nwav, nlay, FIND_G["heating_rate_tolerance"], OPT["max_iterations"]),
         "gpu_tools_seconds": {k: round(v, 4) for k, v in g_secs.items()}, "gpu_tools_total_seconds": round(g_tot, 4),
+        "gpu_tools_seconds_netcdf4_spectra": {k: round(v, 4) for k, v in h5_secs.items()} if h5_secs else None,
+        "gpu_tools_total_seconds_netcdf4_spectra": round(sum(h5_secs.values()), 4) if h5_secs else None,
+        "g_point_maps_identical_classic_vs_netcdf4_spectra": h5_same,
         "cpu_oracle_seconds": {k: round(v, 4) for k, v in c_secs.items()}, "cpu_oracle_total_seconds": round(c_tot, 4),
         "cpu_cores": ncores, "speedup_total": c_tot / g_tot,
         "speedup_per_stage": {k: c_secs[k] / g_secs[k] for k in c_secs if g_secs.get(k)},
