@@ -146,6 +146,26 @@ def _run_ranks(world, *args, cwd=None):
     return [o for o, _ in outs]
 
 
+def test_orderly_teardown_gives_the_same_files(ctx, tmp_path, monkeypatch):
+    """The tools leave their device resources to the process exit (done() in cli/tool.hpp: std::_Exit once the files are closed);
+    ECCKD_NO_FAST_EXIT keeps the orderly teardown: the same output, byte for byte, and the same log either way."""
+    d = tmp_path
+    _make_lw_files(d, nwav=6000)
+    args = ("input=h2o.nc", "wavenumber1=0 1300", "wavenumber2=1300 3260")
+    fast = run_tool("reorder_spectrum", *args, "output=order_fast.nc", cwd=d)
+    monkeypatch.setenv("ECCKD_NO_FAST_EXIT", "1")
+    slow = run_tool("reorder_spectrum", *args, "output=order_slow.nc", cwd=d)
+    assert fast.returncode == 0 and slow.returncode == 0, fast.stderr + slow.stderr
+    assert fast.stdout.replace("order_fast", "X") == slow.stdout.replace("order_slow", "X")
+    a, b = (d / "order_fast.nc").read_bytes(), (d / "order_slow.nc").read_bytes()
+    assert len(a) == len(b)
+    # the history attribute carries the command line (the output's name): compare the variables
+    fa, fb = _nc(d / "order_fast.nc"), _nc(d / "order_slow.nc")
+    for k in fa.variables:
+        assert np.array_equal(fa.variables[k][...], fb.variables[k][...]), k
+    fa.close(); fb.close()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_find_g_points_several_processes(ctx, tmp_path, world):
     """The (gas, band) searches dealt to `world` processes: the g-points file is the one a single process writes, whatever the
