@@ -190,6 +190,12 @@ SIGNATURES = {
                                            C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p]),
     "ecckd_lbl_band_fluxes_sw": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p]),
+    "ecckd_lbl_band_fluxes_lw_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p,
+                                              C.c_void_p, C.c_void_p]),
+    "ecckd_lbl_band_fluxes_sw_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p,
+                                              C.c_void_p, C.c_void_p]),
     "ecckd_gather_f64_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_invert_permutation_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "ecckd_calc_error_multi": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _c_double_p, _c_double_p,

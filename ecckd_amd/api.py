@@ -926,33 +926,50 @@ def merge_spectrum(ctx, optical_depth, scaling_profile, merged=None):
     return merged
 
 
-def lbl_band_fluxes_lw(ctx, temperature_hl, wavenumber, d_wavenumber, optical_depth, band_begin, band_end):
+def lbl_band_fluxes_lw(ctx, temperature_hl, wavenumber, d_wavenumber, optical_depth, band_begin, band_end, boundary=False):
     """Line-by-line longwave fluxes of one column summed per band (planck_function + radiative_transfer_lw):
-    device tensors wavenumber, d_wavenumber, optical_depth (nlay, nwav) -> (flux_dn, flux_up), each (nband, nlay+1)."""
+    device tensors wavenumber, d_wavenumber, optical_depth (nlay, nwav) -> (flux_dn, flux_up), each (nband, nlay+1);
+    boundary=True: also the spectral fluxes at the boundaries, device tensors (nwav,): (..., surface down, TOA up)."""
     t = _f64c(temperature_hl)
     nlay = t.size - 1
     b0 = np.ascontiguousarray(band_begin, dtype=np.int64)
     b1 = np.ascontiguousarray(band_end, dtype=np.int64)
     dn, up = np.empty((b0.size, nlay + 1)), np.empty((b0.size, nlay + 1))
+    torch = _torch()
+    nwav = optical_depth.shape[1]
+    sdn = torch.empty(nwav, dtype=torch.float64, device=ctx.device) if boundary else None
+    tup = torch.empty(nwav, dtype=torch.float64, device=ctx.device) if boundary else None
     ctx.fence_from_torch()
-    check(ctx.lib.ecckd_lbl_band_fluxes_lw(ctx.handle, nlay, optical_depth.shape[1], _hptr(t), _dptr(wavenumber),
-                                           _dptr(d_wavenumber), _dptr(optical_depth), _od_type(optical_depth),
-                                           optical_depth.stride(0), b0.size, _hptr(b0, C.c_int64), _hptr(b1, C.c_int64),
-                                           _hptr(dn), _hptr(up)))
+    check(ctx.lib.ecckd_lbl_band_fluxes_lw_ex(ctx.handle, nlay, nwav, _hptr(t), _dptr(wavenumber),
+                                              _dptr(d_wavenumber), _dptr(optical_depth), _od_type(optical_depth),
+                                              optical_depth.stride(0), b0.size, _hptr(b0, C.c_int64), _hptr(b1, C.c_int64),
+                                              _hptr(dn), _hptr(up), _dptr(sdn) if boundary else None, _dptr(tup) if boundary else None))
+    if boundary:
+        ctx.synchronize()
+        return dn, up, sdn, tup
     return dn, up
 
 
-def lbl_band_fluxes_sw(ctx, cos_sza, ssi, optical_depth, band_begin, band_end, albedo=None):
-    """Line-by-line shortwave direct (and, with a per-wavenumber albedo, reflected) fluxes summed per band."""
+def lbl_band_fluxes_sw(ctx, cos_sza, ssi, optical_depth, band_begin, band_end, albedo=None, boundary=False):
+    """Line-by-line shortwave direct (and, with a per-wavenumber albedo, reflected) fluxes summed per band; boundary=True: also
+    the spectral direct flux at the surface and the upwelling one at the top, device tensors (nwav,)."""
     nlay = optical_depth.shape[0]
     b0 = np.ascontiguousarray(band_begin, dtype=np.int64)
     b1 = np.ascontiguousarray(band_end, dtype=np.int64)
     dn, up = np.empty((b0.size, nlay + 1)), np.empty((b0.size, nlay + 1))
+    torch = _torch()
+    nwav = optical_depth.shape[1]
+    sdn = torch.empty(nwav, dtype=torch.float64, device=ctx.device) if boundary else None
+    tup = torch.empty(nwav, dtype=torch.float64, device=ctx.device) if boundary else None
     ctx.fence_from_torch()
-    check(ctx.lib.ecckd_lbl_band_fluxes_sw(ctx.handle, nlay, optical_depth.shape[1], float(cos_sza), _dptr(ssi),
-                                           _dptr(albedo) if albedo is not None else None, _dptr(optical_depth),
-                                           _od_type(optical_depth), optical_depth.stride(0), b0.size, _hptr(b0, C.c_int64),
-                                           _hptr(b1, C.c_int64), _hptr(dn), _hptr(up)))
+    check(ctx.lib.ecckd_lbl_band_fluxes_sw_ex(ctx.handle, nlay, nwav, float(cos_sza), _dptr(ssi),
+                                              _dptr(albedo) if albedo is not None else None, _dptr(optical_depth),
+                                              _od_type(optical_depth), optical_depth.stride(0), b0.size, _hptr(b0, C.c_int64),
+                                              _hptr(b1, C.c_int64), _hptr(dn), _hptr(up), _dptr(sdn) if boundary else None,
+                                              _dptr(tup) if boundary else None))
+    if boundary:
+        ctx.synchronize()
+        return dn, up, sdn, tup
     return dn, up
 
 

@@ -22,7 +22,8 @@
 // A file may be preceded by  --scale s  (optical depth times s),  --conc c  (scaled so that the file's reference surface
 // mole fraction becomes c)  or  --const c  (a mole fraction c at every level: each level scaled by c / its own).
 // Namelist (&longwave_config / &shortwave_config): band_wavenumber1 / band_wavenumber2, nspectralstride (1 only), nangle (0
-// only: classic two-stream, diffusivity 1.66), surf_albedo, cos_solar_zenith_angle, do_write_spectral_boundary_fluxes; the
+// only: classic two-stream, diffusivity 1.66), surf_albedo, cos_solar_zenith_angle, do_write_spectral_boundary_fluxes (the
+// spectral fluxes at the surface and the top of the atmosphere per wavenumber, with the wavenumber grid); the
 // *_name keys must keep their CKDMIP defaults.  Spectra are streamed from the files into HBM (ecckd_nc_read_dev) and merged
 // there; the per-wavenumber radiative transfer is ecckd_lbl_band_fluxes_lw / _sw.  Output is a classic NetCDF file whatever
 // its name.
@@ -331,7 +332,12 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
       out.var("band_flux_up_sw", NC_FLOAT_T, {"column", "mu0", "half_level", "band_sw"}, "Upwelling shortwave flux in bands", "W m-2");
       out.var("band_flux_dn_direct_sw", NC_FLOAT_T, {"column", "mu0", "half_level", "band_sw"}, "Downwelling direct shortwave flux in bands", "W m-2");
       out.att(ids, "constituent_id");
-      if (nl.boundary_fluxes) WARN("do_write_spectral_boundary_fluxes is not supported by this stand-in: no spectral boundary fluxes written");
+      if (nl.boundary_fluxes) {     // what LblFluxes::read maps to g points (lbl_fluxes.cpp:183-246)
+        out.dim("wavenumber", nwav);
+        out.var("wavenumber", NC_DOUBLE_T, {"wavenumber"}, "Wavenumber", "cm-1");
+        out.var("spectral_flux_dn_direct_surf_sw", NC_FLOAT_T, {"column", "mu0", "wavenumber"}, "Spectral direct shortwave flux at the surface", "W m-2");
+        out.var("spectral_flux_up_toa_sw", NC_FLOAT_T, {"column", "mu0", "wavenumber"}, "Spectral upwelling shortwave flux at top of atmosphere", "W m-2");
+      }
     } else {
       out.dim("gas", gases.size()); out.dim("band_lw", nband);
       out.var("mole_fraction_fl", NC_FLOAT_T, {"column", "gas", "level"}, "Mole fraction at full levels", "1");
@@ -342,7 +348,12 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
       out.var("band_flux_up_lw", NC_FLOAT_T, {"column", "half_level", "band_lw"}, "Upwelling longwave flux in bands", "W m-2");
       out.var("band_flux_dn_lw", NC_FLOAT_T, {"column", "half_level", "band_lw"}, "Downwelling longwave flux in bands", "W m-2");
       out.att(ids, "constituent_id");
-      if (nl.boundary_fluxes) WARN("do_write_spectral_boundary_fluxes is not supported by this stand-in: no spectral boundary fluxes written");
+      if (nl.boundary_fluxes) {     // lbl_fluxes.cpp:301-325
+        out.dim("wavenumber", nwav);
+        out.var("wavenumber", NC_DOUBLE_T, {"wavenumber"}, "Wavenumber", "cm-1");
+        out.var("spectral_flux_dn_surf_lw", NC_FLOAT_T, {"column", "wavenumber"}, "Spectral downwelling longwave flux at the surface", "W m-2");
+        out.var("spectral_flux_up_toa_lw", NC_FLOAT_T, {"column", "wavenumber"}, "Spectral upwelling longwave flux at top of atmosphere", "W m-2");
+      }
     }
     if (!scenario.empty()) out.att(scenario, "scenario");
     out.att(history, "history");
@@ -350,6 +361,14 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
     if (merge_only) out.write("wavenumber", first.wavenumber_cm_1);
     else if (sw) { out.write("band_wavenumber1_sw", nl.band1); out.write("band_wavenumber2_sw", nl.band2); out.write("mu0", mu0); }
     else { out.write("band_wavenumber1_lw", nl.band1); out.write("band_wavenumber2_lw", nl.band2); }
+    DevBuf d_bnd_dn, d_bnd_up;
+    if (!merge_only && nl.boundary_fluxes) {
+      out.write("wavenumber", first.wavenumber_cm_1);
+      d_bnd_dn.alloc(dev, nwav * sizeof(double));
+      d_bnd_up.alloc(dev, nwav * sizeof(double));
+    }
+    double* const p_bnd_dn = nl.boundary_fluxes && !merge_only ? d_bnd_dn.as<double>() : nullptr;
+    double* const p_bnd_up = nl.boundary_fluxes && !merge_only ? d_bnd_up.as<double>() : nullptr;
 
     for (int c = c0; c <= c1; ++c) {
       const Spectrum col = c == 0 ? first : read_spectrum(gases[0].path, c, false);
@@ -390,9 +409,15 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
         const size_t nhl = (size_t)nlay + 1;
         std::vector<double> tdn((size_t)nmu * nhl * nband), tup((size_t)nmu * nhl * nband), sdn((size_t)nmu * nhl, 0.0), sup((size_t)nmu * nhl, 0.0);
         std::vector<double> bdn((size_t)nband * nhl), bup((size_t)nband * nhl);
+        std::vector<double> all_dn, all_up;     // (mu0, wavenumber) boundary fluxes of this column
         for (int m = 0; m < nmu; ++m) {
-          ck(ecckd_lbl_band_fluxes_sw(dev.ctx(), nlay, nwav, mu0[m], d_ssi.as<double>(), d_albedo.as<double>(), d_merged.ptr(), ECCKD_F64, nwav,
-                                      nband, bbegin.data(), bend.data(), bdn.data(), bup.data()));
+          ck(ecckd_lbl_band_fluxes_sw_ex(dev.ctx(), nlay, nwav, mu0[m], d_ssi.as<double>(), d_albedo.as<double>(), d_merged.ptr(), ECCKD_F64, nwav,
+                                         nband, bbegin.data(), bend.data(), bdn.data(), bup.data(), p_bnd_dn, p_bnd_up));
+          if (p_bnd_dn) {
+            const std::vector<double> a = d_bnd_dn.download<double>(), b = d_bnd_up.download<double>();
+            all_dn.insert(all_dn.end(), a.begin(), a.end());
+            all_up.insert(all_up.end(), b.begin(), b.end());
+          }
           for (int b = 0; b < nband; ++b)
             for (size_t i = 0; i < nhl; ++i) {
               tdn[((size_t)m * nhl + i) * nband + b] = bdn[(size_t)b * nhl + i];
@@ -404,11 +429,13 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
         out.write_slice("mole_fraction_fl", oc, vmr_all);
         out.write_slice("band_flux_dn_direct_sw", oc, tdn); out.write_slice("band_flux_up_sw", oc, tup);
         out.write_slice("flux_dn_direct_sw", oc, sdn); out.write_slice("flux_dn_sw", oc, sdn); out.write_slice("flux_up_sw", oc, sup);
+        if (p_bnd_dn) { out.write_slice("spectral_flux_dn_direct_surf_sw", oc, all_dn); out.write_slice("spectral_flux_up_toa_sw", oc, all_up); }
       } else {
         if (col.temperature_hl.empty()) fail(ECCKD_PARAMETER_ERROR, "temperature_hl missing from %s", gases[0].path.c_str());
         std::vector<double> bdn((size_t)nband * (nlay + 1)), bup((size_t)nband * (nlay + 1));
-        ck(ecckd_lbl_band_fluxes_lw(dev.ctx(), nlay, nwav, col.temperature_hl.data(), d_wn.as<double>(), d_dwn.as<double>(),
-                                    d_merged.ptr(), ECCKD_F64, nwav, nband, bbegin.data(), bend.data(), bdn.data(), bup.data()));
+        ck(ecckd_lbl_band_fluxes_lw_ex(dev.ctx(), nlay, nwav, col.temperature_hl.data(), d_wn.as<double>(), d_dwn.as<double>(),
+                                       d_merged.ptr(), ECCKD_F64, nwav, nband, bbegin.data(), bend.data(), bdn.data(), bup.data(),
+                                       p_bnd_dn, p_bnd_up));
         // [band][level] -> (half_level, band) and the broadband sums
         std::vector<double> tdn((size_t)(nlay + 1) * nband), tup((size_t)(nlay + 1) * nband), sdn(nlay + 1, 0.0), sup(nlay + 1, 0.0);
         for (int b = 0; b < nband; ++b)
@@ -421,6 +448,10 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
         out.write_slice("mole_fraction_fl", oc, vmr_all);
         out.write_slice("band_flux_dn_lw", oc, tdn); out.write_slice("band_flux_up_lw", oc, tup);
         out.write_slice("flux_dn_lw", oc, sdn); out.write_slice("flux_up_lw", oc, sup);
+        if (p_bnd_dn) {
+          out.write_slice("spectral_flux_dn_surf_lw", oc, d_bnd_dn.download<double>());
+          out.write_slice("spectral_flux_up_toa_lw", oc, d_bnd_up.download<double>());
+        }
       }
       LOG("  column %d done\n", c + 1);
     }

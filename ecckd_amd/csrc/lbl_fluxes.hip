@@ -34,7 +34,8 @@ template <typename OdT>
 __global__ void __launch_bounds__(LBL_THREADS)
 k_lbl_fluxes_lw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks, const double* __restrict__ hk,
                 const double* __restrict__ wn, const double* __restrict__ dwn, const OdT* __restrict__ od,
-                double* __restrict__ partial) {
+                double* __restrict__ partial, double* __restrict__ surf_dn /* [nwav] or NULL */,
+                double* __restrict__ toa_up /* [nwav] or NULL */) {
   extern __shared__ double s_acc[];
   const int nhl = nlay + 1;
   const BandChunk c = chunks[blockIdx.x];
@@ -67,6 +68,7 @@ k_lbl_fluxes_lw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks
     if (lane == 0) acc_dn[l + 1] += s;
     b_prev = b_next;
   }
+  if (surf_dn && live) surf_dn[j] = flux;         // the spectral flux at the boundary (do_write_spectral_boundary_fluxes)
   // surface: emissivity 1, Planck function at temperature_hl(end) (:52-53)
   flux = b_prev * 1.0 + (1.0 - 1.0) * flux;
   {
@@ -82,6 +84,7 @@ k_lbl_fluxes_lw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks
     if (lane == 0) acc_up[l] += s;
     b_prev = b_l;
   }
+  if (toa_up && live) toa_up[j] = flux;
   __syncthreads();
   for (int t = tid; t < 2 * nhl; t += LBL_THREADS)
     partial[(size_t)blockIdx.x * 2 * nhl + t] = ((s_acc[t] + s_acc[2 * nhl + t]) + s_acc[4 * nhl + t]) + s_acc[6 * nhl + t];
@@ -91,7 +94,8 @@ template <typename OdT>
 __global__ void __launch_bounds__(LBL_THREADS)
 k_lbl_fluxes_sw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks, double cos_sza,
                 const double* __restrict__ ssi, const double* __restrict__ albedo /* per wavenumber or NULL */,
-                const OdT* __restrict__ od, double* __restrict__ partial) {
+                const OdT* __restrict__ od, double* __restrict__ partial, double* __restrict__ surf_dn /* [nwav] or NULL */,
+                double* __restrict__ toa_up /* [nwav] or NULL */) {
   extern __shared__ double s_acc[];
   const int nhl = nlay + 1;
   const BandChunk c = chunks[blockIdx.x];
@@ -114,6 +118,8 @@ k_lbl_fluxes_sw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks
     const double s = wave_sum(flux);
     if (lane == 0) acc_dn[l + 1] += s;
   }
+  if (surf_dn && live) surf_dn[j] = flux;
+  if (toa_up && live && !albedo) toa_up[j] = 0.0;
   if (albedo) {                                                             // :70-76
     flux = flux * albedo[j];
     {
@@ -125,6 +131,7 @@ k_lbl_fluxes_sw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks
       const double s = wave_sum(flux);
       if (lane == 0) acc_up[l] += s;
     }
+    if (toa_up && live) toa_up[j] = flux;
   }
   __syncthreads();
   for (int t = tid; t < 2 * nhl; t += LBL_THREADS)
@@ -170,6 +177,14 @@ int ecckd_lbl_band_fluxes_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double
                              const double* d_wavenumber, const double* d_d_wavenumber, const void* d_od, int od_type,
                              size_t od_stride, int nband, const int64_t* h_band_begin, const int64_t* h_band_end,
                              double* h_flux_dn, double* h_flux_up) {
+  return ecckd_lbl_band_fluxes_lw_ex(ctx, nlay, nwav, h_temperature_hl, d_wavenumber, d_d_wavenumber, d_od, od_type, od_stride, nband,
+                                     h_band_begin, h_band_end, h_flux_dn, h_flux_up, nullptr, nullptr);
+}
+
+int ecckd_lbl_band_fluxes_lw_ex(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_temperature_hl,
+                                const double* d_wavenumber, const double* d_d_wavenumber, const void* d_od, int od_type,
+                                size_t od_stride, int nband, const int64_t* h_band_begin, const int64_t* h_band_end,
+                                double* h_flux_dn, double* h_flux_up, double* d_surf_dn, double* d_toa_up) {
   ECCKD_REQUIRE(ctx && nlay > 0 && h_temperature_hl && d_wavenumber && d_d_wavenumber && d_od && nband > 0 && h_band_begin &&
                 h_band_end && h_flux_dn && h_flux_up, "ecckd_lbl_band_fluxes_lw: bad argument");
   ECCKD_REQUIRE(od_type == ECCKD_F32 || od_type == ECCKD_F64, "ecckd_lbl_band_fluxes_lw: od_type must be 4 or 8");
@@ -178,6 +193,9 @@ int ecckd_lbl_band_fluxes_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double
   const int nhl = nlay + 1;
   std::vector<BandChunk> chunks;
   ECCKD_CHECK(make_chunks(nwav, nband, h_band_begin, h_band_end, chunks));
+  // wavenumbers outside every band carry no flux
+  if (d_surf_dn) ECCKD_HIP_CHECK(hipMemsetAsync(d_surf_dn, 0, nwav * sizeof(double), ctx->stream));
+  if (d_toa_up) ECCKD_HIP_CHECK(hipMemsetAsync(d_toa_up, 0, nwav * sizeof(double), ctx->stream));
   std::vector<double> hk(nhl);
   for (int i = 0; i < nhl; ++i) {
     ECCKD_REQUIRE(h_temperature_hl[i] > 0.0, "ecckd_lbl_band_fluxes_lw: temperature_hl must be positive");
@@ -194,11 +212,11 @@ int ecckd_lbl_band_fluxes_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double
     if (od_type == ECCKD_F32)
       hipLaunchKernelGGL(k_lbl_fluxes_lw<float>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, nlay,
                          od_stride, (const BandChunk*)d_chunks.p, (const double*)d_hk.p, d_wavenumber, d_d_wavenumber,
-                         (const float*)d_od, (double*)d_part.p);
+                         (const float*)d_od, (double*)d_part.p, d_surf_dn, d_toa_up);
     else
       hipLaunchKernelGGL(k_lbl_fluxes_lw<double>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, nlay,
                          od_stride, (const BandChunk*)d_chunks.p, (const double*)d_hk.p, d_wavenumber, d_d_wavenumber,
-                         (const double*)d_od, (double*)d_part.p);
+                         (const double*)d_od, (double*)d_part.p, d_surf_dn, d_toa_up);
     ECCKD_HIP_CHECK(hipGetLastError());
   }
   return combine(ctx, nlay, nband, chunks, (const double*)d_part.p, h_flux_dn, h_flux_up);
@@ -208,6 +226,15 @@ int ecckd_lbl_band_fluxes_sw(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_s
                              const double* d_albedo, const void* d_od, int od_type, size_t od_stride, int nband,
                              const int64_t* h_band_begin, const int64_t* h_band_end, double* h_flux_dn_direct,
                              double* h_flux_up) {
+  return ecckd_lbl_band_fluxes_sw_ex(ctx, nlay, nwav, cos_sza, d_ssi, d_albedo, d_od, od_type, od_stride, nband, h_band_begin,
+                                     h_band_end, h_flux_dn_direct, h_flux_up, nullptr, nullptr);
+}
+
+int ecckd_lbl_band_fluxes_sw_ex(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_sza, const double* d_ssi,
+                                const double* d_albedo, const void* d_od, int od_type, size_t od_stride, int nband,
+                                const int64_t* h_band_begin, const int64_t* h_band_end, double* h_flux_dn_direct,
+                                double* h_flux_up, double* d_surf_dn_direct, double* d_toa_up) {
+  double* const d_surf_dn = d_surf_dn_direct;
   ECCKD_REQUIRE(ctx && nlay > 0 && d_ssi && d_od && nband > 0 && h_band_begin && h_band_end && h_flux_dn_direct,
                 "ecckd_lbl_band_fluxes_sw: bad argument");
   ECCKD_REQUIRE(cos_sza > 0.0, "ecckd_lbl_band_fluxes_sw: cos_sza must be positive");
@@ -217,6 +244,8 @@ int ecckd_lbl_band_fluxes_sw(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_s
   const int nhl = nlay + 1;
   std::vector<BandChunk> chunks;
   ECCKD_CHECK(make_chunks(nwav, nband, h_band_begin, h_band_end, chunks));
+  if (d_surf_dn) ECCKD_HIP_CHECK(hipMemsetAsync(d_surf_dn, 0, nwav * sizeof(double), ctx->stream));
+  if (d_toa_up) ECCKD_HIP_CHECK(hipMemsetAsync(d_toa_up, 0, nwav * sizeof(double), ctx->stream));
   Buf d_chunks, d_part;
   if (!chunks.empty()) {
     ECCKD_HIP_CHECK(hipMalloc(&d_chunks.p, chunks.size() * sizeof(BandChunk)));
@@ -225,10 +254,12 @@ int ecckd_lbl_band_fluxes_sw(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_s
     const size_t lds = (size_t)4 * 2 * nhl * sizeof(double);
     if (od_type == ECCKD_F32)
       hipLaunchKernelGGL(k_lbl_fluxes_sw<float>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, nlay,
-                         od_stride, (const BandChunk*)d_chunks.p, cos_sza, d_ssi, d_albedo, (const float*)d_od, (double*)d_part.p);
+                         od_stride, (const BandChunk*)d_chunks.p, cos_sza, d_ssi, d_albedo, (const float*)d_od, (double*)d_part.p,
+                         d_surf_dn, d_toa_up);
     else
       hipLaunchKernelGGL(k_lbl_fluxes_sw<double>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, nlay,
-                         od_stride, (const BandChunk*)d_chunks.p, cos_sza, d_ssi, d_albedo, (const double*)d_od, (double*)d_part.p);
+                         od_stride, (const BandChunk*)d_chunks.p, cos_sza, d_ssi, d_albedo, (const double*)d_od, (double*)d_part.p,
+                         d_surf_dn, d_toa_up);
     ECCKD_HIP_CHECK(hipGetLastError());
   }
   return combine(ctx, nlay, nband, chunks, (const double*)d_part.p, h_flux_dn_direct, h_flux_up);

@@ -373,6 +373,18 @@ int ecckd_lbl_band_fluxes_sw(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_s
                              const double* d_albedo, const void* d_od, int od_type, size_t od_stride, int nband,
                              const int64_t* h_band_begin, const int64_t* h_band_end, double* h_flux_dn_direct,
                              double* h_flux_up);
+/* The same with the spectral fluxes at the boundaries as well (the CKDMIP tool's do_write_spectral_boundary_fluxes: what
+ * LblFluxes::read maps to g points, lbl_fluxes.cpp:183-246, :301-325): d_surf_dn[nwav] = downwelling (shortwave: direct) flux at
+ * the surface, d_toa_up[nwav] = upwelling flux at the top of the atmosphere, per wavenumber, device arrays, either may be NULL;
+ * zero outside the bands. */
+int ecckd_lbl_band_fluxes_lw_ex(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_temperature_hl,
+                                const double* d_wavenumber, const double* d_d_wavenumber, const void* d_od, int od_type,
+                                size_t od_stride, int nband, const int64_t* h_band_begin, const int64_t* h_band_end,
+                                double* h_flux_dn, double* h_flux_up, double* d_surf_dn, double* d_toa_up);
+int ecckd_lbl_band_fluxes_sw_ex(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_sza, const double* d_ssi,
+                                const double* d_albedo, const void* d_od, int od_type, size_t od_stride, int nband,
+                                const int64_t* h_band_begin, const int64_t* h_band_end, double* h_flux_dn_direct,
+                                double* h_flux_up, double* d_surf_dn_direct, double* d_toa_up);
 
 /* ---- NetCDF classic files (file parts of a1, a9, a21) ----------------------------
  * A self-contained reader / writer for the classic on-disk formats CDF-1, CDF-2 (64-bit offset)

@@ -914,6 +914,34 @@ def test_ckdmip_lw_stand_in(ctx, tmp_path):
     f.close()
     s = ncio.read_lbl_fluxes(d / "lbl_tool.nc", ["h2o", "co2"], ctx=ctx)           # what optimize_lut reads (lbl_fluxes.cpp:52-397)
     assert s["have_band_fluxes"] and s["flux_dn"].shape == (3, nlay + 1, 2) and np.array_equal(s["band_wavenumber2"], [1300.0, 3260.0])
+    # ---- the same with do_write_spectral_boundary_fluxes: the spectral fluxes at the surface and the top (lbl_fluxes.cpp:301-325) ----
+    (d / "lw_b.nam").write_text((d / "lw.nam").read_text().replace("do_write_spectral_boundary_fluxes = false", "do_write_spectral_boundary_fluxes = true"))
+    r = run_tool("ckdmip_lw", "--config", "lw_b.nam", "--scale", "0.5", "ideal_h2o.nc", "--const", "6e-4", "ideal_co2.nc", "--output", "lbl_b.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    f, g = _nc(d / "lbl_tool.nc"), _nc(d / "lbl_b.nc")
+    assert np.array_equal(g.variables["wavenumber"][...], wn)
+    for name in ("band_flux_dn_lw", "band_flux_up_lw", "flux_dn_lw", "flux_up_lw"):
+        assert np.array_equal(f.variables[name][...], g.variables[name][...]), name
+    for col in range(3):
+        h, c = ncio.read_spectrum(d / "ideal_h2o.nc", col), ncio.read_spectrum(d / "ideal_co2.nc", col)
+        od = 0.5 * h["optical_depth"] + (6e-4 / c["vmr_fl"])[:, None] * c["optical_depth"]
+        _, _, sdn, tup = api.lbl_band_fluxes_lw(ctx, h["temperature_hl"], dev(wn), dev(dwn), dev(od), begin, end, boundary=True)
+        assert np.allclose(g.variables["spectral_flux_dn_surf_lw"][col], sdn.cpu().numpy(), rtol=3e-7, atol=1e-37)
+        assert np.allclose(g.variables["spectral_flux_up_toa_lw"][col], tup.cpu().numpy(), rtol=3e-7, atol=1e-37)
+        # summed over the spectrum they are the broadband fluxes at those levels
+        assert np.isclose(g.variables["spectral_flux_dn_surf_lw"][col].astype(np.float64).sum(), g.variables["flux_dn_lw"][col][-1], rtol=1e-5)
+        assert np.isclose(g.variables["spectral_flux_up_toa_lw"][col].astype(np.float64).sum(), g.variables["flux_up_lw"][col][0], rtol=1e-5)
+    # ... and through LblFluxes::read's mirror with a g-points map: the boundary fluxes summed per g point (:308-325)
+    ngp = 5
+    gp = (np.arange(wn.size) * 7919 % ngp).astype(np.int32)
+    gmap = api.GPointMap(ctx, dev(gp), ngp, dev(wn), dev(dwn))
+    sb = ncio.read_lbl_fluxes(d / "lbl_b.nc", ["h2o", "co2"], gmap=gmap, ctx=ctx)
+    for col in range(3):
+        want_dn = np.array([g.variables["spectral_flux_dn_surf_lw"][col].astype(np.float64)[gp == k].sum() for k in range(ngp)])
+        want_up = np.array([g.variables["spectral_flux_up_toa_lw"][col].astype(np.float64)[gp == k].sum() for k in range(ngp)])
+        assert np.allclose(sb["spectral_flux_dn_surf"][col], want_dn, rtol=1e-10) and np.allclose(sb["spectral_flux_up_toa"][col], want_up, rtol=1e-10)
+    gmap.close()
+    f.close(); g.close()
     # ---- errors: an angle quadrature is refused, so is a namelist without bands ----
     (d / "bad.nam").write_text("&longwave_config\nnangle = 4,\nband_wavenumber1(1:1) = 0,\nband_wavenumber2(1:1) = 3260\n/\n")
     r = run_tool("ckdmip_lw", "--config", "bad.nam", "ideal_h2o.nc", "--output", "x.nc", cwd=d)
@@ -1003,6 +1031,23 @@ def test_ckdmip_sw_stand_in(ctx, tmp_path):
     s = ncio.read_lbl_fluxes(d / "lbl_sw_tool.nc", ["h2o", "o3"], ctx=ctx)           # what optimize_lut reads (lbl_fluxes.cpp:52-133)
     assert s["is_sw"] and s["have_band_fluxes"] and s["flux_dn"].shape == (9, nlay + 1, 2)      # 3 columns x the angles 0, 2, 4
     assert np.allclose(s["mu0"], np.tile([0.1, 0.5, 0.9], 3)) and s["tsi"] == pytest.approx(ssi.sum(), rel=1e-6)
+    # ---- the same with do_write_spectral_boundary_fluxes: (column, mu0, wavenumber) fluxes at the boundaries (lbl_fluxes.cpp:183-246) ----
+    (d / "sw_b.nam").write_text((d / "sw.nam").read_text().replace("nspectralstride = 1,", "nspectralstride = 1,\ndo_write_spectral_boundary_fluxes = true,"))
+    r = run_tool("ckdmip_sw", "--config", "sw_b.nam", "--ssi", "ssi.nc", "ideal_h2o.nc", "--scale", "0.5", "ideal_o3.nc", "--output", "lbl_sw_b.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    f, g = _nc(d / "lbl_sw_tool.nc"), _nc(d / "lbl_sw_b.nc")
+    assert np.array_equal(g.variables["wavenumber"][...], wn)
+    for name in ("band_flux_dn_direct_sw", "band_flux_up_sw", "flux_up_sw"):
+        assert np.array_equal(f.variables[name][...], g.variables[name][...]), name
+    assert g.variables["spectral_flux_dn_direct_surf_sw"].shape == (3, 5, nwav)
+    for k, mu in enumerate(mu0s):
+        _, _, sdn, tup = api.lbl_band_fluxes_sw(ctx, mu, dev(ssi), dev(od), begin, end, albedo=alb, boundary=True)
+        for col in (0, 2):
+            assert np.allclose(g.variables["spectral_flux_dn_direct_surf_sw"][col, k], sdn.cpu().numpy(), rtol=3e-7, atol=1e-37)
+            assert np.allclose(g.variables["spectral_flux_up_toa_sw"][col, k], tup.cpu().numpy(), rtol=3e-7, atol=1e-37)
+        assert np.isclose(g.variables["spectral_flux_dn_direct_surf_sw"][1, k].astype(np.float64).sum(), g.variables["flux_dn_direct_sw"][1, k][-1], rtol=1e-5)
+        assert np.isclose(g.variables["spectral_flux_up_toa_sw"][1, k].astype(np.float64).sum(), g.variables["flux_up_sw"][1, k][0], rtol=1e-5)
+    f.close(); g.close()
     # ---- errors ----
     r = run_tool("ckdmip_sw", "--config", "sw.nam", "ideal_h2o.nc", "--output", "x.nc", cwd=d)
     assert r.returncode == 147 and "--ssi" in r.stderr

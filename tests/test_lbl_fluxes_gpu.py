@@ -27,6 +27,17 @@ def test_lbl_band_fluxes_lw(ctx, oracle, dtype, nlay, nwav):
         assert np.allclose(dn[b], fdn[:, sl].sum(1), rtol=1e-10, atol=1e-300)
         assert np.allclose(up[b], fup[:, sl].sum(1), rtol=1e-10, atol=1e-300)
     assert np.all(dn[1] == 0) and np.all(up[1] == 0) and dn[0, -1] > 0
+    # the spectral fluxes at the boundaries (do_write_spectral_boundary_fluxes): per wavenumber against the oracle, zero outside
+    # the bands (here: none outside), and the same band fluxes beside them
+    dn2, up2, sdn, tup = api.lbl_band_fluxes_lw(ctx, t_hl, dev(wn), dev(dwn), dev(od), begin, end, boundary=True)
+    assert np.array_equal(dn2, dn) and np.array_equal(up2, up)
+    covered = np.zeros(nwav, bool)
+    for b in range(4):
+        if end[b] >= begin[b]:
+            covered[begin[b]:end[b] + 1] = True
+    assert np.allclose(sdn.cpu().numpy()[covered], fdn[-1][covered], rtol=1e-11, atol=1e-300)
+    assert np.allclose(tup.cpu().numpy()[covered], fup[0][covered], rtol=1e-11, atol=1e-300)
+    assert np.all(sdn.cpu().numpy()[~covered] == 0) and np.all(tup.cpu().numpy()[~covered] == 0)
     # Stefan-Boltzmann sanity: the opaque limit of the whole spectrum approaches sigma T^4 of the lowest layers
     assert up[:, -1].sum() == pytest.approx(planck[-1].sum(), rel=1e-12)
 
@@ -50,3 +61,11 @@ def test_lbl_band_fluxes_sw(ctx, oracle, with_albedo):
         assert np.allclose(dn[b], fdn[:, sl].sum(1), rtol=1e-11, atol=1e-300)
         assert np.allclose(up[b], fup[:, sl].sum(1), rtol=1e-11, atol=1e-300)
     assert dn[:, 0].sum() == pytest.approx(0.6 * ssi.sum(), rel=1e-12)
+    # boundary fluxes of a partial cover: bands [100, 4999] and [9000, end]
+    begin2, end2 = np.array([100, 9000]), np.array([4999, nwav - 1])
+    _, _, sdn, tup = api.lbl_band_fluxes_sw(ctx, 0.6, dev(ssi), dev(od), begin2, end2, albedo=dev(albedo) if with_albedo else None,
+                                            boundary=True)
+    covered = np.zeros(nwav, bool); covered[100:5000] = True; covered[9000:] = True
+    assert np.allclose(sdn.cpu().numpy()[covered], fdn[-1][covered], rtol=1e-11, atol=1e-300)
+    assert np.allclose(tup.cpu().numpy()[covered], fup[0][covered], rtol=1e-11, atol=1e-300)
+    assert np.all(sdn.cpu().numpy()[~covered] == 0) and np.all(tup.cpu().numpy()[~covered] == 0)
