@@ -43,8 +43,8 @@ inline uint32_t reverse_bits(uint32_t code, int len) {
 }
 
 // canonical Huffman code of `lens[0..n)` into a two-level table with `primary` index bits; `make` turns a symbol into an
-// entry without its length.  False for an over-subscribed code; an incomplete code leaves T_INVALID entries (the reference
-// decoder accepts a single distance code of one bit; anything else that is incomplete fails when such an entry is hit).
+// entry without its length.  False for an over-subscribed code and, as in zlib's inflate_table, for an incomplete one unless it
+// consists of a single one-bit code (a lone distance code); the unused half of that one leaves T_INVALID entries.
 template <typename Make>
 bool build(uint32_t* table, int primary, int sub_bits, const uint8_t* lens, int n, Make make) {
   int count[16] = {};
@@ -53,12 +53,15 @@ bool build(uint32_t* table, int primary, int sub_bits, const uint8_t* lens, int 
   uint32_t next[16];
   uint32_t code = 0;
   long long left = 1;
+  int longest = 0;
   for (int l = 1; l <= 15; ++l) {
     left = (left << 1) - count[l];
     if (left < 0) return false;
+    if (count[l]) longest = l;
     code = (code + (uint32_t)count[l - 1]) << 1;
     next[l] = code;
   }
+  if (left > 0 && longest != 1) return false;
   const uint32_t psize = 1u << primary;
   for (uint32_t i = 0; i < psize; ++i) table[i] = entry(T_INVALID, 0, 0, 0);
   uint32_t used = psize;                        // subtables are handed out behind the primary table
@@ -216,6 +219,7 @@ bool fast_inflate_zlib(void* dst_v, size_t dst_len, const void* src_v, size_t sr
           code = (code + (uint32_t)count[l - 1]) << 1;
           next[l] = code;
         }
+        if (left > 0) return false;            // the code-length code must be complete (zlib: "invalid code lengths set")
         for (uint32_t& e : cltab) e = entry(T_INVALID, 0, 0, 0);
         for (int s = 0; s < 19; ++s) {
           const int l = cl[s];

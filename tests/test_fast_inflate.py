@@ -127,3 +127,39 @@ def test_long_codes_and_far_matches(lib):
             stream = zlib.compress(data, level)
             ok, out = _inflate(lib, stream, len(data))
             assert ok and out == data
+
+
+def test_incomplete_codes_are_refused_like_zlib(lib):
+    """A dynamic block whose literal/length code leaves part of the code space unassigned: zlib's inflate_table refuses it even
+    if the missing codes never occur ("incomplete literal/length tree"); so does this decoder.  Built by hand: code lengths
+    {'a': 1, end-of-block: 2} (one 2-bit code unassigned), one distance code of length 1 (allowed to stand alone)."""
+    bits = []
+    def put(value, n):
+        for i in range(n):
+            bits.append((value >> i) & 1)
+    put(1, 1); put(2, 2)                      # final block, dynamic
+    put(0, 5); put(0, 5); put(14, 4)          # HLIT = 257, HDIST = 1, HCLEN = 18 code-length codes
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    cl = {0: 2, 1: 2, 2: 2, 18: 2}            # a complete code-length code: four 2-bit codes for 0, 1, 2, 18
+    for sym in order[:18]:
+        put(cl.get(sym, 0), 3)
+    code = {0: 0b00, 1: 0b01, 2: 0b10, 18: 0b11}                 # canonical codes (MSB first) of those four
+    def sym(s_):
+        c = code[s_]
+        put((c >> 1) & 1, 1); put(c & 1, 1)
+    # lengths: 97 zeros, 'a' = 1, 158 zeros, end-of-block = 2, then the one distance code = 1
+    sym(18); put(97 - 11, 7)
+    sym(1)
+    sym(18); put(138 - 11, 7)
+    sym(18); put(20 - 11, 7)
+    sym(2)
+    sym(1)
+    put(0, 1)                                  # 'a'
+    put(0b01, 2)                               # end of block = 10 sent MSB first: bits 1, 0
+    while len(bits) % 8:
+        bits.append(0)
+    body = bytes(sum(b << i for i, b in enumerate(bits[k:k + 8])) for k in range(0, len(bits), 8))
+    stream = b"\x78\x9c" + body + zlib.adler32(b"a").to_bytes(4, "big")
+    with pytest.raises(zlib.error):
+        zlib.decompress(stream)
+    assert not _inflate(lib, stream, 1)[0]
