@@ -180,7 +180,13 @@ int parse_header(ecckd_nc* f) {
     uint64_t n = r.count(f->version);
     if (!(tag == 0 && n == 0)) {
       if (tag != TAG_DIM) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: corrupt dimension list", f->path.c_str());
-      for (uint64_t i = 0; i < n; ++i) { Dim d; d.name = r.name(f->version); d.len = r.count(f->version); f->dims.push_back(d); }
+      for (uint64_t i = 0; i < n; ++i) {
+        Dim d;
+        d.name = r.name(f->version);
+        d.len = r.count(f->version);
+        if (!r.ok) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: corrupt or truncated dimension list", f->path.c_str());   // (a damaged count must not spin)
+        f->dims.push_back(d);
+      }
     }
   }
   if (!r.atts(f->version, f->gatts)) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: corrupt global attribute list", f->path.c_str());
@@ -204,6 +210,7 @@ int parse_header(ecckd_nc* f) {
         v.vsize = r.count(f->version);
         v.begin = (f->version == 1) ? r.u32() : r.u64();
         v.record = !v.dimids.empty() && f->dims[v.dimids[0]].len == 0;
+        if (!r.ok) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: truncated header", f->path.c_str());
         if (type_size(v.type) == 0) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: variable %s has unknown type %d", f->path.c_str(), v.name.c_str(), v.type);
         f->vars.push_back(v);
       }
@@ -219,6 +226,24 @@ int parse_header(ecckd_nc* f) {
     uint64_t slab = type_size(v.type);
     for (size_t k = 1; k < v.dimids.size(); ++k) slab *= f->dims[v.dimids[k]].len;
     f->recsize += (nrec == 1) ? slab : pad4(slab);
+  }
+  // every variable's data must lie inside the file: a damaged dimension length or offset is caught here, not by whoever sizes
+  // a buffer from the shape
+  uint64_t file_size = 0;
+  {
+    const long at = std::ftell(f->fp);
+    if (at < 0 || std::fseek(f->fp, 0, SEEK_END) != 0) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: cannot be measured", f->path.c_str());
+    file_size = (uint64_t)std::ftell(f->fp);
+    std::fseek(f->fp, at, SEEK_SET);
+  }
+  for (const Var& v : f->vars) {
+    unsigned __int128 bytes = type_size(v.type);
+    for (size_t k = v.record ? 1 : 0; k < v.dimids.size(); ++k) bytes *= f->dims[v.dimids[k]].len, bytes = bytes > ((unsigned __int128)1 << 100) ? ((unsigned __int128)1 << 100) : bytes;
+    unsigned __int128 last = (unsigned __int128)v.begin + bytes;
+    if (v.record && f->numrecs > 0) last = (unsigned __int128)v.begin + (unsigned __int128)(f->numrecs - 1) * f->recsize + bytes;
+    if ((v.record && f->numrecs == 0) ? v.begin > file_size : last > file_size)
+      return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: variable %s extends past the end of the file (damaged header or truncated file)",
+                         f->path.c_str(), v.name.c_str());
   }
   return ECCKD_OK;
 }

@@ -383,3 +383,60 @@ def test_netcdf4_chunks_are_inflated_in_parallel(tmp_path, monkeypatch):
             assert np.array_equal(f.read("optical_depth"), od.astype(np.float64))
             assert np.array_equal(f.read("x64", 3), x64[3]) and np.array_equal(f.read("x64"), x64)
             assert np.array_equal(f.read("flat"), od[0, 0].astype(np.float64))
+
+
+def test_damaged_classic_files_are_refused_or_read_never_crashed(tmp_path):
+    """The classic reader on files with flipped header bytes, cut-off tails and inflated counts: an EcckdError or a result,
+    never a crash, a hang or a read outside the file (a child process walks 600 damaged copies; it must end normally)."""
+    import subprocess, textwrap
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    good = tmp_path / "good.nc"
+    w = netcdf_file(str(good), "w", version=2)
+    w.createDimension("column", 2); w.createDimension("level", 5); w.createDimension("wavenumber", 301)
+    w.createVariable("wavenumber", "d", ("wavenumber",))[:] = np.linspace(1.0, 3000.0, 301)
+    w.createVariable("pressure_hl", "d", ("column", "level"))[:] = np.arange(10.0).reshape(2, 5)
+    w.createVariable("optical_depth", "f", ("column", "level", "wavenumber"))[:] = np.random.RandomState(0).rand(2, 5, 301).astype("f4")
+    w.constituent_id = "h2o"
+    w.close()
+    child = textwrap.dedent(f"""
+        import numpy as np, sys
+        sys.path.insert(0, {repr(ROOT)})
+        from ecckd_amd import ncio, EcckdError
+        raw = bytearray(open({repr(str(good))}, 'rb').read())
+        header = 400                                 # dimensions, attributes and variable records live here
+        rs = np.random.RandomState(1)
+        ok = refused = 0
+        for k in range(600):
+            b = bytearray(raw)
+            what = k % 4
+            if what == 0:
+                for _ in range(1 + k % 3): b[rs.randint(header)] = rs.randint(256)
+            elif what == 1:
+                del b[rs.randint(8, len(b)):]
+            elif what == 2:
+                p = rs.randint(header - 4); b[p:p + 4] = (0x7fffffff).to_bytes(4, 'big')      # a huge count somewhere
+            else:
+                p = rs.randint(header - 8); b[p:p + 8] = rs.bytes(8)
+            path = {repr(str(tmp_path))} + '/bad.nc'
+            open(path, 'wb').write(b)
+            try:
+                f = ncio.NcFile(path)
+                for name in ('wavenumber', 'pressure_hl', 'optical_depth'):
+                    try:
+                        f.var_info(name); f.read(name); f.read(name, 1)
+                    except (EcckdError, KeyError):            # KeyError: the name itself was hit
+                        pass
+                try:
+                    f.att_text('constituent_id')
+                except (EcckdError, KeyError):
+                    pass
+                f.close()
+                ok += 1
+            except EcckdError:
+                refused += 1
+        print(ok, refused)
+    """)
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    ok, refused = map(int, r.stdout.split())
+    assert ok + refused == 600 and refused > 50
