@@ -1295,20 +1295,26 @@ k_gas_prep_sw_staged(size_t n, size_t npad, int method, double cos_sza, double m
 
   // this wave's 64 x H block of part h: contiguous and 256-byte aligned (npad is a multiple of 64)
   auto stage = [&](int h) {
-    constexpr int NV = 64 * H / 4, NIT = (NV + 63) / 64;
-    constexpr int NVB = NV * (int)(sizeof(BgT) / 4), NITB = (NVB + 63) / 64;
+    constexpr int NV = 64 * H / 4, NIT = (NV + 63) / 64;                    // float4s of the target's block
+    constexpr int NVB = NV * (int)(sizeof(BgT) / 4);                        // 16-byte pieces of the background's block
     const float4* so = reinterpret_cast<const float4*>(od_half + ((size_t)h * npad + wid * 64) * H);
-    const float4* sb = reinterpret_cast<const float4*>(bg_half + ((size_t)h * npad + wid * 64) * H);
+    // no background: the loads still happen, from the target's block (a branch round them would put a full wait behind each)
+    const float4* sb = has_bg ? reinterpret_cast<const float4*>(bg_half + ((size_t)h * npad + wid * 64) * H) : so;
     __builtin_amdgcn_wave_barrier();   // the lanes are done with the part staged before
+    // both arrays' loads go out together, then the LDS writes: one memory round trip per staging
 #pragma unroll
     for (int t = 0; t < NIT; ++t) {
       const int at = t * 64 + lane;
-      if (at < NV) reinterpret_cast<float4*>(my_od)[at] = so[at];
+      if (at < NV) {
+        const float4 vo = so[at], vb = sb[at];
+        reinterpret_cast<float4*>(my_od)[at] = vo;
+        reinterpret_cast<float4*>(my_bg)[at] = vb;
+      }
     }
-    if (has_bg) {
+    if (NVB > NV) {                    // a DOUBLE background: the second half of its block
 #pragma unroll
-      for (int t = 0; t < NITB; ++t) {
-        const int at = t * 64 + lane;
+      for (int t = 0; t < NIT; ++t) {
+        const int at = NV + t * 64 + lane;
         if (at < NVB) reinterpret_cast<float4*>(my_bg)[at] = sb[at];
       }
     }
