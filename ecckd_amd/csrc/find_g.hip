@@ -391,16 +391,36 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
       }
       __builtin_amdgcn_wave_barrier();
     };
+    if (sizeof(BgT) == 4) {
+      // FLOAT (or no) background: both blocks side by side in the buffer, their loads out together - one memory round trip.
+      // No background: the loads still happen, from the target's block (a branch round them would put a full wait behind each).
+      static_assert(2 * NV * 16 <= (H + 1) * 64 * 8, "both FLOAT blocks fit side by side");
+      const float4* so = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(od_col) + blk);
+      const float4* sb = bg_col ? reinterpret_cast<const float4*>(reinterpret_cast<const float*>(bg_col) + blk) : so;
+#pragma unroll
+      for (int t = 0; t < (NV + 63) / 64; ++t) {
+        const int at = t * 64 + lane;
+        if (at < NV) {
+          const float4 vo = so[at], vb = sb[at];
+          reinterpret_cast<float4*>(st)[at] = vo;
+          reinterpret_cast<float4*>(st)[NV + at] = vb;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const bool has_bg = bg_col != nullptr;
+#pragma unroll
+      for (int l = 0; l < H; ++l) {
+        const int kk = lc * H + (half ? H - 1 - l : l);
+        od_in[l] = (OdT)st[kk];
+        bg_in[l] = has_bg ? (BgT)st[64 * H + kk] : (BgT)0;
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
     fill(reinterpret_cast<const float*>(od_col));
 #pragma unroll
     for (int l = 0; l < H; ++l) od_in[l] = (OdT)st[lc * H + (half ? H - 1 - l : l)];
     __builtin_amdgcn_wave_barrier();
-    if (bg_col && sizeof(BgT) == 4) {
-      fill(reinterpret_cast<const float*>(bg_col));
-#pragma unroll
-      for (int l = 0; l < H; ++l) bg_in[l] = (BgT)st[lc * H + (half ? H - 1 - l : l)];
-      __builtin_amdgcn_wave_barrier();
-    } else if (bg_col) {
+    if (bg_col) {
       // DOUBLE (merged) background: the same with 16-byte pairs of doubles
       const double* colb = reinterpret_cast<const double*>(bg_col) + blk;
       double* std_ = s_f1[wave];
@@ -416,6 +436,7 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     } else {
 #pragma unroll
       for (int l = 0; l < H; ++l) bg_in[l] = (BgT)0;
+    }
     }
   } else {
 #pragma unroll
