@@ -67,6 +67,12 @@ def parse():
     # and the event query cost several microseconds per batch of the search
     ap.add_argument("--profile-stride", type=int, default=4)
     ap.add_argument("--sw-tolerance", type=float, default=0.05)          # config 2 (test/do_all_sw.sh: heating_rate_tolerance per model)
+    # the strong-scaling leg beside the headline: ONE configs[3] job dealt to all ranks (default: on when N > 1)
+    ap.add_argument("--strong-leg", dest="strong_leg", action="store_true", default=None)
+    ap.add_argument("--no-strong-leg", dest="strong_leg", action="store_false")
+    ap.add_argument("--no-e2e", action="store_true")
+    # no device work at all: rendezvous (gloo), the one all-reduce, the JSON line.  For the CPU test of the launcher.
+    ap.add_argument("--dry-run", action="store_true")
     args = ap.parse_args()
     if args.nwav is None:
         args.nwav = 3_300_000 if args.config == 2 else 7_200_000
@@ -432,7 +438,7 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
     k1_calls, k1_ms, k1_pts = ctx.profile_get("k_reorder_key_lw")
     # the single collective of the path: max elapsed, total passes, total final cost (RCCL over xGMI)
     from ecckd_amd import shard
-    dt, passes, total_cost = shard.reduce_scalars(dt, passes, info.get("cost_sum", 0.0), device=dev)
+    dt, passes, total_cost, ranks_seen = shard.reduce_scalars(dt, passes, info.get("cost_sum", 0.0), device=dev, count=True)
 
     # What a caller that hands over HOST buffers pays on top (the tools do: spectra come from NetCDF files): the FLOAT
     # target and background spectra of every step over PCIe from pinned memory.  Two measurements beside `value`, never as
@@ -514,6 +520,7 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
             "value": points / dt,
             "unit": "wavenumber-points/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,          # ones summed by the path's single all-reduce (RCCL): the ranks that took part
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -636,8 +643,61 @@ def config4_main(args, ctx, dist, rank, world, barrier):
             "setup_inclusive_seconds": t}
 
 
+def launch_ranks(args):
+    """`bench.py --gpus N` typed on its own (no launcher around it: WORLD_SIZE unset): start the N ranks as CHILD processes
+    through torch.distributed.run, BEFORE this process makes any GPU call (it never does: it only relays), and hand rank 0's
+    JSON line on.  Never an exec: a process that has touched the GPU must not be replaced."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")          # banners and warnings of the ranks: not on the JSON channel
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write("bench.py: the %d-rank job failed (exit code %d)\n" % (args.gpus, proc.returncode))
+        sys.exit(proc.returncode or 1)
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    sys.exit(0)
+
+
+def dry_main(args):
+    """--dry-run: the rendezvous, the path's one all-reduce (gloo on the host) and the JSON line - no device work.  What the
+    CPU test of `--gpus N` runs (tests/test_bench_launcher.py); never a measurement: value is null."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    from ecckd_amd import shard
+    dt, passes, cost, seen = shard.reduce_scalars(1.0 + rank, 1.0, 0.0, count=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "wavenumber-points/s (LW reorder+find_g)", "value": None, "unit": "wavenumber-points/s",
+                          "n_gpus": world, "ranks_seen": seen, "gpus_requested": args.gpus, "dry_run": True,
+                          "steps": args.steps, "warmup": args.warmup, "passes_all_ranks": passes, "max_elapsed": dt}))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                         # does not return
+    if args.dry_run:
+        return dry_main(args)
     # host threads for the CPU baseline: the GPU box gives 16 cores per GPU; more OpenMP threads than that only spin
     ncores = min(16, len(os.sched_getaffinity(0)))
     os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
@@ -645,6 +705,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d\n" % (args.gpus, world, world))
     dist = None
     use_dist = world > 1 or os.environ.get("ECCKD_BENCH_FORCE_DIST") == "1"   # the override exercises the RCCL path on one GPU
     if use_dist:
@@ -672,6 +734,17 @@ def main():
         out = config4_main(args, ctx, dist, rank, world, barrier)
     else:
         out = find_g_main(args, ctx, dist, rank, world, barrier, use_dist)
+        strong = args.strong_leg if args.strong_leg is not None else world > 1
+        if args.config == 1 and strong:
+            # the strong-scaling leg north_star describes: ONE configs[3] job (13 bands x 8 gases) dealt to all the ranks
+            import copy
+            a3 = copy.copy(args)
+            a3.config = 3
+            torch.cuda.empty_cache()
+            leg = find_g_main(a3, ctx, dist, rank, world, barrier, use_dist)
+            if rank == 0:
+                out["strong_leg"] = {k: leg[k] for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup",
+                                                         "ms_per_step", "scaling", "config", "search")}
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -58,23 +58,27 @@ def task_table(gases, nband):
     return [(g, b) for g in gases for b in range(nband)]
 
 
-def reduce_scalars(elapsed_s, passes, cost, device=None, group=None):
+def reduce_scalars(elapsed_s, passes, cost, device=None, group=None, count=False):
     """One all-reduce of [elapsed, passes, cost] -> (max elapsed, total passes, total cost).
 
-    MAX and SUM are folded into a single SUM all-reduce of a (world, 3) one-hot matrix so that
-    exactly one collective is issued (latency-bound on xGMI: a few KB at most)."""
+    MAX and SUM are folded into a single SUM all-reduce of a (world, 4) one-hot matrix so that
+    exactly one collective is issued (latency-bound on xGMI: a few KB at most).  The fourth column
+    carries a one per rank: with `count=True` the number of ranks the collective actually saw is
+    returned as a fourth value (bench.py prints it as `ranks_seen`)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
-        return float(elapsed_s), float(passes), float(cost)
+        out = (float(elapsed_s), float(passes), float(cost))
+        return out + (1,) if count else out
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    buf = torch.zeros((world, 3), dtype=torch.float64, device=device)
-    buf[rank, 0], buf[rank, 1], buf[rank, 2] = float(elapsed_s), float(passes), float(cost)
+    buf = torch.zeros((world, 4), dtype=torch.float64, device=device)
+    buf[rank, 0], buf[rank, 1], buf[rank, 2], buf[rank, 3] = float(elapsed_s), float(passes), float(cost), 1.0
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     b = buf.cpu().numpy()
     # fixed rank order: every rank computes bit-identical totals
-    return float(b[:, 0].max()), float(np.add.reduce(b[:, 1])), float(np.add.reduce(b[:, 2]))
+    out = (float(b[:, 0].max()), float(np.add.reduce(b[:, 1])), float(np.add.reduce(b[:, 2])))
+    return out + (int(round(float(np.add.reduce(b[:, 3])))),) if count else out
 
 
 # ---- optimize_lut: training profiles sharded over the ranks (SURVEY 8e, optimize_lut row) -------------------
