@@ -57,6 +57,7 @@ SIGNATURES = {
     "ecckd_stream": (C.c_void_p, [C.c_void_p]),
     "ecckd_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "ecckd_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ecckd_mem_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ecckd_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ecckd_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ecckd_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -62,13 +62,31 @@ template <class T> bool get_vec(std::ifstream& f, std::vector<T>& v) {
   return n == 0 || (bool)f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(n * sizeof(T)));
 }
 
-void write_part(const std::string& path, const std::vector<BandResult>& res) {
+// A part file carries the identity of its run: a hash of the configuration text, the launcher's rendezvous (MASTER_ADDR,
+// MASTER_PORT, TORCHELASTIC_RUN_ID, ECCKD_RUN_ID), WORLD_SIZE and - known once the ordering files are read - the numbers of
+// gases, bands and wavenumbers.  Process 0 refuses a part whose identity is not its own (a stale file of an aborted earlier
+// run, ordering files that disagree between the processes).
+uint64_t run_identity(const Config& config, int world) {
+  uint64_t h = fnv1a(config.str());
+  for (const char* name : {"MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "ECCKD_RUN_ID"}) {
+    const char* e = std::getenv(name);
+    h = fnv1a(std::string(e ? e : ""), h);
+  }
+  return fnv1a(&world, sizeof world, h);
+}
+uint64_t job_identity(uint64_t run_id, int ngas, int nband, uint64_t nwav) {
+  uint64_t h = fnv1a(&ngas, sizeof ngas, run_id);
+  h = fnv1a(&nband, sizeof nband, h);
+  return fnv1a(&nwav, sizeof nwav, h);
+}
+
+void write_part(const std::string& path, const std::vector<BandResult>& res, uint64_t identity) {
   const std::string tmp = path + ".tmp";
   {
     std::ofstream f(tmp, std::ios::binary);
     if (!f) fail(ECCKD_PROCESSING_ERROR, "Cannot write %s", tmp.c_str());
     const uint64_t magic = 0x45434b4450415254ull, n = res.size();   // "ECKDPART"
-    put(f, magic); put(f, n);
+    put(f, magic); put(f, identity); put(f, n);
     for (const BandResult& r : res) {
       put(f, r.gas); put(f, r.band); put(f, r.ng); put(f, r.status); put(f, r.comp_cost); put(f, r.ibegin); put(f, r.iend);
       put_vec(f, r.rank1); put_vec(f, r.rank2); put_vec(f, r.error); put_vec(f, r.median); put_vec(f, r.rank_slice);
@@ -78,16 +96,35 @@ void write_part(const std::string& path, const std::vector<BandResult>& res) {
   if (std::rename(tmp.c_str(), path.c_str()) != 0) fail(ECCKD_PROCESSING_ERROR, "Cannot rename %s", tmp.c_str());   // complete or absent
 }
 
-std::vector<BandResult> read_part(const std::string& path, double timeout_s) {
+// the marker a process other than 0 leaves when it ends with an error: "<output>.part<r>.failed" = [run identity, exit code]
+void write_failure_marker(const std::string& path, uint64_t run_id, int code) {
+  std::ofstream f(path, std::ios::binary);
+  put(f, run_id); put(f, code);
+}
+
+std::vector<BandResult> read_part(const std::string& path, double timeout_s, uint64_t run_id, uint64_t identity) {
   const auto t0 = std::chrono::steady_clock::now();
+  const std::string failed = path + ".failed";
   while (access(path.c_str(), R_OK) != 0) {
+    if (access(failed.c_str(), R_OK) == 0) {
+      std::ifstream m(failed, std::ios::binary);
+      uint64_t id = 0; int code = 0;
+      if (get(m, id) && get(m, code) && id == run_id) {
+        m.close();
+        std::remove(failed.c_str());
+        fail(ECCKD_PROCESSING_ERROR, "The process that was to write %s ended with exit code %d", path.c_str(), code);
+      }                                         // a marker of another run: not ours to act on
+    }
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-      fail(ECCKD_PROCESSING_ERROR, "Timed out waiting for %s (did the process of that rank fail?)", path.c_str());
+      fail(ECCKD_PROCESSING_ERROR, "Timed out after %g s waiting for %s (was the process of that rank started?)", timeout_s, path.c_str());
     std::this_thread::sleep_for(std::chrono::milliseconds(20));
   }
   std::ifstream f(path, std::ios::binary);
-  uint64_t magic = 0, n = 0;
-  if (!get(f, magic) || magic != 0x45434b4450415254ull || !get(f, n)) fail(ECCKD_PROCESSING_ERROR, "%s is not a find_g_points part file", path.c_str());
+  uint64_t magic = 0, id = 0, n = 0;
+  if (!get(f, magic) || magic != 0x45434b4450415254ull || !get(f, id) || !get(f, n)) fail(ECCKD_PROCESSING_ERROR, "%s is not a find_g_points part file", path.c_str());
+  if (id != identity)
+    fail(ECCKD_PROCESSING_ERROR, "%s belongs to another run (configuration, launcher rendezvous, WORLD_SIZE or the numbers of gases / bands / "
+         "wavenumbers differ from this process's): remove it, and start every process of a run with the same configuration", path.c_str());
   std::vector<BandResult> res((size_t)n);
   for (BandResult& r : res) {
     const bool ok = get(f, r.gas) && get(f, r.band) && get(f, r.ng) && get(f, r.status) && get(f, r.comp_cost) && get(f, r.ibegin) && get(f, r.iend) &&
@@ -146,16 +183,25 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 9; ++k) if (averaging_method == methods[k]) method = k;
     if (method < 0) fail(ECCKD_PARAMETER_ERROR, "Averaging method \"%s\" not understood", averaging_method.c_str());
 
-    Device dev;
-    dev.enable_od_cache();       // a gas's spectrum is the target once and part of the other gases' backgrounds: read once
     const int world = std::max(1, env_int("WORLD_SIZE", 1)), my_rank = env_int("RANK", 0);
     if (my_rank < 0 || my_rank >= world) fail(ECCKD_PARAMETER_ERROR, "RANK=%d outside WORLD_SIZE=%d", my_rank, world);
+    const uint64_t run_id = run_identity(config, world);
+    if (world > 1) {
+      // before anything that can fail (device start-up, the gas list, the files): never a stale part or marker of an earlier
+      // run under this process's name, and from here on a failure of this process is visible to process 0
+      const std::string my_part = output + ".part" + std::to_string(my_rank);
+      std::remove(my_part.c_str());
+      std::remove((my_part + ".tmp").c_str());
+      std::remove((my_part + ".failed").c_str());
+      if (my_rank != 0) on_failure() = [my_part, run_id](int code) { write_failure_marker(my_part + ".failed", run_id, code); };
+    }
+    Device dev;
+    dev.enable_od_cache();       // a gas's spectrum is the target once and part of the other gases' backgrounds: read once
     const std::vector<std::string> gas_list = config.read_list("gases");
     const int ngas = (int)gas_list.size();
     if (ngas == 0) fail(ECCKD_PARAMETER_ERROR, "No gases specified in \"gases\"");
     if (world > 1) {
       LOG("Process %d of %d: the (gas, band) searches are dealt in contiguous shares\n", my_rank, world);
-      std::remove((output + ".part" + std::to_string(my_rank)).c_str());   // never a stale part of an earlier run
     }
     std::vector<BandResult> results;                     // the searches of this process
     std::vector<std::vector<int32_t>> order_rank(ngas);  // process 0: the rank of every gas as its ordering file has it
@@ -455,15 +501,18 @@ int main(int argc, char** argv) {
     double my_cost = 0.0;
     for (const BandResult& r : results) for (double e : r.error) my_cost += e;
     if (world > 1) LOG("Process %d: %zu searches, sum of the g points' errors %.17g K d-1\n", my_rank, results.size(), my_cost);
+    const uint64_t identity = job_identity(run_id, ngas, nband, (uint64_t)nwav);
     if (my_rank != 0) {
-      write_part(output + ".part" + std::to_string(my_rank), results);
+      write_part(output + ".part" + std::to_string(my_rank), results, identity);
       return done(0);
     }
-    double part_timeout = 3600.0;                      // extension key: how long process 0 waits for the others, in seconds
+    // extension key: how long process 0 waits for a part that has not appeared, in seconds.  A process that FAILS says so
+    // through its marker at once; the wait only covers a peer that is still searching (or was never started)
+    double part_timeout = 900.0;
     config.read(part_timeout, "part_timeout");
     for (int r = 1; r < world; ++r) {
       const std::string path = output + ".part" + std::to_string(r);
-      std::vector<BandResult> part = read_part(path, part_timeout);
+      std::vector<BandResult> part = read_part(path, part_timeout, run_id, identity);
       for (BandResult& br : part) results.push_back(std::move(br));
       std::remove(path.c_str());
     }

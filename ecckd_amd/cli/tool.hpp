@@ -17,6 +17,7 @@
 #include <ctime>
 #include <deque>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/ecckd_hip.h"
@@ -398,11 +399,17 @@ class Device {
     return it == od_cache_.end() ? nullptr : &it->second;
   }
   void enable_od_cache() { od_cache_on_ = true; }     // for a tool that reads the same slices again (find_g_points)
+  // Room for one more slice in the cache?  The budget is ECCKD_OD_CACHE_GB (default 64) per process, and never more than
+  // what leaves a quarter of the device's memory - as free as the driver reports it NOW, so that several processes sharing a
+  // GPU see each other - to the gas preparations (a prepared gas holds ~4x the bytes of its FLOAT slice).
   bool od_cache_room(size_t bytes) const {
     if (!od_cache_on_) return false;
     double gb = 64.0;
     if (const char* e = std::getenv("ECCKD_OD_CACHE_GB")) gb = std::atof(e);
-    return (double)(od_cache_bytes_ + bytes) <= gb * 1073741824.0;
+    if ((double)(od_cache_bytes_ + bytes) > gb * 1073741824.0) return false;
+    size_t free_b = 0, total_b = 0;
+    if (ecckd_mem_info(ctx_, &free_b, &total_b) != ECCKD_OK) return false;
+    return (double)bytes <= (double)free_b - 0.25 * (double)total_b;
   }
   void od_cache_put(const std::string& key, void* ptr, size_t bytes, int type) const {
     od_cache_[key] = CachedOd{ptr, bytes, type};
@@ -504,12 +511,13 @@ inline DevOd read_od_dev(const Device& d, const NcIn& f, int iprofile, int nlay,
   }
   if (d.od_cache_room(bytes)) {
     void* p = nullptr;
-    ck(ecckd_dev_alloc(d.ctx(), bytes, &p));
-    const int rc = ecckd_nc_read_dev(d.ctx(), f.handle(), "optical_depth", iprofile, out.type, p, n);
-    if (rc != ECCKD_OK) { ecckd_dev_free(d.ctx(), p); ck(rc); }
-    d.od_cache_put(key, p, bytes, out.type);
-    out.buf = DevBuf::view(d.ctx(), p, bytes);
-    return out;
+    if (ecckd_dev_alloc(d.ctx(), bytes, &p) == ECCKD_OK) {     // no room after all: read into a buffer the caller owns, below
+      const int rc = ecckd_nc_read_dev(d.ctx(), f.handle(), "optical_depth", iprofile, out.type, p, n);
+      if (rc != ECCKD_OK) { ecckd_dev_free(d.ctx(), p); ck(rc); }
+      d.od_cache_put(key, p, bytes, out.type);
+      out.buf = DevBuf::view(d.ctx(), p, bytes);
+      return out;
+    }
   }
   out.buf.alloc(d, bytes);
   ck(ecckd_nc_read_dev(d.ctx(), f.handle(), "optical_depth", iprofile, out.type, out.buf.ptr(), n));
@@ -608,6 +616,21 @@ inline void deal_tasks(int ntasks, int rank, int world, int& begin, int& end) {
   end = begin + base + (rank < extra ? 1 : 0);
 }
 
+// what a tool wants done when it ends with an error (find_g_points under a launcher: leave a failure marker for process 0)
+inline std::function<void(int)>& on_failure() { static std::function<void(int)> f; return f; }
+inline void note_failure(int code) {
+  if (on_failure()) {
+    try { on_failure()(code); } catch (...) {}
+  }
+}
+// FNV-1a over a byte string, chained: the run identity the part files of a several-process find_g_points carry
+inline uint64_t fnv1a(const void* data, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+inline uint64_t fnv1a(const std::string& s, uint64_t h = 0xcbf29ce484222325ull) { return fnv1a(s.data(), s.size() + 1, h); }
+
 // ---- main wrapper: exit codes like THROW(code) (Logging.h:115-117) ----
 template <class Body>
 int run(int argc, char** argv, Body body) {
@@ -624,9 +647,11 @@ int run(int argc, char** argv, Body body) {
     return rc;
   } catch (const Fatal& f) {
     std::fprintf(stderr, "*** Error: %s\n", f.msg.c_str());
+    note_failure(f.code ? f.code : 1);
     return f.code ? f.code : 1;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "*** Error: %s\n", e.what());
+    note_failure(ECCKD_UNEXPECTED_EXCEPTION);
     return ECCKD_UNEXPECTED_EXCEPTION;
   }
 }

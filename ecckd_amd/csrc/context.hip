@@ -200,6 +200,13 @@ int ecckd_dev_alloc(ecckd_ctx* ctx, size_t bytes, void** d_ptr) {
   return ECCKD_OK;
 }
 
+int ecckd_mem_info(ecckd_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+  ECCKD_REQUIRE(ctx && free_bytes && total_bytes, "ecckd_mem_info: NULL argument");
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  ECCKD_HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes));
+  return ECCKD_OK;
+}
+
 int ecckd_dev_free(ecckd_ctx* ctx, void* d_ptr) {
   ECCKD_REQUIRE(ctx, "ecckd_dev_free: ctx is NULL");
   if (!d_ptr) return ECCKD_OK;

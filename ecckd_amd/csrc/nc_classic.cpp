@@ -56,6 +56,7 @@ struct Var {
   int type = 0;
   uint64_t vsize = 0, begin = 0;
   bool record = false;
+  bool past_end = false;   // the header places (part of) its data beyond the end of the file: refused when asked for, see open
 };
 
 // big-endian decode of one element to double
@@ -174,7 +175,8 @@ int parse_header(ecckd_nc* f) {
                        f->path.c_str());
   f->version = magic[3];
   f->numrecs = r.count(f->version);
-  if (f->version != 5 && f->numrecs == 0xFFFFFFFFu) f->numrecs = 0;   // STREAMING: recomputed below if possible
+  const bool streaming = f->version == 5 ? f->numrecs == UINT64_MAX : f->numrecs == 0xFFFFFFFFu;   // recomputed from the file size below
+  if (streaming) f->numrecs = 0;
   {
     uint32_t tag = r.u32();
     uint64_t n = r.count(f->version);
@@ -227,8 +229,10 @@ int parse_header(ecckd_nc* f) {
     for (size_t k = 1; k < v.dimids.size(); ++k) slab *= f->dims[v.dimids[k]].len;
     f->recsize += (nrec == 1) ? slab : pad4(slab);
   }
-  // every variable's data must lie inside the file: a damaged dimension length or offset is caught here, not by whoever sizes
-  // a buffer from the shape
+  // A variable whose data the header places beyond the end of the file (a damaged dimension length or offset, a cut-off
+  // file, a NC_NOFILL file whose last variable was never written) is refused WHEN IT IS ASKED FOR - ecckd_nc_inq_var, which
+  // sizes the callers' buffers, the readers and nc_locate_slice -; the other variables of the file stay readable, as they are
+  // through the NetCDF library.
   uint64_t file_size = 0;
   {
     const long at = std::ftell(f->fp);
@@ -236,16 +240,25 @@ int parse_header(ecckd_nc* f) {
     file_size = (uint64_t)std::ftell(f->fp);
     std::fseek(f->fp, at, SEEK_SET);
   }
-  for (const Var& v : f->vars) {
+  if (streaming) {
+    // numrecs = 0xFFFFFFFF ("indeterminate", written by a streaming producer): as many whole records as the file holds
+    uint64_t first = UINT64_MAX;
+    for (const Var& v : f->vars) if (v.record) first = std::min(first, v.begin);
+    f->numrecs = (f->recsize > 0 && first <= file_size) ? (file_size - first) / f->recsize : 0;
+  }
+  for (Var& v : f->vars) {
     unsigned __int128 bytes = type_size(v.type);
     for (size_t k = v.record ? 1 : 0; k < v.dimids.size(); ++k) bytes *= f->dims[v.dimids[k]].len, bytes = bytes > ((unsigned __int128)1 << 100) ? ((unsigned __int128)1 << 100) : bytes;
     unsigned __int128 last = (unsigned __int128)v.begin + bytes;
     if (v.record && f->numrecs > 0) last = (unsigned __int128)v.begin + (unsigned __int128)(f->numrecs - 1) * f->recsize + bytes;
-    if ((v.record && f->numrecs == 0) ? v.begin > file_size : last > file_size)
-      return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: variable %s extends past the end of the file (damaged header or truncated file)",
-                         f->path.c_str(), v.name.c_str());
+    v.past_end = (v.record && f->numrecs == 0) ? v.begin > file_size : last > file_size;
   }
   return ECCKD_OK;
+}
+
+int refuse_past_end(const ecckd_nc* f, const Var& v) {
+  return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: variable %s extends past the end of the file (damaged header or truncated file)",
+                     f->path.c_str(), v.name.c_str());
 }
 
 void put_u32(std::vector<unsigned char>& b, uint32_t v) { for (int i = 3; i >= 0; --i) b.push_back((unsigned char)(v >> (8 * i))); }
@@ -358,6 +371,7 @@ int ecckd_nc_inq_var(ecckd_nc* f, const char* name, int* exists, int* nc_type, i
   const Var* v = f->find(name);
   *exists = v ? 1 : 0;
   if (!v) return ECCKD_OK;
+  if (v->past_end) return refuse_past_end(f, *v);        // its shape must not size anybody's buffer
   std::vector<uint64_t> sh;
   f->shape_of(*v, sh);
   if (nc_type) *nc_type = v->type;
@@ -380,6 +394,7 @@ int nc_locate_slice(ecckd_nc* f, const char* name, long long slice, NcSlice* out
   if (f->h5) return ECCKD_OK;                 // not contiguous: the caller reads through the HDF5 layer
   const Var* v = f->find(name);
   if (!v) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: no variable \"%s\"", f->path.c_str(), name);
+  if (v->past_end) return refuse_past_end(f, *v);
   std::vector<uint64_t> sh;
   f->shape_of(*v, sh);
   uint64_t per_slice = 1;
@@ -410,6 +425,7 @@ int ecckd_nc_read_double(ecckd_nc* f, const char* name, long long slice, double*
   }
   const Var* v = f->find(name);
   if (!v) return ecckd::fail(ECCKD_PARAMETER_ERROR, "%s: no variable \"%s\"", f->path.c_str(), name);
+  if (v->past_end) return refuse_past_end(f, *v);
   std::vector<uint64_t> sh;
   f->shape_of(*v, sh);
   uint64_t per_slice = 1;

@@ -79,6 +79,7 @@ struct Streamer {
   void* pinned[NBUF] = {};
   void* d_raw[NBUF] = {};
   hipEvent_t done[NBUF] = {};
+  hipEvent_t entry = nullptr;    // recorded on the context's stream when a read begins: the copy stream starts behind it
   bool ready = false;
   void* h5dev = nullptr;         // H5Dev: buffers of the device-inflate path (created on first use)
 };
@@ -98,6 +99,7 @@ int ensure_streamer(ecckd_ctx* ctx) {
     s->d_raw[b] = (char*)s->d_raw[0] + (size_t)b * CHUNK_BYTES;
     ECCKD_HIP_CHECK(hipEventCreateWithFlags(&s->done[b], hipEventDisableTiming));
   }
+  ECCKD_HIP_CHECK(hipEventCreateWithFlags(&s->entry, hipEventDisableTiming));
   s->ready = true;
   return ECCKD_OK;
 }
@@ -499,6 +501,10 @@ int ecckd_nc_read_dev(ecckd_ctx* ctx, ecckd_nc* file, const char* name, long lon
   if (n == 0) return ECCKD_OK;
   ECCKD_CHECK(ensure_streamer(ctx));
   Streamer* st = streamer_of(ctx);
+  // like every other entry point this one is ordered behind what the caller has queued on the context's stream: work there
+  // that still reads or writes d_out finishes before the private copy stream touches it (the read itself ends synchronously)
+  ECCKD_HIP_CHECK(hipEventRecord(st->entry, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamWaitEvent(st->copy, st->entry, 0));
   const size_t ts = sl.nc_type == 5 ? 4 : 8;
   const size_t per_chunk = CHUNK_BYTES / ts;
   const size_t nchunks = (n + per_chunk - 1) / per_chunk;

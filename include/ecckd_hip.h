@@ -72,6 +72,8 @@ int ecckd_trim_cache(ecckd_ctx* ctx);
 void* ecckd_stream(ecckd_ctx* ctx);
 int ecckd_dev_alloc(ecckd_ctx* ctx, size_t bytes, void** d_ptr);
 int ecckd_dev_free(ecckd_ctx* ctx, void* d_ptr);
+/* free and total device memory in bytes as the driver reports them (what another process on the same GPU holds counts as used) */
+int ecckd_mem_info(ecckd_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int ecckd_h2d(ecckd_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int ecckd_d2h(ecckd_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 /* per-kernel timing of the dominant kernels with HIP events on the context's stream:

@@ -199,6 +199,54 @@ def test_find_g_points_several_processes(ctx, tmp_path, world):
         assert "(searched by other processes)" in outs[1]                    # process 1 searches co2 only
 
 
+def test_find_g_points_refuses_stale_parts_and_sees_failed_peers(ctx, tmp_path):
+    """a part file carries the identity of its run (configuration text, launcher rendezvous, WORLD_SIZE, numbers of
+    gases / bands / wavenumbers); process 0 refuses one that is not its own instead of building the g-points file from another
+    run's data, a process removes its stale part before anything that can fail, and a process that ends with an error leaves a
+    marker that process 0 acts on at once instead of waiting for the time-out."""
+    d = tmp_path
+    _make_lw_files(d)
+    os.symlink(d / "h2o.nc", d / "co2_bg_is_h2o.nc")
+    for g in ("h2o", "co2"):
+        r = run_tool("reorder_spectrum", f"input={d}/{g}.nc", f"output={d}/order_{g}.nc", "wavenumber1=0 1300", "wavenumber2=1300 3260")
+        assert r.returncode == 0, r.stderr
+    (d / "find_g.cfg").write_text(LW_CFG.format(d=d))
+    exe = os.path.join(BIN, "find_g_points")
+
+    def start(rank, *extra, env=None):
+        e = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), ECCKD_DEVICE="0", MASTER_PORT="29999")
+        e.update(env or {})
+        return subprocess.Popen([exe, str(d / "find_g.cfg"), f"output={d}/many.nc", "part_timeout=120", *extra], cwd="/", env=e,
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    # (1) a part left by ANOTHER run (here: another tolerance on the command line = another configuration text): refused
+    p1 = start(1, "heating_rate_tolerance=0.5")
+    out, err = p1.communicate(timeout=600)
+    assert p1.returncode == 0, err + out
+    assert (d / "many.nc.part1").exists()
+    p0 = start(0)
+    out, err = p0.communicate(timeout=600)
+    assert p0.returncode == 148 and "belongs to another run" in err, err + out
+    assert not (d / "many.nc").exists()
+    # (2) the stale part is gone as soon as the process of that rank starts, even when it then fails at device start-up; its
+    # marker ends process 0's wait at once (well inside the 120 s time-out)
+    import time
+    t0 = time.perf_counter()
+    p0 = start(0)
+    p1 = start(1, env={"ECCKD_DEVICE": "63"})
+    out1, err1 = p1.communicate(timeout=600)
+    out0, err0 = p0.communicate(timeout=600)
+    assert p1.returncode != 0
+    assert p0.returncode == 148 and "ended with exit code" in err0, err0 + out0
+    assert time.perf_counter() - t0 < 60.0
+    assert not (d / "many.nc.part1").exists() and not (d / "many.nc").exists()
+    # (3) and the run as it should be: same rendezvous on both, parts collected, markers gone
+    p0, p1 = start(0), start(1)
+    (out0, err0), (out1, err1) = p0.communicate(timeout=600), p1.communicate(timeout=600)
+    assert p0.returncode == 0 and p1.returncode == 0, err0 + err1
+    assert (d / "many.nc").exists() and not [f for f in os.listdir(d) if ".part" in f]
+
+
 def test_find_g_points_sw(ctx, tmp_path):
     from ecckd_amd import pipeline
     d = tmp_path

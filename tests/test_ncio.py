@@ -440,3 +440,40 @@ def test_damaged_classic_files_are_refused_or_read_never_crashed(tmp_path):
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     ok, refused = map(int, r.stdout.split())
     assert ok + refused == 600 and refused > 50
+
+
+def test_streaming_record_count_and_unwritten_tail(tmp_path):
+    """(i) numrecs = 0xFFFFFFFF (a streaming producer's "indeterminate") is derived from the file size as the NetCDF
+    library does; (ii) a file whose LAST fixed variable was never completely written (NC_NOFILL, or cut off) keeps its other
+    variables readable - only the variable that extends past the end is refused, when it is asked for."""
+    from ecckd_amd import ncio, EcckdError
+    path = tmp_path / "rec.nc"
+    w = netcdf_file(str(path), "w", version=1)
+    w.createDimension("time", None); w.createDimension("x", 3)
+    w.createVariable("fixed", "d", ("x",))[:] = [1.0, 2.0, 3.0]
+    v = w.createVariable("series", "d", ("time", "x"))
+    for k in range(4):
+        v[k] = np.arange(3.0) + 10 * k
+    w.close()
+    raw = bytearray(path.read_bytes())
+    assert int.from_bytes(raw[4:8], "big") == 4
+    raw[4:8] = (0xFFFFFFFF).to_bytes(4, "big")
+    path.write_bytes(raw)
+    with ncio.NcFile(str(path)) as f:
+        assert f.var_info("series")[1] == (4, 3)
+        assert np.array_equal(f.read("series"), np.arange(3.0)[None, :] + 10 * np.arange(4.0)[:, None])
+        assert np.array_equal(f.read("fixed"), [1.0, 2.0, 3.0])
+    path2 = tmp_path / "tail.nc"
+    w = netcdf_file(str(path2), "w", version=2)
+    w.createDimension("x", 50)
+    w.createVariable("a", "d", ("x",))[:] = np.arange(50.0)
+    w.createVariable("b", "d", ("x",))[:] = np.arange(50.0) * 2
+    w.close()
+    raw = path2.read_bytes()
+    path2.write_bytes(raw[:-100])                       # the tail of the last variable is missing
+    with ncio.NcFile(str(path2)) as f:
+        assert np.array_equal(f.read("a"), np.arange(50.0))
+        with pytest.raises(EcckdError, match="extends past the end"):
+            f.read("b")
+        with pytest.raises(EcckdError, match="extends past the end"):
+            f.var_info("b")
