@@ -34,6 +34,8 @@
 #include "fastmath.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <immintrin.h>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -444,6 +446,468 @@ __global__ void k_opt_forward_adjoint(
   if (threadIdx.x == 0) jcol[col] = jtot;
 }
 
+// ---- K8a, the form that runs (the kernel above stays as the general fall-back and as the cross-check of this one) ----
+// Same arithmetic per cell and the same sequential recurrences, but only what IS sequential runs on one wave:
+//   A  every thread (layer group, g) owns the cells (l = lgrp + j * nlgrp, g), j < NC: LUT gather, clamp + penalty, then the
+//      layer's transmittance and its two source terms (longwave: 1 - eps, B_l (eps - fac) + B_l+1 fac, B_l+1 (eps - fac) +
+//      B_l fac; shortwave: the two transmittances) - the `exp` and the division of every cell, 16 layers side by side;
+//   B  ONE wave runs the two recurrences dn_l+1 = dn_l t_l + s_l, up_l = up_l+1 t_l + s'_l: one FMA per layer from LDS;
+//   C, D  band sums and cost terms as in the kernel above (same code, same summation order);
+//   E  the adjoint recurrences (again one FMA per layer on one wave), then every thread forms dJ/dtau of ITS cells from the
+//      adjoint and forward fluxes at its layer and what it kept in registers (tau, exp(-D tau)).
+// The sequential part of a profile shrinks from 4 x nlay (exp + division + recurrence) to 4 x nlay FMAs.  LDS per profile:
+// longwave t | dn | up, shortwave dn | up only (the transmittances sit in the rows the fluxes then overwrite, and come back
+// from the owners' registers for the adjoint recurrences) -> 107 KB / 79 KB at nlay = 54, ng = 64: two shortwave blocks per CU.
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Optical depth of one cell for the 64 g points of a wave (calc_total_optical_depth, solve_adept.cpp:24-69).  The cell is the
+// same for the whole wave, so its table entries (node row, coefficient) are fetched ONCE, one entry per lane (two coalesced
+// loads instead of 2 x nent same-address loads per lane), and handed round with v_readlane: the row offsets arrive in scalar
+// registers and the nent loads of the coefficient rows are independent of each other - eight in flight per batch, the products
+// still added in entry order; absent entries (idx < 0) add nothing.  `active` = this lane has a g point.
+__device__ __forceinline__ double gather_cell(const int* __restrict__ ei, const double* __restrict__ ec, const double* __restrict__ k,
+                                              int g, bool active, int nent, int ray_ent, double& tau_ray) {
+  const int lane = threadIdx.x & 63;
+  double tau = 0.0;
+  tau_ray = 0.0;
+  for (int e0 = 0; e0 < nent; e0 += 64) {
+    const int ne = min(64, nent - e0);
+    const int my_idx = lane < ne ? ei[e0 + lane] : -1;
+    const double my_c = lane < ne ? ec[e0 + lane] : 0.0;
+    for (int q0 = 0; q0 < ne; q0 += 8) {
+      int ix[8];
+      double cv[8], kv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = (q0 + q) & 63;
+        ix[q] = (q0 + q < ne) ? __builtin_amdgcn_readlane(my_idx, e) : -1;
+        cv[q] = readlane_f64(my_c, e);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) kv[q] = (ix[q] >= 0 && active) ? k[(size_t)ix[q] + g] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double t = ix[q] >= 0 ? cv[q] * kv[q] : 0.0;
+        if (e0 + q0 + q == ray_ent) tau_ray = t; else tau += t;
+      }
+    }
+  }
+  return tau;
+}
+
+constexpr int K8A_CH = 8;      // layers per prefetch chunk of the sequential recurrences
+constexpr int K8A_MAXR = 4;    // (half level, band) slots per thread in the cost phase: (nlay + 1) * nband <= K8A_MAXR * blockDim
+
+template <int NC, bool SW>
+__global__ void __launch_bounds__(1024)
+k_opt_forward_adjoint_cells(
+    const double* __restrict__ mu0, int ray_ent, int keep_negative, const double* __restrict__ rel_flux,
+    int nlay, int ng, int ngpad, int nband, int nent,
+    const double* __restrict__ k, const int* __restrict__ ent_idx, const double* __restrict__ ent_coef,
+    const int* __restrict__ band_of_g, const int* __restrict__ band_ptr /*[nband+1]*/, const int* __restrict__ band_g /*[ng]: g points by band*/,
+    const double* __restrict__ planck_hl, const double* __restrict__ surf_emis,
+    const double* __restrict__ conv, const double* __restrict__ layer_weight, const double* __restrict__ hr_true,
+    const double* __restrict__ fdn_true, const double* __restrict__ fup_true, const double* __restrict__ sfds,
+    const double* __restrict__ sfut, double flux_weight, double flux_profile_weight, double broadband_weight,
+    double spectral_boundary_weight, double negative_od_penalty, double* __restrict__ dtau, double* __restrict__ jcol,
+    double* __restrict__ od_out, double* __restrict__ flux_out, int dbg) {
+  extern __shared__ double smem[];
+  const int nhl = nlay + 1;
+  double* s_T = smem;                                            // longwave only: [nlay][ng] 1 - eps
+  double* s_D = s_T + (SW ? (size_t)0 : (size_t)nlay * ng);      // [nhl][ng] down: sources / transmittances, fluxes, adjoints
+  double* s_U = s_D + (size_t)nhl * ng;                          // [nhl][ng] up
+  double* s_bdn = s_U + (size_t)nhl * ng;                        // [nhl][nband] band fluxes, then dJ/d(band flux)
+  double* s_bup = s_bdn + (size_t)nhl * nband;
+  double* s_r = s_bup + (size_t)nhl * nband;                     // [nlay][nband] heating-rate residuals
+  double* s_rsum = s_r + (size_t)nlay * nband;                   // [nlay] their broadband sums
+  double* s_sd = s_rsum + nlay;                                  // [nhl] broadband flux residuals
+  double* s_su = s_sd + nhl;
+  double* s_red = s_su + nhl;                                    // [16]
+  int* s_bp = (int*)(s_red + 16);                                // [nband + 1]
+  int* s_bg = s_bp + nband + 1;                                  // [ng]
+  const int col = blockIdx.x;
+  const int g = threadIdx.x % ngpad;
+  const int lgrp = __builtin_amdgcn_readfirstlane(threadIdx.x / ngpad);     // ngpad is a multiple of 64: uniform in a wave
+  const int nlgrp = blockDim.x / ngpad;
+  const bool in_range = g < ng;
+  const bool live = in_range && lgrp == 0;
+  const double hr_weight = 3600.0 * 24.0;
+  const double* pl = planck_hl + (size_t)col * nhl * ng;
+  const size_t cell0 = (size_t)col * nlay;
+  bool all_pos = true, all_nonpos = true;
+  double cos_sza = 1.0;
+  if (SW) {
+    for (int b = 0; b < nband; ++b) {
+      const bool pos = surf_emis[(size_t)col * nband + b] > 0.0;
+      all_pos = all_pos && pos;
+      all_nonpos = all_nonpos && !pos;
+    }
+    cos_sza = mu0[col];
+  }
+  const double minus_sec_sza = -1.0 / cos_sza;
+  for (int t = threadIdx.x; t <= nband; t += blockDim.x) s_bp[t] = band_ptr[t];
+  for (int t = threadIdx.x; t < ng; t += blockDim.x) s_bg[t] = band_g[t];
+
+  // ---- A: the cells of this thread ----
+  double c_tau[NC], c_t[NC];       // optical depth as the sweeps see it; exp(-D tau) (longwave) / exp(-tau / mu0) (shortwave)
+  double c_tu[SW ? NC : 1];        // shortwave: exp(-2 tau)
+  unsigned clamp_mask = 0;
+  double penalty = 0.0;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int l = lgrp + j * nlgrp;
+    c_tau[j] = 0.0; c_t[j] = 1.0;
+    if constexpr (SW) c_tu[j] = 1.0;
+    if (l < nlay) {
+      double tau_ray = 0.0;
+      double tau = (dbg & 1) ? 0.1 + 0.01 * l : gather_cell(ent_idx + (cell0 + l) * nent, ent_coef + (cell0 + l) * nent, k, g, in_range, nent, ray_ent, tau_ray);
+      if (in_range) {
+        const double tau_raw = tau;
+        bool clamped = false;
+        if (tau < 0.0) {
+          penalty += tau * tau;                                       // solve_adept.cpp:110-113
+          dtau[(cell0 + l) * ng + g] = 2.0 * negative_od_penalty * tau;
+          tau = 0.0;
+          clamped = true;
+          clamp_mask |= 1u << j;
+        }
+        if (od_out) od_out[(cell0 + l) * ng + g] = (keep_negative && clamped) ? tau_raw : tau;
+        if (keep_negative == 2) tau = tau_raw;
+        tau += tau_ray;
+        c_tau[j] = tau;
+        if constexpr (!SW) {
+          const double ex = ecckd::exp_fast(-kD * tau);
+          const double eps = 1.0 - ex;
+          const double fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;   // radiative_transfer_lw.cpp:41-43
+          const double b0 = pl[l * ng + g], b1 = pl[(l + 1) * ng + g];
+          c_t[j] = ex;
+          s_T[l * ng + g] = 1.0 - eps;
+          s_D[(l + 1) * ng + g] = b0 * (eps - fac) + b1 * fac;        // :47-49, the part of flux_dn(l+1) that is not flux_dn(l)
+          s_U[l * ng + g] = b1 * (eps - fac) + b0 * fac;              // :56-58
+        } else {
+          const double td = ecckd::exp_fast(minus_sec_sza * tau), tu = ecckd::exp_fast(-2.0 * tau);
+          c_t[j] = td;
+          c_tu[j] = tu;
+          s_D[(l + 1) * ng + g] = td;
+          s_U[l * ng + g] = tu;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- B: the two recurrences, one wave; the rows of a chunk of layers are fetched before its chain of FMAs starts ----
+  if (live && !(dbg & 2)) {
+    // full chunks without a test per layer (a scalar branch per step costs more than the step), then the remainder
+    double dn = SW ? cos_sza * pl[g] : 0.0;
+    double* pD = s_D + g;
+    double* pU = s_U + g;
+    const double* pT = s_T + g;
+    pD[0] = dn;
+    int l = 0;
+    for (; l + K8A_CH <= nlay; l += K8A_CH) {
+      double tt[K8A_CH], ss[K8A_CH];
+#pragma unroll
+      for (int q = 0; q < K8A_CH; ++q) {
+        ss[q] = pD[(l + q + 1) * ng];
+        if constexpr (!SW) tt[q] = pT[(l + q) * ng];
+      }
+#pragma unroll
+      for (int q = 0; q < K8A_CH; ++q) {
+        if constexpr (SW) dn = dn * ss[q]; else dn = dn * tt[q] + ss[q];
+        pD[(l + q + 1) * ng] = dn;
+      }
+    }
+    for (; l < nlay; ++l) {
+      if constexpr (SW) dn = dn * pD[(l + 1) * ng]; else dn = dn * pT[l * ng] + pD[(l + 1) * ng];
+      pD[(l + 1) * ng] = dn;
+    }
+    double up;
+    if constexpr (SW) {
+      const double alb = all_nonpos ? 0.0 : surf_emis[(size_t)col * nband + band_of_g[g]];
+      up = dn * alb;
+    } else {
+      const double es = surf_emis[(size_t)col * nband + band_of_g[g]];
+      up = pl[nlay * ng + g] * es + (1.0 - es) * dn;              // surf_planck = planck_hl(end), optimize_lut.cpp:267
+    }
+    pU[nlay * ng] = up;
+    l = nlay - 1;
+    for (; l - (K8A_CH - 1) >= 0; l -= K8A_CH) {
+      double tt[K8A_CH], ss[K8A_CH];
+#pragma unroll
+      for (int q = 0; q < K8A_CH; ++q) {
+        ss[q] = pU[(l - q) * ng];
+        if constexpr (!SW) tt[q] = pT[(l - q) * ng];
+      }
+#pragma unroll
+      for (int q = 0; q < K8A_CH; ++q) {
+        if constexpr (SW) up = up * ss[q]; else up = up * tt[q] + ss[q];
+        pU[(l - q) * ng] = up;
+      }
+    }
+    for (; l >= 0; --l) {
+      if constexpr (SW) up = up * pU[l * ng]; else up = up * pT[l * ng] + pU[l * ng];
+      pU[l * ng] = up;
+    }
+  }
+  __syncthreads();
+  if (flux_out && in_range) {
+    double* fo = flux_out + (size_t)col * 2 * nhl * ng;
+    for (int i = lgrp; i < nhl; i += nlgrp) {
+      fo[i * ng + g] = s_D[i * ng + g];
+      fo[(nhl + i) * ng + g] = s_U[i * ng + g];
+    }
+  }
+  // ---- C: band sums (calc_cost_function_lw.cpp:171-184), the g points of a band in increasing order ----
+  const double* cv = conv + (size_t)col * nlay;
+  const double* lw = layer_weight + (size_t)col * nlay;
+  const double* hrt = hr_true + (size_t)col * nlay * nband;
+  const double* fdt = fdn_true + (size_t)col * nhl * nband;
+  const double* fut = fup_true + (size_t)col * nhl * nband;
+  if (!(dbg & 4))
+  for (int t = threadIdx.x; t < nhl * nband; t += blockDim.x) {
+    const int i = t / nband, b = t % nband;
+    double sd = 0.0, su = 0.0;
+    const double* rel = rel_flux ? rel_flux + (size_t)col * 2 * nhl * ng : nullptr;
+    for (int q = s_bp[b]; q < s_bp[b + 1]; ++q) {
+      const int gg = s_bg[q];
+      // the relative-to fluxes are subtracted per g point before the band sums (calc_cost_function_lw.cpp:162-165)
+      sd += rel ? s_D[i * ng + gg] - rel[i * ng + gg] : s_D[i * ng + gg];
+      su += rel ? s_U[i * ng + gg] - rel[(nhl + i) * ng + gg] : s_U[i * ng + gg];
+    }
+    s_bdn[t] = sd;
+    s_bup[t] = su;
+  }
+  __syncthreads();
+  // ---- D: cost (:186-229) and its derivative with respect to the band fluxes ----
+  // D1 one thread per (layer, band): heating-rate residual; D2 per layer / half level: the broadband sums, bands in order;
+  // D3 per (half level, band): dJ/d(band flux) gathered from the two layers that touch the level and the boundary / profile
+  // terms - every slot has one writer, no atomics.
+  const double spec_scale = (!SW || broadband_weight > 0.0) ? (1.0 - broadband_weight) / nband : 1.0;   // :209, sw :243
+  const double up_in_hr = SW ? 0.0 : 1.0;                         // shortwave heating rate from the direct beam only (:197)
+  const double hrw2 = hr_weight * hr_weight;
+  double jpart = 0.0;
+  if (!(dbg & 8))
+  for (int t = threadIdx.x; t < nlay * nband; t += blockDim.x) {
+    const int l = t / nband, b = t % nband;
+    const double hrf = cv[l] * (s_bdn[(l + 1) * nband + b] - s_bdn[l * nband + b] -
+                                up_in_hr * (s_bup[(l + 1) * nband + b] - s_bup[l * nband + b]));
+    const double r = hrf - hrt[t];
+    s_r[t] = r;
+    jpart += spec_scale * hrw2 * lw[l] * r * r;
+  }
+  __syncthreads();
+  // weights of the squared residuals of dn / up at half level i: spectral (s) and broadband (b)
+  auto level_weights = [&](int i, double& wd_s, double& wu_s, double& wd_b, double& wu_b) {
+    wd_s = 0.0; wu_s = 0.0; wd_b = 0.0; wu_b = 0.0;
+    if (i == nlay) { wd_s = flux_weight; wd_b = flux_weight; }
+    if (i == 0) {
+      wu_s = SW ? 20.0 * flux_weight : flux_weight;              // calc_cost_function_sw.cpp:214
+      wu_b = (!SW || all_pos) ? flux_weight : 0.0;               // :252
+    }
+    if (i >= 1 && i <= nlay - 1 && flux_profile_weight > 0.0) {
+      const double iw = flux_profile_weight * 0.5 * (lw[i - 1] + lw[i]);
+      wd_s = iw; wu_s = iw; wd_b = iw;
+      wu_b = (!SW || all_pos) ? iw : 0.0;                        // :264
+    }
+  };
+  if (!(dbg & 8))
+  for (int t = threadIdx.x; t < nlay + nhl; t += blockDim.x) {
+    if (t < nlay) {
+      double rsum = 0.0;
+      for (int b = 0; b < nband; ++b) rsum += s_r[t * nband + b];
+      s_rsum[t] = rsum;
+      jpart += broadband_weight * hrw2 * lw[t] * rsum * rsum;
+    } else {
+      const int i = t - nlay;
+      double wd_s, wu_s, wd_b, wu_b, sd = 0.0, su = 0.0;
+      level_weights(i, wd_s, wu_s, wd_b, wu_b);
+      if (wd_s != 0.0 || wu_s != 0.0) {
+        for (int b = 0; b < nband; ++b) {
+          sd += s_bdn[i * nband + b] - fdt[i * nband + b];
+          su += s_bup[i * nband + b] - fut[i * nband + b];
+        }
+        jpart += broadband_weight * (wd_b * sd * sd + wu_b * su * su);
+      }
+      s_sd[i] = sd;
+      s_su[i] = su;
+    }
+  }
+  __syncthreads();
+  {
+    // (at most two rounds: nhl * nband <= 2 * blockDim is not required, the values wait in registers for the barrier)
+    constexpr int MAXR = K8A_MAXR;
+    double gd_r[MAXR], gu_r[MAXR];
+    int nr = 0;
+    for (int t = threadIdx.x; t < nhl * nband && nr < MAXR; t += blockDim.x, ++nr) {
+      const int i = t / nband, b = t % nband;
+      double gd = 0.0, gu = 0.0;
+      if (!(dbg & 8)) {
+      if (i >= 1) {                                               // layer i-1 ends at this level
+        const int l = i - 1;
+        const double dhr = 2.0 * hrw2 * lw[l] * (spec_scale * s_r[l * nband + b] + broadband_weight * s_rsum[l]);
+        gd = dhr * cv[l];
+        if (!SW) gu = -dhr * cv[l];
+      }
+      if (i <= nlay - 1) {                                        // layer i starts at it
+        const double dhr = 2.0 * hrw2 * lw[i] * (spec_scale * s_r[i * nband + b] + broadband_weight * s_rsum[i]);
+        gd += -dhr * cv[i];
+        if (!SW) gu += dhr * cv[i];
+      }
+      double wd_s, wu_s, wd_b, wu_b;
+      level_weights(i, wd_s, wu_s, wd_b, wu_b);
+      if (wd_s != 0.0 || wu_s != 0.0) {
+        const double dd = s_bdn[t] - fdt[t];
+        const double du = s_bup[t] - fut[t];
+        jpart += spec_scale * (wd_s * dd * dd + wu_s * du * du);
+        gd += 2.0 * (spec_scale * wd_s * dd + broadband_weight * wd_b * s_sd[i]);
+        gu += 2.0 * (spec_scale * wu_s * du + broadband_weight * wu_b * s_su[i]);
+      }
+      }
+      gd_r[nr] = gd;
+      gu_r[nr] = gu;
+    }
+    __syncthreads();
+    nr = 0;
+    for (int t = threadIdx.x; t < nhl * nband && nr < MAXR; t += blockDim.x, ++nr) {
+      s_bdn[t] = gd_r[nr];                                        // from here on: dJ/d(band flux dn), dJ/d(band flux up)
+      s_bup[t] = gu_r[nr];
+    }
+  }
+  double* s_gdn = s_bdn;
+  double* s_gup = s_bup;
+  // ---- E: adjoint.  The owners take the forward fluxes at their cells before the rows are reused ----
+  double c_f0[NC], c_f1[NC];      // longwave: dn_l, up_l+1; shortwave: dn_l+1, up_l
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int l = lgrp + j * nlgrp;
+    c_f0[j] = 0.0; c_f1[j] = 0.0;
+    if (in_range && l < nlay) {
+      c_f0[j] = SW ? s_D[(l + 1) * ng + g] : s_D[l * ng + g];
+      c_f1[j] = SW ? s_U[l * ng + g] : s_U[(l + 1) * ng + g];
+    }
+  }
+  double g_dn_surf_extra = 0.0, g_up_toa_extra = 0.0;
+  if (live && sfds && sfut && (SW || spectral_boundary_weight > 0.0)) {
+    // per-g boundary terms: calc_cost_function_lw.cpp:223-229 on the un-banded fluxes; calc_cost_function_sw.cpp:271-274
+    // with per-g (erythemal) weights on the surface direct flux
+    const double reld = rel_flux ? rel_flux[((size_t)col * 2 * nhl + nlay) * ng + g] : 0.0;
+    const double a = (s_D[nlay * ng + g] - reld) - sfds[(size_t)col * ng + g];
+    if (SW) {
+      const double wgt = sfut[(size_t)col * ng + g];
+      jpart += wgt * a * a;
+      g_dn_surf_extra = 2.0 * wgt * a;
+    } else {
+      const double relu = rel_flux ? rel_flux[((size_t)col * 2 * nhl + nhl) * ng + g] : 0.0;
+      const double c = (s_U[g] - relu) - sfut[(size_t)col * ng + g];
+      jpart += spectral_boundary_weight * (a * a + c * c);
+      g_dn_surf_extra = 2.0 * spectral_boundary_weight * a;
+      g_up_toa_extra = 2.0 * spectral_boundary_weight * c;
+    }
+  }
+  __syncthreads();
+  if constexpr (SW) {
+    // the transmittances back into the rows the fluxes occupied
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int l = lgrp + j * nlgrp;
+      if (in_range && l < nlay) {
+        s_D[(l + 1) * ng + g] = c_t[j];
+        s_U[l * ng + g] = c_tu[j];
+      }
+    }
+    __syncthreads();
+  }
+  if (live && !(dbg & 2)) {
+    const int b = band_of_g[g];
+    // u_bar[0] = seed[0], u_bar[l+1] = seed[l+1] + u_bar[l] t_l: row l of s_U becomes the adjoint of up[l]
+    double up_bar = s_gup[b] + g_up_toa_extra;
+    double* pD = s_D + g;
+    double* pU = s_U + g;
+    const double* pT = s_T + g;
+    const double* gU = s_gup + b;
+    const double* gD = s_gdn + b;
+    int l = 0;
+    for (; l + K8A_CH <= nlay; l += K8A_CH) {
+      double tt[K8A_CH], ss[K8A_CH];
+#pragma unroll
+      for (int q = 0; q < K8A_CH; ++q) {
+        tt[q] = SW ? pU[(l + q) * ng] : pT[(l + q) * ng];
+        ss[q] = gU[(l + q + 1) * nband];
+      }
+#pragma unroll
+      for (int q = 0; q < K8A_CH; ++q) {
+        pU[(l + q) * ng] = up_bar;
+        up_bar = up_bar * tt[q] + ss[q];
+      }
+    }
+    for (; l < nlay; ++l) {
+      const double t = SW ? pU[l * ng] : pT[l * ng];
+      pU[l * ng] = up_bar;
+      up_bar = up_bar * t + gU[(l + 1) * nband];
+    }
+    // through the surface condition into dn[nlay]; row l+1 of s_D becomes the adjoint of dn[l+1]
+    const double refl = SW ? (all_nonpos ? 0.0 : surf_emis[(size_t)col * nband + b]) : 1.0 - surf_emis[(size_t)col * nband + b];
+    double dn_bar = gD[nlay * nband] + g_dn_surf_extra + up_bar * refl;
+    l = nlay - 1;
+    for (; l - (K8A_CH - 1) >= 0; l -= K8A_CH) {
+      double tt[K8A_CH], ss[K8A_CH];
+#pragma unroll
+      for (int q = 0; q < K8A_CH; ++q) {
+        tt[q] = SW ? pD[(l - q + 1) * ng] : pT[(l - q) * ng];
+        ss[q] = gD[(l - q) * nband];
+      }
+#pragma unroll
+      for (int q = 0; q < K8A_CH; ++q) {
+        pD[(l - q + 1) * ng] = dn_bar;
+        dn_bar = dn_bar * tt[q] + ss[q];
+      }
+    }
+    for (; l >= 0; --l) {
+      const double t = SW ? pD[(l + 1) * ng] : pT[l * ng];
+      pD[(l + 1) * ng] = dn_bar;
+      dn_bar = dn_bar * t + gD[l * nband];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int l = lgrp + j * nlgrp;
+    if (in_range && l < nlay && !((clamp_mask >> j) & 1u) && !(dbg & 16)) {
+      const double ubar_l = s_U[l * ng + g], dnbar = s_D[(l + 1) * ng + g];
+      double tau_bar;
+      if constexpr (SW) {
+        // up_l = up_l+1 exp(-2 tau_l), dn_l+1 = dn_l exp(-tau_l / mu0)
+        tau_bar = ubar_l * c_f1[j] * (-2.0) + dnbar * c_f0[j] * minus_sec_sza;
+      } else {
+        const double tau = c_tau[j], ex = c_t[j];
+        const double eps = 1.0 - ex;
+        const bool thick = eps > 1.0e-5;
+        const double rtau = thick ? ecckd::div_fast(1.0 / kD, tau) : 0.0;      // 1 / (D tau)
+        const double b0 = pl[l * ng + g], b1 = pl[(l + 1) * ng + g];
+        //   dn_{l+1} = dn_l*(1-eps) + B_l*(eps-fac) + B_{l+1}*fac
+        //   up_l     = up_{l+1}*(1-eps) + B_{l+1}*(eps-fac) + B_l*fac
+        const double t_bar = dnbar * c_f0[j] + ubar_l * c_f1[j];
+        const double a_bar = dnbar * b0 + ubar_l * b1;
+        const double f_bar = dnbar * b1 + ubar_l * b0;
+        const double eps_bar = -t_bar + a_bar;
+        const double fac_bar = f_bar - a_bar;
+        // fac(eps, tau): thick: 1 - eps/(D tau); thin: eps/2   (radiative_transfer_lw.cpp:42-43)
+        const double dfac_deps = thick ? -rtau : 0.5;
+        const double dfac_dtau = thick ? eps * rtau * (kD * rtau) : 0.0;        // eps / (D tau^2)
+        tau_bar = (eps_bar + fac_bar * dfac_deps) * (kD * ex) + fac_bar * dfac_dtau;
+      }
+      dtau[(cell0 + l) * ng + g] = tau_bar;
+    }
+  }
+  jpart += negative_od_penalty * penalty;
+  const double jtot = block_reduce_sum(jpart, s_red);
+  if (threadIdx.x == 0) jcol[col] = jtot;
+}
+
 // K8b + K9: gradient of the state.  One thread per (node, g) of the ACTIVE gases.
 //   grad_k = sum over the cells that reference this node of coef * dtau[cell][g]   (fixed order)
 //   grad_x = grad_k * k + B^-1 (x - x_prior) / sigma_g^2                            (:273-283)
@@ -458,32 +922,51 @@ k_opt_gradient(size_t nnode, int ng, int ngpad, const double* __restrict__ x, co
                const int* __restrict__ gas_dims /*[ngas][4]: nconc, nt, np, node0*/,
                const double* __restrict__ tri /* per gas: c(3*nconc) | t(3*nt) | p(3*np) */,
                const int* __restrict__ tri_off /*[ngas]*/, const double* __restrict__ inv_sigma2 /*[ngas][ng]*/,
-               int have_prior, double* __restrict__ grad, double* __restrict__ jb_part /*[nnode]*/) {
+               int have_prior, double* __restrict__ grad, double* __restrict__ jb_part /*[nnode]*/,
+               const int* __restrict__ node_order /*[gridDim.x]: the node of each block, -1 = none*/) {
   // one block per LUT node; blockDim = ngpad * (reference groups).  The references of a node
   // (cells that interpolate from it) are dealt round-robin to the groups and the group sums are
   // combined in group order: a fixed summation order without atomics.
+  // Which block takes which node is a pure speed choice (node_order, built by ecckd_opt_create): the blocks b, b + 8, ...
+  // share an XCD and walk ONE eighth of the pressure axis in order, so the dJ/dtau rows they gather (cells whose pressure
+  // lies between two neighbouring nodes) stay in that XCD's L2 instead of being fetched by all eight.
   extern __shared__ double s_acc[];  // [groups][ngpad] | [4]
-  const size_t node = blockIdx.x;
+  const int ordered = node_order[blockIdx.x];
+  if (ordered < 0) return;
+  const size_t node = (size_t)ordered;
   const int g = threadIdx.x % ngpad;
-  const int rg = threadIdx.x / ngpad;
+  const int rg = __builtin_amdgcn_readfirstlane(threadIdx.x / ngpad);   // ngpad is a multiple of 64: uniform in a wave
   const int nrg = blockDim.x / ngpad;
   double* s4 = s_acc + (size_t)nrg * ngpad;
   double part = 0.0;
-  if (g < ng) {
-    // four references at a time (independent cell -> dtau loads in flight together), added in reference order
+  {
+    // The references of this group (r = first + rg, + nrg, ...), 64 at a time: every lane fetches ONE (cell, coefficient)
+    // pair, v_readlane hands them round as scalars, and the dJ/dtau rows of a batch of eight references are loaded together -
+    // their latencies overlap instead of following each its own cell-index load.  Products added in reference order.
+    const int lane = threadIdx.x & 63;
     const int r1 = ref_ptr[node + 1];
-    int r = ref_ptr[node] + rg;
-    for (; r + 3 * nrg < r1; r += 4 * nrg) {
-      const int c0 = ref_cell[r], c1 = ref_cell[r + nrg], c2 = ref_cell[r + 2 * nrg], c3 = ref_cell[r + 3 * nrg];
-      const double w0 = ref_coef[r], w1 = ref_coef[r + nrg], w2 = ref_coef[r + 2 * nrg], w3 = ref_coef[r + 3 * nrg];
-      const double d0 = dtau[(size_t)c0 * ng + g], d1 = dtau[(size_t)c1 * ng + g];
-      const double d2 = dtau[(size_t)c2 * ng + g], d3 = dtau[(size_t)c3 * ng + g];
-      part += w0 * d0;
-      part += w1 * d1;
-      part += w2 * d2;
-      part += w3 * d3;
+    const bool active = g < ng;
+    for (int r0 = ref_ptr[node] + rg; r0 < r1; r0 += 64 * nrg) {
+      const int myr = r0 + lane * nrg;
+      const int my_cell = myr < r1 ? ref_cell[myr] : -1;
+      const double my_w = myr < r1 ? ref_coef[myr] : 0.0;
+      const int cnt = min(64, (r1 - r0 + nrg - 1) / nrg);
+      for (int q0 = 0; q0 < cnt; q0 += 8) {
+        int c[8];
+        double w[8], d[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int e = (q0 + q) & 63;
+          c[q] = (q0 + q < cnt) ? __builtin_amdgcn_readlane(my_cell, e) : -1;
+          w[q] = readlane_f64(my_w, e);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = (c[q] >= 0 && active) ? dtau[(size_t)c[q] * ng + g] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (c[q] >= 0) part += w[q] * d[q];
+      }
     }
-    for (; r < r1; r += nrg) part += ref_coef[r] * dtau[(size_t)ref_cell[r] * ng + g];
   }
   s_acc[rg * ngpad + g] = part;
   __syncthreads();
@@ -558,81 +1041,118 @@ k_opt_exp(size_t nx, const double* __restrict__ x, double* __restrict__ k) {
 
 // ---------------------------------------------------------------------------------------
 // Device-resident L-BFGS vector kernels.  All reductions are two-stage with a fixed order:
-// stage 1 writes one partial per block, stage 2 (inside the consumer kernel, or k_vec_finish)
-// sums the partials in index order.  Scalars live in a small device array `sc`.
-constexpr int VEC_BLOCKS = 256;   // partials per reduction
-constexpr int VEC_THREADS = 256;
+// stage 1 writes one partial per block (lanes by shuffle, then the block's waves in order), stage 2 (inside the consumer
+// kernel, or k_lb_finish) sums the partials in index order.
+constexpr int VEC_BLOCKS = 256;    // partials per reduction
+constexpr int VEC_THREADS = 1024;  // one or two elements per thread at nx ~ 3e5: every load of a pass is in flight at once
+constexpr int VEC_WAVES = VEC_THREADS / 64;
+constexpr int FIN_THREADS = 256;   // k_lb_finish
 
-__device__ __forceinline__ double sum_partials(const double* __restrict__ part, double* s_tmp) {
-  // every block reduces the same VEC_BLOCKS partials in the same order
-  const int t = threadIdx.x;
-  double v = (t < VEC_BLOCKS) ? part[t] : 0.0;
+__device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// the VEC_BLOCKS partials of one reduction, summed by every caller in the same order (blockDim >= 256)
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, double* s_tmp /*[4]*/) {
+  const int t = threadIdx.x;
+  double v = (t < VEC_BLOCKS) ? part[t] : 0.0;
+  v = wave_sum(v);
   __syncthreads();
-  if ((t & 63) == 0) s_tmp[t >> 6] = v;
+  if ((t & 63) == 0 && t < VEC_BLOCKS) s_tmp[t >> 6] = v;
   __syncthreads();
   return ((s_tmp[0] + s_tmp[1]) + s_tmp[2]) + s_tmp[3];
 }
 
-__device__ __forceinline__ void write_partial(double v, double* __restrict__ part, double* s_tmp) {
+// NACC per-thread accumulators -> one partial per (accumulator, block): waves by shuffle, the block's waves in order
+template <int NACC>
+__device__ __forceinline__ void write_partials(const double (&acc)[NACC], int nused, double* __restrict__ part, double* s_all /*[NACC][VEC_WAVES]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  const int t = threadIdx.x;
+  for (int k = 0; k < NACC; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) s_all[k * VEC_WAVES + wave] = v;
+  }
   __syncthreads();
-  if ((t & 63) == 0) s_tmp[t >> 6] = v;
-  __syncthreads();
-  if (t == 0) part[blockIdx.x] = ((s_tmp[0] + s_tmp[1]) + s_tmp[2]) + s_tmp[3];
+  if ((int)threadIdx.x < nused) {
+    double t = 0.0;
+    for (int w = 0; w < VEC_WAVES; ++w) t += s_all[threadIdx.x * VEC_WAVES + w];
+    part[(size_t)threadIdx.x * VEC_BLOCKS + blockIdx.x] = t;
+  }
 }
 
 // ---- L-BFGS on the device, compact representation (Byrd, Nocedal & Schnabel 1994) -----------------------------
 // With S = [s_0 .. s_{m-1}], Y = [y_0 .. y_{m-1}] (oldest first), R = upper triangle of S^T Y, D = diag(s_i.y_i):
 //   H g = gamma g + S top - gamma Y u,   u = R^-1 (S^T g),   top = R^-T ((D + gamma Y^T Y) u - gamma Y^T g)
-// which is the two-loop recursion in matrix form.  All 2m dot products with the gradient come from ONE pass over
-// S and Y, the m x m solves run on the host, the direction is ONE more pass: four launches per iteration instead of
-// ~30, and two host synchronisations (the scalars of the direction, the cost of the trial point).
+// which is the two-loop recursion in matrix form.  Per iteration: ONE pass that stores the new curvature pair and takes
+// every dot product the update needs (k_lb_update), the m x m solves on the host, the direction in one more pass
+// (k_lb_direction), the trial point and its coefficients exp(x) (k_lb_step): three vector launches and two waits of the host
+// on pinned result slots (the dots; the cost of the trial point).
 constexpr int LB_M = 6;
 struct LbSlots { int n; int slot[LB_M]; };                       // ring slots of the pairs, oldest first
 struct LbCoef { double gamma; double cs[LB_M]; double cy[LB_M]; };
+constexpr int LB_NPART = 3 + 5 * LB_M;
 
-// q = projected gradient (0 at active bounds and at pinned elements); partials [0] |q|^2, [1+a] S_a.q, [1+LB_M+a] Y_a.q
+// The accepted step x -> xn, g -> gn (new_slot >= 0): curvature pair s = xn - x, y = gn - g into its ring slot, and its dots
+// with the pairs that stay (keep): partials [1+2M] s.y, [2+2M] y.y, [3+2M+a] s.Y_a, [3+3M+a] S_a.y, [3+4M+a] y.Y_a.
+// Then, at the new point: q = projected gradient (0 at active bounds and at pinned elements) and partials [0] |q|^2,
+// [1+a] S_a.q, [1+M+a] Y_a.q for the pairs that stay and, as the newest (a = keep.n), the pair just stored.
+// new_slot < 0 (first iteration): only q and |q|^2 at (xn, gn).
 __global__ void __launch_bounds__(VEC_THREADS)
-k_lb_project_dots(size_t n, LbSlots sl, const double* __restrict__ x, const double* __restrict__ g,
-                  const double* __restrict__ xmin, const double* __restrict__ xmax, double* __restrict__ q,
-                  const double* __restrict__ S, const double* __restrict__ Y, double* __restrict__ part) {
-  __shared__ double s_tmp[4];
-  double acc = 0.0, as[LB_M], ay[LB_M];
+k_lb_update(size_t n, LbSlots keep, int new_slot, const double* __restrict__ x, const double* __restrict__ xn,
+            const double* __restrict__ g, const double* __restrict__ gn, const double* __restrict__ xmin,
+            const double* __restrict__ xmax, double* __restrict__ q, double* __restrict__ S, double* __restrict__ Y,
+            double* __restrict__ part) {
+  __shared__ double s_all[LB_NPART * VEC_WAVES];
+  double acc[LB_NPART];
 #pragma unroll
-  for (int a = 0; a < LB_M; ++a) { as[a] = 0.0; ay[a] = 0.0; }
+  for (int k = 0; k < LB_NPART; ++k) acc[k] = 0.0;
+  const bool pair = new_slot >= 0;
   for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
-    double gi = g[i];
-    if (xmin && ((x[i] <= xmin[i] && gi > 0.0) || (x[i] >= xmax[i] && gi < 0.0))) gi = 0.0;
-    if (!(x[i] > MIN_X)) gi = 0.0;
+    const double xi = xn[i];
+    double gi = gn[i];
+    double si = 0.0, yi = 0.0;
+    if (pair) { si = xi - x[i]; yi = gi - g[i]; }
+    if (xmin && ((xi <= xmin[i] && gi > 0.0) || (xi >= xmax[i] && gi < 0.0))) gi = 0.0;
+    if (!(xi > MIN_X)) gi = 0.0;
     q[i] = gi;
-    acc += gi * gi;
+    acc[0] += gi * gi;
+    if (pair) {
+      acc[1 + 2 * LB_M] += si * yi;
+      acc[2 + 2 * LB_M] += yi * yi;
+    }
 #pragma unroll
     for (int a = 0; a < LB_M; ++a)
-      if (a < sl.n) {
-        as[a] += S[(size_t)sl.slot[a] * n + i] * gi;
-        ay[a] += Y[(size_t)sl.slot[a] * n + i] * gi;
+      if (a < keep.n) {
+        const double sa = S[(size_t)keep.slot[a] * n + i], ya = Y[(size_t)keep.slot[a] * n + i];
+        acc[1 + a] += sa * gi;
+        acc[1 + LB_M + a] += ya * gi;
+        if (pair) {
+          acc[3 + 2 * LB_M + a] += si * ya;
+          acc[3 + 3 * LB_M + a] += sa * yi;
+          acc[3 + 4 * LB_M + a] += yi * ya;
+        }
       }
-  }
-  write_partial(acc, part, s_tmp);
+    if (pair) {
+      // the new pair is the newest of this iteration's direction: position keep.n (always < LB_M)
 #pragma unroll
-  for (int a = 0; a < LB_M; ++a)
-    if (a < sl.n) {
-      write_partial(as[a], part + (size_t)(1 + a) * VEC_BLOCKS, s_tmp);
-      write_partial(ay[a], part + (size_t)(1 + LB_M + a) * VEC_BLOCKS, s_tmp);
+      for (int a = 0; a < LB_M; ++a)
+        if (a == keep.n) { acc[1 + a] += si * gi; acc[1 + LB_M + a] += yi * gi; }
+      S[(size_t)new_slot * n + i] = si;     // the slot being written is never among the pairs that stay
+      Y[(size_t)new_slot * n + i] = yi;
     }
+  }
+  write_partials<LB_NPART>(acc, LB_NPART, part, s_all);
 }
 
 // d = -gamma q - sum cs_a S_a + sum cy_a Y_a; partials of d.g and d.d
 __global__ void __launch_bounds__(VEC_THREADS)
 k_lb_direction(size_t n, LbSlots sl, LbCoef cf, const double* __restrict__ q, const double* __restrict__ S,
                const double* __restrict__ Y, const double* __restrict__ g, double* __restrict__ d,
-               double* __restrict__ part_dg, double* __restrict__ part_dd) {
-  __shared__ double s_tmp[4];
-  double a = 0.0, b = 0.0;
+               double* __restrict__ part_dg /* part_dd follows: [2][VEC_BLOCKS] */) {
+  __shared__ double s_all[2 * VEC_WAVES];
+  double acc[2] = {0.0, 0.0};
   for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
     double di = -cf.gamma * q[i];
 #pragma unroll
@@ -642,21 +1162,21 @@ k_lb_direction(size_t n, LbSlots sl, LbCoef cf, const double* __restrict__ q, co
     // count a decrease that the clamped trial point cannot deliver
     if (q[i] == 0.0 && g[i] != 0.0) di = 0.0;
     d[i] = di;
-    a += di * g[i];
-    b += di * di;
+    acc[0] += di * g[i];
+    acc[1] += di * di;
   }
-  write_partial(a, part_dg, s_tmp);
-  write_partial(b, part_dd, s_tmp);
+  write_partials<2>(acc, 2, part_dg, s_all);
 }
 
-// xn = clamp(x + step*d), pinned elements stay.  step < 0: chosen here from |d| (every block reduces the same partials
-// in the same order): first iteration min(1, 1/|d|), later 1, never longer than max_step (solve_adept.cpp:331);
-// out[0] = step, out[1] = d.d, out[2] = d.g
+// xn = clamp(x + step*d), pinned elements stay; kn = exp(xn), the coefficients the cost function starts from (0 where pinned,
+// solve_adept.cpp:242-249).  step < 0: chosen here from |d| (every block reduces the same partials in the same order):
+// first iteration min(1, 1/|d|), later 1, never longer than max_step (solve_adept.cpp:331); out[0] = step, out[1] = d.d,
+// out[2] = d.g (pinned host slots)
 __global__ void __launch_bounds__(VEC_THREADS)
 k_lb_step(size_t n, double step, int first, double max_step, const double* __restrict__ part_dg,
           const double* __restrict__ part_dd, const double* __restrict__ x, const double* __restrict__ d,
           const double* __restrict__ xmin, const double* __restrict__ xmax, double* __restrict__ xn,
-          double* __restrict__ out) {
+          double* __restrict__ kn, double* __restrict__ out) {
   __shared__ double s_tmp[4];
   if (step < 0.0) {
     const double dd = sum_partials(part_dd, s_tmp);
@@ -671,54 +1191,49 @@ k_lb_step(size_t n, double step, int first, double max_step, const double* __res
   for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
     double v = x[i] + step * d[i];
     if (xmin) v = fmin(fmax(v, xmin[i]), xmax[i]);
-    if (!(x[i] > MIN_X)) v = x[i];
+    const bool free_el = x[i] > MIN_X;
+    if (!free_el) v = x[i];
     xn[i] = v;
+    kn[i] = free_el ? exp(v) : 0.0;
   }
 }
 
-// curvature pair s = xn - x, y = gn - g into its ring slot; partials [0] s.y, [1] y.y,
-// [2+a] s.Y_a, [2+LB_M+a] S_a.y, [2+2 LB_M+a] y.Y_a for the pairs that stay
-__global__ void __launch_bounds__(VEC_THREADS)
-k_lb_pair_dots(size_t n, LbSlots sl, int new_slot, const double* __restrict__ x, const double* __restrict__ xn,
-               const double* __restrict__ g, const double* __restrict__ gn, double* __restrict__ S,
-               double* __restrict__ Y, double* __restrict__ part) {
-  __shared__ double s_tmp[4];
-  double sy = 0.0, yy = 0.0, a1[LB_M], a2[LB_M], a3[LB_M];
-#pragma unroll
-  for (int a = 0; a < LB_M; ++a) { a1[a] = 0.0; a2[a] = 0.0; a3[a] = 0.0; }
-  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
-    const double si = xn[i] - x[i], yi = gn[i] - g[i];
-    sy += si * yi;
-    yy += yi * yi;
-#pragma unroll
-    for (int a = 0; a < LB_M; ++a)
-      if (a < sl.n) {
-        const double sa = S[(size_t)sl.slot[a] * n + i], ya = Y[(size_t)sl.slot[a] * n + i];
-        a1[a] += si * ya;
-        a2[a] += sa * yi;
-        a3[a] += yi * ya;
-      }
-    S[(size_t)new_slot * n + i] = si;     // the slot being written is never among the pairs that stay
-    Y[(size_t)new_slot * n + i] = yi;
-  }
-  write_partial(sy, part, s_tmp);
-  write_partial(yy, part + VEC_BLOCKS, s_tmp);
-#pragma unroll
-  for (int a = 0; a < LB_M; ++a)
-    if (a < sl.n) {
-      write_partial(a1[a], part + (size_t)(2 + a) * VEC_BLOCKS, s_tmp);
-      write_partial(a2[a], part + (size_t)(2 + LB_M + a) * VEC_BLOCKS, s_tmp);
-      write_partial(a3[a], part + (size_t)(2 + 2 * LB_M + a) * VEC_BLOCKS, s_tmp);
-    }
-}
-
-// out[k] = sum of partial array k: one block per array
-__global__ void __launch_bounds__(VEC_THREADS)
+// out[k] = sum of partial array k: one block per array.  `out` is pinned, host-coherent memory: the host watches the slots
+// (no copy, no stream synchronisation; see wait_slots)
+__global__ void __launch_bounds__(FIN_THREADS)
 k_lb_finish(const double* __restrict__ part, double* __restrict__ out) {
   __shared__ double s_tmp[4];
   const int k = blockIdx.x;
   const double v = sum_partials(part + (size_t)k * VEC_BLOCKS, s_tmp);
   if (threadIdx.x == 0) out[k] = v;
+}
+
+// The cost of an evaluation: the profiles' costs, then the prior's node terms, each summed in a fixed order (thread t takes
+// the elements t, t + 256, ...; the block combines in thread order), delivered to the host's slot and, for the profile-sharded
+// all-reduce, into the slot behind the gradient.
+__global__ void __launch_bounds__(256)
+k_opt_sum_cost(const double* __restrict__ jcol, size_t ncol, const double* __restrict__ jb, size_t nnode, int prior,
+               double* __restrict__ h_out /*pinned*/, double* __restrict__ d_out /*or NULL*/) {
+  __shared__ double s_tmp[4];
+  double a = 0.0, b = 0.0;
+  for (size_t i = threadIdx.x; i < ncol; i += 256) a += jcol[i];
+  if (prior) for (size_t i = threadIdx.x; i < nnode; i += 256) b += jb[i];
+  double r[2] = {a, b};
+  double tot[2];
+  for (int k = 0; k < 2; ++k) {
+    double v = r[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    tot[k] = ((s_tmp[0] + s_tmp[1]) + s_tmp[2]) + s_tmp[3];
+  }
+  if (threadIdx.x == 0) {
+    const double J = tot[0] + tot[1];
+    if (d_out) *d_out = J;
+    *h_out = J;
+  }
 }
 
 }  // namespace
@@ -744,6 +1259,9 @@ struct ecckd_opt {
   double *d_k = nullptr, *d_x = nullptr, *d_xprior = nullptr, *d_grad = nullptr, *d_dtau = nullptr;
   double *d_jcol = nullptr, *d_jb = nullptr;
   int* d_ent_idx = nullptr; double* d_ent_coef = nullptr; int* d_band = nullptr;
+  int *d_band_ptr = nullptr, *d_band_g = nullptr;   // the g points of each band in increasing order (CSR)
+  int* d_node_order = nullptr;                      // K8b: block -> node (XCD-aware), -1 = idle block
+  unsigned gradient_grid = 0;
   double *d_planck = nullptr, *d_semis = nullptr, *d_conv = nullptr, *d_lw = nullptr;
   double *d_hr = nullptr, *d_fdn = nullptr, *d_fup = nullptr, *d_sfds = nullptr, *d_sfut = nullptr;
   int *d_ref_ptr = nullptr, *d_ref_cell = nullptr; double* d_ref_coef = nullptr;
@@ -753,10 +1271,11 @@ struct ecckd_opt {
   unsigned grad_blocks = 0;
   // pinned host staging: per-profile costs, per-node prior terms, L-BFGS scalars (pageable read-backs cost
   // ~30 us each through the runtime's staging path)
+  // pinned, host-coherent result slots that the kernels write and the host watches: [0, 64) L-BFGS dot products, [64, 67)
+  // step / d.d / d.g, [70] the cost of an evaluation
   double* h_pin = nullptr;
-  double* h_jcol = nullptr;   // [ncol]
-  double* h_jb = nullptr;     // [nnode_active]
-  double* h_rb = nullptr;     // [64] + [4]
+  double* d_pin = nullptr;    // the same memory as the device sees it
+  double* h_rb = nullptr;     // = h_pin
   // device L-BFGS workspace (allocated by ecckd_opt_minimize)
   double *d_xmin = nullptr, *d_xmax = nullptr, *d_xn = nullptr, *d_gn = nullptr, *d_dir = nullptr, *d_q = nullptr;
   double *d_S = nullptr, *d_Y = nullptr, *d_part = nullptr, *d_sc = nullptr;
@@ -791,7 +1310,7 @@ void opt_free(ecckd_opt* o) {
   if (!o) return;
   if (o->ctx) (void)hipStreamSynchronize(o->ctx->stream);
   void* ptrs[] = {o->d_k, o->d_x, o->d_xprior, o->d_grad, o->d_dtau, o->d_jcol, o->d_jb, o->d_ent_idx, o->d_ent_coef,
-                  o->d_band, o->d_planck, o->d_semis, o->d_conv, o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds,
+                  o->d_band, o->d_band_ptr, o->d_band_g, o->d_node_order, o->d_planck, o->d_semis, o->d_conv, o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds,
                   o->d_sfut, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_node_gas, o->d_node_ic, o->d_node_it,
                   o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2, o->d_od_out, o->d_flux_out, o->d_xmin, o->d_xmax,
                   o->d_xn, o->d_gn, o->d_dir, o->d_q, o->d_S, o->d_Y, o->d_part, o->d_sc, o->d_mu0, o->d_rel};
@@ -1157,11 +1676,48 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
       }
   }
 
+  // ---- K8b: which block takes which node.  The pressure axis is cut into 8 contiguous pieces of about equal numbers of
+  // references; piece x is walked, pressure index ascending, by the blocks x, x + 8, x + 16, ... (one XCD, in dispatch order)
+  std::vector<int> node_order;
+  {
+    constexpr int NX = 8;
+    std::vector<long long> refs_of_ip(np, 0);
+    for (size_t nd = 0; nd < o->nnode_active; ++nd) refs_of_ip[node_ip[nd]] += ref_ptr[nd + 1] - ref_ptr[nd] + 1;
+    long long total = 0;
+    for (long long v : refs_of_ip) total += v;
+    std::vector<int> piece_of_ip(np, 0);
+    long long run = 0;
+    for (int ip = 0; ip < np; ++ip) {
+      piece_of_ip[ip] = (int)std::min<long long>(NX - 1, run * NX / std::max<long long>(total, 1));
+      run += refs_of_ip[ip];
+    }
+    std::vector<std::vector<int>> list(NX);
+    for (int ip = 0; ip < np; ++ip)
+      for (size_t nd = 0; nd < o->nnode_active; ++nd)
+        if (node_ip[nd] == ip) list[piece_of_ip[ip]].push_back((int)nd);
+    size_t longest = 0;
+    for (const auto& l : list) longest = std::max(longest, l.size());
+    node_order.assign(longest * NX, -1);
+    for (int x = 0; x < NX; ++x)
+      for (size_t j = 0; j < list[x].size(); ++j) node_order[j * NX + x] = list[x][j];
+    if (const char* e = std::getenv("ECCKD_K8B_PLAIN_ORDER")) if (e[0] == '1') {
+      node_order.resize(o->nnode_active);
+      for (size_t nd = 0; nd < o->nnode_active; ++nd) node_order[nd] = (int)nd;
+    }
+    o->gradient_grid = (unsigned)node_order.size();
+  }
+
   std::vector<int> band(m->iband_per_g, m->iband_per_g + ng);
   int rc = ECCKD_OK;
 #define UP(dst, vec) do { rc = upload(ctx, &o->dst, vec); if (rc) { opt_free(o); return rc; } } while (0)
   UP(d_k, o->h_k0);
-  UP(d_ent_idx, ent_idx); UP(d_ent_coef, ent_coef); UP(d_band, band);
+  std::vector<int> band_ptr(nband + 1, 0), band_g;
+  for (int b = 0; b < nband; ++b) {
+    for (int g = 0; g < ng; ++g) if (band[g] == b) band_g.push_back(g);
+    band_ptr[b + 1] = (int)band_g.size();
+  }
+  band_g.resize(ng, 0);                     // (a g point with a negative band number belongs to no band)
+  UP(d_ent_idx, ent_idx); UP(d_ent_coef, ent_coef); UP(d_band, band); UP(d_band_ptr, band_ptr); UP(d_band_g, band_g);
   UP(d_planck, planck); UP(d_semis, semis); UP(d_conv, conv); UP(d_lw, lwv);
   UP(d_hr, hr); UP(d_fdn, fdn); UP(d_fup, fup);
   if (any_boundary) { UP(d_sfds, sfds); UP(d_sfut, sfut); }
@@ -1184,7 +1740,7 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
       UP(d_rel, rel);
     }
   }
-  UP(d_ref_ptr, ref_ptr); UP(d_ref_cell, ref_cell); UP(d_ref_coef, ref_coef);
+  UP(d_ref_ptr, ref_ptr); UP(d_ref_cell, ref_cell); UP(d_ref_coef, ref_coef); UP(d_node_order, node_order);
   UP(d_node_gas, node_gas); UP(d_node_ic, node_ic); UP(d_node_it, node_it); UP(d_node_ip, node_ip);
   UP(d_gas_dims, gas_dims); UP(d_tri, tri); UP(d_tri_off, tri_off); UP(d_inv_sigma2, inv_sigma2);
 #undef UP
@@ -1196,10 +1752,9 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
     opt_free(o);
     return ecckd::fail(ECCKD_OUT_OF_MEMORY, "ecckd_opt_create: device allocation failed");
   }
-  ECCKD_HIP_CHECK(hipHostMalloc((void**)&o->h_pin, (ncol + o->nnode_active + 72) * sizeof(double), hipHostMallocDefault));
-  o->h_jcol = o->h_pin;
-  o->h_jb = o->h_pin + ncol;
-  o->h_rb = o->h_jb + o->nnode_active;
+  ECCKD_HIP_CHECK(hipHostMalloc((void**)&o->h_pin, 80 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+  ECCKD_HIP_CHECK(hipHostGetDevicePointer((void**)&o->d_pin, o->h_pin, 0));
+  o->h_rb = o->h_pin;
   // x_prior = ln k0 (MIN_X where k0 <= 0), solve_adept.cpp:335-341
   std::vector<double> xp(o->nx);
   for (size_t e = 0; e < o->nx; ++e) xp[e] = o->h_k0[e] > 0.0 ? std::log(o->h_k0[e]) : MIN_X;
@@ -1273,11 +1828,86 @@ int ecckd_opt_initial_state(ecckd_opt* o, double* h_x, double* h_x_min, double* 
 
 // CkdOptimizable::calc_cost_function_gradient (solve_adept.cpp:240-292).
 // cost and gradient at the DEVICE state d_x -> d_grad; J on the host (one stream sync).
+// Results the host needs at once (the cost of a trial point, the dot products of the L-BFGS update) arrive in pinned,
+// host-coherent slots written by the last kernel that produces them; the host marks the slots as pending and watches them
+// instead of queueing a copy and synchronising the stream - two waits per iteration, each a PCIe write away from the kernel's
+// end (the same scheme as the interval errors of find_g.hip).  kOptPending: a NaN payload no arithmetic produces.
+constexpr unsigned long long kOptPending = 0x7ff4dead0b5e55edULL;
+
+static void opt_mark_pending(double* h_slots, int count) {
+  volatile unsigned long long* s = reinterpret_cast<volatile unsigned long long*>(h_slots);
+  for (int k = 0; k < count; ++k) s[k] = kOptPending;
+  std::atomic_thread_fence(std::memory_order_release);
+}
+
+static int opt_wait_slots(ecckd_ctx* ctx, const double* h_slots, int count) {
+  static const bool no_poll = std::getenv("ECCKD_NO_POLL") != nullptr;   // A/B knob: wait through the runtime
+  const volatile unsigned long long* s = reinterpret_cast<const volatile unsigned long long*>(h_slots);
+  auto all_there = [&] {
+    for (int k = 0; k < count; ++k)
+      if (s[k] == kOptPending) return false;
+    return true;
+  };
+  if (no_poll) {
+    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return all_there() ? ECCKD_OK : ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION, "ecckd_opt: results were not delivered by the device");
+  }
+  for (unsigned spins = 1;; ++spins) {
+    if (all_there()) break;
+    if ((spins & 0x3fff) == 0) {
+      const hipError_t q = hipStreamQuery(ctx->stream);       // drained (or dead) without delivering?
+      if (q == hipSuccess) {
+        if (all_there()) break;
+        return ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION, "ecckd_opt: results were not delivered by the device");
+      }
+      if (q != hipErrorNotReady)
+        return ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION, "ecckd_opt: device failure while waiting for results: %s", hipGetErrorString(q));
+    }
+    _mm_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return ECCKD_OK;
+}
+
 static int opt_launch_forward(ecckd_opt* o) {
   ecckd_ctx* ctx = o->ctx;
   const int nlay = o->nlay, nhl = nlay + 1, ng = o->ng, nband = o->nband;
   const int ngpad = (ng + 63) / 64 * 64;
-  static const int k8a_threads = [] { const char* e = std::getenv("ECCKD_K8A_THREADS"); const int v = e ? std::atoi(e) : 0; return v >= 64 && v <= 1024 ? v : 1024; }();
+  static const int env_threads = [] { const char* e = std::getenv("ECCKD_K8A_THREADS"); const int v = e ? std::atoi(e) : 0; return v >= 64 && v <= 1024 ? v : 0; }();
+  const char* env_dbg = std::getenv("ECCKD_K8A_DEBUG");
+  const int dbg = env_dbg ? std::atoi(env_dbg) : 0;
+  const char* env_generic = std::getenv("ECCKD_K8A_GENERIC");       // read at every call: the tests switch between the two kernels
+  const bool force_generic = env_generic && env_generic[0] == '1';
+  // the cell-parallel kernel: longwave 1 024 threads (16 layer groups at ng = 64, one block per CU), shortwave 512 (8 groups,
+  // 79 KB of LDS: two blocks per CU); up to 8 cells per thread, else the general kernel
+  {
+    const int threads_c = env_threads ? env_threads : (o->do_sw ? 512 : 1024);
+    const int lgroups = std::max(1, threads_c / ngpad);
+    const int nc = (nlay + lgroups - 1) / lgroups;
+    const size_t lds = ((o->do_sw ? (size_t)0 : (size_t)nlay * ng) + 2 * (size_t)nhl * ng + 2 * (size_t)nhl * nband + (size_t)nlay * nband +
+                        nlay + 2 * (size_t)nhl + 16) * sizeof(double) + ((size_t)nband + 1 + ng) * sizeof(int);
+    if (!force_generic && nc <= 8 && lds <= 160 * 1024 && ngpad * lgroups <= 1024 && nhl * nband <= K8A_MAXR * ngpad * lgroups) {
+      const int threads = ngpad * lgroups;
+#define ECCKD_K8A_CELLS(NC_, SW_)                                                                                                   \
+      do {                                                                                                                            \
+        ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_opt_forward_adjoint_cells<NC_, SW_>),                  \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                              \
+        hipLaunchKernelGGL((k_opt_forward_adjoint_cells<NC_, SW_>), dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream,       \
+                           o->d_mu0, o->eval_ray_ent, o->eval_keep_negative, o->d_rel, nlay, ng, ngpad, nband, o->nent, o->d_k,     \
+                           o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_band_ptr, o->d_band_g, o->d_planck, o->d_semis, o->d_conv, \
+                           o->d_lw, o->d_hr, o->d_fdn,                                                                               \
+                           o->d_fup, o->d_sfds, o->d_sfut, o->cfg.flux_weight, o->cfg.flux_profile_weight,                          \
+                           o->cfg.broadband_weight, o->cfg.spectral_boundary_weight, o->cfg.negative_od_penalty, o->d_dtau,         \
+                           o->d_jcol, o->d_od_out, o->d_flux_out, dbg);                                                             \
+      } while (0)
+      if (o->do_sw) { if (nc <= 4) ECCKD_K8A_CELLS(4, true); else ECCKD_K8A_CELLS(8, true); }
+      else { if (nc <= 4) ECCKD_K8A_CELLS(4, false); else ECCKD_K8A_CELLS(8, false); }
+#undef ECCKD_K8A_CELLS
+      ECCKD_HIP_CHECK(hipGetLastError());
+      return ECCKD_OK;
+    }
+  }
+  const int k8a_threads = env_threads ? env_threads : 1024;
   const int lgroups = std::max(1, k8a_threads / ngpad);
   const int threads = ngpad * lgroups;
   const size_t lds = ((size_t)nlay * ng + 2 * (size_t)nhl * ng + 4 * (size_t)nhl * nband + 16) * sizeof(double) +
@@ -1294,7 +1924,7 @@ static int opt_launch_forward(ecckd_opt* o) {
   return ECCKD_OK;
 }
 
-static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, double* J) {
+static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, double* J, bool k_ready = false) {
   ecckd_ctx* ctx = o->ctx;
   if (o->eval_fn && o->d_od_out == nullptr) {
     // the caller's cost function and gradient in place of the device's: the minimizer itself is unchanged
@@ -1311,7 +1941,8 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
   }
   const bool reduce = o->reduce_fn != nullptr && o->d_od_out == nullptr;   // not for the diagnostic forward pass
   const bool prior = o->have_prior && (!reduce || o->add_prior);
-  hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, d_x, o->d_k);
+  if (!k_ready)     // (the minimizer's step kernel leaves exp(x) of its trial point in d_k)
+    hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, d_x, o->d_k);
   const int ng = o->ng;
   const int ngpad = (ng + 63) / 64 * 64;
   const int lgroups = std::max(1, 256 / ngpad);
@@ -1320,36 +1951,34 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
   if (timed) ECCKD_HIP_CHECK(hipEventRecord(o->tev[0], ctx->stream));
   ECCKD_CHECK(opt_launch_forward(o));
   if (timed) ECCKD_HIP_CHECK(hipEventRecord(o->tev[1], ctx->stream));
-  hipLaunchKernelGGL(k_opt_gradient, dim3((unsigned)o->nnode_active), dim3(threads),
+  hipLaunchKernelGGL(k_opt_gradient, dim3(o->gradient_grid), dim3(threads),
                      ((size_t)lgroups * ngpad + 16) * sizeof(double), ctx->stream, o->nnode_active, ng, ngpad, d_x, o->d_xprior,
                      o->d_k, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_dtau, o->d_node_gas, o->d_node_ic,
                      o->d_node_it, o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2,
-                     prior ? 1 : 0, d_grad, o->d_jb);
+                     prior ? 1 : 0, d_grad, o->d_jb, o->d_node_order);
   ECCKD_HIP_CHECK(hipGetLastError());
   if (timed) ECCKD_HIP_CHECK(hipEventRecord(o->tev[2], ctx->stream));
-  ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jcol, o->d_jcol, o->ncol * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  ECCKD_HIP_CHECK(hipMemcpyAsync(o->h_jb, o->d_jb, o->nnode_active * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  // the cost: profiles, then the prior's node terms, summed on the device in a fixed order and delivered to the host's slot
+  // (and, for the profile-sharded all-reduce, into the slot behind the gradient: ONE collective of nx + 1 doubles)
+  double* h_cost = o->h_pin + 70;
+  opt_mark_pending(h_cost, 1);
+  hipLaunchKernelGGL(k_opt_sum_cost, dim3(1), dim3(256), 0, ctx->stream, o->d_jcol, o->ncol, o->d_jb, o->nnode_active, prior ? 1 : 0,
+                     o->d_pin + 70, reduce ? d_grad + o->nx : nullptr);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  ECCKD_CHECK(opt_wait_slots(ctx, h_cost, 1));
   if (timed) {
     // "radiative transfer": look-up, penalty, two sweeps, cost and their adjoint; "a-priori": the gradient kernel, which
     // gathers the adjoint back onto the coefficients and adds the prior term (the reference times the prior alone there)
     float ms = 0.f;
+    ECCKD_HIP_CHECK(hipEventSynchronize(o->tev[2]));
     ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, o->tev[0], o->tev[1]));
     o->t_rt += 1e-3 * ms;
     ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, o->tev[1], o->tev[2]));
     o->t_prior += 1e-3 * ms;
   }
-  double j = 0.0;
-  for (size_t c = 0; c < o->ncol; ++c) j += o->h_jcol[c];  // scene/profile order, as the reference accumulates (:157)
-  double jb = 0.0;
-  if (prior)
-    for (size_t c = 0; c < o->nnode_active; ++c) jb += o->h_jb[c];
-  *J = j + jb;
+  *J = *h_cost;
   if (reduce) {
-    // the cost rides in the slot behind the gradient: ONE collective of nx + 1 doubles per evaluation
-    double* slot = o->h_rb + 70;
-    *slot = *J;
-    ECCKD_HIP_CHECK(hipMemcpyAsync(d_grad + o->nx, slot, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    double* slot = o->h_pin + 71;
     ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const int rc = o->reduce_fn(d_grad, o->nx + 1, (void*)ctx->stream, o->reduce_user);
     if (rc != 0) return ecckd::fail(ECCKD_PROCESSING_ERROR, "ecckd_opt: the all-reduce callback failed (%d)", rc);
@@ -1445,10 +2074,10 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
     ECCKD_HIP_CHECK(hipMalloc((void**)p, cnt * sizeof(double)));
     return ECCKD_OK;
   };
-  constexpr int NPART = 3 + 5 * M;   // project/dots: 1 + 2M | pair: 2 + 3M
+  constexpr int NPART = LB_NPART;   // update: |q|^2, S.q, Y.q (1 + 2M) | pair dots (2 + 3M)
   ECCKD_CHECK(dalloc(&o->d_xn, n)); ECCKD_CHECK(dalloc(&o->d_gn, n + 1)); ECCKD_CHECK(dalloc(&o->d_dir, n));
   ECCKD_CHECK(dalloc(&o->d_q, n)); ECCKD_CHECK(dalloc(&o->d_S, (size_t)M * n)); ECCKD_CHECK(dalloc(&o->d_Y, (size_t)M * n));
-  ECCKD_CHECK(dalloc(&o->d_part, (size_t)(NPART + 2) * VEC_BLOCKS)); ECCKD_CHECK(dalloc(&o->d_sc, 64));
+  ECCKD_CHECK(dalloc(&o->d_part, (size_t)(NPART + 2) * VEC_BLOCKS));
   if (bounded) {
     ECCKD_CHECK(dalloc(&o->d_xmin, n)); ECCKD_CHECK(dalloc(&o->d_xmax, n));
     ECCKD_HIP_CHECK(hipMemcpyAsync(o->d_xmin, xmin.data(), n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1458,13 +2087,12 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   const double* bmin = bounded ? o->d_xmin : nullptr;
   const double* bmax = bounded ? o->d_xmax : nullptr;
   double* x = o->d_x; double* g = o->d_grad; double* xn = o->d_xn; double* gn = o->d_gn;
-  double* part_a = o->d_part;                                  // project + dots: 1 + 2M partial arrays
-  double* part_p = o->d_part + (size_t)(1 + 2 * M) * VEC_BLOCKS;   // pair: 2 + 3M
-  double* part_dg = o->d_part + (size_t)NPART * VEC_BLOCKS;
+  double* part_a = o->d_part;                                  // the update's NPART partial arrays
+  double* part_dg = o->d_part + (size_t)NPART * VEC_BLOCKS;    // direction: d.g, then d.d
   double* part_dd = part_dg + VEC_BLOCKS;
-  // device scalars read back: [0 .. 1+2M) direction dots, [1+2M .. 3+5M) pair dots, [56..59) step, d.d, d.g
-  double* sc = o->d_sc;
-  double* sc_step = sc + 56;
+  // scalars the kernels deliver into the pinned slots: [0 .. 1+2M) direction dots, [1+2M .. 3+5M) pair dots, [64..67) step, d.d, d.g
+  double* sc = o->d_pin;
+  double* sc_step = o->d_pin + 64;
   double* h_rb = o->h_rb;
   double* h_step = o->h_rb + 64;
   const dim3 vb(VEC_BLOCKS), vt(VEC_THREADS);
@@ -1475,7 +2103,7 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   int ord[M];        // ring slots, oldest first
   int hist = 0;
   double gamma = 1.0;
-  bool pending = false;   // a pair has been written to `pend_slot`; its dots are read with the next direction
+  bool pending = false;   // a pair has been written to `pend_slot`; its dots arrive with the next direction's
   int pend_slot = 0;
 
   const auto wall0 = std::chrono::steady_clock::now();
@@ -1485,18 +2113,20 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   int st = 2, it = 0;
   double gnorm = 0.0;
   if (!(J == J)) { *status = 6; if (J_final) *J_final = J; return ECCKD_OK; }
-  for (it = 0; it <= max_iterations; ++it) {
-    // projected gradient, its norm and S^T q, Y^T q in one pass (the pending pair included, as the newest)
-    LbSlots sl;
-    sl.n = hist + (pending ? 1 : 0);
-    for (int a = 0; a < hist; ++a) sl.slot[a] = ord[a];
-    if (pending) sl.slot[hist] = pend_slot;
-    for (int a = sl.n; a < M; ++a) sl.slot[a] = 0;
-    hipLaunchKernelGGL(k_lb_project_dots, vb, vt, 0, ctx->stream, n, sl, x, g, bmin, bmax, o->d_q, o->d_S, o->d_Y, part_a);
-    hipLaunchKernelGGL(k_lb_finish, dim3(1 + 2 * M), vt, 0, ctx->stream, part_a, sc);
+  {
+    // projected gradient and its norm at the starting point (no pair yet)
+    LbSlots none;
+    none.n = 0;
+    for (int a = 0; a < M; ++a) none.slot[a] = 0;
+    opt_mark_pending(h_rb, NPART);
+    hipLaunchKernelGGL(k_lb_update, vb, vt, 0, ctx->stream, n, none, -1, x, x, g, g, bmin, bmax, o->d_q, o->d_S, o->d_Y, part_a);
+    hipLaunchKernelGGL(k_lb_finish, dim3(NPART), dim3(FIN_THREADS), 0, ctx->stream, part_a, sc);
     ECCKD_HIP_CHECK(hipGetLastError());
-    ECCKD_HIP_CHECK(hipMemcpyAsync(h_rb, sc, (size_t)(3 + 5 * M) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  for (it = 0; it <= max_iterations; ++it) {
+    // |q|^2, S^T q, Y^T q at the current point (the pending pair included, as the newest) and the pending pair's own dots:
+    // launched at the end of the previous iteration (k_lb_update), awaited here
+    ECCKD_CHECK(opt_wait_slots(ctx, h_rb, NPART));
     int npairs = hist;           // pairs that enter this direction
     if (pending) {
       const double* rp = h_rb + 1 + 2 * M;   // s.y, y.y, s.Y_a, S_a.y, y.Y_a for a < hist
@@ -1556,13 +2186,14 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
         }
         for (int a = 0; a < npairs; ++a) { cf.cs[a] = top[a]; cf.cy[a] = cf.gamma * u[a]; }
       }
-      hipLaunchKernelGGL(k_lb_direction, vb, vt, 0, ctx->stream, n, sd, cf, o->d_q, o->d_S, o->d_Y, g, o->d_dir, part_dg, part_dd);
-      // the trial point with the step chosen on the device, then the cost there; one synchronisation for both
+      hipLaunchKernelGGL(k_lb_direction, vb, vt, 0, ctx->stream, n, sd, cf, o->d_q, o->d_S, o->d_Y, g, o->d_dir, part_dg);
+      // the trial point (and its coefficients) with the step chosen on the device, then the cost there; one wait for both
+      opt_mark_pending(h_step, 3);
       hipLaunchKernelGGL(k_lb_step, vb, vt, 0, ctx->stream, n, -1.0, npairs == 0 ? 1 : 0, max_step, part_dg, part_dd, x,
-                         o->d_dir, bmin, bmax, xn, sc_step);
+                         o->d_dir, bmin, bmax, xn, o->d_k, sc_step);
       ECCKD_HIP_CHECK(hipGetLastError());
-      ECCKD_HIP_CHECK(hipMemcpyAsync(h_step, sc_step, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-      ECCKD_CHECK(opt_cost_grad_dev(o, xn, gn, &Jn));
+      ECCKD_CHECK(opt_cost_grad_dev(o, xn, gn, &Jn, true));
+      ECCKD_CHECK(opt_wait_slots(ctx, h_step, 3));
       step = h_step[0];
       dg = h_step[2];
       if (!(dg < 0.0)) {
@@ -1579,8 +2210,8 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
       for (int ls = 1; !ok && ls < 30; ++ls) {
         step *= 0.5;
         hipLaunchKernelGGL(k_lb_step, vb, vt, 0, ctx->stream, n, step, 0, max_step, part_dg, part_dd, x, o->d_dir, bmin,
-                           bmax, xn, sc_step);
-        ECCKD_CHECK(opt_cost_grad_dev(o, xn, gn, &Jn));
+                           bmax, xn, o->d_k, sc_step);
+        ECCKD_CHECK(opt_cost_grad_dev(o, xn, gn, &Jn, true));
         ok = (Jn == Jn && Jn <= J + 1.0e-4 * step * dg);
       }
       if (!ok && npairs > 0 && !restarted) {
@@ -1595,8 +2226,8 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
       break;
     }
     if (!ok) break;
-    // curvature pair into the next ring slot (replacing the oldest when the ring is full); its dots with the pairs
-    // that stay are read back together with the next direction's
+    // curvature pair into the next ring slot (replacing the oldest when the ring is full); its dots with the pairs that
+    // stay, and the projected gradient at the new point with every pair's dots, in ONE pass; read at the top of the loop
     if (hist == M) {
       pend_slot = ord[0];
       for (int a = 1; a < M; ++a) ord[a - 1] = ord[a];
@@ -1610,14 +2241,16 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
     LbSlots sp;
     sp.n = hist;
     for (int a = 0; a < M; ++a) sp.slot[a] = a < hist ? ord[a] : 0;
-    hipLaunchKernelGGL(k_lb_pair_dots, vb, vt, 0, ctx->stream, n, sp, pend_slot, x, xn, g, gn, o->d_S, o->d_Y, part_p);
-    hipLaunchKernelGGL(k_lb_finish, dim3(2 + 3 * M), vt, 0, ctx->stream, part_p, sc + 1 + 2 * M);
+    opt_mark_pending(h_rb, NPART);
+    hipLaunchKernelGGL(k_lb_update, vb, vt, 0, ctx->stream, n, sp, pend_slot, x, xn, g, gn, bmin, bmax, o->d_q, o->d_S, o->d_Y, part_a);
+    hipLaunchKernelGGL(k_lb_finish, dim3(NPART), dim3(FIN_THREADS), 0, ctx->stream, part_a, sc);
     ECCKD_HIP_CHECK(hipGetLastError());
     pending = true;
     std::swap(x, xn);
     std::swap(g, gn);
     J = Jn;
   }
+  // (a break may leave the slots of an update in flight: they belong to this handle's pinned block, nobody else reads them)
   ECCKD_HIP_CHECK(hipMemcpyAsync(h_x, x, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   o->t_minimizer += std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() - (o->t_rt + o->t_prior - dev0);

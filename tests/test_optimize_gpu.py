@@ -397,3 +397,42 @@ def test_relative_to_fluxes(ctx, oracle, sw):
               - o2.cost_rt(x - h * d) - o2.cost_prior(x - h * d, cfg["prior_error"])[0]) / (2 * h)
         assert np.dot(g, d) == pytest.approx(fd, rel=2e-6, abs=1e-9 * abs(J))
     opt.close()
+
+
+# ---- the cell-parallel K8a against the general kernel (two implementations of the same arithmetic) --------------------
+
+@pytest.mark.parametrize("sw", [False, True])
+@pytest.mark.parametrize("threads", [None, 128])
+def test_cell_parallel_kernel_matches_the_general_one(ctx, oracle, sw, threads, monkeypatch):
+    """k_opt_forward_adjoint_cells (exp / division of every cell side by side, one FMA per layer on the sequential wave) and
+    k_opt_forward_adjoint (everything on the sequential wave): optical depths identical, fluxes, cost and gradient equal to
+    rounding - both follow the same recurrences, only the grouping of the layer's source terms differs (a few ulp)."""
+    if threads:                         # 128 threads = 2 layer groups: 9 of the 18 layers per thread, which the kernel does not
+                                        # take (8 cells at most): both runs use the general kernel; 192: 3 groups, 6 cells (NC = 8)
+        threads = 192
+        monkeypatch.setenv("ECCKD_K8A_THREADS", str(threads))
+    model, scenes, cfg, orc = (_problem_sw if sw else _problem)(oracle, seed=4, boundary=True, ch4_low=True,
+                                                                **({} if sw else dict(spectral_boundary_weight=0.3)))
+    opt = _opt(ctx, model, scenes, cfg)
+    rs = np.random.RandomState(8)
+    x0 = opt.initial_state()
+    free = x0 > -1.0e20
+    x = x0 + np.where(free, 0.2 * rs.normal(size=x0.size), 0.0)
+    sizes = np.cumsum([0] + orc.sizes)
+    x[sizes[3]:sizes[4]] += 9.0                                  # negative optical depths: penalty and clamp
+    out = {}
+    for generic in ("1", "0"):
+        monkeypatch.setenv("ECCKD_K8A_GENERIC", generic)
+        J, g = opt.cost_grad(x)
+        od, fl = opt.forward(x)
+        od_u, fl_u = opt.forward(x, unclamped=True)
+        out[generic] = (J, g, od, fl, od_u, fl_u)
+    a, b = out["1"], out["0"]
+    assert (a[2] == 0).sum() > 10                                # clamped cells are in play
+    # (the two kernels add the look-up products in the same order, but the compiler fuses multiply and add differently)
+    assert np.allclose(a[2], b[2], rtol=1e-13, atol=1e-300) and np.allclose(a[4], b[4], rtol=1e-13, atol=1e-300)
+    assert np.allclose(a[3], b[3], rtol=1e-13, atol=1e-300) and np.allclose(a[5], b[5], rtol=1e-13, atol=1e-300, equal_nan=True)
+    assert b[0] == pytest.approx(a[0], rel=1e-13)
+    assert np.allclose(a[1], b[1], rtol=1e-9, atol=1e-12 * np.abs(a[1]).max())
+    assert np.array_equal(a[1] == 0.0, b[1] == 0.0)
+    opt.close()
