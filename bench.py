@@ -321,7 +321,47 @@ def ckd_model_sw(model, seed=0):
     return m
 
 
-def lut_opt_bench(ctx, iterations, sharded=False, rank=0, world=1, sw=False):
+L2_GATHER_PEAK_GBS = 17600.0   # MI355X_MICROARCH.md, L2 section: rows shared by every workgroup gathered from the XCDs' L2s, 16.8-18.8 TB/s
+
+
+def lut_opt_cpu_baseline(model, scenes, cfg, evaluations=10):
+    """The serial CPU side of one optimize_lut iteration (solve_adept.cpp:72-211 + calc_background_cost_function,
+    ckd_model.cpp:840-877), ONE thread as the reference runs it (optimize_lut.cpp:159): the oracle's forward model
+    (oracle_ckd.c), its hand-written reverse mode (oracle_adjoint.c) and the prior through the dense LAPACK inverse the
+    reference stores (the inverse itself is built once, outside the timed evaluations).  Adept's tape record / reverse is
+    not reproduced, so this is a LOWER bound on the reference's time per iteration."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pyoracle
+    import ckd_synth
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        threadpool_limits = None
+    full = dict(cfg, spectral_boundary_weight=0.0, negative_od_penalty=1.0e4, pressure_weight_power=0.5, cap_relative_linear=0.0)
+    orc = ckd_synth.Oracle(pyoracle, model, scenes, full)
+    x = orc.x0.copy()
+    ctxmgr = threadpool_limits(limits=1) if threadpool_limits else None
+    if ctxmgr:
+        ctxmgr.__enter__()
+    try:
+        orc.prior_matrices()                                    # dense inverse: once per run in the reference too
+        t0 = time.perf_counter()
+        for _ in range(evaluations):
+            J_rt, g_rt = orc.cost_grad_rt(x)
+            J_b, g_b = orc.cost_prior(x, full["prior_error"])
+        dt = (time.perf_counter() - t0) / evaluations
+    finally:
+        if ctxmgr:
+            ctxmgr.__exit__(None, None, None)
+    return {"value": 1.0 / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d cost + gradient evaluations of the SAME longwave problem (8 scenarios x 50 profiles, nx = %d) by the oracle "
+                      "(oracle_ckd.c forward, oracle_adjoint.c reverse, dense-inverse prior through one BLAS thread): %.2f s per "
+                      "evaluation, counted as one evaluation per iteration; J = %.6g" % (evaluations, x.size, dt, J_rt + J_b),
+            "seconds_per_evaluation": dt, "cost_at_start": J_rt + J_b}
+
+
+def lut_opt_bench(ctx, iterations, sharded=False, rank=0, world=1, sw=False, cpu=False):
     """Second half of the headline metric: LUT-optimisation iterations/s (solve_adept.cpp:295-299 logs one
     line per L-BFGS iteration).  Synthetic CKD model with the shapes of configs[4]: ng = 64, 6 x 53 (T, p)
     grid, H2O look-up table with 12 mole fractions (nx ~ 3e5), 8 scenarios x 50 columns x 54 layers."""
@@ -376,6 +416,28 @@ def lut_opt_bench(ctx, iterations, sharded=False, rank=0, world=1, sw=False):
     out = {"iters_per_s": res["iterations"] / dt, "iterations": res["iterations"], "nx": opt.nx,
            "cells": world * 8 * ncs * 54 * 64, "cost_grad_ms": dt_eval * 1e3, "J0": J0, "J_final": res["cost"],
            "status": res["status"], "region": "shortwave" if sw else "longwave", "profiles_per_rank": 8 * ncs}
+    # What bounds an iteration: the look-up gather of K8a (every cell reads one ng-long coefficient row per table entry) and
+    # its transpose in K8b (every node reads the dJ/dtau row of each cell that references it) are served by the L2s - the
+    # coefficient vector (2.4 MB) and dJ/dtau live there -, then the three vector passes of the L-BFGS update.  Algorithmic
+    # bytes per iteration (one evaluation) over the L2 gather rate of the microarchitecture guide:
+    nent = sum(8 if g["conc"] == "lut" else 4 for g in model["gases"]) + (1 if sw else 0)
+    nent_active = sum((8 if g["conc"] == "lut" else 4) for g in model["gases"] if g["active"])
+    ncell = 8 * ncs * 54
+    gather = ncell * nent * 64 * 8.0
+    scatter = ncell * nent_active * 64 * 8.0
+    vectors = 42 * opt.nx * 8.0            # update 21, direction 15, step 6 vectors of nx doubles
+    bytes_it = gather + scatter + vectors
+    ach = bytes_it * out["iters_per_s"] / 1e9
+    out["roofline"] = {"bound": "l2 gather", "achieved": ach, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": ach / L2_GATHER_PEAK_GBS,
+                       "algorithmic_bytes_per_iteration": bytes_it,
+                       "bytes": {"k8a_gather": gather, "k8b_transpose_gather": scatter, "lbfgs_vector_passes": vectors},
+                       "floor_us_per_iteration": bytes_it / (L2_GATHER_PEAK_GBS * 1e9) * 1e6,
+                       "measured_us_per_iteration": 1e6 / out["iters_per_s"],
+                       "launches_per_iteration": 8, "host_waits_per_iteration": 2,
+                       "traffic": None,
+                       "note": "kernel averages of the same command: profiles/r03_opt_kernel_stats.csv"}
+    if cpu and not sw and not sharded:
+        out["cpu_baseline"] = lut_opt_cpu_baseline(model, scenes, cfg)
     if sharded:
         out["ranks"] = world
         out["allreduce_bytes_per_evaluation"] = (opt.nx + 1) * 8
@@ -594,7 +656,8 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
         if lut_sharded is not None:
             out["lut_opt"] = lut_sharded
         elif world == 1 and not args.no_lut_opt and args.config == 1:
-            out["lut_opt"] = lut_opt_bench(ctx, args.lut_opt_iterations)
+            out["lut_opt"] = lut_opt_bench(ctx, args.lut_opt_iterations, cpu=not args.no_cpu)
+            out["lut_opt"]["shortwave"] = lut_opt_bench(ctx, args.lut_opt_iterations, sw=True)
         if world == 1 and not args.no_sw and args.config == 1:
             out["sw_find_g"] = sw_find_g_bench(ctx)
         if world == 1 and not args.no_cpu and args.config == 1:
@@ -625,7 +688,8 @@ def config4_main(args, ctx, dist, rank, world, barrier):
     for name, sw in (("longwave", False), ("shortwave", True)):
         barrier()
         t0 = time.perf_counter()
-        res[name] = lut_opt_bench(ctx, args.lut_opt_iterations, sharded=sharded, rank=rank, world=world, sw=sw)
+        res[name] = lut_opt_bench(ctx, args.lut_opt_iterations, sharded=sharded, rank=rank, world=world, sw=sw,
+                                  cpu=(rank == 0 and not args.no_cpu))
         barrier()
         t[name] = time.perf_counter() - t0
     if rank != 0:
@@ -639,7 +703,8 @@ def config4_main(args, ctx, dist, rank, world, barrier):
                                    "angles in the SW), ng=64, nx=%d, profile-sharded with one all-reduce of [gradient, cost] "
                                    "per evaluation" % res["longwave"]["nx"],
                        "iterations_per_region": args.lut_opt_iterations},
-            "roofline": None, "cpu_baseline": None, "longwave": res["longwave"], "shortwave": res["shortwave"],
+            "roofline": res["longwave"].get("roofline"), "cpu_baseline": res["longwave"].get("cpu_baseline"),
+            "longwave": res["longwave"], "shortwave": res["shortwave"],
             "setup_inclusive_seconds": t}
 
 

@@ -194,6 +194,10 @@ SIGNATURES = {
     "ecckd_lbl_band_fluxes_lw_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, _c_double_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p,
                                               C.c_void_p, C.c_void_p]),
+    "ecckd_lbl_band_fluxes_lw_angles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, _c_double_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p,
+                                              C.c_void_p, C.c_void_p]),
+    "ecckd_gauss_legendre_01": (C.c_int, [C.c_int, _c_double_p, _c_double_p]),
     "ecckd_lbl_band_fluxes_sw_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p,
                                               C.c_void_p, C.c_void_p]),

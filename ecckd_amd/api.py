@@ -926,7 +926,7 @@ def merge_spectrum(ctx, optical_depth, scaling_profile, merged=None):
     return merged
 
 
-def lbl_band_fluxes_lw(ctx, temperature_hl, wavenumber, d_wavenumber, optical_depth, band_begin, band_end, boundary=False):
+def lbl_band_fluxes_lw(ctx, temperature_hl, wavenumber, d_wavenumber, optical_depth, band_begin, band_end, boundary=False, nangle=0):
     """Line-by-line longwave fluxes of one column summed per band (planck_function + radiative_transfer_lw):
     device tensors wavenumber, d_wavenumber, optical_depth (nlay, nwav) -> (flux_dn, flux_up), each (nband, nlay+1);
     boundary=True: also the spectral fluxes at the boundaries, device tensors (nwav,): (..., surface down, TOA up)."""
@@ -940,14 +940,23 @@ def lbl_band_fluxes_lw(ctx, temperature_hl, wavenumber, d_wavenumber, optical_de
     sdn = torch.empty(nwav, dtype=torch.float64, device=ctx.device) if boundary else None
     tup = torch.empty(nwav, dtype=torch.float64, device=ctx.device) if boundary else None
     ctx.fence_from_torch()
-    check(ctx.lib.ecckd_lbl_band_fluxes_lw_ex(ctx.handle, nlay, nwav, _hptr(t), _dptr(wavenumber),
-                                              _dptr(d_wavenumber), _dptr(optical_depth), _od_type(optical_depth),
-                                              optical_depth.stride(0), b0.size, _hptr(b0, C.c_int64), _hptr(b1, C.c_int64),
-                                              _hptr(dn), _hptr(up), _dptr(sdn) if boundary else None, _dptr(tup) if boundary else None))
+    # nangle = 0: the reference's two-stream form; N > 0: N Gauss-Legendre zenith angles per hemisphere (the CKDMIP tool's nangle)
+    check(ctx.lib.ecckd_lbl_band_fluxes_lw_angles(ctx.handle, int(nangle), nlay, nwav, _hptr(t), _dptr(wavenumber),
+                                                  _dptr(d_wavenumber), _dptr(optical_depth), _od_type(optical_depth),
+                                                  optical_depth.stride(0), b0.size, _hptr(b0, C.c_int64), _hptr(b1, C.c_int64),
+                                                  _hptr(dn), _hptr(up), _dptr(sdn) if boundary else None, _dptr(tup) if boundary else None))
     if boundary:
         ctx.synchronize()
         return dn, up, sdn, tup
     return dn, up
+
+
+def gauss_legendre_01(n):
+    """Nodes (ascending) and weights of the n-point Gauss-Legendre rule on (0, 1) (host only)."""
+    from . import _lib
+    mu, w = np.empty(n), np.empty(n)
+    check(_lib.load_library().ecckd_gauss_legendre_01(int(n), _hptr(mu), _hptr(w)))
+    return mu, w
 
 
 def lbl_band_fluxes_sw(ctx, cos_sza, ssi, optical_depth, band_begin, band_end, albedo=None, boundary=False):

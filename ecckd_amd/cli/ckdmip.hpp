@@ -21,8 +21,9 @@
 //                  that run_ckd wrote, fluxes per column.
 // A file may be preceded by  --scale s  (optical depth times s),  --conc c  (scaled so that the file's reference surface
 // mole fraction becomes c)  or  --const c  (a mole fraction c at every level: each level scaled by c / its own).
-// Namelist (&longwave_config / &shortwave_config): band_wavenumber1 / band_wavenumber2, nspectralstride (1 only), nangle (0
-// only: classic two-stream, diffusivity 1.66), surf_albedo, cos_solar_zenith_angle, do_write_spectral_boundary_fluxes (the
+// Namelist (&longwave_config / &shortwave_config): band_wavenumber1 / band_wavenumber2, nspectralstride (1 only), nangle (0:
+// classic two-stream, diffusivity 1.66; N = 1..16: N Gauss-Legendre zenith angles per hemisphere, as test/run_ckd_lw.sh:28
+// and test/copy_to_ckdmip_lw.sh:32 ask for with NANGLE=4), surf_albedo, cos_solar_zenith_angle, do_write_spectral_boundary_fluxes (the
 // spectral fluxes at the surface and the top of the atmosphere per wavenumber, with the wavenumber grid); the
 // *_name keys must keep their CKDMIP defaults.  Spectra are streamed from the files into HBM (ecckd_nc_read_dev) and merged
 // there; the per-wavenumber radiative transfer is ecckd_lbl_band_fluxes_lw / _sw.  Output is a classic NetCDF file whatever
@@ -115,15 +116,15 @@ Namelist read_namelist(const std::string& path) {
   return nl;
 }
 
-// two-stream longwave radiative transfer of one (level, g) matrix on the host: radiative_transfer_lw.cpp:27-60 (unit emissivity)
-void rt_lw_host(int nlay, int ng, const double* planck, const double* od, double* dn, double* up) {
-  const double D = 1.66;
+// longwave radiative transfer of one (level, g) matrix on the host: radiative_transfer_lw.cpp:27-60 (unit emissivity) along the
+// slant path sec * tau; the two-stream form is sec = 1.66
+void rt_lw_host_sec(int nlay, int ng, double sec, const double* planck, const double* od, double* dn, double* up) {
   for (int g = 0; g < ng; ++g) dn[g] = 0.0;
   std::vector<double> eps((size_t)nlay * ng), fac((size_t)nlay * ng);
   for (size_t i = 0; i < (size_t)nlay * ng; ++i) {
-    const double e = 1.0 - std::exp(-D * od[i]);
+    const double e = 1.0 - std::exp(-sec * od[i]);
     eps[i] = e;
-    fac[i] = e > 1.0e-5 ? 1.0 - e * (1.0 / D) / od[i] : 0.5 * e;
+    fac[i] = e > 1.0e-5 ? 1.0 - e * (1.0 / sec) / od[i] : 0.5 * e;
   }
   for (int l = 0; l < nlay; ++l)
     for (int g = 0; g < ng; ++g) {
@@ -136,6 +137,23 @@ void rt_lw_host(int nlay, int ng, const double* planck, const double* od, double
       const size_t i = (size_t)l * ng + g;
       up[i] = up[i + ng] * (1.0 - eps[i]) + planck[i + ng] * (eps[i] - fac[i]) + planck[i] * fac[i];
     }
+}
+
+// nangle = 0: the classic two-stream fluxes (diffusivity 1.66); nangle = N > 0: N Gauss-Legendre zenith angles per hemisphere,
+// flux = sum_k 2 w_k mu_k L(mu_k) (what ecckd_lbl_band_fluxes_lw_angles does per wavenumber)
+void rt_lw_host(int nangle, int nlay, int ng, const double* planck, const double* od, double* dn, double* up) {
+  if (nangle == 0) { rt_lw_host_sec(nlay, ng, 1.66, planck, od, dn, up); return; }
+  std::vector<double> mu(nangle), w(nangle);
+  ck(ecckd_gauss_legendre_01(nangle, mu.data(), w.data()));
+  const size_t n = (size_t)(nlay + 1) * ng;
+  std::vector<double> d(n), u(n);
+  std::fill(dn, dn + n, 0.0);
+  std::fill(up, up + n, 0.0);
+  for (int a = 0; a < nangle; ++a) {
+    rt_lw_host_sec(nlay, ng, 1.0 / mu[a], planck, od, d.data(), u.data());
+    const double wgt = 2.0 * w[a] * mu[a];
+    for (size_t i = 0; i < n; ++i) { dn[i] += wgt * d[i]; up[i] += wgt * u[i]; }
+  }
 }
 
 // direct beam and surface-reflected upwelling flux of one (level, g) matrix: radiative_transfer_sw.cpp:45-77
@@ -183,7 +201,8 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
     Namelist nl;
     if (!config_file.empty()) nl = read_namelist(config_file);
     if (nl.nspectralstride != 1) fail(ECCKD_PARAMETER_ERROR, "nspectralstride = %d is not supported (1 only)", nl.nspectralstride);
-    if (nl.nangle != 0) fail(ECCKD_PARAMETER_ERROR, "nangle = %d is not supported (classic two-stream only)", nl.nangle);
+    if (nl.nangle < 0 || nl.nangle > 16) fail(ECCKD_PARAMETER_ERROR, "nangle = %d outside 0..16", nl.nangle);
+    if (sw && nl.nangle != 0) WARN("nangle = %d has no meaning for the direct solar beam: ignored", nl.nangle);
     const std::string history = history_line(argc, argv);
 
     // ---------------------------------------------------------------------------------------------------------------
@@ -250,7 +269,7 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
       for (int c = 0; c < ncol; ++c) {
         const std::vector<double> od = f.read("optical_depth", c), planck = f.read("planck_hl", c);
         std::vector<double> dn(nhg), up(nhg), bdn(nlay + 1, 0.0), bup(nlay + 1, 0.0);
-        rt_lw_host(nlay, ng, planck.data(), od.data(), dn.data(), up.data());
+        rt_lw_host(nl.nangle, nlay, ng, planck.data(), od.data(), dn.data(), up.data());
         for (int i = 0; i <= nlay; ++i)
           for (int g = 0; g < ng; ++g) { bdn[i] += dn[(size_t)i * ng + g]; bup[i] += up[(size_t)i * ng + g]; }
         out.write_slice("pressure_hl", c, f.read("pressure_hl", c));
@@ -433,7 +452,7 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
       } else {
         if (col.temperature_hl.empty()) fail(ECCKD_PARAMETER_ERROR, "temperature_hl missing from %s", gases[0].path.c_str());
         std::vector<double> bdn((size_t)nband * (nlay + 1)), bup((size_t)nband * (nlay + 1));
-        ck(ecckd_lbl_band_fluxes_lw_ex(dev.ctx(), nlay, nwav, col.temperature_hl.data(), d_wn.as<double>(), d_dwn.as<double>(),
+        ck(ecckd_lbl_band_fluxes_lw_angles(dev.ctx(), nl.nangle, nlay, nwav, col.temperature_hl.data(), d_wn.as<double>(), d_dwn.as<double>(),
                                        d_merged.ptr(), ECCKD_F64, nwav, nband, bbegin.data(), bend.data(), bdn.data(), bup.data(),
                                        p_bnd_dn, p_bnd_up));
         // [band][level] -> (half_level, band) and the broadband sums

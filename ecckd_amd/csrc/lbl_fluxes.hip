@@ -19,9 +19,16 @@ constexpr int LBL_THREADS = 256;
 __device__ constexpr double kPlanckH = 6.62606896e-34;
 __device__ constexpr double kLightC = 2.99792458e8;
 __device__ constexpr double kPi = 3.14159265358979323846;
-__device__ constexpr double kD = ECCKD_LW_DIFFUSIVITY;
 
 struct BandChunk { long long i1, i2; int band; int pad; };
+
+// The zenith angles of the longwave fluxes.  n = 1 with sec = 1.66, weight = 1: the classic two-stream form the reference
+// itself uses (radiative_transfer_lw.cpp:27-60, LW_DIFFUSIVITY).  n = nangle > 0: Gauss-Legendre quadrature in mu = cos(zenith
+// angle) over one hemisphere, flux = sum_k 2 w_k mu_k L(mu_k), each L(mu_k) the same no-scattering recurrence with the slant
+// path tau / mu_k in place of 1.66 tau (CKDMIP's `nangle`, Hogan & Matricardi 2020, GMD 13, 6501-6521, section 3.2: "N angles
+// per hemisphere").  The CKDMIP tool is not among the reference's sources: its node set is unpinned, see DESIGN.md.
+constexpr int LBL_MAX_ANGLES = 16;
+struct Angles { int n; double sec[LBL_MAX_ANGLES]; double weight[LBL_MAX_ANGLES]; };
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -32,7 +39,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // LDS: acc[4][2*nhl]
 template <typename OdT>
 __global__ void __launch_bounds__(LBL_THREADS)
-k_lbl_fluxes_lw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks, const double* __restrict__ hk,
+k_lbl_fluxes_lw(int nang, const double* __restrict__ ang /*[nang] secants, [nang] weights*/, int nlay, size_t od_stride, const BandChunk* __restrict__ chunks, const double* __restrict__ hk,
                 const double* __restrict__ wn, const double* __restrict__ dwn, const OdT* __restrict__ od,
                 double* __restrict__ partial, double* __restrict__ surf_dn /* [nwav] or NULL */,
                 double* __restrict__ toa_up /* [nwav] or NULL */) {
@@ -51,40 +58,47 @@ k_lbl_fluxes_lw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks
   const double freq = wn[j] * inv_cm_2_Hz;
   const double pref = live ? (dwn[j] * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq * freq * freq) : 0.0;
   auto planck = [&](int level) { return ecckd::div_fast(pref, ecckd::exp_fast(freq * hk[level]) - 1.0); };
-  auto layer = [&](int l, double& eps, double& fac) {
-    const double tau = (double)od[(size_t)l * od_stride + j];
-    eps = 1.0 - ecckd::exp_fast(-kD * tau);
-    fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * (1.0 / kD), tau) : 0.5 * eps;   // :41-43
-  };
-  // down sweep from zero at the top of the atmosphere (:45-50); dead lanes carry pref = 0 -> all fluxes 0
-  double flux = 0.0;
-  double b_prev = planck(0);
-  for (int l = 0; l < nlay; ++l) {
-    double eps, fac;
-    layer(l, eps, fac);
-    const double b_next = planck(l + 1);
-    flux = flux * (1.0 - eps) + b_prev * (eps - fac) + b_next * fac;
-    const double s = wave_sum(flux);
-    if (lane == 0) acc_dn[l + 1] += s;
-    b_prev = b_next;
+  double surf_acc = 0.0, toa_acc = 0.0;
+  for (int a = 0; a < nang; ++a) {
+    const double sec = ang[a], wgt = ang[nang + a];          // (uniform: scalar loads)
+    const double rsec = 1.0 / sec;
+    auto layer = [&](int l, double& eps, double& fac) {
+      const double tau = (double)od[(size_t)l * od_stride + j];
+      eps = 1.0 - ecckd::exp_fast(-sec * tau);
+      fac = (eps > 1.0e-5) ? 1.0 - ecckd::div_fast(eps * rsec, tau) : 0.5 * eps;   // :41-43
+    };
+    // down sweep from zero at the top of the atmosphere (:45-50); dead lanes carry pref = 0 -> all fluxes 0
+    double flux = 0.0;
+    double b_prev = planck(0);
+    for (int l = 0; l < nlay; ++l) {
+      double eps, fac;
+      layer(l, eps, fac);
+      const double b_next = planck(l + 1);
+      flux = flux * (1.0 - eps) + b_prev * (eps - fac) + b_next * fac;
+      const double s = wave_sum(wgt * flux);
+      if (lane == 0) acc_dn[l + 1] += s;
+      b_prev = b_next;
+    }
+    surf_acc += wgt * flux;                         // the spectral flux at the boundary (do_write_spectral_boundary_fluxes)
+    // surface: emissivity 1, Planck function at temperature_hl(end) (:52-53)
+    flux = b_prev * 1.0 + (1.0 - 1.0) * flux;
+    {
+      const double s = wave_sum(wgt * flux);
+      if (lane == 0) acc_up[nlay] += s;
+    }
+    for (int l = nlay - 1; l >= 0; --l) {                                    // :55-59
+      double eps, fac;
+      layer(l, eps, fac);
+      const double b_l = planck(l);
+      flux = flux * (1.0 - eps) + b_prev * (eps - fac) + b_l * fac;
+      const double s = wave_sum(wgt * flux);
+      if (lane == 0) acc_up[l] += s;
+      b_prev = b_l;
+    }
+    toa_acc += wgt * flux;
   }
-  if (surf_dn && live) surf_dn[j] = flux;         // the spectral flux at the boundary (do_write_spectral_boundary_fluxes)
-  // surface: emissivity 1, Planck function at temperature_hl(end) (:52-53)
-  flux = b_prev * 1.0 + (1.0 - 1.0) * flux;
-  {
-    const double s = wave_sum(flux);
-    if (lane == 0) acc_up[nlay] += s;
-  }
-  for (int l = nlay - 1; l >= 0; --l) {                                    // :55-59
-    double eps, fac;
-    layer(l, eps, fac);
-    const double b_l = planck(l);
-    flux = flux * (1.0 - eps) + b_prev * (eps - fac) + b_l * fac;
-    const double s = wave_sum(flux);
-    if (lane == 0) acc_up[l] += s;
-    b_prev = b_l;
-  }
-  if (toa_up && live) toa_up[j] = flux;
+  if (surf_dn && live) surf_dn[j] = surf_acc;
+  if (toa_up && live) toa_up[j] = toa_acc;
   __syncthreads();
   for (int t = tid; t < 2 * nhl; t += LBL_THREADS)
     partial[(size_t)blockIdx.x * 2 * nhl + t] = ((s_acc[t] + s_acc[2 * nhl + t]) + s_acc[4 * nhl + t]) + s_acc[6 * nhl + t];
@@ -185,6 +199,51 @@ int ecckd_lbl_band_fluxes_lw_ex(ecckd_ctx* ctx, int nlay, size_t nwav, const dou
                                 const double* d_wavenumber, const double* d_d_wavenumber, const void* d_od, int od_type,
                                 size_t od_stride, int nband, const int64_t* h_band_begin, const int64_t* h_band_end,
                                 double* h_flux_dn, double* h_flux_up, double* d_surf_dn, double* d_toa_up) {
+  return ecckd_lbl_band_fluxes_lw_angles(ctx, 0, nlay, nwav, h_temperature_hl, d_wavenumber, d_d_wavenumber, d_od, od_type, od_stride,
+                                         nband, h_band_begin, h_band_end, h_flux_dn, h_flux_up, d_surf_dn, d_toa_up);
+}
+
+int ecckd_gauss_legendre_01(int n, double* h_mu, double* h_weight) {
+  ECCKD_REQUIRE(n >= 1 && n <= LBL_MAX_ANGLES && h_mu && h_weight, "ecckd_gauss_legendre_01: 1 <= n <= %d", LBL_MAX_ANGLES);
+  // nodes of P_n on (-1, 1) by Newton's iteration from the Chebyshev guess, mapped to (0, 1); ascending mu
+  for (int i = 0; i < n; ++i) {
+    double t = std::cos(3.14159265358979323846 * (i + 0.75) / (n + 0.5));
+    double dp = 1.0;
+    for (int it = 0; it < 100; ++it) {
+      double p0 = 1.0, p1 = t;
+      for (int k = 2; k <= n; ++k) { const double pk = ((2.0 * k - 1.0) * t * p1 - (k - 1.0) * p0) / k; p0 = p1; p1 = pk; }
+      if (n == 1) { p0 = 1.0; p1 = t; }
+      dp = n * (t * p1 - p0) / (t * t - 1.0);
+      const double dt = p1 / dp;
+      t -= dt;
+      if (std::fabs(dt) < 1e-16) break;
+    }
+    {
+      double p0 = 1.0, p1 = t;
+      for (int k = 2; k <= n; ++k) { const double pk = ((2.0 * k - 1.0) * t * p1 - (k - 1.0) * p0) / k; p0 = p1; p1 = pk; }
+      dp = n * (t * p1 - p0) / (t * t - 1.0);
+    }
+    const double w = 2.0 / ((1.0 - t * t) * dp * dp);
+    h_mu[n - 1 - i] = 0.5 * (1.0 + t);
+    h_weight[n - 1 - i] = 0.5 * w;
+  }
+  return ECCKD_OK;
+}
+
+int ecckd_lbl_band_fluxes_lw_angles(ecckd_ctx* ctx, int nangle, int nlay, size_t nwav, const double* h_temperature_hl,
+                                    const double* d_wavenumber, const double* d_d_wavenumber, const void* d_od, int od_type,
+                                    size_t od_stride, int nband, const int64_t* h_band_begin, const int64_t* h_band_end,
+                                    double* h_flux_dn, double* h_flux_up, double* d_surf_dn, double* d_toa_up) {
+  ECCKD_REQUIRE(nangle >= 0 && nangle <= LBL_MAX_ANGLES, "ecckd_lbl_band_fluxes_lw: nangle = %d outside 0..%d", nangle, LBL_MAX_ANGLES);
+  Angles ang{};
+  if (nangle == 0) {
+    ang.n = 1; ang.sec[0] = ECCKD_LW_DIFFUSIVITY; ang.weight[0] = 1.0;
+  } else {
+    double mu[LBL_MAX_ANGLES], w[LBL_MAX_ANGLES];
+    ECCKD_CHECK(ecckd_gauss_legendre_01(nangle, mu, w));
+    ang.n = nangle;
+    for (int a = 0; a < nangle; ++a) { ang.sec[a] = 1.0 / mu[a]; ang.weight[a] = 2.0 * w[a] * mu[a]; }
+  }
   ECCKD_REQUIRE(ctx && nlay > 0 && h_temperature_hl && d_wavenumber && d_d_wavenumber && d_od && nband > 0 && h_band_begin &&
                 h_band_end && h_flux_dn && h_flux_up, "ecckd_lbl_band_fluxes_lw: bad argument");
   ECCKD_REQUIRE(od_type == ECCKD_F32 || od_type == ECCKD_F64, "ecckd_lbl_band_fluxes_lw: od_type must be 4 or 8");
@@ -204,17 +263,20 @@ int ecckd_lbl_band_fluxes_lw_ex(ecckd_ctx* ctx, int nlay, size_t nwav, const dou
   Buf d_chunks, d_hk, d_part;
   if (!chunks.empty()) {
     ECCKD_HIP_CHECK(hipMalloc(&d_chunks.p, chunks.size() * sizeof(BandChunk)));
-    ECCKD_HIP_CHECK(hipMalloc(&d_hk.p, nhl * sizeof(double)));
+    ECCKD_HIP_CHECK(hipMalloc(&d_hk.p, (nhl + 2 * LBL_MAX_ANGLES) * sizeof(double)));
     ECCKD_HIP_CHECK(hipMalloc(&d_part.p, chunks.size() * 2 * nhl * sizeof(double)));
     ECCKD_CHECK(ecckd_h2d(ctx, d_chunks.p, chunks.data(), chunks.size() * sizeof(BandChunk)));
-    ECCKD_CHECK(ecckd_h2d(ctx, d_hk.p, hk.data(), nhl * sizeof(double)));
+    for (int a = 0; a < ang.n; ++a) hk.push_back(ang.sec[a]);
+    for (int a = 0; a < ang.n; ++a) hk.push_back(ang.weight[a]);
+    ECCKD_CHECK(ecckd_h2d(ctx, d_hk.p, hk.data(), hk.size() * sizeof(double)));
+    const double* d_ang = (const double*)d_hk.p + nhl;
     const size_t lds = (size_t)4 * 2 * nhl * sizeof(double);
     if (od_type == ECCKD_F32)
-      hipLaunchKernelGGL(k_lbl_fluxes_lw<float>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, nlay,
+      hipLaunchKernelGGL(k_lbl_fluxes_lw<float>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, ang.n, d_ang, nlay,
                          od_stride, (const BandChunk*)d_chunks.p, (const double*)d_hk.p, d_wavenumber, d_d_wavenumber,
                          (const float*)d_od, (double*)d_part.p, d_surf_dn, d_toa_up);
     else
-      hipLaunchKernelGGL(k_lbl_fluxes_lw<double>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, nlay,
+      hipLaunchKernelGGL(k_lbl_fluxes_lw<double>, dim3((unsigned)chunks.size()), dim3(LBL_THREADS), lds, ctx->stream, ang.n, d_ang, nlay,
                          od_stride, (const BandChunk*)d_chunks.p, (const double*)d_hk.p, d_wavenumber, d_d_wavenumber,
                          (const double*)d_od, (double*)d_part.p, d_surf_dn, d_toa_up);
     ECCKD_HIP_CHECK(hipGetLastError());

@@ -466,43 +466,66 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 
 // Optical depth of one cell for the 64 g points of a wave (calc_total_optical_depth, solve_adept.cpp:24-69).  The cell is the
 // same for the whole wave, so its table entries (node row, coefficient) are fetched ONCE, one entry per lane (two coalesced
-// loads instead of 2 x nent same-address loads per lane), and handed round with v_readlane: the row offsets arrive in scalar
-// registers and the nent loads of the coefficient rows are independent of each other - eight in flight per batch, the products
-// still added in entry order; absent entries (idx < 0) add nothing.  `active` = this lane has a g point.
-__device__ __forceinline__ double gather_cell(const int* __restrict__ ei, const double* __restrict__ ec, const double* __restrict__ k,
-                                              int g, bool active, int nent, int ray_ent, double& tau_ray) {
-  const int lane = threadIdx.x & 63;
-  double tau = 0.0;
-  tau_ray = 0.0;
-  for (int e0 = 0; e0 < nent; e0 += 64) {
-    const int ne = min(64, nent - e0);
-    const int my_idx = lane < ne ? ei[e0 + lane] : -1;
-    const double my_c = lane < ne ? ec[e0 + lane] : 0.0;
-    for (int q0 = 0; q0 < ne; q0 += 8) {
-      int ix[8];
-      double cv[8], kv[8];
+// loads instead of 2 x nent same-address loads per lane; the caller fetches them for all its cells before the first is used),
+// and handed round with v_readlane: the row offsets arrive in scalar registers and the loads of the coefficient rows are
+// independent of each other - sixteen in flight per batch, the products still added in entry order; absent entries (idx < 0)
+// add nothing.  `active` = this lane has a g point.
+constexpr int K8A_GB = 8;      // coefficient rows per batch; two batches are in flight (the next one is issued before the
+                               // current one is used)
+struct GatherBatch { int ix[K8A_GB]; double cv[K8A_GB], kv[K8A_GB]; };
+
+// (row_stride = 1: my_idx is the offset of the row in k; else the row's number, of row_stride doubles each)
+__device__ __forceinline__ void gather_issue(GatherBatch& b, int my_idx, double my_c, int q0, int ne, const double* __restrict__ k, int gl,
+                                             int row_stride = 1) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = (q0 + q) & 63;
-        ix[q] = (q0 + q < ne) ? __builtin_amdgcn_readlane(my_idx, e) : -1;
-        cv[q] = readlane_f64(my_c, e);
-      }
+  for (int q = 0; q < K8A_GB; ++q) {
+    const int e = (q0 + q) & 63;                          // (lanes at and beyond `ne` hold idx = -1: no test needed; a batch
+    b.ix[q] = __builtin_amdgcn_readlane(my_idx, e);       //  never wraps round because ne <= 64 and q0 is a multiple of 8)
+    b.cv[q] = readlane_f64(my_c, e);
+  }
+  // the loads are UNCONDITIONAL (an absent entry reads row 0 and is dropped by the select in gather_use): a test round a
+  // load makes the compiler wait for everything in flight where the paths join, one memory round trip per entry
 #pragma unroll
-      for (int q = 0; q < 8; ++q) kv[q] = (ix[q] >= 0 && active) ? k[(size_t)ix[q] + g] : 0.0;
+  for (int q = 0; q < K8A_GB; ++q) b.kv[q] = k[(size_t)max(b.ix[q], 0) * row_stride + gl];
+}
+
+__device__ __forceinline__ void gather_use(const GatherBatch& b, int e_first, int ray_ent, double& tau, double& tau_ray) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const double t = ix[q] >= 0 ? cv[q] * kv[q] : 0.0;
-        if (e0 + q0 + q == ray_ent) tau_ray = t; else tau += t;
-      }
+  for (int q = 0; q < K8A_GB; ++q) {
+    const double t = b.ix[q] >= 0 ? b.cv[q] * b.kv[q] : 0.0;
+    if (e_first + q == ray_ent) tau_ray = t; else tau += t;
+  }
+}
+
+// NB > 0: the table has at most NB * 8 entries - all NB batches are issued before the first is used, in straight-line code
+// (no loop, no test: the compiler counts the loads in flight exactly).  NB = 0: any length, two batches in flight.
+template <int NB>
+__device__ __forceinline__ void gather_batches(int my_idx, double my_c, int e0, int ne, const double* __restrict__ k, int gl,
+                                               int ray_ent, double& tau, double& tau_ray) {
+  if constexpr (NB > 0) {
+    GatherBatch b[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) gather_issue(b[i], my_idx, my_c, i * K8A_GB, ne, k, gl);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) gather_use(b[i], e0 + i * K8A_GB, ray_ent, tau, tau_ray);
+  } else {
+    GatherBatch A, B;
+    gather_issue(A, my_idx, my_c, 0, ne, k, gl);
+    for (int q0 = 0; q0 < ne; q0 += 2 * K8A_GB) {
+      // (the issues are unconditional - past the end they fetch row 0 and drop it -: a conditional issue makes the compiler
+      // assume the fewest loads in flight and wait for all of them)
+      gather_issue(B, my_idx, my_c, (q0 + K8A_GB) & 63, ne, k, gl);
+      gather_use(A, e0 + q0, ray_ent, tau, tau_ray);
+      gather_issue(A, my_idx, my_c, (q0 + 2 * K8A_GB) & 63, ne, k, gl);
+      if (q0 + K8A_GB < ne) gather_use(B, e0 + q0 + K8A_GB, ray_ent, tau, tau_ray);
     }
   }
-  return tau;
 }
 
 constexpr int K8A_CH = 8;      // layers per prefetch chunk of the sequential recurrences
 constexpr int K8A_MAXR = 4;    // (half level, band) slots per thread in the cost phase: (nlay + 1) * nband <= K8A_MAXR * blockDim
 
-template <int NC, bool SW>
+template <int NC, bool SW, int NB>
 __global__ void __launch_bounds__(1024)
 k_opt_forward_adjoint_cells(
     const double* __restrict__ mu0, int ray_ent, int keep_negative, const double* __restrict__ rel_flux,
@@ -514,7 +537,7 @@ k_opt_forward_adjoint_cells(
     const double* __restrict__ fdn_true, const double* __restrict__ fup_true, const double* __restrict__ sfds,
     const double* __restrict__ sfut, double flux_weight, double flux_profile_weight, double broadband_weight,
     double spectral_boundary_weight, double negative_od_penalty, double* __restrict__ dtau, double* __restrict__ jcol,
-    double* __restrict__ od_out, double* __restrict__ flux_out, int dbg) {
+    double* __restrict__ od_out, double* __restrict__ flux_out) {
   extern __shared__ double smem[];
   const int nhl = nlay + 1;
   double* s_T = smem;                                            // longwave only: [nlay][ng] 1 - eps
@@ -557,14 +580,33 @@ k_opt_forward_adjoint_cells(
   double c_tu[SW ? NC : 1];        // shortwave: exp(-2 tau)
   unsigned clamp_mask = 0;
   double penalty = 0.0;
+  // the table entries of all the cells of this thread first (entries 0..63; tables with more come in further rounds below)
+  const int lane = threadIdx.x & 63;
+  const int gl = in_range ? g : 0;        // lanes beyond the last g point read (and drop) the first one's values
+  int t_idx[NC];
+  double t_c[NC];
+  const int ne0 = min(64, nent);
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int l = lgrp + j * nlgrp;
+    const bool have = l < nlay && lane < ne0;
+    t_idx[j] = have ? ent_idx[(cell0 + l) * nent + lane] : -1;
+    t_c[j] = have ? ent_coef[(cell0 + l) * nent + lane] : 0.0;
+  }
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const int l = lgrp + j * nlgrp;
     c_tau[j] = 0.0; c_t[j] = 1.0;
     if constexpr (SW) c_tu[j] = 1.0;
     if (l < nlay) {
-      double tau_ray = 0.0;
-      double tau = (dbg & 1) ? 0.1 + 0.01 * l : gather_cell(ent_idx + (cell0 + l) * nent, ent_coef + (cell0 + l) * nent, k, g, in_range, nent, ray_ent, tau_ray);
+      double tau = 0.0, tau_ray = 0.0;
+      gather_batches<NB>(t_idx[j], t_c[j], 0, ne0, k, gl, ray_ent, tau, tau_ray);
+      for (int e0 = 64; e0 < nent; e0 += 64) {
+        const int ne = min(64, nent - e0);
+        const int my_idx = lane < ne ? ent_idx[(cell0 + l) * nent + e0 + lane] : -1;
+        const double my_c = lane < ne ? ent_coef[(cell0 + l) * nent + e0 + lane] : 0.0;
+        gather_batches<0>(my_idx, my_c, e0, ne, k, gl, ray_ent, tau, tau_ray);
+      }
       if (in_range) {
         const double tau_raw = tau;
         bool clamped = false;
@@ -600,7 +642,7 @@ k_opt_forward_adjoint_cells(
   }
   __syncthreads();
   // ---- B: the two recurrences, one wave; the rows of a chunk of layers are fetched before its chain of FMAs starts ----
-  if (live && !(dbg & 2)) {
+  if (live) {
     // full chunks without a test per layer (a scalar branch per step costs more than the step), then the remainder
     double dn = SW ? cos_sza * pl[g] : 0.0;
     double* pD = s_D + g;
@@ -667,7 +709,6 @@ k_opt_forward_adjoint_cells(
   const double* hrt = hr_true + (size_t)col * nlay * nband;
   const double* fdt = fdn_true + (size_t)col * nhl * nband;
   const double* fut = fup_true + (size_t)col * nhl * nband;
-  if (!(dbg & 4))
   for (int t = threadIdx.x; t < nhl * nband; t += blockDim.x) {
     const int i = t / nband, b = t % nband;
     double sd = 0.0, su = 0.0;
@@ -690,7 +731,6 @@ k_opt_forward_adjoint_cells(
   const double up_in_hr = SW ? 0.0 : 1.0;                         // shortwave heating rate from the direct beam only (:197)
   const double hrw2 = hr_weight * hr_weight;
   double jpart = 0.0;
-  if (!(dbg & 8))
   for (int t = threadIdx.x; t < nlay * nband; t += blockDim.x) {
     const int l = t / nband, b = t % nband;
     const double hrf = cv[l] * (s_bdn[(l + 1) * nband + b] - s_bdn[l * nband + b] -
@@ -714,7 +754,6 @@ k_opt_forward_adjoint_cells(
       wu_b = (!SW || all_pos) ? iw : 0.0;                        // :264
     }
   };
-  if (!(dbg & 8))
   for (int t = threadIdx.x; t < nlay + nhl; t += blockDim.x) {
     if (t < nlay) {
       double rsum = 0.0;
@@ -745,7 +784,7 @@ k_opt_forward_adjoint_cells(
     for (int t = threadIdx.x; t < nhl * nband && nr < MAXR; t += blockDim.x, ++nr) {
       const int i = t / nband, b = t % nband;
       double gd = 0.0, gu = 0.0;
-      if (!(dbg & 8)) {
+      {
       if (i >= 1) {                                               // layer i-1 ends at this level
         const int l = i - 1;
         const double dhr = 2.0 * hrw2 * lw[l] * (spec_scale * s_r[l * nband + b] + broadband_weight * s_rsum[l]);
@@ -821,7 +860,7 @@ k_opt_forward_adjoint_cells(
     }
     __syncthreads();
   }
-  if (live && !(dbg & 2)) {
+  if (live) {
     const int b = band_of_g[g];
     // u_bar[0] = seed[0], u_bar[l+1] = seed[l+1] + u_bar[l] t_l: row l of s_U becomes the adjoint of up[l]
     double up_bar = s_gup[b] + g_up_toa_extra;
@@ -876,7 +915,7 @@ k_opt_forward_adjoint_cells(
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const int l = lgrp + j * nlgrp;
-    if (in_range && l < nlay && !((clamp_mask >> j) & 1u) && !(dbg & 16)) {
+    if (in_range && l < nlay && !((clamp_mask >> j) & 1u)) {
       const double ubar_l = s_U[l * ng + g], dnbar = s_D[(l + 1) * ng + g];
       double tau_bar;
       if constexpr (SW) {
@@ -908,126 +947,131 @@ k_opt_forward_adjoint_cells(
   if (threadIdx.x == 0) jcol[col] = jtot;
 }
 
-// K8b + K9: gradient of the state.  One thread per (node, g) of the ACTIVE gases.
-//   grad_k = sum over the cells that reference this node of coef * dtau[cell][g]   (fixed order)
+// K8b + K9: gradient of the state, two launches of one WAVE per task, four waves per block, no LDS, no barrier.
+//   grad_k = sum over the cells that reference this node of coef * dtau[cell][g]   (reference order)
 //   grad_x = grad_k * k + B^-1 (x - x_prior) / sigma_g^2                            (:273-283)
-__global__ void __launch_bounds__(256)
-k_opt_gradient(size_t nnode, int ng, int ngpad, const double* __restrict__ x, const double* __restrict__ x_prior,
-               const double* __restrict__ k, const int* __restrict__ ref_ptr /*[nnode+1]*/,
-               const int* __restrict__ ref_cell, const double* __restrict__ ref_coef,
-               const double* __restrict__ dtau,
-               // prior stencil: per node the three local indices and per gas/dimension tridiagonals
-               const int* __restrict__ node_gas, const int* __restrict__ node_ic,
-               const int* __restrict__ node_it, const int* __restrict__ node_ip,
-               const int* __restrict__ gas_dims /*[ngas][4]: nconc, nt, np, node0*/,
-               const double* __restrict__ tri /* per gas: c(3*nconc) | t(3*nt) | p(3*np) */,
-               const int* __restrict__ tri_off /*[ngas]*/, const double* __restrict__ inv_sigma2 /*[ngas][ng]*/,
-               int have_prior, double* __restrict__ grad, double* __restrict__ jb_part /*[nnode]*/,
-               const int* __restrict__ node_order /*[gridDim.x]: the node of each block, -1 = none*/) {
-  // one block per LUT node; blockDim = ngpad * (reference groups).  The references of a node
-  // (cells that interpolate from it) are dealt round-robin to the groups and the group sums are
-  // combined in group order: a fixed summation order without atomics.
-  // Which block takes which node is a pure speed choice (node_order, built by ecckd_opt_create): the blocks b, b + 8, ...
-  // share an XCD and walk ONE eighth of the pressure axis in order, so the dJ/dtau rows they gather (cells whose pressure
-  // lies between two neighbouring nodes) stay in that XCD's L2 instead of being fetched by all eight.
-  extern __shared__ double s_acc[];  // [groups][ngpad] | [4]
-  const int ordered = node_order[blockIdx.x];
-  if (ordered < 0) return;
-  const size_t node = (size_t)ordered;
-  const int g = threadIdx.x % ngpad;
-  const int rg = __builtin_amdgcn_readfirstlane(threadIdx.x / ngpad);   // ngpad is a multiple of 64: uniform in a wave
-  const int nrg = blockDim.x / ngpad;
-  double* s4 = s_acc + (size_t)nrg * ngpad;
-  double part = 0.0;
-  {
-    // The references of this group (r = first + rg, + nrg, ...), 64 at a time: every lane fetches ONE (cell, coefficient)
-    // pair, v_readlane hands them round as scalars, and the dJ/dtau rows of a batch of eight references are loaded together -
-    // their latencies overlap instead of following each its own cell-index load.  Products added in reference order.
-    const int lane = threadIdx.x & 63;
-    const int r1 = ref_ptr[node + 1];
-    const bool active = g < ng;
-    for (int r0 = ref_ptr[node] + rg; r0 < r1; r0 += 64 * nrg) {
-      const int myr = r0 + lane * nrg;
-      const int my_cell = myr < r1 ? ref_cell[myr] : -1;
-      const double my_w = myr < r1 ? ref_coef[myr] : 0.0;
-      const int cnt = min(64, (r1 - r0 + nrg - 1) / nrg);
-      for (int q0 = 0; q0 < cnt; q0 += 8) {
-        int c[8];
-        double w[8], d[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int e = (q0 + q) & 63;
-          c[q] = (q0 + q < cnt) ? __builtin_amdgcn_readlane(my_cell, e) : -1;
-          w[q] = readlane_f64(my_w, e);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) d[q] = (c[q] >= 0 && active) ? dtau[(size_t)c[q] * ng + g] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (c[q] >= 0) part += w[q] * d[q];
-      }
-    }
-  }
-  s_acc[rg * ngpad + g] = part;
-  __syncthreads();
-  double jb = 0.0;
-  if (rg == 0 && g < ng) {
+// The nodes are referenced very unevenly (a few hundred references on average, thousands where the training profiles crowd
+// one corner of the table): with a block or a wave per NODE the kernel lasted as long as its busiest node.  So the references
+// of a node are cut into runs of at most K8B_RUN (host: ecckd_opt_create) and
+//   k_opt_gradient_gather: a wave per (run, 64 g points) adds its run in reference order -> run_sum[run][g];
+//   k_opt_gradient_finish: a wave per (node, 64 g points) adds the node's runs in order, then chain rule and prior.
+// Every sum has a fixed order: bitwise reproducible.  The references come 64 at a time, one (cell, coefficient) pair per lane,
+// v_readlane hands them round as scalars, and the dJ/dtau rows are loaded eight at a time, two batches in flight.
+// Which wave takes which task is a pure speed choice (the order tables built by ecckd_opt_create): the blocks b, b + 8, ...
+// share an XCD and walk ONE eighth of the pressure axis in order, so the dJ/dtau rows they gather (cells whose pressure lies
+// between two neighbouring nodes) tend to stay in that XCD's L2.
+constexpr int K8B_WAVES = 4;
+constexpr int K8B_RUN = 64;
+__global__ void __launch_bounds__(64 * K8B_WAVES)
+k_opt_gradient_gather(int nslot, int ng, int nchunk, const int* __restrict__ run_order /*[nslot]: run * nchunk + chunk, -1 = none*/,
+                      const int* __restrict__ run_r0 /*[nrun + 1]: first reference of each run*/, const int* __restrict__ run_last /*[nrun]: 1 + last reference*/,
+                      const int* __restrict__ ref_cell, const double* __restrict__ ref_coef, const double* __restrict__ dtau,
+                      double* __restrict__ run_sum /*[nrun][nchunk][64]*/) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int vb = blockIdx.x; vb * K8B_WAVES < nslot; vb += gridDim.x) {        // gridDim is a multiple of 8: vb stays on its XCD
+    const int slot = vb * K8B_WAVES + wave;
+    const int ordered = slot < nslot ? run_order[slot] : -1;
+    if (ordered < 0) continue;
+    const int run = ordered / nchunk;
+    const int g = (ordered % nchunk) * 64 + lane;
+    const int gl = g < ng ? g : 0;
+    const int r0 = run_r0[run], r1 = run_last[run];
+    const int myr = r0 + lane;
+    const int my_cell = myr < r1 ? ref_cell[myr] : -1;
+    const double my_w = myr < r1 ? ref_coef[myr] : 0.0;
+    const int cnt = r1 - r0;                                   // <= K8B_RUN = 64
     double gk = 0.0;
-    for (int q = 0; q < nrg; ++q) gk += s_acc[q * ngpad + g];
-    const size_t e = node * ng + g;
-    const double xv = x[e];
-    double gx = 0.0;
-    if (xv > MIN_X) {
-      gx = gk * k[e];
-      if (have_prior) {
-        const int gas = node_gas[node];
-        const int nconc = gas_dims[gas * 4 + 0], nt = gas_dims[gas * 4 + 1], np = gas_dims[gas * 4 + 2];
-        const size_t node0 = (size_t)gas_dims[gas * 4 + 3];
-        const double* tc = tri + tri_off[gas];
-        const double* tt = tc + 3 * nconc;
-        const double* tp = tt + 3 * nt;
-        const int ic = node_ic[node], it = node_it[node], ip = node_ip[node];
-        double acc = 0.0;
-        for (int dc = -1; dc <= 1; ++dc) {
-          const int jc = ic + dc;
-          if (jc < 0 || jc >= nconc) continue;
-          const double wc = tc[(dc + 1) * nconc + ic];
-          if (wc == 0.0) continue;
-          for (int dt = -1; dt <= 1; ++dt) {
-            const int jt = it + dt;
-            if (jt < 0 || jt >= nt) continue;
-            const double wt = tt[(dt + 1) * nt + it];
-            if (wt == 0.0) continue;
-            for (int dp = -1; dp <= 1; ++dp) {
-              const int jp = ip + dp;
-              if (jp < 0 || jp >= np) continue;
-              const double w = wc * wt * tp[(dp + 1) * np + ip];
-              // MIN_ERROR_COVARIANCE, ckd_model.cpp:650,713
-              if (fabs(w) < 1.0e-6) continue;
-              const size_t nb = (node0 + ((size_t)jc * nt + jt) * np + jp) * ng + g;
-              acc += w * (x[nb] - x_prior[nb]);
-            }
-          }
-        }
-        const double gb = acc * inv_sigma2[(size_t)gas * ng + g];
-        jb = 0.5 * (xv - x_prior[e]) * gb;
-        gx += gb;
-      }
-      if (fabs(gx) < 1.0e-80) gx = 0.0;  // :286
-    }
-    grad[e] = gx;
-  }
-  // deterministic block partial of the background cost
+    // the issues are unconditional (lanes past the end hold cell -1 and weight 0: row 0 is fetched and dropped), so that the
+    // compiler counts the loads in flight exactly
+    GatherBatch A, B;
+    gather_issue(A, my_cell, my_w, 0, cnt, dtau, gl, ng);
+    for (int q0 = 0; q0 < cnt; q0 += 2 * K8A_GB) {
+      gather_issue(B, my_cell, my_w, (q0 + K8A_GB) & 63, cnt, dtau, gl, ng);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) jb += __shfl_down(jb, off, 64);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nwave = (blockDim.x + 63) >> 6;
-  if (lane == 0) s4[wave] = jb;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int w = 0; w < nwave; ++w) t += s4[w];
-    jb_part[node] = t;
+      for (int q = 0; q < K8A_GB; ++q) gk += A.ix[q] >= 0 ? A.cv[q] * A.kv[q] : 0.0;
+      gather_issue(A, my_cell, my_w, (q0 + 2 * K8A_GB) & 63, cnt, dtau, gl, ng);
+      const bool use_b = q0 + K8A_GB < cnt;                    // (at q0 + 8 = 64 the issue above wrapped round to batch 0)
+#pragma unroll
+      for (int q = 0; q < K8A_GB; ++q) gk += (use_b && B.ix[q] >= 0) ? B.cv[q] * B.kv[q] : 0.0;
+    }
+    run_sum[(size_t)ordered * 64 + lane] = gk;
+  }
+}
+
+__global__ void __launch_bounds__(64 * K8B_WAVES)
+k_opt_gradient_finish(int nslot /*entries of node_order*/, int ng, int nchunk /*64-g chunks per node*/, const double* __restrict__ x,
+                      const double* __restrict__ x_prior, const double* __restrict__ k,
+                      const int* __restrict__ node_run0 /*[nnode + 1]: first run of each node*/, const double* __restrict__ run_sum,
+                      // prior: per node the (at most 27) neighbours of its Kronecker stencil and their weights, -1 = none
+                      const int* __restrict__ node_gas, const int* __restrict__ st_nb /*[nnode][27]*/,
+                      const double* __restrict__ st_w /*[nnode][27]*/, const double* __restrict__ inv_sigma2 /*[ngas][ng]*/,
+                      int have_prior, double* __restrict__ grad, double* __restrict__ jb_part /*[nnode][nchunk]*/,
+                      const int* __restrict__ node_order /*[nslot]: node * nchunk + chunk of each wave, -1 = none*/) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int vb = blockIdx.x; vb * K8B_WAVES < nslot; vb += gridDim.x) {
+    const int slot = vb * K8B_WAVES + wave;
+    const int ordered = slot < nslot ? node_order[slot] : -1;
+    if (ordered < 0) continue;
+    const size_t node = (size_t)(ordered / nchunk);
+    const int chunk = ordered % nchunk;
+    const int g = chunk * 64 + lane;
+    const bool active = g < ng;
+    const int gl = active ? g : 0;
+    // the node's runs, in order (eight loads in flight)
+    double gk = 0.0;
+    const int t1 = node_run0[node + 1];
+    for (int t = node_run0[node]; t < t1; t += 8) {
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = run_sum[((size_t)min(t + q, t1 - 1) * nchunk + chunk) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) gk += (t + q < t1) ? v[q] : 0.0;
+    }
+    // B^-1 (x - x_prior) / sigma_g^2 at this node (calc_background_cost_function, ckd_model.cpp:852-865): the stencil's
+    // neighbours come one per lane and go round as scalars, their 2 x 27 loads are in flight together, the terms are added in
+    // the order of the host's loops (concentration, temperature, pressure offsets -1, 0, 1)
+    double gb = 0.0;
+    if (have_prior) {
+      const int my_nb = lane < 27 ? st_nb[node * 27 + lane] : -1;
+      const double my_w = lane < 27 ? st_w[node * 27 + lane] : 0.0;
+      double acc = 0.0;
+#pragma unroll
+      for (int q0 = 0; q0 < 27; q0 += 9) {
+        int nb[9];
+        double w[9], xa[9], xb[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { nb[q] = __builtin_amdgcn_readlane(my_nb, q0 + q); w[q] = readlane_f64(my_w, q0 + q); }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          xa[q] = x[(size_t)max(nb[q], 0) * ng + gl];
+          xb[q] = x_prior[(size_t)max(nb[q], 0) * ng + gl];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc += nb[q] >= 0 ? w[q] * (xa[q] - xb[q]) : 0.0;
+      }
+      if (active) gb = acc * inv_sigma2[(size_t)node_gas[node] * ng + g];
+    }
+    double jb = 0.0;
+    if (active) {
+      const size_t e = node * ng + g;
+      const double xv = x[e];
+      double gx = 0.0;
+      if (xv > MIN_X) {
+        gx = gk * k[e];
+        if (have_prior) {
+          gx += gb;
+          jb = 0.5 * (xv - x_prior[e]) * gb;
+        }
+        if (fabs(gx) < 1.0e-80) gx = 0.0;  // :286
+      }
+      grad[e] = gx;
+    }
+    // the node's share of the background cost: lanes in shuffle order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) jb += __shfl_down(jb, off, 64);
+    if (lane == 0) jb_part[ordered] = jb;
   }
 }
 
@@ -1043,8 +1087,8 @@ k_opt_exp(size_t nx, const double* __restrict__ x, double* __restrict__ k) {
 // Device-resident L-BFGS vector kernels.  All reductions are two-stage with a fixed order:
 // stage 1 writes one partial per block (lanes by shuffle, then the block's waves in order), stage 2 (inside the consumer
 // kernel, or k_lb_finish) sums the partials in index order.
-constexpr int VEC_BLOCKS = 256;    // partials per reduction
-constexpr int VEC_THREADS = 1024;  // one or two elements per thread at nx ~ 3e5: every load of a pass is in flight at once
+constexpr int VEC_BLOCKS = 512;    // room for partials per reduction; the launches use min(512, ceil(n / 1024)) blocks
+constexpr int VEC_THREADS = 1024;  // ONE element per thread at nx ~ 3e5: every load of a pass is in flight at once
 constexpr int VEC_WAVES = VEC_THREADS / 64;
 constexpr int FIN_THREADS = 256;   // k_lb_finish
 
@@ -1054,26 +1098,53 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// the VEC_BLOCKS partials of one reduction, summed by every caller in the same order (blockDim >= 256)
-__device__ __forceinline__ double sum_partials(const double* __restrict__ part, double* s_tmp /*[4]*/) {
+// the nblk (<= 512) partials of one reduction, summed by every caller in the same order (blockDim >= 256)
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int nblk, double* s_tmp /*[4]*/) {
   const int t = threadIdx.x;
-  double v = (t < VEC_BLOCKS) ? part[t] : 0.0;
+  double v = 0.0;
+  if (t < 256) {
+    if (t < nblk) v = part[t];
+    if (t + 256 < nblk) v += part[t + 256];
+  }
   v = wave_sum(v);
   __syncthreads();
-  if ((t & 63) == 0 && t < VEC_BLOCKS) s_tmp[t >> 6] = v;
+  if ((t & 63) == 0 && t < 256) s_tmp[t >> 6] = v;
   __syncthreads();
   return ((s_tmp[0] + s_tmp[1]) + s_tmp[2]) + s_tmp[3];
 }
 
-// NACC per-thread accumulators -> one partial per (accumulator, block): waves by shuffle, the block's waves in order
-template <int NACC>
-__device__ __forceinline__ void write_partials(const double (&acc)[NACC], int nused, double* __restrict__ part, double* s_all /*[NACC][VEC_WAVES]*/) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// NACC per-thread accumulators -> one partial per (accumulator, block).  Within a wave the NACC sums are taken TOGETHER: at the
+// exchange over lane distance 32 a lane passes on one half of its values and adds what it receives to the half it keeps, at
+// distance 16 a half of those, ... - NACC + NACC/2 + ... exchanges in all instead of 6 per value (every exchange is an LDS
+// crossbar operation that all the waves of a CU queue for: the plain form cost the update kernel more than its memory traffic).
+// Lane l ends up with the wave's sum of accumulator bitreverse6(l).  Same tree for every value, fixed: bitwise reproducible.
+template <int USED>
+__device__ __forceinline__ void fold_level(double* v, bool upper, int mask) {
+  constexpr int NEXT = (USED + 1) / 2;
 #pragma unroll
-  for (int k = 0; k < NACC; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) s_all[k * VEC_WAVES + wave] = v;
+  for (int i = 0; i < NEXT; ++i) {
+    const double a = v[2 * i];
+    const double b = (2 * i + 1 < USED) ? v[2 * i + 1] : 0.0;
+    const double send = upper ? a : b;
+    double keep = upper ? b : a;
+    keep += __shfl_xor(send, mask, 64);
+    v[i] = keep;
   }
+}
+
+template <int NACC>
+__device__ __forceinline__ void write_partials(double (&acc)[NACC], int nused, double* __restrict__ part, double* s_all /*[NACC][VEC_WAVES]*/) {
+  static_assert(NACC <= 64, "one value per lane at the end");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int U1 = (NACC + 1) / 2, U2 = (U1 + 1) / 2, U3 = (U2 + 1) / 2, U4 = (U3 + 1) / 2, U5 = (U4 + 1) / 2;
+  fold_level<NACC>(acc, (lane & 32) != 0, 32);
+  fold_level<U1>(acc, (lane & 16) != 0, 16);
+  fold_level<U2>(acc, (lane & 8) != 0, 8);
+  fold_level<U3>(acc, (lane & 4) != 0, 4);
+  fold_level<U4>(acc, (lane & 2) != 0, 2);
+  fold_level<U5>(acc, (lane & 1) != 0, 1);
+  const int kk = (int)(__brev((unsigned)lane) >> 26);           // the accumulator this lane now holds
+  if (kk < NACC) s_all[kk * VEC_WAVES + wave] = acc[0];
   __syncthreads();
   if ((int)threadIdx.x < nused) {
     double t = 0.0;
@@ -1109,36 +1180,39 @@ k_lb_update(size_t n, LbSlots keep, int new_slot, const double* __restrict__ x, 
 #pragma unroll
   for (int k = 0; k < LB_NPART; ++k) acc[k] = 0.0;
   const bool pair = new_slot >= 0;
-  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * VEC_THREADS) {
+    // every load of the element first, none behind a test of the number of pairs (a branch per pair put a full memory round
+    // trip behind each): the slots of unused pairs hold zeros or the finite values of dropped pairs (S and Y are cleared when
+    // they are allocated), their partials are never read
+    double sa[LB_M], ya[LB_M];
+#pragma unroll
+    for (int a = 0; a < LB_M; ++a) {
+      sa[a] = S[(size_t)keep.slot[a] * n + i];
+      ya[a] = Y[(size_t)keep.slot[a] * n + i];
+    }
     const double xi = xn[i];
     double gi = gn[i];
-    double si = 0.0, yi = 0.0;
-    if (pair) { si = xi - x[i]; yi = gi - g[i]; }
-    if (xmin && ((xi <= xmin[i] && gi > 0.0) || (xi >= xmax[i] && gi < 0.0))) gi = 0.0;
+    const double xo = x[i], go = g[i];
+    const double lo = xmin ? xmin[i] : 0.0, hi = xmin ? xmax[i] : 0.0;
+    const double si = pair ? xi - xo : 0.0, yi = pair ? gi - go : 0.0;
+    if (xmin && ((xi <= lo && gi > 0.0) || (xi >= hi && gi < 0.0))) gi = 0.0;
     if (!(xi > MIN_X)) gi = 0.0;
     q[i] = gi;
     acc[0] += gi * gi;
-    if (pair) {
-      acc[1 + 2 * LB_M] += si * yi;
-      acc[2 + 2 * LB_M] += yi * yi;
+    acc[1 + 2 * LB_M] += si * yi;
+    acc[2 + 2 * LB_M] += yi * yi;
+#pragma unroll
+    for (int a = 0; a < LB_M; ++a) {
+      // position keep.n is the pair being stored: the newest of this iteration's direction
+      const double sq = (a == keep.n && pair) ? si : sa[a];
+      const double yq = (a == keep.n && pair) ? yi : ya[a];
+      acc[1 + a] += sq * gi;
+      acc[1 + LB_M + a] += yq * gi;
+      acc[3 + 2 * LB_M + a] += si * ya[a];
+      acc[3 + 3 * LB_M + a] += sa[a] * yi;
+      acc[3 + 4 * LB_M + a] += yi * ya[a];
     }
-#pragma unroll
-    for (int a = 0; a < LB_M; ++a)
-      if (a < keep.n) {
-        const double sa = S[(size_t)keep.slot[a] * n + i], ya = Y[(size_t)keep.slot[a] * n + i];
-        acc[1 + a] += sa * gi;
-        acc[1 + LB_M + a] += ya * gi;
-        if (pair) {
-          acc[3 + 2 * LB_M + a] += si * ya;
-          acc[3 + 3 * LB_M + a] += sa * yi;
-          acc[3 + 4 * LB_M + a] += yi * ya;
-        }
-      }
     if (pair) {
-      // the new pair is the newest of this iteration's direction: position keep.n (always < LB_M)
-#pragma unroll
-      for (int a = 0; a < LB_M; ++a)
-        if (a == keep.n) { acc[1 + a] += si * gi; acc[1 + LB_M + a] += yi * gi; }
       S[(size_t)new_slot * n + i] = si;     // the slot being written is never among the pairs that stay
       Y[(size_t)new_slot * n + i] = yi;
     }
@@ -1153,11 +1227,17 @@ k_lb_direction(size_t n, LbSlots sl, LbCoef cf, const double* __restrict__ q, co
                double* __restrict__ part_dg /* part_dd follows: [2][VEC_BLOCKS] */) {
   __shared__ double s_all[2 * VEC_WAVES];
   double acc[2] = {0.0, 0.0};
-  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * VEC_THREADS) {
+    // (no test of the number of pairs round the loads: unused pairs have zero coefficients and finite slots)
+    double sv[LB_M], yv[LB_M];
+#pragma unroll
+    for (int k = 0; k < LB_M; ++k) {
+      sv[k] = S[(size_t)sl.slot[k] * n + i];
+      yv[k] = Y[(size_t)sl.slot[k] * n + i];
+    }
     double di = -cf.gamma * q[i];
 #pragma unroll
-    for (int k = 0; k < LB_M; ++k)
-      if (k < sl.n) di += cf.cy[k] * Y[(size_t)sl.slot[k] * n + i] - cf.cs[k] * S[(size_t)sl.slot[k] * n + i];
+    for (int k = 0; k < LB_M; ++k) di += cf.cy[k] * yv[k] - cf.cs[k] * sv[k];
     // a variable held by an active bound (or pinned) does not move: without this the slope d.g of the Armijo test would
     // count a decrease that the clamped trial point cannot deliver
     if (q[i] == 0.0 && g[i] != 0.0) di = 0.0;
@@ -1179,16 +1259,16 @@ k_lb_step(size_t n, double step, int first, double max_step, const double* __res
           double* __restrict__ kn, double* __restrict__ out) {
   __shared__ double s_tmp[4];
   if (step < 0.0) {
-    const double dd = sum_partials(part_dd, s_tmp);
+    const double dd = sum_partials(part_dd, gridDim.x, s_tmp);
     const double dn = sqrt(dd);
     step = first ? fmin(1.0, 1.0 / fmax(dn, 1e-300)) : 1.0;
     if (step * dn > max_step) step = max_step / dn;
     if (blockIdx.x == 0) {
-      const double dg = sum_partials(part_dg, s_tmp);
+      const double dg = sum_partials(part_dg, gridDim.x, s_tmp);
       if (threadIdx.x == 0) { out[0] = step; out[1] = dd; out[2] = dg; }
     }
   }
-  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)VEC_BLOCKS * VEC_THREADS) {
+  for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * VEC_THREADS) {
     double v = x[i] + step * d[i];
     if (xmin) v = fmin(fmax(v, xmin[i]), xmax[i]);
     const bool free_el = x[i] > MIN_X;
@@ -1201,10 +1281,10 @@ k_lb_step(size_t n, double step, int first, double max_step, const double* __res
 // out[k] = sum of partial array k: one block per array.  `out` is pinned, host-coherent memory: the host watches the slots
 // (no copy, no stream synchronisation; see wait_slots)
 __global__ void __launch_bounds__(FIN_THREADS)
-k_lb_finish(const double* __restrict__ part, double* __restrict__ out) {
+k_lb_finish(const double* __restrict__ part, int nblk, double* __restrict__ out) {
   __shared__ double s_tmp[4];
   const int k = blockIdx.x;
-  const double v = sum_partials(part + (size_t)k * VEC_BLOCKS, s_tmp);
+  const double v = sum_partials(part + (size_t)k * VEC_BLOCKS, nblk, s_tmp);
   if (threadIdx.x == 0) out[k] = v;
 }
 
@@ -1260,13 +1340,17 @@ struct ecckd_opt {
   double *d_jcol = nullptr, *d_jb = nullptr;
   int* d_ent_idx = nullptr; double* d_ent_coef = nullptr; int* d_band = nullptr;
   int *d_band_ptr = nullptr, *d_band_g = nullptr;   // the g points of each band in increasing order (CSR)
-  int* d_node_order = nullptr;                      // K8b: block -> node (XCD-aware), -1 = idle block
-  unsigned gradient_grid = 0;
+  int* d_node_order = nullptr;                      // K8b finish: wave slot -> node * nchunk + chunk (XCD-aware), -1 = idle
+  int *d_run_order = nullptr, *d_run_r0 = nullptr, *d_run_last = nullptr, *d_node_run0 = nullptr;   // K8b gather: the runs
+  double* d_run_sum = nullptr;                      // [nrun][nchunk][64]
+  unsigned gradient_grid = 0, gather_grid = 0;
+  int grad_nchunk = 1, grad_nslot = 0, gather_nslot = 0;
+  size_t grad_nrun = 0;
   double *d_planck = nullptr, *d_semis = nullptr, *d_conv = nullptr, *d_lw = nullptr;
   double *d_hr = nullptr, *d_fdn = nullptr, *d_fup = nullptr, *d_sfds = nullptr, *d_sfut = nullptr;
   int *d_ref_ptr = nullptr, *d_ref_cell = nullptr; double* d_ref_coef = nullptr;
-  int *d_node_gas = nullptr, *d_node_ic = nullptr, *d_node_it = nullptr, *d_node_ip = nullptr, *d_gas_dims = nullptr;
-  double* d_tri = nullptr; int* d_tri_off = nullptr; double* d_inv_sigma2 = nullptr;
+  int *d_node_gas = nullptr, *d_st_nb = nullptr;    // K9: gas of each active node, its stencil's neighbours [nnode][27]
+  double *d_st_w = nullptr, *d_inv_sigma2 = nullptr;
   double* d_od_out = nullptr; double* d_flux_out = nullptr;
   unsigned grad_blocks = 0;
   // pinned host staging: per-profile costs, per-node prior terms, L-BFGS scalars (pageable read-backs cost
@@ -1310,9 +1394,9 @@ void opt_free(ecckd_opt* o) {
   if (!o) return;
   if (o->ctx) (void)hipStreamSynchronize(o->ctx->stream);
   void* ptrs[] = {o->d_k, o->d_x, o->d_xprior, o->d_grad, o->d_dtau, o->d_jcol, o->d_jb, o->d_ent_idx, o->d_ent_coef,
-                  o->d_band, o->d_band_ptr, o->d_band_g, o->d_node_order, o->d_planck, o->d_semis, o->d_conv, o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds,
-                  o->d_sfut, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_node_gas, o->d_node_ic, o->d_node_it,
-                  o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2, o->d_od_out, o->d_flux_out, o->d_xmin, o->d_xmax,
+                  o->d_band, o->d_band_ptr, o->d_band_g, o->d_node_order, o->d_run_order, o->d_run_r0, o->d_run_last, o->d_node_run0,
+                  o->d_run_sum, o->d_planck, o->d_semis, o->d_conv, o->d_lw, o->d_hr, o->d_fdn, o->d_fup, o->d_sfds,
+                  o->d_sfut, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_node_gas, o->d_st_nb, o->d_st_w, o->d_inv_sigma2, o->d_od_out, o->d_flux_out, o->d_xmin, o->d_xmax,
                   o->d_xn, o->d_gn, o->d_dir, o->d_q, o->d_S, o->d_Y, o->d_part, o->d_sc, o->d_mu0, o->d_rel};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1678,7 +1762,7 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
 
   // ---- K8b: which block takes which node.  The pressure axis is cut into 8 contiguous pieces of about equal numbers of
   // references; piece x is walked, pressure index ascending, by the blocks x, x + 8, x + 16, ... (one XCD, in dispatch order)
-  std::vector<int> node_order;
+  std::vector<int> node_order, run_order, run_r0_v, run_last_v, node_run0_v;
   {
     constexpr int NX = 8;
     std::vector<long long> refs_of_ip(np, 0);
@@ -1695,16 +1779,90 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
     for (int ip = 0; ip < np; ++ip)
       for (size_t nd = 0; nd < o->nnode_active; ++nd)
         if (node_ip[nd] == ip) list[piece_of_ip[ip]].push_back((int)nd);
-    size_t longest = 0;
-    for (const auto& l : list) longest = std::max(longest, l.size());
-    node_order.assign(longest * NX, -1);
-    for (int x = 0; x < NX; ++x)
-      for (size_t j = 0; j < list[x].size(); ++j) node_order[j * NX + x] = list[x][j];
-    if (const char* e = std::getenv("ECCKD_K8B_PLAIN_ORDER")) if (e[0] == '1') {
-      node_order.resize(o->nnode_active);
-      for (size_t nd = 0; nd < o->nnode_active; ++nd) node_order[nd] = (int)nd;
+    // a wave per task, K8B_WAVES waves per block: virtual block j of piece x (= j * NX + x) takes the next K8B_WAVES entries of
+    // the piece's list.  Tasks of the first launch: the runs (at most K8B_RUN references of one node) x 64-g chunks; of the
+    // second: the nodes x 64-g chunks.
+    const int nchunk = (ng + 63) / 64;
+    o->grad_nchunk = nchunk;
+    const bool plain = [] { const char* e = std::getenv("ECCKD_K8B_PLAIN_ORDER"); return e && e[0] == '1'; }();
+    std::vector<int> node_run0(o->nnode_active + 1, 0), run_r0, run_last;
+    for (size_t nd = 0; nd < o->nnode_active; ++nd) {
+      node_run0[nd] = (int)run_r0.size();
+      for (int r = ref_ptr[nd]; r < ref_ptr[nd + 1]; r += K8B_RUN) {
+        run_r0.push_back(r);
+        run_last.push_back(std::min(r + K8B_RUN, ref_ptr[nd + 1]));
+      }
     }
-    o->gradient_grid = (unsigned)node_order.size();
+    node_run0[o->nnode_active] = (int)run_r0.size();
+    o->grad_nrun = run_r0.size();
+    auto lay_out = [&](const std::vector<std::vector<int>>& entries) {
+      size_t longest = 0;
+      for (const auto& l : entries) longest = std::max(longest, (l.size() + K8B_WAVES - 1) / K8B_WAVES);
+      std::vector<int> order(longest * NX * K8B_WAVES, -1);
+      for (int x = 0; x < NX; ++x)
+        for (size_t q = 0; q < entries[x].size(); ++q) order[((q / K8B_WAVES) * NX + x) * K8B_WAVES + q % K8B_WAVES] = entries[x][q];
+      return order;
+    };
+    std::vector<std::vector<int>> node_entries(NX), run_entries(NX);
+    for (int x = 0; x < NX; ++x)
+      for (int nd : list[x]) {
+        for (int c = 0; c < nchunk; ++c) node_entries[x].push_back(nd * nchunk + c);
+        for (int t = node_run0[nd]; t < node_run0[nd + 1]; ++t)
+          for (int c = 0; c < nchunk; ++c) run_entries[x].push_back(t * nchunk + c);
+      }
+    if (plain) {
+      for (auto& v : node_entries) v.clear();
+      for (auto& v : run_entries) v.clear();
+      for (size_t q = 0; q < o->nnode_active * nchunk; ++q) node_entries[(q / K8B_WAVES) % NX].push_back((int)q);
+      for (size_t q = 0; q < run_r0.size() * nchunk; ++q) run_entries[(q / K8B_WAVES) % NX].push_back((int)q);
+    }
+    node_order = lay_out(node_entries);
+    run_order = lay_out(run_entries);
+    run_r0_v = run_r0; run_last_v = run_last; node_run0_v = node_run0;
+    // every virtual block resident at once where that fits (8 blocks of 4 waves per CU), else a grid-stride loop
+    auto grid_of = [&](size_t nslot) {
+      unsigned gsz = (unsigned)std::min<size_t>((nslot + K8B_WAVES - 1) / K8B_WAVES, (size_t)std::max(ctx->num_cu, 1) * 8);
+      return std::max(8u, (gsz + 7) / 8 * 8);
+    };
+    o->gradient_grid = grid_of(node_order.size());
+    o->gather_grid = grid_of(run_order.size());
+  }
+
+  // ---- K9: the prior's stencil per node.  B^-1 is the Kronecker product of the three AR(1) inverses (tridiagonal each):
+  // up to 27 neighbours, weight = wc * wt * wp, entries below MIN_ERROR_COVARIANCE dropped as the reference zeroes them in its
+  // dense inverse (ckd_model.cpp:650, :709-713, :776-780); neighbours in the order (dc, dt, dp) = (-1,-1,-1) ... (1,1,1)
+  std::vector<int> st_nb(o->nnode_active * 27, -1);
+  std::vector<double> st_w(o->nnode_active * 27, 0.0);
+  for (size_t nd = 0; nd < o->nnode_active; ++nd) {
+    const int gas = node_gas[nd];
+    const int nconc = gas_dims[gas * 4 + 0];
+    const size_t node0 = (size_t)gas_dims[gas * 4 + 3];
+    const double* tc = tri.data() + tri_off[gas];
+    const double* tt = tc + 3 * nconc;
+    const double* tp = tt + 3 * nt;
+    const int ic = node_ic[nd], it = node_it[nd], ip = node_ip[nd];
+    int slot = 0;
+    for (int dc = -1; dc <= 1; ++dc) {
+      const int jc = ic + dc;
+      if (jc < 0 || jc >= nconc) continue;
+      const double wc = tc[(dc + 1) * nconc + ic];
+      if (wc == 0.0) continue;
+      for (int dt = -1; dt <= 1; ++dt) {
+        const int jt = it + dt;
+        if (jt < 0 || jt >= nt) continue;
+        const double wt = tt[(dt + 1) * nt + it];
+        if (wt == 0.0) continue;
+        for (int dp = -1; dp <= 1; ++dp) {
+          const int jp = ip + dp;
+          if (jp < 0 || jp >= np) continue;
+          const double w = wc * wt * tp[(dp + 1) * np + ip];
+          if (std::fabs(w) < 1.0e-6) continue;             // MIN_ERROR_COVARIANCE
+          st_nb[nd * 27 + slot] = (int)(node0 + ((size_t)jc * nt + jt) * np + jp);
+          st_w[nd * 27 + slot] = w;
+          ++slot;
+        }
+      }
+    }
   }
 
   std::vector<int> band(m->iband_per_g, m->iband_per_g + ng);
@@ -1741,14 +1899,17 @@ int ecckd_opt_create(ecckd_ctx* ctx, const ecckd_opt_model* m, int nscene, const
     }
   }
   UP(d_ref_ptr, ref_ptr); UP(d_ref_cell, ref_cell); UP(d_ref_coef, ref_coef); UP(d_node_order, node_order);
-  UP(d_node_gas, node_gas); UP(d_node_ic, node_ic); UP(d_node_it, node_it); UP(d_node_ip, node_ip);
-  UP(d_gas_dims, gas_dims); UP(d_tri, tri); UP(d_tri_off, tri_off); UP(d_inv_sigma2, inv_sigma2);
+  UP(d_run_order, run_order); UP(d_run_r0, run_r0_v); UP(d_run_last, run_last_v); UP(d_node_run0, node_run0_v);
+  o->grad_nslot = (int)node_order.size();
+  o->gather_nslot = (int)run_order.size();
+  UP(d_node_gas, node_gas); UP(d_st_nb, st_nb); UP(d_st_w, st_w); UP(d_inv_sigma2, inv_sigma2);
 #undef UP
   o->grad_blocks = (unsigned)((o->nx + 255) / 256);
   auto dalloc = [&](double** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(double)); };
   if (dalloc(&o->d_x, o->nx) != hipSuccess || dalloc(&o->d_xprior, o->nx) != hipSuccess ||
       dalloc(&o->d_grad, o->nx + 1) != hipSuccess || dalloc(&o->d_dtau, o->ncell * ng) != hipSuccess ||
-      dalloc(&o->d_jcol, ncol) != hipSuccess || dalloc(&o->d_jb, o->nnode_active) != hipSuccess) {
+      dalloc(&o->d_run_sum, std::max<size_t>(o->grad_nrun, 1) * o->grad_nchunk * 64) != hipSuccess ||
+      dalloc(&o->d_jcol, ncol) != hipSuccess || dalloc(&o->d_jb, o->nnode_active * (size_t)((ng + 63) / 64)) != hipSuccess) {
     opt_free(o);
     return ecckd::fail(ECCKD_OUT_OF_MEMORY, "ecckd_opt_create: device allocation failed");
   }
@@ -1874,8 +2035,6 @@ static int opt_launch_forward(ecckd_opt* o) {
   const int nlay = o->nlay, nhl = nlay + 1, ng = o->ng, nband = o->nband;
   const int ngpad = (ng + 63) / 64 * 64;
   static const int env_threads = [] { const char* e = std::getenv("ECCKD_K8A_THREADS"); const int v = e ? std::atoi(e) : 0; return v >= 64 && v <= 1024 ? v : 0; }();
-  const char* env_dbg = std::getenv("ECCKD_K8A_DEBUG");
-  const int dbg = env_dbg ? std::atoi(env_dbg) : 0;
   const char* env_generic = std::getenv("ECCKD_K8A_GENERIC");       // read at every call: the tests switch between the two kernels
   const bool force_generic = env_generic && env_generic[0] == '1';
   // the cell-parallel kernel: longwave 1 024 threads (16 layer groups at ng = 64, one block per CU), shortwave 512 (8 groups,
@@ -1888,20 +2047,32 @@ static int opt_launch_forward(ecckd_opt* o) {
                         nlay + 2 * (size_t)nhl + 16) * sizeof(double) + ((size_t)nband + 1 + ng) * sizeof(int);
     if (!force_generic && nc <= 8 && lds <= 160 * 1024 && ngpad * lgroups <= 1024 && nhl * nband <= K8A_MAXR * ngpad * lgroups) {
       const int threads = ngpad * lgroups;
-#define ECCKD_K8A_CELLS(NC_, SW_)                                                                                                   \
+#define ECCKD_K8A_CELLS(NC_, SW_, NB_)                                                                                              \
       do {                                                                                                                            \
-        ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_opt_forward_adjoint_cells<NC_, SW_>),                  \
+        ECCKD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_opt_forward_adjoint_cells<NC_, SW_, NB_>),             \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                              \
-        hipLaunchKernelGGL((k_opt_forward_adjoint_cells<NC_, SW_>), dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream,       \
+        hipLaunchKernelGGL((k_opt_forward_adjoint_cells<NC_, SW_, NB_>), dim3((unsigned)o->ncol), dim3(threads), lds, ctx->stream,  \
                            o->d_mu0, o->eval_ray_ent, o->eval_keep_negative, o->d_rel, nlay, ng, ngpad, nband, o->nent, o->d_k,     \
                            o->d_ent_idx, o->d_ent_coef, o->d_band, o->d_band_ptr, o->d_band_g, o->d_planck, o->d_semis, o->d_conv, \
                            o->d_lw, o->d_hr, o->d_fdn,                                                                               \
                            o->d_fup, o->d_sfds, o->d_sfut, o->cfg.flux_weight, o->cfg.flux_profile_weight,                          \
                            o->cfg.broadband_weight, o->cfg.spectral_boundary_weight, o->cfg.negative_od_penalty, o->d_dtau,         \
-                           o->d_jcol, o->d_od_out, o->d_flux_out, dbg);                                                             \
+                           o->d_jcol, o->d_od_out, o->d_flux_out);                                                                  \
       } while (0)
-      if (o->do_sw) { if (nc <= 4) ECCKD_K8A_CELLS(4, true); else ECCKD_K8A_CELLS(8, true); }
-      else { if (nc <= 4) ECCKD_K8A_CELLS(4, false); else ECCKD_K8A_CELLS(8, false); }
+#define ECCKD_K8A_NB(NC_, SW_)                                                                                                      \
+      do {                                                                                                                            \
+        switch (nb) {                                                                                                                 \
+          case 1: ECCKD_K8A_CELLS(NC_, SW_, 1); break;                                                                                \
+          case 2: ECCKD_K8A_CELLS(NC_, SW_, 2); break;                                                                                \
+          case 3: ECCKD_K8A_CELLS(NC_, SW_, 3); break;                                                                                \
+          case 4: ECCKD_K8A_CELLS(NC_, SW_, 4); break;                                                                                \
+          default: ECCKD_K8A_CELLS(NC_, SW_, 0); break;                                                                               \
+        }                                                                                                                             \
+      } while (0)
+      const int nb = (std::min(o->nent, 64) + K8A_GB - 1) / K8A_GB;       // 8-entry batches of a cell's table (first 64 entries)
+      if (o->do_sw) { if (nc <= 4) ECCKD_K8A_NB(4, true); else ECCKD_K8A_NB(8, true); }
+      else { if (nc <= 4) ECCKD_K8A_NB(4, false); else ECCKD_K8A_NB(8, false); }
+#undef ECCKD_K8A_NB
 #undef ECCKD_K8A_CELLS
       ECCKD_HIP_CHECK(hipGetLastError());
       return ECCKD_OK;
@@ -1944,17 +2115,14 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
   if (!k_ready)     // (the minimizer's step kernel leaves exp(x) of its trial point in d_k)
     hipLaunchKernelGGL(k_opt_exp, dim3(o->grad_blocks), dim3(256), 0, ctx->stream, o->nx, d_x, o->d_k);
   const int ng = o->ng;
-  const int ngpad = (ng + 63) / 64 * 64;
-  const int lgroups = std::max(1, 256 / ngpad);
-  const int threads = ngpad * lgroups;
   const bool timed = o->tev[0] != nullptr;
   if (timed) ECCKD_HIP_CHECK(hipEventRecord(o->tev[0], ctx->stream));
   ECCKD_CHECK(opt_launch_forward(o));
   if (timed) ECCKD_HIP_CHECK(hipEventRecord(o->tev[1], ctx->stream));
-  hipLaunchKernelGGL(k_opt_gradient, dim3(o->gradient_grid), dim3(threads),
-                     ((size_t)lgroups * ngpad + 16) * sizeof(double), ctx->stream, o->nnode_active, ng, ngpad, d_x, o->d_xprior,
-                     o->d_k, o->d_ref_ptr, o->d_ref_cell, o->d_ref_coef, o->d_dtau, o->d_node_gas, o->d_node_ic,
-                     o->d_node_it, o->d_node_ip, o->d_gas_dims, o->d_tri, o->d_tri_off, o->d_inv_sigma2,
+  hipLaunchKernelGGL(k_opt_gradient_gather, dim3(o->gather_grid), dim3(64 * K8B_WAVES), 0, ctx->stream, o->gather_nslot, ng, o->grad_nchunk,
+                     o->d_run_order, o->d_run_r0, o->d_run_last, o->d_ref_cell, o->d_ref_coef, o->d_dtau, o->d_run_sum);
+  hipLaunchKernelGGL(k_opt_gradient_finish, dim3(o->gradient_grid), dim3(64 * K8B_WAVES), 0, ctx->stream, o->grad_nslot, ng, o->grad_nchunk,
+                     d_x, o->d_xprior, o->d_k, o->d_node_run0, o->d_run_sum, o->d_node_gas, o->d_st_nb, o->d_st_w, o->d_inv_sigma2,
                      prior ? 1 : 0, d_grad, o->d_jb, o->d_node_order);
   ECCKD_HIP_CHECK(hipGetLastError());
   if (timed) ECCKD_HIP_CHECK(hipEventRecord(o->tev[2], ctx->stream));
@@ -1962,7 +2130,7 @@ static int opt_cost_grad_dev(ecckd_opt* o, const double* d_x, double* d_grad, do
   // (and, for the profile-sharded all-reduce, into the slot behind the gradient: ONE collective of nx + 1 doubles)
   double* h_cost = o->h_pin + 70;
   opt_mark_pending(h_cost, 1);
-  hipLaunchKernelGGL(k_opt_sum_cost, dim3(1), dim3(256), 0, ctx->stream, o->d_jcol, o->ncol, o->d_jb, o->nnode_active, prior ? 1 : 0,
+  hipLaunchKernelGGL(k_opt_sum_cost, dim3(1), dim3(256), 0, ctx->stream, o->d_jcol, o->ncol, o->d_jb, o->nnode_active * (size_t)o->grad_nchunk, prior ? 1 : 0,
                      o->d_pin + 70, reduce ? d_grad + o->nx : nullptr);
   ECCKD_HIP_CHECK(hipGetLastError());
   ECCKD_CHECK(opt_wait_slots(ctx, h_cost, 1));
@@ -2077,6 +2245,8 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   constexpr int NPART = LB_NPART;   // update: |q|^2, S.q, Y.q (1 + 2M) | pair dots (2 + 3M)
   ECCKD_CHECK(dalloc(&o->d_xn, n)); ECCKD_CHECK(dalloc(&o->d_gn, n + 1)); ECCKD_CHECK(dalloc(&o->d_dir, n));
   ECCKD_CHECK(dalloc(&o->d_q, n)); ECCKD_CHECK(dalloc(&o->d_S, (size_t)M * n)); ECCKD_CHECK(dalloc(&o->d_Y, (size_t)M * n));
+  ECCKD_HIP_CHECK(hipMemsetAsync(o->d_S, 0, (size_t)M * n * sizeof(double), ctx->stream));     // unused pairs are read (with zero weight)
+  ECCKD_HIP_CHECK(hipMemsetAsync(o->d_Y, 0, (size_t)M * n * sizeof(double), ctx->stream));
   ECCKD_CHECK(dalloc(&o->d_part, (size_t)(NPART + 2) * VEC_BLOCKS));
   if (bounded) {
     ECCKD_CHECK(dalloc(&o->d_xmin, n)); ECCKD_CHECK(dalloc(&o->d_xmax, n));
@@ -2095,7 +2265,10 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
   double* sc_step = o->d_pin + 64;
   double* h_rb = o->h_rb;
   double* h_step = o->h_rb + 64;
-  const dim3 vb(VEC_BLOCKS), vt(VEC_THREADS);
+  // one block of 16 waves per CU is what the update kernel's registers allow: no more blocks than CUs (a second, nearly empty
+  // round would cost a whole pass again)
+  const int nblk = (int)std::min<size_t>(std::min<size_t>(VEC_BLOCKS, (size_t)std::max(ctx->num_cu, 1)), std::max<size_t>(1, (n + VEC_THREADS - 1) / VEC_THREADS));
+  const dim3 vb(nblk), vt(VEC_THREADS);
   const double max_step = 2.0;  // minimizer.set_max_step_size(2.0), solve_adept.cpp:331
 
   // host side of the compact representation: S^T Y and Y^T Y of the stored pairs, by ring slot
@@ -2120,7 +2293,7 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
     for (int a = 0; a < M; ++a) none.slot[a] = 0;
     opt_mark_pending(h_rb, NPART);
     hipLaunchKernelGGL(k_lb_update, vb, vt, 0, ctx->stream, n, none, -1, x, x, g, g, bmin, bmax, o->d_q, o->d_S, o->d_Y, part_a);
-    hipLaunchKernelGGL(k_lb_finish, dim3(NPART), dim3(FIN_THREADS), 0, ctx->stream, part_a, sc);
+    hipLaunchKernelGGL(k_lb_finish, dim3(NPART), dim3(FIN_THREADS), 0, ctx->stream, part_a, nblk, sc);
     ECCKD_HIP_CHECK(hipGetLastError());
   }
   for (it = 0; it <= max_iterations; ++it) {
@@ -2243,7 +2416,7 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
     for (int a = 0; a < M; ++a) sp.slot[a] = a < hist ? ord[a] : 0;
     opt_mark_pending(h_rb, NPART);
     hipLaunchKernelGGL(k_lb_update, vb, vt, 0, ctx->stream, n, sp, pend_slot, x, xn, g, gn, bmin, bmax, o->d_q, o->d_S, o->d_Y, part_a);
-    hipLaunchKernelGGL(k_lb_finish, dim3(NPART), dim3(FIN_THREADS), 0, ctx->stream, part_a, sc);
+    hipLaunchKernelGGL(k_lb_finish, dim3(NPART), dim3(FIN_THREADS), 0, ctx->stream, part_a, nblk, sc);
     ECCKD_HIP_CHECK(hipGetLastError());
     pending = true;
     std::swap(x, xn);

@@ -383,6 +383,18 @@ int ecckd_lbl_band_fluxes_lw_ex(ecckd_ctx* ctx, int nlay, size_t nwav, const dou
                                 const double* d_wavenumber, const double* d_d_wavenumber, const void* d_od, int od_type,
                                 size_t od_stride, int nband, const int64_t* h_band_begin, const int64_t* h_band_end,
                                 double* h_flux_dn, double* h_flux_up, double* d_surf_dn, double* d_toa_up);
+/* The same with the zenith-angle quadrature of the external CKDMIP tool (namelist key nangle, test/run_ckd_lw.sh:28,
+ * test/copy_to_ckdmip_lw.sh:32): nangle = 0 is the classic two-stream form above (diffusivity 1.66); nangle = N > 0 integrates
+ * N Gauss-Legendre angles per hemisphere, flux = sum_k 2 w_k mu_k L(mu_k), each L(mu_k) the no-scattering recurrence of
+ * radiative_transfer_lw.cpp:27-60 along the slant path tau / mu_k.  N <= 16.  The CKDMIP tool is not part of the reference's
+ * sources: its node set is unpinned. */
+int ecckd_lbl_band_fluxes_lw_angles(ecckd_ctx* ctx, int nangle, int nlay, size_t nwav, const double* h_temperature_hl,
+                                    const double* d_wavenumber, const double* d_d_wavenumber, const void* d_od, int od_type,
+                                    size_t od_stride, int nband, const int64_t* h_band_begin, const int64_t* h_band_end,
+                                    double* h_flux_dn, double* h_flux_up, double* d_surf_dn, double* d_toa_up);
+/* Gauss-Legendre nodes mu_k (ascending) and weights w_k of n points on (0, 1): sum_k w_k f(mu_k) ~ int_0^1 f(mu) dmu. */
+int ecckd_gauss_legendre_01(int n, double* h_mu, double* h_weight);
+
 int ecckd_lbl_band_fluxes_sw_ex(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_sza, const double* d_ssi,
                                 const double* d_albedo, const void* d_od, int od_type, size_t od_stride, int nband,
                                 const int64_t* h_band_begin, const int64_t* h_band_end, double* h_flux_dn_direct,

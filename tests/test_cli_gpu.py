@@ -990,8 +990,24 @@ def test_ckdmip_lw_stand_in(ctx, tmp_path):
         assert np.allclose(sb["spectral_flux_dn_surf"][col], want_dn, rtol=1e-10) and np.allclose(sb["spectral_flux_up_toa"][col], want_up, rtol=1e-10)
     gmap.close()
     f.close(); g.close()
-    # ---- errors: an angle quadrature is refused, so is a namelist without bands ----
-    (d / "bad.nam").write_text("&longwave_config\nnangle = 4,\nband_wavenumber1(1:1) = 0,\nband_wavenumber2(1:1) = 3260\n/\n")
+    # ---- nangle = 4, what test/run_ckd_lw.sh:28,83 and test/copy_to_ckdmip_lw.sh:32 write into the namelist: four Gauss-Legendre
+    # zenith angles per hemisphere instead of the two-stream diffusivity; same file layout, fluxes equal to the library's quadrature
+    (d / "lw4.nam").write_text((d / "lw.nam").read_text().replace("nangle = 0, ! classic", "nangle = 4,"))
+    r = run_tool("ckdmip_lw", "--config", "lw4.nam", "--scale", "0.5", "ideal_h2o.nc", "--const", "6e-4", "ideal_co2.nc", "--output", "lbl_4.nc", cwd=d)
+    assert r.returncode == 0, r.stderr + r.stdout
+    f, g = _nc(d / "lbl_tool.nc"), _nc(d / "lbl_4.nc")
+    for col in range(3):
+        h, c = ncio.read_spectrum(d / "ideal_h2o.nc", col), ncio.read_spectrum(d / "ideal_co2.nc", col)
+        od = 0.5 * h["optical_depth"] + (6e-4 / c["vmr_fl"])[:, None] * c["optical_depth"]
+        dn4, up4 = api.lbl_band_fluxes_lw(ctx, h["temperature_hl"], dev(wn), dev(dwn), dev(od), begin, end, nangle=4)
+        assert np.allclose(g.variables["band_flux_dn_lw"][col], dn4.T, rtol=3e-7, atol=1e-30)
+        assert np.allclose(g.variables["band_flux_up_lw"][col], up4.T, rtol=3e-7)
+        # the two-stream fluxes are an approximation of the same integral: close, not equal
+        two, four = f.variables["flux_up_lw"][col].astype(np.float64), g.variables["flux_up_lw"][col].astype(np.float64)
+        assert 0.0 < np.max(np.abs(two - four) / four) < 0.03
+    f.close(); g.close()
+    # ---- errors: more angles than the library integrates, a namelist without bands ----
+    (d / "bad.nam").write_text("&longwave_config\nnangle = 40,\nband_wavenumber1(1:1) = 0,\nband_wavenumber2(1:1) = 3260\n/\n")
     r = run_tool("ckdmip_lw", "--config", "bad.nam", "ideal_h2o.nc", "--output", "x.nc", cwd=d)
     assert r.returncode == 147 and "nangle" in r.stderr
     r = run_tool("ckdmip_lw", "ideal_h2o.nc", "--output", "x.nc", cwd=d)
@@ -1020,7 +1036,32 @@ def test_ckdmip_lw_stand_in(ctx, tmp_path):
     for k in ("flux_dn_lw", "flux_up_lw"):          # run_ckd's own fluxes come from the unrounded optical depths: FLOAT agreement
         assert np.allclose(b.variables[k][...], a.variables[k][...], rtol=2e-5, atol=1e-4), k
     assert b.variables["spectral_flux_dn_lw"].shape == a.variables["optical_depth"].shape[:1] + (nhl, a.variables["optical_depth"].shape[2])
-    a.close(); b.close()
+    # ... and with the namelist of test/run_ckd_lw.sh:76-90 (NANGLE=4): the quadrature on the g points' optical depths,
+    # checked against the same four angles evaluated with numpy
+    (e / "ckd4.nam").write_text("&longwave_config\noptical_depth_name = \"optical_depth\",\nnangle = 4,\niverbose = 3\n/\n")
+    r = run_tool("ckdmip_lw", "--config", "ckd4.nam", "--scenario", "present", "--ckd", "od.nc", "--output", "fluxes4.nc", cwd=e)
+    assert r.returncode == 0, r.stderr + r.stdout
+    c4 = _nc(e / "fluxes4.nc")
+    od = a.variables["optical_depth"][...].astype(np.float64)
+    pl = a.variables["planck_hl"][...].astype(np.float64) if "planck_hl" in a.variables else None
+    mu, wq = api.gauss_legendre_01(4)
+    if pl is not None:
+        want_dn = np.zeros_like(pl); want_up = np.zeros_like(pl)
+        for m, w_ in zip(mu, wq):
+            eps = 1.0 - np.exp(-od / m)
+            fac = np.where(eps > 1e-5, 1.0 - eps * m / np.where(od > 0, od, 1.0), 0.5 * eps)
+            dn_ = np.zeros_like(pl); up_ = np.zeros_like(pl)
+            for l in range(nhl - 1):
+                dn_[:, l + 1] = dn_[:, l] * (1 - eps[:, l]) + pl[:, l] * (eps[:, l] - fac[:, l]) + pl[:, l + 1] * fac[:, l]
+            up_[:, -1] = pl[:, -1]
+            for l in range(nhl - 2, -1, -1):
+                up_[:, l] = up_[:, l + 1] * (1 - eps[:, l]) + pl[:, l + 1] * (eps[:, l] - fac[:, l]) + pl[:, l] * fac[:, l]
+            want_dn += 2 * w_ * m * dn_; want_up += 2 * w_ * m * up_
+        assert np.allclose(c4.variables["spectral_flux_dn_lw"][...], want_dn, rtol=3e-5, atol=1e-6)
+        assert np.allclose(c4.variables["spectral_flux_up_lw"][...], want_up, rtol=3e-5, atol=1e-6)
+    diff = np.abs(c4.variables["flux_up_lw"][...].astype(np.float64) - b.variables["flux_up_lw"][...].astype(np.float64))
+    assert 0.0 < diff.max() < 0.03 * np.abs(b.variables["flux_up_lw"][...]).max()
+    a.close(); b.close(); c4.close()
 
 
 def test_ckdmip_sw_stand_in(ctx, tmp_path):

@@ -69,3 +69,65 @@ def test_lbl_band_fluxes_sw(ctx, oracle, with_albedo):
     assert np.allclose(sdn.cpu().numpy()[covered], fdn[-1][covered], rtol=1e-11, atol=1e-300)
     assert np.allclose(tup.cpu().numpy()[covered], fup[0][covered], rtol=1e-11, atol=1e-300)
     assert np.all(sdn.cpu().numpy()[~covered] == 0) and np.all(tup.cpu().numpy()[~covered] == 0)
+
+
+def test_lbl_band_fluxes_lw_angle_quadrature(ctx, oracle):
+    """nangle > 0 (the CKDMIP tool's zenith-angle quadrature, test/run_ckd_lw.sh:28): N Gauss-Legendre angles per hemisphere,
+    flux = sum_k 2 w_k mu_k L(mu_k), L the reference's no-scattering recurrence (radiative_transfer_lw.cpp:27-60) along the slant
+    path tau / mu_k.  Unpinned by the reference (the CKDMIP tool is not among its sources); checked here against (i) the same
+    angles evaluated one by one with numpy, (ii) convergence as N grows, (iii) the two-stream value lying next to the
+    converged one, and (iv) nangle = 0 being bit for bit the two-stream kernel of the reference's own scheme."""
+    from ecckd_amd import api, synthetic as syn
+    nlay, nwav = 30, 6001
+    p, wn, dwn, od = make_lw_case(nwav, nlay=nlay, seed=9, dtype="float64")
+    t_hl = syn.temperature_profile(p)
+    begin, end = np.array([0, 3000]), np.array([2999, nwav - 1])
+    dev = lambda a: torch.as_tensor(a, device=ctx.device)
+    planck = oracle.planck_function(t_hl, wn, dwn)
+
+    def numpy_angle(sec):
+        eps = 1.0 - np.exp(-sec * od)
+        fac = np.where(eps > 1.0e-5, 1.0 - (eps * (1.0 / sec)) / np.where(od > 0, od, 1.0), 0.5 * eps)
+        dn = np.zeros((nlay + 1, nwav)); up = np.zeros((nlay + 1, nwav))
+        for l in range(nlay):
+            dn[l + 1] = dn[l] * (1 - eps[l]) + planck[l] * (eps[l] - fac[l]) + planck[l + 1] * fac[l]
+        up[nlay] = planck[nlay]
+        for l in range(nlay - 1, -1, -1):
+            up[l] = up[l + 1] * (1 - eps[l]) + planck[l + 1] * (eps[l] - fac[l]) + planck[l] * fac[l]
+        return dn, up
+
+    res = {}
+    for n in (0, 1, 2, 4, 8, 16):
+        dn, up, sdn, tup = api.lbl_band_fluxes_lw(ctx, t_hl, dev(wn), dev(dwn), dev(od), begin, end, boundary=True, nangle=n)
+        res[n] = (dn, up, sdn.cpu().numpy(), tup.cpu().numpy())
+        if n == 0:
+            want_dn, want_up = numpy_angle(1.66)
+        else:
+            mu, w = api.gauss_legendre_01(n)
+            want_dn = np.zeros((nlay + 1, nwav)); want_up = np.zeros((nlay + 1, nwav))
+            for m, w_ in zip(mu, w):
+                d, u = numpy_angle(1.0 / m)
+                want_dn += 2 * w_ * m * d; want_up += 2 * w_ * m * u
+        for b in range(2):
+            sl = slice(begin[b], end[b] + 1)
+            # (1 - eps / (sec tau) next to the 1e-5 switch amplifies the last bit of exp by 1e5: 1e-8, not 1e-10)
+            assert np.allclose(dn[b], want_dn[:, sl].sum(1), rtol=1e-8, atol=1e-300), n
+            assert np.allclose(up[b], want_up[:, sl].sum(1), rtol=1e-8), n
+        assert np.allclose(res[n][2], want_dn[-1], rtol=1e-7, atol=1e-300) and np.allclose(res[n][3], want_up[0], rtol=1e-7, atol=1e-300)
+    # (iv) nangle = 0 is the plain entry point
+    dn0, up0 = api.lbl_band_fluxes_lw(ctx, t_hl, dev(wn), dev(dwn), dev(od), begin, end)
+    assert np.array_equal(dn0, res[0][0]) and np.array_equal(up0, res[0][1])
+    # (ii) convergence: successive refinements shrink; 8 and 16 angles agree to 1e-5
+    tot = {n: res[n][1].sum(0) for n in res}                       # broadband upwelling flux profile
+    err = {n: np.max(np.abs(tot[n] - tot[16]) / tot[16]) for n in (1, 2, 4, 8)}
+    assert err[1] > err[2] > err[4] > err[8] and err[8] < 1e-5 and err[4] < 1e-3
+    # (iii) the two-stream diffusivity approximates the same integral: within 2 % of the converged flux, and not better than 4 angles
+    e2s = np.max(np.abs(tot[0] - tot[16]) / tot[16])
+    assert err[4] < e2s < 0.02
+    # an isothermal, opaque column radiates sigma T^4 per band whatever the angles: sum_k 2 w_k mu_k = 1
+    od_thick = np.full((nlay, nwav), 50.0)
+    t_iso = np.full(nlay + 1, 250.0)
+    pl_iso = oracle.planck_function(t_iso, wn, dwn)
+    for n in (0, 3, 4):
+        dn, up = api.lbl_band_fluxes_lw(ctx, t_iso, dev(wn), dev(dwn), dev(od_thick), begin, end, nangle=n)
+        assert np.allclose(up[:, 0].sum(), pl_iso[0].sum(), rtol=1e-12) and np.allclose(dn[:, -1].sum(), pl_iso[-1].sum(), rtol=1e-12)
