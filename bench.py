@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--tolerance", type=float, default=0.0161)   # fsck, test/do_all_lw.sh:59-60
     ap.add_argument("--tolerance-tolerance", type=float, default=0.01)  # test/find_g_points_lw.sh
     ap.add_argument("--max-iterations", type=int, default=60)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 15)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 18)      # within 30x of the headline's 7.2e6 points
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lut-opt", action="store_true")
     ap.add_argument("--no-sw", action="store_true")
@@ -641,10 +641,22 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                                                                           / (256 * 4 * 2.4e9) * 1e3) / max(k1_ms / max(k1_calls, 1), 1e-12)}},
         }
         if args.config == 2:
-            # the shortwave sweep (k_rt_sw_bb) has no event slot in the library; its roofline figures
-            # are the rocprofv3 ones in profiles/ (fp64-VALU-bound, traffic = algorithmic bytes)
-            out["roofline"] = {"bound": "hbm", "kernel": "k_rt_sw (not instrumented in this leg; see profiles/r01_pmc_k_rt_sw_bb_fast.md)",
-                               "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+            # the shortwave sweep: one launch evaluates an interval with both scaled fits from ONE fetch of the column of
+            # optical depths, (nlay + 1) * 8 B per point (background optical depths + solar irradiance); it is bound by fp64
+            # issue (2 x 2 nlay exp per point), the HBM figure is reported against the same peak for comparison
+            sw_calls, sw_ms, sw_pts = ctx.profile_get("k_rt_sw_bb")
+            sw_all, _, sw_all_pts = ctx.profile_get("k_rt_sw_bb.all")
+            sw_bytes = (nlay + 1) * 8
+            sw_gbs = sw_pts * sw_bytes / (sw_ms * 1e-3) / 1e9 if sw_ms > 0 else 0.0
+            exp_per_pt = 2 * 2 * nlay                      # two fits x (direct + reflected beam) x nlay
+            out["roofline"] = {"bound": "hbm", "kernel": "k_rt_sw_bb_fast", "achieved": sw_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": sw_gbs / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes_per_point": sw_bytes, "launches": sw_all, "launches_timed": sw_calls,
+                               "avg_launch_ms": sw_ms / max(sw_calls, 1), "points_per_launch": sw_pts / max(sw_calls, 1),
+                               "binding_roof": {"bound": "fp64 issue", "exp_per_point": exp_per_pt,
+                                                "exp_per_second": sw_pts * exp_per_pt / max(sw_ms * 1e-3, 1e-12),
+                                                "note": "~21 fp64 VALU instructions per exp (fastmath.hpp): see profiles/r01_pmc_k_rt_sw_bb_fast.md"},
+                               "timing": "HIP events around every %d-th batch's sweep launches inside the timed region" % max(1, args.profile_stride)}
         if h2d_ms is not None:
             step_ms = dt * 1e3 / args.steps
             out["pcie_inclusive"] = {"h2d_ms_per_step": h2d_ms, "bytes_per_step": 2 * nlay * nwav * 4,
@@ -660,11 +672,25 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
             out["lut_opt"]["shortwave"] = lut_opt_bench(ctx, args.lut_opt_iterations, sw=True)
         if world == 1 and not args.no_sw and args.config == 1:
             out["sw_find_g"] = sw_find_g_bench(ctx)
+        if world == 1 and not args.no_e2e and args.config == 1:
+            # the end-to-end number north_star asks for: the do_all_lw chain with the tools as fresh child processes at the
+            # headline size against the CPU oracle chain (tools/e2e_bench.py); a failure there must not cost the headline line
+            try:
+                del od, bg
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import e2e_bench
+                out["e2e"] = e2e_bench.run(ctx, nwav=nwav, nlay=nlay)
+            except Exception as exc:                                      # noqa: BLE001
+                import traceback
+                out["e2e"] = {"error": repr(exc), "traceback": traceback.format_exc()[-1500:]}
         if world == 1 and not args.no_cpu and args.config == 1:
             cb = cpu_baseline(args, args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance, args.tolerance_tolerance,
                               args.max_iterations, dev)
             out["cpu_baseline"] = {"value": cb["points"] / cb["seconds"], "unit": "wavenumber-points/s",
                                    "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+                                   "nwav": args.cpu_sample, "ng": cb["ng"], "n_pass": cb["n_pass"], "search_status": cb["status"],
+                                   "seconds": cb["seconds"], "headline_over_sample_points": nwav / args.cpu_sample,
                                    "sample": "oracle/oracle_chain.c (C end to end: reorder + gas preparation + the reference's "
                                              "equipartition.cpp from oracle/_ref over the oracle's calc_error, OpenMP at the "
                                              "reference's sites), same generator at nwav=%d: ng=%d, N_pass=%.1f (every request "

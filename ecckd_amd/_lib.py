@@ -111,6 +111,7 @@ SIGNATURES = {
     "ecckd_partition_n": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.POINTER(C.c_int)]),
     "ecckd_partition_e": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int),
                                     _c_double_p, _c_double_p, C.c_int, C.POINTER(C.c_int)]),
+    "ecckd_partition_set_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ecckd_partition_status_string": (C.c_char_p, [C.c_int]),
     "ecckd_opt_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "ecckd_opt_destroy": (C.c_int, [C.c_void_p]),
@@ -276,6 +277,7 @@ class OptConfig(C.Structure):
                 ("temperature_corr", C.c_double), ("conc_corr", C.c_double), ("cap_relative_linear", C.c_double)]
 
 
+TRACE_FN = C.CFUNCTYPE(None, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p)
 ERROR_FN = C.CFUNCTYPE(C.c_int, C.c_int, _c_double_p, _c_double_p, _c_double_p, C.c_void_p)
 EVALUATOR_FN = C.CFUNCTYPE(C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)   # ecckd_evaluator_fn
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_double, C.c_double, C.c_void_p)                 # ecckd_progress_fn

@@ -243,9 +243,12 @@ class PartitionSearch:
     (ecckd_partition_*; replaces class Equipartition, equipartition.h:63-208)."""
 
     def __init__(self, error_fn, resolution=0.0, partition_tolerance=0.05, partition_max_iterations=20,
-                 line_search_max_iterations=10, cubic=False, minimize_frac_range=True):
+                 line_search_max_iterations=10, cubic=False, minimize_frac_range=True, trace=False):
         self.lib = _lib.load_library()
         self.calls = []
+        # trace=True: self.events lists, in order, ("req", bound1[], bound2[], error[]) for every evaluation and
+        # ("dec", site, lhs, rhs, taken) for every comparison that steers the search (ecckd_partition_set_trace)
+        self.events = [] if trace else None
 
         def cb(n, b1, b2, err, _user):
             try:
@@ -255,6 +258,8 @@ class PartitionSearch:
                 for i in range(n):
                     err[i] = e[i]
                 self.calls.append((bb1, bb2, list(e)))
+                if self.events is not None:
+                    self.events.append(("req", bb1, bb2, list(e)))
                 return 0
             except Exception:  # surfaced as PROCESSING_ERROR by the search
                 import traceback
@@ -267,6 +272,10 @@ class PartitionSearch:
         self.handle = h
         check(self.lib.ecckd_partition_configure(h, resolution, partition_tolerance, partition_max_iterations,
                                                  line_search_max_iterations, int(cubic), int(minimize_frac_range)))
+        if trace:
+            ev = self.events
+            self._trace_cb = _lib.TRACE_FN(lambda site, lhs, rhs, taken, _u: ev.append(("dec", site, lhs, rhs, taken)))
+            check(self.lib.ecckd_partition_set_trace(h, C.cast(self._trace_cb, C.c_void_p), None))
 
     def __del__(self):
         try:

@@ -35,6 +35,7 @@ struct ecckd_ctx {
   struct KernelStat { double ms = 0.0; double units = 0.0; long long calls = 0; double all_units = 0.0; long long all_calls = 0; };
   KernelStat stat_rt_lw;     // k_rt_lw_bb: units = wavenumber points processed
   KernelStat stat_key_lw;    // k_reorder_key_lw: units = wavenumber points
+  KernelStat stat_rt_sw;     // k_rt_sw_bb: units = wavenumber points (both fits of a total-transmission evaluation: one launch)
   KernelStat stat_sort;      // whole K3 pass sequence: units = keys sorted
   // Caching device allocator (ecckd::dev_malloc / dev_release): blocks released by a handle are kept
   // and handed out again for a request of the same size, so that preparing gas after gas (13 GB of

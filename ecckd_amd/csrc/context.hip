@@ -242,6 +242,7 @@ int ecckd_profile_enable(ecckd_ctx* ctx, int on) {
   ctx->profile_seq = 0;
   ctx->stat_rt_lw = ecckd_ctx::KernelStat();
   ctx->stat_key_lw = ecckd_ctx::KernelStat();
+  ctx->stat_rt_sw = ecckd_ctx::KernelStat();
   ctx->stat_sort = ecckd_ctx::KernelStat();
   return ECCKD_OK;
 }
@@ -251,7 +252,14 @@ int ecckd_profile_get(ecckd_ctx* ctx, const char* kernel, long long* calls, doub
   const ecckd_ctx::KernelStat* st = nullptr;
   if (!strcmp(kernel, "k_rt_lw_bb")) st = &ctx->stat_rt_lw;
   else if (!strcmp(kernel, "k_reorder_key_lw")) st = &ctx->stat_key_lw;
+  else if (!strcmp(kernel, "k_rt_sw_bb")) st = &ctx->stat_rt_sw;
   else if (!strcmp(kernel, "radix_sort")) st = &ctx->stat_sort;
+  if (!strcmp(kernel, "k_rt_sw_bb.all")) {
+    if (calls) *calls = ctx->stat_rt_sw.all_calls;
+    if (ms) *ms = 0.0;
+    if (units) *units = ctx->stat_rt_sw.all_units;
+    return ECCKD_OK;
+  }
   if (!strcmp(kernel, "k_rt_lw_bb.all")) {     // every launch since profile_enable, timed or not (ms = 0)
     if (calls) *calls = ctx->stat_rt_lw.all_calls;
     if (ms) *ms = 0.0;

@@ -2641,6 +2641,10 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
     const size_t part_stride = (size_t)nchunks * 2 * nhl;
     static const bool no_same = std::getenv("ECCKD_SW_NO_SAME") != nullptr;   // A/B knob
     const bool same_exp = g->cos_sza == 0.5 && !no_same;
+    // HIP events round the sweep launches of every profile_stride-th batch (ecckd_profile_enable), as for the longwave sweep
+    const bool timed_sw = ctx->profile && (ctx->profile_seq++ % ctx->profile_stride) == 0;
+    if (ctx->profile) { ctx->stat_rt_sw.all_calls += 1; ctx->stat_rt_sw.all_units += (double)total_pts; }
+    if (timed_sw) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
     for (int pass = 0; pass < (dual ? 1 : npass); ++pass) {
       double* part = d_part + (size_t)pass * part_stride;
 #define ECCKD_SW_SWEEP(NL, NF, SM, FIT)                                                                                         \
@@ -2656,6 +2660,7 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
       else if (nlay == 30) { if (same_exp) ECCKD_SW_SWEEP(30, 1, true, fit1); else ECCKD_SW_SWEEP(30, 1, false, fit1); }
 #undef ECCKD_SW_SWEEP
     }
+    if (timed_sw) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
     // both evaluations in one launch; the errors go straight into the pinned host buffer (a few bytes over PCIe)
     SwTruthRows rows;
     rows.rH[0] = is_tt ? R.HL : R.H;      rows.rH[1] = R.HH;
@@ -2666,6 +2671,14 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
     ECCKD_HIP_CHECK(hipGetLastError());
     ECCKD_CHECK(wait_for_slots(ctx, h_err, nslots));
     for (int k = 0; k < n; ++k) error[k] = is_tt ? 0.5 * (h_err[k] + h_err[n + k]) : h_err[k];  // :386
+    if (timed_sw) {
+      float ms = 0.f;
+      ECCKD_HIP_CHECK(hipEventSynchronize(ctx->pev1));
+      ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1));
+      ctx->stat_rt_sw.ms += ms;
+      ctx->stat_rt_sw.units += (double)total_pts;
+      ctx->stat_rt_sw.calls += 1;
+    }
     return ECCKD_OK;
   }
   if (g_turn.on) t_first = std::chrono::steady_clock::now();
@@ -2866,6 +2879,13 @@ int ecckd_partition_e(ecckd_partition* p, double target_error, double bound0, do
   ECCKD_REQUIRE(n <= capacity, "ecckd_partition_e: %d intervals exceed the caller's capacity %d", n, capacity);
   std::memcpy(bounds, b.data(), (size_t)(n + 1) * sizeof(double));
   std::memcpy(error, e.data(), (size_t)n * sizeof(double));
+  return ECCKD_OK;
+}
+
+int ecckd_partition_set_trace(ecckd_partition* p, ecckd_trace_fn fn, void* user) {
+  ECCKD_REQUIRE(p, "ecckd_partition_set_trace: NULL handle");
+  if (fn) p->ps->set_trace([fn, user](int site, double lhs, double rhs, int taken) { fn(site, lhs, rhs, taken, user); });
+  else p->ps->set_trace(nullptr);
   return ECCKD_OK;
 }
 

@@ -294,32 +294,36 @@ __global__ void k_opt_forward_adjoint(
   for (int t = threadIdx.x; t < nhl * nband; t += blockDim.x) { s_gdn[t] = 0.0; s_gup[t] = 0.0; }
   __syncthreads();
   double jpart = 0.0;
-  // heating-rate terms: thread per layer (the broadband residual needs all bands of a layer)
-  for (int l = threadIdx.x; l < nlay; l += blockDim.x) {
-    double rsum = 0.0;
-    for (int b = 0; b < nband; ++b) {
-      const double hrf = cv[l] * (s_bdn[(l + 1) * nband + b] - s_bdn[l * nband + b] -
-                                  up_in_hr * (s_bup[(l + 1) * nband + b] - s_bup[l * nband + b]));
-      rsum += hrf - hrt[l * nband + b];
-    }
-    for (int b = 0; b < nband; ++b) {
-      const double hrf = cv[l] * (s_bdn[(l + 1) * nband + b] - s_bdn[l * nband + b] -
-                                  up_in_hr * (s_bup[(l + 1) * nband + b] - s_bup[l * nband + b]));
-      const double r = hrf - hrt[l * nband + b];
-      jpart += spec_scale * hr_weight * hr_weight * lw[l] * r * r;
-      const double dhr = 2.0 * hr_weight * hr_weight * lw[l] * (spec_scale * r + broadband_weight * rsum);
-      // hr_l = conv_l * (dn[l+1] - dn[l] - up[l+1] + up[l]); layer l owns these four slots of
-      // the two half levels it touches -> accumulate per (l) into separate arrays to avoid races
-      atomicAdd(&s_gdn[(l + 1) * nband + b], dhr * cv[l]);
-      atomicAdd(&s_gdn[l * nband + b], -dhr * cv[l]);
-      if (!do_sw) {
-        atomicAdd(&s_gup[(l + 1) * nband + b], -dhr * cv[l]);
-        atomicAdd(&s_gup[l * nband + b], dhr * cv[l]);
+  // heating-rate terms: thread per layer (the broadband residual needs all bands of a layer).  A half level receives the
+  // contributions of the layer above and of the layer below it: the even layers add theirs first, then the odd ones - each
+  // slot has ONE writer per pass, a fixed order without atomics
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int l = threadIdx.x; l < nlay; l += blockDim.x) {
+      if ((l & 1) != pass) continue;
+      double rsum = 0.0;
+      for (int b = 0; b < nband; ++b) {
+        const double hrf = cv[l] * (s_bdn[(l + 1) * nband + b] - s_bdn[l * nband + b] -
+                                    up_in_hr * (s_bup[(l + 1) * nband + b] - s_bup[l * nband + b]));
+        rsum += hrf - hrt[l * nband + b];
       }
+      for (int b = 0; b < nband; ++b) {
+        const double hrf = cv[l] * (s_bdn[(l + 1) * nband + b] - s_bdn[l * nband + b] -
+                                    up_in_hr * (s_bup[(l + 1) * nband + b] - s_bup[l * nband + b]));
+        const double r = hrf - hrt[l * nband + b];
+        jpart += spec_scale * hr_weight * hr_weight * lw[l] * r * r;
+        const double dhr = 2.0 * hr_weight * hr_weight * lw[l] * (spec_scale * r + broadband_weight * rsum);
+        // hr_l = conv_l * (dn[l+1] - dn[l] - up[l+1] + up[l])
+        s_gdn[(l + 1) * nband + b] += dhr * cv[l];
+        s_gdn[l * nband + b] += -dhr * cv[l];
+        if (!do_sw) {
+          s_gup[(l + 1) * nband + b] += -dhr * cv[l];
+          s_gup[l * nband + b] += dhr * cv[l];
+        }
+      }
+      jpart += broadband_weight * hr_weight * hr_weight * lw[l] * rsum * rsum;
     }
-    jpart += broadband_weight * hr_weight * hr_weight * lw[l] * rsum * rsum;
+    __syncthreads();
   }
-  __syncthreads();
   // boundary-flux and flux-profile terms: thread per half level
   for (int i = threadIdx.x; i < nhl; i += blockDim.x) {
     const bool is_surf = (i == nlay), is_toa = (i == 0);

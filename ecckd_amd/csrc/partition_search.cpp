@@ -18,8 +18,13 @@
 
 namespace ecckd {
 
+// the comparisons that steer the search, numbered for the decision trace (PartitionSearch::set_trace): 1 line search;
+// 2-10 equipartition_2; 12-15 equipartition_n; 16-17 equipartition_e; 18-26 next_bound_below; 27-35 next_bound_above
+#define LT(site, a, b) decide_lt((site), (a), (b))
+#define GT(site, a, b) decide_gt((site), (a), (b))
+#define EQ(site, a, b) decide_eq((site), (a), (b))
+
 namespace {
-inline double max_like_std(double a, double b) { return (a < b) ? b : a; }
 
 // abound <- ascale*abound + bscale*bbound, ni+1 values (equipartition.cpp:23-28)
 inline void blend(int ni, double* a, const double* b, double ascale, double bscale) {
@@ -82,7 +87,8 @@ int PartitionSearch::line_search(int ni, double* bounds, double* newbounds, doub
     calc_error_all(ni, newbounds, error);
     errors_up_to_date_ = false;
     if (eval_status_) return PS_FAILURE;
-    if (cost_function(ni, error) < start_cost) {
+    const double trial_cost = cost_function(ni, error);
+    if (LT(1, trial_cost, start_cost)) {
       blend(ni, bounds, newbounds, 0.0, 1.0);
       errors_up_to_date_ = true;
       return PS_SUCCESS;
@@ -105,7 +111,7 @@ int PartitionSearch::equipartition_2(double* bounds, double* error) {
   double ne[2] = {error[0], error[1]};
   int left = partition_max_iterations_;
 
-  if (error[0] > error[1]) {
+  if (GT(2, error[0], error[1])) {
     // the middle bound is too far right: march it left until the sign flips
     bound_right = bounds[1];
     ediff_right = error[1] - error[0];
@@ -113,7 +119,7 @@ int PartitionSearch::equipartition_2(double* bounds, double* error) {
       nb[1] = (-ediff_right * nb[0] + (ne[0] + ediff_right) * nb[1]) / ne[0];
       calc_error_all(2, nb, ne);
       if (eval_status_) return PS_FAILURE;
-      if (ne[0] < ne[1]) {
+      if (LT(3, ne[0], ne[1])) {
         bound_left = nb[1];
         ediff_left = ne[1] - ne[0];
         break;
@@ -128,7 +134,7 @@ int PartitionSearch::equipartition_2(double* bounds, double* error) {
       nb[1] = (ediff_left * nb[2] + (ne[1] - ediff_left) * nb[1]) / ne[1];
       calc_error_all(2, nb, ne);
       if (eval_status_) return PS_FAILURE;
-      if (ne[0] > ne[1]) {
+      if (GT(4, ne[0], ne[1])) {
         bound_right = nb[1];
         ediff_right = ne[1] - ne[0];
         break;
@@ -148,17 +154,17 @@ int PartitionSearch::equipartition_2(double* bounds, double* error) {
     if (eval_status_) return PS_FAILURE;
     const double ediff = ne[1] - ne[0];
     frac_error = 0.5 * std::fabs(ediff) / (ne[0] + ne[1]);
-    if (frac_error < partition_tolerance_ && frac_error < frac_error_orig) {
+    if (LT(5, frac_error, partition_tolerance_) && LT(6, frac_error, frac_error_orig)) {
       bounds[1] = nb[1];
       error[0] = ne[0];
       error[1] = ne[1];
       errors_up_to_date_ = true;
       return PS_SUCCESS;
-    } else if (frac_error == prev_frac_error) {
+    } else if (EQ(7, frac_error, prev_frac_error)) {
       if (stalled) break;
       stalled = true;
     }
-    if (ediff < 0) {
+    if (LT(8, ediff, 0.0)) {
       ediff_right = ediff;
       bound_right = nb[1];
     } else {
@@ -169,12 +175,12 @@ int PartitionSearch::equipartition_2(double* bounds, double* error) {
     --left;
   }
 
-  if (!(frac_error < frac_error_orig)) return PS_NO_PROGRESS;
+  if (!LT(9, frac_error, frac_error_orig)) return PS_NO_PROGRESS;
   bounds[1] = nb[1];
   error[0] = ne[0];
   error[1] = ne[1];
   errors_up_to_date_ = true;
-  if (bound_right - bound_left < resolution_) return PS_RESOLUTION_LIMIT_REACHED;
+  if (LT(10, bound_right - bound_left, resolution_)) return PS_RESOLUTION_LIMIT_REACHED;
   if (!left) return PS_MAX_ITERATIONS_REACHED;
   return PS_SUCCESS;
 }
@@ -196,7 +202,7 @@ int PartitionSearch::equipartition_n(int ni, double* bounds_out, double* error) 
       errors_up_to_date_ = true;
     }
     if (eval_status_) { status = PS_FAILURE; break; }
-    if (cost_function(ni, error) < partition_tolerance_) break;
+    if (LT(12, cost_function(ni, error), partition_tolerance_)) break;
 
     // move every interior bound to where the cumulative error (piecewise linear
     // or cubic in the bound) reaches an equal share
@@ -208,7 +214,7 @@ int PartitionSearch::equipartition_n(int ni, double* bounds_out, double* error) 
     int k = 0;
     for (int j = 1; j < ni; ++j) {
       const double target = share * j;
-      while (k + 1 < ni && cum[k + 1] < target) ++k;
+      while (k + 1 < ni && LT(13, cum[k + 1], target)) ++k;
       if (cubic_interpolation_) {
         const double u = (target - cum[k]) / (cum[k + 1] - cum[k]);
         const double u2 = u * u;
@@ -227,7 +233,7 @@ int PartitionSearch::equipartition_n(int ni, double* bounds_out, double* error) 
     if (resolution_ > 0.0) {
       bool moved = false;
       for (int i = 1; i < ni; ++i) {
-        if (std::fabs(trial[i] - bounds[i]) > resolution_) { moved = true; break; }
+        if (GT(14, std::fabs(trial[i] - bounds[i]), resolution_)) { moved = true; break; }
       }
       if (!moved) {
         for (int i = 0; i <= ni; ++i) bounds_out[i] = bounds[i];
@@ -255,7 +261,7 @@ int PartitionSearch::equipartition_n(int ni, double* bounds_out, double* error) 
         }
         --shuffles_left;
         if (eval_status_) { status = PS_FAILURE; break; }
-        if (cost_function(ni, error) < partition_tolerance_) {
+        if (LT(15, cost_function(ni, error), partition_tolerance_)) {
           status = PS_SUCCESS;
           break;
         } else if (stuck >= ni * 2 - 3) {
@@ -285,7 +291,7 @@ int PartitionSearch::equipartition_e(double target_error, double bound0, double 
   const double upper_bound =
       next_bound_below(target_error, bound0, boundn, 0.05 * bound0 + 0.95 * boundn, &upper_error);
   if (eval_status_) return PS_FAILURE;
-  if (upper_bound == bound0) {
+  if (EQ(16, upper_bound, bound0)) {
     ni = 1;
     bounds.assign({bound0, boundn});
     error.assign({upper_error});
@@ -296,7 +302,7 @@ int PartitionSearch::equipartition_e(double target_error, double bound0, double 
   error.clear();
   // then fill upwards from bound0 until the topmost interval is met
   size_t i = 0;
-  while (bounds[i] < upper_bound) {
+  while (LT(17, bounds[i], upper_bound)) {
     double e = -1.0;
     double b = next_bound_above(target_error, bounds[i], upper_bound, 0.25 * bounds[i] + 0.75 * upper_bound, &e);
     if (eval_status_) return PS_FAILURE;
@@ -322,25 +328,26 @@ double PartitionSearch::next_bound_below(double target_error, double bound0, dou
   double error_test = (*error_test_value < 0.0) ? calc_error(bound1_test, bound2) : *error_test_value;
 
   for (int left = next_bound_max_iterations_;
-       left > 0 && (error_test > max_error || error_test < min_error); --left) {
+       left > 0 && (GT(18, error_test, max_error) || LT(19, error_test, min_error)); --left) {
     if (eval_status_) break;
-    if (error_test > target_error) {
+    if (GT(20, error_test, target_error)) {
       lo = bound1_test;
       error_lo = error_test;
     } else {
       hi = bound1_test;
       error_hi = error_test;
     }
-    if (lo == hi) break;
-    if (error_lo > 0.0) {
+    if (EQ(21, lo, hi)) break;
+    if (GT(22, error_lo, 0.0)) {
       bound1_test = ((target_error - error_hi) * lo + (error_lo - target_error) * hi) / (error_lo - error_hi);
-      if (error_hi == 0.0) {
+      if (EQ(23, error_hi, 0.0)) {
         bound1_test = 0.5 * (bound1_test + hi);
-      } else if (error_test < min_error && error_lo > 2.0 * max_error) {
+      } else if (LT(24, error_test, min_error) && GT(25, error_lo, 2.0 * max_error)) {
         bound1_test = 0.75 * bound1_test + 0.25 * lo;
       }
     } else {
-      bound1_test = max_like_std(lo, hi - 0.5 * target_error * (bound2 - hi) / error_hi);
+      const double extrapolated = hi - 0.5 * target_error * (bound2 - hi) / error_hi;
+      bound1_test = LT(26, lo, extrapolated) ? extrapolated : lo;      // std::max(lo, extrapolated)
     }
     error_test = calc_error(bound1_test, bound2);
   }
@@ -357,25 +364,26 @@ double PartitionSearch::next_bound_above(double target_error, double bound1, dou
   double error_test = (*error_test_value < 0.0) ? calc_error(bound1, bound2_test) : *error_test_value;
 
   for (int left = next_bound_max_iterations_;
-       left > 0 && (error_test > max_error || error_test < min_error); --left) {
+       left > 0 && (GT(27, error_test, max_error) || LT(28, error_test, min_error)); --left) {
     if (eval_status_) break;
-    if (error_test > target_error) {
+    if (GT(29, error_test, target_error)) {
       hi = bound2_test;
       error_hi = error_test;
     } else {
       lo = bound2_test;
       error_lo = error_test;
     }
-    if (lo == hi) break;
-    if (error_hi > 0.0) {
+    if (EQ(30, lo, hi)) break;
+    if (GT(31, error_hi, 0.0)) {
       bound2_test = ((target_error - error_lo) * hi + (error_hi - target_error) * lo) / (error_hi - error_lo);
-      if (error_lo == 0.0) {
+      if (EQ(32, error_lo, 0.0)) {
         bound2_test = 0.5 * (bound2_test + lo);
-      } else if (error_test < min_error && error_lo > 2.0 * max_error) {
+      } else if (LT(33, error_test, min_error) && GT(34, error_lo, 2.0 * max_error)) {
         bound2_test = 0.75 * bound2_test + 0.25 * hi;
       }
     } else {
-      bound2_test = max_like_std(hi, hi - 0.5 * target_error * (lo - bound1) / error_lo);
+      const double extrapolated = hi - 0.5 * target_error * (lo - bound1) / error_lo;
+      bound2_test = LT(35, hi, extrapolated) ? extrapolated : hi;      // std::max(hi, extrapolated)
     }
     error_test = calc_error(bound1, bound2_test);
   }

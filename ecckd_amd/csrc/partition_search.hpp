@@ -63,6 +63,11 @@ public:
   // non-zero once an evaluation has failed; the search then unwinds with PS_FAILURE
   int evaluator_status() const { return eval_status_; }
 
+  // Decision trace (audits only; tests/test_decision_trace_gpu.py): every floating-point comparison that steers the search
+  // is reported as (site, lhs, rhs, outcome) in the order it is taken.  The sites are numbered in partition_search.cpp.
+  using Trace = std::function<void(int site, double lhs, double rhs, int taken)>;
+  void set_trace(Trace t) { trace_ = std::move(t); }
+
 private:
   double calc_error(double b1, double b2);
   double next_bound_above(double target_error, double bound1, double boundn, double bound2_test,
@@ -72,7 +77,16 @@ private:
   int equipartition_2(double* bounds, double* error);
   int line_search(int ni, double* bounds, double* newbounds, double* error);
 
+  bool decide(int site, double lhs, double rhs, bool taken) const {
+    if (trace_) trace_(site, lhs, rhs, taken ? 1 : 0);
+    return taken;
+  }
+  bool decide_lt(int site, double a, double b) const { return decide(site, a, b, a < b); }
+  bool decide_gt(int site, double a, double b) const { return decide(site, a, b, a > b); }
+  bool decide_eq(int site, double a, double b) const { return decide(site, a, b, a == b); }
+
   Evaluator evaluate_;
+  Trace trace_;
   int eval_status_ = 0;
   // defaults of equipartition.h:191-205
   double next_bound_error_tolerance_ = 0.05;

@@ -248,6 +248,11 @@ int ecckd_partition_n(ecckd_partition* p, int ni, double* bounds, double* error,
 int ecckd_partition_e(ecckd_partition* p, double target_error, double bound0, double boundn,
                       int* ni, double* bounds, double* error, int capacity, int* status);
 const char* ecckd_partition_status_string(int status);
+/* Audit hook: every floating-point comparison that steers the search is reported, in the order it is taken, as (site, lhs,
+ * rhs, outcome); the sites are numbered in csrc/partition_search.cpp.  fn = NULL switches it off.  The search itself is
+ * unchanged (tests/test_partition_search.py runs with and without). */
+typedef void (*ecckd_trace_fn)(int site, double lhs, double rhs, int taken, void* user);
+int ecckd_partition_set_trace(ecckd_partition* p, ecckd_trace_fn fn, void* user);
 
 /* One band of the main loop, find_g_points.cpp:1152-1266 (no sub-bands / base split):
  * equipartition_e to the heating-rate tolerance, restart with equipartition_n from

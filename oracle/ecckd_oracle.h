@@ -198,6 +198,14 @@ double orc_calc_cost_function_ckd_lw_ad(int nlay, int ng, int nband, const doubl
                                         double spectral_boundary_weight, const double* layer_weight,
                                         const double* relative_ckd_flux_dn, const double* relative_ckd_flux_up,
                                         const int* band_mapping, double* d_od);
+double orc_calc_cost_function_ckd_sw_ad(int nlay, int ng, int nband, double cos_sza, const double* pressure_hl,
+                                        const double* ssi, const double* albedo, const double* optical_depth,
+                                        const double* flux_dn, const double* flux_up, const double* hr,
+                                        const double* spectral_flux_dn_surf, double flux_weight,
+                                        double flux_profile_weight, double broadband_weight,
+                                        const double* spectral_boundary_weights, const double* layer_weight,
+                                        const double* relative_ckd_flux_dn, const double* relative_ckd_flux_up,
+                                        const int* band_mapping, double* d_od);
 int orc_ckd_optical_depth_ad(int ng, int nt, int np, const double* log_pressure, const double* temperature,
                              int conc_dependence, int nconc, const double* vmr_lut, double reference_vmr, int ncol, int nlay,
                              const double* pressure_hl, const double* temperature_fl, const double* vmr_fl,
@@ -224,4 +232,5 @@ int orc_find_g_lw_chain_ex(const char* refep_path, int nlay, size_t nwav, const 
 #ifdef __cplusplus
 }
 #endif
+void orc_chain_set_background64(const double* bg64);   /* oracle_chain.c */
 #endif

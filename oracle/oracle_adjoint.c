@@ -255,3 +255,172 @@ int orc_ckd_optical_depth_ad(int ng, int nt, int np, const double* log_pressure,
     }
   return 0;
 }
+
+/* Shortwave twin: cost of one profile as orc_calc_cost_function_ckd_sw (calc_cost_function_sw.cpp:116-277) and
+ * d_od[nlay][ng] += d cost / d optical_depth, reverse mode by hand of the oracle's OWN forward statements
+ * (radiative_transfer_direct_sw / _norayleigh_sw, radiative_transfer_sw.cpp:26-77; the all-albedo <= 0 direct-only branch
+ * :145-150; band sums; heating rate from the direct beam :197; per-band terms with the twenty-fold top-of-atmosphere weight
+ * :214; the broadband mix only if broadband_weight > 0 :243 and its upwelling parts only if all albedos > 0 :252, :264; the
+ * per-g boundary term :271-274).  Shares no code with the device adjoint. */
+double orc_calc_cost_function_ckd_sw_ad(int nlay, int ng, int nband, double cos_sza, const double* pressure_hl,
+                                        const double* ssi, const double* albedo, const double* optical_depth,
+                                        const double* flux_dn, const double* flux_up, const double* hr,
+                                        const double* spectral_flux_dn_surf, double flux_weight,
+                                        double flux_profile_weight, double broadband_weight,
+                                        const double* spectral_boundary_weights, const double* layer_weight,
+                                        const double* relative_ckd_flux_dn, const double* relative_ckd_flux_up,
+                                        const int* band_mapping, double* d_od) {
+  static const double hr_weight = 3600.0 * 24.0;
+  const double W2 = hr_weight * hr_weight;
+  const int nhl = nlay + 1;
+  const size_t nlg = (size_t)nlay * ng, nhg = (size_t)nhl * ng, nhb = (size_t)nhl * nband;
+  const double minus_sec_sza = -1.0 / cos_sza;
+  double* td = (double*)malloc(nlg * sizeof(double));    /* exp(-tau / mu0) */
+  double* tu = (double*)malloc(nlg * sizeof(double));    /* exp(-2 tau) */
+  double* dn = (double*)malloc(nhg * sizeof(double));    /* per-g fluxes before the relative-to subtraction */
+  double* up = (double*)calloc(nhg, sizeof(double));
+  double* alb_g = (double*)malloc((size_t)ng * sizeof(double));
+  double* fdn = (double*)calloc(nhb, sizeof(double));
+  double* fup = (double*)calloc(nhb, sizeof(double));
+  double* hrf = (double*)malloc((size_t)nlay * nband * sizeof(double));
+  double* a_fdn = (double*)calloc(nhb, sizeof(double));
+  double* a_fup = (double*)calloc(nhb, sizeof(double));
+  double* a_dn = (double*)calloc(nhg, sizeof(double));
+  double* a_up = (double*)calloc(nhg, sizeof(double));
+  double* conv = (double*)malloc((size_t)nlay * sizeof(double));
+  int all_nonpos = 1, all_pos = 1;
+  for (int b = 0; b < nband; ++b) {
+    if (albedo[b] > 0.0) all_nonpos = 0;
+    if (!(albedo[b] > 0.0)) all_pos = 0;
+  }
+  /* ---------------- forward ---------------- */
+  for (int g = 0; g < ng; ++g) alb_g[g] = all_nonpos ? 0.0 : albedo[band_mapping[g]];
+  for (size_t i = 0; i < nlg; ++i) {
+    td[i] = exp(minus_sec_sza * optical_depth[i]);
+    tu[i] = exp(-2.0 * optical_depth[i]);
+  }
+  for (int g = 0; g < ng; ++g) dn[g] = cos_sza * ssi[g];
+  for (int l = 0; l < nlay; ++l)
+    for (int g = 0; g < ng; ++g) dn[(size_t)(l + 1) * ng + g] = dn[(size_t)l * ng + g] * td[(size_t)l * ng + g];
+  if (!all_nonpos) {
+    for (int g = 0; g < ng; ++g) up[(size_t)nlay * ng + g] = dn[(size_t)nlay * ng + g] * alb_g[g];
+    for (int l = nlay - 1; l >= 0; --l)
+      for (int g = 0; g < ng; ++g) up[(size_t)l * ng + g] = up[(size_t)(l + 1) * ng + g] * tu[(size_t)l * ng + g];
+  }
+  for (int i = 0; i < nhl; ++i)
+    for (int g = 0; g < ng; ++g) {
+      const int b = band_mapping[g];
+      double d = dn[(size_t)i * ng + g], u = up[(size_t)i * ng + g];
+      if (relative_ckd_flux_dn) { d -= relative_ckd_flux_dn[(size_t)i * ng + g]; u -= relative_ckd_flux_up[(size_t)i * ng + g]; }
+      fdn[(size_t)i * nband + b] += d;
+      fup[(size_t)i * nband + b] += u;
+    }
+  for (int l = 0; l < nlay; ++l) {
+    conv[l] = -(ORC_ACCEL_GRAVITY / ORC_SPECIFIC_HEAT_AIR) / (pressure_hl[l + 1] - pressure_hl[l]);
+    for (int b = 0; b < nband; ++b)      /* heating rate from the direct beam only */
+      hrf[(size_t)l * nband + b] = conv[l] * (fdn[(size_t)(l + 1) * nband + b] - fdn[(size_t)l * nband + b]);
+  }
+  /* ---------------- cost and the adjoints of the band fluxes ---------------- */
+  const int mix = broadband_weight > 0.0;
+  const double alpha = mix ? (1.0 - broadband_weight) / nband : 1.0;     /* weight of the per-band terms */
+  double cost_bands = 0.0;
+  for (int b = 0; b < nband; ++b) {
+    double s = 0.0;
+    for (int l = 0; l < nlay; ++l) {
+      const double d = hrf[(size_t)l * nband + b] - hr[(size_t)l * nband + b];
+      s += layer_weight[l] * d * d;
+      const double a_h = alpha * W2 * 2.0 * layer_weight[l] * d;
+      a_fdn[(size_t)(l + 1) * nband + b] += a_h * conv[l];
+      a_fdn[(size_t)l * nband + b] -= a_h * conv[l];
+    }
+    const double ds = fdn[(size_t)nlay * nband + b] - flux_dn[(size_t)nlay * nband + b];
+    const double dt = fup[b] - flux_up[b];
+    cost_bands += W2 * s + flux_weight * (ds * ds + 20.0 * dt * dt);
+    a_fdn[(size_t)nlay * nband + b] += alpha * flux_weight * 2.0 * ds;
+    a_fup[b] += alpha * flux_weight * 40.0 * dt;
+    if (flux_profile_weight > 0.0)
+      for (int i = 1; i < nlay; ++i) {
+        const double iw = flux_profile_weight * 0.5 * (layer_weight[i - 1] + layer_weight[i]);
+        const double dd = fdn[(size_t)i * nband + b] - flux_dn[(size_t)i * nband + b];
+        const double du = fup[(size_t)i * nband + b] - flux_up[(size_t)i * nband + b];
+        cost_bands += iw * (dd * dd + du * du);
+        a_fdn[(size_t)i * nband + b] += alpha * iw * 2.0 * dd;
+        a_fup[(size_t)i * nband + b] += alpha * iw * 2.0 * du;
+      }
+  }
+  double cost = cost_bands * alpha;
+  if (mix) {
+    double sbb = 0.0, rs = 0.0, rt = 0.0;
+    for (int l = 0; l < nlay; ++l) {
+      double r = 0.0;
+      for (int b = 0; b < nband; ++b) r += hrf[(size_t)l * nband + b] - hr[(size_t)l * nband + b];
+      sbb += layer_weight[l] * (r * r);
+      const double a_h = broadband_weight * W2 * 2.0 * layer_weight[l] * r;
+      for (int b = 0; b < nband; ++b) {
+        a_fdn[(size_t)(l + 1) * nband + b] += a_h * conv[l];
+        a_fdn[(size_t)l * nband + b] -= a_h * conv[l];
+      }
+    }
+    for (int b = 0; b < nband; ++b) {
+      rs += fdn[(size_t)nlay * nband + b] - flux_dn[(size_t)nlay * nband + b];
+      rt += fup[b] - flux_up[b];
+    }
+    cost += broadband_weight * W2 * sbb + broadband_weight * flux_weight * (rs * rs);
+    for (int b = 0; b < nband; ++b) a_fdn[(size_t)nlay * nband + b] += broadband_weight * flux_weight * 2.0 * rs;
+    if (all_pos) {
+      cost += broadband_weight * flux_weight * (rt * rt);
+      for (int b = 0; b < nband; ++b) a_fup[b] += broadband_weight * flux_weight * 2.0 * rt;
+    }
+    if (flux_profile_weight > 0.0)
+      for (int i = 1; i < nlay; ++i) {
+        const double iw = flux_profile_weight * 0.5 * (layer_weight[i - 1] + layer_weight[i]);
+        double ed = 0.0, eu = 0.0;
+        for (int b = 0; b < nband; ++b) {
+          ed += fdn[(size_t)i * nband + b] - flux_dn[(size_t)i * nband + b];
+          eu += fup[(size_t)i * nband + b] - flux_up[(size_t)i * nband + b];
+        }
+        cost += broadband_weight * iw * (ed * ed);
+        for (int b = 0; b < nband; ++b) a_fdn[(size_t)i * nband + b] += broadband_weight * iw * 2.0 * ed;
+        if (all_pos) {
+          cost += broadband_weight * iw * (eu * eu);
+          for (int b = 0; b < nband; ++b) a_fup[(size_t)i * nband + b] += broadband_weight * iw * 2.0 * eu;
+        }
+      }
+  }
+  for (int i = 0; i < nhl; ++i)
+    for (int g = 0; g < ng; ++g) {
+      a_dn[(size_t)i * ng + g] = a_fdn[(size_t)i * nband + band_mapping[g]];
+      a_up[(size_t)i * ng + g] = a_fup[(size_t)i * nband + band_mapping[g]];
+    }
+  if (spectral_boundary_weights && spectral_flux_dn_surf) {               /* calc_cost_function_sw.cpp:271-274 */
+    double s = 0.0;
+    for (int g = 0; g < ng; ++g) {
+      double a = dn[(size_t)nlay * ng + g] - spectral_flux_dn_surf[g];
+      if (relative_ckd_flux_dn) a -= relative_ckd_flux_dn[(size_t)nlay * ng + g];
+      s += spectral_boundary_weights[g] * a * a;
+      a_dn[(size_t)nlay * ng + g] += spectral_boundary_weights[g] * 2.0 * a;
+    }
+    cost += s;
+  }
+  /* ---------------- reverse of the two sweeps ---------------- */
+  for (int g = 0; g < ng; ++g) {
+    if (!all_nonpos) {
+      for (int l = 0; l < nlay; ++l) {                     /* up(l) = up(l+1) tu(l) */
+        const size_t i = (size_t)l * ng + g;
+        const double au = a_up[i];
+        a_up[i + ng] += au * tu[i];
+        d_od[i] += au * up[i + ng] * tu[i] * (-2.0);
+      }
+      a_dn[(size_t)nlay * ng + g] += a_up[(size_t)nlay * ng + g] * alb_g[g];   /* up(nlay) = dn(nlay) albedo */
+    }
+    for (int l = nlay - 1; l >= 0; --l) {                  /* dn(l+1) = dn(l) td(l) */
+      const size_t i = (size_t)l * ng + g;
+      const double ad = a_dn[i + ng];
+      a_dn[i] += ad * td[i];
+      d_od[i] += ad * dn[i] * td[i] * minus_sec_sza;
+    }
+  }
+  free(td); free(tu); free(dn); free(up); free(alb_g); free(fdn); free(fup); free(hrf); free(a_fdn); free(a_fup);
+  free(a_dn); free(a_up); free(conv);
+  return cost;
+}

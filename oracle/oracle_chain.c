@@ -98,6 +98,11 @@ int orc_find_g_lw_chain(const char* refep_path, int nlay, size_t nwav, const dou
  * ordering; 1 = the same, and copied to planck_io[(nlay+1)*nwav] (the FIRST gas of a find_g_points run); 2 = planck_io is
  * used INSTEAD - the reference evaluates the matrix for the first gas only and keeps it for the later ones
  * (find_g_points.cpp:529, :970-984). */
+/* A merged background of several gases is a DOUBLE matrix (read_merged_spectrum.cpp:135-166 sums scaling * optical depth in
+ * double): handed over here for the NEXT call of orc_find_g_lw_chain_ex, which then ignores its FLOAT background argument. */
+static const double* g_background64 = NULL;
+void orc_chain_set_background64(const double* bg64) { g_background64 = bg64; }
+
 int orc_find_g_lw_chain_ex(const char* refep_path, int nlay, size_t nwav, const double* pressure_hl,
                            const double* temperature_hl, const double* wn, const double* dwn, const float* od32,
                            const float* bg32, double threshold_optical_depth, int nband, const double* band_bound1,
@@ -107,6 +112,8 @@ int orc_find_g_lw_chain_ex(const char* refep_path, int nlay, size_t nwav, const 
                            int64_t* rank1, int64_t* rank2, double* error_out, double* median_out, double* key_out,
                            double* planck_io, int planck_mode) {
   refep_api ep;
+  const double* bg64 = g_background64;
+  g_background64 = NULL;
   if (load_refep(refep_path, &ep)) return 10;
   const size_t nhl = (size_t)nlay + 1;
   const size_t mat = (size_t)nlay * nwav;
@@ -122,7 +129,7 @@ int orc_find_g_lw_chain_ex(const char* refep_path, int nlay, size_t nwav, const 
          *hr = NULL, *metric = NULL, *ones = NULL, *lw = NULL, *fds = NULL, *fut = NULL;
   if (!od || !bg || !key || !col || !iband || !ordered || !t_ideal) { rc = 11; goto done; }
   for (size_t i = 0; i < mat; ++i) od[i] = (double)od32[i];
-  for (size_t i = 0; i < mat; ++i) bg[i] = bg32 ? (double)bg32[i] : 0.0;
+  for (size_t i = 0; i < mat; ++i) bg[i] = bg64 ? bg64[i] : (bg32 ? (double)bg32[i] : 0.0);
 
   /* ---- reorder_spectrum.cpp:111-300 ---- */
   double t0 = now_s();

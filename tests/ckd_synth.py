@@ -158,21 +158,8 @@ class Oracle:
                 pw = cfg["pressure_weight_power"]
                 lw = (np.sqrt(p[c, 1:]) - np.sqrt(p[c, :-1])) if pw == 0.5 else (p[c, 1:] ** pw - p[c, :-1] ** pw)
                 lw = np.ascontiguousarray(lw / lw.sum())
-                pl = self.planck(T[c])
-                fd, fu = np.ascontiguousarray(scene["flux_dn"][c]), np.ascontiguousarray(scene["flux_up"][c])
-                hr = np.ascontiguousarray(self.o.heating_rate(p[c], fd, fu))
-                sfd, sfu = scene.get("spectral_flux_dn_surf"), scene.get("spectral_flux_up_toa")
-                rd, ru = scene.get("relative_flux_dn"), scene.get("relative_flux_up")
                 dc = np.zeros((nlay, ng))
-                J += L.orc_calc_cost_function_ckd_lw_ad(
-                    C.c_int(nlay), C.c_int(ng), C.c_int(nband), P(np.ascontiguousarray(p[c])), P(pl), P(np.ones(nband)),
-                    P(np.ascontiguousarray(pl[-1])), P(np.ascontiguousarray(odc[c])), P(fd), P(fu), P(hr),
-                    P(np.ascontiguousarray(sfd[c])) if sfd is not None else None,
-                    P(np.ascontiguousarray(sfu[c])) if sfu is not None else None, C.c_double(cfg["flux_weight"]),
-                    C.c_double(cfg["flux_profile_weight"]), C.c_double(cfg["broadband_weight"]),
-                    C.c_double(cfg["spectral_boundary_weight"]), P(lw),
-                    P(np.ascontiguousarray(rd[c])) if rd is not None else None,
-                    P(np.ascontiguousarray(ru[c])) if ru is not None else None, ib.ctypes.data_as(C.POINTER(C.c_int)), P(dc))
+                J += self._profile_cost_ad(scene, c, odc[c], lw, ib, nband, dc)
                 d_od[c] = dc
             # the clamped cells pass nothing on but the penalty's derivative (:110-113)
             d_od = np.where(neg, 2.0 * cfg["negative_od_penalty"] * od, d_od)
@@ -198,6 +185,26 @@ class Oracle:
             grad[off:off + n] = np.where(xx > -1.0e20, dk[i].ravel() * kk, 0.0)
             off += n
         return J, grad
+
+    def _profile_cost_ad(self, scene, c, od_c, lw, ib, nband, dc):
+        """cost of profile c of `scene` and dc += d cost / d optical depth (oracle_adjoint.c, longwave)"""
+        cfg, P, L = self.cfg, self.o._p, self.L
+        p, T = np.ascontiguousarray(scene["pressure_hl"]), np.ascontiguousarray(scene["temperature_hl"])
+        nlay, ng = od_c.shape
+        pl = self.planck(T[c])
+        fd, fu = np.ascontiguousarray(scene["flux_dn"][c]), np.ascontiguousarray(scene["flux_up"][c])
+        hr = np.ascontiguousarray(self.o.heating_rate(p[c], fd, fu))
+        sfd, sfu = scene.get("spectral_flux_dn_surf"), scene.get("spectral_flux_up_toa")
+        rd, ru = scene.get("relative_flux_dn"), scene.get("relative_flux_up")
+        return L.orc_calc_cost_function_ckd_lw_ad(
+            C.c_int(nlay), C.c_int(ng), C.c_int(nband), P(np.ascontiguousarray(p[c])), P(pl), P(np.ones(nband)),
+            P(np.ascontiguousarray(pl[-1])), P(np.ascontiguousarray(od_c)), P(fd), P(fu), P(hr),
+            P(np.ascontiguousarray(sfd[c])) if sfd is not None else None,
+            P(np.ascontiguousarray(sfu[c])) if sfu is not None else None, C.c_double(cfg["flux_weight"]),
+            C.c_double(cfg["flux_profile_weight"]), C.c_double(cfg["broadband_weight"]),
+            C.c_double(cfg["spectral_boundary_weight"]), P(lw),
+            P(np.ascontiguousarray(rd[c])) if rd is not None else None,
+            P(np.ascontiguousarray(ru[c])) if ru is not None else None, ib.ctypes.data_as(C.POINTER(C.c_int)), P(dc))
 
     def prior_matrices(self):
         """Dense inverse covariance per active gas exactly as create_error_covariances builds it
@@ -289,6 +296,26 @@ class OracleSW(Oracle):
 
     def ssi(self, scene):
         return np.ascontiguousarray(scene["tsi"] / self.m["solar_irradiance"].sum() * self.m["solar_irradiance"])
+
+    def _profile_cost_ad(self, scene, c, od_c, lw, ib, nband, dc):
+        """cost of profile c and dc += d cost / d optical depth: the shortwave reverse mode of oracle_adjoint.c"""
+        cfg, P, L = self.cfg, self.o._p, self.L
+        L.orc_calc_cost_function_ckd_sw_ad.restype = C.c_double
+        p = np.ascontiguousarray(scene["pressure_hl"])
+        nlay, ng = od_c.shape
+        fd, fu = np.ascontiguousarray(scene["flux_dn"][c]), np.ascontiguousarray(scene["flux_up"][c])
+        hr = np.ascontiguousarray(self.o.heating_rate(p[c], fd, None))
+        sfd, sbw = scene.get("spectral_flux_dn_surf"), scene.get("spectral_boundary_weights")
+        use_b = sfd is not None and sbw is not None
+        rd, ru = scene.get("relative_flux_dn"), scene.get("relative_flux_up")
+        return L.orc_calc_cost_function_ckd_sw_ad(
+            C.c_int(nlay), C.c_int(ng), C.c_int(nband), C.c_double(scene["mu0"][c]), P(np.ascontiguousarray(p[c])),
+            P(self.ssi(scene)), P(np.ascontiguousarray(scene["albedo"])), P(np.ascontiguousarray(od_c)), P(fd), P(fu), P(hr),
+            P(np.ascontiguousarray(sfd[c])) if use_b else None, C.c_double(cfg["flux_weight"]),
+            C.c_double(cfg["flux_profile_weight"]), C.c_double(cfg["broadband_weight"]),
+            P(np.ascontiguousarray(sbw)) if use_b else None, P(lw),
+            P(np.ascontiguousarray(rd[c])) if rd is not None else None,
+            P(np.ascontiguousarray(ru[c])) if ru is not None else None, ib.ctypes.data_as(C.POINTER(C.c_int)), P(dc))
 
     def fluxes(self, x, scene):
         od = np.maximum(self.optical_depth(x, scene), 0.0)

@@ -136,6 +136,15 @@ def test_interval_errors_band_offset_f32_and_flux_weight_zero(ctx, oracle):
     err = gas.calc_error_batch(i1, i2 - i1 + 1, b1, b2)
     ref = np.array([eq.calc_error(x, y) for x, y in zip(b1, b2)])
     assert np.allclose(err, ref, rtol=ERR_RTOL, atol=1e-12)
+    # ... and from rows the oracle prepared itself from the raw spectra of that window (find_g_points.cpp:891-1150)
+    od_w, bg_w, wn_w, dwn_w = window(i1, n)
+    planck_w = oracle.planck_function(t_hl, wn_w, dwn_w)
+    fdn_w, fup_w = oracle.radiative_transfer_lw(planck_w, bg_w + od_w, np.ones(n), planck_w[-1])
+    eq_own = oracle.CkdEquipartitionLW("transmission", 0.02, oracle.layer_weight(p, 0.0), p, np.ones(n), planck_w[-1], fdn_w[-1].copy(),
+                                       fup_w[0].copy(), planck_w, bg_w, oracle.metric("transmission", od_w),
+                                       oracle.heating_rate(p, fdn_w, fup_w))
+    ref_own = np.array([eq_own.calc_error(x, y) for x, y in zip(b1, b2)])
+    assert np.all(np.abs(err - ref_own) <= 1e-9 * np.abs(ref_own) + 1e-10)
     gas.close()
 
 
@@ -246,18 +255,24 @@ class _DevView:
 
 
 def test_full_size_find_g_against_oracle_slices(ctx, oracle):
-    """BASELINE full size (nwav = 7.2e6, nlay = 54, FLOAT spectra, one band): the oracle cannot run the whole problem in
-    seconds, so it replays (a) the gas preparation of three 4096-point windows of the sorted spectrum (start, deep inside,
-    end) and (b) the interval errors of a 20 000-point band placed deep inside it, from the device's own prepared rows;
-    (c) repeated and regrouped batches give bit-identical errors; (d) the full-band search converges within its tolerance."""
+    """BASELINE full size ON THE BENCH'S OWN WORKLOAD (nwav = 7.2e6, nlay = 54, FLOAT line spectra of
+    synthetic.optical_depth_lines, 12 000 + 4 000 lines, one band): the oracle cannot run the whole problem in seconds, so it
+    (a) PREPARES three 4096-point windows of the sorted spectrum itself (start, deep inside, end) and (b) evaluates the
+    interval errors of a 20 000-point band placed deep inside it twice - from the device's prepared rows (rtol 1e-9) and from
+    rows it prepared ITSELF from the raw spectra (rtol 1e-9 + 1e-10 K/d: two independent preparations); (c) repeated and
+    regrouped batches give bit-identical errors; (d) the full-band search of the bench ends as bench.py reports it (it runs
+    into its 60 iterations on these spectra) and the errors it returns are those of its final intervals.  The whole search
+    against an oracle-driven one, decision by decision: tests/test_decision_trace_gpu.py (2^22 points)."""
     from ecckd_amd import api, synthetic as syn
     nwav, nlay = 7_200_000, 54
     dev = ctx.device
     p = syn.pressure_grid(nlay)
     wn_h, dwn_h = syn.wavenumber_grid(nwav)
     wn, dwn = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
-    od = syn.optical_depth(torch, p, wn, syn.SEED_BASE + 1, nlines=32, device=dev, chunk=1 << 20)
-    bg = syn.optical_depth(torch, p, wn, syn.SEED_BASE + 1001, nlines=24, column_scale=3.0, zero_fraction=0.0, device=dev, chunk=1 << 20)
+    # exactly bench.py's make_inputs(seed = SEED_BASE + 1)
+    od = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 1, nlines=12000, column_scale=30.0, device=dev)
+    bg = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 1001, nlines=4000, column_scale=3.0, zero_fraction=0.0, nclusters=5,
+                                 device=dev)
     t_hl = syn.temperature_profile(p)
     key, col = api.reorder_key_lw(ctx, p, api.idealised_temperature(p), wn, dwn, od, 0.5)
     rank, _ = api.stable_argsort_bands(ctx, key, [0], [nwav - 1], want_ordered=False)
@@ -300,6 +315,15 @@ def test_full_size_find_g_against_oracle_slices(ctx, oracle):
     err = gas.calc_error_batch(i1, n, b1, b2)
     ref = np.array([eq.calc_error(x, y) for x, y in zip(b1, b2)])
     assert np.allclose(err, ref, rtol=ERR_RTOL, atol=1e-12)
+    # ... and from rows the oracle prepared itself from the raw spectra of that window (find_g_points.cpp:891-1150)
+    od_w, bg_w, wn_w, dwn_w = window(i1, n)
+    planck_w = oracle.planck_function(t_hl, wn_w, dwn_w)
+    fdn_w, fup_w = oracle.radiative_transfer_lw(planck_w, bg_w + od_w, np.ones(n), planck_w[-1])
+    eq_own = oracle.CkdEquipartitionLW("transmission", 0.02, oracle.layer_weight(p, 0.0), p, np.ones(n), planck_w[-1], fdn_w[-1].copy(),
+                                       fup_w[0].copy(), planck_w, bg_w, oracle.metric("transmission", od_w),
+                                       oracle.heating_rate(p, fdn_w, fup_w))
+    ref_own = np.array([eq_own.calc_error(x, y) for x, y in zip(b1, b2)])
+    assert np.all(np.abs(err - ref_own) <= 1e-9 * np.abs(ref_own) + 1e-10)
 
     # (c) the whole band: an interval's error is a function of the interval alone (fixed-order reductions, no atomics, chunk
     # size set by the interval's length): the same bits alone, with its neighbours, in another order, next to other intervals
@@ -316,8 +340,12 @@ def test_full_size_find_g_against_oracle_slices(ctx, oracle):
     # reports are those of its final intervals
     gas = api.GasLW(ctx, p, t_hl, wn, dwn, rank, od, bg, "transmission", flux_weight=0.0)
     st, b, e, cc = gas.find_g_band(0, nwav - 1, 0.0161, 0.01, 60)
-    assert st == 0 and len(e) >= 4 and b[0] == 0.0 and b[-1] == 1.0 and np.all(np.diff(b) > 0)
-    assert np.all(np.isfinite(e)) and np.all(e > 0) and cc > len(e) and e[:-1].max() <= 0.0161 * 1.0101
+    assert st in (0, 1, 2) and len(e) >= 20 and b[0] == 0.0 and b[-1] == 1.0 and np.all(np.diff(b) > 0)   # 1 / 2: iterations ran out / no convergence
+    assert np.all(np.isfinite(e)) and np.all(e > 0) and cc > len(e)
+    if st == 0:
+        assert e[:-1].max() <= 0.0161 * 1.0101
+    else:
+        assert e.max() <= 0.0161 * 2.0                       # not converged, but every g point within a factor of the tolerance
     assert np.allclose(gas.calc_error_batch(0, nwav, b[:-1], b[1:]), e, rtol=1e-12, atol=0)
     gas.close()
 

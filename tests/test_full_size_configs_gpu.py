@@ -1,8 +1,11 @@
 """BASELINE configs[2], configs[3] and configs[4] at full size (the oracle cannot run them whole in seconds; it replays windows).
 
-configs[3]: one find_g_points job over the 13 narrow longwave bands at nwav = 7.2e6, nlay = 54 (three gases here, eight in
-bench.py --config 3), through the resident-data driver that bench.py and the sharded runs use.  Checked: (a) oracle replay
-of the interval errors of one narrow band deep inside the spectrum, from the device's own prepared rows; (b) every
+configs[3]: one find_g_points job over the 13 narrow longwave bands at nwav = 7.2e6, nlay = 54, all eight gases of
+bench.py --config 3 (composite, h2o, o3, co2, ch4, n2o and the two CFC-scale absorbers), through the resident-data driver that
+bench.py and the sharded runs use.  Checked: (a) oracle replay of the interval errors of one narrow band deep inside the
+spectrum, from the device's own prepared rows AND from rows the oracle prepares itself from the raw spectra of that band
+(with the first gas's Planck matrix, as the reference reuses it: find_g_points.cpp:529, :970-984), for a strong absorber and
+for a CFC-scale one; (b) every
 wavenumber is assigned to exactly one merged g point, the per-gas maps are those of the g points' rank ranges;
 (c) searching the bands one at a time (the reference's order of evaluation) ends at the same g points as side by side;
 (d) the shares of a two-process deal, run one after the other here, give the same per-band results as the whole job.
@@ -32,8 +35,9 @@ class _DevView:
 
 def test_config3_thirteen_bands_full_size(ctx, oracle):
     from ecckd_amd import api, pipeline, shard
-    nwav, nlay, names = 7_200_000, 54, ["composite", "h2o", "o3"]
-    scales = [30.0, 100.0, 10.0]
+    nwav, nlay = 7_200_000, 54
+    names = ["composite", "h2o", "o3", "co2", "ch4", "n2o", "cfc11", "cfc12"]          # bench.py GAS_NAMES (create_lut_lw.sh:143)
+    scales = [30.0, 100.0, 10.0, 50.0, 5.0, 5.0, 0.5, 0.5]                             # bench.py GAS_COLUMN_SCALE
     dev = ctx.device
     p = syn.pressure_grid(nlay)
     wn_h, dwn_h = syn.wavenumber_grid(nwav)
@@ -80,34 +84,49 @@ def test_config3_thirteen_bands_full_size(ctx, oracle):
         assert np.all(np.isfinite(e)) and np.all(e > 0)
     assert res["cost_sum"] == pytest.approx(sum(sum(g["error"]) for g in res["gases"]), rel=1e-13)
 
-    # (a) oracle replay of a narrow band (band 3: 630-700 cm-1, ~155 000 points) of the second gas, from its prepared rows
-    od, bg = spectra[1]
-    key, rnk = orders[1]
+    # (a) oracle replay of a narrow band (band 3: 630-700 cm-1, ~155 000 points) of a strong absorber (h2o) and of a CFC-scale
+    # one (cfc11), from the device's prepared rows and from the oracle's own preparation of that band
     planck_first = api.planck_hl_sorted(ctx, t_file, wn, dwn, orders[0][1])
-    gas = api.GasLW(ctx, p, t_file, wn, dwn, rnk, od, bg, "transmission", 0.0, 0.0, planck_hl_reuse=planck_first.data_ptr())
-    i0, i1 = int(begin[3]), int(end[3])
-    n = i1 - i0 + 1
-    view = lambda name: torch.as_tensor(_DevView(*gas.view_ptr(name)), device=dev)
-    sl = slice(i0, i1 + 1)
-    ireorder = api.invert_permutation(ctx, rnk).long()
-    od_s = od[:, ireorder[sl]].double().cpu().numpy()
-    pl = planck_first[:, sl].cpu().numpy()
-    eq = oracle.CkdEquipartitionLW("transmission", 0.0, oracle.layer_weight(p, 0.0), p, np.ones(n), pl[-1],
-                                   view("flux_dn_surf")[0, sl].cpu().numpy(), view("flux_up_toa")[0, sl].cpu().numpy(), pl,
-                                   view("bg_optical_depth")[:, sl].cpu().numpy(), oracle.metric("transmission", od_s),
-                                   view("hr")[:, sl].cpu().numpy())
-    g1 = res["gases"][1]
-    first = int(np.sum(g1["n_g_points"][:3]))
-    ng3 = g1["n_g_points"][3]
-    r1, r2 = np.array(g1["rank1"][first:first + ng3]), np.array(g1["rank2"][first:first + ng3])
-    b_lo, b_hi = (r1 - i0 - 0.25) / (n - 1), (r2 - i0 + 0.25) / (n - 1)   # ceil / floor (find_g_points.cpp:282-287) land on r1, r2
-    err = gas.calc_error_batch(i0, n, b_lo, b_hi)
-    pick = sorted({0, ng3 // 2, ng3 - 1})                    # the oracle walks ~1e5 points x 54 layers per interval
-    ref = np.array([eq.calc_error(b_lo[k], b_hi[k]) for k in pick])
-    assert np.allclose(err[pick], ref, rtol=ERR_RTOL, atol=1e-12)
-    # the errors the search reported are those of its final intervals (same rank ranges -> same bits)
-    assert np.array_equal(err, g1["error"][first:first + ng3])
-    gas.close()
+    ireorder_first = api.invert_permutation(ctx, orders[0][1]).long()
+    for gi in (1, 6):
+        od, bg = spectra[gi]
+        key, rnk = orders[gi]
+        gas = api.GasLW(ctx, p, t_file, wn, dwn, rnk, od, bg, "transmission", 0.0, 0.0, planck_hl_reuse=planck_first.data_ptr())
+        i0, i1 = int(begin[3]), int(end[3])
+        n = i1 - i0 + 1
+        view = lambda name: torch.as_tensor(_DevView(*gas.view_ptr(name)), device=dev)
+        sl = slice(i0, i1 + 1)
+        ireorder = api.invert_permutation(ctx, rnk).long()
+        od_s = od[:, ireorder[sl]].double().cpu().numpy()
+        bg_s = bg[:, ireorder[sl]].double().cpu().numpy()
+        pl = planck_first[:, sl].cpu().numpy()
+        eq = oracle.CkdEquipartitionLW("transmission", 0.0, oracle.layer_weight(p, 0.0), p, np.ones(n), pl[-1],
+                                       view("flux_dn_surf")[0, sl].cpu().numpy(), view("flux_up_toa")[0, sl].cpu().numpy(), pl,
+                                       view("bg_optical_depth")[:, sl].cpu().numpy(), oracle.metric("transmission", od_s),
+                                       view("hr")[:, sl].cpu().numpy())
+        # the oracle's own preparation: Planck function on the FIRST gas's ordering of the grid (the reference evaluates it once
+        # and keeps it for every gas), radiative transfer of background + target in THIS gas's ordering
+        idx_first = ireorder_first[sl].cpu().numpy()
+        pl_own = oracle.planck_function(t_file, wn_h[idx_first], dwn_h[idx_first])
+        assert np.allclose(pl, pl_own, rtol=1e-11, atol=0)
+        fdn_o, fup_o = oracle.radiative_transfer_lw(pl_own, bg_s + od_s, np.ones(n), pl_own[-1])
+        eq_own = oracle.CkdEquipartitionLW("transmission", 0.0, oracle.layer_weight(p, 0.0), p, np.ones(n), pl_own[-1], fdn_o[-1].copy(),
+                                           fup_o[0].copy(), pl_own, bg_s, oracle.metric("transmission", od_s),
+                                           oracle.heating_rate(p, fdn_o, fup_o))
+        g1 = res["gases"][gi]
+        first = int(np.sum(g1["n_g_points"][:3]))
+        ng3 = g1["n_g_points"][3]
+        r1, r2 = np.array(g1["rank1"][first:first + ng3]), np.array(g1["rank2"][first:first + ng3])
+        b_lo, b_hi = (r1 - i0 - 0.25) / (n - 1), (r2 - i0 + 0.25) / (n - 1)   # ceil / floor (find_g_points.cpp:282-287) land on r1, r2
+        err = gas.calc_error_batch(i0, n, b_lo, b_hi)
+        pick = sorted({0, ng3 // 2, ng3 - 1})                    # the oracle walks ~1e5 points x 54 layers per interval
+        ref = np.array([eq.calc_error(b_lo[k], b_hi[k]) for k in pick])
+        assert np.allclose(err[pick], ref, rtol=ERR_RTOL, atol=1e-12), names[gi]
+        ref_own = np.array([eq_own.calc_error(b_lo[k], b_hi[k]) for k in pick])
+        assert np.all(np.abs(err[pick] - ref_own) <= 1e-9 * np.abs(ref_own) + 1e-10), (names[gi], err[pick], ref_own)
+        # the errors the search reported are those of its final intervals (same rank ranges -> same bits)
+        assert np.array_equal(err, g1["error"][first:first + ng3])
+        gas.close()
 
     # (c) one band at a time == side by side
     seq = pipeline.find_g_points_resident(ctx, names, load_gas, nband, 0.013, first_order, sequential_bands=True, merged_map=False, **kw)

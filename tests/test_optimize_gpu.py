@@ -341,6 +341,38 @@ def test_sw_cost_and_gradient(ctx, oracle, variant):
     opt.close()
 
 
+@pytest.mark.parametrize("variant", ["base", "spectral_only", "direct_only", "mixed_albedo", "boundary", "negative_od"])
+def test_sw_gradient_matches_the_oracles_reverse_mode(ctx, oracle, variant):
+    """Shortwave device adjoint against the oracle's hand-written shortwave reverse mode (orc_calc_cost_function_ckd_sw_ad,
+    pinned to central differences in tests/test_oracle_adjoint.py): the second derivation of dJ/dx that the longwave already
+    had, element by element, in every branch of calc_cost_function_ckd_sw."""
+    kw = {}
+    if variant == "spectral_only":
+        kw = dict(broadband_weight=0.0)
+    if variant == "direct_only":
+        kw = dict(albedo=(0.0, 0.0, -1.0))
+    if variant == "mixed_albedo":
+        kw = dict(albedo=(0.2, 0.0, 0.1))
+    if variant == "boundary":
+        kw = dict(boundary=True)
+    if variant == "negative_od":
+        kw = dict(ch4_low=True)
+    model, scenes, cfg, orc = _problem_sw(oracle, seed=5, **kw)
+    opt = _opt(ctx, model, scenes, dict(cfg, prior_error=1.0e30))       # the radiative-transfer part of the cost alone
+    rs = np.random.RandomState(4)
+    x0 = opt.initial_state()
+    free = x0 > -1.0e20
+    x = x0 + np.where(free, 0.2 * rs.normal(size=x0.size), 0.0)
+    if variant == "negative_od":
+        sizes = np.cumsum([0] + orc.sizes)
+        x[sizes[3]:sizes[4]] += 9.0
+    J, g = opt.cost_grad(x)
+    J_ref, g_ref = orc.cost_grad_rt(x)
+    assert J == pytest.approx(J_ref, rel=1e-10)
+    assert np.allclose(g, g_ref, rtol=1e-8, atol=1e-11 * np.abs(g_ref).max())
+    opt.close()
+
+
 def test_sw_minimize_reduces_cost(ctx, oracle):
     model, scenes, cfg, orc = _problem_sw(oracle, seed=7)
     opt = _opt(ctx, model, scenes, cfg)

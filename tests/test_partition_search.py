@@ -130,3 +130,30 @@ def test_callback_failure_aborts_search():
     with pytest.raises(EcckdError) as e:
         ps.equipartition_e(1.0)
     assert e.value.code == 148
+
+
+def test_decision_trace_reports_without_changing_the_search():
+    """ecckd_partition_set_trace: the comparisons that steer the search are reported in order; results are the same bits."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ecckd_amd import api
+    x = np.exp(np.linspace(-2, 10, 200000))
+    cum = np.concatenate([[0.0], np.cumsum(x)])
+
+    def err(b1, b2):
+        n = x.size
+        return [float(cum[min(n, int(np.floor(b * n)) + 0)] - cum[int(np.ceil(a * n))]) / cum[-1] for a, b in zip(b1, b2)]
+
+    plain = api.PartitionSearch(err, partition_max_iterations=30)
+    traced = api.PartitionSearch(err, partition_max_iterations=30, trace=True)
+    sa, ba, ea = plain.equipartition_e(0.07)
+    sb, bb, eb = traced.equipartition_e(0.07)
+    assert sa == sb and np.array_equal(ba, bb) and np.array_equal(ea, eb)
+    assert plain.events is None
+    kinds = [e[0] for e in traced.events]
+    assert kinds.count("req") == len(traced.calls) and kinds.count("dec") > kinds.count("req")
+    sites = {e[1] for e in traced.events if e[0] == "dec"}
+    assert sites <= set(range(1, 36)) and {16, 17, 18, 27} <= sites          # equipartition_e and both next_bound searches
+    for e in traced.events:
+        if e[0] == "dec" and e[1] in (1, 3, 5, 6, 8, 9, 10, 12, 13, 15, 17, 19, 24, 26, 33, 35):     # the "<" sites
+            assert e[4] == int(e[2] < e[3])
