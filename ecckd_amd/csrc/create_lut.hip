@@ -16,6 +16,7 @@
 // The Planck weights are recomputed from (T, wavenumber) on the fly instead of being read from
 // an (nlay, nwav) matrix: 8 B/point/layer of HBM traffic traded for one exp.
 #include "common.hpp"
+#include "fastmath.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -25,7 +26,7 @@ namespace {
 
 constexpr double kD = ECCKD_LW_DIFFUSIVITY;
 constexpr int GA_THREADS = 256;
-constexpr int GA_PPT = 4;                       // points per thread
+constexpr int GA_PPT = 8;                       // points per thread (halves the cross-lane reductions per point)
 constexpr int GA_CHUNK = GA_THREADS * GA_PPT;   // sorted positions per block
 
 __device__ constexpr double kPlanckH = 6.62606896e-34;
@@ -83,14 +84,47 @@ k_gmap_check(size_t nassigned, const int32_t* __restrict__ order, const int32_t*
   if (g_point[order[i]] == g_point[order[i + 1]] && !(wn_s[i + 1] >= wn_s[i])) atomicOr(flag, 2);
 }
 
-// K6a.  partial[chunk][layer][6] = { num, den, den_nz, cnt_nz, min, max }
+// Several per-lane values reduced over the wave TOGETHER: at lane distance 32 a lane hands over one half of its values and
+// combines what it receives with the half it keeps, at distance 16 a half of those, ... - NV + NV/2 + ... exchanges instead of
+// six per value (every exchange is an LDS crossbar operation that all the waves of a CU queue for).  Lane l ends up with the
+// wave's result of value bitreverse6(l).  A fixed tree: bitwise reproducible.
+template <int USED, typename Op>
+__device__ __forceinline__ void fold_level(double* v, bool upper, int mask, Op op) {
+  constexpr int NEXT = (USED + 1) / 2;
+#pragma unroll
+  for (int i = 0; i < NEXT; ++i) {
+    const double a = v[2 * i];
+    const double b = (2 * i + 1 < USED) ? v[2 * i + 1] : a;      // (odd tail: the same value from both halves)
+    const double send = upper ? a : b;
+    const double keep = upper ? b : a;
+    v[i] = op(keep, __shfl_xor(send, mask, 64));
+  }
+}
+template <int NV, typename Op>
+__device__ __forceinline__ void fold_wave(double (&v)[NV], int lane, Op op) {
+  constexpr int U1 = (NV + 1) / 2, U2 = (U1 + 1) / 2, U3 = (U2 + 1) / 2, U4 = (U3 + 1) / 2, U5 = (U4 + 1) / 2;
+  fold_level<NV>(v, (lane & 32) != 0, 32, op);
+  fold_level<U1>(v, (lane & 16) != 0, 16, op);
+  fold_level<U2>(v, (lane & 8) != 0, 8, op);
+  fold_level<U3>(v, (lane & 4) != 0, 4, op);
+  fold_level<U4>(v, (lane & 2) != 0, 2, op);
+  fold_level<U5>(v, (lane & 1) != 0, 1, op);
+}
+
+// K6a.  partial[chunk][layer][6] = { num, den, den_nz, cnt_nz, min, max }.  Per layer and point: the Planck weight at the
+// layer's temperature (planck_function.cpp:48-50) and the averaged quantity of the layer's method
+// (average_optical_depth.cpp:43-133) - the same two exp per layer and point as K1, with the same < 1 ulp exp / division
+// (fastmath.hpp) instead of the library's -; the six per-layer sums of a wave are folded together (above), the waves' results
+// wait in LDS and are combined in wave order once, after the last layer: no barrier inside the layer loop.
+// dynamic LDS: [nlay][6][GA_THREADS / 64]
 template <typename OdT>
 __global__ void __launch_bounds__(GA_THREADS)
 k_gavg_partial(int nlay, size_t od_stride, const Chunk* __restrict__ chunks, const int32_t* __restrict__ order,
                const double* __restrict__ wn_s, const double* __restrict__ dwn_s, const OdT* __restrict__ od,
                const double* __restrict__ hk /*[nlay] (h/k)/T_fl, LW*/, const double* __restrict__ ssi /*SW, original order*/,
                const int* __restrict__ layer_method, double* __restrict__ partial) {
-  __shared__ double s_red[6][4];
+  extern __shared__ double s_part[];
+  constexpr int NW = GA_THREADS / 64;
   const Chunk c = chunks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   size_t jj[GA_PPT];
@@ -112,41 +146,41 @@ k_gavg_partial(int nlay, size_t od_stride, const Chunk* __restrict__ chunks, con
       pref[p] = ssi[jj[p]];
     }
   }
+  const int kk = (int)(__brev((unsigned)lane) >> 26);           // which folded value this lane ends up with
   for (int l = 0; l < nlay; ++l) {
     const int lm = layer_method[l];
-    double num = 0.0, den = 0.0, den_nz = 0.0, cnt = 0.0;
-    double mn = INFINITY, mx = -INFINITY;
+    // every optical depth of the layer first: the gathers are independent
+    double o[GA_PPT];
+#pragma unroll
+    for (int p = 0; p < GA_PPT; ++p) o[p] = (double)od[(size_t)l * od_stride + jj[p]];
+    double sums[4] = {0.0, 0.0, 0.0, 0.0};      // num, den, den_nz, cnt_nz
+    double mm[2] = {INFINITY, INFINITY};        // min, -max
+    const double hkl = hk ? hk[l] : 0.0;
+    const double dscale = lm == M_TRANS ? kD : lm == M_TRANS2 ? 2.0 * kD : lm == M_TRANS3 ? 3.0 * kD : lm == M_TRANS10 ? 10.0 * kD : 0.0;
 #pragma unroll
     for (int p = 0; p < GA_PPT; ++p) {
       if (!live[p]) continue;
-      const double o = (double)od[(size_t)l * od_stride + jj[p]];
-      const double w = hk ? pref[p] / (exp(freq[p] * hk[l]) - 1.0) : pref[p];
-      den += w;
-      mn = fmin(mn, o);
-      mx = fmax(mx, o);
-      switch (lm) {
-        case M_LINEAR: num += o * w; break;
-        case M_TRANS: num += (1.0 - exp(-o * (kD * 1.0 * 1.0))) * w; break;
-        case M_TRANS2: num += (1.0 - exp(-o * (kD * 1.0 * 2.0))) * w; break;
-        case M_TRANS3: num += (1.0 - exp(-o * (kD * 1.0 * 3.0))) * w; break;
-        case M_TRANS10: num += (1.0 - exp(-o * (kD * 1.0 * 10.0))) * w; break;
-        case M_SQRT: num += sqrt(o) * w; break;
-        default:  // logarithmic
-          if (o > 0.0) { num += log(o) * w; den_nz += w; cnt += 1.0; }
-      }
+      const double w = hk ? ecckd::div_fast(pref[p], ecckd::exp_fast(freq[p] * hkl) - 1.0) : pref[p];
+      sums[1] += w;
+      mm[0] = fmin(mm[0], o[p]);
+      mm[1] = fmin(mm[1], -o[p]);
+      if (dscale > 0.0) sums[0] += (1.0 - ecckd::exp_fast(-o[p] * dscale)) * w;
+      else if (lm == M_LINEAR) sums[0] += o[p] * w;
+      else if (lm == M_SQRT) sums[0] += sqrt(o[p]) * w;
+      else if (o[p] > 0.0) { sums[0] += log(o[p]) * w; sums[2] += w; sums[3] += 1.0; }      // logarithmic
     }
-    const double r0 = wave_sum(num), r1 = wave_sum(den), r2 = wave_sum(den_nz), r3 = wave_sum(cnt);
-    const double r4 = wave_min(mn), r5 = wave_max(mx);
-    __syncthreads();
-    if (lane == 0) { s_red[0][wave] = r0; s_red[1][wave] = r1; s_red[2][wave] = r2; s_red[3][wave] = r3; s_red[4][wave] = r4; s_red[5][wave] = r5; }
-    __syncthreads();
-    if (tid < 6) {
-      double v;
-      if (tid < 4) v = ((s_red[tid][0] + s_red[tid][1]) + s_red[tid][2]) + s_red[tid][3];
-      else if (tid == 4) v = fmin(fmin(s_red[4][0], s_red[4][1]), fmin(s_red[4][2], s_red[4][3]));
-      else v = fmax(fmax(s_red[5][0], s_red[5][1]), fmax(s_red[5][2], s_red[5][3]));
-      partial[((size_t)blockIdx.x * nlay + l) * 6 + tid] = v;
-    }
+    fold_wave<4>(sums, lane, [](double a, double b) { return a + b; });
+    fold_wave<2>(mm, lane, [](double a, double b) { return fmin(a, b); });
+    if (kk < 4) s_part[((size_t)l * 6 + kk) * NW + wave] = sums[0];
+    if (kk < 2) s_part[((size_t)l * 6 + 4 + kk) * NW + wave] = kk == 0 ? mm[0] : -mm[0];
+  }
+  __syncthreads();
+  for (int t = tid; t < nlay * 6; t += GA_THREADS) {
+    const double* q = s_part + (size_t)t * NW;
+    const int k = t % 6;
+    double v = q[0];
+    for (int w = 1; w < NW; ++w) v = k < 4 ? v + q[w] : (k == 4 ? fmin(v, q[w]) : fmax(v, q[w]));
+    partial[(size_t)blockIdx.x * nlay * 6 + t] = v;
   }
 }
 
@@ -501,11 +535,11 @@ int ecckd_average_to_gpoints(ecckd_gmap* m, int nlay, const double* h_pressure_h
   ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // hk/dp/lm are stack-owned
   if (nchunk > 0) {
     if (od_type == ECCKD_F32)
-      hipLaunchKernelGGL(k_gavg_partial<float>, dim3((unsigned)nchunk), dim3(GA_THREADS), 0, ctx->stream, nlay, od_stride,
+      hipLaunchKernelGGL(k_gavg_partial<float>, dim3((unsigned)nchunk), dim3(GA_THREADS), (size_t)nlay * 6 * (GA_THREADS / 64) * sizeof(double), ctx->stream, nlay, od_stride,
                          m->d_chunks, m->order, m->wn_s, m->dwn_s, (const float*)d_od, h_temperature_fl ? d_hk : nullptr,
                          d_ssi, d_lm, d_part);
     else
-      hipLaunchKernelGGL(k_gavg_partial<double>, dim3((unsigned)nchunk), dim3(GA_THREADS), 0, ctx->stream, nlay, od_stride,
+      hipLaunchKernelGGL(k_gavg_partial<double>, dim3((unsigned)nchunk), dim3(GA_THREADS), (size_t)nlay * 6 * (GA_THREADS / 64) * sizeof(double), ctx->stream, nlay, od_stride,
                          m->d_chunks, m->order, m->wn_s, m->dwn_s, (const double*)d_od, h_temperature_fl ? d_hk : nullptr,
                          d_ssi, d_lm, d_part);
   }

@@ -1615,7 +1615,9 @@ k_rt_sw_bb(int nlay, size_t n, int nint, const Interval* __restrict__ iv,
 // swept with both fitted optical depths, partial sums of the second fit nchunks * 2 NHL further on.
 // SAME: cos_sza == 0.5, so -tau / cos_sza == -2 tau exactly and the transmittance of the way down is the one of the way up
 // (radiative_transfer_sw.cpp:134-139 and :176-183): the last fit overwrites the column with it instead of evaluating it twice.
-template <int NLAY, int NFIT, bool SAME, int OCC = (NFIT == 1 ? 3 : 2)>
+// (three blocks per CU only where the column's transmittance is shared by the two beams: without SAME the second exponential's
+// temporaries do not fit 168 registers - 56 B per lane went to scratch - and the cosine is the reference's 0.5 everywhere but in tests)
+template <int NLAY, int NFIT, bool SAME, int OCC = (NFIT == 1 && SAME ? 3 : 2)>
 __global__ void __launch_bounds__(RT_THREADS, OCC)
 k_rt_sw_bb_fast(size_t n, int nint, const Interval* __restrict__ iv, double cos_sza,
                 const double* __restrict__ ssi, const double* __restrict__ bg_od, const double* __restrict__ od_fit,

@@ -38,7 +38,7 @@ struct StreamDesc {
 };
 
 enum : int { INF_OK = 0, INF_BAD_HEADER = 1, INF_BAD_BLOCK = 2, INF_BAD_CODE = 3, INF_BAD_DISTANCE = 4, INF_OVERRUN = 5,
-             INF_SHORT = 6, INF_INPUT = 7 };
+             INF_SHORT = 6, INF_INPUT = 7, INF_CHECKSUM = 8 };
 
 __constant__ u16 c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ u8 c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -70,9 +70,12 @@ struct Lds {
 };
 
 // Build a code from the lengths len[0..n).  Cooperative: the wave's lanes fill the replicated table entries.  Returns false
-// for an over-subscribed set of lengths (an incomplete one is allowed, as zlib allows it for a single distance code).
+// for an over-subscribed set of lengths, and for an incomplete one unless `allow_single` and the set is one code of one bit -
+// what zlib (inftrees.c) and the host decoder (fast_inflate.cpp build()) accept: the distance code of a block with a single
+// distance.
 // Rare (once per DEFLATE block): kept out of line so that the symbol loop stays small and keeps its registers.
-__device__ __noinline__ bool huff_build(u16* table, int bits, u16* count, u16* symbol, const u8* len, int n, int lane) {
+__device__ __noinline__ bool huff_build(u16* table, int bits, u16* count, u16* symbol, const u8* len, int n, int lane,
+                                        bool allow_single = false) {
   for (int i = lane; i < (1 << bits); i += 64) table[i] = 0;
   __builtin_amdgcn_wave_barrier();
   // every lane runs the same serial passes over the (at most 288) symbols: the results are wave-uniform
@@ -96,6 +99,13 @@ __device__ __noinline__ bool huff_build(u16* table, int bits, u16* count, u16* s
     if (b < 15) offs[b + 1] = offs[b] + cnt[b];
     code = (code + (b > 1 ? cnt[b - 1] : 0u)) << 1;
     next[b] = code;
+  }
+  if (left > 0) {                                  // incomplete
+    u32 total = 0;
+#pragma unroll
+    for (int b = 1; b < 16; ++b) total += cnt[b];
+    if (!(allow_single && total == 1 && cnt[1] == 1) && total != 0) return false;
+    if (total == 0 && !allow_single) return false;
   }
   if (lane == 0) {
     count[0] = 0;
@@ -262,7 +272,7 @@ __device__ __noinline__ int read_dynamic_header(Lds& L, const u8* src, int lane)
   __builtin_amdgcn_wave_barrier();
   if (uni(lens[256]) == 0) return INF_BAD_CODE;       // no end-of-block code
   if (!uni(huff_build(L.lit.table, LIT_BITS, L.lit.count, L.lit.symbol, lens, nlen, lane))) return INF_BAD_CODE;
-  if (!uni(huff_build(L.dist.table, DIST_BITS, L.dist.count, L.dist.symbol, lens + nlen, ndist, lane))) return INF_BAD_CODE;
+  if (!uni(huff_build(L.dist.table, DIST_BITS, L.dist.count, L.dist.symbol, lens + nlen, ndist, lane, true))) return INF_BAD_CODE;
   save_state(L, b, opos, lane);
   return INF_OK;
 }
@@ -272,7 +282,7 @@ __device__ __noinline__ void fixed_tables(Lds& L, int lane) {
   if (lane < 30) L.len[288 + lane] = 5;
   __builtin_amdgcn_wave_barrier();
   huff_build(L.lit.table, LIT_BITS, L.lit.count, L.lit.symbol, L.len, 288, lane);
-  huff_build(L.dist.table, DIST_BITS, L.dist.count, L.dist.symbol, L.len + 288, 30, lane);
+  huff_build(L.dist.table, DIST_BITS, L.dist.count, L.dist.symbol, L.len + 288, 30, lane, true);     // (30 five-bit codes: incomplete by design)
 }
 
 // a stored block: to the byte boundary, LEN, NLEN, then LEN bytes as they are
@@ -394,6 +404,41 @@ k_inflate(int nstreams, const u8* __restrict__ in, const StreamDesc* __restrict_
   }
   if (!err && opos != out_bytes) err = INF_SHORT;
   if (!err && b.ipos - b.cnt / 8 > in_bytes) err = INF_INPUT;      // the decoder ran into the padding behind the stream
+  // RFC 1950: the stream ends with the Adler-32 of the inflated bytes, big-endian, directly behind the last block (the bit
+  // reader is byte-aligned there); nothing may follow it - what zlib, the HDF5 filter and the host decoder check
+  if (!err) {
+    const u32 at = b.ipos - b.cnt / 8;             // first byte not consumed by the blocks
+    if (at + 4u != in_bytes) err = INF_INPUT;
+    else {
+      __builtin_amdgcn_wave_barrier();
+      // s1 = 1 + sum b_i, s2 = n + sum (n - i) b_i (mod 65521): every lane takes a contiguous slice, the slices' sums are
+      // combined over the wave; 64-bit partial sums stay far below 2^64 for slices of up to 2^26 bytes
+      const u32 n = out_bytes;
+      const u32 per = (n + 63u) / 64u;
+      const u32 i0 = min(n, (u32)lane * per), i1 = min(n, i0 + per);
+      u64 a = 0, w = 0;                            // sum of bytes, sum of (i1 - i) * byte over the slice
+      for (u32 i = i0; i < i1; ++i) {
+        const u64 v = dst[i];
+        a += v;
+        w += (u64)(i1 - i) * v;
+        if (((i - i0) & 0xffffu) == 0xffffu) { a %= 65521u; w %= 65521u; }
+      }
+      a %= 65521u; w %= 65521u;
+      // contribution of the slice to s2: bytes of the slice count (n - i) = (n - i1) + (i1 - i) times
+      u64 s2 = (w + (u64)((n - i1) % 65521u) * a) % 65521u;
+      u64 s1 = a;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        s1 += (u64)__shfl_down((unsigned long long)s1, off, 64);
+        s2 += (u64)__shfl_down((unsigned long long)s2, off, 64);
+      }
+      s1 = (1u + s1) % 65521u;
+      s2 = ((u64)(n % 65521u) + s2) % 65521u;
+      const u32 want = ((u32)src[at] << 24) | ((u32)src[at + 1] << 16) | ((u32)src[at + 2] << 8) | (u32)src[at + 3];
+      const u32 got = ((u32)s2 << 16) | (u32)s1;
+      if (uni(lane == 0 ? (got != want ? 1u : 0u) : 0u)) err = INF_CHECKSUM;
+    }
+  }
   if (lane == 0) status[s] = err;
 }
 

