@@ -571,9 +571,7 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
         # WRITE_SIZE collected separately; 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md section HBM),
         # scaled to this run's points per launch
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic_k_rt_lw_bb.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic_k_rt_lw_bb.json")
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_traffic_k_rt_lw_bb.json" % r) for r in (3, 2, 1)) if os.path.exists(q)), "")
         if os.path.exists(tpath) and rt_calls:
             with open(tpath) as f:
                 traffic = json.load(f)["corrected_bytes_per_point"] * rt_pts / rt_calls

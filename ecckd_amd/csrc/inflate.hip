@@ -70,12 +70,13 @@ struct Lds {
 };
 
 // Build a code from the lengths len[0..n).  Cooperative: the wave's lanes fill the replicated table entries.  Returns false
-// for an over-subscribed set of lengths, and for an incomplete one unless `allow_single` and the set is one code of one bit -
-// what zlib (inftrees.c) and the host decoder (fast_inflate.cpp build()) accept: the distance code of a block with a single
-// distance.
+// for an over-subscribed set of lengths, and for an incomplete one as zlib does (inftrees.c: `left > 0 && (type == CODES ||
+// max != 1)`): `incomplete` = 0 never (the code-length code), 1 only if no code is longer than one bit (a literal/length or
+// distance code of a single symbol) or there is no code at all (a block without matches), 2 always (the fixed block's
+// 30 five-bit distance codes).
 // Rare (once per DEFLATE block): kept out of line so that the symbol loop stays small and keeps its registers.
 __device__ __noinline__ bool huff_build(u16* table, int bits, u16* count, u16* symbol, const u8* len, int n, int lane,
-                                        bool allow_single = false) {
+                                        int incomplete = 0) {
   for (int i = lane; i < (1 << bits); i += 64) table[i] = 0;
   __builtin_amdgcn_wave_barrier();
   // every lane runs the same serial passes over the (at most 288) symbols: the results are wave-uniform
@@ -100,12 +101,11 @@ __device__ __noinline__ bool huff_build(u16* table, int bits, u16* count, u16* s
     code = (code + (b > 1 ? cnt[b - 1] : 0u)) << 1;
     next[b] = code;
   }
-  if (left > 0) {                                  // incomplete
-    u32 total = 0;
+  if (left > 0 && incomplete < 2) {                // incomplete
+    u32 longer = 0;                                // codes of more than one bit
 #pragma unroll
-    for (int b = 1; b < 16; ++b) total += cnt[b];
-    if (!(allow_single && total == 1 && cnt[1] == 1) && total != 0) return false;
-    if (total == 0 && !allow_single) return false;
+    for (int b = 2; b < 16; ++b) longer += cnt[b];
+    if (incomplete == 0 || longer != 0) return false;
   }
   if (lane == 0) {
     count[0] = 0;
@@ -271,8 +271,8 @@ __device__ __noinline__ int read_dynamic_header(Lds& L, const u8* src, int lane)
   }
   __builtin_amdgcn_wave_barrier();
   if (uni(lens[256]) == 0) return INF_BAD_CODE;       // no end-of-block code
-  if (!uni(huff_build(L.lit.table, LIT_BITS, L.lit.count, L.lit.symbol, lens, nlen, lane))) return INF_BAD_CODE;
-  if (!uni(huff_build(L.dist.table, DIST_BITS, L.dist.count, L.dist.symbol, lens + nlen, ndist, lane, true))) return INF_BAD_CODE;
+  if (!uni(huff_build(L.lit.table, LIT_BITS, L.lit.count, L.lit.symbol, lens, nlen, lane, 1))) return INF_BAD_CODE;
+  if (!uni(huff_build(L.dist.table, DIST_BITS, L.dist.count, L.dist.symbol, lens + nlen, ndist, lane, 1))) return INF_BAD_CODE;
   save_state(L, b, opos, lane);
   return INF_OK;
 }
@@ -282,7 +282,7 @@ __device__ __noinline__ void fixed_tables(Lds& L, int lane) {
   if (lane < 30) L.len[288 + lane] = 5;
   __builtin_amdgcn_wave_barrier();
   huff_build(L.lit.table, LIT_BITS, L.lit.count, L.lit.symbol, L.len, 288, lane);
-  huff_build(L.dist.table, DIST_BITS, L.dist.count, L.dist.symbol, L.len + 288, 30, lane, true);     // (30 five-bit codes: incomplete by design)
+  huff_build(L.dist.table, DIST_BITS, L.dist.count, L.dist.symbol, L.len + 288, 30, lane, 2);     // (30 five-bit codes: incomplete by design)
 }
 
 // a stored block: to the byte boundary, LEN, NLEN, then LEN bytes as they are

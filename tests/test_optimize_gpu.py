@@ -468,3 +468,48 @@ def test_cell_parallel_kernel_matches_the_general_one(ctx, oracle, sw, threads, 
     assert np.allclose(a[1], b[1], rtol=1e-9, atol=1e-12 * np.abs(a[1]).max())
     assert np.array_equal(a[1] == 0.0, b[1] == 0.0)
     opt.close()
+
+
+@pytest.mark.parametrize("sw", [False, True])
+def test_more_than_64_g_points(ctx, oracle, sw):
+    """ng = 70: rows of the tables are 70 long, a wave covers 64 of them - two g chunks per node in K8b, 128-wide layer groups
+    in K8a (the narrow-band models of the reference's scripts have 64 ... 128 g points; the other tests use 12).  Cost against
+    the oracle, gradient against the oracle's reverse mode, the two K8a kernels against each other."""
+    import os
+    mk_model = ckd_synth.make_model_sw if sw else ckd_synth.make_model
+    model = mk_model(seed=6, ng=70, nband=5)
+    truth = mk_model(seed=6, ng=70, nband=5)
+    rs = np.random.RandomState(11)
+    for g in truth["gases"]:
+        g["molar_abs"] = g["molar_abs"] * np.exp(0.25 * rs.normal(size=g["molar_abs"].shape))
+    cfg = dict(CFG)
+    if sw:
+        scenes = ckd_synth.make_scenes_sw(model, np.array([0.15, 0.3, 0.06, 0.2, 0.1]))
+        Orc = ckd_synth.OracleSW
+    else:
+        scenes = ckd_synth.make_scenes(model)
+        Orc = ckd_synth.Oracle
+    t = Orc(oracle, truth, scenes, cfg)
+    for s in scenes:
+        bf = t.band_fluxes(t.x0, s)
+        s["flux_dn"], s["flux_up"] = np.ascontiguousarray(bf[:, 0]), np.ascontiguousarray(bf[:, 1])
+    orc = Orc(oracle, model, scenes, cfg)
+    opt = _opt(ctx, model, scenes, cfg)
+    x0 = opt.initial_state()
+    free = x0 > -1.0e20
+    x = x0 + np.where(free, 0.2 * rs.normal(size=x0.size), 0.0)
+    J, g = opt.cost_grad(x)
+    J_rt, g_rt = orc.cost_grad_rt(x)
+    J_b, g_b = orc.cost_prior(x, cfg["prior_error"])
+    assert J == pytest.approx(J_rt + J_b, rel=1e-10)
+    g_ref = np.where(free, g_rt + g_b, 0.0)
+    assert np.allclose(g, g_ref, rtol=1e-8, atol=1e-11 * np.abs(g_ref).max())
+    os.environ["ECCKD_K8A_GENERIC"] = "1"
+    try:
+        J2, g2 = opt.cost_grad(x)
+    finally:
+        del os.environ["ECCKD_K8A_GENERIC"]
+    assert J2 == pytest.approx(J, rel=1e-13) and np.allclose(g2, g, rtol=1e-9, atol=1e-12 * np.abs(g).max())
+    res = opt.minimize(max_iterations=25, convergence_criterion=0.0, bounded=True)
+    assert res["status"] in (0, 2) and res["cost"] < J
+    opt.close()
