@@ -95,6 +95,46 @@ void encode(unsigned char* p, int t, double v) {
   }
 }
 
+// Runs of one type at a time: the per-element switch of encode() / decode() held the tools' 1-D variables (an order file is
+// six arrays of 7.2e6 values) at ~0.5 GB/s; the four types those files use get loops the compiler vectorises.  Same C conversion
+// rules as encode() / decode().
+void encode_run(unsigned char* p, int t, const double* v, size_t n) {
+  switch (t) {
+    case NC_DOUBLE:
+      for (size_t i = 0; i < n; ++i) { uint64_t u; std::memcpy(&u, &v[i], 8); u = __builtin_bswap64(u); std::memcpy(p + 8 * i, &u, 8); }
+      return;
+    case NC_FLOAT:
+      for (size_t i = 0; i < n; ++i) { const float f = (float)v[i]; uint32_t u; std::memcpy(&u, &f, 4); u = __builtin_bswap32(u); std::memcpy(p + 4 * i, &u, 4); }
+      return;
+    case NC_INT:
+      for (size_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)(int32_t)v[i]; u = __builtin_bswap32(u); std::memcpy(p + 4 * i, &u, 4); }
+      return;
+    case NC_SHORT:
+      for (size_t i = 0; i < n; ++i) { uint16_t u = (uint16_t)(int16_t)v[i]; u = __builtin_bswap16(u); std::memcpy(p + 2 * i, &u, 2); }
+      return;
+    default:
+      for (size_t i = 0; i < n; ++i) encode(p + i * type_size(t), t, v[i]);
+  }
+}
+void decode_run(const unsigned char* p, int t, double* out, size_t n) {
+  switch (t) {
+    case NC_DOUBLE:
+      for (size_t i = 0; i < n; ++i) { uint64_t u; std::memcpy(&u, p + 8 * i, 8); u = __builtin_bswap64(u); std::memcpy(&out[i], &u, 8); }
+      return;
+    case NC_FLOAT:
+      for (size_t i = 0; i < n; ++i) { uint32_t u; std::memcpy(&u, p + 4 * i, 4); u = __builtin_bswap32(u); float x; std::memcpy(&x, &u, 4); out[i] = (double)x; }
+      return;
+    case NC_INT:
+      for (size_t i = 0; i < n; ++i) { uint32_t u; std::memcpy(&u, p + 4 * i, 4); out[i] = (double)(int32_t)__builtin_bswap32(u); }
+      return;
+    case NC_SHORT:
+      for (size_t i = 0; i < n; ++i) { uint16_t u; std::memcpy(&u, p + 2 * i, 2); out[i] = (double)(int16_t)__builtin_bswap16(u); }
+      return;
+    default:
+      for (size_t i = 0; i < n; ++i) out[i] = decode(p + i * type_size(t), t);
+  }
+}
+
 }  // namespace
 
 struct ecckd_nc {
@@ -456,13 +496,8 @@ int ecckd_nc_read_double(ecckd_nc* f, const char* name, long long slice, double*
     while (left > 0) {
       const size_t n = (size_t)std::min<uint64_t>(left, buf.size() / ts);
       if (fread(buf.data(), ts, n, f->fp) != n) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: short read of \"%s\"", f->path.c_str(), name);
-      if (v->type == NC_DOUBLE) {
-        for (size_t i = 0; i < n; ++i) { uint64_t u; std::memcpy(&u, buf.data() + i * 8, 8); u = __builtin_bswap64(u); std::memcpy(&out[o++], &u, 8); }
-      } else if (v->type == NC_FLOAT) {
-        for (size_t i = 0; i < n; ++i) { uint32_t u; std::memcpy(&u, buf.data() + i * 4, 4); u = __builtin_bswap32(u); float x; std::memcpy(&x, &u, 4); out[o++] = (double)x; }
-      } else {
-        for (size_t i = 0; i < n; ++i) out[o++] = decode(buf.data() + i * ts, v->type);
-      }
+      decode_run(buf.data(), v->type, out + o, n);
+      o += n;
       left -= n;
     }
   }
@@ -625,7 +660,7 @@ int ecckd_nc_write_double(ecckd_nc* f, const char* name, const double* data, siz
   size_t i = 0;
   while (i < count) {
     const size_t n = std::min(count - i, buf.size() / ts);
-    for (size_t k = 0; k < n; ++k) encode(buf.data() + k * ts, v->type, data[i + k]);
+    encode_run(buf.data(), v->type, data + i, n);
     if (std::fwrite(buf.data(), ts, n, f->fp) != n) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: short write of \"%s\"", f->path.c_str(), name);
     i += n;
   }
@@ -650,7 +685,7 @@ int ecckd_nc_write_slice_double(ecckd_nc* f, const char* name, size_t slice, con
   size_t i = 0;
   while (i < count) {
     const size_t n = std::min(count - i, buf.size() / ts);
-    for (size_t k = 0; k < n; ++k) encode(buf.data() + k * ts, v->type, data[i + k]);
+    encode_run(buf.data(), v->type, data + i, n);
     if (std::fwrite(buf.data(), ts, n, f->fp) != n) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: short write of \"%s\"", f->path.c_str(), name);
     i += n;
   }

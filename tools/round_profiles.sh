@@ -26,4 +26,7 @@ done
 python3 bench.py --config 2 --steps 3 > $out/bench_config2.json 2> $out/c2.err
 python3 bench.py --config 3 --steps 2 > $out/bench_config3.json 2> $out/c3.err
 python3 bench.py --config 4 > $out/bench_config4.json 2> $out/c4.err
-ls -la $out | tail -30
+# gpurun returns at most 64 MiB: keep the summaries, drop the raw traces they were computed from
+cp $out/ks/ks_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
+rm -rf $out/ks $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/k6_*/
+du -sh $out; ls -la $out | tail -30
