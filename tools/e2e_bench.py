@@ -22,6 +22,7 @@ import ctypes as C
 import json
 import os
 import shutil
+import re
 import subprocess
 import sys
 import tempfile
@@ -175,12 +176,20 @@ def gpu_chain(d, inp):
     b1, b2 = bands()
     names = inp["names"]
     secs, fixed = {}, {}
+    per_process = []
 
     def run(stage, name, *args):
         t0 = time.perf_counter()
         r = subprocess.run([os.path.join(bindir, name), *[str(a) for a in args]], cwd=d, capture_output=True, text=True, timeout=3600,
                            env=dict(os.environ, ECCKD_LOG_TIMES="1"))
-        secs[stage] = secs.get(stage, 0.0) + time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        secs[stage] = secs.get(stage, 0.0) + dt
+        # the tool's own clock (ECCKD_LOG_TIMES: seconds since its start in front of every log line): last stamp = its run time
+        stamps = re.findall(r"^\[\s*([0-9.]+)\] (.{0,48})", r.stdout, flags=re.M)
+        rec = {"tool": name, "seconds": round(dt, 3), "last_log_stamp": float(stamps[-1][0]) if stamps else None}
+        if stage == "reorder_spectrum":
+            rec["log"] = ["%s %s" % st for st in stamps]
+        per_process.append(rec)
         if r.returncode != 0:
             raise RuntimeError(f"{name} failed ({r.returncode}): {r.stderr[-2000:]}")
         return r
@@ -212,6 +221,7 @@ def gpu_chain(d, inp):
         f = netcdf_file(os.path.join(d, f"fluxes_{tag}.nc"), "r", mmap=False)
         out[tag] = (f.variables["flux_dn_lw"][...].astype(np.float64), f.variables["flux_up_lw"][...].astype(np.float64))
         f.close()
+    out["per_process"] = per_process
     return secs, out
 
 
@@ -367,6 +377,29 @@ def cpu_chain(ctx, d, inp):
 SIZE_STAGES = ("reorder_spectrum", "find_g_points", "create_look_up_table")      # work proportional to nwav
 
 
+def host_memory():
+    """MemAvailable / Cached / Dirty / Writeback of /proc/meminfo in GB and the cgroup's limit: the tools read their inputs
+    from the page cache, so the state of the host's memory is part of the measurement."""
+    out = {}
+    try:
+        for line in open("/proc/meminfo"):
+            k, v = line.split(":")
+            if k in ("MemTotal", "MemAvailable", "Cached", "Dirty", "Writeback"):
+                out[k + "_GB"] = round(int(v.split()[0]) / 1048576.0, 2)
+        for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            if os.path.exists(f):
+                v = open(f).read().strip()
+                out["cgroup_limit_GB"] = v if v == "max" else round(int(v) / 2.0**30, 2)
+                break
+        for f in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+            if os.path.exists(f):
+                out["cgroup_current_GB"] = round(int(open(f).read().strip()) / 2.0**30, 2)
+                break
+    except Exception as exc:       # diagnostics only
+        out["error"] = repr(exc)
+    return out
+
+
 def run(ctx, nwav=7_200_000, nlay=54, cpu_nwav=(1 << 17, 1 << 18), workdir=None, keep=False):
     from ecckd_amd import ncio
     top = workdir or tempfile.mkdtemp(prefix="ecckd_e2e_")
@@ -384,6 +417,12 @@ def run(ctx, nwav=7_200_000, nlay=54, cpu_nwav=(1 << 17, 1 << 18), workdir=None,
         hr_lbl_full = hr_k_per_day(p1, inp["bdn"].sum(-1), inp["bup"].sum(-1))
         write_s = inp["seconds_writing_spectra"]
         del inp["base"]
+        # the chain starts from files at rest: the write-back of the 30 GB just written is part of the setup, not of stage 1
+        mem_before_sync = host_memory()
+        t0 = time.perf_counter()
+        os.sync()
+        sync_s = time.perf_counter() - t0
+        mem_at_start = host_memory()
         g_secs, g_out = gpu_chain(d, inp)
         gpf = ncio.read_g_points(os.path.join(d, "gpoints.nc"))
         ng_full = int(gpf["g_point"].max()) + 1
@@ -441,7 +480,10 @@ def run(ctx, nwav=7_200_000, nlay=54, cpu_nwav=(1 << 17, 1 << 18), workdir=None,
             "cpu_oracle_total_seconds_scaled": round(c_tot, 2), "cpu_cores": ncores,
             "speedup_total": c_tot / g_tot, "speedup_per_stage": {k: scaled[k] / g_secs[k] for k in scaled if g_secs.get(k)},
             "agreement_at_reduced_size": agreement,
-            "setup_seconds_not_timed": {"generating_and_writing_inputs": round(setup_s, 1), "of_which_writing_spectra_files": round(write_s, 1)},
+            "setup_seconds_not_timed": {"generating_and_writing_inputs": round(setup_s, 1), "of_which_writing_spectra_files": round(write_s, 1),
+                                        "sync_after_writing": round(sync_s, 1)},
+            "tool_processes_seconds": g_out.get("per_process"),
+            "host_memory": {"after_writing": mem_before_sync, "at_chain_start": mem_at_start},
             "note": "each tool is a separate process: its wall time includes process start (~0.25 s of HIP initialisation), reading its "
                     "NetCDF inputs from the page cache and writing its outputs; CPU: oracle chain (restated reference + the reference's "
                     "equipartition.cpp) on %d cores, size-proportional stages scaled linearly from nwav=%d" % (ncores, n_hi),
