@@ -479,7 +479,8 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
             gas = api.GasLW(ctx, p, t_file, wn, dwn, rnk, od, bg, "transmission", flux_weight=0.0)
             st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance,
                                            args.max_iterations)
-            info.update(ng=len(e), status=st, comp_cost=cc, cost_sum=float(np.sum(e)), eval_stats=gas.eval_stats())
+            info.update(ng=len(e), status=st, comp_cost=cc, cost_sum=float(np.sum(e)), eval_stats=gas.eval_stats(),
+                        sweep_bytes_per_point=gas.sweep_bytes_per_point())
             gas.close()
             # passes over the spectrum in this step: the reorder pass + what the search actually swept on the device.  (The
             # reference's counter total_comp_cost counts every interval the search asks for; the library answers an
@@ -562,9 +563,11 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
 
     if rank == 0:
         points = nwav * passes
-        # dominant kernel: K5c k_rt_lw_bb.  Algorithmic bytes per point and pass:
-        # planck (nlay+1) + background optical depth (nlay) rows of f64 = (2*nlay+1)*8 B.
-        rt_bytes_per_pt = (2 * nlay + 1) * 8
+        # dominant kernel: K5c k_rt_lw_bb.  Algorithmic bytes per point and pass: planck (nlay+1) rows of f64 +
+        # background optical depth (nlay) rows = (2*nlay+1)*8 B with DOUBLE background rows; a FLOAT background (the bench's, as
+        # in the CKDMIP files) is kept as FLOAT pairs and widened in the sweep - the same bits - so (nlay+1)*8 + nlay*4 B
+        # are what the algorithm has to read (ecckd_gas_sweep_bytes_per_point tells which layout the gas holds).
+        rt_bytes_per_pt = info.get("sweep_bytes_per_point", (2 * nlay + 1) * 8) if isinstance(info, dict) else (2 * nlay + 1) * 8
         rt_gbs = rt_pts * rt_bytes_per_pt / (rt_ms * 1e-3) / 1e9 if rt_ms > 0 else 0.0
         k1_bytes_per_pt = nlay * 4 + 32                  # FLOAT optical depths
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and

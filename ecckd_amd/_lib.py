@@ -95,6 +95,7 @@ SIGNATURES = {
                                       C.POINTER(C.c_void_p)]),
     "ecckd_gas_set_band_albedo": (C.c_int, [C.c_void_p, C.c_double]),
     "ecckd_gas_eval_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _c_double_p, _c_double_p]),
+    "ecckd_gas_sweep_bytes_per_point": (C.c_int, [C.c_void_p, _c_double_p]),
     "ecckd_gas_destroy": (C.c_int, [C.c_void_p]),
     "ecckd_gas_view": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                  C.POINTER(C.c_size_t)]),

@@ -388,6 +388,13 @@ class GasLW:
         check(self.lib.ecckd_gas_eval_stats(self.handle, C.byref(rq), C.byref(hit), C.byref(pr), C.byref(pe)))
         return dict(requests=rq.value, memo_hits=hit.value, points_requested=pr.value, points_evaluated=pe.value)
 
+    def sweep_bytes_per_point(self):
+        """Bytes the error sweep reads per point (ecckd_gas_sweep_bytes_per_point): 656 at 54 layers with a FLOAT background
+        (kept as FLOAT pairs), 872 with a DOUBLE one."""
+        b = C.c_double()
+        check(self.lib.ecckd_gas_sweep_bytes_per_point(self.handle, C.byref(b)))
+        return b.value
+
     def calc_error_batch(self, ibegin, npoints, bound1, bound2):
         b1 = np.ascontiguousarray(bound1, dtype=np.float64)
         b2 = np.ascontiguousarray(bound2, dtype=np.float64)

@@ -923,6 +923,31 @@ __device__ __forceinline__ void eps_fac_one(double od, double& eps, double& fac)
   fac = fmax(1.0 - (1.0 / kD) * fast_div(fmax(eps, TE), fmax(od, TE / kD)), 0.5 * TE);
 }
 
+typedef float float_x2 __attribute__((ext_vector_type(2)));
+typedef float_x2 float_x2_store;
+
+// The background optical depths of a longwave gas as FLOAT pairs: out[p][i] = (bg_od[2p][i], bg_od[2p+1][i]).  A value that
+// is not a float (or is a subnormal float: the conversion back may flush it) raises `inexact`, and the gas keeps to its
+// DOUBLE rows.
+__global__ void __launch_bounds__(256)
+k_pack_bg32(int npair, size_t n, const double* __restrict__ bg_od, float_x2_store* __restrict__ out, int* __restrict__ inexact) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  bool bad = false;
+#pragma unroll 3
+  for (int p = 0; p < npair; ++p) {
+    const double x = __builtin_nontemporal_load(&bg_od[(size_t)(2 * p) * n + i]);
+    const double y = __builtin_nontemporal_load(&bg_od[(size_t)(2 * p + 1) * n + i]);
+    const float fx = (float)x, fy = (float)y;
+    bad |= !((double)fx == x) || !((double)fy == y);
+    bad |= (fx != 0.f && fabsf(fx) < 1.17549435e-38f) || (fy != 0.f && fabsf(fy) < 1.17549435e-38f);
+    float_x2_store v;
+    v.x = fx; v.y = fy;
+    __builtin_nontemporal_store(v, &out[(size_t)p * n + i]);
+  }
+  if (bad) atomicOr(inexact, 1);
+}
+
 // K5c mirror path.  The two-stream equations are symmetric under turning the column upside down:
 // the up sweep through layer l, up_l = up_{l+1} t + B_{l+1}(eps-fac) + B_l fac, is the down sweep
 // dn_{l+1} = dn_l t + B_l(eps-fac) + B_{l+1} fac with the two Planck values exchanged
@@ -939,10 +964,18 @@ __device__ __forceinline__ void eps_fac_one(double od, double& eps, double& fac)
 // state is NLAY+1 doubles instead of 2*NLAY+1, which fits 3 waves per SIMD - the dependent
 // v_fma_f64 chains need that (tools/fp64_latency.hip).  Level sums: as in the fast path, through a
 // wave-private transposed LDS tile every 16 slots.
-template <int NLAY>
+//
+// BG32: the background optical depths come from the packed FLOAT rows (k_pack_bg32: row p holds the layers 2p and 2p+1 of
+// a point side by side, 8 bytes per point like a DOUBLE row) instead of the DOUBLE rows - 656 instead of 872 bytes per point.
+// The rows exist only when every value IS a float (a FLOAT background spectrum, as the CKDMIP files store it), so the
+// converted value is the DOUBLE row's value bit for bit and so is everything computed from it.  The even wave takes the
+// pairs top-down, the odd wave bottom-up with the two halves of a pair exchanged; with an odd number of layers per half the
+// middle pair is shared: .x is the even wave's last layer, .y the odd wave's.
+template <int NLAY, bool BG32>
 __global__ void __launch_bounds__(RT_THREADS, 3)
 k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
                   const double* __restrict__ planck_hl, const double* __restrict__ bg_od,
+                  const float_x2* __restrict__ bg_pair,
                   const double* __restrict__ od_fit, double* __restrict__ partial) {
   static_assert(NLAY % 2 == 0, "the column is split into two equal halves");
   constexpr int NHL = NLAY + 1;
@@ -975,6 +1008,8 @@ k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
   const long long grey_step = half ? -1 : 1;
   const double* __restrict__ grey = od_fit + (size_t)k * NLAY + (half ? NLAY - 1 : 0);  // wave-uniform -> scalar loads
   const double* __restrict__ od0 = bg_od + (half ? (size_t)(NLAY - 1) * n : 0);
+  const float_x2* __restrict__ pr0 = bg_pair + (half ? (size_t)(NLAY / 2 - 1) * n : 0);
+  const float* __restrict__ mid = (const float*)(bg_pair + (size_t)(H / 2) * n) + half;
   const double* __restrict__ pl0 = planck_hl + (half ? (size_t)NLAY * n : 0);
 
   double* tile = s_tile[wave];
@@ -991,10 +1026,26 @@ k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
     double a[H];       // optical depth -> transmittance
     double b[H + 1];   // Planck function -> source of the second sweep
     __builtin_amdgcn_s_setprio(ECCKD_PRIO_LOAD);     // a wave that is about to issue its 55 loads goes ahead of the waves that are computing
+    if constexpr (BG32) {
+      float_x2 v[H / 2];
+      float vm = 0.f;
 #pragma unroll
-    for (int l = 0; l < H; ++l) a[l] = __builtin_nontemporal_load(&od0[(long long)l * row_step + (long long)ii]);
+      for (int q = 0; q < H / 2; ++q) v[q] = __builtin_nontemporal_load(&pr0[(long long)q * row_step + (long long)ii]);
+      if (H & 1) vm = __builtin_nontemporal_load(&mid[2 * ii]);
 #pragma unroll
-    for (int l = 0; l <= H; ++l) b[l] = __builtin_nontemporal_load(&pl0[(long long)l * row_step + (long long)ii]);
+      for (int l = 0; l <= H; ++l) b[l] = __builtin_nontemporal_load(&pl0[(long long)l * row_step + (long long)ii]);
+#pragma unroll
+      for (int q = 0; q < H / 2; ++q) {
+        a[2 * q] = (double)(half ? v[q].y : v[q].x);
+        a[2 * q + 1] = (double)(half ? v[q].x : v[q].y);
+      }
+      if (H & 1) a[H - 1] = (double)vm;
+    } else {
+#pragma unroll
+      for (int l = 0; l < H; ++l) a[l] = __builtin_nontemporal_load(&od0[(long long)l * row_step + (long long)ii]);
+#pragma unroll
+      for (int l = 0; l <= H; ++l) b[l] = __builtin_nontemporal_load(&pl0[(long long)l * row_step + (long long)ii]);
+    }
     __builtin_amdgcn_s_setprio(ECCKD_PRIO_SWEEP1);   // first sweep: the partner wave waits for its result
 
     int slot = 0;
@@ -1900,7 +1951,7 @@ void gas_free(ecckd_gas* g) {
   auto fr = [ctx](void* p) { if (p) ecckd::dev_release(ctx, p); };
   if (g->owns_planck) fr(g->planck_hl);
   fr(g->ssi); fr(g->tf); fr(g->tg); fr(g->hr_low); fr(g->hr_high); fr(g->fx);
-  fr(g->bg_od); fr(g->w1); fr(g->w2); fr(g->cnt); fr(g->hr); fr(g->fds); fr(g->fut);
+  fr(g->bg_od); fr(g->bg_pair); fr(g->w1); fr(g->w2); fr(g->cnt); fr(g->hr); fr(g->fds); fr(g->fut);
   fr(g->wn_sorted); fr(g->dwn_sorted); fr(g->ireorder); fr((void*)g->rows); fr(g->tile_sums); fr(g->super_sums);
   fr(g->lev); fr(g->work);
   delete g;
@@ -2142,13 +2193,25 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   hipLaunchKernelGGL(k_super_sums, dim3((unsigned)g->nsuper, (unsigned)g->nrows), dim3(256), 0, ctx->stream, g->ntiles, g->nsuper,
                      (const double*)g->tile_sums, g->super_sums);
   GTRY(hipGetLastError());
-  int flag = 0;
-  GTRY(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  // FLOAT pairs of the background rows for the sweep (k_rt_lw_bb_mirror<.., true>), kept if every value is a float
+  const bool want_pairs = (nlay == 54 || nlay == 30) && std::getenv("ECCKD_BG64") == nullptr;
+  if (want_pairs) {
+    GTRY(ecckd::dev_malloc(ctx, (void**)&g->bg_pair, (size_t)(nlay / 2) * nwav * 2 * sizeof(float)));
+    hipLaunchKernelGGL(k_pack_bg32, dim3(eblocks), dim3(256), 0, ctx->stream, nlay / 2, nwav, (const double*)g->bg_od,
+                       (float_x2_store*)g->bg_pair, d_flag + 1);
+    GTRY(hipGetLastError());
+  }
+  int flag[2] = {0, 0};
+  GTRY(hipMemcpyAsync(flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   GTRY(hipStreamSynchronize(ctx->stream));
 #undef GTRY
-  if (flag) {
+  if (flag[0]) {
     gas_free(g);
     return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_gas_create_lw: rank is not a permutation of 0..nwav-1");
+  }
+  if (want_pairs && flag[1]) {          // a DOUBLE background with values between the floats: the DOUBLE rows serve
+    ecckd::dev_release(ctx, g->bg_pair);
+    g->bg_pair = nullptr;
   }
   *out = g;
   return ECCKD_OK;
@@ -2688,12 +2751,14 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
   const bool timed = ctx->profile && (ctx->profile_seq++ % ctx->profile_stride) == 0;
   if (ctx->profile) { ctx->stat_rt_lw.all_calls += 1; ctx->stat_rt_lw.all_units += (double)total_pts; }
   if (timed) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
+#define ECCKD_LW_MIRROR(NL, P32)                                                                                          \
+  hipLaunchKernelGGL((k_rt_lw_bb_mirror<NL, P32>), dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, n, d_iv,     \
+                     g->planck_hl, g->bg_od, (const float_x2*)g->bg_pair, d_fit, d_part)
   if (fast_path && nlay == 54) {
-    hipLaunchKernelGGL(k_rt_lw_bb_mirror<54>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
-                       n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+    if (g->bg_pair) ECCKD_LW_MIRROR(54, true); else ECCKD_LW_MIRROR(54, false);
   } else if (fast_path && nlay == 30) {
-    hipLaunchKernelGGL(k_rt_lw_bb_mirror<30>, dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n,
-                       n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
+    if (g->bg_pair) ECCKD_LW_MIRROR(30, true); else ECCKD_LW_MIRROR(30, false);
+#undef ECCKD_LW_MIRROR
   } else {
     hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, ctx->stream, nlay, g->n,
                        n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
@@ -2819,6 +2884,16 @@ int ecckd_gas_eval_stats(ecckd_gas* gas, long long* requests, long long* memo_hi
   if (memo_hits) *memo_hits = gas->memo_hits;
   if (points_requested) *points_requested = gas->points_requested;
   if (points_evaluated) *points_evaluated = gas->points_evaluated;
+  return ECCKD_OK;
+}
+
+// Bytes the error sweep (K5c) reads per spectral point of an interval: the Planck rows and the background rows as this gas
+// holds them (FLOAT pairs if every background value is a float, DOUBLE rows otherwise); shortwave: background rows + ssi.
+int ecckd_gas_sweep_bytes_per_point(ecckd_gas* gas, double* bytes) {
+  ECCKD_REQUIRE(gas && bytes, "ecckd_gas_sweep_bytes_per_point: NULL argument");
+  const int nlay = gas->nlay;
+  if (gas->do_sw) *bytes = (double)(nlay + 1) * 8.0;
+  else *bytes = (double)(nlay + 1) * 8.0 + (double)nlay * (gas->bg_pair ? 4.0 : 8.0);
   return ECCKD_OK;
 }
 

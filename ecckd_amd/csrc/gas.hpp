@@ -59,6 +59,7 @@ struct ecckd_gas {
   double* planck_hl = nullptr;  // [nlay+1][n]
   bool owns_planck = true;
   double* bg_od = nullptr;      // [nlay][n]
+  float* bg_pair = nullptr;     // [nlay/2][n][2]  longwave, only if every background value is a float: layers 2p, 2p+1 of a point side by side
   double* w1 = nullptr;         // [nlay][n]  metric * weight          (log: log(metric)*weight)
   double* w2 = nullptr;         // [nlay][n]  log only: weight of the denominator where metric > 0
   double* cnt = nullptr;        // [nlay][n]  log only: 1 where metric > 0

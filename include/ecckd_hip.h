@@ -226,6 +226,11 @@ int ecckd_calc_error_multi(ecckd_gas* gas, int n, const size_t* h_ibegin, const 
  * (read per call) switches the memo off. */
 int ecckd_gas_eval_stats(ecckd_gas* gas, long long* requests, long long* memo_hits, double* points_requested,
                          double* points_evaluated);
+/* Bytes the error sweep reads per spectral point of an interval it evaluates.  Longwave: (nlay+1) Planck values in DOUBLE
+ * plus nlay background optical depths - 4 bytes each when every background value of the gas is exactly a float (a FLOAT
+ * spectrum as the CKDMIP files hold it: the gas then keeps them as FLOAT pairs and the sweep widens them, the same bits as
+ * reading the DOUBLE rows), 8 bytes otherwise.  Shortwave: nlay background optical depths + the solar irradiance. */
+int ecckd_gas_sweep_bytes_per_point(ecckd_gas* gas, double* bytes);
 
 /* The fitted grey optical depth alone: replaces fit_optical_depth_lw / fit_optical_depth_sw /
  * fit_optical_depth_sw_total_trans (find_g_points.cpp:54-106, :112-165, :171-204) for n

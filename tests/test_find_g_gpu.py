@@ -451,3 +451,80 @@ def test_full_size_compile_time_sweeps_match_run_time_sweeps(ctx, monkeypatch, s
     assert np.array_equal(fast, again)                        # the knob is read per call
     assert np.allclose(fast, generic, rtol=1e-9, atol=1e-12)
     assert not np.array_equal(fast, generic)                  # really two different sweeps (different summation order)
+
+
+@pytest.mark.parametrize("nlay", [54, 30])
+def test_float_background_pairs_give_the_bits_of_the_double_rows(ctx, oracle, monkeypatch, nlay):
+    """A background spectrum whose values are floats (a FLOAT file, find_g_points.cpp:899 reads it into doubles) is kept as
+    FLOAT pairs for the sweep (656 instead of 872 bytes per point at 54 layers); the sweep widens them, so every interval
+    error has the bits it has with the DOUBLE rows (ECCKD_BG64=1).  A background with values between the floats, or with a
+    subnormal float, keeps the DOUBLE rows."""
+    from ecckd_amd import api
+    n = 70_001                      # ragged last tile
+    o = _lw_problem(oracle, n, nlay=nlay, seed=33, method="transmission")
+    bg32 = o["bg"].astype(np.float32)
+    rs = np.random.RandomState(5)
+    cuts = np.concatenate([[0.0], np.sort(rs.uniform(0, 1, 9)), [1.0]])
+    b1, b2 = cuts[:-1], cuts[1:]
+    full, packed = (2 * nlay + 1) * 8, (nlay + 1) * 8 + nlay * 4
+
+    def gas_with(bg, bg64=False):
+        if bg64:
+            monkeypatch.setenv("ECCKD_BG64", "1")
+        else:
+            monkeypatch.delenv("ECCKD_BG64", raising=False)
+        g = api.GasLW(ctx, o["p"], o["t_hl"], _dev(ctx, o["wn"]), _dev(ctx, o["dwn"]), _dev(ctx, o["rank"].astype(np.int32)),
+                      _dev(ctx, o["od"].astype(np.float32)), None if bg is None else _dev(ctx, bg), "transmission", 0.02, 0.0)
+        monkeypatch.delenv("ECCKD_BG64", raising=False)
+        return g
+
+    def errors(g):
+        return np.concatenate([g.calc_error_batch(0, n, b1, b2), g.calc_error_batch(1000, 50_000, b1[:4], b2[:4]),
+                               g.calc_error_batch(0, n, [0.0], [1.0])])
+
+    ga = gas_with(bg32)
+    assert ga.sweep_bytes_per_point() == packed
+    ea = errors(ga)
+    bg_rows = ga.view("bg_optical_depth")
+    ireorder = np.empty(n, dtype=np.int64)
+    ireorder[o["rank"]] = np.arange(n)
+    assert np.array_equal(bg_rows, bg32.astype(np.float64)[:, ireorder])          # the DOUBLE rows are still there for the views
+    ga.close()
+    gb = gas_with(bg32, bg64=True)
+    assert gb.sweep_bytes_per_point() == full
+    eb = errors(gb)
+    gb.close()
+    assert np.array_equal(ea, eb)
+    # against the oracle too
+    o32 = dict(o, bg_s=bg32.astype(np.float64)[:, ireorder])
+    fdn, fup = oracle.radiative_transfer_lw(o["planck"], o32["bg_s"] + o["od"].astype(np.float32).astype(np.float64)[:, ireorder],
+                                            np.ones(n), o["surf_planck"])
+    o32.update(hr=oracle.heating_rate(o["p"], fdn, fup), fds=fdn[-1].copy(), fut=fup[0].copy(),
+               metric=oracle.metric("transmission", o["od"].astype(np.float32).astype(np.float64)[:, ireorder]))
+    eq = _oracle_eq(oracle, o32, "transmission", 0.02)
+    ref = np.array([eq.calc_error(x, y) for x, y in zip(b1[:3], b2[:3])])
+    assert np.allclose(ea[:3], ref, rtol=ERR_RTOL, atol=1e-12)
+    # the same values handed over as DOUBLE: still floats, still pairs
+    gc = gas_with(bg32.astype(np.float64))
+    assert gc.sweep_bytes_per_point() == packed
+    assert np.array_equal(errors(gc), ea)
+    gc.close()
+    # no background at all: zeros are floats
+    gz = gas_with(None)
+    assert gz.sweep_bytes_per_point() == packed
+    ez = errors(gz)
+    gz.close()
+    gz64 = gas_with(None, bg64=True)
+    assert np.array_equal(errors(gz64), ez)
+    gz64.close()
+    # one value between two floats / one subnormal float: the DOUBLE rows serve, and the errors are those of that background
+    for poke in (np.float64(bg32[nlay // 2, 12345]) * (1.0 + 2.0**-40), np.float64(1e-40)):
+        bgd = bg32.astype(np.float64)
+        bgd[nlay // 2, 12345] = poke
+        gd = gas_with(bgd)
+        assert gd.sweep_bytes_per_point() == full
+        ed = errors(gd)
+        gd.close()
+        gd64 = gas_with(bgd, bg64=True)
+        assert np.array_equal(errors(gd64), ed)
+        gd64.close()
