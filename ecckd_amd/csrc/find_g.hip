@@ -700,7 +700,10 @@ k_interval_sums_fit_lw(IntervalArgs ka, int nlay, int method, RowMap R, size_t n
     out[R.A + l] = a;
     out[R.B + l] = b;
     if (is_log) out[R.N + l] = nnz;
-    od_fit[(size_t)k * nlay + l] = fit_lw_layer(method, a, b, nnz, (double)(i2 - i1 + 1));
+    const double fit = fit_lw_layer(method, a, b, nnz, (double)(i2 - i1 + 1));
+    od_fit[(size_t)k * nlay + l] = fit;
+    // the same values bottom-up behind the table: the sweep's odd waves read their layers at ascending addresses too
+    od_fit[((size_t)gridDim.y + k) * nlay + (nlay - 1 - l)] = fit;
   }
 }
 
@@ -971,9 +974,9 @@ k_pack_bg32(int npair, size_t n, const double* __restrict__ bg_od, float_x2_stor
 // converted value is the DOUBLE row's value bit for bit and so is everything computed from it.  The even wave takes the
 // pairs top-down, the odd wave bottom-up with the two halves of a pair exchanged; with an odd number of layers per half the
 // middle pair is shared: .x is the even wave's last layer, .y the odd wave's.
-template <int NLAY, bool BG32>
+template <int NLAY, bool BG32, int PROBE = 0>
 __global__ void __launch_bounds__(RT_THREADS, 3)
-k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
+k_rt_lw_bb_mirror(size_t n, int nint, long long nchunks, const Interval* __restrict__ iv,
                   const double* __restrict__ planck_hl, const double* __restrict__ bg_od,
                   const float_x2* __restrict__ bg_pair,
                   const double* __restrict__ od_fit, double* __restrict__ partial) {
@@ -991,34 +994,40 @@ k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = wave & 1, pair = wave >> 1;
 
-  const long long chunk = blockIdx.x;
-  int lo = 0, hi = nint - 1;
+  // rows of this wave: layers / levels 0,1,2,.. (even wave) or NLAY-1,NLAY-2,.. / NLAY,NLAY-1,.. (odd wave)
+  const long long row_step = half ? -(long long)n : (long long)n;
+  const double* __restrict__ od0 = bg_od + (half ? (size_t)(NLAY - 1) * n : 0);
+  const float_x2* __restrict__ pr0 = bg_pair + (half ? (size_t)(NLAY / 2 - 1) * n : 0);
+  const float* __restrict__ mid = (const float*)(bg_pair + (size_t)(H / 2) * n) + half;
+  const double* __restrict__ pl0 = planck_hl + (half ? (size_t)NLAY * n : 0);
+  double* tile = s_tile[wave];
+  const int rr = lane & 15, qq = lane >> 4;
+  int parity = 0;
+  int klo = 0;
+
+  // A block works through the chunks blockIdx.x, blockIdx.x + gridDim.x, ...; the launch gives every chunk its own block
+  // (gridDim.x = nchunks) unless ECCKD_RT_PERSISTENT asks for one resident round of blocks (see the launch site).  A chunk is
+  // what is summed by itself, in the same order, into its own row of `partial`, either way.
+  for (long long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  int lo = klo, hi = nint - 1;
   while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (iv[mid].chunk0 <= chunk) lo = mid; else hi = mid - 1;
+    int mid_k = (lo + hi + 1) >> 1;
+    if (iv[mid_k].chunk0 <= chunk) lo = mid_k; else hi = mid_k - 1;
   }
   const int k = lo;
+  klo = k;
   const long long chunk_pts = iv[k].chunk_pts;
   const long long c = chunk - iv[k].chunk0;
   const long long p0 = iv[k].i1 + c * chunk_pts;
   long long p1 = p0 + chunk_pts - 1;
   if (p1 > iv[k].i2) p1 = iv[k].i2;
-  // rows of this wave: layers / levels 0,1,2,.. (even wave) or NLAY-1,NLAY-2,.. / NLAY,NLAY-1,.. (odd wave)
-  const long long row_step = half ? -(long long)n : (long long)n;
-  const long long grey_step = half ? -1 : 1;
-  const double* __restrict__ grey = od_fit + (size_t)k * NLAY + (half ? NLAY - 1 : 0);  // wave-uniform -> scalar loads
-  const double* __restrict__ od0 = bg_od + (half ? (size_t)(NLAY - 1) * n : 0);
-  const float_x2* __restrict__ pr0 = bg_pair + (half ? (size_t)(NLAY / 2 - 1) * n : 0);
-  const float* __restrict__ mid = (const float*)(bg_pair + (size_t)(H / 2) * n) + half;
-  const double* __restrict__ pl0 = planck_hl + (half ? (size_t)NLAY * n : 0);
-
-  double* tile = s_tile[wave];
-  const int rr = lane & 15, qq = lane >> 4;
+  // wave-uniform -> scalar loads; the odd waves read the bottom-up copy (k_interval_sums_fit_lw), so that both halves take
+  // their layers at ascending constant offsets
+  const double* __restrict__ grey = od_fit + ((size_t)(half ? nint : 0) + k) * NLAY;
   double acc[NCH];
 #pragma unroll
   for (int j = 0; j < NCH; ++j) acc[j] = 0.0;
 
-  int parity = 0;
   for (long long base = p0; base <= p1; base += PTS, parity ^= 1) {
     const long long i = base + pair * 64 + lane;
     const bool live = i <= p1;
@@ -1026,14 +1035,34 @@ k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
     double a[H];       // optical depth -> transmittance
     double b[H + 1];   // Planck function -> source of the second sweep
     __builtin_amdgcn_s_setprio(ECCKD_PRIO_LOAD);     // a wave that is about to issue its 55 loads goes ahead of the waves that are computing
+    // Addresses: a wave-uniform row pointer (scalar registers, advanced row by row with scalar adds) + the point's 32-bit byte
+    // offset in a row (8 bytes per point in the DOUBLE rows and in the FLOAT-pair rows alike).  The row step is made opaque
+    // once per tile, otherwise the compiler keeps all 42-55 row pointers of the unrolled loads in scalar registers across the
+    // tile loop and spills them.
+    const unsigned voff = (unsigned)ii * 8u;
+    long long step_b = row_step * 8;
+    asm volatile("" : "+s"(step_b));
     if constexpr (BG32) {
       float_x2 v[H / 2];
       float vm = 0.f;
+      if constexpr (PROBE & 1) {
 #pragma unroll
-      for (int q = 0; q < H / 2; ++q) v[q] = __builtin_nontemporal_load(&pr0[(long long)q * row_step + (long long)ii]);
-      if (H & 1) vm = __builtin_nontemporal_load(&mid[2 * ii]);
+        for (int q = 0; q < H / 2; ++q) { v[q].x = 1e-3f * (float)(lane + q); v[q].y = 2e-3f * (float)(lane + q); }
+        vm = 0.5f;
+      } else {
+        const char* rp = (const char*)pr0;
 #pragma unroll
-      for (int l = 0; l <= H; ++l) b[l] = __builtin_nontemporal_load(&pl0[(long long)l * row_step + (long long)ii]);
+        for (int q = 0; q < H / 2; ++q, rp += step_b) v[q] = __builtin_nontemporal_load((const float_x2*)(rp + voff));
+        if (H & 1) vm = __builtin_nontemporal_load((const float*)((const char*)mid + voff));
+      }
+      if constexpr (PROBE & 2) {
+#pragma unroll
+        for (int l = 0; l <= H; ++l) b[l] = 1.0 + 0.01 * (double)(lane + l);
+      } else {
+        const char* rp = (const char*)pl0;
+#pragma unroll
+        for (int l = 0; l <= H; ++l, rp += step_b) b[l] = __builtin_nontemporal_load((const double*)(rp + voff));
+      }
 #pragma unroll
       for (int q = 0; q < H / 2; ++q) {
         a[2 * q] = (double)(half ? v[q].y : v[q].x);
@@ -1041,16 +1070,25 @@ k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
       }
       if (H & 1) a[H - 1] = (double)vm;
     } else {
+      const char* rp = (const char*)od0;
 #pragma unroll
-      for (int l = 0; l < H; ++l) a[l] = __builtin_nontemporal_load(&od0[(long long)l * row_step + (long long)ii]);
+      for (int l = 0; l < H; ++l, rp += step_b) a[l] = __builtin_nontemporal_load((const double*)(rp + voff));
+      rp = (const char*)pl0;
 #pragma unroll
-      for (int l = 0; l <= H; ++l) b[l] = __builtin_nontemporal_load(&pl0[(long long)l * row_step + (long long)ii]);
+      for (int l = 0; l <= H; ++l, rp += step_b) b[l] = __builtin_nontemporal_load((const double*)(rp + voff));
     }
     __builtin_amdgcn_s_setprio(ECCKD_PRIO_SWEEP1);   // first sweep: the partner wave waits for its result
 
+    // A lane past the end of the chunk (only the chunk's last tile has any) sweeps zero Planck functions: every flux of its
+    // column is then an exact zero and adds nothing to the level sums - no select per level.
+    if (base + PTS - 1 > p1) {
+      const double keep = live ? 1.0 : 0.0;
+#pragma unroll
+      for (int l = 0; l <= H; ++l) b[l] *= keep;
+    }
     int slot = 0;
     auto push = [&](double flux) {
-      tile[(slot & 15) * ROW + lane] = live ? flux : 0.0;
+      tile[(slot & 15) * ROW + lane] = flux;
       if ((slot & 15) == 15 || slot == NSLOT - 1) {
         const int ch = slot >> 4;
         __builtin_amdgcn_wave_barrier();
@@ -1080,13 +1118,13 @@ k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
 #pragma unroll
     for (int l = 0; l + 1 < H; l += 2) {
       double eps0, fac0, eps1, fac1;
-      eps_fac_pair(a[l] + grey[(long long)l * grey_step], a[l + 1] + grey[(long long)(l + 1) * grey_step], eps0, fac0, eps1, fac1);
+      eps_fac_pair(a[l] + grey[l], a[l + 1] + grey[l + 1], eps0, fac0, eps1, fac1);
       layer(l, eps0, fac0);
       layer(l + 1, eps1, fac1);
     }
     if (H & 1) {
       double eps0, fac0;
-      eps_fac_one(a[H - 1] + grey[(long long)(H - 1) * grey_step], eps0, fac0);
+      eps_fac_one(a[H - 1] + grey[H - 1], eps0, fac0);
       layer(H - 1, eps0, fac0);
     }
     // the flux that enters this half from the other side is the partner wave's result
@@ -1099,17 +1137,15 @@ k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
       flux = flux * a[l] + b[l];
       push(flux);
     }
-    if ((NSLOT & 15) != 0) {
-#pragma unroll
-      for (int j = (NSLOT & 15); j < 16; ++j) tile[j * ROW + lane] = 0.0;
-    }
+    // (the rows NSLOT % 16 .. 15 of the last group keep the values of the group before: they reach only the sums of slots
+    // >= NSLOT, which nothing reads)
   }
 
   if (lane < 16) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) s_out[wave][j * 16 + lane] = acc[j];
   }
-  __syncthreads();
+  __syncthreads();      // the next chunk's s_out is written behind at least one more barrier (its tile loop)
   for (int t = tid; t < 2 * NHL; t += RT_THREADS) {
     // even waves (0, 2): slot 1+i = dn[i+1], slot H+1+k = up[H-1-k];
     // odd waves (1, 3):  slot 0 = up[NLAY], slot 1+i = up[NLAY-1-i], slot H+1+k = dn[H+1+k]
@@ -1126,6 +1162,7 @@ k_rt_lw_bb_mirror(size_t n, int nint, const Interval* __restrict__ iv,
     double v = 0.0;
     if (sl >= 0) v = s_out[par][sl] + s_out[par + 2][sl];
     partial[(size_t)chunk * 2 * NHL + t] = v;
+  }
   }
 }
 
@@ -2752,9 +2789,21 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
   if (ctx->profile) { ctx->stat_rt_lw.all_calls += 1; ctx->stat_rt_lw.all_units += (double)total_pts; }
   if (timed) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
 #define ECCKD_LW_MIRROR(NL, P32)                                                                                          \
-  hipLaunchKernelGGL((k_rt_lw_bb_mirror<NL, P32>), dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, n, d_iv,     \
+  hipLaunchKernelGGL((k_rt_lw_bb_mirror<NL, P32>), dim3(mirror_grid), dim3(RT_THREADS), 0, ctx->stream, g->n, n, nchunks, d_iv,     \
                      g->planck_hl, g->bg_od, (const float_x2*)g->bg_pair, d_fit, d_part)
-  if (fast_path && nlay == 54) {
+  // a block per chunk.  (ECCKD_RT_PERSISTENT: one resident round of blocks, each taking every mirror_grid-th chunk - measured
+  // SLOWER on a partition of unequal intervals, 1 069 against 1 015 us per pass of 38 intervals over 7.2e6 points, equal on
+  // equal intervals: the hardware's block dispatcher balances chunks of one to three tiles better than a fixed deal.)
+  static const bool persistent = std::getenv("ECCKD_RT_PERSISTENT") != nullptr;
+  const unsigned mirror_grid = (unsigned)(persistent ? std::min<long long>(nchunks, target_blocks) : nchunks);
+  static const int rt_probe = std::getenv("ECCKD_RT_PROBE") ? std::atoi(std::getenv("ECCKD_RT_PROBE")) : 0;
+  if (fast_path && nlay == 54 && g->bg_pair && rt_probe) {
+#define ECCKD_LW_PROBE(PR)                                                                                          \
+  hipLaunchKernelGGL((k_rt_lw_bb_mirror<54, true, PR>), dim3(mirror_grid), dim3(RT_THREADS), 0, ctx->stream, g->n, n, nchunks, d_iv,     \
+                     g->planck_hl, g->bg_od, (const float_x2*)g->bg_pair, d_fit, d_part)
+    if (rt_probe == 1) ECCKD_LW_PROBE(1); else if (rt_probe == 2) ECCKD_LW_PROBE(2); else ECCKD_LW_PROBE(3);
+#undef ECCKD_LW_PROBE
+  } else if (fast_path && nlay == 54) {
     if (g->bg_pair) ECCKD_LW_MIRROR(54, true); else ECCKD_LW_MIRROR(54, false);
   } else if (fast_path && nlay == 30) {
     if (g->bg_pair) ECCKD_LW_MIRROR(30, true); else ECCKD_LW_MIRROR(30, false);
