@@ -666,12 +666,27 @@ __device__ __forceinline__ double fit_lw_layer(int method, double a, double b, d
   }
 }
 
+// The rows of a longwave gas by number, from their base pointers in the kernel arguments (the device table of row pointers
+// costs a dependent load in front of every row's own loads).
+struct LwRowBases {
+  const double *w1, *w2, *cnt, *planck_hl, *hr, *fds, *fut;
+  size_t n;
+  int is_log;
+  __device__ __forceinline__ const double* row(const RowMap& R, int nlay, int r) const {
+    if (r < R.B) return w1 + (size_t)(r - R.A) * n;
+    if (r < R.B + nlay) return is_log ? w2 + (size_t)(r - R.B) * n : planck_hl + (size_t)(r - R.B + 1) * n;
+    if (is_log && r < R.H) return cnt + (size_t)(r - R.N) * n;
+    if (r < R.FDS) return hr + (size_t)(r - R.H) * n;
+    return r == R.FDS ? fds : fut;
+  }
+};
+
 // K5a + K5b in one launch for the longwave: the fit of layer l needs only the sums of its own rows (A+l, B+l and, for the
 // logarithmic method, N+l), so the block that owns layer l adds up those rows and finishes the fit itself; the remaining
 // rows (heating rate, boundary fluxes) get one block each as before.  grid (nlay + rows from R.H on, nint), block 256.
 __global__ void __launch_bounds__(256)
 k_interval_sums_fit_lw(IntervalArgs ka, int nlay, int method, RowMap R, size_t ntiles, size_t nsuper, const Interval* __restrict__ iv,
-                       int use_ka, Interval* __restrict__ iv_out, const double* const* __restrict__ rows,
+                       int use_ka, Interval* __restrict__ iv_out, LwRowBases rows,
                        const double* __restrict__ ts, const double* __restrict__ ss, double* __restrict__ sums,
                        double* __restrict__ od_fit) {
   __shared__ double s4[4];
@@ -683,7 +698,7 @@ k_interval_sums_fit_lw(IntervalArgs ka, int nlay, int method, RowMap R, size_t n
   double* out = sums + (size_t)k * R.total;
   if (bx >= nlay) {
     const int r = R.H + (bx - nlay);
-    const double s = block_sum_256(interval_row_acc(rows[r], ts + (size_t)r * ntiles, ss + (size_t)r * nsuper, i1, i2, tid), s4);
+    const double s = block_sum_256(interval_row_acc(rows.row(R, nlay, r), ts + (size_t)r * ntiles, ss + (size_t)r * nsuper, i1, i2, tid), s4);
     if (tid == 0) out[r] = s;
     return;
   }
@@ -691,10 +706,10 @@ k_interval_sums_fit_lw(IntervalArgs ka, int nlay, int method, RowMap R, size_t n
   const bool is_log = method == ECCKD_AVG_LOGARITHMIC;
   // the loads of the two (three) rows go out together: one memory round trip and one pair of barriers instead of two (three)
   __shared__ double s43[3][4];
-  double a = interval_row_acc(rows[R.A + l], ts + (size_t)(R.A + l) * ntiles, ss + (size_t)(R.A + l) * nsuper, i1, i2, tid);
-  double b = interval_row_acc(rows[R.B + l], ts + (size_t)(R.B + l) * ntiles, ss + (size_t)(R.B + l) * nsuper, i1, i2, tid);
+  double a = interval_row_acc(rows.row(R, nlay, R.A + l), ts + (size_t)(R.A + l) * ntiles, ss + (size_t)(R.A + l) * nsuper, i1, i2, tid);
+  double b = interval_row_acc(rows.row(R, nlay, R.B + l), ts + (size_t)(R.B + l) * ntiles, ss + (size_t)(R.B + l) * nsuper, i1, i2, tid);
   double nnz = 0.0;
-  if (is_log) nnz = interval_row_acc(rows[R.N + l], ts + (size_t)(R.N + l) * ntiles, ss + (size_t)(R.N + l) * nsuper, i1, i2, tid);
+  if (is_log) nnz = interval_row_acc(rows.row(R, nlay, R.N + l), ts + (size_t)(R.N + l) * ntiles, ss + (size_t)(R.N + l) * nsuper, i1, i2, tid);
   block_sum_256_x3(a, b, nnz, s43);
   if (tid == 0) {
     out[R.A + l] = a;
@@ -1194,14 +1209,17 @@ k_cost_lw(int nlay, RowMap R, const Interval* __restrict__ iv, long long nchunks
     const long long cb = c0 + cg * 32;
     const int cnt = (int)((c1 - cb) < 32 ? (c1 - cb) : 32);
     if (t < nv) {
+      // sixteen loads in flight, unconditionally (behind the end of a short group: its last chunk again, the value replaced
+      // by 0.0), added in chunk order.  (All 32 of a group in flight: 11.7 instead of 10.1 us per launch - the one CU that sums
+      // an interval is bound by its own load path, not by the round trips.)
       double a = 0.0;
 #pragma unroll 1
-      for (int h = 0; h < 32; h += 16) {               // sixteen loads in flight, added in chunk order
+      for (int h = 0; h < 32; h += 16) {
         double q[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) q[u] = h + u < cnt ? partial[(size_t)(cb + h + u) * nv + t] : 0.0;
+        for (int u = 0; u < 16; ++u) q[u] = partial[(size_t)(cb + (h + u < cnt ? h + u : cnt - 1)) * nv + t];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) a += q[u];        // + 0.0 behind the last chunk of a short group changes nothing
+        for (int u = 0; u < 16; ++u) a += h + u < cnt ? q[u] : 0.0;      // + 0.0 changes nothing
       }
       s_grp[(size_t)cg * nv + t] = a;
     }
@@ -1873,14 +1891,17 @@ k_cost_sw(int nlay, int ntotal, SwTruthRows rows, const Interval* __restrict__ i
     const long long cb = c0 + cg * 32;
     const int cnt = (int)((c1 - cb) < 32 ? (c1 - cb) : 32);
     if (t < nv) {
+      // sixteen loads in flight, unconditionally (behind the end of a short group: its last chunk again, the value replaced
+      // by 0.0), added in chunk order.  (All 32 of a group in flight: 11.7 instead of 10.1 us per launch - the one CU that sums
+      // an interval is bound by its own load path, not by the round trips.)
       double a = 0.0;
 #pragma unroll 1
-      for (int h = 0; h < 32; h += 16) {               // sixteen loads in flight, added in chunk order
+      for (int h = 0; h < 32; h += 16) {
         double q[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) q[u] = h + u < cnt ? partial[(size_t)(cb + h + u) * nv + t] : 0.0;
+        for (int u = 0; u < 16; ++u) q[u] = partial[(size_t)(cb + (h + u < cnt ? h + u : cnt - 1)) * nv + t];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) a += q[u];        // + 0.0 behind the last chunk of a short group changes nothing
+        for (int u = 0; u < 16; ++u) a += h + u < cnt ? q[u] : 0.0;      // + 0.0 changes nothing
       }
       s_grp[(size_t)cg * nv + t] = a;
     }
@@ -2717,9 +2738,12 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
     ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, h_iv, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
   }
 
+  LwRowBases lw_rows;
+  lw_rows.w1 = g->w1; lw_rows.w2 = g->w2; lw_rows.cnt = g->cnt; lw_rows.planck_hl = g->planck_hl; lw_rows.hr = g->hr;
+  lw_rows.fds = g->fds; lw_rows.fut = g->fut; lw_rows.n = g->n; lw_rows.is_log = g->method == ECCKD_AVG_LOGARITHMIC;
   if (!g->do_sw)
     hipLaunchKernelGGL(k_interval_sums_fit_lw, dim3(nlay + (g->rm.total - g->rm.H), n), dim3(256), 0, ctx->stream, ka, nlay, g->method,
-                       g->rm, g->ntiles, g->nsuper, d_iv, use_ka, d_iv, (const double* const*)g->rows, g->tile_sums, g->super_sums,
+                       g->rm, g->ntiles, g->nsuper, d_iv, use_ka, d_iv, lw_rows, g->tile_sums, g->super_sums,
                        d_sums, d_fit);
   else
     hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, ka, g->nrows, g->ntiles, g->nsuper, d_iv, use_ka,
