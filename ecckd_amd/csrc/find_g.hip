@@ -989,7 +989,7 @@ k_pack_bg32(int npair, size_t n, const double* __restrict__ bg_od, float_x2_stor
 // converted value is the DOUBLE row's value bit for bit and so is everything computed from it.  The even wave takes the
 // pairs top-down, the odd wave bottom-up with the two halves of a pair exchanged; with an odd number of layers per half the
 // middle pair is shared: .x is the even wave's last layer, .y the odd wave's.
-template <int NLAY, bool BG32, int PROBE = 0>
+template <int NLAY, bool BG32>
 __global__ void __launch_bounds__(RT_THREADS, 3)
 k_rt_lw_bb_mirror(size_t n, int nint, long long nchunks, const Interval* __restrict__ iv,
                   const double* __restrict__ planck_hl, const double* __restrict__ bg_od,
@@ -1060,20 +1060,13 @@ k_rt_lw_bb_mirror(size_t n, int nint, long long nchunks, const Interval* __restr
     if constexpr (BG32) {
       float_x2 v[H / 2];
       float vm = 0.f;
-      if constexpr (PROBE & 1) {
-#pragma unroll
-        for (int q = 0; q < H / 2; ++q) { v[q].x = 1e-3f * (float)(lane + q); v[q].y = 2e-3f * (float)(lane + q); }
-        vm = 0.5f;
-      } else {
+      {
         const char* rp = (const char*)pr0;
 #pragma unroll
         for (int q = 0; q < H / 2; ++q, rp += step_b) v[q] = __builtin_nontemporal_load((const float_x2*)(rp + voff));
         if (H & 1) vm = __builtin_nontemporal_load((const float*)((const char*)mid + voff));
       }
-      if constexpr (PROBE & 2) {
-#pragma unroll
-        for (int l = 0; l <= H; ++l) b[l] = 1.0 + 0.01 * (double)(lane + l);
-      } else {
+      {
         const char* rp = (const char*)pl0;
 #pragma unroll
         for (int l = 0; l <= H; ++l, rp += step_b) b[l] = __builtin_nontemporal_load((const double*)(rp + voff));
@@ -1178,204 +1171,6 @@ k_rt_lw_bb_mirror(size_t n, int nint, long long nchunks, const Interval* __restr
     if (sl >= 0) v = s_out[par][sl] + s_out[par + 2][sl];
     partial[(size_t)chunk * 2 * NHL + t] = v;
   }
-  }
-}
-
-// K5c for batches of many chunks (whole partitions): the same pair-of-waves sweep with the NEXT tile's rows in flight while the
-// current tile is swept.  The plain kernel above has a tile's loads in flight only while it waits for the first of them, and its
-// registers are full (the load destinations ARE most of them); here a wave owns 256 registers (2 waves per SIMD), the 42
-// loads of the next tile are issued before the first sweep of the current one into registers of their own, and a block walks
-// the chunks blockIdx.x, blockIdx.x + gridDim.x, ... (one resident round of 2 blocks per CU), so that the next tile is known
-// across chunk boundaries.  Chunks, tiles, the order of every addition and the layout of `partial` are those of the plain
-// kernel: an interval's error has the same bits whichever of the two evaluated it.  FLOAT-pair background only; up to 64
-// intervals (their table is copied to LDS once per block).
-template <int NLAY>
-__global__ void __launch_bounds__(RT_THREADS, 2)
-k_rt_lw_bb_mirror_ahead(size_t n, int nint, long long nchunks, const Interval* __restrict__ iv,
-                        const double* __restrict__ planck_hl, const float_x2* __restrict__ bg_pair,
-                        const double* __restrict__ od_fit, double* __restrict__ partial) {
-  static_assert(NLAY % 2 == 0, "the column is split into two equal halves");
-  constexpr int NHL = NLAY + 1;
-  constexpr int H = NLAY / 2;
-  constexpr int NSLOT = 2 * H + 1;
-  constexpr int NCH = (NSLOT + 15) / 16;
-  constexpr int ROW = 65;
-  constexpr int PTS = RT_THREADS / 2;
-  __shared__ double s_tile[4][16 * ROW];
-  __shared__ double s_out[4][NCH * 16];
-  __shared__ double s_x[2][4][64];
-  __shared__ long long s_c0[64], s_i1[64], s_i2[64], s_cp[64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = wave & 1, pair = wave >> 1;
-  if (tid < nint) {
-    const Interval me = iv[tid];
-    s_c0[tid] = me.chunk0; s_i1[tid] = me.i1; s_i2[tid] = me.i2; s_cp[tid] = me.chunk_pts;
-  }
-  __syncthreads();
-
-  const long long row_step = half ? -(long long)n : (long long)n;
-  const float_x2* __restrict__ pr0 = bg_pair + (half ? (size_t)(NLAY / 2 - 1) * n : 0);
-  const float* __restrict__ mid = (const float*)(bg_pair + (size_t)(H / 2) * n) + half;
-  const double* __restrict__ pl0 = planck_hl + (half ? (size_t)NLAY * n : 0);
-  double* tile = s_tile[wave];
-  const int rr = lane & 15, qq = lane >> 4;
-
-  // interval of a chunk (chunks ascend along a block's walk: the search starts at the interval of the chunk before)
-  auto locate = [&](long long chunk, int k_from, int& k, long long& p0, long long& p1) {
-    int kk = k_from;
-    while (kk + 1 < nint && s_c0[kk + 1] <= chunk) ++kk;
-    kk = __builtin_amdgcn_readfirstlane(kk);
-    const long long cp = s_cp[kk];
-    long long a0 = s_i1[kk] + (chunk - s_c0[kk]) * cp;
-    long long a1 = a0 + cp - 1;
-    const long long e = s_i2[kk];
-    if (a1 > e) a1 = e;
-    k = kk;
-    p0 = ((long long)__builtin_amdgcn_readfirstlane((int)(a0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a0);
-    p1 = ((long long)__builtin_amdgcn_readfirstlane((int)(a1 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a1);
-  };
-  // the rows of the tile that starts at `base` of a chunk that ends at `last`, into the registers of the tile ahead
-  float_x2 nv[H / 2];
-  float nvm = 0.f;
-  double nb[H + 1];
-  auto fetch = [&](long long base, long long last) {
-    const long long i = base + pair * 64 + lane;
-    const size_t ii = i <= last ? (size_t)i : (size_t)last;
-    const unsigned voff = (unsigned)ii * 8u;
-    long long step_b = row_step * 8;
-    asm volatile("" : "+s"(step_b));
-    const char* rp = (const char*)pr0;
-#pragma unroll
-    for (int q = 0; q < H / 2; ++q, rp += step_b) nv[q] = __builtin_nontemporal_load((const float_x2*)(rp + voff));
-    if (H & 1) nvm = __builtin_nontemporal_load((const float*)((const char*)mid + voff));
-    rp = (const char*)pl0;
-#pragma unroll
-    for (int l = 0; l <= H; ++l, rp += step_b) nb[l] = __builtin_nontemporal_load((const double*)(rp + voff));
-  };
-
-  long long chunk = blockIdx.x;
-  int k;
-  long long base, p1;
-  locate(chunk, 0, k, base, p1);
-  fetch(base, p1);
-  double acc[NCH];
-#pragma unroll
-  for (int j = 0; j < NCH; ++j) acc[j] = 0.0;
-  int parity = 0;
-  for (;;) {
-    // the tile ahead becomes the tile in hand
-    double a[H];
-    double b[H + 1];
-#pragma unroll
-    for (int q = 0; q < H / 2; ++q) {
-      a[2 * q] = (double)(half ? nv[q].y : nv[q].x);
-      a[2 * q + 1] = (double)(half ? nv[q].x : nv[q].y);
-    }
-    if (H & 1) a[H - 1] = (double)nvm;
-#pragma unroll
-    for (int l = 0; l <= H; ++l) b[l] = nb[l];
-    const bool live = base + pair * 64 + lane <= p1;
-    const bool last_of_chunk = base + PTS > p1;
-    // which tile comes next; its loads go out now (behind the block's last tile: that tile again - no branch round the loads)
-    long long nchunk = chunk, nbase = base + PTS, np1 = p1;
-    int nk = k;
-    bool more = true;
-    if (last_of_chunk) {
-      nchunk = chunk + gridDim.x;
-      if (nchunk < nchunks) locate(nchunk, k, nk, nbase, np1);
-      else { more = false; nchunk = chunk; nbase = base; }
-    }
-    __builtin_amdgcn_s_setprio(ECCKD_PRIO_LOAD);
-    fetch(nbase, np1);
-    __builtin_amdgcn_s_setprio(ECCKD_PRIO_SWEEP1);
-    if (last_of_chunk) {           // only a chunk's last tile has lanes past its end: they sweep zero Planck functions
-      const double keep = live ? 1.0 : 0.0;
-#pragma unroll
-      for (int l = 0; l <= H; ++l) b[l] *= keep;
-    }
-    const double* __restrict__ grey = od_fit + ((size_t)(half ? nint : 0) + k) * NLAY;
-
-    int slot = 0;
-    auto push = [&](double flux) {
-      tile[(slot & 15) * ROW + lane] = flux;
-      if ((slot & 15) == 15 || slot == NSLOT - 1) {
-        const int ch = slot >> 4;
-        __builtin_amdgcn_wave_barrier();
-        double sum = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) sum += tile[rr * ROW + qq * 16 + j];
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        acc[ch] += sum;
-        __builtin_amdgcn_wave_barrier();
-      }
-      ++slot;
-    };
-    double flux = half ? b[0] : 0.0;
-    push(flux);
-    auto layer = [&](int l, double eps, double fac) {
-      const double emf = eps - fac;
-      const double t = 1.0 - eps;
-      const double near = b[l], far = b[l + 1];
-      flux = flux * t + near * emf + far * fac;
-      a[l] = t;
-      b[l] = far * emf + near * fac;
-      push(flux);
-    };
-#pragma unroll
-    for (int l = 0; l + 1 < H; l += 2) {
-      double eps0, fac0, eps1, fac1;
-      eps_fac_pair(a[l] + grey[l], a[l + 1] + grey[l + 1], eps0, fac0, eps1, fac1);
-      layer(l, eps0, fac0);
-      layer(l + 1, eps1, fac1);
-    }
-    if (H & 1) {
-      double eps0, fac0;
-      eps_fac_one(a[H - 1] + grey[H - 1], eps0, fac0);
-      layer(H - 1, eps0, fac0);
-    }
-    s_x[parity][wave][lane] = flux;
-    __builtin_amdgcn_s_setprio(ECCKD_PRIO_SWEEP2);
-    // a barrier that leaves the loads of the tile ahead in flight: only the LDS writes have to be done
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    flux = s_x[parity][wave ^ 1][lane];
-    parity ^= 1;
-#pragma unroll
-    for (int l = H - 1; l >= 0; --l) {
-      flux = flux * a[l] + b[l];
-      push(flux);
-    }
-    if (last_of_chunk) {
-      if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) s_out[wave][j * 16 + lane] = acc[j];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-      for (int t = tid; t < 2 * NHL; t += RT_THREADS) {
-        int par = -1, sl = -1;
-        if (t < NHL) {
-          if (t >= 1 && t <= H) { par = 0; sl = t; }
-          else if (t > H) { par = 1; sl = t; }
-        } else {
-          const int u = t - NHL;
-          if (u == NLAY) { par = 1; sl = 0; }
-          else if (u >= H) { par = 1; sl = NLAY - u; }
-          else { par = 0; sl = 2 * H - u; }
-        }
-        double v = 0.0;
-        if (sl >= 0) v = s_out[par][sl] + s_out[par + 2][sl];
-        partial[(size_t)chunk * 2 * NHL + t] = v;
-      }
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) acc[j] = 0.0;
-    }
-    if (!more) break;
-    chunk = nchunk; k = nk; base = nbase; p1 = np1;
   }
 }
 
@@ -3018,25 +2813,7 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
   // equal intervals: the hardware's block dispatcher balances chunks of one to three tiles better than a fixed deal.)
   static const bool persistent = std::getenv("ECCKD_RT_PERSISTENT") != nullptr;
   const unsigned mirror_grid = (unsigned)(persistent ? std::min<long long>(nchunks, target_blocks) : nchunks);
-  static const int rt_probe = std::getenv("ECCKD_RT_PROBE") ? std::atoi(std::getenv("ECCKD_RT_PROBE")) : 0;
-  // batches of many chunks: the kernel that keeps the next tile's rows in flight (2 blocks per CU, one resident round)
-  static const long long ahead_min = std::getenv("ECCKD_RT_AHEAD_MIN") ? std::atoll(std::getenv("ECCKD_RT_AHEAD_MIN")) : 0;   // off: measured slower, see DESIGN 4
-  const bool ahead = fast_path && g->bg_pair && n <= 64 && ahead_min > 0 && nchunks >= ahead_min && !rt_probe;
-  if (ahead) {
-    const unsigned ahead_grid = (unsigned)std::min<long long>(nchunks, 2LL * ctx->num_cu);
-    if (nlay == 54)
-      hipLaunchKernelGGL((k_rt_lw_bb_mirror_ahead<54>), dim3(ahead_grid), dim3(RT_THREADS), 0, ctx->stream, g->n, n, nchunks, d_iv,
-                         g->planck_hl, (const float_x2*)g->bg_pair, d_fit, d_part);
-    else
-      hipLaunchKernelGGL((k_rt_lw_bb_mirror_ahead<30>), dim3(ahead_grid), dim3(RT_THREADS), 0, ctx->stream, g->n, n, nchunks, d_iv,
-                         g->planck_hl, (const float_x2*)g->bg_pair, d_fit, d_part);
-  } else if (fast_path && nlay == 54 && g->bg_pair && rt_probe) {
-#define ECCKD_LW_PROBE(PR)                                                                                          \
-  hipLaunchKernelGGL((k_rt_lw_bb_mirror<54, true, PR>), dim3(mirror_grid), dim3(RT_THREADS), 0, ctx->stream, g->n, n, nchunks, d_iv,     \
-                     g->planck_hl, g->bg_od, (const float_x2*)g->bg_pair, d_fit, d_part)
-    if (rt_probe == 1) ECCKD_LW_PROBE(1); else if (rt_probe == 2) ECCKD_LW_PROBE(2); else ECCKD_LW_PROBE(3);
-#undef ECCKD_LW_PROBE
-  } else if (fast_path && nlay == 54) {
+  if (fast_path && nlay == 54) {
     if (g->bg_pair) ECCKD_LW_MIRROR(54, true); else ECCKD_LW_MIRROR(54, false);
   } else if (fast_path && nlay == 30) {
     if (g->bg_pair) ECCKD_LW_MIRROR(30, true); else ECCKD_LW_MIRROR(30, false);

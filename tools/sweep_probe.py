@@ -1,6 +1,6 @@
 """Timing probe for the longwave sweep kernel alone: a fixed whole-partition batch (38 intervals over the 7.2e6 points) and a
-fixed single interval, timed by the library's HIP events around every launch.  With ECCKD_RT_PROBE=1|2|3 (a build that has
-the probe variants) the kernel runs without its background loads / Planck loads / any loads: where the floors are.
+few single intervals, timed by the library's HIP events around every launch (ECCKD_BG64=1: with DOUBLE background rows;
+ECCKD_RT_PERSISTENT=1: one resident round of blocks walking the chunks).
 usage: python tools/sweep_probe.py [nwav]"""
 import os, sys, json
 import numpy as np
@@ -22,7 +22,7 @@ rank, _ = api.stable_argsort_bands(ctx, key, [0], [nwav - 1], want_ordered=False
 gas = api.GasLW(ctx, p, syn.temperature_profile(p), wn, dwn, rank, od, bg, "transmission", flux_weight=0.0)
 bpp = gas.sweep_bytes_per_point()
 cuts = np.linspace(0.0, 1.0, 39) ** 1.5
-out = {"probe": os.environ.get("ECCKD_RT_PROBE", "0"), "bytes_per_point": bpp}
+out = {"bytes_per_point": bpp}
 even = np.linspace(0.0, 1.0, 39)
 for label, (b1, b2) in (("whole partition, 38 intervals", (cuts[:-1], cuts[1:])), ("whole partition, 38 equal intervals", (even[:-1], even[1:])),
                         ("whole partition, 1 interval", ([0.0], [1.0])), ("whole partition, 4 equal intervals", ([0.0, 0.25, 0.5, 0.75], [0.25, 0.5, 0.75, 1.0])),
