@@ -628,6 +628,11 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                          "timing": "HIP events around every %d-th launch inside the timed region; averages over the timed launches" % max(1, args.profile_stride),
                          "avg_launch_ms": rt_ms / max(rt_calls, 1),
                          "algorithmic_bytes_per_point": rt_bytes_per_pt,
+                         # rounds 1-2 read the background as DOUBLE rows, SURVEY 8d's (2*nlay+1)*8 bytes per point: the same
+                         # launches priced at that figure, for comparison across rounds (NOT what the kernel reads now)
+                         "at_double_rows": {"bytes_per_point": (2 * nlay + 1) * 8,
+                                            "achieved": rt_gbs * (2 * nlay + 1) * 8 / rt_bytes_per_pt,
+                                            "frac": rt_gbs * (2 * nlay + 1) * 8 / rt_bytes_per_pt / HBM_PEAK_GBS},
                          "points_per_launch": rt_pts / max(rt_calls, 1),
                          "share_of_step_time": rt_ms / max(rt_calls, 1) * all_calls * 1e-3 / dt,
                          # K1 is bound by fp64 vector issue, not by HBM: ~94 VALU instructions per layer and point (2 exp, 2

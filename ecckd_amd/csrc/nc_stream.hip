@@ -24,9 +24,10 @@
 namespace {
 
 constexpr size_t CHUNK_BYTES = (size_t)16 << 20;
-constexpr int NBUF = 6;            // pinned buffers in flight
+constexpr int NBUF = 12;           // pinned buffers in flight
 // pread threads (ECCKD_READ_THREADS): one per buffer by default - 503 MB from the page cache in 34-36 ms the first time and 14-18 ms
-// after, against 51-53 / 30-38 ms with four threads striding over six buffers (tools/classic_read_probe.py)
+// after with six buffers and threads, against 51-53 / 30-38 ms with four threads striding over six buffers
+// (tools/classic_read_probe.py); twelve of each: create_look_up_table over 23 GB of spectra 2.23 -> 1.84 s (tools/e2e_bench.py)
 constexpr int NREADERS_DEFAULT = NBUF, NREADERS_MAX = NBUF;
 inline int nreaders_wanted() {
   static const int n = [] {

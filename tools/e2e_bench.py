@@ -190,6 +190,11 @@ def gpu_chain(d, inp):
         if stage == "reorder_spectrum":
             rec["log"] = ["%s %s" % st for st in stamps]
         per_process.append(rec)
+        if os.environ.get("ECCKD_E2E_LOGDIR"):                 # every tool's timed log, for looking at a stage from inside
+            ld = os.path.join(os.environ["ECCKD_E2E_LOGDIR"], os.path.basename(os.path.normpath(d)))
+            os.makedirs(ld, exist_ok=True)
+            with open(os.path.join(ld, "%02d_%s.log" % (len(per_process), name)), "w") as lf:
+                lf.write(r.stdout + r.stderr)
         if r.returncode != 0:
             raise RuntimeError(f"{name} failed ({r.returncode}): {r.stderr[-2000:]}")
         return r
