@@ -6,8 +6,6 @@ tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/${tag}_profiles; mkdir -p $out
 quiet="--no-cpu --no-lut-opt --no-sw --no-e2e"
-# the bench line as the driver runs it
-python3 bench.py > $out/bench.json 2> $out/bench.err
 # per-kernel totals of the headline step
 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python3 bench.py --steps 2 --warmup 1 $quiet > $out/ks_bench.json 2> $out/ks.err
 # HBM bytes of the dominant kernel: separate --pmc passes, kernel trace only beside them
@@ -15,6 +13,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $quiet > $out/pmc_$c.json 2> $out/pmc_$c.err
 done
 python3 tools/traffic_json.py k_rt_lw_bb $out/pmc_FETCH_SIZE/p_counter_collection.csv $out/pmc_WRITE_SIZE/p_counter_collection.csv $out/pmc_FETCH_SIZE.json > $out/traffic_k_rt_lw_bb.json
+# the bench line as the driver runs it; its `traffic` comes from profiles/<tag>_traffic_k_rt_lw_bb.json: this build's, just measured
+cp $out/traffic_k_rt_lw_bb.json profiles/${tag}_traffic_k_rt_lw_bb.json
+python3 bench.py > $out/bench.json 2> $out/bench.err
 # K6 (g-point averaging) and K2 / K7: timings, then the SQ counters and HBM bytes of K6
 python3 tools/k267_probe.py > $out/k267_probe.json 2> $out/k267.err
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
