@@ -1768,8 +1768,16 @@ k_rt_sw_bb_fast(size_t n, int nint, const Interval* __restrict__ iv, double cos_
     const size_t ii = live ? (size_t)i : (size_t)p1;
     double tau[NLAY];
     __builtin_amdgcn_s_setprio(3);     // as in the longwave kernel: the wave that is about to fetch its column goes first
+    {
+      // one wave-uniform row pointer walked with scalar adds + the point's 32-bit byte offset (as in the longwave kernel: the
+      // 54 row pointers of the unrolled loads otherwise live in scalar registers across the tile loop and spill)
+      const unsigned voff = (unsigned)ii * 8u;
+      long long step_b = (long long)n * 8;
+      asm volatile("" : "+s"(step_b));
+      const char* rp = (const char*)bg_od;
 #pragma unroll
-    for (int l = 0; l < NLAY; ++l) tau[l] = __builtin_nontemporal_load(&bg_od[(size_t)l * n + ii]);
+      for (int l = 0; l < NLAY; ++l, rp += step_b) tau[l] = __builtin_nontemporal_load((const double*)(rp + voff));
+    }
     const double sv = live ? ssi[ii] : 0.0;   // a lane past the end carries zero flux through both sweeps: nothing else to mask
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
