@@ -73,6 +73,7 @@ inline bool& leaving() { static bool v = false; return v; }
 inline int done(int rc) {
   static const bool orderly = std::getenv("ECCKD_NO_FAST_EXIT") != nullptr;
   leaving() = !orderly;
+  if (log_times() && log_level() >= 2) { std::printf("[%8.3f] Output written\n", seconds_since_start()); std::fflush(stdout); }
   return rc;
 }
 

@@ -23,6 +23,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -647,6 +649,55 @@ int ecckd_nc_enddef(ecckd_nc* f) {
   return ECCKD_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// `count` values of variable v to the file from byte offset `at`: encoded in pieces of 2^20 values; a long run (the 1-D variables
+// of an ordering or g-points file: 7.2e6 values each) is cut into up to eight ranges that are encoded and written by a thread
+// each (pwrite at the range's own offset), since one thread encodes and copies into the page cache at ~1 GB/s only.
+int write_values(ecckd_nc* f, const Var& v, const char* name, uint64_t at, const double* data, size_t count) {
+  const size_t ts = type_size(v.type);
+  const size_t piece = (size_t)1 << 20;
+  auto write_range = [&](size_t first, size_t n_values, int fd) -> bool {
+    std::vector<unsigned char> buf(std::min(n_values, piece) * ts);
+    size_t i = 0;
+    while (i < n_values) {
+      const size_t n = std::min(n_values - i, piece);
+      encode_run(buf.data(), v.type, data + first + i, n);
+      size_t done = 0;
+      while (done < n * ts) {
+        const ssize_t w = ::pwrite(fd, buf.data() + done, n * ts - done, (off_t)(at + (uint64_t)(first + i) * ts + done));
+        if (w <= 0) return false;
+        done += (size_t)w;
+      }
+      i += n;
+    }
+    return true;
+  };
+  if (std::fflush(f->fp) != 0) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: flush failed", f->path.c_str());
+  const int fd = ::fileno(f->fp);
+  const size_t nthreads = std::min<size_t>(8, count / (2 * piece));
+  bool ok = true;
+  if (nthreads < 2) {
+    ok = write_range(0, count, fd);
+  } else {
+    std::vector<std::thread> pool;
+    std::vector<char> good(nthreads, 1);
+    const size_t share = (count + nthreads - 1) / nthreads;
+    for (size_t t = 0; t < nthreads; ++t) {
+      const size_t first = t * share, n_values = first < count ? std::min(share, count - first) : 0;
+      pool.emplace_back([&, t, first, n_values] { if (n_values && !write_range(first, n_values, fd)) good[t] = 0; });
+    }
+    for (auto& th : pool) th.join();
+    for (char gd : good) ok = ok && gd;
+  }
+  if (!ok) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: short write of \"%s\"", f->path.c_str(), name);
+  return ECCKD_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int ecckd_nc_write_double(ecckd_nc* f, const char* name, const double* data, size_t count) {
   ECCKD_REQUIRE(f && f->writing && !f->defining && name && data, "ecckd_nc_write_double: bad argument or still in define mode");
   const Var* v = f->find(name);
@@ -654,17 +705,7 @@ int ecckd_nc_write_double(ecckd_nc* f, const char* name, const double* data, siz
   uint64_t nel = 1;
   for (int id : v->dimids) nel *= f->dims[id].len;
   ECCKD_REQUIRE(count == nel, "ecckd_nc_write_double: \"%s\" has %llu elements, %zu given", name, (unsigned long long)nel, count);
-  const size_t ts = type_size(v->type);
-  if (fseeko(f->fp, (off_t)v->begin, SEEK_SET) != 0) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: seek failed", f->path.c_str());
-  std::vector<unsigned char> buf((size_t)std::min<uint64_t>(nel, (uint64_t)1 << 20) * ts);
-  size_t i = 0;
-  while (i < count) {
-    const size_t n = std::min(count - i, buf.size() / ts);
-    encode_run(buf.data(), v->type, data + i, n);
-    if (std::fwrite(buf.data(), ts, n, f->fp) != n) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: short write of \"%s\"", f->path.c_str(), name);
-    i += n;
-  }
-  return ECCKD_OK;
+  return write_values(f, *v, name, v->begin, data, count);
 }
 
 // one index of the slowest dimension of a (fixed-size) variable: what lets a tool write a (column, level, wavenumber)
@@ -678,18 +719,7 @@ int ecckd_nc_write_slice_double(ecckd_nc* f, const char* name, size_t slice, con
   for (size_t k = 1; k < v->dimids.size(); ++k) per *= f->dims[v->dimids[k]].len;
   ECCKD_REQUIRE(slice < f->dims[v->dimids[0]].len && count == per, "ecckd_nc_write_slice_double: \"%s\" slice %zu / %zu values do not fit",
                 name, slice, count);
-  const size_t ts = type_size(v->type);
-  if (fseeko(f->fp, (off_t)(v->begin + (uint64_t)slice * per * ts), SEEK_SET) != 0)
-    return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: seek failed", f->path.c_str());
-  std::vector<unsigned char> buf((size_t)std::min<uint64_t>(per, (uint64_t)1 << 20) * ts);
-  size_t i = 0;
-  while (i < count) {
-    const size_t n = std::min(count - i, buf.size() / ts);
-    encode_run(buf.data(), v->type, data + i, n);
-    if (std::fwrite(buf.data(), ts, n, f->fp) != n) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: short write of \"%s\"", f->path.c_str(), name);
-    i += n;
-  }
-  return ECCKD_OK;
+  return write_values(f, *v, name, v->begin + (uint64_t)slice * per * type_size(v->type), data, count);
 }
 
 

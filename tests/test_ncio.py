@@ -477,3 +477,29 @@ def test_streaming_record_count_and_unwritten_tail(tmp_path):
             f.read("b")
         with pytest.raises(EcckdError, match="extends past the end"):
             f.var_info("b")
+
+
+def test_long_variables_are_written_by_several_threads(tmp_path):
+    """A 1-D variable of millions of values (the ordering / g-points files of a 7.2e6-point spectrum) is cut into ranges that
+    are encoded and written by a thread each: every value must land where the single-threaded writer puts it - checked
+    through an independent reader (scipy) for every external type of the ordering file, at a length that is not a multiple
+    of the piece size."""
+    from scipy.io import netcdf_file
+    n = 5 * (1 << 20) + 12345
+    rs = np.random.RandomState(3)
+    wn = np.cumsum(rs.uniform(1e-4, 2e-4, n))
+    iband = (np.arange(n) // (n // 3 + 1)).astype(np.int16)
+    rank = rs.permutation(n).astype(np.int32)
+    key = rs.normal(size=n)
+    col = rs.lognormal(size=n)
+    p = str(tmp_path / "order_big.nc")
+    ncio.write_order(p, [0.0], [3260.0], wn, np.full(n, 1e-4), iband, rank, key, col, molecule="h2o")
+    f = netcdf_file(p, "r", mmap=False)
+    assert np.array_equal(f.variables["wavenumber"][:], wn)
+    assert np.array_equal(f.variables["rank"][:], rank)
+    assert np.array_equal(f.variables["band_number"][:], iband)
+    assert np.array_equal(f.variables["sorting_variable"][:], key.astype(np.float32))
+    assert np.array_equal(f.variables["column_optical_depth"][:], col.astype(np.float32))
+    f.close()
+    o = ncio.read_order(p)
+    assert np.array_equal(o["rank"], rank) and np.array_equal(o["wavenumber"], wn)

@@ -188,7 +188,7 @@ def gpu_chain(d, inp):
         stamps = re.findall(r"^\[\s*([0-9.]+)\] (.{0,48})", r.stdout, flags=re.M)
         rec = {"tool": name, "seconds": round(dt, 3), "last_log_stamp": float(stamps[-1][0]) if stamps else None}
         if stage == "reorder_spectrum":
-            rec["log"] = ["%s %s" % st for st in stamps]
+            rec["log"] = ["%s %s" % st for st in stamps if "Band " not in st[1]]
         per_process.append(rec)
         if os.environ.get("ECCKD_E2E_LOGDIR"):                 # every tool's timed log, for looking at a stage from inside
             ld = os.path.join(os.environ["ECCKD_E2E_LOGDIR"], os.path.basename(os.path.normpath(d)))
