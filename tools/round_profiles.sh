@@ -23,11 +23,17 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_A
   rocprofv3 --kernel-trace --pmc $set -d $out/k6_$n -o p --output-format csv -- python3 tools/k267_probe.py > /dev/null 2> $out/k6_$n.err
   python3 tools/pmc_summary.py k_gavg_partial $out/k6_$n/p_counter_collection.csv >> $out/pmc_k6.txt
 done
+# the sweep kernel alone on fixed batches (FLOAT pairs / DOUBLE rows), and where a search batch's time goes (rocpd database of
+# one step's kernel trace)
+python3 tools/sweep_probe.py > $out/sweep_probe.json 2> $out/sp.err
+ECCKD_BG64=1 python3 tools/sweep_probe.py > $out/sweep_probe_double_rows.json 2>> $out/sp.err
+rocprofv3 --kernel-trace -d $out/bb -o bb --output-format rocpd -- python3 bench.py --steps 1 --warmup 0 $quiet > /dev/null 2> $out/bb.err
+python3 tools/batch_breakdown.py $(ls $out/bb/*.db | head -1) > $out/batch_breakdown.txt 2>> $out/bb.err
 # the other configurations
 python3 bench.py --config 2 --steps 3 > $out/bench_config2.json 2> $out/c2.err
 python3 bench.py --config 3 --steps 2 > $out/bench_config3.json 2> $out/c3.err
 python3 bench.py --config 4 > $out/bench_config4.json 2> $out/c4.err
 # gpurun returns at most 64 MiB: keep the summaries, drop the raw traces they were computed from
 cp $out/ks/ks_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
-rm -rf $out/ks $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/k6_*/
+rm -rf $out/ks $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/k6_*/ $out/bb
 du -sh $out; ls -la $out | tail -30
