@@ -1300,8 +1300,24 @@ k_opt_sum_cost(const double* __restrict__ jcol, size_t ncol, const double* __res
                double* __restrict__ h_out /*pinned*/, double* __restrict__ d_out /*or NULL*/) {
   __shared__ double s_tmp[4];
   double a = 0.0, b = 0.0;
-  for (size_t i = threadIdx.x; i < ncol; i += 256) a += jcol[i];
-  if (prior) for (size_t i = threadIdx.x; i < nnode; i += 256) b += jb[i];
+  // a thread's elements are loaded together (one memory round trip instead of one per element: the kernel is a single block
+  // whose time is its chain of loads) and added in the order they always were
+  constexpr int U = 8;
+  for (size_t i0 = threadIdx.x; i0 < ncol; i0 += (size_t)256 * U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const size_t i = i0 + (size_t)256 * u; v[u] = jcol[i < ncol ? i : ncol - 1]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (i0 + (size_t)256 * u < ncol) a += v[u];
+  }
+  if (prior && nnode > 0)
+    for (size_t i0 = threadIdx.x; i0 < nnode; i0 += (size_t)256 * U) {
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const size_t i = i0 + (size_t)256 * u; v[u] = jb[i < nnode ? i : nnode - 1]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (i0 + (size_t)256 * u < nnode) b += v[u];
+    }
   double r[2] = {a, b};
   double tot[2];
   for (int k = 0; k < 2; ++k) {
