@@ -415,6 +415,12 @@ def run(ctx, nwav=7_200_000, nlay=54, cpu_nwav=(1 << 17, 1 << 18), workdir=None,
         # ---- the tools at full size ----
         d = os.path.join(top, "full")
         os.makedirs(d, exist_ok=True)
+        # the inputs are 19 spectra of nlay x nwav FLOATs (4 present-day, 4 x 3 idealised temperatures, 3 of h2o at 4 x the
+        # mole fraction): say so at once if the work directory has no room for them
+        need = 19 * nlay * nwav * 4 * 1.1
+        free = shutil.disk_usage(top).free
+        if free < need:
+            raise RuntimeError("e2e: %s has %.1f GB free, the input spectra need %.1f GB" % (top, free / 1e9, need / 1e9))
         t0 = time.perf_counter()
         inp = make_inputs(ctx, d, nwav, nlay)
         setup_s = time.perf_counter() - t0
