@@ -7,6 +7,7 @@
 // threshold_optical_depth, molecule, wavenumber1, wavenumber2, log_level (:54-83, :232-234).
 // The sweep and the per-band stable sort run on the GPU through ecckd_reorder_spectrum (include/ecckd_hip.h).
 #include <algorithm>
+#include <thread>
 
 #include "tool.hpp"
 
@@ -28,6 +29,13 @@ int main(int argc, char** argv) {
     LOG("Reading %s\n", input.c_str());
     Device dev;
     Spectrum s = read_spectrum(paths.find(input), iprofile, false);
+    // the per-wavenumber results (160 MB at 7.2e6 points): allocated and touched by a second thread while the optical depths
+    // stream in - first-touch page faults, 60 ms of a tool that runs 0.4 s
+    std::vector<double> key, col;
+    std::vector<int16_t> iband;
+    std::vector<int32_t> rank;
+    std::thread results_ready([&, n = s.nwav] { key.resize(n); col.resize(n); iband.resize(n); rank.resize(n); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } results_joiner{results_ready};
     DevOd d_od = read_od_dev(dev, NcIn(paths.find(input)), iprofile, s.nlay, s.nwav);   // file -> pinned buffers -> HBM, decoded there
     std::string molecule = s.molecule;
     config.read(molecule, "molecule");
@@ -56,9 +64,7 @@ int main(int argc, char** argv) {
     else LOG("Splitting the spectrum into %d bands\n", nband);
     LOG(do_sw ? "Sorting by peak heating\n" : "Sorting by peak cooling\n");
 
-    std::vector<double> key(s.nwav), col(s.nwav);
-    std::vector<int16_t> iband(s.nwav);
-    std::vector<int32_t> rank(s.nwav);
+    results_ready.join();
     ck(ecckd_reorder_spectrum_od_dev(dev.ctx(), s.nlay, s.nwav, s.pressure_hl.data(), s.wavenumber_cm_1.data(),
                                      s.d_wavenumber_cm_1.data(), d_od.buf.ptr(), d_od.type, do_sw ? ssi.data() : nullptr,
                                      threshold_optical_depth, nband, band_bound1.data(), band_bound2.data(), key.data(), col.data(),
