@@ -490,6 +490,39 @@ int ecckd_nc_read_double(ecckd_nc* f, const char* name, long long slice, double*
   // interleaved with the others record by record
   const uint64_t nrun = v->record ? (s1 - s0) : 1;
   const uint64_t run_elems = v->record ? per_slice : total;
+  // a long run of a file opened for reading (the 1-D variables of an ordering or g-points file: 7.2e6 values each): cut into
+  // up to eight ranges that a thread each reads (pread at the range's own offset) and decodes - one thread manages ~1 GB/s
+  const size_t piece = (size_t)1 << 20;
+  if (nrun == 1 && run_elems >= 4 * piece) {
+    const int fd = ::fileno(f->fp);
+    const uint64_t at = v->begin + s0 * per_slice * ts;
+    const size_t nthreads = (size_t)std::min<uint64_t>(8, run_elems / (2 * piece));
+    const size_t share = (size_t)((run_elems + nthreads - 1) / nthreads);
+    std::vector<char> good(nthreads, 1);
+    std::vector<std::thread> pool;
+    const int vtype = v->type;
+    for (size_t t = 0; t < nthreads; ++t) {
+      const size_t first = t * share, n_values = first < run_elems ? (size_t)std::min<uint64_t>(share, run_elems - first) : 0;
+      pool.emplace_back([&, t, first, n_values] {
+        std::vector<unsigned char> b(std::min(n_values, piece) * ts);
+        size_t i = 0;
+        while (i < n_values) {
+          const size_t n = std::min(n_values - i, piece);
+          size_t done = 0;
+          while (done < n * ts) {
+            const ssize_t got = ::pread(fd, b.data() + done, n * ts - done, (off_t)(at + (uint64_t)(first + i) * ts + done));
+            if (got <= 0) { good[t] = 0; return; }
+            done += (size_t)got;
+          }
+          decode_run(b.data(), vtype, out + first + i, n);
+          i += n;
+        }
+      });
+    }
+    for (auto& th : pool) th.join();
+    for (char gd : good) if (!gd) return ecckd::fail(ECCKD_PROCESSING_ERROR, "%s: short read of \"%s\"", f->path.c_str(), name);
+    return ECCKD_OK;
+  }
   std::vector<unsigned char> buf((size_t)std::min<uint64_t>(std::max<uint64_t>(run_elems, 1), (uint64_t)1 << 20) * ts);
   for (uint64_t r = 0; r < nrun; ++r) {
     const uint64_t off = v->record ? v->begin + (s0 + r) * f->recsize : v->begin + s0 * per_slice * ts;
