@@ -47,6 +47,8 @@ constexpr int TILE = 256;          // points per tile sum
 #ifndef ECCKD_PRIO_SWEEP2
 #define ECCKD_PRIO_SWEEP2 0
 #endif
+typedef float float_x2 __attribute__((ext_vector_type(2)));
+typedef float_x2 float_x2_store;
 constexpr int RT_THREADS = 256;    // K5c block
 constexpr int PREP_THREADS = 256;  // K4 block
 
@@ -296,7 +298,9 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
                      double* __restrict__ bg_od, double* __restrict__ w1, double* __restrict__ hr,
                      double* __restrict__ fds, double* __restrict__ fut,
                      double* __restrict__ wave_part /* [3*NLAY+2][nw]: sums over this wave's 64 points of every summable row */,
-                     size_t nw) {
+                     size_t nw,
+                     float_x2_store* __restrict__ bg_pair /* FLOAT background only, or NULL: the rows as FLOAT pairs (layers 2p, 2p+1
+                                                             of a point side by side) INSTEAD of the DOUBLE rows bg_od */) {
   static_assert(NLAY % 2 == 0 && PREP_THREADS == 256, "two wave pairs per block, equal halves");
   constexpr int H = NLAY / 2;
   constexpr bool STAGED = sizeof(OdT) == 4;   // the columns arrive in two runs of H layers, see below (always, on this path)
@@ -480,7 +484,21 @@ k_gas_prep_lw_mirror(size_t n, int method, const int32_t* __restrict__ ireorder,
     if (live) {
       const size_t o = (size_t)L * n + i;
       // written once, read by later kernels: streaming stores
-      __builtin_nontemporal_store(bg, &bg_od[o]);
+      if (sizeof(BgT) == 4 && bg_pair) {
+        // the background as the sweep reads it (k_rt_lw_bb_mirror<.., true>): a pair is complete at every second layer of the
+        // half column - the even wave has met its layers in the pair's order, the odd wave the other way round; the middle
+        // pair of an odd half belongs to both waves, each stores its own float
+        if (l & 1) {
+          float_x2_store v;
+          v.x = half ? (float)bg_in[l] : (float)bg_in[l - 1];
+          v.y = half ? (float)bg_in[l - 1] : (float)bg_in[l];
+          __builtin_nontemporal_store(v, &bg_pair[(size_t)(L / 2) * n + i]);
+        } else if (l == H - 1) {
+          ((float*)&bg_pair[(size_t)(L / 2) * n + i])[L & 1] = (float)bg_in[l];
+        }
+      } else {
+        __builtin_nontemporal_store(bg, &bg_od[o]);
+      }
       if (!REUSE) __builtin_nontemporal_store(b_far, &planck_hl[(size_t)lev_far * n + i]);   // level NLAY/2 is written by both waves with the same bits
       __builtin_nontemporal_store(m * (half ? b_near : b_far), &w1[o]);          // weight = Planck function at the base of the layer
     }
@@ -941,9 +959,6 @@ __device__ __forceinline__ void eps_fac_one(double od, double& eps, double& fac)
   fac = fmax(1.0 - (1.0 / kD) * fast_div(fmax(eps, TE), fmax(od, TE / kD)), 0.5 * TE);
 }
 
-typedef float float_x2 __attribute__((ext_vector_type(2)));
-typedef float_x2 float_x2_store;
-
 // The background optical depths of a longwave gas as FLOAT pairs: out[p][i] = (bg_od[2p][i], bg_od[2p+1][i]).  A value that
 // is not a float (or is a subnormal float: the conversion back may flush it) raises `inexact`, and the gas keeps to its
 // DOUBLE rows.
@@ -964,6 +979,19 @@ k_pack_bg32(int npair, size_t n, const double* __restrict__ bg_od, float_x2_stor
     __builtin_nontemporal_store(v, &out[(size_t)p * n + i]);
   }
   if (bad) atomicOr(inexact, 1);
+}
+
+// ... and back: the DOUBLE rows of a gas that holds only the pairs, when something asks for them (ecckd_gas_view, the
+// run-time-nlay sweep).
+__global__ void __launch_bounds__(256)
+k_unpack_bg32(int npair, size_t n, const float_x2_store* __restrict__ pairs, double* __restrict__ bg_od) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  for (int p = 0; p < npair; ++p) {
+    const float_x2_store v = pairs[(size_t)p * n + i];
+    bg_od[(size_t)(2 * p) * n + i] = (double)v.x;
+    bg_od[(size_t)(2 * p + 1) * n + i] = (double)v.y;
+  }
 }
 
 // K5c mirror path.  The two-stream equations are symmetric under turning the column upside down:
@@ -2016,6 +2044,21 @@ void gas_free(ecckd_gas* g) {
   delete g;
 }
 
+// The DOUBLE rows of the background optical depths.  A longwave gas whose background is FLOAT holds the FLOAT pairs only
+// (ecckd_gas_create_lw); the rows are made from them when something asks: ecckd_gas_view, the run-time-nlay sweep.
+static int gas_bg_rows(ecckd_gas* g) {
+  if (g->bg_od || !g->bg_pair) return ECCKD_OK;
+  ecckd_ctx* ctx = g->ctx;
+  const hipError_t e = ecckd::dev_malloc(ctx, (void**)&g->bg_od, (size_t)g->nlay * g->n * sizeof(double));
+  if (e != hipSuccess) return ecckd::fail(e == hipErrorOutOfMemory ? ECCKD_OUT_OF_MEMORY : ECCKD_UNEXPECTED_EXCEPTION,
+                                          "background rows: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(k_unpack_bg32, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, ctx->stream, g->nlay / 2, g->n,
+                     (const float_x2_store*)g->bg_pair, g->bg_od);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2074,7 +2117,14 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   } else {
     GTRY(ecckd::dev_malloc(ctx, (void**)&g->planck_hl, nhl * nwav * sizeof(double)));
   }
-  GTRY(ecckd::dev_malloc(ctx, (void**)&g->bg_od, mat));
+  // The background rows.  FLOAT pairs for the sweep (k_rt_lw_bb_mirror<.., true>) whenever every value is a float: with a
+  // FLOAT background (or none) on the 54-layer path K4 writes them itself INSTEAD of the DOUBLE rows (which are then made on
+  // demand only, gas_bg_rows: 3.1 GB less to write and to hold per gas at 7.2e6 points); otherwise the DOUBLE rows are
+  // written and k_pack_bg32 tries to pack them below.  ECCKD_BG64: DOUBLE rows only.
+  const bool want_pairs = (nlay == 54 || nlay == 30) && std::getenv("ECCKD_BG64") == nullptr;
+  const bool pairs_in_k4 = want_pairs && nlay == 54 && od_type == ECCKD_F32 && !is_log && (!d_bg_od || bg_type == ECCKD_F32);
+  if (want_pairs) GTRY(ecckd::dev_malloc(ctx, (void**)&g->bg_pair, (size_t)(nlay / 2) * nwav * 2 * sizeof(float)));
+  if (!pairs_in_k4) GTRY(ecckd::dev_malloc(ctx, (void**)&g->bg_od, mat));
   GTRY(ecckd::dev_malloc(ctx, (void**)&g->w1, mat));
   if (is_log) {
     GTRY(ecckd::dev_malloc(ctx, (void**)&g->w2, mat));
@@ -2193,7 +2243,7 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   hipLaunchKernelGGL((k_gas_prep_lw_mirror<54, BG, float, REUSE>), dim3(fblocks), dim3(PREP_THREADS), 0, ctx->stream, nwav,    \
                      averaging_method, g->ireorder, hkd, convd, d_wavenumber, d_d_wavenumber, (const BG*)bg_col,               \
                      (const float*)od_col, d_planck_hl_reuse, g->wn_sorted, g->dwn_sorted, g->planck_hl, g->bg_od, g->w1,      \
-                     g->hr, g->fds, g->fut, wave_part, nw64)
+                     g->hr, g->fds, g->fut, wave_part, nw64, pairs_in_k4 ? (float_x2_store*)g->bg_pair : nullptr)
     if (bg32 || !d_bg_od) { if (d_planck_hl_reuse) LAUNCH_MIRROR(float, true); else LAUNCH_MIRROR(float, false); }
     else { if (d_planck_hl_reuse) LAUNCH_MIRROR(double, true); else LAUNCH_MIRROR(double, false); }
 #undef LAUNCH_MIRROR
@@ -2252,10 +2302,8 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
   hipLaunchKernelGGL(k_super_sums, dim3((unsigned)g->nsuper, (unsigned)g->nrows), dim3(256), 0, ctx->stream, g->ntiles, g->nsuper,
                      (const double*)g->tile_sums, g->super_sums);
   GTRY(hipGetLastError());
-  // FLOAT pairs of the background rows for the sweep (k_rt_lw_bb_mirror<.., true>), kept if every value is a float
-  const bool want_pairs = (nlay == 54 || nlay == 30) && std::getenv("ECCKD_BG64") == nullptr;
-  if (want_pairs) {
-    GTRY(ecckd::dev_malloc(ctx, (void**)&g->bg_pair, (size_t)(nlay / 2) * nwav * 2 * sizeof(float)));
+  // FLOAT pairs from the DOUBLE rows where K4 has not written them itself: kept if every value is a float
+  if (want_pairs && !pairs_in_k4) {
     hipLaunchKernelGGL(k_pack_bg32, dim3(eblocks), dim3(256), 0, ctx->stream, nlay / 2, nwav, (const double*)g->bg_od,
                        (float_x2_store*)g->bg_pair, d_flag + 1);
     GTRY(hipGetLastError());
@@ -2268,7 +2316,7 @@ int ecckd_gas_create_lw(ecckd_ctx* ctx, int nlay, size_t nwav, const double* h_p
     gas_free(g);
     return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_gas_create_lw: rank is not a permutation of 0..nwav-1");
   }
-  if (want_pairs && flag[1]) {          // a DOUBLE background with values between the floats: the DOUBLE rows serve
+  if (want_pairs && !pairs_in_k4 && flag[1]) {          // a DOUBLE background with values between the floats: the DOUBLE rows serve
     ecckd::dev_release(ctx, g->bg_pair);
     g->bg_pair = nullptr;
   }
@@ -2564,7 +2612,7 @@ int ecckd_gas_view(ecckd_gas* gas, const char* name, const double** d_ptr, size_
   size_t r = 0;
   const double* p = nullptr;
   if (!strcmp(name, "planck_hl")) { p = gas->planck_hl; r = nlay + 1; }
-  else if (!strcmp(name, "bg_optical_depth")) { p = gas->bg_od; r = nlay; }
+  else if (!strcmp(name, "bg_optical_depth")) { ECCKD_CHECK(gas_bg_rows(gas)); p = gas->bg_od; r = nlay; }
   else if (!strcmp(name, "weighted_metric")) { p = gas->w1; r = nlay; }
   else if (!strcmp(name, "hr")) { p = gas->hr; r = nlay; }
   else if (!strcmp(name, "flux_dn_surf")) { p = gas->fds; r = 1; }
@@ -2827,6 +2875,7 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
     if (g->bg_pair) ECCKD_LW_MIRROR(30, true); else ECCKD_LW_MIRROR(30, false);
 #undef ECCKD_LW_MIRROR
   } else {
+    ECCKD_CHECK(gas_bg_rows(g));
     hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, ctx->stream, nlay, g->n,
                        n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
   }
