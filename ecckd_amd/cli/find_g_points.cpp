@@ -234,11 +234,19 @@ int main(int argc, char** argv) {
       {
         // the four per-wavenumber variables side by side, each through a handle of its own: a 7.2e6-point variable costs
         // ~20 ms, most of it the first touch of the 58 MB it is decoded into
+        // (a classic file only: a NetCDF-4 one is read through the HDF5 library, which must not be entered by two threads)
         const std::string order_path = paths.find(reordering_input);
+        bool classic = false;
+        if (FILE* fp = std::fopen(order_path.c_str(), "rb")) {
+          char magic[4] = {0, 0, 0, 0};
+          classic = std::fread(magic, 1, 4, fp) == 4 && magic[0] == 'C' && magic[1] == 'D' && magic[2] == 'F';
+          std::fclose(fp);
+        }
+        const std::launch how = classic ? std::launch::async : std::launch::deferred;
         auto read_var = [order_path](const char* name) { NcIn g(order_path); return g.read(name); };
-        auto f_rank = std::async(std::launch::async, [&] { std::vector<double> r = read_var("rank"); return std::vector<int32_t>(r.begin(), r.end()); });
-        auto f_band = std::async(std::launch::async, [&] { std::vector<double> b = read_var("band_number"); return std::vector<int>(b.begin(), b.end()); });
-        auto f_sort = std::async(std::launch::async, [&] { return read_var("sorting_variable"); });
+        auto f_rank = std::async(how, [&] { std::vector<double> r = read_var("rank"); return std::vector<int32_t>(r.begin(), r.end()); });
+        auto f_band = std::async(how, [&] { std::vector<double> b = read_var("band_number"); return std::vector<int>(b.begin(), b.end()); });
+        auto f_sort = std::async(how, [&] { return read_var("sorting_variable"); });
         NcIn f(order_path);
         band_bound1 = f.read("wavenumber1_band");
         band_bound2 = f.read("wavenumber2_band");
