@@ -495,7 +495,8 @@ int ecckd_nc_read_double(ecckd_nc* f, const char* name, long long slice, double*
   const size_t piece = (size_t)1 << 20;
   if (nrun == 1 && run_elems >= 4 * piece) {
     const int fd = ::fileno(f->fp);
-    const uint64_t at = v->begin + s0 * per_slice * ts;
+    // (one record of a record variable: the records lie recsize apart, not per_slice * ts)
+    const uint64_t at = v->record ? v->begin + s0 * f->recsize : v->begin + s0 * per_slice * ts;
     const size_t nthreads = (size_t)std::min<uint64_t>(8, run_elems / (2 * piece));
     const size_t share = (size_t)((run_elems + nthreads - 1) / nthreads);
     std::vector<char> good(nthreads, 1);

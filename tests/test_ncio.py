@@ -503,3 +503,31 @@ def test_long_variables_are_written_by_several_threads(tmp_path):
     f.close()
     o = ncio.read_order(p)
     assert np.array_equal(o["rank"], rank) and np.array_equal(o["wavenumber"], wn)
+
+
+def test_large_record_variable_slices_next_to_another_record_variable(tmp_path):
+    """the threaded read of a long run took the offset of slice k of a RECORD variable as k * (values per
+    slice) although the records of a file lie `recsize` apart (all record variables of one record side by side).  Two record
+    variables, one of them past the 4 * 2^20 values per record at which the threaded path starts: every slice must come back
+    as an independent reader (scipy) sees it, and the whole variable too."""
+    nbig = 4 * (1 << 20) + 4097
+    rs = np.random.RandomState(11)
+    p = str(tmp_path / "two_records.nc")
+    w = netcdf_file(p, "w", version=2)
+    w.createDimension("column", None); w.createDimension("three", 3); w.createDimension("wavenumber", nbig)
+    small = w.createVariable("small", "d", ("column", "three"))
+    big = w.createVariable("big", "f", ("column", "wavenumber"))
+    rows = rs.normal(size=(3, nbig)).astype(np.float32)
+    for k in range(3):
+        small[k] = np.arange(3.0) + 10 * k
+        big[k] = rows[k]
+    w.close()
+    r = netcdf_file(p, "r", mmap=False)
+    seen = np.array(r.variables["big"][:], dtype=np.float64)
+    r.close()
+    assert np.array_equal(seen, rows.astype(np.float64))
+    with ncio.NcFile(p) as f:
+        for k in range(3):
+            assert np.array_equal(f.read("big", k), seen[k]), k
+            assert np.array_equal(f.read("small", k), np.arange(3.0) + 10 * k)
+        assert np.array_equal(f.read("big"), seen)
