@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """bench.py - LW reorder + find_g_points hot path on synthetic CKDMIP-like spectra.
 
-One "step" = one pass of the hot path over one device-resident gas column
-(BASELINE.json configs[1]: LW FSCK = one band over 0-3260 cm-1, nwav = 7.2e6, nlay = 54,
-FLOAT optical depths as in the CKDMIP files, tolerance 0.0161 K/d as test/do_all_lw.sh:59-60):
+One "step" = one find_g_points job of BASELINE.json configs[1], "LW FSCK all well-mixed gases" (ecckd_amd/fsck_job.py):
+one band over 0-3260 cm-1, nwav = 7.2e6, nlay = 54, the gases composite, h2o, o3, co2, ch4, n2o, FLOAT spectra as
+in the CKDMIP files, every gas with a background MERGED from 2-5 spectra in double (read_merged_spectrum.cpp:135-166, as
+test/find_g_points_lw.sh:176-285 configures it), tolerance 0.0161 K/d (test/do_all_lw.sh:59-60).  Per gas:
+   merged background                       (read_merged_spectrum.cpp:117-166)
    K1 sorting key + K3 stable sort        (reorder_spectrum.cpp:111-300)
    K4 gas preparation                     (find_g_points.cpp:872-1150)
-   g-point partition search, every interval-error evaluation batched on the device (K5)
-                                          (find_g_points.cpp:1152-1266)
-Metric = wavenumber-points/s = nwav * (1 + N_pass) / t, where N_pass is the reference's own
-work counter total_comp_cost = sum of (bound2 - bound1) over all calc_error calls
-(find_g_points.cpp:320).  Ranks process independent gases (weak scaling, no data-path
-collective); rank 0 prints ONE JSON line.
+then the g-point partition searches of ALL gases side by side, one HIP stream per gas (K5, find_g_points.cpp:1152-1266), the
+overlap of the gases' g points and the merged g-point map (:1452-1483).
+Metric = wavenumber-points/s = nwav * (ngas + N_pass) / t, N_pass = the passes over the spectrum the searches swept on the
+device (the reference's counter total_comp_cost, find_g_points.cpp:320, also counts the requests the memo of interval
+errors answered; reported beside it).  Ranks run independent jobs (weak scaling, no data-path collective); rank 0 prints ONE
+JSON line.  Beside the headline, on one GPU: the same job gas after gas, and round 3's single-gas step (`single_gas`).
 
 --config 1 (default)  BASELINE configs[1], the configuration the metric is quoted on: as above.
 --config 3            BASELINE configs[3]: ONE find_g_points job over the 13 narrow longwave bands (test/config.h:141-142)
@@ -47,7 +49,7 @@ def parse():
     ap.add_argument("--tolerance", type=float, default=0.0161)   # fsck, test/do_all_lw.sh:59-60
     ap.add_argument("--tolerance-tolerance", type=float, default=0.01)  # test/find_g_points_lw.sh
     ap.add_argument("--max-iterations", type=int, default=60)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 18)      # within 30x of the headline's 7.2e6 points
+    ap.add_argument("--cpu-sample", type=int, default=1 << 16)      # points per gas of the CPU baseline's sample of the six-gas job
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lut-opt", action="store_true")
     ap.add_argument("--no-sw", action="store_true")
@@ -71,6 +73,11 @@ def parse():
     ap.add_argument("--strong-leg", dest="strong_leg", action="store_true", default=None)
     ap.add_argument("--no-strong-leg", dest="strong_leg", action="store_false")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--fsck-gases", type=int, default=6)               # config 1: gases of the job (composite h2o o3 co2 ch4 n2o)
+    # config 1: gases searched side by side on the device (0 = all the host has cores for, 1 = gas after gas as the reference)
+    ap.add_argument("--gases-side-by-side", type=int, default=0)
+    ap.add_argument("--no-single-gas", action="store_true")            # skip round 3's single-gas step beside the headline
+    ap.add_argument("--cpu-gases", type=int, default=6)                # gases of the job the CPU baseline runs on its sample
     # no device work at all: rendezvous (gloo), the one all-reduce, the JSON line.  For the CPU test of the launcher.
     ap.add_argument("--dry-run", action="store_true")
     args = ap.parse_args()
@@ -97,50 +104,81 @@ def make_inputs(xp, nwav, nlay, seed, device=None, spectra="lines", nlines=12000
     return p, wn_h, dwn_h, od, bg
 
 
-def cpu_baseline(args, nwav_s, nlay, seed, tol, tol_tol, max_it, device):
-    """The oracle ("port") on the host cores: reorder_spectrum -> find_g_points for one gas of the same generator at
-    `nwav_s` points, in C end to end (oracle/oracle_chain.c: restated pieces composed as the reference's main() functions
-    do, the partition search by the REFERENCE's own Equipartition built into oracle/_ref, a C callback for calc_error - no
-    Python inside), OpenMP at the reference's sites (planck_function.cpp:50, equipartition.h:101 as find_g_points.cpp:231
-    enables it).  The sample spectrum is generated on the device and handed to the host."""
+def SPECTRA_OF_JOB(args):
+    from ecckd_amd import fsck_job
+    gases = fsck_job.GASES[:args.fsck_gases]
+    return sorted({g[1] for g in gases} | {b for g in gases for b, _ in g[2]})
+
+
+def cpu_baseline(args, nwav_s, nlay, seed, tol, tol_tol, max_it, ctx, ngas=None):
+    """The oracle ("port") on the host cores: the SAME find_g_points job (ecckd_amd/fsck_job.py: the gases with their merged
+    backgrounds) at `nwav_s` points per gas - reorder_spectrum -> find_g_points gas after gas, in C end to end
+    (oracle/oracle_chain.c: restated pieces composed as the reference's main() functions do, the partition search by the
+    REFERENCE's own Equipartition built into oracle/_ref, a C callback for calc_error - no Python inside; the first gas's Planck
+    matrix kept for the later ones as find_g_points.cpp:529, :970-984), OpenMP at the reference's sites
+    (planck_function.cpp:50, equipartition.h:101 as find_g_points.cpp:231 enables it).  The sample spectra are generated on the
+    device and handed to the host; a background is the double sum of its scaled spectra (read_merged_spectrum.cpp:135-166)."""
     import ctypes as C
-    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as o
-    from ecckd_amd import synthetic as syn
-    p, wn, dwn, od, bg = make_inputs(torch, nwav_s, nlay, seed, device=device, spectra=args.spectra, nlines=args.nlines)
-    od32 = np.ascontiguousarray(od.cpu().numpy(), dtype=np.float32)
-    bg32 = np.ascontiguousarray(bg.cpu().numpy(), dtype=np.float32)
-    del od, bg
-    t_hl = np.ascontiguousarray(syn.temperature_profile(p))
+    from ecckd_amd import fsck_job
+    job = fsck_job.FsckJob(ctx, nwav_s, nlay, ngas=ngas or args.cpu_gases, nlines=args.nlines, seed=seed, spectra=args.spectra)
+    host = {name: np.ascontiguousarray(od.cpu().numpy(), dtype=np.float32) for name, od in job.od.items()}
+    p, wn, dwn, t_hl = np.ascontiguousarray(job.p), job.wn_h, job.dwn_h, np.ascontiguousarray(job.t_file)
+    gases = job.gases
+    job.close()
     L = o.lib()
     ref = os.path.join(ROOT, "oracle", "_ref", "libequipartition_ref.so")
     if not os.path.exists(ref):
         raise RuntimeError("oracle/_ref not built")
     P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    I64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
     b1, b2, tolv = np.array([0.0]), np.array([3260.0]), np.array([float(tol)])
-    ng, st = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
-    cc, secs = np.zeros(1), np.zeros(3)
-    rank = np.zeros(nwav_s, dtype=np.int32)
-    L.orc_find_g_lw_chain.restype = C.c_int
+    planck = np.empty((nlay + 1) * nwav_s)
+    cap = 4096
+    L.orc_find_g_lw_chain_ex.restype = C.c_int
+    per_gas, failed = [], []
     devnull = os.open(os.devnull, os.O_WRONLY)
     saved = os.dup(1)
     os.dup2(devnull, 1)  # the reference search prints progress to stdout
+    wall0 = time.perf_counter()
     try:
-        t0 = time.perf_counter()
-        rc = L.orc_find_g_lw_chain(ref.encode(), C.c_int(nlay), C.c_size_t(nwav_s), P(np.ascontiguousarray(p)), P(t_hl), P(wn), P(dwn),
-                                   od32.ctypes.data_as(C.POINTER(C.c_float)), bg32.ctypes.data_as(C.POINTER(C.c_float)),
-                                   C.c_double(0.5), C.c_int(1), P(b1), P(b2), C.c_int(1), C.c_double(0.0), C.c_double(0.0), P(tolv),
-                                   C.c_double(tol_tol), C.c_int(max_it), C.c_int(1), ng.ctypes.data_as(C.POINTER(C.c_int)), P(cc),
-                                   st.ctypes.data_as(C.POINTER(C.c_int)), P(secs), rank.ctypes.data_as(C.POINTER(C.c_int32)))
-        dt = time.perf_counter() - t0
+        for gi, (name, target, bgs) in enumerate(gases):
+            bg64 = None
+            for bname, conc in bgs:
+                refv = fsck_job.SPECTRA[bname][2]
+                term = host[bname].astype(np.float64) * (1.0 if conc < 0.0 else conc / refv)
+                bg64 = term if bg64 is None else bg64 + term
+            bg64 = np.ascontiguousarray(bg64)
+            ng, st = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
+            cc, secs = np.zeros(1), np.zeros(3)
+            rank = np.zeros(nwav_s, dtype=np.int32)
+            r1, r2 = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64)
+            err, med, key = np.zeros(cap), np.zeros(cap), np.zeros(nwav_s)
+            L.orc_chain_set_background64(P(bg64))
+            rc = L.orc_find_g_lw_chain_ex(ref.encode(), C.c_int(nlay), C.c_size_t(nwav_s), P(p), P(t_hl), P(wn), P(dwn),
+                                          host[target].ctypes.data_as(C.POINTER(C.c_float)), None, C.c_double(0.5), C.c_int(1),
+                                          P(b1), P(b2), C.c_int(1), C.c_double(0.0), C.c_double(0.0), P(tolv), C.c_double(tol_tol),
+                                          C.c_int(max_it), C.c_int(1), ng.ctypes.data_as(C.POINTER(C.c_int)), P(cc),
+                                          st.ctypes.data_as(C.POINTER(C.c_int)), P(secs), rank.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          C.c_int(cap), I64(r1), I64(r2), P(err), P(med), P(key), P(planck), C.c_int(1 if gi == 0 else 2))
+            if rc >= 20:
+                # the search of this gas ended in one of calc_error's THROWs (find_g_points.cpp:296-312: bounds one rounding out
+                # of order on a sample this small) - the reference run would have stopped here; the gas is left out of both sums
+                failed.append(name)
+                continue
+            if rc:
+                raise RuntimeError("orc_find_g_lw_chain_ex failed with code %d for %s" % (rc, name))
+            per_gas.append(dict(name=name, ng=int(ng[0]), n_pass=float(cc[0]), status=int(st[0]), seconds=secs.copy()))
     finally:
         os.dup2(saved, 1)
         os.close(devnull)
-    if rc:
-        raise RuntimeError("orc_find_g_lw_chain failed with code %d" % rc)
-    return dict(points=nwav_s * (1.0 + cc[0]), seconds=float(secs.sum()), wall=dt, ng=int(ng[0]), n_pass=float(cc[0]),
-                status=int(st[0]), stage_seconds=dict(reorder=secs[0], preparation=secs[1], search=secs[2]))
+    wall = time.perf_counter() - wall0
+    secs = np.sum([g["seconds"] for g in per_gas], axis=0)
+    n_pass = sum(g["n_pass"] for g in per_gas)
+    return dict(points=nwav_s * (len(per_gas) + n_pass), seconds=float(secs.sum()), wall=wall, ng=[g["ng"] for g in per_gas],
+                n_pass=n_pass, n_pass_per_gas=[g["n_pass"] for g in per_gas], status=[g["status"] for g in per_gas],
+                gases=[g["name"] for g in per_gas], failed_gases=failed, stage_seconds=dict(reorder=secs[0], preparation=secs[1], search=secs[2]))
 
 
 def sw_find_g_bench(ctx, nwav=3_300_000, nlay=54, tol=0.047, nlines=12000):
@@ -461,31 +499,26 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
         def step():
             return step3() / nwav             # passes over the nwav-point spectrum done by this rank
     else:
-        # each rank owns a different synthetic gas: independent (gas, band) shards, SURVEY.md 8e
-        p, wn_h, dwn_h, od, bg = make_inputs(torch, nwav, nlay, syn.SEED_BASE + 1 + 17 * rank, device=dev, spectra=args.spectra,
-                                             nlines=args.nlines)
-        wn = torch.as_tensor(wn_h, device=dev)
-        dwn = torch.as_tensor(dwn_h, device=dev)
-        t_ideal = api.idealised_temperature(p)
-        t_file = syn.temperature_profile(p)
-        key = torch.empty(nwav, dtype=torch.float64, device=dev)
-        col = torch.empty(nwav, dtype=torch.float64, device=dev)
-        rnk = torch.empty(nwav, dtype=torch.int32, device=dev)
+        # every rank runs its own six-gas job on its own synthetic spectra: independent jobs, SURVEY.md 8e
+        from ecckd_amd import fsck_job
+        job = fsck_job.FsckJob(ctx, nwav, nlay, ngas=args.fsck_gases, nlines=args.nlines, seed=syn.SEED_BASE + 1 + 170 * rank,
+                               spectra=args.spectra)
+        od = None
         torch.cuda.synchronize()
 
+        def job_step(side_by_side):
+            res = job.run(args.tolerance, args.tolerance_tolerance, args.max_iterations, gases_side_by_side=side_by_side)
+            info.update(ng=res["ng"], ng_per_gas=[int(sum(g["n_g_points"])) for g in res["gases"]],
+                        status=[int(g["status"][0]) for g in res["gases"]], comp_cost=res["comp_cost_sum"], cost_sum=res["cost_sum"],
+                        n_unassigned=res["n_unassigned"], phase_seconds=res["phase_seconds"],
+                        sweep_bytes_per_point=(2 * nlay + 1) * 8, points=res["points"])
+            # passes over the spectrum in this step: one reorder / preparation pass per gas + what the searches actually swept
+            # on the device.  (The reference's counter total_comp_cost counts every interval the searches ask for; the library
+            # answers an interval it has evaluated before from its memo, so fewer points are swept than the counter says.)
+            return res["points"] / nwav
+
         def step():
-            api.reorder_key_lw(ctx, p, t_ideal, wn, dwn, od, 0.5, key=key, col_od=col)
-            api.stable_argsort_bands(ctx, key, [0], [nwav - 1], rank=rnk, want_ordered=False, sync=False)
-            gas = api.GasLW(ctx, p, t_file, wn, dwn, rnk, od, bg, "transmission", flux_weight=0.0)
-            st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance,
-                                           args.max_iterations)
-            info.update(ng=len(e), status=st, comp_cost=cc, cost_sum=float(np.sum(e)), eval_stats=gas.eval_stats(),
-                        sweep_bytes_per_point=gas.sweep_bytes_per_point())
-            gas.close()
-            # passes over the spectrum in this step: the reorder pass + what the search actually swept on the device.  (The
-            # reference's counter total_comp_cost counts every interval the search asks for; the library answers an
-            # interval it has evaluated before from its memo, so fewer points are swept than the counter says.)
-            return 1.0 + info["eval_stats"]["points_evaluated"] / nwav
+            return job_step(args.gases_side_by_side)
     for _ in range(args.warmup):
         step()
     ctx.profile_enable(max(1, args.profile_stride))
@@ -503,59 +536,92 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
     from ecckd_amd import shard
     dt, passes, total_cost, ranks_seen = shard.reduce_scalars(dt, passes, info.get("cost_sum", 0.0), device=dev, count=True)
 
-    # What a caller that hands over HOST buffers pays on top (the tools do: spectra come from NetCDF files): the FLOAT
-    # target and background spectra of every step over PCIe from pinned memory.  Two measurements beside `value`, never as
-    # `value`: the bare copy time, and the step loop run again with the NEXT step's spectra uploaded on a second stream while
-    # the current step searches (double-buffered; the step waits for its own upload before it starts) - how the tools read
-    # their files (ecckd_nc_read_dev) and what a multi-gas find_g_points run does gas after gas.
+    gw_calls, gw_ms, gw_pts = ctx.profile_get("find_g_gases")          # the windows in which the gases' searches ran side by side
+
+    # Beside the headline, one GPU only, never as `value`:
+    #  * what a caller that hands over HOST buffers pays on top (the tools do: spectra come from NetCDF files): the job's FLOAT
+    #    spectra over PCIe from pinned memory, one after the other (the tools' reader overlaps this with the previous gas);
+    #  * the same job gas after gas - the reference's loop - with the sweep launches timed while they have the device to
+    #    themselves;
+    #  * round 3's step: ONE gas with a single-file FLOAT background (kept as FLOAT pairs: 656 B per point).
     h2d_ms = None
-    overlapped = None
-    out = None
+    gas_after_gas = None
+    single_gas = None
     if rank == 0 and world == 1 and args.config == 1:
         try:
+            any_od = next(iter(job.od.values()))
             host_od = torch.empty((nlay, nwav), dtype=torch.float32).pin_memory()
-            host_bg = torch.empty((nlay, nwav), dtype=torch.float32).pin_memory()
-            host_od.copy_(od.cpu()); host_bg.copy_(bg.cpu())
-            bufs = [(od, bg), (torch.empty_like(od), torch.empty_like(bg))]
+            host_od.copy_(any_od.cpu())
+            dst = torch.empty_like(any_od)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            bufs[1][0].copy_(host_od, non_blocking=True); bufs[1][1].copy_(host_bg, non_blocking=True)
+            for _ in range(len(job.od)):
+                dst.copy_(host_od, non_blocking=True)
             torch.cuda.synchronize()
             h2d_ms = (time.perf_counter() - t1) * 1e3
-            side = torch.cuda.Stream()
-            done = [torch.cuda.Event(), torch.cuda.Event()]
-
-            def upload(k):
-                with torch.cuda.stream(side):
-                    bufs[k][0].copy_(host_od, non_blocking=True); bufs[k][1].copy_(host_bg, non_blocking=True)
-                    done[k].record(side)
-
-            def step_on(k):
-                nonlocal_od, nonlocal_bg = bufs[k]
-                api.reorder_key_lw(ctx, p, t_ideal, wn, dwn, nonlocal_od, 0.5, key=key, col_od=col)
-                api.stable_argsort_bands(ctx, key, [0], [nwav - 1], rank=rnk, want_ordered=False, sync=False)
-                gas = api.GasLW(ctx, p, t_file, wn, dwn, rnk, nonlocal_od, nonlocal_bg, "transmission", flux_weight=0.0)
-                st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance, args.max_iterations)
-                pts = gas.eval_stats()["points_evaluated"]
-                gas.close()
-                return 1.0 + pts / nwav
-
-            upload(0)
-            ctx.synchronize(); torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            passes_o = 0.0
-            for i in range(args.steps):
-                k = i % 2
-                done[k].synchronize()                 # this step's spectra have arrived
-                if i + 1 < args.steps:
-                    upload(1 - k)                     # the next step's travel while this one searches
-                passes_o += step_on(k)
-            ctx.synchronize(); torch.cuda.synchronize()
-            dt_o = time.perf_counter() - t1
-            overlapped = {"value": nwav * passes_o / dt_o, "ms_per_step": dt_o / args.steps * 1e3}
-            del host_od, host_bg, bufs
+            del host_od, dst
         except RuntimeError:
             h2d_ms = None
+        head_info = dict(info)
+        ctx.profile_enable(max(1, args.profile_stride))
+        barrier()
+        t1 = time.perf_counter()
+        p_seq = job_step(1)
+        barrier()
+        dt_seq = time.perf_counter() - t1
+        seq_info = dict(info)
+        info.clear()
+        info.update(head_info)
+        same = all(seq_info.get(k) == head_info.get(k) for k in ("ng", "ng_per_gas", "status", "cost_sum", "comp_cost", "points", "n_unassigned"))
+        sq_calls, sq_ms, sq_pts = ctx.profile_get("k_rt_lw_bb")
+        sq_all, _, sq_all_pts = ctx.profile_get("k_rt_lw_bb.all")
+        bpp = (2 * nlay + 1) * 8
+        gas_after_gas = {"ms_per_step": dt_seq * 1e3, "value": nwav * p_seq / dt_seq, "unit": "wavenumber-points/s",
+                         "phase_ms": {k: round(v * 1e3, 2) for k, v in seq_info.get("phase_seconds", {}).items()},
+                         # g points per gas, search statuses, the sum of the g points' errors (bit for bit), points swept
+                         "identical_results": bool(same),
+                         "sweep_launches": sq_all, "sweep_launches_timed": sq_calls, "avg_launch_ms": sq_ms / max(sq_calls, 1),
+                         "points_per_launch": sq_pts / max(sq_calls, 1),
+                         "achieved_GBs_per_launch": sq_pts * bpp / max(sq_ms * 1e-3, 1e-12) / 1e9,
+                         "frac_per_launch": sq_pts * bpp / max(sq_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                         "note": "the same job with the reference's gas loop (find_g_points.cpp:655): merge, reorder, prepare, search, "
+                                 "release, one gas after the other on one stream; every sweep launch has the device to itself"}
+        if not args.no_single_gas:
+            job.close()
+            torch.cuda.empty_cache()
+            p1, wn_h, dwn_h, od1, bg1 = make_inputs(torch, nwav, nlay, syn.SEED_BASE + 1, device=dev, spectra=args.spectra, nlines=args.nlines)
+            wn1, dwn1 = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
+            t_ideal, t_file = api.idealised_temperature(p1), syn.temperature_profile(p1)
+            sg = {}
+
+            def single_step():
+                key1, _ = api.reorder_key_lw(ctx, p1, t_ideal, wn1, dwn1, od1, 0.5)
+                rnk1, _ = api.stable_argsort_bands(ctx, key1, [0], [nwav - 1], want_ordered=False)
+                gas = api.GasLW(ctx, p1, t_file, wn1, dwn1, rnk1, od1, bg1, "transmission", flux_weight=0.0)
+                st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance, args.max_iterations)
+                sg.update(ng=len(e), status=int(st), comp_cost=cc, cost_sum=float(np.sum(e)), eval_stats=gas.eval_stats(),
+                          bytes=gas.sweep_bytes_per_point())
+                gas.close()
+                return 1.0 + sg["eval_stats"]["points_evaluated"] / nwav
+
+            single_step()
+            ctx.profile_enable(max(1, args.profile_stride))
+            barrier()
+            t1 = time.perf_counter()
+            nst = max(2, min(args.steps, 5))
+            ps = sum(single_step() for _ in range(nst))
+            barrier()
+            dt1 = time.perf_counter() - t1
+            s_calls, s_ms, s_pts = ctx.profile_get("k_rt_lw_bb")
+            s_gbs = s_pts * sg["bytes"] / max(s_ms * 1e-3, 1e-12) / 1e9
+            single_gas = {"workload": "round 3's step: ONE gas, single-file FLOAT background (FLOAT pairs in the sweep), nwav=%d" % nwav,
+                          "value": nwav * ps / dt1, "unit": "wavenumber-points/s", "ms_per_step": dt1 / nst * 1e3, "steps": nst,
+                          "ng": sg["ng"], "search_status": sg["status"], "n_pass_per_step": ps / nst - 1.0,
+                          "n_pass_reference_counter": sg["comp_cost"], "final_cost_sum_K_per_day": sg["cost_sum"],
+                          "roofline": {"kernel": "k_rt_lw_bb_mirror<54,true>", "algorithmic_bytes_per_point": sg["bytes"],
+                                       "achieved": s_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s_gbs / HBM_PEAK_GBS,
+                                       "avg_launch_ms": s_ms / max(s_calls, 1), "points_per_launch": s_pts / max(s_calls, 1)}}
+            del od1, bg1
 
     lut_sharded = None
     if args.lut_dist and use_dist and not args.no_lut_opt:
@@ -574,7 +640,7 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
         # WRITE_SIZE collected separately; 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md section HBM),
         # scaled to this run's points per launch
         traffic = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_traffic_k_rt_lw_bb.json" % r) for r in (3, 2, 1)) if os.path.exists(q)), "")
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_traffic_k_rt_lw_bb.json" % r) for r in (4, 3, 2, 1)) if os.path.exists(q)), "")
         if os.path.exists(tpath) and rt_calls:
             with open(tpath) as f:
                 traffic = json.load(f)["corrected_bytes_per_point"] * rt_pts / rt_calls
@@ -592,14 +658,21 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": ({"workload": "configs[1]: LW FSCK (1 band 0-3260 cm-1), 1 synthetic gas + background per "
-                                    "rank, nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging transmission"
-                                    % (nwav, nlay, args.tolerance),
-                        "n_pass_per_step": (passes / args.steps / world) - 1.0,
-                        "n_pass_reference_counter": info.get("comp_cost"), "ng": info.get("ng"),
-                        "interval_requests": info.get("eval_stats", {}).get("requests"),
-                        "interval_requests_answered_from_memo": info.get("eval_stats", {}).get("memo_hits"),
-                        "search_status": info.get("status"), "final_cost_sum_K_per_day": total_cost}
+            "config": ({"workload": "configs[1]: ONE find_g_points job per rank, LW FSCK (1 band 0-3260 cm-1) x %d gases (%s), every gas "
+                                    "with a background merged in double from %s spectra (DOUBLE rows in the sweep: %d B per point), "
+                                    "nwav=%d, nlay=%d, spectra FLOAT, tolerance %g K/d, averaging transmission; per gas merge + reorder "
+                                    "(key, sort) + preparation, then %s, overlap of the gases' g points, merged g-point map"
+                                    % (args.fsck_gases, " ".join(job.names), "/".join(str(len(v)) for v in job.background_names.values()),
+                                       (2 * nlay + 1) * 8, nwav, nlay, args.tolerance,
+                                       "the searches gas after gas" if args.gases_side_by_side == 1 else
+                                       "the searches of all gases side by side (one HIP stream per gas)"),
+                        "gases": job.names, "background_spectra": job.background_names,
+                        "gases_side_by_side": args.gases_side_by_side if args.gases_side_by_side else len(job.names),
+                        "n_pass_per_step": (passes / args.steps / world) - len(job.names),
+                        "n_pass_reference_counter": info.get("comp_cost"), "ng_merged": info.get("ng"), "ng_per_gas": info.get("ng_per_gas"),
+                        "search_status_per_gas": info.get("status"), "n_unassigned": info.get("n_unassigned"),
+                        "final_cost_sum_K_per_day": total_cost,
+                        "phase_ms_last_step": {k: round(v * 1e3, 2) for k, v in info.get("phase_seconds", {}).items()}}
                        if args.config == 1 else
                        {"workload": ("configs[3]: ONE find_g_points job, 13 narrow LW bands (test/config.h:141-142) x %d gases "
                                      "(%s), nwav=%d, nlay=%d, od FLOAT, tolerance %g K/d, averaging transmission; the %d "
@@ -628,11 +701,6 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                          "timing": "HIP events around every %d-th launch inside the timed region; averages over the timed launches" % max(1, args.profile_stride),
                          "avg_launch_ms": rt_ms / max(rt_calls, 1),
                          "algorithmic_bytes_per_point": rt_bytes_per_pt,
-                         # rounds 1-2 read the background as DOUBLE rows, SURVEY 8d's (2*nlay+1)*8 bytes per point: the same
-                         # launches priced at that figure, for comparison across rounds (NOT what the kernel reads now)
-                         "at_double_rows": {"bytes_per_point": (2 * nlay + 1) * 8,
-                                            "achieved": rt_gbs * (2 * nlay + 1) * 8 / rt_bytes_per_pt,
-                                            "frac": rt_gbs * (2 * nlay + 1) * 8 / rt_bytes_per_pt / HBM_PEAK_GBS},
                          "points_per_launch": rt_pts / max(rt_calls, 1),
                          "share_of_step_time": rt_ms / max(rt_calls, 1) * all_calls * 1e-3 / dt,
                          # K1 is bound by fp64 vector issue, not by HBM: ~94 VALU instructions per layer and point (2 exp, 2
@@ -646,6 +714,36 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                                               "frac_of_fp64_issue_roof": (K1_VALU_PER_POINT * (k1_pts / max(k1_calls, 1)) / 64.0 * 4.0
                                                                           / (256 * 4 * 2.4e9) * 1e3) / max(k1_ms / max(k1_calls, 1), 1e-12)}},
         }
+        if args.config == 1 and gw_calls and gw_ms > 0:
+            # The gases' searches ran side by side, every gas on its own stream: sweep launches of several streams overlap, so
+            # a launch's own duration (its HIP events) includes the time it shared the device and says nothing about the memory
+            # system.  What does: the algorithmic bytes of ALL sweep launches over the time in which the searches ran - the
+            # window between two HIP events that ecckd_find_g_gases records on the context's stream round the searches (every
+            # lane synchronised at both ends).  Average launch duration = window / launches: the device time a launch cost.
+            # The window also holds the interval-sum and cost kernels and the host's turnarounds, so the figure is a LOWER
+            # bound of the sweep's own rate.  Per-launch figures with the device to itself: `gas_after_gas`.
+            agg = gw_pts * rt_bytes_per_pt / (gw_ms * 1e-3) / 1e9
+            rl = out["roofline"]
+            rl.update({"kernel": "k_rt_lw_bb_mirror<54,false>", "achieved": agg, "frac": agg / HBM_PEAK_GBS,
+                       "algorithmic_bytes_per_launch": rt_bytes_per_pt * all_pts / max(all_calls, 1),
+                       "points_per_launch": all_pts / max(all_calls, 1), "avg_launch_ms": gw_ms / max(all_calls, 1),
+                       "traffic": (traffic / (rt_pts / max(rt_calls, 1)) * (all_pts / max(all_calls, 1))) if traffic else None,
+                       "search_windows": gw_calls, "search_window_ms_per_step": gw_ms / max(args.steps, 1),
+                       "points_swept_per_step": gw_pts / max(args.steps, 1),
+                       "share_of_step_time": gw_ms * 1e-3 / dt,
+                       "timing": "the gases' sweeps overlap on %d streams: achieved = algorithmic bytes of all sweep launches / the "
+                                 "HIP-event window round the side-by-side searches (ecckd_find_g_gases), avg_launch_ms = that window / "
+                                 "launches; a lower bound (the window holds the small kernels and host turnarounds too)"
+                                 % len(job.names),
+                       "per_launch_under_overlap": {"launches_timed": rt_calls, "avg_launch_ms": rt_ms / max(rt_calls, 1),
+                                                    "points_per_launch": rt_pts / max(rt_calls, 1), "achieved": rt_gbs,
+                                                    "note": "HIP events round every %d-th launch on its own stream: durations include "
+                                                            "the time shared with the other gases' kernels" % max(1, args.profile_stride)}})
+        if gas_after_gas is not None:
+            out["gas_after_gas"] = gas_after_gas
+            out["gas_after_gas"]["side_by_side_speedup"] = gas_after_gas["ms_per_step"] / (dt / args.steps * 1e3)
+        if single_gas is not None:
+            out["single_gas"] = single_gas
         if args.config == 2:
             # the shortwave sweep: one launch evaluates an interval with both scaled fits from ONE fetch of the column of
             # optical depths, (nlay + 1) * 8 B per point (background optical depths + solar irradiance); it is bound by fp64
@@ -664,13 +762,11 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                                                 "note": "~21 fp64 VALU instructions per exp (fastmath.hpp): see profiles/r01_pmc_k_rt_sw_bb_fast.md"},
                                "timing": "HIP events around every %d-th batch's sweep launches inside the timed region" % max(1, args.profile_stride)}
         if h2d_ms is not None:
-            step_ms = dt * 1e3 / args.steps
-            out["pcie_inclusive"] = {"h2d_ms_per_step": h2d_ms, "bytes_per_step": 2 * nlay * nwav * 4,
-                                     "value_not_overlapped": points / (dt + args.steps * h2d_ms * 1e-3),
-                                     "value": overlapped["value"] if overlapped else None,
-                                     "ms_per_step": overlapped["ms_per_step"] if overlapped else None, "unit": "wavenumber-points/s",
-                                     "note": "FLOAT target + background spectra of every step uploaded from pinned host memory on a "
-                                             "second stream while the previous step searches (double-buffered)"}
+            out["pcie_inclusive"] = {"h2d_ms_per_step": h2d_ms, "bytes_per_step": len(SPECTRA_OF_JOB(args)) * nlay * nwav * 4,
+                                     "value_not_overlapped": points / (dt + args.steps * h2d_ms * 1e-3), "unit": "wavenumber-points/s",
+                                     "note": "the job's FLOAT spectra (each read once: a gas's spectrum is the target once and part of "
+                                             "other gases' backgrounds) uploaded from pinned host memory in front of every step, not "
+                                             "overlapped; the tools' reader streams a gas's files while the previous gas is prepared"}
         if lut_sharded is not None:
             out["lut_opt"] = lut_sharded
         elif world == 1 and not args.no_lut_opt and args.config == 1:
@@ -682,7 +778,8 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
             # the end-to-end number north_star asks for: the do_all_lw chain with the tools as fresh child processes at the
             # headline size against the CPU oracle chain (tools/e2e_bench.py); a failure there must not cost the headline line
             try:
-                del od, bg
+                if args.config == 1:
+                    job.close()
                 torch.cuda.empty_cache()
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import e2e_bench
@@ -692,17 +789,19 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                 out["e2e"] = {"error": repr(exc), "traceback": traceback.format_exc()[-1500:]}
         if world == 1 and not args.no_cpu and args.config == 1:
             cb = cpu_baseline(args, args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance, args.tolerance_tolerance,
-                              args.max_iterations, dev)
+                              args.max_iterations, ctx)
             out["cpu_baseline"] = {"value": cb["points"] / cb["seconds"], "unit": "wavenumber-points/s",
                                    "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
-                                   "nwav": args.cpu_sample, "ng": cb["ng"], "n_pass": cb["n_pass"], "search_status": cb["status"],
+                                   "nwav": args.cpu_sample, "gases": cb["gases"], "gases_whose_search_threw": cb["failed_gases"], "ng": cb["ng"], "n_pass": cb["n_pass"],
+                                   "n_pass_per_gas": cb["n_pass_per_gas"], "search_status": cb["status"],
                                    "seconds": cb["seconds"], "headline_over_sample_points": nwav / args.cpu_sample,
                                    "sample": "oracle/oracle_chain.c (C end to end: reorder + gas preparation + the reference's "
                                              "equipartition.cpp from oracle/_ref over the oracle's calc_error, OpenMP at the "
-                                             "reference's sites), same generator at nwav=%d: ng=%d, N_pass=%.1f (every request "
-                                             "swept, as the reference does), search status %d, %.1f s (reorder %.2f, "
-                                             "preparation %.2f, search %.2f)"
-                                             % (args.cpu_sample, cb["ng"], cb["n_pass"], cb["status"], cb["seconds"],
+                                             "reference's sites), the same %d-gas job (merged double backgrounds, the first gas's "
+                                             "Planck matrix kept) from the same generator at nwav=%d per gas: N_pass=%.1f in all "
+                                             "(every request swept, as the reference does), %.1f s (reorder %.2f, preparation "
+                                             "%.2f, search %.2f)"
+                                             % (len(cb["gases"]), args.cpu_sample, cb["n_pass"], cb["seconds"],
                                                 cb["stage_seconds"]["reorder"], cb["stage_seconds"]["preparation"],
                                                 cb["stage_seconds"]["search"])}
     return out

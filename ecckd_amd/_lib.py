@@ -210,6 +210,8 @@ SIGNATURES = {
     "ecckd_find_g_bands_ex": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _c_double_p, C.c_double,
                                         C.c_int, C.c_void_p, C.POINTER(C.c_int), _c_double_p, _c_double_p, _c_int64_p, _c_int64_p,
                                         C.c_int, C.POINTER(C.c_int), _c_double_p]),
+    "ecckd_gas_reset_memo": (C.c_int, [C.c_void_p]),
+    "ecckd_find_g_gases": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int]),
     "ecckd_opt_set_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ecckd_cfg_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ecckd_cfg_from_args": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]),
@@ -244,6 +246,13 @@ class BandOptions(C.Structure):
                 ("base_wn_bound", _c_double_p), ("d_wavenumber", C.c_void_p), ("d_rank", C.c_void_p),
                 ("nwav", C.c_size_t), ("band_albedo", C.c_double)]
 
+
+class GasSearch(C.Structure):
+    """ecckd_gas_search (include/ecckd_hip.h): one gas's request of ecckd_find_g_gases."""
+    _fields_ = [("gas", C.c_void_p), ("nband", C.c_int), ("ibegin", C.POINTER(C.c_size_t)), ("iend", C.POINTER(C.c_size_t)),
+                ("heating_rate_tolerance", _c_double_p), ("opt", C.c_void_p), ("ng", C.POINTER(C.c_int)), ("bounds", _c_double_p),
+                ("error", _c_double_p), ("rank1", _c_int64_p), ("rank2", _c_int64_p), ("capacity", C.c_int),
+                ("status", C.POINTER(C.c_int)), ("comp_cost", _c_double_p), ("rc", C.c_int)]
 
 
 class OptGas(C.Structure):

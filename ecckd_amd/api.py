@@ -388,6 +388,10 @@ class GasLW:
         check(self.lib.ecckd_gas_eval_stats(self.handle, C.byref(rq), C.byref(hit), C.byref(pr), C.byref(pe)))
         return dict(requests=rq.value, memo_hits=hit.value, points_requested=pr.value, points_evaluated=pe.value)
 
+    def reset_memo(self):
+        """Forget the interval errors answered so far and zero the counters (ecckd_gas_reset_memo)."""
+        check(self.lib.ecckd_gas_reset_memo(self.handle))
+
     def sweep_bytes_per_point(self):
         """Bytes the error sweep reads per point (ecckd_gas_sweep_bytes_per_point): 656 at 54 layers with a FLOAT background
         (kept as FLOAT pairs), 872 with a DOUBLE one."""
@@ -544,6 +548,42 @@ class GasLW:
                                                          i1.ctypes.data_as(C.POINTER(C.c_int64)),
                                                          i2.ctypes.data_as(C.POINTER(C.c_int64)), _hptr(out)))
         return out
+
+
+def find_g_gases(gases, requests, tolerance_tolerance=0.02, max_iterations=60, max_concurrent=0, capacity=1024):
+    """The band searches of several prepared gases side by side on one device (ecckd_find_g_gases: one host thread and one
+    HIP stream per gas, every gas the launch trains it runs alone).  requests[k] = dict(ibegin, iend, heating_rate_tolerance,
+    options=None) as Gas.find_g_bands_ex takes them for gases[k].  max_concurrent: gases at a time (1 = gas after gas, 0 =
+    what the host has cores for).  -> per gas the list of per-band result dicts of find_g_bands_ex."""
+    n = len(gases)
+    req = (_lib.GasSearch * n)()
+    keep, out = [], []
+    for k, (gas, r) in enumerate(zip(gases, requests)):
+        nband = len(r["ibegin"])
+        ib = np.ascontiguousarray(r["ibegin"], dtype=np.uint64)
+        ie = np.ascontiguousarray(r["iend"], dtype=np.uint64)
+        tol = np.ascontiguousarray(np.broadcast_to(np.asarray(r["heating_rate_tolerance"], dtype=np.float64), (nband,)))
+        opts = (_lib.BandOptions * nband)()
+        options = r.get("options")
+        for j in range(nband):
+            opts[j] = gas._band_options(keep, **((options[j] if options else None) or {}))
+        b = np.zeros((nband, capacity + 1)); e = np.zeros((nband, capacity))
+        r1 = np.zeros((nband, capacity), dtype=np.int64); r2 = np.zeros((nband, capacity), dtype=np.int64)
+        ng = np.zeros(nband, dtype=np.int32); st = np.zeros(nband, dtype=np.int32); cc = np.zeros(nband)
+        keep += [ib, ie, tol, opts]
+        out.append((nband, b, e, r1, r2, ng, st, cc))
+        q = req[k]
+        q.gas, q.nband = gas.handle, nband
+        q.ibegin, q.iend = ib.ctypes.data_as(C.POINTER(C.c_size_t)), ie.ctypes.data_as(C.POINTER(C.c_size_t))
+        q.heating_rate_tolerance, q.opt = _hptr(tol), C.cast(opts, C.c_void_p)
+        q.ng, q.bounds, q.error = ng.ctypes.data_as(C.POINTER(C.c_int)), _hptr(b), _hptr(e)
+        q.rank1, q.rank2 = r1.ctypes.data_as(C.POINTER(C.c_int64)), r2.ctypes.data_as(C.POINTER(C.c_int64))
+        q.capacity, q.status, q.comp_cost = capacity, st.ctypes.data_as(C.POINTER(C.c_int)), _hptr(cc)
+        gas.ctx.fence_from_torch()
+    check(gases[0].lib.ecckd_find_g_gases(n, C.cast(req, C.c_void_p), float(tolerance_tolerance), int(max_iterations), int(max_concurrent)))
+    return [[dict(status=int(st[j]), bounds=b[j, :ng[j] + 1].copy(), error=e[j, :ng[j]].copy(), rank1=r1[j, :ng[j]].copy(),
+                  rank2=r2[j, :ng[j]].copy(), comp_cost=float(cc[j])) for j in range(nband)]
+            for nband, b, e, r1, r2, ng, st, cc in out]
 
 
 def regroup_rank_by_wavenumber(ctx, wavenumber, rank, rank_lo, rank_hi, wn_bound):

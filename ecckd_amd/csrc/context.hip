@@ -44,7 +44,17 @@ DevCache* cache_of(ecckd_ctx* ctx) {
 }
 }  // namespace
 
+namespace {
+void cache_trim_locked(ecckd_ctx* ctx, DevCache* c) {
+  if (!c->free_blocks.empty()) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
+  c->free_blocks.clear();
+  c->cached_bytes = 0;
+}
+}  // namespace
+
 hipError_t dev_malloc(ecckd_ctx* ctx, void** p, size_t bytes) {
+  std::lock_guard<std::mutex> lock(ctx->cache_mutex);
   DevCache* c = cache_of(ctx);
   if (bytes == 0) bytes = 1;
   auto it = c->free_blocks.find(bytes);
@@ -58,7 +68,7 @@ hipError_t dev_malloc(ecckd_ctx* ctx, void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes);
   if (e == hipErrorOutOfMemory && !c->free_blocks.empty()) {
     (void)hipGetLastError();
-    dev_cache_trim(ctx);
+    cache_trim_locked(ctx, c);
     e = hipMalloc(p, bytes);
   }
   if (e == hipSuccess) c->live[*p] = bytes;
@@ -67,6 +77,7 @@ hipError_t dev_malloc(ecckd_ctx* ctx, void** p, size_t bytes) {
 
 void dev_release(ecckd_ctx* ctx, void* p) {
   if (!p) return;
+  std::lock_guard<std::mutex> lock(ctx->cache_mutex);
   DevCache* c = cache_of(ctx);
   auto it = c->live.find(p);
   if (it == c->live.end()) { (void)hipFree(p); return; }   // not ours (allocated before the cache existed)
@@ -83,12 +94,60 @@ void dev_cache_delete(ecckd_ctx* ctx) {
 }
 
 void dev_cache_trim(ecckd_ctx* ctx) {
+  std::lock_guard<std::mutex> lock(ctx->cache_mutex);
   if (!ctx->cache_impl) return;
-  DevCache* c = (DevCache*)ctx->cache_impl;
-  if (!c->free_blocks.empty()) (void)hipStreamSynchronize(ctx->stream);
-  for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
-  c->free_blocks.clear();
-  c->cached_bytes = 0;
+  cache_trim_locked(ctx, (DevCache*)ctx->cache_impl);
+}
+
+// The lanes of a context: a stream, pinned result slots and timing events each (common.hpp).
+ecckd_lane* lane_acquire(ecckd_ctx* ctx) {
+  std::lock_guard<std::mutex> lock(ctx->lane_mutex);
+  for (ecckd_lane* l : ctx->lanes)
+    if (!l->busy) {
+      l->busy = true;
+      l->profile_seq = 0;
+      l->stat_rt_lw = ecckd_lane_stat();
+      l->stat_rt_sw = ecckd_lane_stat();
+      return l;
+    }
+  ecckd_lane* l = new ecckd_lane();
+  if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&l->pev0) != hipSuccess ||
+      hipEventCreate(&l->pev1) != hipSuccess) {
+    if (l->stream) (void)hipStreamDestroy(l->stream);
+    if (l->pev0) (void)hipEventDestroy(l->pev0);
+    delete l;
+    (void)fail(ECCKD_UNEXPECTED_EXCEPTION, "a stream for a side-by-side search could not be created");
+    return nullptr;
+  }
+  l->busy = true;
+  ctx->lanes.push_back(l);
+  return l;
+}
+
+void lane_release(ecckd_ctx* ctx, ecckd_lane* lane) {
+  if (!lane) return;
+  std::lock_guard<std::mutex> lock(ctx->lane_mutex);
+  auto fold = [](ecckd_lane_stat& into, const ecckd_lane_stat& from) {
+    into.ms += from.ms; into.units += from.units; into.calls += from.calls;
+    into.all_units += from.all_units; into.all_calls += from.all_calls;
+  };
+  fold(ctx->stat_rt_lw, lane->stat_rt_lw);
+  fold(ctx->stat_rt_sw, lane->stat_rt_sw);
+  lane->busy = false;
+}
+
+int lane_ensure_pinned(ecckd_lane* lane, size_t bytes) {
+  if (bytes <= lane->pinned_bytes) return ECCKD_OK;
+  if (lane->pinned) {
+    ECCKD_HIP_CHECK(hipStreamSynchronize(lane->stream));
+    ECCKD_HIP_CHECK(hipHostFree(lane->pinned));
+    lane->pinned = nullptr;
+    lane->pinned_bytes = 0;
+  }
+  const size_t want = ecckd_align_up(bytes * 2, 4096);
+  ECCKD_HIP_CHECK(hipHostMalloc(&lane->pinned, want, hipHostMallocMapped | hipHostMallocCoherent));
+  lane->pinned_bytes = want;
+  return ECCKD_OK;
 }
 
 int ensure_scratch(ecckd_ctx* ctx, size_t bytes) {
@@ -165,6 +224,15 @@ int ecckd_destroy(ecckd_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ecckd::streamer_delete(ctx);
+  for (ecckd_lane* l : ctx->lanes) {
+    (void)hipStreamSynchronize(l->stream);
+    if (l->pinned) (void)hipHostFree(l->pinned);
+    (void)hipEventDestroy(l->pev0);
+    (void)hipEventDestroy(l->pev1);
+    (void)hipStreamDestroy(l->stream);
+    delete l;
+  }
+  ctx->lanes.clear();
   ecckd::dev_cache_trim(ctx);
   ecckd::dev_cache_delete(ctx);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -244,6 +312,7 @@ int ecckd_profile_enable(ecckd_ctx* ctx, int on) {
   ctx->stat_key_lw = ecckd_ctx::KernelStat();
   ctx->stat_rt_sw = ecckd_ctx::KernelStat();
   ctx->stat_sort = ecckd_ctx::KernelStat();
+  ctx->stat_gases = ecckd_ctx::KernelStat();
   return ECCKD_OK;
 }
 
@@ -254,6 +323,7 @@ int ecckd_profile_get(ecckd_ctx* ctx, const char* kernel, long long* calls, doub
   else if (!strcmp(kernel, "k_reorder_key_lw")) st = &ctx->stat_key_lw;
   else if (!strcmp(kernel, "k_rt_sw_bb")) st = &ctx->stat_rt_sw;
   else if (!strcmp(kernel, "radix_sort")) st = &ctx->stat_sort;
+  else if (!strcmp(kernel, "find_g_gases")) st = &ctx->stat_gases;
   if (!strcmp(kernel, "k_rt_sw_bb.all")) {
     if (calls) *calls = ctx->stat_rt_sw.all_calls;
     if (ms) *ms = 0.0;

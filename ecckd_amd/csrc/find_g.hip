@@ -1975,10 +1975,10 @@ void mark_pending(double* h_slots, int count) {
   std::atomic_thread_fence(std::memory_order_release);
 }
 
-int wait_for_slots(ecckd_ctx* ctx, const double* h_slots, int count) {
+int wait_for_slots(hipStream_t stream, const double* h_slots, int count) {
   static const bool no_poll = std::getenv("ECCKD_NO_POLL") != nullptr;   // A/B knob: wait through the runtime
   if (no_poll) {
-    ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ECCKD_HIP_CHECK(hipStreamSynchronize(stream));
     return ECCKD_OK;
   }
   const volatile unsigned long long* s = reinterpret_cast<const volatile unsigned long long*>(h_slots);
@@ -1991,7 +1991,7 @@ int wait_for_slots(ecckd_ctx* ctx, const double* h_slots, int count) {
     if (all_there()) break;
     if ((spins & 0x3fff) == 0) {
       // now and then: has the stream drained (or died) without delivering?  An idle stream has made all its writes visible.
-      const hipError_t q = hipStreamQuery(ctx->stream);
+      const hipError_t q = hipStreamQuery(stream);
       if (q == hipSuccess) {
         if (all_there()) break;
         return ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION, "interval errors were not delivered by the device");
@@ -2015,7 +2015,7 @@ long long interval_chunk_pts(long long len, long long blocks, long long gran) {
 int gas_ensure_work(ecckd_gas* g, size_t dev_bytes, size_t pinned_bytes) {
   if (dev_bytes > g->work_bytes) {
     if (g->work) {
-      ECCKD_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+      ECCKD_HIP_CHECK(hipStreamSynchronize(g->eval_stream()));
       ecckd::dev_release(g->ctx, g->work);
       g->work = nullptr;
       g->work_bytes = 0;
@@ -2024,7 +2024,13 @@ int gas_ensure_work(ecckd_gas* g, size_t dev_bytes, size_t pinned_bytes) {
     ECCKD_HIP_CHECK(ecckd::dev_malloc(g->ctx, &g->work, want));
     g->work_bytes = want;
   }
-  // the pinned staging area belongs to the context (one caller per context at a time)
+  // the pinned staging area belongs to the context (one caller per context at a time) or to the lane the gas was lent
+  if (g->lane) {
+    ECCKD_CHECK(ecckd::lane_ensure_pinned(g->lane, pinned_bytes));
+    g->pinned = g->lane->pinned;
+    g->pinned_bytes = g->lane->pinned_bytes;
+    return ECCKD_OK;
+  }
   ECCKD_CHECK(ecckd::ensure_pinned(g->ctx, pinned_bytes));
   g->pinned = g->ctx->pinned;
   g->pinned_bytes = g->ctx->pinned_bytes;
@@ -2724,6 +2730,13 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
   std::chrono::steady_clock::time_point t_first, t_last;
   const int n = (int)iv.size();
   ecckd_ctx* ctx = g->ctx;
+  // the lane of this evaluation: the context's own stream, events and counters, or the ones this gas was lent (ecckd_find_g_gases)
+  ecckd_lane* const lane = g->lane;
+  const hipStream_t stream = g->eval_stream();
+  hipEvent_t const pev0 = lane ? lane->pev0 : ctx->pev0, pev1 = lane ? lane->pev1 : ctx->pev1;
+  long long& profile_seq = lane ? lane->profile_seq : ctx->profile_seq;
+  ecckd_lane_stat& stat_rt_lw = lane ? lane->stat_rt_lw : ctx->stat_rt_lw;
+  ecckd_lane_stat& stat_rt_sw = lane ? lane->stat_rt_sw : ctx->stat_rt_sw;
   const int nlay = g->nlay, nhl = nlay + 1;
   long long total_pts = 0;
   for (int k = 0; k < n; ++k) total_pts += iv[k].i2 - iv[k].i1 + 1;
@@ -2784,24 +2797,24 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
   } else {
     std::memset(&ka, 0, sizeof ka);
     std::memcpy(h_iv, iv.data(), (size_t)n * sizeof(Interval));
-    ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, h_iv, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, ctx->stream));
+    ECCKD_HIP_CHECK(hipMemcpyAsync(d_iv, h_iv, (size_t)n * sizeof(Interval), hipMemcpyHostToDevice, stream));
   }
 
   LwRowBases lw_rows;
   lw_rows.w1 = g->w1; lw_rows.w2 = g->w2; lw_rows.cnt = g->cnt; lw_rows.planck_hl = g->planck_hl; lw_rows.hr = g->hr;
   lw_rows.fds = g->fds; lw_rows.fut = g->fut; lw_rows.n = g->n; lw_rows.is_log = g->method == ECCKD_AVG_LOGARITHMIC;
   if (!g->do_sw)
-    hipLaunchKernelGGL(k_interval_sums_fit_lw, dim3(nlay + (g->rm.total - g->rm.H), n), dim3(256), 0, ctx->stream, ka, nlay, g->method,
+    hipLaunchKernelGGL(k_interval_sums_fit_lw, dim3(nlay + (g->rm.total - g->rm.H), n), dim3(256), 0, stream, ka, nlay, g->method,
                        g->rm, g->ntiles, g->nsuper, d_iv, use_ka, d_iv, lw_rows, g->tile_sums, g->super_sums,
                        d_sums, d_fit);
   else
-    hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, ctx->stream, ka, g->nrows, g->ntiles, g->nsuper, d_iv, use_ka,
+    hipLaunchKernelGGL(k_interval_sums, dim3(g->nrows, n), dim3(256), 0, stream, ka, g->nrows, g->ntiles, g->nsuper, d_iv, use_ka,
                        d_iv, (const double* const*)g->rows, g->tile_sums, g->super_sums, d_sums);
   if (g->do_sw) {
     // CkdEquipartition::calc_error, shortwave branches (find_g_points.cpp:341-402)
     const bool is_tt = g->method == ECCKD_AVG_TOTAL_TRANSMISSION;
     const RowMap& R = g->rm;
-    hipLaunchKernelGGL(k_fit_sw, dim3(n), dim3(128), nlay * sizeof(double), ctx->stream, nlay, g->method, R, n,
+    hipLaunchKernelGGL(k_fit_sw, dim3(n), dim3(128), nlay * sizeof(double), stream, nlay, g->method, R, n,
                        g->min_scaling, g->max_scaling, d_iv, d_sums, d_fit);
     const size_t rt_lds_sw = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
     const size_t cost_lds_sw = (size_t)(COST_GROUPS * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
@@ -2817,17 +2830,17 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
     static const bool no_same = std::getenv("ECCKD_SW_NO_SAME") != nullptr;   // A/B knob
     const bool same_exp = g->cos_sza == 0.5 && !no_same;
     // HIP events round the sweep launches of every profile_stride-th batch (ecckd_profile_enable), as for the longwave sweep
-    const bool timed_sw = ctx->profile && (ctx->profile_seq++ % ctx->profile_stride) == 0;
-    if (ctx->profile) { ctx->stat_rt_sw.all_calls += 1; ctx->stat_rt_sw.all_units += (double)total_pts; }
-    if (timed_sw) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
+    const bool timed_sw = ctx->profile && (profile_seq++ % ctx->profile_stride) == 0;
+    if (ctx->profile) { stat_rt_sw.all_calls += 1; stat_rt_sw.all_units += (double)total_pts; }
+    if (timed_sw) ECCKD_HIP_CHECK(hipEventRecord(pev0, stream));
     for (int pass = 0; pass < (dual ? 1 : npass); ++pass) {
       double* part = d_part + (size_t)pass * part_stride;
 #define ECCKD_SW_SWEEP(NL, NF, SM, FIT)                                                                                         \
-  hipLaunchKernelGGL((k_rt_sw_bb_fast<NL, NF, SM>), dim3((unsigned)nchunks), dim3(RT_THREADS), 0, ctx->stream, g->n, n, \
+  hipLaunchKernelGGL((k_rt_sw_bb_fast<NL, NF, SM>), dim3((unsigned)nchunks), dim3(RT_THREADS), 0, stream, g->n, n, \
                      d_iv, g->cos_sza, g->ssi, g->bg_od, FIT, part)
       const double* fit1 = d_fit + (size_t)pass * n * nlay;
       if (!fast_path)
-        hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, ctx->stream, nlay, g->n,
+        hipLaunchKernelGGL(k_rt_sw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds_sw, stream, nlay, g->n,
                            n, d_iv, g->cos_sza, g->ssi, g->bg_od, fit1, part);
       else if (nlay == 54 && dual) { if (same_exp) ECCKD_SW_SWEEP(54, 2, true, d_fit); else ECCKD_SW_SWEEP(54, 2, false, d_fit); }
       else if (nlay == 30 && dual) { if (same_exp) ECCKD_SW_SWEEP(30, 2, true, d_fit); else ECCKD_SW_SWEEP(30, 2, false, d_fit); }
@@ -2835,34 +2848,34 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
       else if (nlay == 30) { if (same_exp) ECCKD_SW_SWEEP(30, 1, true, fit1); else ECCKD_SW_SWEEP(30, 1, false, fit1); }
 #undef ECCKD_SW_SWEEP
     }
-    if (timed_sw) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
+    if (timed_sw) ECCKD_HIP_CHECK(hipEventRecord(pev1, stream));
     // both evaluations in one launch; the errors go straight into the pinned host buffer (a few bytes over PCIe)
     SwTruthRows rows;
     rows.rH[0] = is_tt ? R.HL : R.H;      rows.rH[1] = R.HH;
     rows.rFDS[0] = is_tt ? R.FDSL : R.FDS; rows.rFDS[1] = R.FDSH;
     rows.rFUT[0] = is_tt ? R.FUTL : R.FUT; rows.rFUT[1] = R.FUTH;
-    hipLaunchKernelGGL(k_cost_sw, dim3(n, npass), dim3(1024), cost_lds_sw, ctx->stream, nlay, R.total, rows, d_iv, nchunks,
+    hipLaunchKernelGGL(k_cost_sw, dim3(n, npass), dim3(1024), cost_lds_sw, stream, nlay, R.total, rows, d_iv, nchunks,
                        d_part, part_stride, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, g->cos_sza, h_err_dev);
     ECCKD_HIP_CHECK(hipGetLastError());
-    ECCKD_CHECK(wait_for_slots(ctx, h_err, nslots));
+    ECCKD_CHECK(wait_for_slots(stream, h_err, nslots));
     for (int k = 0; k < n; ++k) error[k] = is_tt ? 0.5 * (h_err[k] + h_err[n + k]) : h_err[k];  // :386
     if (timed_sw) {
       float ms = 0.f;
-      ECCKD_HIP_CHECK(hipEventSynchronize(ctx->pev1));
-      ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1));
-      ctx->stat_rt_sw.ms += ms;
-      ctx->stat_rt_sw.units += (double)total_pts;
-      ctx->stat_rt_sw.calls += 1;
+      ECCKD_HIP_CHECK(hipEventSynchronize(pev1));
+      ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, pev0, pev1));
+      stat_rt_sw.ms += ms;
+      stat_rt_sw.units += (double)total_pts;
+      stat_rt_sw.calls += 1;
     }
     return ECCKD_OK;
   }
   if (g_turn.on) t_first = std::chrono::steady_clock::now();
   const size_t rt_lds = (size_t)(4 * 2 * nhl + nlay) * sizeof(double);
-  const bool timed = ctx->profile && (ctx->profile_seq++ % ctx->profile_stride) == 0;
-  if (ctx->profile) { ctx->stat_rt_lw.all_calls += 1; ctx->stat_rt_lw.all_units += (double)total_pts; }
-  if (timed) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev0, ctx->stream));
+  const bool timed = ctx->profile && (profile_seq++ % ctx->profile_stride) == 0;
+  if (ctx->profile) { stat_rt_lw.all_calls += 1; stat_rt_lw.all_units += (double)total_pts; }
+  if (timed) ECCKD_HIP_CHECK(hipEventRecord(pev0, stream));
 #define ECCKD_LW_MIRROR(NL, P32)                                                                                          \
-  hipLaunchKernelGGL((k_rt_lw_bb_mirror<NL, P32>), dim3(mirror_grid), dim3(RT_THREADS), 0, ctx->stream, g->n, n, nchunks, d_iv,     \
+  hipLaunchKernelGGL((k_rt_lw_bb_mirror<NL, P32>), dim3(mirror_grid), dim3(RT_THREADS), 0, stream, g->n, n, nchunks, d_iv,     \
                      g->planck_hl, g->bg_od, (const float_x2*)g->bg_pair, d_fit, d_part)
   // a block per chunk.  (ECCKD_RT_PERSISTENT: one resident round of blocks, each taking every mirror_grid-th chunk - measured
   // SLOWER on a partition of unequal intervals, 1 069 against 1 015 us per pass of 38 intervals over 7.2e6 points, equal on
@@ -2876,18 +2889,18 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
 #undef ECCKD_LW_MIRROR
   } else {
     ECCKD_CHECK(gas_bg_rows(g));
-    hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, ctx->stream, nlay, g->n,
+    hipLaunchKernelGGL(k_rt_lw_bb, dim3((unsigned)nchunks), dim3(RT_THREADS), rt_lds, stream, nlay, g->n,
                        n, d_iv, g->planck_hl, g->bg_od, d_fit, d_part);
   }
-  if (timed) ECCKD_HIP_CHECK(hipEventRecord(ctx->pev1, ctx->stream));
+  if (timed) ECCKD_HIP_CHECK(hipEventRecord(pev1, stream));
   const size_t cost_lds = (size_t)(COST_GROUPS * 2 * nhl + 2 * nhl + nlay) * sizeof(double);
   ECCKD_REQUIRE(target_blocks <= 32 * COST_GROUPS && cost_lds <= 64 * 1024, "ecckd_calc_error_batch: %lld chunks per interval / %d layers exceed the cost kernel's room",
                 target_blocks, nlay);
-  hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, ctx->stream, nlay, g->rm, d_iv,
+  hipLaunchKernelGGL(k_cost_lw, dim3(n), dim3(1024), cost_lds, stream, nlay, g->rm, d_iv,
                      nchunks, d_part, d_sums, g->lev + nhl, g->lev + nhl + nlay, g->flux_weight, h_err_dev);
   ECCKD_HIP_CHECK(hipGetLastError());
   if (g_turn.on) t_last = std::chrono::steady_clock::now();
-  ECCKD_CHECK(wait_for_slots(ctx, h_err, nslots));
+  ECCKD_CHECK(wait_for_slots(stream, h_err, nslots));
   if (g_turn.on) {
     const auto now = std::chrono::steady_clock::now();
     if (g_turn.have_seen && std::chrono::duration<double>(t_entry - g_turn.seen).count() < 500e-6) {   // not the pause between two searches
@@ -2903,11 +2916,11 @@ static int eval_intervals(ecckd_gas* g, std::vector<Interval>& iv, double* error
   std::memcpy(error, h_err, (size_t)n * sizeof(double));
   if (timed) {
     float ms = 0.f;
-    ECCKD_HIP_CHECK(hipEventSynchronize(ctx->pev1));    // long past: the cost kernel behind it has delivered
-    ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, ctx->pev0, ctx->pev1));
-    ctx->stat_rt_lw.ms += ms;
-    ctx->stat_rt_lw.units += (double)total_pts;
-    ctx->stat_rt_lw.calls += 1;
+    ECCKD_HIP_CHECK(hipEventSynchronize(pev1));    // long past: the cost kernel behind it has delivered
+    ECCKD_HIP_CHECK(hipEventElapsedTime(&ms, pev0, pev1));
+    stat_rt_lw.ms += ms;
+    stat_rt_lw.units += (double)total_pts;
+    stat_rt_lw.calls += 1;
     // ECCKD_SWEEP_LOG=<file>: one line per sweep launch (intervals, points, chunks, ms) for tools/sweep_sizes.py
     static FILE* sweep_log = std::getenv("ECCKD_SWEEP_LOG") ? std::fopen(std::getenv("ECCKD_SWEEP_LOG"), "a") : nullptr;
     if (sweep_log) std::fprintf(sweep_log, "%d %lld %lld %.6f\n", n, total_pts, nchunks, (double)ms);
@@ -3000,6 +3013,17 @@ int ecckd_gas_eval_stats(ecckd_gas* gas, long long* requests, long long* memo_hi
   if (memo_hits) *memo_hits = gas->memo_hits;
   if (points_requested) *points_requested = gas->points_requested;
   if (points_evaluated) *points_evaluated = gas->points_evaluated;
+  return ECCKD_OK;
+}
+
+// Forget every interval error this gas has answered and zero the counters of ecckd_gas_eval_stats: the next search sweeps
+// every interval again (timing one prepared gas twice; the reference has no memo at all).
+int ecckd_gas_reset_memo(ecckd_gas* gas) {
+  ECCKD_REQUIRE(gas, "ecckd_gas_reset_memo: NULL handle");
+  gas->error_memo.clear();
+  gas->memo_requests = gas->memo_hits = 0;
+  gas->points_requested = gas->points_evaluated = 0.0;
+  gas->total_comp_cost = 0.0;
   return ECCKD_OK;
 }
 

@@ -351,7 +351,11 @@ class BandBatcher {
     Slot& s = slots_[id];
     s.ibegin = ibegin; s.npoints = npoints; s.albedo = albedo; s.n = n; s.b1 = b1; s.b2 = b2; s.e = e;
     s.state.store(PENDING, std::memory_order_release);
-    while (s.state.load(std::memory_order_acquire) != DONE) _mm_pause();
+    // (spin, then give the core away now and then: with several gases searched side by side there can be more searches than
+    // cores, and the thread that serves the batch must get to run)
+    for (unsigned spins = 1; s.state.load(std::memory_order_acquire) != DONE; ++spins) {
+      if ((spins & 0xfff) == 0) std::this_thread::yield(); else _mm_pause();
+    }
     s.state.store(IDLE, std::memory_order_relaxed);
     if (s.rc != ECCKD_OK) ecckd::fail(s.rc, "%s", s.message.c_str());   // the message was recorded on the thread that ran the batch
     return s.rc;
@@ -368,6 +372,7 @@ class BandBatcher {
     std::vector<size_t> ib, np;
     std::vector<double> b1, b2, alb, err;
     std::vector<int> who;
+    unsigned idle = 0;
     while (active_.load(std::memory_order_acquire) > 0) {
       // a round is complete when no search is between two requests
       bool complete = true;
@@ -377,7 +382,11 @@ class BandBatcher {
         if (st == PENDING) who.push_back((int)i);
         else if (st != LEFT) { complete = false; break; }
       }
-      if (!complete || who.empty()) { _mm_pause(); continue; }
+      if (!complete || who.empty()) {
+        if ((++idle & 0xfff) == 0) std::this_thread::yield(); else _mm_pause();
+        continue;
+      }
+      idle = 0;
       // laid out by band (slot order = band order): the batch is the same from run to run
       ib.clear(); np.clear(); b1.clear(); b2.clear(); alb.clear();
       for (int i : who) {
@@ -533,10 +542,10 @@ int ecckd_find_g_band_ex(ecckd_gas* g, size_t ibegin, size_t iend, double heatin
       if (ibegin != 0) return ecckd::fail(ECCKD_PARAMETER_ERROR, "Failed to account for all wavenumbers in split");
       std::vector<int64_t> count(nwavsplit);
       {
-        // the other searches never touch the device themselves while this one is not waiting in the batcher, but two
-        // searches could get here together
-        std::unique_lock<std::mutex> device_lock(g_band_device_mutex, std::defer_lock);
-        if (batcher) device_lock.lock();
+        // the regrouping runs on the context's stream with the context's sort scratch: one search at a time.  (The other
+        // searches of this gas never touch the device themselves; two of them, or two
+        // searches could get here together (other bands of this gas, other gases searched side by side)
+        std::lock_guard<std::mutex> device_lock(g_band_device_mutex);
         ECCKD_CHECK(ecckd_regroup_rank_by_wavenumber_dev(g->ctx, opt->nwav, opt->d_wavenumber, opt->d_rank, 0, (size_t)ind2,
                                                          nwavsplit, opt->base_wn_bound, count.data()));
       }
@@ -626,6 +635,107 @@ int ecckd_find_g_bands_ex(ecckd_gas* g, int nband, const size_t* ibegin, const s
   for (std::thread& t : threads) t.join();
   for (int b = 0; b < nband; ++b)
     if (rc[b] != ECCKD_OK) return ecckd::fail(rc[b], "band %d: %s", b, message[b].c_str());
+  return ECCKD_OK;
+}
+
+// find_g_points.cpp:655-1266, the gas loop: the band searches of SEVERAL gases side by side on one device.  The reference
+// searches gas after gas; the searches are independent of each other (each gas has its own prepared rows; the shared Planck
+// matrix is only read), and a single search cannot fill the chip: 86 % of its error batches are one or two intervals that
+// are bound by launch and memory latency (~35 us each, a few per cent of the CUs), and every batch depends on the one before.
+// So every gas gets a host thread and a lane of its own - HIP stream, pinned result slots, timing events - and runs EXACTLY
+// the launch trains it runs alone: an interval's error does not depend on what else is on the device, so every search takes
+// the decisions it takes alone (same g points, same errors to the last bit), and one gas's latency-bound batches run in the
+// shadow of another gas's whole-partition passes.  (Merging the gases' requests into ONE launch train per round, as the
+// bands of one gas are merged by BandBatcher, would make every single-interval request last as long as the longest pass of
+// the round - ~1 ms instead of ~35 us on each of the ~2 000 dependent steps of a search.)
+int ecckd_find_g_gases(int ngas, ecckd_gas_search* req, double tolerance_tolerance, int max_iterations, int max_concurrent) {
+  ECCKD_REQUIRE(ngas > 0 && req, "ecckd_find_g_gases: bad argument");
+  for (int k = 0; k < ngas; ++k) {
+    ecckd_gas_search& r = req[k];
+    ECCKD_REQUIRE(r.gas && r.nband > 0 && r.ibegin && r.iend && r.heating_rate_tolerance && r.opt && r.ng && r.bounds && r.error &&
+                  r.status && r.capacity > 0, "ecckd_find_g_gases: request %d is incomplete", k);
+    ECCKD_REQUIRE(r.gas->lane == nullptr, "ecckd_find_g_gases: gas %d is already being searched", k);
+    for (int j = 0; j < k; ++j) ECCKD_REQUIRE(req[j].gas != r.gas, "ecckd_find_g_gases: requests %d and %d name the same gas", j, k);
+    r.rc = ECCKD_OK;
+  }
+  int width = max_concurrent > 0 ? std::min(max_concurrent, ngas) : ngas;
+  if (max_concurrent <= 0) {
+    // a gas with several bands runs a thread per band and one that serves their batches: do not start more spinning threads
+    // than the host has cores
+    const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+    int per_gas = 1;
+    for (int k = 0; k < ngas; ++k) per_gas = std::max(per_gas, req[k].nband > 1 || req[k].gas->do_sw ? req[k].nband + 1 : 1);
+    width = std::max(1, std::min(ngas, cores / per_gas));
+  }
+  if (const char* e = std::getenv("ECCKD_GASES_SIDE_BY_SIDE")) width = std::max(1, std::min(ngas, std::atoi(e)));
+  // what the preparations left on the contexts' streams must have landed before the lanes' streams read it
+  for (int k = 0; k < ngas; ++k) {
+    ECCKD_HIP_CHECK(hipSetDevice(req[k].gas->ctx->device));
+    ECCKD_HIP_CHECK(hipStreamSynchronize(req[k].gas->ctx->stream));
+  }
+  // with the timing switched on (ecckd_profile_enable): the window in which the searches run, between two events on the first
+  // gas's context stream (idle in between; every lane is synchronised before the second one is recorded), and the points the
+  // gases' sweeps processed in it - side by side the sweeps of several streams overlap, so bytes over THIS time, not bytes per
+  // launch over a launch's duration, say how busy the memory system was
+  ecckd_ctx* const ctx0 = req[0].gas->ctx;
+  const bool timed = ctx0->profile && ctx0->pev0;
+  double points_before = 0.0;
+  hipEvent_t w0 = nullptr, w1 = nullptr;
+  if (timed) {
+    for (int k = 0; k < ngas; ++k) points_before += req[k].gas->points_evaluated;
+    ECCKD_HIP_CHECK(hipEventCreate(&w0));
+    ECCKD_HIP_CHECK(hipEventCreate(&w1));
+    ECCKD_HIP_CHECK(hipEventRecord(w0, ctx0->stream));
+  }
+  std::vector<std::string> message(ngas);
+  auto search = [&](int k) {
+    ecckd_gas_search& r = req[k];
+    r.rc = ecckd_find_g_bands_ex(r.gas, r.nband, r.ibegin, r.iend, r.heating_rate_tolerance, tolerance_tolerance, max_iterations,
+                                 r.opt, r.ng, r.bounds, r.error, r.rank1, r.rank2, r.capacity, r.status, r.comp_cost);
+    if (r.rc != ECCKD_OK) message[k] = ecckd_last_error();
+  };
+  if (width <= 1) {
+    for (int k = 0; k < ngas; ++k) search(k);
+  } else {
+    std::atomic<int> next{0};
+    std::vector<std::thread> threads;
+    threads.reserve(width);
+    for (int t = 0; t < width; ++t)
+      threads.emplace_back([&] {
+        for (int k = next.fetch_add(1); k < ngas; k = next.fetch_add(1)) {
+          ecckd_gas* g = req[k].gas;
+          if (hipSetDevice(g->ctx->device) != hipSuccess) { req[k].rc = ECCKD_UNEXPECTED_EXCEPTION; message[k] = "hipSetDevice failed"; continue; }
+          g->lane = ecckd::lane_acquire(g->ctx);
+          if (!g->lane) { req[k].rc = ECCKD_UNEXPECTED_EXCEPTION; message[k] = ecckd_last_error(); continue; }
+          // the gas's work buffer and the device alias of its pinned slots belong to the stream they were used on
+          g->pinned_dev_of = nullptr;
+          search(k);
+          (void)hipStreamSynchronize(g->lane->stream);
+          ecckd::lane_release(g->ctx, g->lane);
+          g->lane = nullptr;
+          g->pinned_dev_of = nullptr;
+          g->pinned = nullptr;
+          g->pinned_bytes = 0;
+        }
+      });
+    for (std::thread& t : threads) t.join();
+  }
+  if (timed) {
+    float ms = 0.f;
+    bool ok = hipEventRecord(w1, ctx0->stream) == hipSuccess && hipEventSynchronize(w1) == hipSuccess &&
+              hipEventElapsedTime(&ms, w0, w1) == hipSuccess;
+    (void)hipEventDestroy(w0);
+    (void)hipEventDestroy(w1);
+    if (ok) {
+      double points_after = 0.0;
+      for (int k = 0; k < ngas; ++k) points_after += req[k].gas->points_evaluated;
+      ctx0->stat_gases.ms += ms;
+      ctx0->stat_gases.units += points_after - points_before;
+      ctx0->stat_gases.calls += 1;
+    }
+  }
+  for (int k = 0; k < ngas; ++k)
+    if (req[k].rc != ECCKD_OK) return ecckd::fail(req[k].rc, "gas %d: %s", k, message[k].c_str());
   return ECCKD_OK;
 }
 

@@ -98,5 +98,9 @@ struct ecckd_gas {
   size_t pinned_bytes = 0;
   void* pinned_dev = nullptr;      // device alias of `pinned` (hipHostGetDevicePointer), valid while pinned_dev_of == pinned
   void* pinned_dev_of = nullptr;
+  // the lane the error evaluations of this gas are issued on: nullptr = the context's own stream, pinned slots and counters;
+  // ecckd_find_g_gases lends one per gas for the length of the call
+  ecckd_lane* lane = nullptr;
+  hipStream_t eval_stream() const { return lane ? lane->stream : ctx->stream; }
 };
 

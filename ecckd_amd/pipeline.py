@@ -302,18 +302,9 @@ def reorder_spectrum(ctx, input_path, output_path, band_bound1, band_bound2, ipr
     return dict(spectrum=s, key=key, column_optical_depth=col, band_number=iband, rank=rank)
 
 
-def _search_gas(ctx, g, bands, tol, tolerance_tolerance, max_iterations, averaging_method, flux_weight, min_pressure,
-                sequential_bands, planck_reuse=None, sw=None):
-    """One gas of the loop find_g_points.cpp:655-1450 with everything already on the device: gas preparation (:872-1150),
-    the searches of `bands` (:1152-1414, side by side unless sequential_bands) and the median sorting variable of every
-    g point (:1404-1409).
-
-    g:  dict(pressure_hl, temperature_hl (host), wn, dwn, rank (int32), od, bg (or None), sorting_variable: device tensors in
-        ORIGINAL wavenumber order; band_begin[nband], band_end[nband]: first / last sorted index of every band;
-        min_g_points[nband], max_g_points[nband]; shortwave: min_scaling, max_scaling)
-    sw: None (longwave; planck_reuse = device pointer of the first gas's Planck matrix or None) or
-        dict(ssi, albedo: device tensors, band_albedo[nband], cos_sza).
-    Returns (gas handle - the caller closes it -, [(band, dict(rank1, rank2, error, status, comp_cost, sorting_variable))])."""
+def _prepare_gas(ctx, g, averaging_method, flux_weight, min_pressure, planck_reuse=None, sw=None):
+    """Gas preparation (find_g_points.cpp:872-1150) of one gas whose spectra are on the device, and its sorting variable in
+    sorted order (:781).  g, sw, planck_reuse: see _search_gas.  -> (gas handle, sorting variable sorted, band albedo or None)"""
     import time
     timing = g.setdefault("timing", {})
     t0 = time.perf_counter()
@@ -327,25 +318,25 @@ def _search_gas(ctx, g, bands, tol, tolerance_tolerance, max_iterations, averagi
         band_albedo = sw["band_albedo"]
     sv_sorted = api.gather_f64(ctx, g["sorting_variable"], api.invert_permutation(ctx, g["rank"]))
     ctx.synchronize()
-    t1 = time.perf_counter()
-    timing["preparation"] = timing.get("preparation", 0.0) + t1 - t0
+    timing["preparation"] = timing.get("preparation", 0.0) + time.perf_counter() - t0
+    return gas, sv_sorted, band_albedo
+
+
+def _band_requests(g, bands, tol, band_albedo):
+    """The arguments of ecckd_find_g_bands_ex for `bands` of gas g: first / last sorted index, tolerance and options per band;
+    a shortwave band brings its albedo (init_sw(..., band_albedo(jband), ...)) with it."""
     begin, end = g["band_begin"], g["band_end"]
     opts = [dict(min_g_points=int(g["min_g_points"][b]), max_g_points=int(g["max_g_points"][b])) for b in bands]
-    if len(bands) > 1 and not sequential_bands:
-        # bands side by side, sharing their error batches (ecckd_find_g_bands_ex): same decisions per band; a shortwave
-        # band brings its albedo (init_sw(..., band_albedo(jband), ...)) with it
-        side = [dict(o, band_albedo=float(band_albedo[b])) if band_albedo is not None else o for b, o in zip(bands, opts)]
-        band_res = gas.find_g_bands_ex([int(begin[b]) for b in bands], [int(end[b]) for b in bands],
-                                       np.ascontiguousarray(np.asarray(tol)[bands]), tolerance_tolerance, max_iterations, side)
-    else:
-        band_res = []
-        for b, o in zip(bands, opts):
-            if band_albedo is not None:
-                gas.set_band_albedo(band_albedo[b])                                                   # init_sw(..., band_albedo(jband), ...)
-            band_res.append(gas.find_g_band_ex(int(begin[b]), int(end[b]), float(tol[b]), tolerance_tolerance, max_iterations, **o))
+    if band_albedo is not None:
+        opts = [dict(o, band_albedo=float(band_albedo[b])) for b, o in zip(bands, opts)]
+    return dict(ibegin=[int(begin[b]) for b in bands], iend=[int(end[b]) for b in bands],
+                heating_rate_tolerance=np.ascontiguousarray(np.asarray(tol)[bands]), options=opts)
+
+
+def _finish_gas(gas, g, bands, band_res, sv_sorted):
+    """The median sorting variable of every g point of these bands in one call (:1404-1409) and the per-band result dicts."""
+    import time
     t2 = time.perf_counter()
-    timing["search"] = timing.get("search", 0.0) + t2 - t1
-    # the median sorting variable of every g point of these bands in one call
     r1_all = np.concatenate([np.asarray(res["rank1"], dtype=np.int64) for res in band_res])
     r2_all = np.concatenate([np.asarray(res["rank2"], dtype=np.int64) for res in band_res])
     med_all = gas.median_sorting_variable(sv_sorted, r1_all, r2_all)
@@ -358,8 +349,42 @@ def _search_gas(ctx, g, bands, tol, tolerance_tolerance, max_iterations, averagi
         out.append((b, dict(rank1=[int(v) for v in res["rank1"]], rank2=[int(v) for v in res["rank2"]],
                             error=[float(v) for v in res["error"]], status=int(res["status"]),
                             comp_cost=float(res["comp_cost"]), sorting_variable=[float(v) for v in med])))
+    timing = g.setdefault("timing", {})
     timing["medians"] = timing.get("medians", 0.0) + time.perf_counter() - t2
-    return gas, out
+    return out
+
+
+def _search_gas(ctx, g, bands, tol, tolerance_tolerance, max_iterations, averaging_method, flux_weight, min_pressure,
+                sequential_bands, planck_reuse=None, sw=None):
+    """One gas of the loop find_g_points.cpp:655-1450 with everything already on the device: gas preparation (:872-1150),
+    the searches of `bands` (:1152-1414, side by side unless sequential_bands) and the median sorting variable of every
+    g point (:1404-1409).
+
+    g:  dict(pressure_hl, temperature_hl (host), wn, dwn, rank (int32), od, bg (or None), sorting_variable: device tensors in
+        ORIGINAL wavenumber order; band_begin[nband], band_end[nband]: first / last sorted index of every band;
+        min_g_points[nband], max_g_points[nband]; shortwave: min_scaling, max_scaling)
+    sw: None (longwave; planck_reuse = device pointer of the first gas's Planck matrix or None) or
+        dict(ssi, albedo: device tensors, band_albedo[nband], cos_sza).
+    Returns (gas handle - the caller closes it -, [(band, dict(rank1, rank2, error, status, comp_cost, sorting_variable))])."""
+    import time
+    gas, sv_sorted, band_albedo = _prepare_gas(ctx, g, averaging_method, flux_weight, min_pressure, planck_reuse, sw)
+    timing = g["timing"]
+    t1 = time.perf_counter()
+    req = _band_requests(g, bands, tol, band_albedo)
+    if len(bands) > 1 and not sequential_bands:
+        # bands side by side, sharing their error batches (ecckd_find_g_bands_ex): same decisions per band
+        band_res = gas.find_g_bands_ex(req["ibegin"], req["iend"], req["heating_rate_tolerance"], tolerance_tolerance, max_iterations,
+                                       req["options"])
+    else:
+        band_res = []
+        for k, b in enumerate(bands):
+            o = dict(req["options"][k])
+            o.pop("band_albedo", None)
+            if band_albedo is not None:
+                gas.set_band_albedo(band_albedo[b])                                                   # init_sw(..., band_albedo(jband), ...)
+            band_res.append(gas.find_g_band_ex(req["ibegin"][k], req["iend"][k], float(tol[b]), tolerance_tolerance, max_iterations, **o))
+    timing["search"] = timing.get("search", 0.0) + time.perf_counter() - t1
+    return gas, _finish_gas(gas, g, bands, band_res, sv_sorted)
 
 
 def _deal(ngas, nband, rank, world_size, group):
@@ -518,7 +543,8 @@ def find_g_points(ctx, gases, band_bound1, band_bound2, heating_rate_tolerance, 
 
 def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, first_gas_order=None, averaging_method="transmission",
                            flux_weight=0.02, min_pressure=0.0, tolerance_tolerance=0.02, max_iterations=60,
-                           sequential_bands=False, rank=None, world_size=None, group=None, merged_map=True, sw=None):
+                           sequential_bands=False, rank=None, world_size=None, group=None, merged_map=True, sw=None,
+                           gases_side_by_side=1):
     """find_g_points on spectra that are already resident in HBM (bench.py, the full-size tests): the same dealing of the
     (gas, band) tasks, the same per-gas work (_search_gas) and the same collection as find_g_points, with `load_gas(gi)`
     handing over the device tensors of gas gi (the dict _search_gas takes; the call may do the gas's reorder_spectrum step,
@@ -530,6 +556,10 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
     its bands (what the file driver reads from the first gas's ordering file), for the shared Planck matrix.
     merged_map: every gas's per-wavenumber g points travel to rank 0 (one reduce per gas; each wavenumber is set by exactly
     one process), which forms the merged g-point map (:1459-1475).
+    gases_side_by_side: 1 = gas after gas as the reference's loop (:655): load, prepare, search, release; otherwise every gas
+    of this process is loaded and prepared first (all resident: ~9.5 GB per gas at 7.2e6 points), then ALL their band searches
+    run side by side (ecckd_find_g_gases: one host thread and HIP stream per gas; n > 1: at most n gases at a time, 0: what the
+    host has cores for) - same g points, same errors, the gases' latency-bound batches in each other's shadow.
     -> rank 0: dict(ng, band_number, gases, g_point (device), n_unassigned, cost_sum, comp_cost_sum, points);
        others: dict(cost_sum, comp_cost_sum, points).  `points`: wavenumber points this process worked through: one pass over its bands (reorder, preparation) + the points
     its searches swept on the device (an interval asked for twice is swept once: the memo of interval errors)."""
@@ -545,24 +575,61 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
     points = 0.0
     nwav = None
     phase = {"reorder": 0.0, "preparation": 0.0, "search": 0.0, "medians": 0.0, "maps": 0.0, "collect": 0.0}
+    side_by_side = gases_side_by_side != 1 and len(my_bands) > 1
+    prepared = {}
+    if side_by_side:
+        # every gas of this process loaded and prepared, then all their searches at once
+        for gi in sorted(my_bands):
+            tl = time.perf_counter()
+            g = load_gas(gi)
+            ctx.synchronize()
+            phase["reorder"] += time.perf_counter() - tl
+            reuse = None
+            if sw is not None:
+                pass
+            elif gi > 0 and first_lw_gas is not None:
+                reuse = first_lw_gas.view_ptr("planck_hl")[0]
+            elif gi > 0:
+                if planck_first is None:
+                    o0 = first_gas_order()
+                    planck_first = api.planck_hl_sorted(ctx, o0["temperature_hl"], o0["wn"], o0["dwn"], o0["rank"])
+                reuse = planck_first.data_ptr()
+            gas, sv_sorted, band_albedo = _prepare_gas(ctx, g, averaging_method, flux_weight, min_pressure, reuse, sw)
+            for k in ("od", "bg"):                # the spectra are in the gas's rows now
+                g.pop(k, None)
+            prepared[gi] = (g, gas, sv_sorted, _band_requests(g, my_bands[gi], tol, band_albedo))
+            if gi == 0 and sw is None:
+                first_lw_gas = gas
+        ts = time.perf_counter()
+        order = sorted(prepared)
+        all_res = api.find_g_gases([prepared[gi][1] for gi in order], [prepared[gi][3] for gi in order], tolerance_tolerance,
+                                   max_iterations, max_concurrent=gases_side_by_side)
+        phase["search"] += time.perf_counter() - ts
+        for gi, band_res in zip(order, all_res):
+            g, gas, sv_sorted, _ = prepared[gi]
+            prepared[gi] = (g, gas, _finish_gas(gas, g, my_bands[gi], band_res, sv_sorted))
     for gi in sorted(my_bands):
-        tl = time.perf_counter()
-        g = load_gas(gi)
-        ctx.synchronize()
-        phase["reorder"] += time.perf_counter() - tl
-        nwav = g["rank"].numel()
-        reuse = None
-        if sw is not None:
-            pass
-        elif gi > 0 and first_lw_gas is not None:
-            reuse = first_lw_gas.view_ptr("planck_hl")[0]
-        elif gi > 0:
-            if planck_first is None:
-                o0 = first_gas_order()
-                planck_first = api.planck_hl_sorted(ctx, o0["temperature_hl"], o0["wn"], o0["dwn"], o0["rank"])
-            reuse = planck_first.data_ptr()
-        gas, res = _search_gas(ctx, g, my_bands[gi], tol, tolerance_tolerance, max_iterations, averaging_method, flux_weight,
-                               min_pressure, sequential_bands, reuse, sw)
+        if side_by_side:
+            g, gas, res = prepared.pop(gi)
+            nwav = g["rank"].numel()
+        else:
+            tl = time.perf_counter()
+            g = load_gas(gi)
+            ctx.synchronize()
+            phase["reorder"] += time.perf_counter() - tl
+            nwav = g["rank"].numel()
+            reuse = None
+            if sw is not None:
+                pass
+            elif gi > 0 and first_lw_gas is not None:
+                reuse = first_lw_gas.view_ptr("planck_hl")[0]
+            elif gi > 0:
+                if planck_first is None:
+                    o0 = first_gas_order()
+                    planck_first = api.planck_hl_sorted(ctx, o0["temperature_hl"], o0["wn"], o0["dwn"], o0["rank"])
+                reuse = planck_first.data_ptr()
+            gas, res = _search_gas(ctx, g, my_bands[gi], tol, tolerance_tolerance, max_iterations, averaging_method, flux_weight,
+                                   min_pressure, sequential_bands, reuse, sw)
         for b, r in res:
             r["index_range"] = (int(g["band_begin"][b]), int(g["band_end"][b]))
             points += g["band_end"][b] - g["band_begin"][b] + 1            # the reorder / preparation pass over the band

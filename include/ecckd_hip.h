@@ -226,6 +226,9 @@ int ecckd_calc_error_multi(ecckd_gas* gas, int n, const size_t* h_ibegin, const 
  * (read per call) switches the memo off. */
 int ecckd_gas_eval_stats(ecckd_gas* gas, long long* requests, long long* memo_hits, double* points_requested,
                          double* points_evaluated);
+/* Forget the interval errors the gas has answered so far (its memo) and zero the counters above: the next search sweeps
+ * every interval again - for timing the same prepared gas twice. */
+int ecckd_gas_reset_memo(ecckd_gas* gas);
 /* Bytes the error sweep reads per spectral point of an interval it evaluates.  Longwave: (nlay+1) Planck values in DOUBLE
  * plus nlay background optical depths - 4 bytes each when every background value of the gas is exactly a float (a FLOAT
  * spectrum as the CKDMIP files hold it: the gas then keeps them as FLOAT pairs and the sweep widens them, the same bits as
@@ -344,14 +347,41 @@ int ecckd_find_g_band_ex(ecckd_gas* gas, size_t ibegin, size_t iend, double heat
  * when only the widest bands are still refining, stays latency-bound).  Shortwave gases too: every band brings its surface
  * albedo in opt[b].band_albedo and the sweep takes it per interval (the gas's own band albedo, ecckd_gas_set_band_albedo,
  * is neither used nor changed).  Results per band as ecckd_find_g_band_ex, arrays [nband] or [nband][capacity(+1)].
- * Interval errors differ from the one-band-at-a-time values in the last bits (the chunking of the sums follows the batch);
- * the logic is the same, so a search ends at the same g points unless one of its comparisons sits within that rounding of
- * a tie - seen only in searches that do not converge (status != 0), which the reference's bracketing leaves sensitive to
- * the last bits of the errors.  Measured: 13 longwave bands 3.0e9 -> 3.65e9 points/s, 32 shortwave bands 1.7e9 -> 3.2e9. */
+ * An interval's error has the same bits alone and in any batch (every interval is summed in chunks of ITS OWN size), so a
+ * search side by side ends where it ends on its own, converged or not.
+ * Measured: 13 longwave bands 3.0e9 -> 3.65e9 points/s, 32 shortwave bands 1.7e9 -> 3.2e9. */
 int ecckd_find_g_bands_ex(ecckd_gas* gas, int nband, const size_t* ibegin, const size_t* iend,
                           const double* heating_rate_tolerance, double tolerance_tolerance, int max_iterations,
                           const ecckd_band_options* opt /* [nband] */, int* ng, double* bounds, double* error,
                           int64_t* rank1, int64_t* rank2, int capacity, int* status, double* comp_cost);
+
+/* The gas loop of find_g_points.cpp:655-1266 with the searches of SEVERAL prepared gases side by side on one device.  The
+ * reference searches gas after gas; the searches are independent (each gas has its own prepared rows, the shared Planck
+ * matrix is only read) and one search cannot fill the chip - most of its error batches are one or two intervals, bound by
+ * launch and memory latency, each depending on the one before.  Every gas gets a host thread and a HIP stream of its own
+ * (with its own pinned result slots and timing events) and runs exactly the launch trains it runs alone, so every search
+ * takes the decisions it takes alone (same g points, same errors to the last bit) while one gas's short batches run in the
+ * shadow of another gas's whole-partition passes.  One request per gas: the arguments of ecckd_find_g_bands_ex.
+ * max_concurrent: gases searched at a time; <= 0: as many as the host has cores for (a gas with several bands runs a
+ * thread per band).  The gases may belong to one context or to several.  req[k].rc = the gas's own return code. */
+typedef struct {
+  ecckd_gas* gas;
+  int nband;
+  const size_t* ibegin;                    /* [nband] */
+  const size_t* iend;                      /* [nband] */
+  const double* heating_rate_tolerance;    /* [nband] */
+  const ecckd_band_options* opt;           /* [nband] */
+  int* ng;                                 /* [nband] */
+  double* bounds;                          /* [nband][capacity + 1] */
+  double* error;                           /* [nband][capacity] */
+  int64_t* rank1;                          /* [nband][capacity] or NULL */
+  int64_t* rank2;                          /* [nband][capacity] or NULL */
+  int capacity;
+  int* status;                             /* [nband] */
+  double* comp_cost;                       /* [nband] or NULL */
+  int rc;                                  /* out */
+} ecckd_gas_search;
+int ecckd_find_g_gases(int ngas, ecckd_gas_search* req, double tolerance_tolerance, int max_iterations, int max_concurrent);
 
 /* calc_median_sorting_variable (find_g_points.cpp:35-49) for n g points: the sorting variable
  * at the point where the cumulative weight (LW: surface Planck function, SW: solar irradiance,

@@ -70,7 +70,7 @@ def test_struct_mirrors_match_the_header():
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    mirrors = {"ecckd_band_options": _lib.BandOptions, "ecckd_opt_gas": _lib.OptGas, "ecckd_opt_model": _lib.OptModel,
+    mirrors = {"ecckd_band_options": _lib.BandOptions, "ecckd_gas_search": _lib.GasSearch, "ecckd_opt_gas": _lib.OptGas, "ecckd_opt_model": _lib.OptModel,
                "ecckd_opt_scene": _lib.OptScene, "ecckd_opt_config": _lib.OptConfig}
     lines = []
     for cname, cls in mirrors.items():
