@@ -212,6 +212,9 @@ SIGNATURES = {
                                         C.c_int, C.POINTER(C.c_int), _c_double_p]),
     "ecckd_gas_reset_memo": (C.c_int, [C.c_void_p]),
     "ecckd_find_g_gases": (C.c_int, [C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int]),
+    "ecckd_find_g_gases_begin": (C.c_int, [C.c_double, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ecckd_find_g_gases_add": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ecckd_find_g_gases_wait": (C.c_int, [C.c_void_p]),
     "ecckd_opt_set_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ecckd_cfg_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ecckd_cfg_from_args": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]),

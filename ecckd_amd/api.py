@@ -550,40 +550,82 @@ class GasLW:
         return out
 
 
-def find_g_gases(gases, requests, tolerance_tolerance=0.02, max_iterations=60, max_concurrent=0, capacity=1024):
-    """The band searches of several prepared gases side by side on one device (ecckd_find_g_gases: one host thread and one
-    HIP stream per gas, every gas the launch trains it runs alone).  requests[k] = dict(ibegin, iend, heating_rate_tolerance,
-    options=None) as Gas.find_g_bands_ex takes them for gases[k].  max_concurrent: gases at a time (1 = gas after gas, 0 =
-    what the host has cores for).  -> per gas the list of per-band result dicts of find_g_bands_ex."""
-    n = len(gases)
-    req = (_lib.GasSearch * n)()
-    keep, out = [], []
-    for k, (gas, r) in enumerate(zip(gases, requests)):
-        nband = len(r["ibegin"])
-        ib = np.ascontiguousarray(r["ibegin"], dtype=np.uint64)
-        ie = np.ascontiguousarray(r["iend"], dtype=np.uint64)
-        tol = np.ascontiguousarray(np.broadcast_to(np.asarray(r["heating_rate_tolerance"], dtype=np.float64), (nband,)))
+class GasSearchJob:
+    """The band searches of several prepared gases side by side on one device (ecckd_find_g_gases_begin / _add / _wait: one host
+    thread and one HIP stream per gas, every gas the launch trains it runs alone).  add() starts a gas's search at once and
+    returns: the caller goes on to load and prepare the next gas while the gases added so far are being searched; wait() joins
+    the searches -> per gas (in the order added) the list of per-band result dicts of Gas.find_g_bands_ex.
+    max_concurrent: gases at a time (1 = each gas searched inside add(), the reference's gas-after-gas order; 0 = what the host
+    has cores for)."""
+
+    def __init__(self, tolerance_tolerance=0.02, max_iterations=60, max_concurrent=0, capacity=1024):
+        self.lib = _lib.load_library()
+        self.capacity = capacity
+        self.handle = C.c_void_p()
+        check(self.lib.ecckd_find_g_gases_begin(float(tolerance_tolerance), int(max_iterations), int(max_concurrent), C.byref(self.handle)))
+        self._keep, self._out = [], []
+
+    def add(self, gas, ibegin, iend, heating_rate_tolerance, options=None):
+        """Start the search of the bands [ibegin[k], iend[k]] of `gas` (arguments as Gas.find_g_bands_ex)."""
+        capacity = self.capacity
+        nband = len(ibegin)
+        ib = np.ascontiguousarray(ibegin, dtype=np.uint64)
+        ie = np.ascontiguousarray(iend, dtype=np.uint64)
+        tol = np.ascontiguousarray(np.broadcast_to(np.asarray(heating_rate_tolerance, dtype=np.float64), (nband,)))
         opts = (_lib.BandOptions * nband)()
-        options = r.get("options")
         for j in range(nband):
-            opts[j] = gas._band_options(keep, **((options[j] if options else None) or {}))
+            opts[j] = gas._band_options(self._keep, **((options[j] if options else None) or {}))
         b = np.zeros((nband, capacity + 1)); e = np.zeros((nband, capacity))
         r1 = np.zeros((nband, capacity), dtype=np.int64); r2 = np.zeros((nband, capacity), dtype=np.int64)
         ng = np.zeros(nband, dtype=np.int32); st = np.zeros(nband, dtype=np.int32); cc = np.zeros(nband)
-        keep += [ib, ie, tol, opts]
-        out.append((nband, b, e, r1, r2, ng, st, cc))
-        q = req[k]
+        q = _lib.GasSearch()
         q.gas, q.nband = gas.handle, nband
         q.ibegin, q.iend = ib.ctypes.data_as(C.POINTER(C.c_size_t)), ie.ctypes.data_as(C.POINTER(C.c_size_t))
         q.heating_rate_tolerance, q.opt = _hptr(tol), C.cast(opts, C.c_void_p)
         q.ng, q.bounds, q.error = ng.ctypes.data_as(C.POINTER(C.c_int)), _hptr(b), _hptr(e)
         q.rank1, q.rank2 = r1.ctypes.data_as(C.POINTER(C.c_int64)), r2.ctypes.data_as(C.POINTER(C.c_int64))
         q.capacity, q.status, q.comp_cost = capacity, st.ctypes.data_as(C.POINTER(C.c_int)), _hptr(cc)
+        self._keep += [ib, ie, tol, opts, q, gas]
+        self._out.append((nband, b, e, r1, r2, ng, st, cc))
         gas.ctx.fence_from_torch()
-    check(gases[0].lib.ecckd_find_g_gases(n, C.cast(req, C.c_void_p), float(tolerance_tolerance), int(max_iterations), int(max_concurrent)))
-    return [[dict(status=int(st[j]), bounds=b[j, :ng[j] + 1].copy(), error=e[j, :ng[j]].copy(), rank1=r1[j, :ng[j]].copy(),
-                  rank2=r2[j, :ng[j]].copy(), comp_cost=float(cc[j])) for j in range(nband)]
-            for nband, b, e, r1, r2, ng, st, cc in out]
+        check(self.lib.ecckd_find_g_gases_add(self.handle, C.byref(q)))
+
+    def wait(self):
+        h, self.handle = self.handle, None
+        check(self.lib.ecckd_find_g_gases_wait(h))
+        res = [[dict(status=int(st[j]), bounds=b[j, :ng[j] + 1].copy(), error=e[j, :ng[j]].copy(), rank1=r1[j, :ng[j]].copy(),
+                     rank2=r2[j, :ng[j]].copy(), comp_cost=float(cc[j])) for j in range(nband)]
+               for nband, b, e, r1, r2, ng, st, cc in self._out]
+        self._keep, self._out = [], []
+        return res
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            try:
+                self.lib.ecckd_find_g_gases_wait(self.handle)     # never leave searches running on buffers that go away
+            except Exception:                                     # noqa: BLE001
+                pass
+            self.handle = None
+
+
+def find_g_gases(gases, requests, tolerance_tolerance=0.02, max_iterations=60, max_concurrent=0, capacity=1024):
+    """All at once: requests[k] = dict(ibegin, iend, heating_rate_tolerance, options=None) as Gas.find_g_bands_ex takes them for
+    gases[k] -> per gas the list of per-band result dicts.  See GasSearchJob."""
+    job = GasSearchJob(tolerance_tolerance, max_iterations, 1 if len(gases) == 1 else max_concurrent, capacity)
+    first_error = None
+    for gas, r in zip(gases, requests):
+        try:
+            job.add(gas, r["ibegin"], r["iend"], r["heating_rate_tolerance"], r.get("options"))
+        except EcckdError as exc:
+            first_error = exc
+            break
+    if first_error is not None:
+        try:
+            job.wait()
+        except EcckdError:
+            pass
+        raise first_error
+    return job.wait()
 
 
 def regroup_rank_by_wavenumber(ctx, wavenumber, rank, rank_lo, rank_hi, wn_bound):

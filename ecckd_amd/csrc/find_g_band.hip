@@ -11,7 +11,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -335,6 +337,24 @@ int ecckd_gas_median_sorting_variable(ecckd_gas* g, const double* d_sorting_vari
 
 }  // extern "C"
 
+// ecckd_find_g_gases_begin / _add / _wait: the searches in flight
+struct ecckd_gas_search_job {
+  double tolerance_tolerance = 0.02;
+  int max_iterations = 60;
+  int width = 0;                       // gases at a time; <= 0: what the host's cores allow
+  std::vector<ecckd_gas_search*> req;
+  std::deque<std::string> message;     // (a deque: the searches in flight keep pointers to their own slot while others are added)
+  std::vector<std::thread> threads;
+  std::mutex mutex;
+  std::condition_variable cv;
+  int running = 0, threads_running = 0;
+  // timing window (ecckd_profile_enable)
+  ecckd_ctx* ctx0 = nullptr;
+  bool timed = false;
+  hipEvent_t w0 = nullptr, w1 = nullptr;
+  double points_before = 0.0;
+};
+
 namespace {
 
 // Merges the error evaluations that several band searches (one host thread each) ask for at the same time into one
@@ -648,95 +668,134 @@ int ecckd_find_g_bands_ex(ecckd_gas* g, int nband, const size_t* ibegin, const s
 // shadow of another gas's whole-partition passes.  (Merging the gases' requests into ONE launch train per round, as the
 // bands of one gas are merged by BandBatcher, would make every single-interval request last as long as the longest pass of
 // the round - ~1 ms instead of ~35 us on each of the ~2 000 dependent steps of a search.)
-int ecckd_find_g_gases(int ngas, ecckd_gas_search* req, double tolerance_tolerance, int max_iterations, int max_concurrent) {
-  ECCKD_REQUIRE(ngas > 0 && req, "ecckd_find_g_gases: bad argument");
-  for (int k = 0; k < ngas; ++k) {
-    ecckd_gas_search& r = req[k];
-    ECCKD_REQUIRE(r.gas && r.nband > 0 && r.ibegin && r.iend && r.heating_rate_tolerance && r.opt && r.ng && r.bounds && r.error &&
-                  r.status && r.capacity > 0, "ecckd_find_g_gases: request %d is incomplete", k);
-    ECCKD_REQUIRE(r.gas->lane == nullptr, "ecckd_find_g_gases: gas %d is already being searched", k);
-    for (int j = 0; j < k; ++j) ECCKD_REQUIRE(req[j].gas != r.gas, "ecckd_find_g_gases: requests %d and %d name the same gas", j, k);
-    r.rc = ECCKD_OK;
-  }
-  int width = max_concurrent > 0 ? std::min(max_concurrent, ngas) : ngas;
-  if (max_concurrent <= 0) {
-    // a gas with several bands runs a thread per band and one that serves their batches: do not start more spinning threads
-    // than the host has cores
-    const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
-    int per_gas = 1;
-    for (int k = 0; k < ngas; ++k) per_gas = std::max(per_gas, req[k].nband > 1 || req[k].gas->do_sw ? req[k].nband + 1 : 1);
-    width = std::max(1, std::min(ngas, cores / per_gas));
-  }
-  if (const char* e = std::getenv("ECCKD_GASES_SIDE_BY_SIDE")) width = std::max(1, std::min(ngas, std::atoi(e)));
-  // what the preparations left on the contexts' streams must have landed before the lanes' streams read it
-  for (int k = 0; k < ngas; ++k) {
-    ECCKD_HIP_CHECK(hipSetDevice(req[k].gas->ctx->device));
-    ECCKD_HIP_CHECK(hipStreamSynchronize(req[k].gas->ctx->stream));
-  }
-  // with the timing switched on (ecckd_profile_enable): the window in which the searches run, between two events on the first
-  // gas's context stream (idle in between; every lane is synchronised before the second one is recorded), and the points the
-  // gases' sweeps processed in it - side by side the sweeps of several streams overlap, so bytes over THIS time, not bytes per
-  // launch over a launch's duration, say how busy the memory system was
-  ecckd_ctx* const ctx0 = req[0].gas->ctx;
-  const bool timed = ctx0->profile && ctx0->pev0;
-  double points_before = 0.0;
-  hipEvent_t w0 = nullptr, w1 = nullptr;
-  if (timed) {
-    for (int k = 0; k < ngas; ++k) points_before += req[k].gas->points_evaluated;
-    ECCKD_HIP_CHECK(hipEventCreate(&w0));
-    ECCKD_HIP_CHECK(hipEventCreate(&w1));
-    ECCKD_HIP_CHECK(hipEventRecord(w0, ctx0->stream));
-  }
-  std::vector<std::string> message(ngas);
-  auto search = [&](int k) {
-    ecckd_gas_search& r = req[k];
-    r.rc = ecckd_find_g_bands_ex(r.gas, r.nband, r.ibegin, r.iend, r.heating_rate_tolerance, tolerance_tolerance, max_iterations,
-                                 r.opt, r.ng, r.bounds, r.error, r.rank1, r.rank2, r.capacity, r.status, r.comp_cost);
-    if (r.rc != ECCKD_OK) message[k] = ecckd_last_error();
-  };
-  if (width <= 1) {
-    for (int k = 0; k < ngas; ++k) search(k);
-  } else {
-    std::atomic<int> next{0};
-    std::vector<std::thread> threads;
-    threads.reserve(width);
-    for (int t = 0; t < width; ++t)
-      threads.emplace_back([&] {
-        for (int k = next.fetch_add(1); k < ngas; k = next.fetch_add(1)) {
-          ecckd_gas* g = req[k].gas;
-          if (hipSetDevice(g->ctx->device) != hipSuccess) { req[k].rc = ECCKD_UNEXPECTED_EXCEPTION; message[k] = "hipSetDevice failed"; continue; }
-          g->lane = ecckd::lane_acquire(g->ctx);
-          if (!g->lane) { req[k].rc = ECCKD_UNEXPECTED_EXCEPTION; message[k] = ecckd_last_error(); continue; }
-          // the gas's work buffer and the device alias of its pinned slots belong to the stream they were used on
-          g->pinned_dev_of = nullptr;
-          search(k);
-          (void)hipStreamSynchronize(g->lane->stream);
-          ecckd::lane_release(g->ctx, g->lane);
-          g->lane = nullptr;
-          g->pinned_dev_of = nullptr;
-          g->pinned = nullptr;
-          g->pinned_bytes = 0;
-        }
-      });
-    for (std::thread& t : threads) t.join();
-  }
-  if (timed) {
-    float ms = 0.f;
-    bool ok = hipEventRecord(w1, ctx0->stream) == hipSuccess && hipEventSynchronize(w1) == hipSuccess &&
-              hipEventElapsedTime(&ms, w0, w1) == hipSuccess;
-    (void)hipEventDestroy(w0);
-    (void)hipEventDestroy(w1);
-    if (ok) {
-      double points_after = 0.0;
-      for (int k = 0; k < ngas; ++k) points_after += req[k].gas->points_evaluated;
-      ctx0->stat_gases.ms += ms;
-      ctx0->stat_gases.units += points_after - points_before;
-      ctx0->stat_gases.calls += 1;
+int ecckd_find_g_gases_begin(double tolerance_tolerance, int max_iterations, int max_concurrent, ecckd_gas_search_job** out) {
+  ECCKD_REQUIRE(out, "ecckd_find_g_gases_begin: NULL argument");
+  ecckd_gas_search_job* job = new ecckd_gas_search_job();
+  job->tolerance_tolerance = tolerance_tolerance;
+  job->max_iterations = max_iterations;
+  job->width = max_concurrent;
+  if (const char* e = std::getenv("ECCKD_GASES_SIDE_BY_SIDE")) job->width = std::max(1, std::atoi(e));
+  *out = job;
+  return ECCKD_OK;
+}
+
+int ecckd_find_g_gases_add(ecckd_gas_search_job* job, ecckd_gas_search* r) {
+  ECCKD_REQUIRE(job && r, "ecckd_find_g_gases_add: NULL argument");
+  const int k = (int)job->req.size();
+  ECCKD_REQUIRE(r->gas && r->nband > 0 && r->ibegin && r->iend && r->heating_rate_tolerance && r->opt && r->ng && r->bounds && r->error &&
+                r->status && r->capacity > 0, "ecckd_find_g_gases: request %d is incomplete", k);
+  for (int j = 0; j < k; ++j) ECCKD_REQUIRE(job->req[j]->gas != r->gas, "ecckd_find_g_gases: requests %d and %d name the same gas", j, k);
+  ECCKD_REQUIRE(r->gas->lane == nullptr, "ecckd_find_g_gases: gas %d is already being searched", k);
+  r->rc = ECCKD_OK;
+  ecckd_gas* const g = r->gas;
+  ecckd_ctx* const ctx = g->ctx;
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  // what the preparation left on the context's stream must have landed before the lane's stream reads it
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (job->req.empty()) {
+    // with the timing switched on (ecckd_profile_enable): the window in which the searches run, between two events on the first
+    // gas's context stream (every lane is synchronised before the second one is recorded), and the points the gases' sweeps
+    // process in it - side by side the sweeps of several streams overlap, so bytes over THIS time, not bytes per launch over a
+    // launch's duration, say how busy the memory system was
+    job->ctx0 = ctx;
+    job->timed = ctx->profile && ctx->pev0;
+    if (job->timed) {
+      ECCKD_HIP_CHECK(hipEventCreate(&job->w0));
+      ECCKD_HIP_CHECK(hipEventCreate(&job->w1));
+      ECCKD_HIP_CHECK(hipEventRecord(job->w0, ctx->stream));
     }
   }
-  for (int k = 0; k < ngas; ++k)
-    if (req[k].rc != ECCKD_OK) return ecckd::fail(req[k].rc, "gas %d: %s", k, message[k].c_str());
+  job->points_before += g->points_evaluated;
+  job->req.push_back(r);
+  job->message.emplace_back();
+  std::string* const msg = &job->message.back();
+  // a gas with several bands runs a thread per band and one that serves their batches: not more spinning threads than the host
+  // has cores (width <= 0: what the cores allow)
+  const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+  const int per_gas = (r->nband > 1 || g->do_sw) ? r->nband + 1 : 1;
+  // a search that re-ranks its base g point by wavenumber (ecckd_regroup_rank_by_wavenumber_dev) works on the context's stream
+  // with the context's scratch, which the caller may be using for the next gas's preparation: such a gas is searched here and now
+  bool needs_context = false;
+  for (int b = 0; b < r->nband; ++b) needs_context |= r->opt[b].nbase_wn_bound > 2;
+  auto search = [job, r, msg] {
+    r->rc = ecckd_find_g_bands_ex(r->gas, r->nband, r->ibegin, r->iend, r->heating_rate_tolerance, job->tolerance_tolerance,
+                                  job->max_iterations, r->opt, r->ng, r->bounds, r->error, r->rank1, r->rank2, r->capacity, r->status,
+                                  r->comp_cost);
+    if (r->rc != ECCKD_OK) *msg = ecckd_last_error();
+  };
+  if (job->width == 1 || needs_context) {
+    search();
+    return ECCKD_OK;      // (a failure is reported by _wait, like the others')
+  }
+  job->threads.emplace_back([job, r, msg, g, ctx, per_gas, cores, search] {
+    {
+      // at most `width` gases at a time, and not more threads than cores
+      std::unique_lock<std::mutex> lock(job->mutex);
+      job->cv.wait(lock, [&] {
+        return job->running == 0 || ((job->width <= 0 || job->running < job->width) && job->threads_running + per_gas <= cores);
+      });
+      job->running += 1;
+      job->threads_running += per_gas;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) { r->rc = ECCKD_UNEXPECTED_EXCEPTION; *msg = "hipSetDevice failed"; }
+    else if (!(g->lane = ecckd::lane_acquire(ctx))) { r->rc = ECCKD_UNEXPECTED_EXCEPTION; *msg = ecckd_last_error(); }
+    else {
+      g->pinned_dev_of = nullptr;       // the device alias of the pinned slots belongs to the buffer of the lane
+      search();
+      (void)hipStreamSynchronize(g->lane->stream);
+      ecckd::lane_release(ctx, g->lane);
+      g->lane = nullptr;
+      g->pinned_dev_of = nullptr;
+      g->pinned = nullptr;
+      g->pinned_bytes = 0;
+    }
+    {
+      std::lock_guard<std::mutex> lock(job->mutex);
+      job->running -= 1;
+      job->threads_running -= per_gas;
+    }
+    job->cv.notify_all();
+  });
   return ECCKD_OK;
+}
+
+int ecckd_find_g_gases_wait(ecckd_gas_search_job* job) {
+  ECCKD_REQUIRE(job, "ecckd_find_g_gases_wait: NULL argument");
+  for (std::thread& t : job->threads) t.join();
+  if (job->timed) {
+    float ms = 0.f;
+    const bool ok = hipEventRecord(job->w1, job->ctx0->stream) == hipSuccess && hipEventSynchronize(job->w1) == hipSuccess &&
+                    hipEventElapsedTime(&ms, job->w0, job->w1) == hipSuccess;
+    (void)hipEventDestroy(job->w0);
+    (void)hipEventDestroy(job->w1);
+    if (ok) {
+      double points_after = 0.0;
+      for (ecckd_gas_search* r : job->req) points_after += r->gas->points_evaluated;
+      job->ctx0->stat_gases.ms += ms;
+      job->ctx0->stat_gases.units += points_after - job->points_before;
+      job->ctx0->stat_gases.calls += 1;
+    }
+  }
+  int rc = ECCKD_OK;
+  for (size_t k = 0; k < job->req.size() && rc == ECCKD_OK; ++k)
+    if (job->req[k]->rc != ECCKD_OK) rc = ecckd::fail(job->req[k]->rc, "gas %zu: %s", k, job->message[k].c_str());
+  delete job;
+  return rc;
+}
+
+int ecckd_find_g_gases(int ngas, ecckd_gas_search* req, double tolerance_tolerance, int max_iterations, int max_concurrent) {
+  ECCKD_REQUIRE(ngas > 0 && req, "ecckd_find_g_gases: bad argument");
+  ecckd_gas_search_job* job = nullptr;
+  ECCKD_CHECK(ecckd_find_g_gases_begin(tolerance_tolerance, max_iterations, ngas == 1 ? 1 : max_concurrent, &job));
+  int rc = ECCKD_OK;
+  std::string message;
+  for (int k = 0; k < ngas && rc == ECCKD_OK; ++k) {
+    rc = ecckd_find_g_gases_add(job, &req[k]);
+    if (rc != ECCKD_OK) message = ecckd_last_error();
+  }
+  const int rc_wait = ecckd_find_g_gases_wait(job);      // the searches already started are waited for whatever happened
+  if (rc != ECCKD_OK) return ecckd::fail(rc, "%s", message.c_str());
+  return rc_wait;
 }
 
 }  // extern "C"

@@ -578,8 +578,12 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
     side_by_side = gases_side_by_side != 1 and len(my_bands) > 1
     prepared = {}
     if side_by_side:
-        # every gas of this process loaded and prepared, then all their searches at once
-        for gi in sorted(my_bands):
+        # every gas of this process is loaded and prepared; its searches start as soon as it is (GasSearchJob.add returns at once)
+        # and run while the next gas is merged, reordered and prepared on the context's stream
+        job = api.GasSearchJob(tolerance_tolerance, max_iterations, max_concurrent=gases_side_by_side)
+        ts = None
+        order = sorted(my_bands)
+        for gi in order:
             tl = time.perf_counter()
             g = load_gas(gi)
             ctx.synchronize()
@@ -597,16 +601,18 @@ def find_g_points_resident(ctx, names, load_gas, nband, heating_rate_tolerance, 
             gas, sv_sorted, band_albedo = _prepare_gas(ctx, g, averaging_method, flux_weight, min_pressure, reuse, sw)
             for k in ("od", "bg"):                # the spectra are in the gas's rows now
                 g.pop(k, None)
-            prepared[gi] = (g, gas, sv_sorted, _band_requests(g, my_bands[gi], tol, band_albedo))
+            req = _band_requests(g, my_bands[gi], tol, band_albedo)
+            prepared[gi] = (g, gas, sv_sorted)
             if gi == 0 and sw is None:
                 first_lw_gas = gas
-        ts = time.perf_counter()
-        order = sorted(prepared)
-        all_res = api.find_g_gases([prepared[gi][1] for gi in order], [prepared[gi][3] for gi in order], tolerance_tolerance,
-                                   max_iterations, max_concurrent=gases_side_by_side)
-        phase["search"] += time.perf_counter() - ts
+            ts = ts or time.perf_counter()
+            job.add(gas, req["ibegin"], req["iend"], req["heating_rate_tolerance"], req["options"])
+        tw = time.perf_counter()
+        all_res = job.wait()
+        phase["search"] += time.perf_counter() - tw           # what is left of the searches when the last gas is prepared
+        phase["search_window"] = phase.get("search_window", 0.0) + time.perf_counter() - ts
         for gi, band_res in zip(order, all_res):
-            g, gas, sv_sorted, _ = prepared[gi]
+            g, gas, sv_sorted = prepared[gi]
             prepared[gi] = (g, gas, _finish_gas(gas, g, my_bands[gi], band_res, sv_sorted))
     for gi in sorted(my_bands):
         if side_by_side:

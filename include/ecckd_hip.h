@@ -382,6 +382,15 @@ typedef struct {
   int rc;                                  /* out */
 } ecckd_gas_search;
 int ecckd_find_g_gases(int ngas, ecckd_gas_search* req, double tolerance_tolerance, int max_iterations, int max_concurrent);
+/* The same in pieces, for a caller that reads and prepares the NEXT gas while the gases it has prepared are being searched (the
+ * tool: a gas's files stream in and its preparation runs on the context's stream while the lanes search): _begin opens a job,
+ * _add starts the search of one prepared gas at once (its request and everything it points to must stay where it is until
+ * _wait), _wait joins the searches, returns the first failure and closes the job.  A gas whose search re-ranks its base g
+ * point by wavenumber (opt.nbase_wn_bound > 2) needs the context itself and is searched inside _add. */
+typedef struct ecckd_gas_search_job ecckd_gas_search_job;
+int ecckd_find_g_gases_begin(double tolerance_tolerance, int max_iterations, int max_concurrent, ecckd_gas_search_job** job);
+int ecckd_find_g_gases_add(ecckd_gas_search_job* job, ecckd_gas_search* req);
+int ecckd_find_g_gases_wait(ecckd_gas_search_job* job);
 
 /* calc_median_sorting_variable (find_g_points.cpp:35-49) for n g points: the sorting variable
  * at the point where the cumulative weight (LW: surface Planck function, SW: solar irradiance,
