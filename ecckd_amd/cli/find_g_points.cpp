@@ -23,6 +23,7 @@
 #include <cctype>
 
 #include <future>
+#include <list>
 #include "tool.hpp"
 
 using namespace tool;
@@ -286,6 +287,79 @@ int main(int argc, char** argv) {
                                      &o.isubband2[(size_t)b * o.nsb], &o.iupperindex[b]));
     };
 
+    // The searches of a gas start as soon as the gas is prepared and run - a host thread and a HIP stream per gas
+    // (ecckd_find_g_gases_begin / _add / _wait) - while the next gas's files are read, merged and prepared: the reference's loop
+    // (:655) takes gas after gas, but a search is a chain of small dependent evaluations that cannot fill the device, and the
+    // reading of the next gas needs the host.  Every search takes the decisions it takes alone.  Extension keys:
+    // gases_side_by_side = n (gases searched at a time; 1 = the reference's order, 0 = what the host has cores for),
+    // sequential_bands (one band at a time, which also means gas after gas).
+    struct GasJob {
+      int gi = 0;
+      Ordering ord;
+      ecckd_gas* gas = nullptr;
+      DevBuf d_sv_sorted;
+      std::vector<int> mine;
+      std::vector<double> band_albedo;
+      std::vector<ecckd_band_options> opts;
+      std::vector<std::vector<double>> wn_bounds;
+      std::vector<size_t> ib, ie;
+      std::vector<double> tol, comp_costs, bounds, error;
+      std::vector<int> ngs, statuses;
+      std::vector<int64_t> r1, r2;
+      ecckd_gas_search req;
+      bool searched = false;
+    };
+    const int band_capacity = 1024;
+    bool sequential_bands = false;                 // extension key: the reference's one-band-at-a-time order of evaluation
+    config.read(sequential_bands, "sequential_bands");
+    int gases_side_by_side = 0;
+    config.read(gases_side_by_side, "gases_side_by_side");
+    if (sequential_bands) gases_side_by_side = 1;
+    std::list<GasJob> pending;
+    ecckd_gas_search_job* search_job = nullptr;
+
+    // what follows a gas's searches (:1396-1414): log, median sorting variable of every g point, the ranks as the searches left them
+    auto finish_gas = [&](GasJob& gj) {
+      const int nmine = (int)gj.mine.size();
+      std::string Gas = gas_list[gj.gi];
+      std::transform(Gas.begin(), Gas.end(), Gas.begin(), ::toupper);
+      LOG("*** G POINTS OF %s\n", Gas.c_str());
+      for (int m = 0; m < nmine; ++m) {
+        const int b = gj.mine[m];
+        LOG("  Band %d: %g-%g cm-1\n", b, band_bound1[b], band_bound2[b]);
+        const size_t o = (size_t)m * band_capacity;
+        const int ng = gj.ngs[m];
+        LOG("    %s: %d g points, computational cost = %g\n", ecckd_partition_status_string(gj.statuses[m]), ng, gj.comp_costs[m]);
+        BandResult br;
+        br.gas = gj.gi; br.band = b; br.ng = ng; br.status = gj.statuses[m]; br.comp_cost = gj.comp_costs[m];
+        br.ibegin = gj.ord.ibegin[b]; br.iend = gj.ord.iend[b];
+        br.median.resize(ng);
+        ck(ecckd_gas_median_sorting_variable(gj.gas, gj.d_sv_sorted.as<double>(), ng, &gj.r1[o], &gj.r2[o], br.median.data()));
+        br.rank1.assign(gj.r1.begin() + o, gj.r1.begin() + o + ng);
+        br.rank2.assign(gj.r2.begin() + o, gj.r2.begin() + o + ng);
+        br.error.assign(gj.error.begin() + o, gj.error.begin() + o + ng);
+        for (int k = 0; k < ng; ++k)
+          LOG("    g point %d: ranks %lld-%lld, error %g K d-1\n", k, (long long)gj.r1[o + k], (long long)gj.r2[o + k], gj.error[o + k]);
+        // the ranks of this band as the search left them (sub-bands and base splits re-rank inside a band)
+        br.rank_slice.resize((size_t)(br.iend - br.ibegin + 1));
+        ck(ecckd_d2h(dev.ctx(), br.rank_slice.data(), gj.ord.d_rank.as<int32_t>() + br.ibegin, br.rank_slice.size() * sizeof(int32_t)));
+        results.push_back(std::move(br));
+      }
+      if (gj.gas != first_lw_gas) ck(ecckd_gas_destroy(gj.gas));
+      gj.gas = nullptr;
+      LOG("\n");
+    };
+    // wait for the searches in flight and finish their gases, in the order of the gas list
+    auto flush = [&]() {
+      if (search_job) {
+        ecckd_gas_search_job* j = search_job;
+        search_job = nullptr;
+        ck(ecckd_find_g_gases_wait(j));
+      }
+      for (GasJob& gj : pending) finish_gas(gj);
+      pending.clear();
+    };
+
     for (int gi = 0; gi < ngas; ++gi) {
       const std::string& gas_str = gas_list[gi];
       std::string Gas = gas_str;
@@ -298,8 +372,24 @@ int main(int argc, char** argv) {
       min_scaling = std::min(0.5, min_scaling);   // :666-667
       max_scaling = std::max(2.5, max_scaling);
 
+      // all gases of the run stay resident until their searches are over: when the device runs short (3 x nlay + 8 rows of
+      // doubles per gas, and the spectra it is made from while it is prepared), the searches in flight are finished first
+      if (!pending.empty() && nwav > 0) {
+        size_t free_b = 0, total_b = 0;
+        const double need = 6.0 * 60.0 * 8.0 * (double)nwav;
+        ck(ecckd_mem_info(dev.ctx(), &free_b, &total_b));
+        if ((double)free_b < need) {           // (blocks parked in the library's allocator count as used: hand them back first)
+          ck(ecckd_trim_cache(dev.ctx()));
+          ck(ecckd_mem_info(dev.ctx(), &free_b, &total_b));
+        }
+        if ((double)free_b < need) flush();
+      }
+
       // ---- ordering (:669-683) ----
-      Ordering ord;
+      pending.emplace_back();
+      GasJob& gj = pending.back();
+      gj.gi = gi;
+      Ordering& ord = gj.ord;
       read_ordering(gas_str, ord);
       if (my_rank == 0) order_rank[gi] = ord.rank;
 
@@ -315,6 +405,7 @@ int main(int argc, char** argv) {
         }
       if (mine.empty()) {
         LOG("  (searched by other processes)\n\n");
+        pending.pop_back();
         continue;
       }
       const int nmine = (int)mine.size();
@@ -419,27 +510,29 @@ int main(int argc, char** argv) {
       target.single.buf.release();
 
       // sorting variable in sorted order (:781): sorted[r] = orig[ireorder[r]]
-      DevBuf d_ireorder(dev, nwav * sizeof(int32_t)), d_sv, d_sv_sorted(dev, nwav * sizeof(double));
+      gj.gas = gas;
+      gj.mine = mine;
+      gj.band_albedo = band_albedo;
+      DevBuf d_ireorder(dev, nwav * sizeof(int32_t)), d_sv;
+      gj.d_sv_sorted.alloc(dev, nwav * sizeof(double));
       d_sv.upload(dev, ord.sorting_variable);
       ck(ecckd_invert_permutation_dev(dev.ctx(), nwav, d_rank.as<int32_t>(), d_ireorder.as<int32_t>()));
-      ck(ecckd_gather_f64_dev(dev.ctx(), nwav, d_sv.as<double>(), d_ireorder.as<int32_t>(), d_sv_sorted.as<double>()));
+      ck(ecckd_gather_f64_dev(dev.ctx(), nwav, d_sv.as<double>(), d_ireorder.as<int32_t>(), gj.d_sv_sorted.as<double>()));
       ck(ecckd_synchronize(dev.ctx()));
 
       // ---- the bands (:1152-1414) ----
-      const int capacity = 1024;
       // Options of every band first: the bands are then searched side by side (ecckd_find_g_bands_ex); a shortwave band brings
       // its albedo (init_sw(..., band_albedo(jband), ...), :1177) with it.
-      std::vector<ecckd_band_options> opts(nmine);
-      std::vector<std::vector<double>> wn_bounds(nmine);
-      std::vector<size_t> ib(nmine), ie(nmine);
-      std::vector<double> tol(nmine);
+      gj.opts.resize(nmine);
+      gj.wn_bounds.resize(nmine);
+      gj.ib.resize(nmine); gj.ie.resize(nmine); gj.tol.resize(nmine);
       for (int m = 0; m < nmine; ++m) {
         const int b = mine[m];
         if (ord.ibegin[b] < 0) fail(ECCKD_PARAMETER_ERROR, "Band %d contains no wavenumbers", b);
-        ib[m] = (size_t)ord.ibegin[b];
-        ie[m] = (size_t)ord.iend[b];
-        tol[m] = tolerance[b];
-        ecckd_band_options& opt = opts[m];
+        gj.ib[m] = (size_t)ord.ibegin[b];
+        gj.ie[m] = (size_t)ord.iend[b];
+        gj.tol[m] = tolerance[b];
+        ecckd_band_options& opt = gj.opts[m];
         std::memset(&opt, 0, sizeof opt);
         opt.min_g_points = min_g_points[b];
         opt.max_g_points = max_g_points[b];
@@ -452,7 +545,7 @@ int main(int argc, char** argv) {
         }
         opt.base_split = base_split[b];
         opt.band_albedo = do_sw ? band_albedo[b] : 0.0;
-        std::vector<double>& wn_bound = wn_bounds[m];
+        std::vector<double>& wn_bound = gj.wn_bounds[m];
         std::vector<double> interior;
         for (double w : base_wavenumber_boundary) if (w > band_bound1[b] && w < band_bound2[b]) interior.push_back(w);
         if (base_split[b] != 1.0 || !interior.empty()) {   // :1268-1301
@@ -466,49 +559,35 @@ int main(int argc, char** argv) {
           opt.nwav = nwav;
         }
       }
-      std::vector<int> ngs(nmine, 0), statuses(nmine, 0);
-      std::vector<double> comp_costs(nmine, 0.0);
-      std::vector<double> bounds((size_t)nmine * (capacity + 1)), error((size_t)nmine * capacity);
-      std::vector<int64_t> r1((size_t)nmine * capacity), r2((size_t)nmine * capacity);
-      bool sequential_bands = false;                 // extension key: the reference's one-band-at-a-time order of evaluation
-      config.read(sequential_bands, "sequential_bands");
-      const bool side_by_side = nmine > 1 && !sequential_bands;
-      if (side_by_side)
-        ck(ecckd_find_g_bands_ex(gas, nmine, ib.data(), ie.data(), tol.data(), tolerance_tolerance, max_iterations, opts.data(),
-                                 ngs.data(), bounds.data(), error.data(), r1.data(), r2.data(), capacity, statuses.data(), comp_costs.data()));
-      for (int m = 0; m < nmine; ++m) {
-        const int b = mine[m];
-        LOG("  Band %d: %g-%g cm-1\n", b, band_bound1[b], band_bound2[b]);
-        const size_t o = (size_t)m * capacity;
-        if (!side_by_side) {
-          if (do_sw) ck(ecckd_gas_set_band_albedo(gas, band_albedo[b]));
-          ck(ecckd_find_g_band_ex(gas, ib[m], ie[m], tol[m], tolerance_tolerance, max_iterations, &opts[m], &ngs[m],
-                                  &bounds[(size_t)m * (capacity + 1)], &error[o], &r1[o], &r2[o], capacity, &statuses[m], &comp_costs[m]));
+      gj.ngs.assign(nmine, 0); gj.statuses.assign(nmine, 0);
+      gj.comp_costs.assign(nmine, 0.0);
+      gj.bounds.assign((size_t)nmine * (band_capacity + 1), 0.0); gj.error.assign((size_t)nmine * band_capacity, 0.0);
+      gj.r1.assign((size_t)nmine * band_capacity, 0); gj.r2.assign((size_t)nmine * band_capacity, 0);
+      if (sequential_bands) {
+        // one band at a time, here and now
+        for (int m = 0; m < nmine; ++m) {
+          const size_t o = (size_t)m * band_capacity;
+          if (do_sw) ck(ecckd_gas_set_band_albedo(gas, band_albedo[mine[m]]));
+          ck(ecckd_find_g_band_ex(gas, gj.ib[m], gj.ie[m], gj.tol[m], tolerance_tolerance, max_iterations, &gj.opts[m], &gj.ngs[m],
+                                  &gj.bounds[(size_t)m * (band_capacity + 1)], &gj.error[o], &gj.r1[o], &gj.r2[o], band_capacity, &gj.statuses[m],
+                                  &gj.comp_costs[m]));
         }
-        const int ng = ngs[m];
-        LOG("    %s: %d g points, computational cost = %g\n", ecckd_partition_status_string(statuses[m]), ng, comp_costs[m]);
-        BandResult br;
-        br.gas = gi; br.band = b; br.ng = ng; br.status = statuses[m]; br.comp_cost = comp_costs[m];
-        br.ibegin = ord.ibegin[b]; br.iend = ord.iend[b];
-        br.median.resize(ng);
-        ck(ecckd_gas_median_sorting_variable(gas, d_sv_sorted.as<double>(), ng, &r1[o], &r2[o], br.median.data()));
-        br.rank1.assign(r1.begin() + o, r1.begin() + o + ng);
-        br.rank2.assign(r2.begin() + o, r2.begin() + o + ng);
-        br.error.assign(error.begin() + o, error.begin() + o + ng);
-        for (int k = 0; k < ng; ++k)
-          LOG("    g point %d: ranks %lld-%lld, error %g K d-1\n", k, (long long)r1[o + k], (long long)r2[o + k], error[o + k]);
-        results.push_back(std::move(br));
+        flush();
+      } else {
+        // the bands of this gas side by side, next to the gases whose searches are still running
+        ecckd_gas_search& rq = gj.req;
+        std::memset(&rq, 0, sizeof rq);
+        rq.gas = gas; rq.nband = nmine; rq.ibegin = gj.ib.data(); rq.iend = gj.ie.data(); rq.heating_rate_tolerance = gj.tol.data();
+        rq.opt = gj.opts.data(); rq.ng = gj.ngs.data(); rq.bounds = gj.bounds.data(); rq.error = gj.error.data();
+        rq.rank1 = gj.r1.data(); rq.rank2 = gj.r2.data(); rq.capacity = band_capacity; rq.status = gj.statuses.data();
+        rq.comp_cost = gj.comp_costs.data();
+        if (!search_job) ck(ecckd_find_g_gases_begin(tolerance_tolerance, max_iterations, gases_side_by_side, &search_job));
+        ck(ecckd_find_g_gases_add(search_job, &rq));
+        if (gases_side_by_side == 1) flush();
       }
-      // the ranks of these bands as the searches left them (sub-bands and base splits re-rank inside a band)
-      ck(ecckd_synchronize(dev.ctx()));
-      for (size_t k = results.size() - (size_t)nmine; k < results.size(); ++k) {
-        BandResult& br = results[k];
-        br.rank_slice.resize((size_t)(br.iend - br.ibegin + 1));
-        ck(ecckd_d2h(dev.ctx(), br.rank_slice.data(), d_rank.as<int32_t>() + br.ibegin, br.rank_slice.size() * sizeof(int32_t)));
-      }
-      if (gas != first_lw_gas) ck(ecckd_gas_destroy(gas));
       LOG("\n");
     }
+    flush();
     if (first_lw_gas) ck(ecckd_gas_destroy(first_lw_gas));
     d_planck_rebuilt.release();
 

@@ -264,7 +264,9 @@ void* ecckd_stream(ecckd_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; 
 int ecckd_dev_alloc(ecckd_ctx* ctx, size_t bytes, void** d_ptr) {
   ECCKD_REQUIRE(ctx && d_ptr, "ecckd_dev_alloc: NULL argument");
   ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
-  ECCKD_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 1));
+  // through the context's caching allocator: a tool allocates the same nwav-sized arrays for gas after gas, and a hipFree
+  // waits for every stream of the device - with other gases' searches in flight (ecckd_find_g_gases_add) for milliseconds
+  ECCKD_HIP_CHECK(ecckd::dev_malloc(ctx, d_ptr, bytes ? bytes : 1));
   return ECCKD_OK;
 }
 
@@ -278,8 +280,8 @@ int ecckd_mem_info(ecckd_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
 int ecckd_dev_free(ecckd_ctx* ctx, void* d_ptr) {
   ECCKD_REQUIRE(ctx, "ecckd_dev_free: ctx is NULL");
   if (!d_ptr) return ECCKD_OK;
-  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  ECCKD_HIP_CHECK(hipFree(d_ptr));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));     // whatever still reads it on the context's stream
+  ecckd::dev_release(ctx, d_ptr);                         // parked for the next request of this size (ecckd_trim_cache frees)
   return ECCKD_OK;
 }
 

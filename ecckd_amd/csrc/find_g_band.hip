@@ -193,9 +193,14 @@ k_median_sorting(const long long* __restrict__ ind1, const long long* __restrict
   if (tid == 0) out[k] = sv[s_found != NONE ? s_found : i2];
 }
 
+// a temporary from the context's caching allocator (a hipFree would wait for every stream of the device, the other gases' searches
+// included)
 struct DevBuf {
+  ecckd_ctx* ctx = nullptr;
   void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  explicit DevBuf(ecckd_ctx* c) : ctx(c) {}
+  hipError_t alloc(size_t bytes) { return ecckd::dev_malloc(ctx, &p, bytes); }
+  ~DevBuf() { if (p) { (void)hipStreamSynchronize(ctx->stream); ecckd::dev_release(ctx, p); } }
 };
 
 }  // namespace
@@ -215,8 +220,8 @@ int ecckd_invert_permutation_dev(ecckd_ctx* ctx, size_t n, const int32_t* d_perm
   ECCKD_REQUIRE(ctx && (n == 0 || (d_perm && d_inverse)), "ecckd_invert_permutation_dev: NULL argument");
   if (n == 0) return ECCKD_OK;
   ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
-  DevBuf flag;
-  ECCKD_HIP_CHECK(hipMalloc(&flag.p, sizeof(int)));
+  DevBuf flag(ctx);
+  ECCKD_HIP_CHECK(flag.alloc(sizeof(int)));
   ECCKD_HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
   hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, d_perm, d_inverse,
                      (int*)flag.p);
@@ -240,10 +245,10 @@ int ecckd_regroup_rank_by_wavenumber_dev(ecckd_ctx* ctx, size_t nwav, const doub
   GroupBounds gb;
   gb.n = nsub;
   for (int q = 0; q <= nsub; ++q) gb.b[q] = h_wn_bound[q];
-  DevBuf key, newpos, count;
-  ECCKD_HIP_CHECK(hipMalloc(&key.p, m * sizeof(double)));
-  ECCKD_HIP_CHECK(hipMalloc(&newpos.p, m * sizeof(int32_t)));
-  ECCKD_HIP_CHECK(hipMalloc(&count.p, (MAX_GROUPS + 1) * sizeof(unsigned long long)));
+  DevBuf key(ctx), newpos(ctx), count(ctx);
+  ECCKD_HIP_CHECK(key.alloc(m * sizeof(double)));
+  ECCKD_HIP_CHECK(newpos.alloc(m * sizeof(int32_t)));
+  ECCKD_HIP_CHECK(count.alloc((MAX_GROUPS + 1) * sizeof(unsigned long long)));
   ECCKD_HIP_CHECK(hipMemsetAsync(count.p, 0, (MAX_GROUPS + 1) * sizeof(unsigned long long), ctx->stream));
   // a rank that is not a permutation leaves holes: fill with the "no group" key so they are counted
   const unsigned eblocks = (unsigned)((nwav + 255) / 256);
