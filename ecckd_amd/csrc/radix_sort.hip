@@ -218,6 +218,131 @@ k_sort_scatter(size_t n, int shift, const unsigned long long* __restrict__ skey_
   }
 }
 
+// (3') the same scatter with the tile put in order in LDS first.  In (3) every lane stores its own element straight to its
+// final position: a wave's 64 consecutive inputs go to up to 64 different buckets, so a tile of 4096 keys is written as 2 x 4096
+// stores that each touch one cache line for 8 (4) bytes.  Here the block first places its elements at their rank WITHIN the tile
+// (digit-major, input order inside a digit: the same stable order) in LDS, then consecutive threads copy consecutive LDS entries
+// out: the ~16 keys a bucket receives from a tile leave as one 128-byte run (64 bytes of indices), 16 times fewer write
+// transactions.  The position of every element is the one (3) computes; the output is identical bit for bit.
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_scatter_lds(size_t n, int shift, const unsigned long long* __restrict__ skey_in,
+                   const unsigned* __restrict__ sidx_in, unsigned long long* __restrict__ skey_out,
+                   unsigned* __restrict__ sidx_out, const unsigned* __restrict__ tile_offs,
+                   unsigned ntiles, const unsigned* __restrict__ digit_total, SegTable st) {
+  __shared__ unsigned long long s_key[SORT_TILE];
+  __shared__ unsigned s_idx[SORT_TILE];
+  __shared__ unsigned s_cnt[SORT_WAVES][RADIX];  // per-wave digit counts, then running LOCAL offsets
+  __shared__ unsigned s_gbase[RADIX];            // global position of the tile's first element of a digit
+  __shared__ unsigned s_lstart[RADIX];           // its position in the tile's digit-major order
+  __shared__ unsigned s_scan[RADIX];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  for (int w = 0; w < SORT_WAVES; ++w) s_cnt[w][tid] = 0;
+  unsigned dig_excl;
+  {
+    // exclusive scan of 256 digit totals: wave scan + 4 wave carries
+    const unsigned v0 = digit_total[tid];
+    unsigned x = v0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    s_scan[tid] = x;  // inclusive within the wave
+    __syncthreads();
+    unsigned woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_scan[w * 64 + 63];
+    dig_excl = woff + x - v0;
+  }
+  __syncthreads();
+
+  const size_t tile_base = (size_t)blockIdx.x * SORT_TILE;
+  const size_t wave_base = tile_base + (size_t)wave * (SORT_ITEMS * 64);
+  unsigned long long k[SORT_ITEMS];
+  unsigned v[SORT_ITEMS];
+#pragma unroll
+  for (int c = 0; c < SORT_ITEMS; ++c) {
+    size_t i = wave_base + (size_t)c * 64 + lane;
+    bool valid = i < n;
+    k[c] = valid ? skey_in[i] : ~0ull;
+    v[c] = valid ? sidx_in[i] : 0u;
+    if (valid) atomicAdd(&s_cnt[wave][digit_of(k[c], v[c], shift, st)], 1u);
+  }
+  __syncthreads();
+  // thread `tid` owns digit `tid`: the tile's count of it, the exclusive scan of those counts over the digits (the tile's
+  // digit-major order), per-wave local start offsets
+  {
+    unsigned cw[SORT_WAVES];
+    unsigned tot = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) { cw[w] = s_cnt[w][tid]; tot += cw[w]; }
+    unsigned x = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    s_scan[tid] = x;
+    __syncthreads();
+    unsigned woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_scan[w * 64 + 63];
+    const unsigned lstart = woff + x - tot;
+    s_lstart[tid] = lstart;
+    s_gbase[tid] = dig_excl + tile_offs[(size_t)tid * ntiles + blockIdx.x];
+    unsigned run = lstart;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) {
+      s_cnt[w][tid] = run;
+      run += cw[w];
+    }
+  }
+  __syncthreads();
+
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int c = 0; c < SORT_ITEMS; ++c) {
+    size_t i = wave_base + (size_t)c * 64 + lane;
+    bool valid = i < n;
+    unsigned d = digit_of(k[c], v[c], shift, st);
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < RADIX_BITS; ++b) {
+      unsigned long long vote = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? vote : ~vote;
+    }
+    unsigned rank = (unsigned)__popcll(peers & lt_mask);
+    unsigned count = (unsigned)__popcll(peers);
+    volatile unsigned* wcnt = s_cnt[wave];
+    unsigned start = 0;
+    if (valid) start = wcnt[d];
+    // all peers have read the running offset before the last peer bumps it:
+    // LDS operations of one wave execute in issue order.
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == count - 1) wcnt[d] = start + count;
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      const unsigned lpos = start + rank;
+      s_key[lpos] = k[c];
+      s_idx[lpos] = v[c];
+    }
+  }
+  __syncthreads();
+  const unsigned nvalid = (unsigned)((n - tile_base) < (size_t)SORT_TILE ? (n - tile_base) : (size_t)SORT_TILE);
+#pragma unroll
+  for (int it = 0; it < SORT_ITEMS; ++it) {
+    const unsigned i = (unsigned)it * SORT_THREADS + tid;
+    if (i < nvalid) {
+      const unsigned long long kk = s_key[i];
+      const unsigned vv = s_idx[i];
+      const unsigned d = digit_of(kk, vv, shift, st);
+      const size_t pos = (size_t)s_gbase[d] + (i - s_lstart[d]);
+      skey_out[pos] = kk;
+      sidx_out[pos] = vv;
+    }
+  }
+}
+
 // final: ordered_index[off+i] = idx[i]; rank[idx[i]] = off+i  (reorder_spectrum.cpp:297-300)
 __global__ void __launch_bounds__(256)
 k_sort_finish(size_t off, size_t n, const unsigned* __restrict__ sidx, int32_t* __restrict__ rank,
@@ -278,6 +403,7 @@ extern "C" int ecckd_stable_argsort_bands_dev(ecckd_ctx* ctx, size_t nwav, const
 
   SegTable none;
   std::memset(&none, 0, sizeof none);
+  const bool direct = std::getenv("ECCKD_SORT_DIRECT") != nullptr;     // A/B knob: every lane stores to its final position itself
   // several bands, ascending and disjoint (reorder_spectrum.cpp:277-289 builds them so): one nine-pass sort of the whole
   // spectrum instead of one eight-pass sort per band
   bool one_sort = nband > 1 && 2 * nband + 1 <= MAX_SEG && std::getenv("ECCKD_SORT_PER_BAND") == nullptr;
@@ -318,8 +444,12 @@ extern "C" int ecckd_stable_argsort_bands_dev(ecckd_ctx* ctx, size_t nwav, const
       const int shift = pass * RADIX_BITS;      // the last one, 64: by segment
       hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, ks[cur], is[cur], st, hs, ntiles);
       hipLaunchKernelGGL(k_sort_scan_rows, dim3(RADIX), dim3(256), 0, ctx->stream, hs, ntiles, dt);
-      hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, ks[cur], is[cur], ks[cur ^ 1],
-                         is[cur ^ 1], hs, ntiles, dt, st);
+      if (direct)
+        hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, ks[cur], is[cur], ks[cur ^ 1],
+                           is[cur ^ 1], hs, ntiles, dt, st);
+      else
+        hipLaunchKernelGGL(k_sort_scatter_lds, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, ks[cur], is[cur], ks[cur ^ 1],
+                           is[cur ^ 1], hs, ntiles, dt, st);
       cur ^= 1;
     }
     hipLaunchKernelGGL(k_sort_finish, dim3(eblocks), dim3(256), 0, ctx->stream, (size_t)0, n, is[cur], d_rank, d_ordered_index);
@@ -340,8 +470,12 @@ extern "C" int ecckd_stable_argsort_bands_dev(ecckd_ctx* ctx, size_t nwav, const
       hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift, keys[cur], idxs[cur], none,
                          hist, ntiles);
       hipLaunchKernelGGL(k_sort_scan_rows, dim3(RADIX), dim3(256), 0, ctx->stream, hist, ntiles, digit_total);
-      hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift,
-                         keys[cur], idxs[cur], keys[cur ^ 1], idxs[cur ^ 1], hist, ntiles, digit_total, none);
+      if (direct)
+        hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift,
+                           keys[cur], idxs[cur], keys[cur ^ 1], idxs[cur ^ 1], hist, ntiles, digit_total, none);
+      else
+        hipLaunchKernelGGL(k_sort_scatter_lds, dim3(ntiles), dim3(SORT_THREADS), 0, ctx->stream, n, shift,
+                           keys[cur], idxs[cur], keys[cur ^ 1], idxs[cur ^ 1], hist, ntiles, digit_total, none);
       cur ^= 1;
     }
     hipLaunchKernelGGL(k_sort_finish, dim3(eblocks), dim3(256), 0, ctx->stream, off, n, idxs[cur], d_rank,

@@ -32,14 +32,27 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-NWAV = 1 << 22
-NLAY = 30
 import os
-# heating-rate tolerance (K/d).  0.0161 (the fsck tolerance of test/do_all_lw.sh:59-60): converges with 33 g points after 1 639
-# requests, ~4 min with the two oracle-driven searches; ECCKD_AUDIT_TOL=0.013 is the regime of the headline bench - the search
-# runs into its 60 iterations (status 2) after 13 422 requests - and takes the oracle ~15 min: run by hand, result committed as
-# profiles/r03_decision_trace_tol0.013.txt
-TOL = float(os.environ.get("ECCKD_AUDIT_TOL", "0.0161"))
+# The cases (points, layers, heating-rate tolerance in K/d, expected status of the device-driven search, the multiple of the
+# stated tolerance rtol 1e-9 + 1e-10 K/d within which the oracle over the DEVICE's rows must reproduce the device's errors):
+#  * 2^22 points, 30 layers, 0.0161 (the fsck tolerance of test/do_all_lw.sh:59-60): converges with 33 g points after 1 639
+#    requests, ~4 min with the two oracle-driven searches - the k_rt_lw_bb_mirror<30,...> sweep;
+#  * 54 layers - the <54,...> kernels the bench times - in the regime the headline bench's searches end in: the search runs
+#    into its 60 iterations (status 2, "Maximum iterations reached").  In the suite: 2^19 points at 0.04 K/d (2 946 requests,
+#    ~1 min; device- and oracle-driven searches part at an index rounding 1 783 requests in - two bounds 2.6e-4 index steps
+#    apart on either side of an integer - and end at the same 18 g points).  Run by hand and committed
+#    (profiles/r04_decision_trace_54layers_2e20_status2.txt, ECCKD_AUDIT_CASE=1048576,54,0.0161,2, 4.4 min): 2^20 points at the
+#    fsck tolerance, 15 243 requests, 43 207 intervals, 38 721 comparisons - device- and oracle-driven searches take the SAME
+#    decisions throughout and end at the same 37 g points, the oracle over the device's rows reproduces the errors to 3e-12.
+#    (Round 3 at 2^22 points, 30 layers and 0.013 K/d, by hand: profiles/r03_decision_trace_tol0.013.txt.)
+# ECCKD_AUDIT_CASE=nwav,nlay,tol[,status] runs another case by hand.
+CASES = [
+    pytest.param(1 << 22, 30, 0.0161, 0, 1.0, id="2^22 points, 30 layers, converging"),
+    pytest.param(1 << 19, 54, 0.04, 2, 1.0, id="2^19 points, 54 layers, 60 iterations reached"),
+]
+if os.environ.get("ECCKD_AUDIT_CASE"):
+    _c = os.environ["ECCKD_AUDIT_CASE"].split(",")
+    CASES = [pytest.param(int(_c[0]), int(_c[1]), float(_c[2]), int(_c[3]) if len(_c) > 3 else None, 1.0, id="by hand")]
 TOL_TOL = 0.01          # tolerance_tolerance of test/find_g_points_lw.sh
 MAX_IT = 60
 
@@ -58,7 +71,9 @@ def _margin(lhs, rhs):
     return abs(lhs - rhs) / s if s > 0 else 0.0
 
 
-def test_first_divergence_of_device_and_oracle_searches_is_a_knife_edge(ctx, oracle, monkeypatch, capsys):
+@pytest.mark.parametrize("NWAV,NLAY,TOL,expected_status,same_rows_multiple", CASES)
+def test_first_divergence_of_device_and_oracle_searches_is_a_knife_edge(ctx, oracle, monkeypatch, capsys, NWAV, NLAY, TOL, expected_status,
+                                                                        same_rows_multiple):
     from ecckd_amd import api, synthetic as syn
     monkeypatch.setenv("ECCKD_NO_ERROR_MEMO", "1")                  # every request evaluated, none answered from the memo
     dev = ctx.device
@@ -176,11 +191,17 @@ def test_first_divergence_of_device_and_oracle_searches_is_a_knife_edge(ctx, ora
     d_hr, d_planck = gas.view("hr"), gas.view("planck_hl")
     d_fds, d_fut = gas.view("flux_dn_surf")[0].copy(), gas.view("flux_up_toa")[0].copy()
     hr_scale = np.abs(hr).max(axis=1, keepdims=True)
+    # the boundary fluxes against the scale they live on, the column's surface Planck flux: on a near-transparent column the
+    # downwelling flux at the surface is a sum of emissions of ~1e-8 of that scale, each the difference 1 - exp(-x) of nearly
+    # equal numbers, and its RELATIVE difference between two correct evaluations reaches 4e-8 although nothing differs by more
+    # than a rounding of the scale
     prep_diff = dict(planck=float(np.max(np.abs(d_planck - planck) / np.maximum(np.abs(planck), 1e-300))),
                      hr_rel_to_layer_max=float(np.max(np.abs(d_hr - hr) / hr_scale)),
                      hr_layer_sums_rel=float(np.max(np.abs(d_hr.sum(1) - hr.sum(1)) / np.maximum(np.abs(hr.sum(1)), 1e-300))),
                      flux_dn_surf=float(np.max(np.abs(d_fds - fds) / np.maximum(np.abs(fds), 1e-300))),
-                     flux_up_toa=float(np.max(np.abs(d_fut - fut) / np.maximum(np.abs(fut), 1e-300))))
+                     flux_dn_surf_rel_to_surface_planck=float(np.max(np.abs(d_fds - fds) / np.maximum(surf_planck, 1e-300))),
+                     flux_up_toa=float(np.max(np.abs(d_fut - fut) / np.maximum(np.abs(fut), 1e-300))),
+                     flux_up_toa_rel_to_surface_planck=float(np.max(np.abs(d_fut - fut) / np.maximum(surf_planck, 1e-300))))
     eq_dev = oracle.CkdEquipartitionLW("transmission", 0.0, oracle.layer_weight(p, 0.0), p, np.ones(n), d_planck[-1].copy(), d_fds, d_fut,
                                        d_planck, bg_s, metric, d_hr)
     reqs = [(ev[1][k], ev[2][k], ev[3][k]) for ev in ev_a if ev[0] == "req" for k in range(len(ev[1]))]
@@ -189,6 +210,7 @@ def test_first_divergence_of_device_and_oracle_searches_is_a_knife_edge(ctx, ora
     same_rows = list(pool.map(lambda r: eq_dev.calc_error(r[0], r[1]), sample))
     # (stated tolerance of the interval errors: rtol 1e-9 + 1e-10 K/d, tests/test_find_g_gpu.py)
     worst_same_rows = max(abs(a - r[2]) / (abs(r[2]) + 0.1) for a, r in zip(same_rows, sample))
+    worst_same_rows_tol = max(abs(a - r[2]) / (1e-9 * abs(r[2]) + 1e-10) for a, r in zip(same_rows, sample))
     del d_hr, d_planck, eq_dev
     gas.close()
     pool.shutdown()
@@ -279,8 +301,8 @@ def test_first_divergence_of_device_and_oracle_searches_is_a_knife_edge(ctx, ora
         print("[decision trace] index roundings of run A within 1e-6 / 1e-4 / 1e-2 of an integer: %d / %d / %d of %d" % (*near, fr.size))
         print("[decision trace] the two preparations (device K4 vs oracle), max rel. difference: " +
               ", ".join("%s %.2e" % kv for kv in prep_diff.items()))
-        print("[decision trace] interval errors, oracle over the DEVICE's rows vs device: max rel. difference %.2e (%d sampled requests)"
-              % (worst_same_rows, len(sample)))
+        print("[decision trace] interval errors, oracle over the DEVICE's rows vs device: max difference %.2e of (|error| + 0.1 K/d) = %.2f x "
+              "the stated tolerance (rtol 1e-9 + 1e-10 K/d) (%d sampled requests)" % (worst_same_rows, worst_same_rows_tol, len(sample)))
         print("[decision trace] interval errors, device vs oracle over its OWN rows: max rel. difference %.2e, max abs. %.2e K/d, "
               "%.2f x the stated tolerance (rtol 1e-9 + 1e-10 K/d) over the requests with identical index ranges; %.2e rel. after the "
               "ranges began to differ (largest shift %d points)"
@@ -296,14 +318,19 @@ def test_first_divergence_of_device_and_oracle_searches_is_a_knife_edge(ctx, ora
 
     # ---- the assertions ----
     assert nreq > 200 and aligned_req > 50
+    if expected_status is not None:
+        assert st_a == expected_status, "the device-driven search ended with status %d" % st_a
+    # the two preparations of the gas (device K4, oracle) agree to rounding on the scale of every quantity
+    assert prep_diff["planck"] <= 1e-11 and prep_diff["hr_rel_to_layer_max"] <= 1e-11
+    assert prep_diff["flux_dn_surf_rel_to_surface_planck"] <= 2e-12 and prep_diff["flux_up_toa_rel_to_surface_planck"] <= 2e-12
     # same rows in, same error out: the stated tolerance (rtol 1e-9 + 1e-10 K/d) holds on the converging searches (3e-11
     # measured); the non-converging one asks for intervals of a few points of the most opaque end of the spectrum, where the
     # transmission fit takes -ln(1 - mean) of a mean within 1e-16 of one (average_optical_depth.cpp:43-133, find_g_points.cpp:
     # 64-68): 2.4e-9 measured there
-    assert worst_same_rows <= 1e-8
+    assert worst_same_rows_tol <= same_rows_multiple, "%.2f x the stated tolerance" % worst_same_rows_tol
     # two independent preparations: the large RELATIVE differences (4e-5 ... 1e-4) sit on intervals whose error is ~1e-6 K/d
     # (nothing absorbs there); in K/d the two never differ by more than 2e-8 (north_star's heating-rate tolerance: 1e-6 K/d)
-    assert worst_abs_identical <= 1e-7
+    assert worst_abs_identical <= 2e-8
     if first_index_flip is not None:
         pos, k, xa, xb = first_index_flip
         # a knife edge: the two bounds agree to a small fraction of an index step yet round to different integers

@@ -327,22 +327,26 @@ def test_full_size_find_g_against_oracle_slices(ctx, oracle):
     assert np.all(np.isfinite(e_all)) and np.all(e_all > 0)
 
     gas.close()
-    # (d) the band search of the bench workload (flux_weight 0 as test/find_g_points_lw.sh): converges, and the errors it
-    # reports are those of its final intervals
+    # (d) the band search of round 3's bench workload (flux_weight 0 as test/find_g_points_lw.sh; bench.py's `single_gas` leg).
+    # On these spectra it does NOT converge: it runs into its 60 iterations (status 2, "Maximum iterations reached") with 38 g
+    # points.  The outcome is pinned: the status, the number of g points, and - element by element - the bounds and
+    # the errors that the REFERENCE's own equipartition.cpp (oracle/_ref) returns when it is driven over the device's interval
+    # errors one call at a time as the reference drives calc_error: after a failed line search the error array holds the
+    # errors of the LAST TRIAL bounds, not of the bounds returned (equipartition.cpp:207-210) - that, too, must be reproduced.
     gas = api.GasLW(ctx, p, t_hl, wn, dwn, rank, od, bg, "transmission", flux_weight=0.0)
     st, b, e, cc = gas.find_g_band(0, nwav - 1, 0.0161, 0.01, 60)
-    assert st in (0, 1, 2) and len(e) >= 20 and b[0] == 0.0 and b[-1] == 1.0 and np.all(np.diff(b) > 0)   # 1 / 2: iterations ran out / no convergence
+    assert st == 2 and len(e) == 38 and b[0] == 0.0 and b[-1] == 1.0 and np.all(np.diff(b) > 0)
     assert np.all(np.isfinite(e)) and np.all(e > 0) and cc > len(e)
+    assert abs(float(np.sum(e)) - 0.5853104621649818) <= 1e-9        # the final cost bench.py has printed since round 2
+    assert e.max() <= 0.0161 * 2.0
     final = gas.calc_error_batch(0, nwav, b[:-1], b[1:])
-    if st == 0:
-        assert e[:-1].max() <= 0.0161 * 1.0101
-        assert np.allclose(final, e, rtol=1e-12, atol=0)     # the errors it returns are those of its final intervals
-    else:
-        # not converged: every g point within a factor of the tolerance; the error array is the reference's - after a failed
-        # line search it holds the errors of the LAST TRIAL bounds, not of the bounds returned (equipartition.cpp:207-210,
-        # partition_search.cpp parity notes) - so only most entries are those of the final intervals
-        assert e.max() <= 0.0161 * 2.0 and final.max() <= 0.0161 * 2.0
-        assert np.mean(np.isclose(final, e, rtol=1e-12, atol=0)) > 0.5
+    assert final.max() <= 0.0161 * 2.0
+    if oracle.ref_lib() is not None:
+        ref = oracle.RefEquipartition(lambda x, y: gas.calc_error_batch(0, nwav, [x], [y])[0], resolution=1.0 / nwav,
+                                      partition_tolerance=0.01, partition_max_iterations=60)
+        st_r, b_r, e_r = ref.equipartition_e(0.0161)
+        assert st_r == st and np.array_equal(b_r, b) and np.array_equal(e_r, e)
+        del ref
     gas.close()
 
 

@@ -1,4 +1,14 @@
-"""BASELINE configs[2], configs[3] and configs[4] at full size (the oracle cannot run them whole in seconds; it replays windows).
+"""BASELINE configs[1], configs[2], configs[3] and configs[4] at full size (the oracle cannot run them whole in seconds; it replays
+windows).
+
+configs[1]: the six-gas FSCK job of bench.py's headline (ecckd_amd/fsck_job.py) at nwav = 7.2e6, nlay = 54: every gas has a
+background merged in double from 2-5 spectra, so its sweep is k_rt_lw_bb_mirror<54, false> over DOUBLE rows (872 B per point).
+Checked for co2 (five background spectra, two of them scaled by background_conc / reference mole fraction): (a) the merged
+background rows bit for bit against the double sum of read_merged_spectrum.cpp:135-166 done by numpy on windows of the raw
+spectra; (b) the preparation of those windows against the oracle's own (Planck from the FIRST gas's ordering, as
+find_g_points.cpp:529, :970-984 reuses it); (c) interval errors of a range deep inside the spectrum from the device's rows
+and from rows the oracle prepared itself; (d) the same bits alone, with neighbours, in another order; (e) the job side by side
+and gas after gas: same g points, same errors, same merged map.
 
 configs[3]: one find_g_points job over the 13 narrow longwave bands at nwav = 7.2e6, nlay = 54, all eight gases of
 bench.py --config 3 (composite, h2o, o3, co2, ch4, n2o and the two CFC-scale absorbers), through the resident-data driver that
@@ -31,6 +41,100 @@ ERR_RTOL = 1e-9
 class _DevView:
     def __init__(self, ptr, rows, cols):
         self.__cuda_array_interface__ = {"shape": (rows, cols), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def test_config1_six_gases_merged_double_backgrounds_full_size(ctx, oracle):
+    from ecckd_amd import api, fsck_job, pipeline
+    nwav, nlay = 7_200_000, 54
+    dev = ctx.device
+    job = fsck_job.FsckJob(ctx, nwav, nlay, ngas=6)
+    p, wn_h, dwn_h, t_hl = job.p, job.wn_h, job.dwn_h, job.t_file
+    gi = job.names.index("co2")
+    # the first gas lends its Planck matrix (in ITS ordering) to every later gas
+    g0 = job.load_gas(0)
+    gas0, _, _ = pipeline._prepare_gas(ctx, g0, "transmission", 0.0, 0.0, None, None)
+    ireorder0 = api.invert_permutation(ctx, g0["rank"]).long()
+    g = job.load_gas(gi)
+    gas, _, _ = pipeline._prepare_gas(ctx, g, "transmission", 0.02, 0.0, gas0.view_ptr("planck_hl")[0], None)
+    assert gas.sweep_bytes_per_point() == (2 * nlay + 1) * 8.0          # DOUBLE background rows
+    ireorder = api.invert_permutation(ctx, g["rank"]).long()
+    view = lambda h, name: torch.as_tensor(_DevView(*h.view_ptr(name)), device=dev)
+    planck_d, bg_d, hr_d, w1_d = view(gas, "planck_hl"), view(gas, "bg_optical_depth"), view(gas, "hr"), view(gas, "weighted_metric")
+    fds_d, fut_d = view(gas, "flux_dn_surf"), view(gas, "flux_up_toa")
+    target = job.od[job.gases[gi][1]]
+
+    def merged_window(idx):
+        bg = None
+        for name, conc in job.gases[gi][2]:
+            ref = fsck_job.SPECTRA[name][2]
+            sp, _ = api.merge_scaling(p, conc=conc, reference_surface_vmr=ref if ref is not None else -1.0)
+            term = job.od[name][:, idx].double().cpu().numpy() * np.asarray(sp)[:, None]
+            bg = term if bg is None else bg + term
+        return bg
+
+    def window(i1, n):
+        idx = ireorder[i1:i1 + n]
+        idx0 = ireorder0[i1:i1 + n].cpu().numpy()                # the FIRST gas's ordering: whose wavenumbers its Planck rows hold
+        return target[:, idx].double().cpu().numpy(), merged_window(idx), wn_h[idx0], dwn_h[idx0]
+
+    conv = (9.80665 / 1004.0) / np.diff(p)
+    for i1 in (0, 3_333_333, nwav - 4096):
+        od_s, bg_s, wn_s, dwn_s = window(i1, 4096)
+        sl = slice(i1, i1 + 4096)
+        assert np.array_equal(bg_d[:, sl].cpu().numpy(), bg_s)                          # (a) the merged rows, bit for bit
+        planck = oracle.planck_function(t_hl, wn_s, dwn_s)                              # (b)
+        assert np.allclose(planck_d[:, sl].cpu().numpy(), planck, rtol=1e-11, atol=0)
+        fdn, fup = oracle.radiative_transfer_lw(planck, bg_s + od_s, np.ones(4096), planck[-1])
+        hr = oracle.heating_rate(p, fdn, fup)
+        tol = 1e-9 * np.abs(hr).max(axis=0, keepdims=True) + 1e-13 * conv[:, None] * fup[0][None, :]
+        assert np.all(np.abs(hr_d[:, sl].cpu().numpy() - hr) <= tol)
+        assert np.all(np.abs(fds_d[0, sl].cpu().numpy() - fdn[-1]) <= 1e-10 * np.abs(fdn[-1]) + 1e-13 * planck[-1])
+        assert np.allclose(fut_d[0, sl].cpu().numpy(), fup[0], rtol=1e-10)
+        assert np.allclose(w1_d[:, sl].cpu().numpy(), oracle.metric("transmission", od_s) * planck[1:], rtol=1e-11, atol=1e-300)
+
+    # (c) interval errors of a range deep inside the spectrum: the <54, false> sweep over the DOUBLE rows
+    i1, n = 2_987_123, 20_000
+    sl = slice(i1, i1 + n)
+    od_w, bg_w, wn_w, dwn_w = window(i1, n)
+    pl = planck_d[:, sl].cpu().numpy()
+    eq = oracle.CkdEquipartitionLW("transmission", 0.02, oracle.layer_weight(p, 0.0), p, np.ones(n), pl[-1], fds_d[0, sl].cpu().numpy(),
+                                   fut_d[0, sl].cpu().numpy(), pl, bg_d[:, sl].cpu().numpy(), oracle.metric("transmission", od_w),
+                                   hr_d[:, sl].cpu().numpy())
+    b1 = np.array([0.0, 0.2, 0.55, 0.9, 0.0])
+    b2 = np.array([0.2, 0.55, 0.9, 1.0, 1.0])
+    err = gas.calc_error_batch(i1, n, b1, b2)
+    ref = np.array([eq.calc_error(x, y) for x, y in zip(b1, b2)])
+    assert np.allclose(err, ref, rtol=ERR_RTOL, atol=1e-12)
+    planck_w = oracle.planck_function(t_hl, wn_w, dwn_w)
+    fdn_w, fup_w = oracle.radiative_transfer_lw(planck_w, bg_w + od_w, np.ones(n), planck_w[-1])
+    eq_own = oracle.CkdEquipartitionLW("transmission", 0.02, oracle.layer_weight(p, 0.0), p, np.ones(n), planck_w[-1], fdn_w[-1].copy(),
+                                       fup_w[0].copy(), planck_w, bg_w, oracle.metric("transmission", od_w),
+                                       oracle.heating_rate(p, fdn_w, fup_w))
+    ref_own = np.array([eq_own.calc_error(x, y) for x, y in zip(b1, b2)])
+    assert np.all(np.abs(err - ref_own) <= 1e-9 * np.abs(ref_own) + 1e-10)
+
+    # (d) the whole band: the same bits alone, with neighbours, in another order
+    e_all = gas.calc_error_batch(0, nwav, [0.0, 0.3, 0.7], [0.3, 0.7, 1.0])
+    e_rev = gas.calc_error_batch(0, nwav, [0.7, 0.0, 0.3], [1.0, 0.3, 0.7])
+    e_one = np.array([gas.calc_error_batch(0, nwav, [a], [b])[0] for a, b in ((0.0, 0.3), (0.3, 0.7), (0.7, 1.0))])
+    assert np.array_equal(e_all, e_one) and np.array_equal(e_all, e_rev[[1, 2, 0]])
+    assert np.all(np.isfinite(e_all)) and np.all(e_all > 0)
+    gas.close()
+    gas0.close()
+    del planck_d, bg_d, hr_d, w1_d, fds_d, fut_d, g, g0
+
+    # (e) the job: side by side = gas after gas
+    a = job.run(0.0161, 0.01, 60, gases_side_by_side=0)
+    b = job.run(0.0161, 0.01, 60, gases_side_by_side=1)
+    job.close()
+    assert a["ng"] == b["ng"] and a["cost_sum"] == b["cost_sum"] and a["points"] == b["points"] and a["n_unassigned"] == b["n_unassigned"] == 0
+    assert torch.equal(a["g_point"], b["g_point"])
+    for ga, gb in zip(a["gases"], b["gases"]):
+        assert ga["rank1"] == gb["rank1"] and ga["rank2"] == gb["rank2"] and ga["error"] == gb["error"] and ga["status"] == gb["status"]
+    # every wavenumber in exactly one g point of every gas, the g points of a gas cover its ranks without gaps
+    for ga in a["gases"]:
+        r1, r2 = np.asarray(ga["rank1"]), np.asarray(ga["rank2"])
+        assert r1[0] == 0 and r2[-1] == nwav - 1 and np.array_equal(r1[1:], r2[:-1] + 1)
 
 
 def test_config3_thirteen_bands_full_size(ctx, oracle):

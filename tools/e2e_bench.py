@@ -239,7 +239,12 @@ def cpu_chain(ctx, d, inp):
     o.build()
     L = o.lib()
     P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-    p1, wn, dwn, nlay, nwav, names = inp["p1"], inp["wn"], inp["dwn"], inp["nlay"], inp["nwav"], inp["names"]
+    p1, wn, nlay, nwav, names = inp["p1"], inp["wn"], inp["nlay"], inp["nwav"], inp["names"]
+    # the spectra files carry no d_wavenumber: every tool derives it from the grid as read_spectrum.cpp:55-65 does - half the
+    # distance between a point's neighbours, and HALF of its neighbour's value at the two ends - and so does the oracle chain
+    dwn = np.empty(nwav)
+    dwn[1:-1] = 0.5 * (wn[2:] - wn[:-2])
+    dwn[0], dwn[-1] = 0.5 * dwn[1], 0.5 * dwn[-2]
     b1, b2 = bands()
     nband = len(b1)
     t_hl = np.ascontiguousarray(inp["t0"])
@@ -338,9 +343,16 @@ def cpu_chain(ctx, d, inp):
     model["wavenumber2"] = 10.0 * np.arange(1, 327, dtype=np.float64)
     model["gpoint_fraction"] = o.gpoint_fraction(ng, g_point, wn, dwn, model["wavenumber1"], model["wavenumber2"])
     secs["create_look_up_table"] = time.perf_counter() - t0
-    raw = dict(model, gases=[dict(g, **{k: np.asarray(g[k]).astype(np.float32).astype(np.float64) for k in ("molar_abs", "min_molar_abs", "max_molar_abs")})
+    # The raw model reaches optimize_lut and run_ckd through the CKD-definition FILE, whose tables, temperatures, pressures and
+    # mole fractions are FLOAT variables (CkdModel::write, ckd_model.cpp:318-326, :352, :418-445; read back by CkdModel::read,
+    # :32-286): the oracle chain rounds where the file rounds
+    f32 = lambda a: np.asarray(a).astype(np.float32).astype(np.float64)
+    raw = dict(model, gases=[dict(g, **{k: f32(g[k]) for k in ("molar_abs", "min_molar_abs", "max_molar_abs", "vmr") if k in g})
                              for g in model["gases"]])
-    raw["planck_function"] = model["planck_function"].astype(np.float32).astype(np.float64)
+    raw["planck_function"] = f32(model["planck_function"])
+    raw["temperature"] = f32(model["temperature"])
+    raw["log_pressure"] = np.log(f32(np.exp(model["log_pressure"])))
+    raw["temperature_planck"] = f32(model["temperature_planck"])
 
     # ---- optimize_lut (optimize_lut.cpp:60-330): the library's L-BFGS over the oracle's cost function and gradient ----
     t0 = time.perf_counter()
@@ -370,13 +382,42 @@ def cpu_chain(ctx, d, inp):
     # ---- run_ckd (run_ckd.cpp:27-373) on the evaluation profiles ----
     t0 = time.perf_counter()
     ev = dict(pressure_hl=np.tile(p1, (inp["ncol"], 1)), temperature_hl=inp["T"], vmr_fl=inp["vmr"], gas_present=None)
-    out = {"iterations": res["iterations"], "status": res["status"], "ng": ng, "g_point": g_point, "per_gas": per_gas}
+    out = {"iterations": res["iterations"], "status": res["status"], "ng": ng, "g_point": g_point, "per_gas": per_gas,
+           "models": {"raw": raw, "optimised": optimised}, "cfg": cfg}
     for tag, m in (("raw", raw), ("optimised", optimised)):
         oo = ckd_synth.Oracle(o, m, [ev], cfg)
         f = oo.fluxes(oo.x0, ev)                              # (ncol, 2, nhl, ng)
-        out[tag] = (f[:, 0].sum(-1), f[:, 1].sum(-1))
+        out[tag] = (f32(f[:, 0].sum(-1)), f32(f[:, 1].sum(-1)))   # FLOAT in run_ckd's file (run_ckd.cpp:221-230)
     secs["run_ckd"] = time.perf_counter() - t0
     return secs, out
+
+
+def oracle_fluxes_of_model(model, inp, cfg):
+    """Broadband fluxes (DOUBLE, in memory) of the evaluation profiles from a CKD model by the oracle's evaluator (oracle_ckd.c):
+    what run_ckd computes before it writes its FLOAT file (run_ckd.cpp:221-230, :355-356)."""
+    import pyoracle as o
+    import ckd_synth
+    ev = dict(pressure_hl=np.tile(inp["p1"], (inp["ncol"], 1)), temperature_hl=inp["T"], vmr_fl=inp["vmr"], gas_present=None)
+    oo = ckd_synth.Oracle(o, model, [ev], cfg)
+    f = oo.fluxes(oo.x0, ev)
+    return f[:, 0].sum(-1), f[:, 1].sum(-1)
+
+
+def compare_models(a, b):
+    """Table by table: how many coefficients of two CKD models differ and by how much (relative), and which one differs most."""
+    out = {}
+    for ga, gb in zip(a["gases"], b["gases"]):
+        ka, kb = np.asarray(ga["molar_abs"], dtype=np.float64), np.asarray(gb["molar_abs"], dtype=np.float64)
+        if ka.shape != kb.shape:
+            out[ga["name"]] = {"shapes": [list(ka.shape), list(kb.shape)]}
+            continue
+        rel = np.abs(ka - kb) / np.maximum(np.maximum(np.abs(ka), np.abs(kb)), 1e-300)
+        rel[(ka == 0) & (kb == 0)] = 0.0
+        worst = np.unravel_index(int(np.argmax(rel)), rel.shape)
+        out[ga["name"]] = {"coefficients": int(ka.size), "different": int((ka != kb).sum()), "max_relative_difference": float(rel.max()),
+                           "worst_index_(conc,)temperature,pressure,g": [int(v) for v in worst],
+                           "different_by_more_than_1e-6": int((rel > 1e-6).sum())}
+    return out
 
 
 SIZE_STAGES = ("reorder_spectrum", "find_g_points", "create_look_up_table")      # work proportional to nwav
@@ -457,11 +498,23 @@ def run(ctx, nwav=7_200_000, nlay=54, cpu_nwav=(1 << 17, 1 << 18), workdir=None,
                 hr_t = {k: hr_k_per_day(p1, *s_out[k]) for k in ("raw", "optimised")}
                 hr_c = {k: hr_k_per_day(p1, *c_out[k]) for k in ("raw", "optimised")}
                 hr_l = hr_k_per_day(p1, inp_n["bdn"].sum(-1), inp_n["bup"].sum(-1))
+                # ... and in DOUBLE: run_ckd's file holds FLOAT fluxes (run_ckd.cpp:221-230) - 3e-5 W m-2 of rounding on a 400 W m-2
+                # flux is 0.03 K/day in a top layer of 1 Pa - so the two chains' MODELS (the tools' from their CKD files) are
+                # evaluated by one evaluator in double
+                in_double, tables = {}, {}
+                for tag, fname in (("raw", "raw_ckd.nc"), ("optimised", "ckd.nc")):
+                    mt = ncio.read_ckd_model(os.path.join(dn, fname))
+                    ft = oracle_fluxes_of_model(mt, inp_n, c_out["cfg"])
+                    fc = oracle_fluxes_of_model(c_out["models"][tag], inp_n, c_out["cfg"])
+                    in_double[tag] = hr_rms_difference(p1, hr_k_per_day(p1, *ft), hr_k_per_day(p1, *fc))
+                    tables[tag] = compare_models(mt, c_out["models"][tag])
                 agreement = {"nwav": n, "ng_tools": int(gp_tools.max()) + 1, "ng_oracle": int(c_out["ng"]),
                              "g_point_maps_identical": bool(np.array_equal(gp_tools, c_out["g_point"])),
                              "wavenumbers_in_another_g_point": int((gp_tools != c_out["g_point"]).sum()) if gp_tools.shape == c_out["g_point"].shape else None,
                              "iterations_tools": s_out["iterations"], "iterations_oracle": c_out["iterations"],
                              "hr_rms_difference_K_per_day_tools_vs_oracle": {k: hr_rms_difference(p1, hr_t[k], hr_c[k]) for k in hr_t},
+                             "hr_rms_difference_K_per_day_of_the_two_chains_models_in_double": in_double,
+                             "coefficient_tables_tools_vs_oracle": tables,
                              "hr_rms_error_against_lbl_K_per_day": {"tools_" + k: hr_rms_difference(p1, hr_t[k], hr_l) for k in hr_t}
                                                                    | {"oracle_" + k: hr_rms_difference(p1, hr_c[k], hr_l) for k in hr_c},
                              "tools_seconds_at_this_size": {k: round(v, 3) for k, v in s_secs.items()}}
