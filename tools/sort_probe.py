@@ -28,11 +28,19 @@ def main():
     wn_h, dwn_h = syn.wavenumber_grid(n)
     wn, dwn = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
     od = syn.optical_depth_lines(torch, p, wn, syn.SEED_BASE + 1, nlines=12000, device=dev)
-    key, _ = api.reorder_key_lw(ctx, p, api.idealised_temperature(p), wn, dwn, od, 0.5)
+    t_ideal = api.idealised_temperature(p)
+    key, col = api.reorder_key_lw(ctx, p, t_ideal, wn, dwn, od, 0.5)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        api.reorder_key_lw(ctx, p, t_ideal, wn, dwn, od, 0.5, key=key, col_od=col)
+    ctx.synchronize()
+    k1_ms = (time.perf_counter() - t0) / args.reps * 1e3
+    key_checksum = float(key.double().sum().item())
     del od
     b1, b2 = syn.LW_NARROW_BANDS
     _, begin, end = api.band_ranges(wn_h, b1, b2)
-    out = {"nwav": n}
+    out = {"nwav": n, "k1_key_lw_ms_per_call": k1_ms, "k1_key_sum": key_checksum}
     rank = torch.empty(n, dtype=torch.int32, device=dev)
     for name, (bb, be) in (("one_band", ([0], [n - 1])), ("thirteen_bands", (begin, end))):
         api.stable_argsort_bands(ctx, key, bb, be, rank=rank, want_ordered=False, sync=True)
