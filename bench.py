@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--fsck-gases", type=int, default=6)               # config 1: gases of the job (composite h2o o3 co2 ch4 n2o)
     # config 1: gases searched side by side on the device (0 = all the host has cores for, 1 = gas after gas as the reference)
     ap.add_argument("--gases-side-by-side", type=int, default=0)
+    ap.add_argument("--no-gas-after-gas", action="store_true")         # skip the same job with the reference's gas loop beside the headline
     ap.add_argument("--no-single-gas", action="store_true")            # skip round 3's single-gas step beside the headline
     ap.add_argument("--cpu-gases", type=int, default=6)                # gases of the job the CPU baseline runs on its sample
     # no device work at all: rendezvous (gloo), the one all-reduce, the JSON line.  For the CPU test of the launcher.
@@ -563,6 +564,7 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
         except RuntimeError:
             h2d_ms = None
         head_info = dict(info)
+    if rank == 0 and world == 1 and args.config == 1 and not args.no_gas_after_gas:
         ctx.profile_enable(max(1, args.profile_stride))
         barrier()
         t1 = time.perf_counter()
@@ -586,42 +588,42 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                          "frac_per_launch": sq_pts * bpp / max(sq_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
                          "note": "the same job with the reference's gas loop (find_g_points.cpp:655): merge, reorder, prepare, search, "
                                  "release, one gas after the other on one stream; every sweep launch has the device to itself"}
-        if not args.no_single_gas:
-            job.close()
-            torch.cuda.empty_cache()
-            p1, wn_h, dwn_h, od1, bg1 = make_inputs(torch, nwav, nlay, syn.SEED_BASE + 1, device=dev, spectra=args.spectra, nlines=args.nlines)
-            wn1, dwn1 = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
-            t_ideal, t_file = api.idealised_temperature(p1), syn.temperature_profile(p1)
-            sg = {}
+    if rank == 0 and world == 1 and args.config == 1 and not args.no_single_gas:
+        job.close()
+        torch.cuda.empty_cache()
+        p1, wn_h, dwn_h, od1, bg1 = make_inputs(torch, nwav, nlay, syn.SEED_BASE + 1, device=dev, spectra=args.spectra, nlines=args.nlines)
+        wn1, dwn1 = torch.as_tensor(wn_h, device=dev), torch.as_tensor(dwn_h, device=dev)
+        t_ideal, t_file = api.idealised_temperature(p1), syn.temperature_profile(p1)
+        sg = {}
 
-            def single_step():
-                key1, _ = api.reorder_key_lw(ctx, p1, t_ideal, wn1, dwn1, od1, 0.5)
-                rnk1, _ = api.stable_argsort_bands(ctx, key1, [0], [nwav - 1], want_ordered=False)
-                gas = api.GasLW(ctx, p1, t_file, wn1, dwn1, rnk1, od1, bg1, "transmission", flux_weight=0.0)
-                st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance, args.max_iterations)
-                sg.update(ng=len(e), status=int(st), comp_cost=cc, cost_sum=float(np.sum(e)), eval_stats=gas.eval_stats(),
-                          bytes=gas.sweep_bytes_per_point())
-                gas.close()
-                return 1.0 + sg["eval_stats"]["points_evaluated"] / nwav
+        def single_step():
+            key1, _ = api.reorder_key_lw(ctx, p1, t_ideal, wn1, dwn1, od1, 0.5)
+            rnk1, _ = api.stable_argsort_bands(ctx, key1, [0], [nwav - 1], want_ordered=False)
+            gas = api.GasLW(ctx, p1, t_file, wn1, dwn1, rnk1, od1, bg1, "transmission", flux_weight=0.0)
+            st, b, e, cc = gas.find_g_band(0, nwav - 1, args.tolerance, args.tolerance_tolerance, args.max_iterations)
+            sg.update(ng=len(e), status=int(st), comp_cost=cc, cost_sum=float(np.sum(e)), eval_stats=gas.eval_stats(),
+                      bytes=gas.sweep_bytes_per_point())
+            gas.close()
+            return 1.0 + sg["eval_stats"]["points_evaluated"] / nwav
 
-            single_step()
-            ctx.profile_enable(max(1, args.profile_stride))
-            barrier()
-            t1 = time.perf_counter()
-            nst = max(2, min(args.steps, 5))
-            ps = sum(single_step() for _ in range(nst))
-            barrier()
-            dt1 = time.perf_counter() - t1
-            s_calls, s_ms, s_pts = ctx.profile_get("k_rt_lw_bb")
-            s_gbs = s_pts * sg["bytes"] / max(s_ms * 1e-3, 1e-12) / 1e9
-            single_gas = {"workload": "round 3's step: ONE gas, single-file FLOAT background (FLOAT pairs in the sweep), nwav=%d" % nwav,
-                          "value": nwav * ps / dt1, "unit": "wavenumber-points/s", "ms_per_step": dt1 / nst * 1e3, "steps": nst,
-                          "ng": sg["ng"], "search_status": sg["status"], "n_pass_per_step": ps / nst - 1.0,
-                          "n_pass_reference_counter": sg["comp_cost"], "final_cost_sum_K_per_day": sg["cost_sum"],
-                          "roofline": {"kernel": "k_rt_lw_bb_mirror<54,true>", "algorithmic_bytes_per_point": sg["bytes"],
-                                       "achieved": s_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s_gbs / HBM_PEAK_GBS,
-                                       "avg_launch_ms": s_ms / max(s_calls, 1), "points_per_launch": s_pts / max(s_calls, 1)}}
-            del od1, bg1
+        single_step()
+        ctx.profile_enable(max(1, args.profile_stride))
+        barrier()
+        t1 = time.perf_counter()
+        nst = max(2, min(args.steps, 5))
+        ps = sum(single_step() for _ in range(nst))
+        barrier()
+        dt1 = time.perf_counter() - t1
+        s_calls, s_ms, s_pts = ctx.profile_get("k_rt_lw_bb")
+        s_gbs = s_pts * sg["bytes"] / max(s_ms * 1e-3, 1e-12) / 1e9
+        single_gas = {"workload": "round 3's step: ONE gas, single-file FLOAT background (FLOAT pairs in the sweep), nwav=%d" % nwav,
+                      "value": nwav * ps / dt1, "unit": "wavenumber-points/s", "ms_per_step": dt1 / nst * 1e3, "steps": nst,
+                      "ng": sg["ng"], "search_status": sg["status"], "n_pass_per_step": ps / nst - 1.0,
+                      "n_pass_reference_counter": sg["comp_cost"], "final_cost_sum_K_per_day": sg["cost_sum"],
+                      "roofline": {"kernel": "k_rt_lw_bb_mirror<54,true>", "algorithmic_bytes_per_point": sg["bytes"],
+                                   "achieved": s_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": s_gbs / HBM_PEAK_GBS,
+                                   "avg_launch_ms": s_ms / max(s_calls, 1), "points_per_launch": s_pts / max(s_calls, 1)}}
+        del od1, bg1
 
     lut_sharded = None
     if args.lut_dist and use_dist and not args.no_lut_opt:

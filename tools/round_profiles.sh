@@ -8,11 +8,25 @@ out=gpurun_out/${tag}_profiles; mkdir -p $out
 quiet="--no-cpu --no-lut-opt --no-sw --no-e2e"
 # per-kernel totals of the headline step
 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python3 bench.py --steps 2 --warmup 1 $quiet > $out/ks_bench.json 2> $out/ks.err
+# the same with the side-by-side steps only: the UNION of the time in which a sweep launch was executing (the launches of the six
+# streams overlap: launches x average duration is not the device time of the sweep) and its bytes over that time
+rocprofv3 --kernel-trace -d $out/kt -o kt --output-format csv -- python3 bench.py --steps 2 --warmup 1 $quiet --no-gas-after-gas --no-single-gas > $out/kt_bench.json 2> $out/kt.err
+python3 - > $out/sweep_union.json 2>> $out/kt.err <<PYEOF
+import json, subprocess, glob
+line = json.loads(open("$out/kt_bench.json").read().strip().splitlines()[-1])
+rl = line["roofline"]
+# (3 steps ran: warm-up + 2 timed; points swept per step x bytes per point x 3)
+total = rl["points_swept_per_step"] * rl["algorithmic_bytes_per_point"] * (line["steps"] + line["warmup"])
+trace = glob.glob("$out/kt/*kernel_trace.csv")[0]
+u = json.loads(subprocess.check_output(["python3", "tools/kernel_union.py", trace, "--kernel", "k_rt_lw_bb_mirror", "--total-bytes", str(total)]))
+u["bench_line_roofline"] = {k: rl[k] for k in ("achieved", "frac", "avg_launch_ms", "launches", "search_window_ms_per_step", "points_swept_per_step")}
+print(json.dumps(u, indent=1))
+PYEOF
 # HBM bytes of the dominant kernel: separate --pmc passes, kernel trace only beside them
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $quiet > $out/pmc_$c.json 2> $out/pmc_$c.err
+  rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 $quiet --no-gas-after-gas --no-single-gas > $out/pmc_$c.json 2> $out/pmc_$c.err
 done
-python3 tools/traffic_json.py k_rt_lw_bb $out/pmc_FETCH_SIZE/p_counter_collection.csv $out/pmc_WRITE_SIZE/p_counter_collection.csv $out/pmc_FETCH_SIZE.json > $out/traffic_k_rt_lw_bb.json
+python3 tools/traffic_json.py k_rt_lw_bb_mirror $out/pmc_FETCH_SIZE/p_counter_collection.csv $out/pmc_WRITE_SIZE/p_counter_collection.csv $out/pmc_FETCH_SIZE.json > $out/traffic_k_rt_lw_bb.json
 # the bench line as the driver runs it; its `traffic` comes from profiles/<tag>_traffic_k_rt_lw_bb.json: this build's, just measured
 cp $out/traffic_k_rt_lw_bb.json profiles/${tag}_traffic_k_rt_lw_bb.json
 python3 bench.py > $out/bench.json 2> $out/bench.err
@@ -35,5 +49,5 @@ python3 bench.py --config 3 --steps 2 > $out/bench_config3.json 2> $out/c3.err
 python3 bench.py --config 4 > $out/bench_config4.json 2> $out/c4.err
 # gpurun returns at most 64 MiB: keep the summaries, drop the raw traces they were computed from
 cp $out/ks/ks_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
-rm -rf $out/ks $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/k6_*/ $out/bb
+rm -rf $out/ks $out/kt $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/k6_*/ $out/bb
 du -sh $out; ls -la $out | tail -30
