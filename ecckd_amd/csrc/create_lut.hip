@@ -342,29 +342,63 @@ k_erythemal_partial(const Chunk* __restrict__ chunks, const double* __restrict__
   }
 }
 
-// K7b.  gpoint_fraction: grid (nint + 1, ng), block 64.  blockIdx.x == nint computes the total
-// spectral width of the g point; the others the width inside (wavenumber1, wavenumber2].
+// K7b.  gpoint_fraction: the spectral width of every g point inside every interval (wavenumber1, wavenumber2], and its total
+// width.  Inside its segment of the g-sorted order a g point's wavenumbers ascend, so an interval is a run of positions found by
+// two binary searches; grid (nint, ng), block 64 (an interval holds n / (nint ng) points of a g point on average: a few hundred).
 __global__ void __launch_bounds__(64)
 k_gpoint_width(int nint, const long long* __restrict__ seg_begin /*[ng+1]*/, const double* __restrict__ wn_s,
                const double* __restrict__ dwn_s, const double* __restrict__ w1, const double* __restrict__ w2,
                double* __restrict__ width /*[ng][nint+1]*/) {
   const int iw = blockIdx.x, g = blockIdx.y;
   const long long b = seg_begin[g], e = seg_begin[g + 1];
-  long long lo = b, hi = e;
-  if (iw < nint) {
-    // wavenumbers ascend inside the segment: first position with wn > w1, first with wn > w2
-    const double a1 = w1[iw], a2 = w2[iw];
-    long long l = b, r = e;
-    while (l < r) { long long m = (l + r) >> 1; if (wn_s[m] > a1) r = m; else l = m + 1; }
-    lo = l;
-    l = lo; r = e;
-    while (l < r) { long long m = (l + r) >> 1; if (wn_s[m] > a2) r = m; else l = m + 1; }
-    hi = l;
+  // wavenumbers ascend inside the segment: first position with wn > w1, first with wn > w2
+  const double a1 = w1[iw], a2 = w2[iw];
+  long long l = b, r = e;
+  while (l < r) { long long m = (l + r) >> 1; if (wn_s[m] > a1) r = m; else l = m + 1; }
+  const long long lo = l;
+  r = e;
+  while (l < r) { long long m = (l + r) >> 1; if (wn_s[m] > a2) r = m; else l = m + 1; }
+  const long long hi = l;
+  // four loads in flight per lane
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  long long i = lo + threadIdx.x;
+  for (; i + 192 < hi; i += 256) { s0 += dwn_s[i]; s1 += dwn_s[i + 64]; s2 += dwn_s[i + 128]; s3 += dwn_s[i + 192]; }
+  for (; i < hi; i += 64) s0 += dwn_s[i];
+  const double s = wave_sum((s0 + s1) + (s2 + s3));
+  if (threadIdx.x == 0) width[(size_t)g * (nint + 1) + iw] = s;
+}
+
+// The TOTAL width of a g point is a sum over its whole segment (n / ng points: 2e5 at 7.2e6 points and 38 g points), which one
+// 64-thread block per g point used to walk with one load in flight per lane - 7.3 ms, 20 GB/s.  Now: the chunks of the segment
+// (the same 2048-position chunks K6 works on) are summed by a block each, the chunk sums of a g point added in chunk order.
+__global__ void __launch_bounds__(GA_THREADS)
+k_width_chunk_sums(const Chunk* __restrict__ chunks, const double* __restrict__ dwn_s, double* __restrict__ partial) {
+  __shared__ double s_red[4];
+  const Chunk c = chunks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double v[GA_PPT];
+#pragma unroll
+  for (int p = 0; p < GA_PPT; ++p) {
+    const long long i = c.p0 + (long long)p * GA_THREADS + tid;
+    v[p] = i <= c.p1 ? dwn_s[i] : 0.0;
   }
   double s = 0.0;
-  for (long long i = lo + threadIdx.x; i < hi; i += 64) s += dwn_s[i];
+#pragma unroll
+  for (int p = 0; p < GA_PPT; ++p) s += v[p];
   s = wave_sum(s);
-  if (threadIdx.x == 0) width[(size_t)g * (nint + 1) + iw] = s;
+  if (lane == 0) s_red[wave] = s;
+  __syncthreads();
+  if (tid == 0) partial[blockIdx.x] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+}
+
+__global__ void __launch_bounds__(256)
+k_width_totals(int ng, int nint, const int* __restrict__ seg_chunk0, const double* __restrict__ partial,
+               double* __restrict__ width /*[ng][nint+1]*/) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  double s = 0.0;
+  for (int c = seg_chunk0[g]; c < seg_chunk0[g + 1]; ++c) s += partial[c];
+  width[(size_t)g * (nint + 1) + nint] = s;
 }
 
 }  // namespace
@@ -562,16 +596,22 @@ int ecckd_gpoint_fraction(ecckd_gmap* m, int nint, const double* h_wavenumber1, 
   ecckd_ctx* ctx = m->ctx;
   ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
   const int ng = m->ng;
+  const size_t nchunk = m->chunks.size();
   const size_t wb = ecckd_align_up((size_t)ng * (nint + 1) * sizeof(double), 256);
   const size_t gb = ecckd_align_up((size_t)nint * sizeof(double), 256);
-  ECCKD_CHECK(gmap_work(m, wb + 2 * gb));
+  const size_t cb = ecckd_align_up(std::max<size_t>(nchunk, 1) * sizeof(double), 256);
+  ECCKD_CHECK(gmap_work(m, wb + 2 * gb + cb));
   double* d_width = (double*)m->work;
   double* d_w1 = (double*)((char*)m->work + wb);
   double* d_w2 = (double*)((char*)m->work + wb + gb);
+  double* d_csum = (double*)((char*)m->work + wb + 2 * gb);
   ECCKD_CHECK(ecckd_h2d(ctx, d_w1, h_wavenumber1, (size_t)nint * sizeof(double)));
   ECCKD_CHECK(ecckd_h2d(ctx, d_w2, h_wavenumber2, (size_t)nint * sizeof(double)));
-  hipLaunchKernelGGL(k_gpoint_width, dim3(nint + 1, ng), dim3(64), 0, ctx->stream, nint, m->d_seg_begin, m->wn_s, m->dwn_s,
+  hipLaunchKernelGGL(k_gpoint_width, dim3(nint, ng), dim3(64), 0, ctx->stream, nint, m->d_seg_begin, m->wn_s, m->dwn_s,
                      d_w1, d_w2, d_width);
+  if (nchunk > 0)
+    hipLaunchKernelGGL(k_width_chunk_sums, dim3((unsigned)nchunk), dim3(GA_THREADS), 0, ctx->stream, m->d_chunks, m->dwn_s, d_csum);
+  hipLaunchKernelGGL(k_width_totals, dim3((ng + 255) / 256), dim3(256), 0, ctx->stream, ng, nint, m->d_seg_chunk0, d_csum, d_width);
   ECCKD_HIP_CHECK(hipGetLastError());
   std::vector<double> width((size_t)ng * (nint + 1));
   ECCKD_CHECK(ecckd_d2h(ctx, width.data(), d_width, width.size() * sizeof(double)));

@@ -1210,11 +1210,13 @@ k_lb_update(size_t n, LbSlots keep, int new_slot, const double* __restrict__ x, 
       // position keep.n is the pair being stored: the newest of this iteration's direction
       const double sq = (a == keep.n && pair) ? si : sa[a];
       const double yq = (a == keep.n && pair) ? yi : ya[a];
-      acc[1 + a] += sq * gi;
-      acc[1 + LB_M + a] += yq * gi;
-      acc[3 + 2 * LB_M + a] += si * ya[a];
-      acc[3 + 3 * LB_M + a] += sa[a] * yi;
-      acc[3 + 4 * LB_M + a] += yi * ya[a];
+      // (positions behind the pairs in use alias ring slot 0: dropped by a select, never multiplied)
+      const bool used = a < keep.n || (a == keep.n && pair);
+      acc[1 + a] += used ? sq * gi : 0.0;
+      acc[1 + LB_M + a] += used ? yq * gi : 0.0;
+      acc[3 + 2 * LB_M + a] += a < keep.n ? si * ya[a] : 0.0;
+      acc[3 + 3 * LB_M + a] += a < keep.n ? sa[a] * yi : 0.0;
+      acc[3 + 4 * LB_M + a] += a < keep.n ? yi * ya[a] : 0.0;
     }
     if (pair) {
       S[(size_t)new_slot * n + i] = si;     // the slot being written is never among the pairs that stay
@@ -1232,7 +1234,8 @@ k_lb_direction(size_t n, LbSlots sl, LbCoef cf, const double* __restrict__ q, co
   __shared__ double s_all[2 * VEC_WAVES];
   double acc[2] = {0.0, 0.0};
   for (size_t i = (size_t)blockIdx.x * VEC_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * VEC_THREADS) {
-    // (no test of the number of pairs round the loads: unused pairs have zero coefficients and finite slots)
+    // (no test of the number of pairs round the LOADS - a branch per pair put a memory round trip behind each -; an unused
+    // position, which aliases ring slot 0, is dropped by a select: 0 x a stale non-finite value would be NaN)
     double sv[LB_M], yv[LB_M];
 #pragma unroll
     for (int k = 0; k < LB_M; ++k) {
@@ -1241,7 +1244,7 @@ k_lb_direction(size_t n, LbSlots sl, LbCoef cf, const double* __restrict__ q, co
     }
     double di = -cf.gamma * q[i];
 #pragma unroll
-    for (int k = 0; k < LB_M; ++k) di += cf.cy[k] * yv[k] - cf.cs[k] * sv[k];
+    for (int k = 0; k < LB_M; ++k) di += (k < sl.n) ? cf.cy[k] * yv[k] - cf.cs[k] * sv[k] : 0.0;
     // a variable held by an active bound (or pinned) does not move: without this the slope d.g of the Armijo test would
     // count a decrease that the clamped trial point cannot deliver
     if (q[i] == 0.0 && g[i] != 0.0) di = 0.0;
@@ -1254,10 +1257,10 @@ k_lb_direction(size_t n, LbSlots sl, LbCoef cf, const double* __restrict__ q, co
 
 // xn = clamp(x + step*d), pinned elements stay; kn = exp(xn), the coefficients the cost function starts from (0 where pinned,
 // solve_adept.cpp:242-249).  step < 0: chosen here from |d| (every block reduces the same partials in the same order):
-// first iteration min(1, 1/|d|), later 1, never longer than max_step (solve_adept.cpp:331); out[0] = step, out[1] = d.d,
+// first iteration min(1, 1/|d|), later 1, never longer than max_step (solve_adept.cpp:331), times `hint`; out[0] = step, out[1] = d.d,
 // out[2] = d.g (pinned host slots)
 __global__ void __launch_bounds__(VEC_THREADS)
-k_lb_step(size_t n, double step, int first, double max_step, const double* __restrict__ part_dg,
+k_lb_step(size_t n, double step, int first, double max_step, double hint, const double* __restrict__ part_dg,
           const double* __restrict__ part_dd, const double* __restrict__ x, const double* __restrict__ d,
           const double* __restrict__ xmin, const double* __restrict__ xmax, double* __restrict__ xn,
           double* __restrict__ kn, double* __restrict__ out) {
@@ -1267,6 +1270,7 @@ k_lb_step(size_t n, double step, int first, double max_step, const double* __res
     const double dn = sqrt(dd);
     step = first ? fmin(1.0, 1.0 / fmax(dn, 1e-300)) : 1.0;
     if (step * dn > max_step) step = max_step / dn;
+    step *= hint;             // the fraction of that step the line search starts from (ecckd_opt_minimize)
     if (blockIdx.x == 0) {
       const double dg = sum_partials(part_dg, gridDim.x, s_tmp);
       if (threadIdx.x == 0) { out[0] = step; out[1] = dd; out[2] = dg; }
@@ -2382,8 +2386,8 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
       hipLaunchKernelGGL(k_lb_direction, vb, vt, 0, ctx->stream, n, sd, cf, o->d_q, o->d_S, o->d_Y, g, o->d_dir, part_dg);
       // the trial point (and its coefficients) with the step chosen on the device, then the cost there; one wait for both
       opt_mark_pending(h_step, 3);
-      hipLaunchKernelGGL(k_lb_step, vb, vt, 0, ctx->stream, n, -1.0, npairs == 0 ? 1 : 0, max_step, part_dg, part_dd, x,
-                         o->d_dir, bmin, bmax, xn, o->d_k, sc_step);
+      hipLaunchKernelGGL(k_lb_step, vb, vt, 0, ctx->stream, n, -1.0, npairs == 0 ? 1 : 0, max_step, 1.0, part_dg,
+                         part_dd, x, o->d_dir, bmin, bmax, xn, o->d_k, sc_step);
       ECCKD_HIP_CHECK(hipGetLastError());
       ECCKD_CHECK(opt_cost_grad_dev(o, xn, gn, &Jn, true));
       ECCKD_CHECK(opt_wait_slots(ctx, h_step, 3));
@@ -2400,9 +2404,13 @@ int ecckd_opt_minimize(ecckd_opt* o, int max_iterations, double convergence_crit
         continue;
       }
       ok = (Jn == Jn && Jn <= J + 1.0e-4 * step * dg);
+      // (Tried in round 4 and dropped: a line search that remembers - the next iteration starting from the fraction of the capped
+      // step that was accepted last, doubled after a first-trial acceptance.  Over 300 iterations at nx = 3.05e5: 5 800 against
+      // 6 000 iterations/s longwave, 3 830 against 3 730 shortwave, final costs 66.62 against 66.39 and 53.62 against 53.56 -
+      // fewer evaluations per iteration, smaller steps, nothing gained.)
       for (int ls = 1; !ok && ls < 30; ++ls) {
         step *= 0.5;
-        hipLaunchKernelGGL(k_lb_step, vb, vt, 0, ctx->stream, n, step, 0, max_step, part_dg, part_dd, x, o->d_dir, bmin,
+        hipLaunchKernelGGL(k_lb_step, vb, vt, 0, ctx->stream, n, step, 0, max_step, 1.0, part_dg, part_dd, x, o->d_dir, bmin,
                            bmax, xn, o->d_k, sc_step);
         ECCKD_CHECK(opt_cost_grad_dev(o, xn, gn, &Jn, true));
         ok = (Jn == Jn && Jn <= J + 1.0e-4 * step * dg);

@@ -6,6 +6,7 @@ the union are printed for the kernel matching --kernel.
     python tools/kernel_union.py <kernel_trace.csv> [--kernel k_rt_lw_bb_mirror] [--total-bytes 1.48e13]"""
 import argparse
 import csv
+import re
 import json
 import sys
 from collections import defaultdict
@@ -23,7 +24,9 @@ def main():
             name = row.get("Kernel_Name") or row.get("kernel_name") or ""
             a = int(row.get("Start_Timestamp") or row.get("start_timestamp"))
             b = int(row.get("End_Timestamp") or row.get("end_timestamp"))
-            short = name.split("(")[0]
+            # "void (anonymous namespace)::k_rt_lw_bb_mirror<54, false>(unsigned long, ...)" -> "k_rt_lw_bb_mirror<54, false>"
+            m = re.search(r"(k_[A-Za-z0-9_]+(?:<[^()]*?>)?)\(", name)
+            short = m.group(1) if m else name.split("(")[0].replace("void ", "")[:80]
             spans[short].append((a, b))
     out = {}
     for name, sp in spans.items():
