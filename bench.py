@@ -792,6 +792,13 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
             except Exception as exc:                                      # noqa: BLE001
                 import traceback
                 out["e2e"] = {"error": repr(exc), "traceback": traceback.format_exc()[-1500:]}
+            # the shipped path of the headline job itself: the six-gas FSCK job by bin/reorder_spectrum + bin/find_g_points on files
+            try:
+                import fsck_tools_bench
+                out["tools_fsck_job"] = fsck_tools_bench.run(ctx, nwav=nwav, nlay=nlay, tolerance=args.tolerance, nlines=args.nlines)
+            except Exception as exc:                                      # noqa: BLE001
+                import traceback
+                out["tools_fsck_job"] = {"error": repr(exc), "traceback": traceback.format_exc()[-1500:]}
         if world == 1 and not args.no_cpu and args.config == 1:
             cb = cpu_baseline(args, args.cpu_sample, nlay, syn.SEED_BASE + 1, args.tolerance, args.tolerance_tolerance,
                               args.max_iterations, ctx)
@@ -856,7 +863,11 @@ def launch_ranks(args):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import uuid
+    # ECCKD_RUN_ID: the identity rank-aware tools stamp their part files with (bin/find_g_points): unique per launch, so that a
+    # part left by an earlier launch with the same configuration and port is never taken for this one's
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               ECCKD_RUN_ID=os.environ.get("ECCKD_RUN_ID", uuid.uuid4().hex))
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for ln in proc.stdout.splitlines():

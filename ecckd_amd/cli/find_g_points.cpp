@@ -600,9 +600,10 @@ int main(int argc, char** argv) {
       write_part(output + ".part" + std::to_string(my_rank), results, identity);
       return done(0);
     }
-    // extension key: how long process 0 waits for a part that has not appeared, in seconds.  A process that FAILS says so
-    // through its marker at once; the wait only covers a peer that is still searching (or was never started)
-    double part_timeout = 900.0;
+    // extension key: how long process 0 waits for a part that has not appeared, in seconds.  A process that FAILS through an
+    // error path says so through its marker at once; one that is killed (a signal, the out-of-memory killer, a HIP abort) leaves
+    // none, so the wait is what bounds that case - the reference-sized default stays an hour
+    double part_timeout = 3600.0;
     config.read(part_timeout, "part_timeout");
     for (int r = 1; r < world; ++r) {
       const std::string path = output + ".part" + std::to_string(r);

@@ -199,6 +199,32 @@ def test_find_g_points_several_processes(ctx, tmp_path, world):
         assert "(searched by other processes)" in outs[1]                    # process 1 searches co2 only
 
 
+@pytest.mark.parametrize("variant", ["plain", "g_split", "sequential_bands"])
+def test_find_g_points_gases_side_by_side_write_the_file_of_gas_after_gas(ctx, tmp_path, variant):
+    """bin/find_g_points searches a gas from the moment it is prepared while it reads and prepares the next one
+    (ecckd_find_g_gases_begin / _add / _wait, a HIP stream per gas); gases_side_by_side=1 is the reference's gas loop
+    (find_g_points.cpp:655).  Both must write the same g-points file - also with sub-bands (the re-ranking of a band happens
+    before the gas is prepared) and with sequential_bands, which implies gas after gas."""
+    d = tmp_path
+    _make_lw_files(d)
+    os.symlink(d / "h2o.nc", d / "co2_bg_is_h2o.nc")
+    for g in ("h2o", "co2"):
+        r = run_tool("reorder_spectrum", f"input={d}/{g}.nc", f"output={d}/order_{g}.nc", "wavenumber1=0 1300", "wavenumber2=1300 3260")
+        assert r.returncode == 0, r.stderr
+    cfg = LW_CFG.format(d=d)
+    if variant == "g_split":
+        cfg = cfg.replace("  background_input \"co2.nc\"\n", "  background_input \"co2.nc\"\n  g_split 0 0.7\n  subband_wavenumber_boundary 2000 2600\n")
+        assert "g_split" in cfg
+    (d / "find_g.cfg").write_text(cfg)
+    extra = ["sequential_bands=1"] if variant == "sequential_bands" else []
+    r = run_tool("find_g_points", d / "find_g.cfg", f"output={d}/side.nc", *extra, cwd="/")
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "*** G POINTS OF H2O" in r.stdout and "*** G POINTS OF CO2" in r.stdout
+    r = run_tool("find_g_points", d / "find_g.cfg", f"output={d}/after.nc", "gases_side_by_side=1", cwd="/")
+    assert r.returncode == 0, r.stderr + r.stdout
+    _same_files(d / "side.nc", d / "after.nc", skip=("history", "config"))
+
+
 def test_find_g_points_refuses_stale_parts_and_sees_failed_peers(ctx, tmp_path):
     """a part file carries the identity of its run (configuration text, launcher rendezvous, WORLD_SIZE, numbers of
     gases / bands / wavenumbers); process 0 refuses one that is not its own instead of building the g-points file from another
@@ -316,6 +342,14 @@ def test_exit_codes(tmp_path):
     (tmp_path / "bad.cfg").write_text("output g.nc\ngases h2o\n")
     r = run_tool("find_g_points", "bad.cfg", cwd=tmp_path)
     assert r.returncode == 147 and "heating_rate_tolerance not defined" in r.stderr
+    # Rayleigh scattering as an OPTIMISED pseudo-gas (rayleigh_prior_error > 0; commented out in the shipped scripts,
+    # test/optimize_lut_sw.sh) is a documented refusal, not a silent difference: the reference adds that prior to the cost but
+    # not to the gradient (ckd_model.cpp:869-874) and leaves the bounds of those state elements unset (:136-137,
+    # solve_adept.cpp:346-347) - there is no well-defined minimisation to reproduce ("Known differences")
+    r = run_tool("optimize_lut", "input=raw.nc", "output=opt.nc", "rayleigh_prior_error=0.5", cwd=tmp_path)
+    assert r.returncode == 147 and "rayleigh_prior_error > 0" in r.stderr
+    r = run_tool("optimize_lut", "input=raw.nc", "output=opt.nc", "rayleigh_prior_error=0", cwd=tmp_path)
+    assert r.returncode != 147 or "rayleigh_prior_error" not in r.stderr                # 0 (the scripts' value) is accepted
 
 
 def _write_columns(path, gas, p1, t, wn, seed, scale, vmr, lo=0.0, hi=3260.0):

@@ -38,7 +38,7 @@ for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 # name: (seed offset, column scale, surface mole fraction, concentration dependence)
 GASES = {"h2o": (61, 40.0, 5e-3, "lut"), "co2": (63, 10.0, 4e-4, "linear"), "o3": (65, 4.0, 3e-6, "linear"), "ch4": (67, 2.0, 1.8e-6, "linear")}
 FIND_G = dict(heating_rate_tolerance=0.05, max_iterations=60, tolerance_tolerance=0.01, flux_weight=0.0)      # find_g_points_lw.sh
-OPT = dict(max_iterations=40, flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, prior_error=4.0, convergence_criterion=0.0)
+OPT = dict(max_iterations=500, flux_weight=0.2, flux_profile_weight=0.0, broadband_weight=0.5, prior_error=4.0, convergence_criterion=0.0)
 OPT_DEFAULTS = dict(spectral_boundary_weight=0.0, negative_od_penalty=1.0e4, pressure_weight_power=0.5, pressure_corr=0.5,
                     temperature_corr=0.5, conc_corr=0.5)                # optimize_lut.cpp:97-113, :185
 NCOL_TRAIN = 50
@@ -542,7 +542,10 @@ def run(ctx, nwav=7_200_000, nlay=54, cpu_nwav=(1 << 17, 1 << 18), workdir=None,
             "cpu_scaling_exponent_between_the_two_sizes": expo,
             "cpu_oracle_seconds_scaled_to_full_size": {k: round(v, 2) for k, v in scaled.items()},
             "cpu_oracle_total_seconds_scaled": round(c_tot, 2), "cpu_cores": ncores,
-            "speedup_total": c_tot / g_tot, "speedup_per_stage": {k: scaled[k] / g_secs[k] for k in scaled if g_secs.get(k)},
+            # the CPU side is the oracle chain at the larger reduced size with its size-proportional stages scaled LINEARLY to the full size (the
+            # exponent measured between the two reduced sizes is beside it: > 1 for find_g_points, so this understates the CPU)
+            "speedup_vs_linearly_scaled_cpu": c_tot / g_tot,
+            "speedup_per_stage_vs_linearly_scaled_cpu": {k: scaled[k] / g_secs[k] for k in scaled if g_secs.get(k)},
             "agreement_at_reduced_size": agreement,
             "setup_seconds_not_timed": {"generating_and_writing_inputs": round(setup_s, 1), "of_which_writing_spectra_files": round(write_s, 1),
                                         "sync_after_writing": round(sync_s, 1)},
