@@ -697,6 +697,17 @@ def find_g_main(args, ctx, dist, rank, world, barrier, use_dist):
                         "phase_ms_last_step_rank_0": {k: round(v * 1e3, 2) for k, v in info.get("phase_seconds", {}).items()},
                         "tasks_on_rank_0": extra["tasks_this_rank"]}),
             "spectra": {"generator": args.spectra, "lines_per_gas": args.nlines if args.spectra == "lines" else 32},
+            # who does what at this world size, and what crosses the links: the (gas, band) searches of every rank and the path's
+            # single collective (ecckd_amd/shard.py: one all-reduce of [elapsed, points, final cost, 1])
+            "sharding": ({"scaling": "weak", "jobs_per_rank": 1, "searches_per_rank": [args.fsck_gases] * world,
+                          "collectives_per_run": 1, "allreduce_bytes": 4 * 8, "data_path_collectives": 0}
+                         if args.config == 1 else
+                         {"scaling": "strong", "tasks": extra["tasks"],
+                          "searches_per_rank": [len(shard.deal_tasks(extra["tasks"], r, world)) for r in range(world)],
+                          "collectives_per_step": "1 gather of the per-band results to rank 0 (a few numbers per g point), 1 all-reduce of "
+                                                  "[work counter, final cost] (16 B), 1 max-reduce of every gas's g-point map to rank 0 "
+                                                  "(nwav int32 per gas)",
+                          "data_path_collectives": 0}),
             "search": {"error_batches_per_step": all_calls / max(args.steps, 1),
                        "points_per_batch": all_pts / max(all_calls, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_rt_lw_bb", "achieved": rt_gbs, "peak": HBM_PEAK_GBS,

@@ -200,6 +200,9 @@ SIGNATURES = {
                                               C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p,
                                               C.c_void_p, C.c_void_p]),
     "ecckd_gauss_legendre_01": (C.c_int, [C.c_int, _c_double_p, _c_double_p]),
+    "ecckd_rt_lw_gpoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    "ecckd_rt_sw_gpoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _c_double_p, _c_double_p, _c_double_p,
+                                      _c_double_p]),
     "ecckd_lbl_band_fluxes_sw_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int, C.c_size_t, C.c_int, _c_int64_p, _c_int64_p, _c_double_p, _c_double_p,
                                               C.c_void_p, C.c_void_p]),

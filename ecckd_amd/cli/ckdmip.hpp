@@ -116,62 +116,6 @@ Namelist read_namelist(const std::string& path) {
   return nl;
 }
 
-// longwave radiative transfer of one (level, g) matrix on the host: radiative_transfer_lw.cpp:27-60 (unit emissivity) along the
-// slant path sec * tau; the two-stream form is sec = 1.66
-void rt_lw_host_sec(int nlay, int ng, double sec, const double* planck, const double* od, double* dn, double* up) {
-  for (int g = 0; g < ng; ++g) dn[g] = 0.0;
-  std::vector<double> eps((size_t)nlay * ng), fac((size_t)nlay * ng);
-  for (size_t i = 0; i < (size_t)nlay * ng; ++i) {
-    const double e = 1.0 - std::exp(-sec * od[i]);
-    eps[i] = e;
-    fac[i] = e > 1.0e-5 ? 1.0 - e * (1.0 / sec) / od[i] : 0.5 * e;
-  }
-  for (int l = 0; l < nlay; ++l)
-    for (int g = 0; g < ng; ++g) {
-      const size_t i = (size_t)l * ng + g;
-      dn[i + ng] = dn[i] * (1.0 - eps[i]) + planck[i] * (eps[i] - fac[i]) + planck[i + ng] * fac[i];
-    }
-  for (int g = 0; g < ng; ++g) up[(size_t)nlay * ng + g] = planck[(size_t)nlay * ng + g];
-  for (int l = nlay - 1; l >= 0; --l)
-    for (int g = 0; g < ng; ++g) {
-      const size_t i = (size_t)l * ng + g;
-      up[i] = up[i + ng] * (1.0 - eps[i]) + planck[i + ng] * (eps[i] - fac[i]) + planck[i] * fac[i];
-    }
-}
-
-// nangle = 0: the classic two-stream fluxes (diffusivity 1.66); nangle = N > 0: N Gauss-Legendre zenith angles per hemisphere,
-// flux = sum_k 2 w_k mu_k L(mu_k) (what ecckd_lbl_band_fluxes_lw_angles does per wavenumber)
-void rt_lw_host(int nangle, int nlay, int ng, const double* planck, const double* od, double* dn, double* up) {
-  if (nangle == 0) { rt_lw_host_sec(nlay, ng, 1.66, planck, od, dn, up); return; }
-  std::vector<double> mu(nangle), w(nangle);
-  ck(ecckd_gauss_legendre_01(nangle, mu.data(), w.data()));
-  const size_t n = (size_t)(nlay + 1) * ng;
-  std::vector<double> d(n), u(n);
-  std::fill(dn, dn + n, 0.0);
-  std::fill(up, up + n, 0.0);
-  for (int a = 0; a < nangle; ++a) {
-    rt_lw_host_sec(nlay, ng, 1.0 / mu[a], planck, od, d.data(), u.data());
-    const double wgt = 2.0 * w[a] * mu[a];
-    for (size_t i = 0; i < n; ++i) { dn[i] += wgt * d[i]; up[i] += wgt * u[i]; }
-  }
-}
-
-// direct beam and surface-reflected upwelling flux of one (level, g) matrix: radiative_transfer_sw.cpp:45-77
-void rt_sw_host(int nlay, int ng, double mu0, double albedo, const double* incoming, const double* od, double* dn, double* up) {
-  for (int g = 0; g < ng; ++g) dn[g] = mu0 * incoming[g];
-  for (int l = 0; l < nlay; ++l)
-    for (int g = 0; g < ng; ++g) {
-      const size_t i = (size_t)l * ng + g;
-      dn[i + ng] = dn[i] * std::exp(-od[i] / mu0);
-    }
-  for (int g = 0; g < ng; ++g) up[(size_t)nlay * ng + g] = dn[(size_t)nlay * ng + g] * albedo;
-  for (int l = nlay - 1; l >= 0; --l)
-    for (int g = 0; g < ng; ++g) {
-      const size_t i = (size_t)l * ng + g;
-      up[i] = up[i + ng] * std::exp(-2.0 * od[i]);
-    }
-}
-
 }  // namespace
 
 inline int ckdmip_main(int argc, char** argv, bool sw) {
@@ -207,6 +151,7 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
 
     // ---------------------------------------------------------------------------------------------------------------
     if (!ckd_file.empty()) {   // radiative transfer on a CKD model's optical depths (test/run_ckd_lw.sh:133-137)
+      Device dev;
       NcIn f(ckd_file);
       const std::vector<size_t> sh = f.shape("optical_depth");
       if (sh.size() != 3) fail(ECCKD_PARAMETER_ERROR, "optical_depth in %s is not (column, level, g_point)", ckd_file.c_str());
@@ -240,7 +185,8 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
           const std::vector<double> incoming = f.read("incoming_sw", c);
           std::vector<double> dn_all(nmu * nhg), up_all(nmu * nhg), bdn((size_t)nmu * (nlay + 1), 0.0), bup((size_t)nmu * (nlay + 1), 0.0);
           for (int m = 0; m < nmu; ++m) {
-            rt_sw_host(nlay, ng, mu0[m], nl.surf_albedo, incoming.data(), od.data(), &dn_all[m * nhg], &up_all[m * nhg]);
+            // radiative_transfer_sw.cpp:45-77 per g point, on the device (ecckd_rt_sw_gpoints)
+            ck(ecckd_rt_sw_gpoints(dev.ctx(), 1, nlay, ng, mu0[m], nl.surf_albedo, incoming.data(), od.data(), &dn_all[m * nhg], &up_all[m * nhg]));
             for (int i = 0; i <= nlay; ++i)
               for (int g = 0; g < ng; ++g) {
                 bdn[(size_t)m * (nlay + 1) + i] += dn_all[m * nhg + (size_t)i * ng + g];
@@ -269,7 +215,8 @@ inline int ckdmip_main(int argc, char** argv, bool sw) {
       for (int c = 0; c < ncol; ++c) {
         const std::vector<double> od = f.read("optical_depth", c), planck = f.read("planck_hl", c);
         std::vector<double> dn(nhg), up(nhg), bdn(nlay + 1, 0.0), bup(nlay + 1, 0.0);
-        rt_lw_host(nl.nangle, nlay, ng, planck.data(), od.data(), dn.data(), up.data());
+        // radiative_transfer_lw.cpp:27-60 per g point (two-stream or nangle Gauss-Legendre angles), on the device
+        ck(ecckd_rt_lw_gpoints(dev.ctx(), nl.nangle, 1, nlay, ng, planck.data(), od.data(), dn.data(), up.data()));
         for (int i = 0; i <= nlay; ++i)
           for (int g = 0; g < ng; ++g) { bdn[i] += dn[(size_t)i * ng + g]; bup[i] += up[(size_t)i * ng + g]; }
         out.write_slice("pressure_hl", c, f.read("pressure_hl", c));

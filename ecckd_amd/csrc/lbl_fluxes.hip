@@ -152,6 +152,61 @@ k_lbl_fluxes_sw(int nlay, size_t od_stride, const BandChunk* __restrict__ chunks
     partial[(size_t)blockIdx.x * 2 * nhl + t] = ((s_acc[t] + s_acc[2 * nhl + t]) + s_acc[4 * nhl + t]) + s_acc[6 * nhl + t];
 }
 
+// Fluxes of (level, g point) matrices - what run_ckd leaves for a flux evaluation (test/run_ckd_lw.sh:133-137: optical depth and
+// Planck function per g point) - one thread per (column, g point): radiative_transfer_lw.cpp:27-60 with unit emissivity along the
+// slant path sec * tau, nangle = 0 the two-stream form (sec = 1.66), otherwise the sum over the Gauss-Legendre angles with the
+// weights 2 w mu (as k_lbl_lw does per wavenumber).
+__global__ void __launch_bounds__(256)
+k_rt_lw_gpoints(int ncol, int nlay, int ng, int nsec, const double* __restrict__ sec_wgt /*[2][nsec]*/, const double* __restrict__ planck,
+                const double* __restrict__ od, double* __restrict__ dn, double* __restrict__ up) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)ncol * ng) return;
+  const size_t c = t / ng, g = t % ng;
+  const double* pl = planck + c * (size_t)(nlay + 1) * ng + g;
+  const double* tau = od + c * (size_t)nlay * ng + g;
+  double* fd = dn + c * (size_t)(nlay + 1) * ng + g;
+  double* fu = up + c * (size_t)(nlay + 1) * ng + g;
+  for (int l = 0; l <= nlay; ++l) { fd[(size_t)l * ng] = 0.0; fu[(size_t)l * ng] = 0.0; }
+  for (int a = 0; a < nsec; ++a) {
+    const double sec = sec_wgt[a], w = sec_wgt[nsec + a];
+    double f = 0.0;
+    for (int l = 0; l < nlay; ++l) {
+      const double x = tau[(size_t)l * ng];
+      const double e = 1.0 - exp(-sec * x);
+      const double fac = e > 1.0e-5 ? 1.0 - e * (1.0 / sec) / x : 0.5 * e;
+      f = f * (1.0 - e) + pl[(size_t)l * ng] * (e - fac) + pl[(size_t)(l + 1) * ng] * fac;
+      fd[(size_t)(l + 1) * ng] += w * f;
+    }
+    f = pl[(size_t)nlay * ng];
+    fu[(size_t)nlay * ng] += w * f;
+    for (int l = nlay - 1; l >= 0; --l) {
+      const double x = tau[(size_t)l * ng];
+      const double e = 1.0 - exp(-sec * x);
+      const double fac = e > 1.0e-5 ? 1.0 - e * (1.0 / sec) / x : 0.5 * e;
+      f = f * (1.0 - e) + pl[(size_t)(l + 1) * ng] * (e - fac) + pl[(size_t)l * ng] * fac;
+      fu[(size_t)l * ng] += w * f;
+    }
+  }
+}
+
+// direct beam and surface-reflected upwelling flux per g point: radiative_transfer_sw.cpp:45-77 (norayleigh)
+__global__ void __launch_bounds__(256)
+k_rt_sw_gpoints(int ncol, int nlay, int ng, double mu0, double albedo, const double* __restrict__ incoming /*[ncol][ng]*/,
+                const double* __restrict__ od, double* __restrict__ dn, double* __restrict__ up) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)ncol * ng) return;
+  const size_t c = t / ng, g = t % ng;
+  const double* tau = od + c * (size_t)nlay * ng + g;
+  double* fd = dn + c * (size_t)(nlay + 1) * ng + g;
+  double* fu = up + c * (size_t)(nlay + 1) * ng + g;
+  double f = mu0 * incoming[c * ng + g];
+  fd[0] = f;
+  for (int l = 0; l < nlay; ++l) { f = f * exp(-tau[(size_t)l * ng] / mu0); fd[(size_t)(l + 1) * ng] = f; }
+  f = f * albedo;
+  fu[(size_t)nlay * ng] = f;
+  for (int l = nlay - 1; l >= 0; --l) { f = f * exp(-2.0 * tau[(size_t)l * ng]); fu[(size_t)l * ng] = f; }
+}
+
 struct Buf {
   void* p = nullptr;
   ~Buf() { if (p) (void)hipFree(p); }
@@ -325,6 +380,69 @@ int ecckd_lbl_band_fluxes_sw_ex(ecckd_ctx* ctx, int nlay, size_t nwav, double co
     ECCKD_HIP_CHECK(hipGetLastError());
   }
   return combine(ctx, nlay, nband, chunks, (const double*)d_part.p, h_flux_dn_direct, h_flux_up);
+}
+
+// The fluxes of a CKD model's g points from the optical depths and Planck functions run_ckd wrote (the `--ckd` mode of the
+// CKDMIP tools as the scripts use them, test/run_ckd_lw.sh:133-137, test/run_ckd_sw.sh:125-128).  Host arrays in and out (a few
+// thousand values per column), the radiative transfer on the device.
+int ecckd_rt_lw_gpoints(ecckd_ctx* ctx, int nangle, int ncol, int nlay, int ng, const double* h_planck_hl, const double* h_od,
+                        double* h_flux_dn, double* h_flux_up) {
+  ECCKD_REQUIRE(ctx && ncol > 0 && nlay > 0 && ng > 0 && h_planck_hl && h_od && h_flux_dn && h_flux_up, "ecckd_rt_lw_gpoints: bad argument");
+  ECCKD_REQUIRE(nangle >= 0 && nangle <= LBL_MAX_ANGLES, "ecckd_rt_lw_gpoints: nangle %d outside 0..%d", nangle, LBL_MAX_ANGLES);
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const int nsec = nangle == 0 ? 1 : nangle;
+  std::vector<double> sw(2 * (size_t)nsec);
+  if (nangle == 0) { sw[0] = ECCKD_LW_DIFFUSIVITY; sw[1] = 1.0; }
+  else {
+    std::vector<double> mu(nangle), w(nangle);
+    ECCKD_CHECK(ecckd_gauss_legendre_01(nangle, mu.data(), w.data()));
+    for (int a = 0; a < nangle; ++a) { sw[a] = 1.0 / mu[a]; sw[nsec + a] = 2.0 * w[a] * mu[a]; }
+  }
+  const size_t nl = (size_t)ncol * nlay * ng, nh = (size_t)ncol * (nlay + 1) * ng;
+  const size_t b_sw = ecckd_align_up(sw.size() * sizeof(double), 256), b_l = ecckd_align_up(nl * sizeof(double), 256),
+               b_h = ecckd_align_up(nh * sizeof(double), 256);
+  ECCKD_CHECK(ecckd::ensure_scratch(ctx, b_sw + b_l + 3 * b_h));
+  char* q = (char*)ctx->scratch;
+  double* d_sw = (double*)q; q += b_sw;
+  double* d_od = (double*)q; q += b_l;
+  double* d_pl = (double*)q; q += b_h;
+  double* d_dn = (double*)q; q += b_h;
+  double* d_up = (double*)q;
+  ECCKD_HIP_CHECK(hipMemcpyAsync(d_sw, sw.data(), sw.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(d_od, h_od, nl * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(d_pl, h_planck_hl, nh * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_rt_lw_gpoints, dim3((unsigned)(((size_t)ncol * ng + 255) / 256)), dim3(256), 0, ctx->stream, ncol, nlay, ng, nsec, d_sw,
+                     d_pl, d_od, d_dn, d_up);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  ECCKD_HIP_CHECK(hipMemcpyAsync(h_flux_dn, d_dn, nh * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(h_flux_up, d_up, nh * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
+}
+
+int ecckd_rt_sw_gpoints(ecckd_ctx* ctx, int ncol, int nlay, int ng, double cos_sza, double albedo, const double* h_incoming,
+                        const double* h_od, double* h_flux_dn, double* h_flux_up) {
+  ECCKD_REQUIRE(ctx && ncol > 0 && nlay > 0 && ng > 0 && h_incoming && h_od && h_flux_dn && h_flux_up, "ecckd_rt_sw_gpoints: bad argument");
+  ECCKD_REQUIRE(cos_sza > 0.0, "ecckd_rt_sw_gpoints: cos_sza must be positive");
+  ECCKD_HIP_CHECK(hipSetDevice(ctx->device));
+  const size_t nl = (size_t)ncol * nlay * ng, nh = (size_t)ncol * (nlay + 1) * ng, ni = (size_t)ncol * ng;
+  const size_t b_i = ecckd_align_up(ni * sizeof(double), 256), b_l = ecckd_align_up(nl * sizeof(double), 256),
+               b_h = ecckd_align_up(nh * sizeof(double), 256);
+  ECCKD_CHECK(ecckd::ensure_scratch(ctx, b_i + b_l + 2 * b_h));
+  char* q = (char*)ctx->scratch;
+  double* d_in = (double*)q; q += b_i;
+  double* d_od = (double*)q; q += b_l;
+  double* d_dn = (double*)q; q += b_h;
+  double* d_up = (double*)q;
+  ECCKD_HIP_CHECK(hipMemcpyAsync(d_in, h_incoming, ni * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(d_od, h_od, nl * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_rt_sw_gpoints, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, ctx->stream, ncol, nlay, ng, cos_sza, albedo, d_in,
+                     d_od, d_dn, d_up);
+  ECCKD_HIP_CHECK(hipGetLastError());
+  ECCKD_HIP_CHECK(hipMemcpyAsync(h_flux_dn, d_dn, nh * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipMemcpyAsync(h_flux_up, d_up, nh * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ECCKD_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ECCKD_OK;
 }
 
 }  // extern "C"

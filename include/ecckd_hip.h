@@ -443,6 +443,15 @@ int ecckd_lbl_band_fluxes_lw_angles(ecckd_ctx* ctx, int nangle, int nlay, size_t
                                     double* h_flux_dn, double* h_flux_up, double* d_surf_dn, double* d_toa_up);
 /* Gauss-Legendre nodes mu_k (ascending) and weights w_k of n points on (0, 1): sum_k w_k f(mu_k) ~ int_0^1 f(mu) dmu. */
 int ecckd_gauss_legendre_01(int n, double* h_mu, double* h_weight);
+/* Fluxes per g point from what run_ckd wrote (optical depth [ncol][nlay][ng], Planck function [ncol][nlay+1][ng] or incoming
+ * solar flux [ncol][ng]): the `--ckd` evaluation of the CKDMIP tools as the scripts use it (test/run_ckd_lw.sh:133-137,
+ * test/run_ckd_sw.sh:125-128), restricted to the reference's own no-scattering transfer - radiative_transfer_lw.cpp:27-60 with
+ * unit emissivity (nangle as ecckd_lbl_band_fluxes_lw_angles) and radiative_transfer_sw.cpp:45-77.  Host arrays in and out
+ * ([ncol][nlay+1][ng] fluxes), the arithmetic on the device. */
+int ecckd_rt_lw_gpoints(ecckd_ctx* ctx, int nangle, int ncol, int nlay, int ng, const double* h_planck_hl, const double* h_od,
+                        double* h_flux_dn, double* h_flux_up);
+int ecckd_rt_sw_gpoints(ecckd_ctx* ctx, int ncol, int nlay, int ng, double cos_sza, double albedo, const double* h_incoming,
+                        const double* h_od, double* h_flux_dn, double* h_flux_up);
 
 int ecckd_lbl_band_fluxes_sw_ex(ecckd_ctx* ctx, int nlay, size_t nwav, double cos_sza, const double* d_ssi,
                                 const double* d_albedo, const void* d_od, int od_type, size_t od_stride, int nband,
