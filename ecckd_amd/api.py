@@ -75,6 +75,10 @@ class Context:
     def synchronize(self):
         check(self.lib.ecckd_synchronize(self.handle))
 
+    def trim_cache(self):
+        """Hand the device blocks that released handles have parked in the context back to the driver (ecckd_trim_cache)."""
+        check(self.lib.ecckd_trim_cache(self.handle))
+
     @property
     def torch_stream(self):
         """The context's HIP stream wrapped for torch (events must be recorded on it)."""

@@ -51,6 +51,11 @@ def run(ctx, nwav=7_200_000, nlay=54, tolerance=0.0161, workdir=None, keep=False
             e2e_bench._write_spectrum(os.path.join(top, name + ".nc"), name.split("_")[0], job.p, [job.t_file], job.wn_h, od.cpu().numpy(), vmr)
         names, gases = job.names, job.gases
         job.close()
+        # the tools are child processes on the SAME device: hand back what this process has parked (torch's cache, the blocks the
+        # library's allocator keeps for the next gas) - a six-gas job wants ~90 GB for itself
+        import torch
+        torch.cuda.empty_cache()
+        ctx.trim_cache()
         os.sync()
         write_s = time.perf_counter() - t0
         procs = []
