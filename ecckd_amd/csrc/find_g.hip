@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 #include <immintrin.h>
 
@@ -1999,7 +2000,7 @@ int wait_for_slots(hipStream_t stream, const double* h_slots, int count) {
       if (q != hipErrorNotReady)
         return ecckd::fail(ECCKD_UNEXPECTED_EXCEPTION, "device failure while waiting for interval errors: %s", hipGetErrorString(q));
     }
-    _mm_pause();
+    if ((spins & 0x3f) == 0 && ecckd::host_oversubscribed()) std::this_thread::yield(); else _mm_pause();
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   return ECCKD_OK;

@@ -362,6 +362,19 @@ struct ecckd_gas_search_job {
 
 namespace {
 
+// Host threads that wait on each other by spinning (band searches on their batcher, a batcher on its searches).  While there
+// are no more of them than cores they spin with a pause; with several multi-band gases searched side by side
+// (ecckd_find_g_gases) there are more, and every turn of a wait loop gives the core away so that the thread waited for runs.
+std::atomic<int> g_spinning_threads{0};
+inline bool oversubscribed() {
+  static const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+  return g_spinning_threads.load(std::memory_order_relaxed) > cores;
+}
+struct SpinningThread {
+  SpinningThread() { g_spinning_threads.fetch_add(1, std::memory_order_relaxed); }
+  ~SpinningThread() { g_spinning_threads.fetch_sub(1, std::memory_order_relaxed); }
+};
+
 // Merges the error evaluations that several band searches (one host thread each) ask for at the same time into one
 // ecckd_calc_error_multi call.  A search posts its batch in its own slot and spins on it; the thread that started the
 // searches (ecckd_find_g_bands_ex) watches the slots and runs the merged batch when EVERY search that is still going has
@@ -379,7 +392,7 @@ class BandBatcher {
     // (spin, then give the core away now and then: with several gases searched side by side there can be more searches than
     // cores, and the thread that serves the batch must get to run)
     for (unsigned spins = 1; s.state.load(std::memory_order_acquire) != DONE; ++spins) {
-      if ((spins & 0xfff) == 0) std::this_thread::yield(); else _mm_pause();
+      if ((spins & 0xfff) == 0 || ((spins & 0x1f) == 0 && oversubscribed())) std::this_thread::yield(); else _mm_pause();
     }
     s.state.store(IDLE, std::memory_order_relaxed);
     if (s.rc != ECCKD_OK) ecckd::fail(s.rc, "%s", s.message.c_str());   // the message was recorded on the thread that ran the batch
@@ -408,7 +421,8 @@ class BandBatcher {
         else if (st != LEFT) { complete = false; break; }
       }
       if (!complete || who.empty()) {
-        if ((++idle & 0xfff) == 0) std::this_thread::yield(); else _mm_pause();
+        ++idle;
+        if ((idle & 0xfff) == 0 || ((idle & 0x1f) == 0 && oversubscribed())) std::this_thread::yield(); else _mm_pause();
         continue;
       }
       idle = 0;
@@ -458,6 +472,10 @@ thread_local BatcherRef tl_batcher = {nullptr, -1};
 std::mutex g_band_device_mutex;
 
 }  // namespace
+
+namespace ecckd {
+bool host_oversubscribed() { return oversubscribed(); }
+}
 
 extern "C" {
 
@@ -642,6 +660,7 @@ int ecckd_find_g_bands_ex(ecckd_gas* g, int nband, const size_t* ibegin, const s
   threads.reserve(nband);
   for (int b = 0; b < nband; ++b) {
     threads.emplace_back([&, b] {
+      SpinningThread counted;
       tl_batcher = {&batcher, b};
       struct Leave {   // whatever way the search ends, the others must stop waiting for it
         BandBatcher& bb;
@@ -656,7 +675,10 @@ int ecckd_find_g_bands_ex(ecckd_gas* g, int nband, const size_t* ibegin, const s
       tl_batcher = {nullptr, -1};
     });
   }
-  batcher.serve();
+  {
+    SpinningThread counted;
+    batcher.serve();
+  }
   for (std::thread& t : threads) t.join();
   for (int b = 0; b < nband; ++b)
     if (rc[b] != ECCKD_OK) return ecckd::fail(rc[b], "band %d: %s", b, message[b].c_str());
@@ -714,9 +736,10 @@ int ecckd_find_g_gases_add(ecckd_gas_search_job* job, ecckd_gas_search* r) {
   job->req.push_back(r);
   job->message.emplace_back();
   std::string* const msg = &job->message.back();
-  // a gas with several bands runs a thread per band and one that serves their batches: not more spinning threads than the host
-  // has cores (width <= 0: what the cores allow)
-  const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+  // a gas with several bands runs a thread per band and one that serves their batches; they wait for each other by spinning
+  // and yield the core when there are more of them than cores (oversubscribed()), so the limit is generous: four threads per
+  // core (width <= 0: what that allows; 13 bands on 16 cores: four gases at a time)
+  const int cores = 4 * (int)std::max(1u, std::thread::hardware_concurrency());
   const int per_gas = (r->nband > 1 || g->do_sw) ? r->nband + 1 : 1;
   // a search that re-ranks its base g point by wavenumber (ecckd_regroup_rank_by_wavenumber_dev) works on the context's stream
   // with the context's scratch, which the caller may be using for the next gas's preparation: such a gas is searched here and now

@@ -6,6 +6,10 @@
 #include <unordered_map>
 #include <vector>
 
+namespace ecckd {
+bool host_oversubscribed();     // find_g_band.hip: more spinning search / batcher threads than cores (they then yield while waiting)
+}
+
 // Row table of a gas: which summable per-point rows exist and where (indices into
 // ecckd_gas::rows / the per-interval sums).  Blocks of nlay consecutive rows start at the
 // given offsets; -1 = absent.
