@@ -632,6 +632,15 @@ inline uint64_t fnv1a(const void* data, size_t n, uint64_t h = 0xcbf29ce48422232
 }
 inline uint64_t fnv1a(const std::string& s, uint64_t h = 0xcbf29ce484222325ull) { return fnv1a(s.data(), s.size() + 1, h); }
 
+// A tool that fails may have searches of other gases in flight on their own threads and streams (find_g_points): the process ends
+// at once with the reference's exit code, without unwinding statics under those threads.
+inline int failed(int code) {
+  std::fflush(stdout);
+  std::fflush(stderr);
+  std::_Exit(code);
+  return code;
+}
+
 // ---- main wrapper: exit codes like THROW(code) (Logging.h:115-117) ----
 template <class Body>
 int run(int argc, char** argv, Body body) {
@@ -649,11 +658,11 @@ int run(int argc, char** argv, Body body) {
   } catch (const Fatal& f) {
     std::fprintf(stderr, "*** Error: %s\n", f.msg.c_str());
     note_failure(f.code ? f.code : 1);
-    return f.code ? f.code : 1;
+    return failed(f.code ? f.code : 1);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "*** Error: %s\n", e.what());
     note_failure(ECCKD_UNEXPECTED_EXCEPTION);
-    return ECCKD_UNEXPECTED_EXCEPTION;
+    return failed(ECCKD_UNEXPECTED_EXCEPTION);
   }
 }
 

@@ -68,8 +68,11 @@ def run(ctx, nwav=7_200_000, nlay=54, tolerance=0.0161, workdir=None, keep=False
             if r.returncode != 0:
                 raise RuntimeError(f"{name} failed ({r.returncode}): {r.stderr[-2000:]}")
             stamps = re.findall(r"^\[\s*([0-9.]+)\]", r.stdout, flags=re.M)
-            procs.append({"tool": name, "args": " ".join(str(a) for a in args)[:80], "seconds": round(dt, 3),
-                          "last_log_stamp": float(stamps[-1]) if stamps else None})
+            rec = {"tool": name, "args": " ".join(str(a) for a in args)[:80], "seconds": round(dt, 3),
+                   "last_log_stamp": float(stamps[-1]) if stamps else None}
+            if name == "find_g_points":       # where its time goes: the tool's own clock in front of its log lines
+                rec["log"] = [ln[:110] for ln in r.stdout.splitlines() if ln.startswith("[") and "g point " not in ln and "Band " not in ln][:120]
+            procs.append(rec)
             return dt, r
 
         t_reorder = 0.0
