@@ -367,6 +367,17 @@ def ckd_model_sw(model, seed=0):
 L2_GATHER_PEAK_GBS = 17600.0   # MI355X_MICROARCH.md, L2 section: rows shared by every workgroup gathered from the XCDs' L2s, 16.8-18.8 TB/s
 
 
+def _lut_opt_traffic(sw):
+    if sw:
+        return None
+    for r in (4,):
+        q = os.path.join(ROOT, "profiles", "r%02d_traffic_lut_opt.json" % r)
+        if os.path.exists(q):
+            with open(q) as f:
+                return json.load(f)["corrected_bytes_per_iteration"]
+    return None
+
+
 def lut_opt_cpu_baseline(model, scenes, cfg, evaluations=10):
     """The serial CPU side of one optimize_lut iteration (solve_adept.cpp:72-211 + calc_background_cost_function,
     ckd_model.cpp:840-877), ONE thread as the reference runs it (optimize_lut.cpp:159): the oracle's forward model
@@ -477,7 +488,9 @@ def lut_opt_bench(ctx, iterations, sharded=False, rank=0, world=1, sw=False, cpu
                        "floor_us_per_iteration": bytes_it / (L2_GATHER_PEAK_GBS * 1e9) * 1e6,
                        "measured_us_per_iteration": 1e6 / out["iters_per_s"],
                        "launches_per_iteration": 8, "host_waits_per_iteration": 2,
-                       "traffic": None,
+                       # HBM bytes per iteration from the committed counter passes (2 x FETCH_SIZE + WRITE_SIZE of the optimiser's
+                       # kernels, tools/opt_traffic.py): the gathers themselves are served by the L2s
+                       "traffic": _lut_opt_traffic(sw),
                        "note": "kernel averages of the same command: profiles/r03_opt_kernel_stats.csv"}
     if cpu and not sw and not sharded:
         out["cpu_baseline"] = lut_opt_cpu_baseline(model, scenes, cfg)
