@@ -302,6 +302,32 @@ def reorder_spectrum(ctx, input_path, output_path, band_bound1, band_bound2, ipr
     return dict(spectrum=s, key=key, column_optical_depth=col, band_number=iband, rank=rank)
 
 
+def reorder_single_band_sharded(ctx, pressure_hl, wn, dwn, od, threshold_optical_depth=0.5, group=None):
+    """reorder_spectrum of ONE longwave band (the fsck structure) with the key sweep split by wavenumber range over the processes
+    of `group`: every process runs K1 on its own whole-tile range of the resident spectrum, the keys and column
+    optical depths travel to rank 0 once (16 B per wavenumber), rank 0 runs the one stable sort (K3).  A wavenumber's key is a
+    function of its column alone, so key, column optical depth and rank have the bits one process gives.
+    -> (key, col_od, rank) device tensors on rank 0, (None, None, None) elsewhere."""
+    from . import shard
+    t_ideal = api.idealised_temperature(pressure_hl)
+    nwav = od.shape[1]
+
+    def key_of_range(b, e):
+        if e <= b:
+            import torch
+            z = torch.empty(0, dtype=torch.float64, device=ctx.device)
+            return z, z
+        key, col = api.reorder_key_lw(ctx, pressure_hl, t_ideal, wn[b:e], dwn[b:e], od[:, b:e], threshold_optical_depth)
+        ctx.synchronize()
+        return key, col
+
+    def sort_on_root(key):
+        rnk, _ = api.stable_argsort_bands(ctx, key, [0], [nwav - 1], want_ordered=False)
+        return rnk
+
+    return shard.reorder_single_band(key_of_range, nwav, sort_on_root, group=group, device=ctx.device)
+
+
 def _prepare_gas(ctx, g, averaging_method, flux_weight, min_pressure, planck_reuse=None, sw=None):
     """Gas preparation (find_g_points.cpp:872-1150) of one gas whose spectra are on the device, and its sorting variable in
     sorted order (:781).  g, sw, planck_reuse: see _search_gas.  -> (gas handle, sorting variable sorted, band albedo or None)"""

@@ -81,6 +81,62 @@ def reduce_scalars(elapsed_s, passes, cost, device=None, group=None, count=False
     return out + (int(round(float(np.add.reduce(b[:, 3])))),) if count else out
 
 
+# ---- reorder_spectrum of ONE band on several GPUs: the key sweep split by wavenumber range (reorder row) ----------
+
+def wavenumber_range(nwav, rank, world_size, align=256):
+    """Contiguous share [begin, end) of the nwav wavenumbers owned by `rank`: shares of whole `align`-point tiles (the key
+    kernel's block) whose sizes differ by at most one tile; the last rank takes the ragged end."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    ntile = (nwav + align - 1) // align
+    base, extra = divmod(ntile, world_size)
+    t0 = rank * base + min(rank, extra)
+    t1 = t0 + base + (1 if rank < extra else 0)
+    return min(t0 * align, nwav), min(t1 * align, nwav)
+
+
+def reorder_single_band(key_of_range, nwav, sort_on_root, group=None, device=None):
+    """reorder_spectrum.cpp:111-300 for ONE band (the fsck structure) on several processes: the sorting key of a wavenumber
+    depends on that wavenumber's column alone (:162-228), so every rank sweeps its own range - `key_of_range(begin, end)` ->
+    (key, column optical depth) of [begin, end), float64 tensors or arrays - the pieces are gathered on rank 0 in rank order
+    (the exchange step of this stage: 16 B per wavenumber, once) and rank 0 sorts: `sort_on_root(key)` -> rank (the per-band
+    stable sort, :262-300, is one sort for one band).  Returns (key, col_od, rank) on rank 0, (None, None, None) elsewhere.
+    Without a process group: everything on this process."""
+    import torch
+    r, ws = world(group)
+    b, e = wavenumber_range(nwav, r, ws)
+    key, col = key_of_range(b, e)
+    key = torch.as_tensor(key, dtype=torch.float64)
+    col = torch.as_tensor(col, dtype=torch.float64)
+    if ws > 1:
+        import torch.distributed as dist
+        nccl = dist.get_backend(group) == "nccl"
+        mine = torch.stack([key, col]).contiguous()                      # (2, n_r)
+        if not nccl:
+            mine = mine.cpu()
+        sizes = [wavenumber_range(nwav, q, ws)[1] - wavenumber_range(nwav, q, ws)[0] for q in range(ws)]
+        pieces = [torch.empty((2, n), dtype=torch.float64, device=mine.device) for n in sizes] if r == 0 else None
+        dist.gather(mine, pieces, dst=0, group=group) if len(set(sizes)) == 1 else _gather_ragged(mine, pieces, sizes, r, ws, group)
+        if r != 0:
+            return None, None, None
+        whole = torch.cat(pieces, dim=1)
+        key, col = whole[0], whole[1]
+        if device is not None:
+            key, col = key.to(device), col.to(device)
+    return key, col, sort_on_root(key)
+
+
+def _gather_ragged(mine, pieces, sizes, r, ws, group):
+    """gather of pieces of different lengths: point-to-point to rank 0 in rank order"""
+    import torch.distributed as dist
+    if r == 0:
+        pieces[0].copy_(mine)
+        for q in range(1, ws):
+            dist.recv(pieces[q], src=q, group=group)
+    else:
+        dist.send(mine, dst=0, group=group)
+
+
 # ---- optimize_lut: training profiles sharded over the ranks (SURVEY 8e, optimize_lut row) -------------------
 
 _PER_COLUMN = ("pressure_hl", "temperature_hl", "vmr_fl", "flux_dn", "flux_up", "spectral_flux_dn_surf", "spectral_flux_up_toa",

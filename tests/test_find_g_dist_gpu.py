@@ -135,3 +135,48 @@ def test_planck_matrix_of_an_ordering_is_the_gas_preparations(ctx, nlay):
     e_a = a.calc_error_batch(0, n, [0.0, 0.4], [0.4, 1.0])
     assert np.array_equal(e_a, b.calc_error_batch(0, n, [0.0, 0.4], [0.4, 1.0]))
     a.close(); b.close(); first.close()
+
+
+def _reorder_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ecckd_amd import api, pipeline
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with api.Context(0) as ctx:
+            n, nlay = 70_001, 54
+            p = syn.pressure_grid(nlay)
+            wn_h, dwn_h = syn.wavenumber_grid(n)
+            od = torch.as_tensor(syn.optical_depth(np, p, wn_h, syn.SEED_BASE + 5, nlines=40), device=ctx.device)
+            wn, dwn = torch.as_tensor(wn_h, device=ctx.device), torch.as_tensor(dwn_h, device=ctx.device)
+            key, col, rnk = pipeline.reorder_single_band_sharded(ctx, p, wn, dwn, od, 0.5)
+            out = None
+            if rank == 0:
+                k1, c1 = api.reorder_key_lw(ctx, p, api.idealised_temperature(p), wn, dwn, od, 0.5)
+                r1, _ = api.stable_argsort_bands(ctx, k1, [0], [n - 1], want_ordered=False)
+                out = (bool(torch.equal(key, k1)), bool(torch.equal(col, c1)), bool(torch.equal(rnk, r1)))
+        q.put((rank, out))
+    except Exception as exc:
+        q.put((rank, repr(exc)))
+        raise
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_band_reorder_split_by_wavenumber_range(ctx):
+    """one band (fsck) reordered by two processes - each sweeps its own wavenumber range (K1), rank 0 gathers and sorts:
+    key, column optical depth and rank equal the single-process ones bit for bit."""
+    world = 2
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_reorder_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0] == (True, True, True) and res[1] is None

@@ -180,3 +180,75 @@ def test_deal_tasks_contiguous_and_complete():
     with pytest.raises(ValueError):
         shard.deal_tasks(10, 3, 3)
     assert shard.world() == (0, 1) and shard.gather_to_root("x") == ["x"]
+
+
+def _reorder_worker(rank, world, port, q, nwav):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    from ecckd_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rs = np.random.RandomState(7)
+    key_all = rs.normal(size=nwav)
+    key_all[rs.uniform(size=nwav) < 0.05] = -0.5            # a tie group, as the zero columns of a spectrum give
+    col_all = np.abs(rs.normal(size=nwav))
+    seen = []
+
+    def key_of_range(b, e):                                 # stand-in for K1 over this rank's wavenumbers
+        seen.append((b, e))
+        return key_all[b:e], col_all[b:e]
+
+    def sort_on_root(key):                                  # std::stable_sort of the indices by key, then rank[ordered[i]] = i
+        order = np.argsort(key.numpy(), kind="stable")
+        rank_of = np.empty(nwav, dtype=np.int32)
+        rank_of[order] = np.arange(nwav, dtype=np.int32)
+        return rank_of
+
+    key, col, rnk = shard.reorder_single_band(key_of_range, nwav, sort_on_root)
+    q.put((rank, seen, None if key is None else (key.numpy().tobytes(), col.numpy().tobytes(), rnk.tobytes())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nwav", [70_001, 4096])
+def test_single_band_reorder_with_the_key_sweep_split_by_range(nwav):
+    """SURVEY 8e, reorder row, one band (the fsck structure): the key sweep split by wavenumber range over two gloo ranks, the
+    pieces gathered on rank 0, one stable sort there - the same key, column optical depth and rank as one process gives, the
+    ranges whole tiles, disjoint and complete (ragged last share)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reorder_worker, args=(r, world, port, q, nwav)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (b0, e0), (b1, e1) = res[0][1][0], res[1][1][0]
+    assert b0 == 0 and e0 == b1 and e1 == nwav and e0 % 256 == 0 and abs((e0 - b0) - (e1 - b1)) < 512
+    assert res[1][2] is None
+    rs = np.random.RandomState(7)
+    key_all = rs.normal(size=nwav)
+    key_all[rs.uniform(size=nwav) < 0.05] = -0.5
+    col_all = np.abs(rs.normal(size=nwav))
+    order = np.argsort(key_all, kind="stable")
+    rank_of = np.empty(nwav, dtype=np.int32)
+    rank_of[order] = np.arange(nwav, dtype=np.int32)
+    assert res[0][2] == (key_all.tobytes(), col_all.tobytes(), rank_of.tobytes())
+
+
+def test_wavenumber_range_properties():
+    from ecckd_amd import shard
+    for nwav in (1, 255, 256, 257, 7_200_000, 3_300_001):
+        for world in (1, 2, 3, 8):
+            pieces = [shard.wavenumber_range(nwav, r, world) for r in range(world)]
+            assert pieces[0][0] == 0 and pieces[-1][1] == nwav
+            assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+            assert all(b % 256 == 0 for b, _ in pieces if b < nwav)
+            sizes = [e - b for b, e in pieces]
+            assert max(sizes) - min(sizes) <= 256 + 255
