@@ -183,6 +183,8 @@ SIGNATURES = {
     "ecckd_nc_def_var": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ecckd_nc_put_att_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     "ecckd_nc_put_att_double": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, _c_double_p]),
+    "ecckd_nc_deflate_var": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "ecckd_nc_is_netcdf4": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ecckd_nc_enddef": (C.c_int, [C.c_void_p]),
     "ecckd_nc_write_double": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p, C.c_size_t]),
     "ecckd_nc_write_slice_double": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, _c_double_p, C.c_size_t]),

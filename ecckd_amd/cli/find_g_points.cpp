@@ -711,7 +711,11 @@ int main(int argc, char** argv) {
     }
     file.var("wavenumber", NC_DOUBLE_T, {"wavenumber"}, "Wavenumber", "cm-1");
     file.var("g_point", NC_SHORT_T, {"wavenumber"}, "G point of each wavenumber");
-    for (const GasResult& g : gases) file.var(g.molecule + "_g_point", NC_SHORT_T, {"wavenumber"}, "Single-gas g point of each wavenumber");
+    file.deflate("g_point");                                               // find_g_points.cpp:1580
+    for (const GasResult& g : gases) {
+      file.var(g.molecule + "_g_point", NC_SHORT_T, {"wavenumber"}, "Single-gas g point of each wavenumber");
+      file.deflate(g.molecule + "_g_point");                               // :1587
+    }
     file.att(do_sw ? "Definition of the spectral intervals of a shortwave CKD model"
                    : "Definition of the spectral intervals of a longwave CKD model", "title");
     file.att(molecule_list, "constituent_id");

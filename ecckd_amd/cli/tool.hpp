@@ -291,6 +291,8 @@ class NcOut {
   void att(const std::string& text, const std::string& name, const char* var = nullptr) {
     ck(ecckd_nc_put_att_text(f_, var, name.c_str(), text.c_str()));
   }
+  // OutputDataFile::deflate_variable (:345-359): shuffle + deflate level 2 where the file is NetCDF-4 (*.h5 / *.hdf), nothing otherwise
+  void deflate(const std::string& name) { ck(ecckd_nc_deflate_var(f_, name.c_str())); }
   void end_define() { ck(ecckd_nc_enddef(f_)); }
   void write(const std::string& name, const std::vector<double>& v) { ck(ecckd_nc_write_double(f_, name.c_str(), v.data(), v.size())); }
   void write_slice(const std::string& name, size_t slice, const std::vector<double>& v) {

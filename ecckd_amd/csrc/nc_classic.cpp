@@ -2,7 +2,8 @@
 // (CDF-1, CDF-2 "64-bit offset", CDF-5 "64-bit data"), which is what the reference produces and
 // consumes for files named *.nc / *.cdf (src/tools/DataFile.cpp:88-96, OutputDataFile.cpp:84-157).
 // The image has no NetCDF library.  NetCDF-4 files (HDF5 containers) are recognised by their signature and READ
-// through nc_hdf5.cpp (the system's HDF5 library, loaded at run time); everything written is classic.
+// through nc_hdf5.cpp (the system's HDF5 library, loaded at run time); files named *.h5 / *.hdf are WRITTEN as NetCDF-4 through
+// nc_hdf5_write.cpp where that library (and its high-level library) can be loaded, classic otherwise.
 //
 // Layout (NetCDF classic format specification): big-endian throughout;
 //   header = magic numrecs dim_list gatt_list var_list;  lists = tag(4) nelems [entries] or ABSENT (two zeros);
@@ -58,6 +59,7 @@ struct Var {
   int type = 0;
   uint64_t vsize = 0, begin = 0;
   bool record = false;
+  bool deflate = false;    // NetCDF-4 output only: deflate_variable (OutputDataFile.cpp:345-359)
   bool past_end = false;   // the header places (part of) its data beyond the end of the file: refused when asked for, see open
 };
 
@@ -141,6 +143,8 @@ void decode_run(const unsigned char* p, int t, double* out, size_t n) {
 
 struct ecckd_nc {
   ecckd::H5File* h5 = nullptr;   // set for a NetCDF-4 file opened for reading; the classic fields are then unused
+  bool netcdf4 = false;          // a file being WRITTEN as NetCDF-4 (its name ends in .h5 / .hdf, OutputDataFile.cpp:84-111)
+  ecckd::H5Writer* h5w = nullptr;
   FILE* fp = nullptr;
   bool writing = false, defining = false;
   int version = 1;
@@ -393,6 +397,12 @@ int ecckd_nc_close(ecckd_nc* f) {
   if (!f) return ECCKD_OK;
   if (f->h5) { ecckd::h5_close(f->h5); delete f; return ECCKD_OK; }
   int rc = ECCKD_OK;
+  if (f->netcdf4) {
+    if (f->defining) rc = ecckd::fail(ECCKD_PROCESSING_ERROR, "%s closed while still in define mode", f->path.c_str());
+    const int rc2 = ecckd::h5w_close(f->h5w);
+    delete f;
+    return rc != ECCKD_OK ? rc : rc2;
+  }
   if (f->writing && f->defining) rc = ecckd::fail(ECCKD_PROCESSING_ERROR, "%s closed while still in define mode", f->path.c_str());
   if (f->fp && std::fclose(f->fp) != 0) rc = ecckd::fail(ECCKD_PROCESSING_ERROR, "error closing %s", f->path.c_str());
   delete f;
@@ -586,6 +596,22 @@ int ecckd_nc_read_att_double(ecckd_nc* f, const char* var, const char* att, int*
 int ecckd_nc_create(const char* path, ecckd_nc** out) {
   ECCKD_REQUIRE(path && out, "ecckd_nc_create: NULL argument");
   *out = nullptr;
+  // The reference picks the format by the file name (OutputDataFile.cpp:84-111): .nc / .cdf -> classic, .h5 / .hdf -> NetCDF-4.
+  // NetCDF-4 needs the HDF5 library and its high-level library at run time (nc_hdf5_write.cpp); where they are missing, or with
+  // ECCKD_CLASSIC_OUTPUT set, the file is written in the classic format under the name asked for (the NetCDF library and this
+  // repository's reader key on the content, not the name).
+  const std::string name(path);
+  const size_t dot = name.find_last_of('.');
+  const std::string ext = dot == std::string::npos ? std::string() : name.substr(dot + 1);
+  const bool wants4 = (ext == "h5" || ext == "hdf") && std::getenv("ECCKD_CLASSIC_OUTPUT") == nullptr;
+  if (wants4 && ecckd::h5w_available(nullptr)) {
+    ecckd_nc* f = new ecckd_nc;
+    f->path = path;
+    f->netcdf4 = true;
+    f->writing = f->defining = true;
+    *out = f;
+    return ECCKD_OK;
+  }
   FILE* fp = std::fopen(path, "wb");
   if (!fp) return ecckd::fail(ECCKD_PARAMETER_ERROR, "cannot open %s for writing", path);
   ecckd_nc* f = new ecckd_nc;
@@ -651,8 +677,47 @@ int ecckd_nc_put_att_double(ecckd_nc* f, const char* var, const char* att, int n
   return ECCKD_OK;
 }
 
+// deflate_variable (OutputDataFile.cpp:345-359): shuffle + deflate level 2 in a NetCDF-4 file, nothing in a classic one
+int ecckd_nc_deflate_var(ecckd_nc* f, const char* name) {
+  ECCKD_REQUIRE(f && f->defining && name, "ecckd_nc_deflate_var: bad argument");
+  Var* v = f->find(name);
+  if (!v) return ecckd::fail(ECCKD_PARAMETER_ERROR, "ecckd_nc_deflate_var: no variable \"%s\"", name);
+  v->deflate = true;
+  return ECCKD_OK;
+}
+
+int ecckd_nc_is_netcdf4(ecckd_nc* f, int* is_netcdf4) {
+  ECCKD_REQUIRE(f && is_netcdf4, "ecckd_nc_is_netcdf4: NULL argument");
+  *is_netcdf4 = (f->netcdf4 || f->h5) ? 1 : 0;
+  return ECCKD_OK;
+}
+
 int ecckd_nc_enddef(ecckd_nc* f) {
   ECCKD_REQUIRE(f && f->writing && f->defining, "ecckd_nc_enddef: not in define mode");
+  if (f->netcdf4) {
+    auto conv = [](const Att& a) {
+      ecckd::H5WAtt o;
+      o.name = a.name;
+      o.nc_type = a.type;
+      if (a.type == NC_CHAR) o.text.assign((const char*)a.raw.data(), a.raw.size());
+      else for (size_t i = 0; i < a.nelems; ++i) o.values.push_back(decode(a.raw.data() + i * type_size(a.type), a.type));
+      return o;
+    };
+    std::vector<ecckd::H5WDim> dims;
+    for (const Dim& d : f->dims) { ecckd::H5WDim o; o.name = d.name; o.len = d.len; dims.push_back(o); }
+    std::vector<ecckd::H5WVar> vars;
+    for (const Var& v : f->vars) {
+      ecckd::H5WVar o;
+      o.name = v.name; o.nc_type = v.type; o.dimids = v.dimids; o.deflate = v.deflate;
+      for (const Att& a : v.atts) o.atts.push_back(conv(a));
+      vars.push_back(o);
+    }
+    std::vector<ecckd::H5WAtt> gatts;
+    for (const Att& a : f->gatts) gatts.push_back(conv(a));
+    ECCKD_CHECK(ecckd::h5w_create(f->path.c_str(), dims, vars, gatts, &f->h5w));
+    f->defining = false;
+    return ECCKD_OK;
+  }
   // sizes first: they decide the format variant (CDF-1: every offset < 2 GiB; CDF-2: every variable < 4 GiB; else CDF-5)
   uint64_t data_bytes = 0, max_var = 0;
   for (Var& v : f->vars) {
@@ -739,6 +804,7 @@ int ecckd_nc_write_double(ecckd_nc* f, const char* name, const double* data, siz
   uint64_t nel = 1;
   for (int id : v->dimids) nel *= f->dims[id].len;
   ECCKD_REQUIRE(count == nel, "ecckd_nc_write_double: \"%s\" has %llu elements, %zu given", name, (unsigned long long)nel, count);
+  if (f->netcdf4) return ecckd::h5w_write(f->h5w, (int)(v - f->vars.data()), -1, data, count);
   return write_values(f, *v, name, v->begin, data, count);
 }
 
@@ -753,6 +819,7 @@ int ecckd_nc_write_slice_double(ecckd_nc* f, const char* name, size_t slice, con
   for (size_t k = 1; k < v->dimids.size(); ++k) per *= f->dims[v->dimids[k]].len;
   ECCKD_REQUIRE(slice < f->dims[v->dimids[0]].len && count == per, "ecckd_nc_write_slice_double: \"%s\" slice %zu / %zu values do not fit",
                 name, slice, count);
+  if (f->netcdf4) return ecckd::h5w_write(f->h5w, (int)(v - f->vars.data()), (long long)slice, data, count);
   return write_values(f, *v, name, v->begin + (uint64_t)slice * per * type_size(v->type), data, count);
 }
 
@@ -804,6 +871,9 @@ int ecckd_write_order_file(const char* path, const char* molecule, const char* c
   }
   if (history) NCTRY(ecckd_nc_put_att_text(f, nullptr, "history", history));
   NCTRY(ecckd_nc_put_att_text(f, nullptr, "config", config_str ? config_str : ""));
+  // write_order.cpp:59-94 deflates every per-wavenumber variable (a NetCDF-4 file only)
+  for (const char* v : {"wavenumber", "d_wavenumber", "band_number", "rank", "sorting_variable"}) NCTRY(ecckd_nc_deflate_var(f, v));
+  if (column_optical_depth) NCTRY(ecckd_nc_deflate_var(f, "column_optical_depth"));
   NCTRY(ecckd_nc_enddef(f));
   NCTRY(ecckd_nc_write_double(f, "wavenumber1_band", band_bound1, (size_t)nband));
   NCTRY(ecckd_nc_write_double(f, "wavenumber2_band", band_bound2, (size_t)nband));

@@ -194,13 +194,41 @@ void h5_close(H5File* h) {
   delete h;
 }
 
+// A variable that shares its name with a dimension it is not the coordinate variable of (the g-points file: dimension
+// "g_point" = number of g points, variable "g_point"(wavenumber)) is stored under "_nc4_non_coord_<name>" (NetCDF-4 format);
+// the plain name is then the dimension's scale dataset.
+static std::string dataset_of_variable(H5File* h, const char* name) {
+  const std::string alt = std::string("_nc4_non_coord_") + name;
+  return h->a->H5Lexists(h->file, alt.c_str(), 0) > 0 ? alt : std::string(name);
+}
+
+static int inq_dataset(H5File* h, const char* name, int* exists, int* nc_type, int* ndims, size_t* shape, int shape_capacity);
+
 int h5_inq_var(H5File* h, const char* name, int* exists, int* nc_type, int* ndims, size_t* shape, int shape_capacity) {
+  const std::string ds = dataset_of_variable(h, name);
+  int want_type = 0;
+  return inq_dataset(h, ds.c_str(), exists, nc_type ? nc_type : &want_type, ndims, shape, shape_capacity);
+}
+
+static int inq_dataset(H5File* h, const char* name, int* exists, int* nc_type, int* ndims, size_t* shape, int shape_capacity) {
   Api* a = h->a;
   *exists = a->H5Lexists(h->file, name, 0) > 0 ? 1 : 0;
   if (!*exists) return ECCKD_OK;
   const hid_t d = a->H5Dopen2(h->file, name, 0);
   if (d < 0) { *exists = 0; return ECCKD_OK; }   // a group, not a variable
   const hid_t sp = a->H5Dget_space(d), t = a->H5Dget_type(d);
+  // a dimension without a coordinate variable is a data-less scale dataset whose NAME says so (NetCDF-4 format): it has a
+  // length (ecckd_nc_inq_dim) but is no variable
+  if (nc_type && a->H5Aexists_by_name(h->file, name, "NAME", 0) > 0) {
+    char text[80] = "";
+    int ex = 0;
+    if (h5_read_att_text(h, name, "NAME", &ex, text, sizeof text) == ECCKD_OK && ex &&
+        std::strncmp(text, "This is a netCDF dimension but not a netCDF variable.", 53) == 0) {
+      *exists = 0;
+      a->H5Tclose(t); a->H5Sclose(sp); a->H5Dclose(d);
+      return ECCKD_OK;
+    }
+  }
   const int nd = a->H5Sget_simple_extent_ndims(sp);
   hsize_t dims[32] = {};
   if (nd > 0) a->H5Sget_simple_extent_dims(sp, dims, nullptr);
@@ -218,14 +246,16 @@ int h5_inq_var(H5File* h, const char* name, int* exists, int* nc_type, int* ndim
 int h5_inq_dim(H5File* h, const char* name, size_t* len) {
   int exists = 0, nd = 0;
   size_t shape[32];
-  ECCKD_CHECK(h5_inq_var(h, name, &exists, nullptr, &nd, shape, 32));   // a NetCDF-4 dimension is a (scale) dataset of its name
+  ECCKD_CHECK(inq_dataset(h, name, &exists, nullptr, &nd, shape, 32));   // a NetCDF-4 dimension is a (scale) dataset of its name
   if (!exists || nd != 1) return fail(ECCKD_PARAMETER_ERROR, "%s: no dimension \"%s\"", h->path.c_str(), name);
   *len = shape[0];
   return ECCKD_OK;
 }
 
-int h5_read_double(H5File* h, const char* name, long long slice, double* out, size_t capacity) {
+int h5_read_double(H5File* h, const char* var_name, long long slice, double* out, size_t capacity) {
   Api* a = h->a;
+  const std::string ds = dataset_of_variable(h, var_name);
+  const char* name = ds.c_str();
   if (a->H5Lexists(h->file, name, 0) <= 0) return fail(ECCKD_PARAMETER_ERROR, "%s: no variable \"%s\"", h->path.c_str(), name);
   const hid_t d = a->H5Dopen2(h->file, name, 0);
   if (d < 0) return fail(ECCKD_PARAMETER_ERROR, "%s: cannot open variable \"%s\"", h->path.c_str(), name);
@@ -265,8 +295,10 @@ int h5_read_double(H5File* h, const char* name, long long slice, double* out, si
 // out of the file (H5Dread_chunk: no filter pipeline, the library is not thread-safe), worker threads inflate, unshuffle and
 // place them - the HDF5 library would do all of that on the one calling thread.  *handled = false: the layout is not
 // one this path takes apart (contiguous, other filters, big-endian, missing chunks, old library); the caller falls back to H5Dread.
-int h5_read_real_parallel(H5File* h, const char* name, long long slice, int out_type, void* out, size_t capacity, bool* handled) {
+int h5_read_real_parallel(H5File* h, const char* var_name, long long slice, int out_type, void* out, size_t capacity, bool* handled) {
   Api* a = h->a;
+  const std::string ds = dataset_of_variable(h, var_name);
+  const char* name = ds.c_str();
   *handled = false;
   if (!a->H5Dread_chunk || !a->H5Dget_chunk_storage_size || !a->H5Dget_create_plist || !a->H5Pget_layout || !a->H5Pget_chunk ||
       !a->H5Pget_nfilters || !a->H5Pget_filter2 || !a->H5Pclose || !a->H5Tget_order || !a->z_uncompress ||
@@ -419,8 +451,10 @@ void h5_chunks_close(H5ChunkReader* r) {
 }
 
 // *out = nullptr (and ECCKD_OK) if the variable's layout is not [shuffle,] deflate over little-endian FLOAT / DOUBLE chunks
-int h5_chunks_open(H5File* h, const char* name, long long slice, size_t capacity, H5ChunkReader** out, H5ChunkPlan* plan) {
+int h5_chunks_open(H5File* h, const char* var_name, long long slice, size_t capacity, H5ChunkReader** out, H5ChunkPlan* plan) {
   Api* a = h->a;
+  const std::string ds = dataset_of_variable(h, var_name);
+  const char* name = ds.c_str();
   *out = nullptr;
   if (!a->H5Dread_chunk || !a->H5Dget_chunk_storage_size || !a->H5Dget_create_plist || !a->H5Pget_layout || !a->H5Pget_chunk ||
       !a->H5Pget_nfilters || !a->H5Pget_filter2 || !a->H5Pclose || !a->H5Tget_order)
@@ -542,7 +576,8 @@ const char* h5_path(H5File* h) { return h->path.c_str(); }
 
 static hid_t open_att(H5File* h, const char* var, const char* att) {
   Api* a = h->a;
-  const char* obj = (var && var[0]) ? var : "/";
+  const std::string ds = (var && var[0]) ? dataset_of_variable(h, var) : std::string("/");
+  const char* obj = ds.c_str();
   if (obj[0] != '/' && a->H5Lexists(h->file, obj, 0) <= 0) return -2;
   if (a->H5Aexists_by_name(h->file, obj, att, 0) <= 0) return -1;
   return a->H5Aopen_by_name(h->file, obj, att, 0, 0);

@@ -1,6 +1,8 @@
 // nc_hdf5.hpp - the NetCDF-4 (HDF5) read backend behind ecckd_nc_* (csrc/nc_hdf5.cpp); classic files: nc_classic.cpp
 #pragma once
 #include <cstddef>
+#include <string>
+#include <vector>
 
 namespace ecckd {
 
@@ -34,5 +36,16 @@ bool h5_has_zlib(H5File* h);
 bool h5_inflate_host(H5File* h, void* dst, size_t dst_len, const void* src, size_t src_len);
 int h5_read_att_text(H5File* h, const char* var, const char* att, int* exists, char* out, size_t capacity);
 int h5_read_att_double(H5File* h, const char* var, const char* att, int* nelems, double* out, size_t capacity);
+
+// ---- writing (nc_hdf5_write.cpp): a NetCDF-4 file laid out through the HDF5 library and its high-level library ----
+struct H5WDim { std::string name; unsigned long long len = 0; };
+struct H5WAtt { std::string name; int nc_type = 0; std::string text; std::vector<double> values; };   // NC_CHAR: text; else values
+struct H5WVar { std::string name; int nc_type = 0; std::vector<int> dimids; std::vector<H5WAtt> atts; bool deflate = false; };
+struct H5Writer;
+bool h5w_available(const char** why);
+int h5w_create(const char* path, const std::vector<H5WDim>& dims, const std::vector<H5WVar>& vars, const std::vector<H5WAtt>& gatts,
+               H5Writer** out);
+int h5w_write(H5Writer* w, int varindex, long long slice /* < 0: the whole variable */, const double* data, size_t count);
+int h5w_close(H5Writer* w);
 
 }  // namespace ecckd

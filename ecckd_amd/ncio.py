@@ -130,6 +130,17 @@ class NcWriter:
             check(self.lib.ecckd_nc_put_att_double(self.handle, _b(var), _b(name), NC_TYPES["double"], v.size,
                                                    v.ctypes.data_as(C.POINTER(C.c_double))))
 
+    def deflate_variable(self, name):
+        """OutputDataFile::deflate_variable (:345-359): shuffle + deflate level 2 where the file is written as NetCDF-4 (a name
+        ending in .h5 / .hdf), nothing in a classic file."""
+        check(self.lib.ecckd_nc_deflate_var(self.handle, _b(name)))
+
+    @property
+    def is_netcdf4(self):
+        v = C.c_int()
+        check(self.lib.ecckd_nc_is_netcdf4(self.handle, C.byref(v)))
+        return bool(v.value)
+
     def end_define_mode(self):
         check(self.lib.ecckd_nc_enddef(self.handle))
 
@@ -533,8 +544,10 @@ def write_g_points(path, band_bound1, band_bound2, band_number, gases, wavenumbe
         w.define_variable(m + "_g_max", "int", "g_point")
     w.define_variable("wavenumber", "double", "wavenumber")
     w.define_variable("g_point", "short", "wavenumber")
+    w.deflate_variable("g_point")                                          # find_g_points.cpp:1580
     for g in gases:
         w.define_variable(g["name"] + "_g_point", "short", "wavenumber")
+        w.deflate_variable(g["name"] + "_g_point")                         # :1587
     w.write_attribute("constituent_id", " ".join(g["name"] for g in gases))
     if history:
         w.write_attribute("history", history)

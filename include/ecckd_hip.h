@@ -503,6 +503,11 @@ int ecckd_nc_def_dim(ecckd_nc* file, const char* name, size_t length, int* dimid
 int ecckd_nc_def_var(ecckd_nc* file, const char* name, int nc_type, int ndims, const int* dimids, int* varid);
 int ecckd_nc_put_att_text(ecckd_nc* file, const char* var, const char* att, const char* text);
 int ecckd_nc_put_att_double(ecckd_nc* file, const char* var, const char* att, int nc_type, int n, const double* values);
+/* deflate_variable (OutputDataFile.cpp:345-359): shuffle + deflate level 2 for this variable when the file is written as
+ * NetCDF-4 (a name ending in .h5 / .hdf where the HDF5 libraries can be loaded; ECCKD_CLASSIC_OUTPUT forces classic), nothing
+ * otherwise.  ecckd_nc_is_netcdf4: which of the two an open handle is. */
+int ecckd_nc_deflate_var(ecckd_nc* file, const char* name);
+int ecckd_nc_is_netcdf4(ecckd_nc* file, int* is_netcdf4);
 int ecckd_nc_enddef(ecckd_nc* file);
 int ecckd_nc_write_double(ecckd_nc* file, const char* name, const double* data, size_t count);
 /* one index of the slowest dimension of a fixed-size variable (count = the elements below that dimension) */

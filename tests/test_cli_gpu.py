@@ -749,9 +749,10 @@ def test_do_all_lw_with_the_tools(ctx, oracle, tmp_path):
 
 
 def test_tools_read_netcdf4_inputs(ctx, tmp_path):
-    """The scripts' file names end in .h5 (NetCDF-4).  Inputs in that format are read through the HDF5 library; outputs are
-    classic files whatever they are called (the NetCDF library detects the format from the content), so a chain of *.h5
-    names works: spectrum.h5 -> reorder_spectrum -> order.h5 -> find_g_points -> gpoints.h5."""
+    """The scripts' file names end in .h5 (NetCDF-4).  Inputs in that format are read through the HDF5 library; since round 4
+    outputs named *.h5 are WRITTEN as NetCDF-4 too (OutputDataFile.cpp:84-157; the per-wavenumber variables deflated as
+    write_order.cpp:59-94 and find_g_points.cpp:1580-1587 ask), so this chain hands NetCDF-4 files from tool to tool:
+    spectrum.h5 -> reorder_spectrum -> order.h5 -> find_g_points -> gpoints.h5."""
     import h5_fixture as h5
     from ecckd_amd import ncio
     if not h5.available():

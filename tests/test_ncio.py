@@ -531,3 +531,82 @@ def test_large_record_variable_slices_next_to_another_record_variable(tmp_path):
             assert np.array_equal(f.read("big", k), seen[k]), k
             assert np.array_equal(f.read("small", k), np.arange(3.0) + 10 * k)
         assert np.array_equal(f.read("big"), seen)
+
+
+def test_netcdf4_output_by_file_name(tmp_path, monkeypatch):
+    """OutputDataFile.cpp:84-157: a file named *.h5 / *.hdf is written as NetCDF-4 (HDF5), *.nc as classic; deflate_variable
+    (:345-359) = shuffle + deflate level 2 in the former, nothing in the latter.  The NetCDF-4 layout (dimension scales,
+    `_nc4_non_coord_` for a variable that shares its name with a dimension it does not run over, `_Netcdf4Dimid`) is checked
+    through the HDF5 library itself and read back by this repository's reader; there is no NetCDF library here to read it with
+    (DESIGN: unpinned)."""
+    import ctypes as C
+    import h5_fixture
+    if not h5_fixture.available():
+        pytest.skip("no HDF5 library")
+    rs = np.random.RandomState(5)
+    nwav, ng = 3 * (1 << 20) + 17, 7
+    wn = np.cumsum(rs.uniform(1e-4, 2e-4, nwav))
+    gp = rs.randint(0, ng, nwav).astype(np.int16)
+    err = rs.uniform(0, 1, ng).astype(np.float32)
+
+    def write(path):
+        w = ncio.NcWriter(path)
+        w.define_dimension("band", 2)
+        w.define_dimension("g_point", ng)
+        w.define_dimension("wavenumber", nwav)
+        w.define_variable("n_gases", "int")
+        w.define_variable("wavenumber1_band", "float", "band")
+        w.define_variable("h2o_error", "float", "g_point")
+        w.define_variable("wavenumber", "double", "wavenumber")          # a coordinate variable
+        w.define_variable("g_point", "short", "wavenumber")              # shares its name with the dimension g_point
+        w.deflate_variable("g_point")
+        w.deflate_variable("wavenumber")
+        w.write_attribute("units", "cm-1", "wavenumber")
+        w.write_attribute("constituent_id", "h2o")
+        w.write_attribute("scale", [1.5, -2.0])
+        is4 = w.is_netcdf4
+        w.end_define_mode()
+        w.write("n_gases", [1]); w.write("wavenumber1_band", [0.0, 1300.0]); w.write("h2o_error", err)
+        w.write("wavenumber", wn); w.write("g_point", gp)
+        w.close()
+        return is4
+
+    p4, p3 = str(tmp_path / "gpoints.h5"), str(tmp_path / "gpoints.nc")
+    assert write(p4) is True and write(p3) is False
+    assert open(p4, "rb").read(8) == b"\x89HDF\r\n\x1a\n" and open(p3, "rb").read(3) == b"CDF"
+    assert os.path.getsize(p4) < 0.8 * os.path.getsize(p3)               # the deflated variables
+    for p in (p4, p3):
+        with ncio.NcFile(p) as f:
+            assert f.dim("g_point") == ng and f.dim("wavenumber") == nwav and f.dim("band") == 2
+            assert np.array_equal(f.read("g_point"), gp) and np.array_equal(f.read("wavenumber"), wn)
+            assert np.array_equal(f.read("h2o_error"), err.astype(np.float64)) and int(np.asarray(f.read("n_gases")).reshape(-1)[0]) == 1
+            assert f.att_text("units", "wavenumber") == "cm-1" and f.att_text("constituent_id") == "h2o"
+            assert np.array_equal(f.att_values("scale"), [1.5, -2.0])
+            assert f.var_info("g_point")[1] == (nwav,) and not f.exist("band")        # a dimension without a variable is no variable
+    # the HDF5 view of the NetCDF-4 file
+    h = h5_fixture.lib()
+    hid = C.c_int64
+    for name, res, args in (("H5Fopen", hid, [C.c_char_p, C.c_uint, hid]), ("H5Lexists", C.c_int, [hid, C.c_char_p, hid]),
+                            ("H5Dopen2", hid, [hid, C.c_char_p, hid]), ("H5Dget_create_plist", hid, [hid]),
+                            ("H5Pget_layout", C.c_int, [hid]), ("H5Pget_nfilters", C.c_int, [hid]),
+                            ("H5Aexists_by_name", C.c_int, [hid, C.c_char_p, C.c_char_p, hid])):
+        fn = getattr(h, name)
+        fn.restype, fn.argtypes = res, args
+    f = h.H5Fopen(p4.encode(), 0, 0)
+    assert f >= 0
+    assert h.H5Lexists(f, b"_nc4_non_coord_g_point", 0) > 0 and h.H5Lexists(f, b"g_point", 0) > 0 and h.H5Lexists(f, b"band", 0) > 0
+    for ds, chunked, nfilters in ((b"_nc4_non_coord_g_point", True, 2), (b"wavenumber", True, 2), (b"h2o_error", False, 0)):
+        d = h.H5Dopen2(f, ds, 0)
+        pl = h.H5Dget_create_plist(d)
+        assert (h.H5Pget_layout(pl) == 2) == chunked and h.H5Pget_nfilters(pl) == nfilters, ds     # H5D_CHUNKED = 2
+        h.H5Pclose(pl); h.H5Dclose(d)
+    for ds in (b"g_point", b"band", b"wavenumber"):                       # every dimension is a dimension scale with its id
+        assert h.H5Aexists_by_name(f, ds, b"CLASS", 0) > 0 and h.H5Aexists_by_name(f, ds, b"_Netcdf4Dimid", 0) > 0, ds
+    for ds in (b"_nc4_non_coord_g_point", b"h2o_error", b"wavenumber1_band"):     # every variable is attached to its dimensions' scales
+        assert h.H5Aexists_by_name(f, ds, b"DIMENSION_LIST", 0) > 0, ds
+    assert h.H5Aexists_by_name(f, b"wavenumber", b"DIMENSION_LIST", 0) <= 0      # a coordinate variable is not attached to itself
+    h.H5Fclose(f)
+    # ECCKD_CLASSIC_OUTPUT: classic under the name asked for
+    monkeypatch.setenv("ECCKD_CLASSIC_OUTPUT", "1")
+    p5 = str(tmp_path / "classic.h5")
+    assert write(p5) is False and open(p5, "rb").read(3) == b"CDF"
