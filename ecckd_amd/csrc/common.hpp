@@ -86,6 +86,9 @@ ecckd_lane* lane_acquire(ecckd_ctx* ctx);            // nullptr on failure (erro
 void lane_release(ecckd_ctx* ctx, ecckd_lane* lane); // folds the lane's timing counters into the context's
 int lane_ensure_pinned(ecckd_lane* lane, size_t bytes);
 void streamer_delete(ecckd_ctx* ctx);               // nc_stream.hip
+// Cores THIS process may count on (context.hip): the affinity mask, capped by the cgroup's CPU quota, divided by the processes
+// the launcher started on this node (LOCAL_WORLD_SIZE: one process per GPU); ECCKD_HOST_CORES overrides.  At least 1.
+int host_cores();
 
 }  // namespace ecckd
 

@@ -5,10 +5,49 @@
 #include <unordered_map>
 #include <cstdlib>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <sched.h>
+#include <thread>
 
 namespace ecckd {
+
+int host_cores() {
+  static const int cores = [] {
+    if (const char* e = std::getenv("ECCKD_HOST_CORES")) {
+      const int v = std::atoi(e);
+      if (v > 0) return v;
+    }
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = CPU_COUNT(&set);
+    // cgroup v2 "quota period" (a container's CPU share; "max" = unlimited), then the v1 pair
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      long long quota = 0, period = 0;
+      if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+        n = std::min<long long>(n, (quota + period - 1) / period);
+      std::fclose(f);
+    } else if (FILE* q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      long long quota = -1, period = 0;
+      if (std::fscanf(q, "%lld", &quota) != 1) quota = -1;
+      std::fclose(q);
+      if (FILE* pf = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(pf, "%lld", &period) != 1) period = 0;
+        std::fclose(pf);
+      }
+      if (quota > 0 && period > 0) n = std::min<long long>(n, (quota + period - 1) / period);
+    }
+    // one process per GPU: the launcher's ranks on this node share the cores
+    if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) {
+      const int lws = std::atoi(e);
+      if (lws > 1) n /= lws;
+    }
+    return std::max(1, n);
+  }();
+  return cores;
+}
 
 static thread_local char g_err[1024] = "";
 

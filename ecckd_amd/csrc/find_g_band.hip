@@ -367,7 +367,7 @@ namespace {
 // (ecckd_find_g_gases) there are more, and every turn of a wait loop gives the core away so that the thread waited for runs.
 std::atomic<int> g_spinning_threads{0};
 inline bool oversubscribed() {
-  static const int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+  static const int cores = ecckd::host_cores();
   return g_spinning_threads.load(std::memory_order_relaxed) > cores;
 }
 struct SpinningThread {
@@ -739,7 +739,7 @@ int ecckd_find_g_gases_add(ecckd_gas_search_job* job, ecckd_gas_search* r) {
   // a gas with several bands runs a thread per band and one that serves their batches; they wait for each other by spinning
   // and yield the core when there are more of them than cores (oversubscribed()), so the limit is generous: four threads per
   // core (width <= 0: what that allows; 13 bands on 16 cores: four gases at a time)
-  const int cores = 4 * (int)std::max(1u, std::thread::hardware_concurrency());
+  const int cores = 4 * ecckd::host_cores();
   const int per_gas = (r->nband > 1 || g->do_sw) ? r->nband + 1 : 1;
   // a search that re-ranks its base g point by wavenumber (ecckd_regroup_rank_by_wavenumber_dev) works on the context's stream
   // with the context's scratch, which the caller may be using for the next gas's preparation: such a gas is searched here and now

@@ -352,7 +352,7 @@ int h5_read_real_parallel(H5File* h, const char* var_name, long long slice, int 
       chunk_elems *= (size_t)cdims[k];
     }
     struct Job { hsize_t off[8]; std::vector<unsigned char> raw; unsigned mask; };
-    const unsigned nworkers = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nworkers = (unsigned)std::max(1, std::min(16, ecckd::host_cores()));
     std::vector<Job> jobs(nchunks);
     std::atomic<size_t> produced{0}, next{0};
     std::atomic<int> bad{0};

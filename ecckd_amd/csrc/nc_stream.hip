@@ -309,7 +309,7 @@ static int read_h5_dev(ecckd_ctx* ctx, H5File* h5, const char* name, long long s
     std::atomic<size_t> next{0};
     std::atomic<long long> freed{(long long)nslots - 1};   // chunk j may use slot j % nslots once chunk j - nslots has been shipped: j <= freed
     std::atomic<int> stop{0};
-    const unsigned nworkers = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nworkers = (unsigned)std::max(1, std::min(16, ecckd::host_cores()));
     auto worker = [&]() {
       for (;;) {
         const size_t j = next.fetch_add(1);
