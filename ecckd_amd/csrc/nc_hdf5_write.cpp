@@ -10,7 +10,12 @@
 // followed by the length -; every variable attached to the scales of its dimensions; `_Netcdf4Dimid` on every scale;
 // link / attribute creation order tracked (the order variables and attributes are listed in); NC_CHAR attributes as
 // fixed-length null-terminated scalar strings, numeric attributes as 1-D arrays; little-endian IEEE / two's-complement
-// file types; contiguous layout unless a variable is deflated (then chunks of at most 2^20 values along the last dimension).
+// file types; contiguous layout unless a variable is deflated (then chunks of at most 2^18 values along the last dimension).
+// A deflated variable's chunks are converted, shuffled and deflated by worker threads (the zlib found at run time, the call
+// the library's own filter makes: compress2 at level 2) and handed to the library as finished chunks (H5Dwrite_chunk, HDF5
+// >= 1.10.3): the library's filter pipeline is one thread at ~40 MB/s - 4.6 s for the six 7.2e6-value variables of an ordering
+// file, 0.19 s for the same file in the classic format.  Without H5Dwrite_chunk or zlib, or with ECCKD_H5_SERIAL_WRITE=1, the
+// library's pipeline does it.
 // Unpinned: there is no NetCDF library here to read the result back with; the tests read it through the HDF5 library
 // (structure, filters, attributes) and through this repository's own reader.
 #include "common.hpp"
@@ -20,8 +25,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace ecckd {
@@ -60,6 +69,9 @@ struct WApi {
   herr_t (*H5Awrite)(hid_t, hid_t, const void*);
   herr_t (*H5Aclose)(hid_t);
   int (*H5Zfilter_avail)(int);
+  herr_t (*H5Dwrite_chunk)(hid_t, hid_t, unsigned, const hsize_t*, size_t, const void*) = nullptr;   // 1.10.3 on
+  int (*z_compress2)(unsigned char*, unsigned long*, const unsigned char*, unsigned long, int) = nullptr;
+  unsigned long (*z_compressBound)(unsigned long) = nullptr;
   herr_t (*H5DSset_scale)(hid_t, const char*);
   herr_t (*H5DSattach_scale)(hid_t, hid_t, unsigned);
   hid_t p_file_create, p_dataset_create;
@@ -120,12 +132,55 @@ WApi& wapi() {
     a.t_c_s1 = id("H5T_C_S1_g");
     if (!ids) return;
     if (a.H5Zfilter_avail(1) <= 0) { a.why = "this HDF5 library has no deflate filter"; return; }
+    a.H5Dwrite_chunk = reinterpret_cast<decltype(a.H5Dwrite_chunk)>(dlsym(a.lib, "H5Dwrite_chunk"));
+    for (const char* zn : {"libz.so.1", "libz.so", "/opt/conda/lib/libz.so.1"}) {
+      if (void* z = dlopen(zn, RTLD_NOW | RTLD_LOCAL)) {
+        a.z_compress2 = reinterpret_cast<decltype(a.z_compress2)>(dlsym(z, "compress2"));
+        a.z_compressBound = reinterpret_cast<decltype(a.z_compressBound)>(dlsym(z, "compressBound"));
+        if (a.z_compress2 && a.z_compressBound) break;
+        a.z_compress2 = nullptr;
+      }
+    }
     a.ok = true;
   });
   return a;
 }
 
 enum { NC_BYTE = 1, NC_CHAR = 2, NC_SHORT = 3, NC_INT = 4, NC_FLOAT = 5, NC_DOUBLE = 6, NC_UBYTE = 7 };
+constexpr hsize_t kChunkValues = (hsize_t)1 << 18;      // values per chunk of a deflated variable (along its last dimension)
+
+size_t file_type_size(int nc_type) {
+  switch (nc_type) {
+    case NC_SHORT: return 2;
+    case NC_INT: case NC_FLOAT: return 4;
+    case NC_DOUBLE: return 8;
+    default: return 1;
+  }
+}
+
+// `n` doubles as little-endian file values of type t (x86: native order), the conversion the library makes on H5Dwrite:
+// to float by rounding, to the integer types by truncation with the ends of the type's range as limits
+template <typename T> inline T clamp_to(double v, double lo, double hi) { return (T)(v < lo ? lo : v > hi ? hi : v); }
+void to_file_values(unsigned char* out, int t, const double* v, size_t n) {
+  switch (t) {
+    case NC_DOUBLE: std::memcpy(out, v, n * 8); return;
+    case NC_FLOAT: { float* o = reinterpret_cast<float*>(out); for (size_t i = 0; i < n; ++i) o[i] = (float)v[i]; return; }
+    case NC_INT: { int32_t* o = reinterpret_cast<int32_t*>(out); for (size_t i = 0; i < n; ++i) o[i] = clamp_to<int32_t>(v[i], -2147483648.0, 2147483647.0); return; }
+    case NC_SHORT: { int16_t* o = reinterpret_cast<int16_t*>(out); for (size_t i = 0; i < n; ++i) o[i] = clamp_to<int16_t>(v[i], -32768.0, 32767.0); return; }
+    case NC_BYTE: { int8_t* o = reinterpret_cast<int8_t*>(out); for (size_t i = 0; i < n; ++i) o[i] = clamp_to<int8_t>(v[i], -128.0, 127.0); return; }
+    default: for (size_t i = 0; i < n; ++i) out[i] = clamp_to<uint8_t>(v[i], 0.0, 255.0);
+  }
+}
+
+// the shuffle filter: byte b of every value, then byte b + 1 of every value ...
+void shuffle_bytes(unsigned char* out, const unsigned char* in, size_t n, size_t ts) {
+  if (ts == 1) { std::memcpy(out, in, n); return; }
+  for (size_t b = 0; b < ts; ++b) {
+    unsigned char* o = out + b * n;
+    const unsigned char* q = in + b;
+    for (size_t i = 0; i < n; ++i) o[i] = q[i * ts];
+  }
+}
 
 hid_t file_type(const WApi& a, int nc_type) {
   switch (nc_type) {
@@ -214,7 +269,7 @@ int h5w_create(const char* path, const std::vector<H5WDim>& dims, const std::vec
     const hid_t dcpl = a.H5Pcreate(a.p_dataset_create);
     a.H5Pset_attr_creation_order(dcpl, order);
     if (var.deflate && nd > 0) {
-      chunk[nd - 1] = shape[nd - 1] < ((hsize_t)1 << 20) ? shape[nd - 1] : ((hsize_t)1 << 20);
+      chunk[nd - 1] = shape[nd - 1] < kChunkValues ? shape[nd - 1] : kChunkValues;
       a.H5Pset_chunk(dcpl, nd, chunk);
       a.H5Pset_shuffle(dcpl);
       a.H5Pset_deflate(dcpl, 2);            // nc_def_var_deflate(ncid, varid, 1, 1, 2), OutputDataFile.cpp:356
@@ -287,12 +342,75 @@ int h5w_create(const char* path, const std::vector<H5WDim>& dims, const std::vec
   return ECCKD_OK;
 }
 
+namespace {
+// The chunks of a deflated variable that the flat run data[0 .. count) covers - whole rows of the last dimension, from row
+// `row0` of the variable on - built by worker threads and handed over as finished chunks.  Returns 1 when the direct path does
+// not apply (the caller then writes through the library's pipeline), ECCKD_OK or an error code otherwise.
+int write_deflated_chunks(WApi& a, H5Writer* w, int varindex, size_t row0, const double* data, size_t count) {
+  const H5WVar& var = w->vars[varindex];
+  const int nd = (int)var.dimids.size();
+  if (!var.deflate || nd == 0 || !a.H5Dwrite_chunk || !a.z_compress2 || std::getenv("ECCKD_H5_SERIAL_WRITE")) return 1;
+  const size_t last = w->dims[var.dimids[nd - 1]].len;
+  if (last == 0 || count % last != 0) return 1;
+  const size_t nrows = count / last;
+  const size_t cv = (size_t)std::min<hsize_t>(last, kChunkValues);     // values per chunk (the dataset's chunk shape, h5w_create)
+  const size_t per_row = (last + cv - 1) / cv;
+  const size_t nchunks = nrows * per_row;
+  const size_t ts = file_type_size(var.nc_type);
+  struct Done { std::vector<unsigned char> bytes; int rc = 0; };
+  std::vector<Done> done(nchunks);
+  std::atomic<size_t> next{0};
+  auto worker = [&] {
+    std::vector<unsigned char> raw(cv * ts), shuffled(cv * ts);
+    for (;;) {
+      const size_t c = next.fetch_add(1);
+      if (c >= nchunks) return;
+      const size_t row = c / per_row, first = (c % per_row) * cv;
+      const size_t n = std::min(cv, last - first);
+      to_file_values(raw.data(), var.nc_type, data + row * last + first, n);
+      if (n < cv) std::memset(raw.data() + n * ts, 0, (cv - n) * ts);        // an edge chunk is stored whole
+      shuffle_bytes(shuffled.data(), raw.data(), cv, ts);
+      unsigned long size = a.z_compressBound((unsigned long)(cv * ts));
+      done[c].bytes.resize(size);
+      if (a.z_compress2(done[c].bytes.data(), &size, shuffled.data(), (unsigned long)(cv * ts), 2) != 0) { done[c].rc = 1; continue; }
+      done[c].bytes.resize(size);
+    }
+  };
+  const size_t nthreads = std::min<size_t>(nchunks, (size_t)std::max(1, std::min(16, host_cores())));
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+  worker();
+  for (std::thread& t : pool) t.join();
+  // the library is not thread-safe: the chunks go in from this thread, in order
+  hsize_t offset[32];
+  for (size_t c = 0; c < nchunks; ++c) {
+    if (done[c].rc != 0) return fail(ECCKD_PROCESSING_ERROR, "%s: deflate of \"%s\" failed", w->path.c_str(), var.name.c_str());
+    size_t row = row0 + c / per_row;
+    for (int k = nd - 2; k >= 0; --k) {
+      const size_t len = w->dims[var.dimids[k]].len;
+      offset[k] = row % len;
+      row /= len;
+    }
+    offset[nd - 1] = (hsize_t)((c % per_row) * cv);
+    if (a.H5Dwrite_chunk(w->var_ids[varindex], 0, 0u, offset, done[c].bytes.size(), done[c].bytes.data()) < 0)
+      return fail(ECCKD_PROCESSING_ERROR, "%s: write of \"%s\" failed", w->path.c_str(), var.name.c_str());
+  }
+  return ECCKD_OK;
+}
+}  // namespace
+
 int h5w_write(H5Writer* w, int varindex, long long slice, const double* data, size_t count) {
   WApi& a = wapi();
   const H5WVar& var = w->vars[varindex];
   const hid_t d = w->var_ids[varindex];
   const int nd = (int)var.dimids.size();
   herr_t e;
+  if (var.deflate && nd > 0) {
+    size_t rows_per_slice = 1;
+    for (int k = 1; k + 1 < nd; ++k) rows_per_slice *= w->dims[var.dimids[k]].len;
+    const int rc = write_deflated_chunks(a, w, varindex, slice < 0 || nd == 1 ? 0 : (size_t)slice * rows_per_slice, data, count);
+    if (rc != 1) return rc;
+  }
   if (slice < 0 || nd == 0) {
     const hsize_t n = count;
     const hid_t mem = nd == 0 ? a.H5Screate(0) : a.H5Screate_simple(1, &n, nullptr);

@@ -148,6 +148,11 @@ class NcWriter:
         d = np.ascontiguousarray(data, dtype=np.float64)
         check(self.lib.ecckd_nc_write_double(self.handle, _b(name), d.ctypes.data_as(C.POINTER(C.c_double)), d.size))
 
+    def write_slice(self, name, index, data):
+        """One index of the variable's slowest dimension (ecckd_nc_write_slice_double)."""
+        d = np.ascontiguousarray(data, dtype=np.float64)
+        check(self.lib.ecckd_nc_write_slice_double(self.handle, _b(name), int(index), d.ctypes.data_as(C.POINTER(C.c_double)), d.size))
+
     def close(self):
         if getattr(self, "handle", None):
             h, self.handle = self.handle, None
