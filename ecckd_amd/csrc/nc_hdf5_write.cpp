@@ -12,8 +12,9 @@
 // fixed-length null-terminated scalar strings, numeric attributes as 1-D arrays; little-endian IEEE / two's-complement
 // file types; contiguous layout unless a variable is deflated (then chunks of at most 2^18 values along the last dimension).
 // A deflated variable's chunks are converted, shuffled and deflated by worker threads (the zlib found at run time, the call
-// the library's own filter makes: compress2 at level 2) and handed to the library as finished chunks (H5Dwrite_chunk, HDF5
-// >= 1.10.3): the library's filter pipeline is one thread at ~40 MB/s - 4.6 s for the six 7.2e6-value variables of an ordering
+// the library's own filter makes: compress2 at level 2) while the caller goes on to the next variable, and handed to the library
+// as finished chunks when the file is closed (H5Dwrite_chunk, HDF5 >= 1.10.3): the library's filter pipeline is one thread at
+// ~40 MB/s - 4.6 s for the six 7.2e6-value variables of an ordering
 // file, 0.19 s for the same file in the classic format.  Without H5Dwrite_chunk or zlib, or with ECCKD_H5_SERIAL_WRITE=1, the
 // library's pipeline does it.
 // Unpinned: there is no NetCDF library here to read the result back with; the tests read it through the HDF5 library
@@ -27,7 +28,9 @@
 #include <dlfcn.h>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -230,6 +233,20 @@ struct H5Writer {
   std::vector<hid_t> dimonly_ids;
   std::vector<H5WVar> vars;
   std::vector<H5WDim> dims;
+  // deflated variables on their way through the worker threads (queue_deflated_chunks)
+  struct Chunk {
+    int var = 0;
+    size_t type_size = 1;
+    hsize_t offset[32] = {0};
+    std::vector<unsigned char> raw, z;      // file values of the whole chunk; shuffled + deflated
+    int state = 0;                          // 0 queued, 1 deflated, -1 failed
+  };
+  std::deque<Chunk> queue;                  // (a deque: the workers hold pointers to its elements while more are queued)
+  size_t next_job = 0, finished = 0, queued_bytes = 0;
+  bool stop = false;
+  std::mutex m;
+  std::condition_variable cv, cv_done;
+  std::vector<std::thread> pool;
 };
 
 bool h5w_available(const char** why) {
@@ -343,58 +360,115 @@ int h5w_create(const char* path, const std::vector<H5WDim>& dims, const std::vec
 }
 
 namespace {
-// The chunks of a deflated variable that the flat run data[0 .. count) covers - whole rows of the last dimension, from row
-// `row0` of the variable on - built by worker threads and handed over as finished chunks.  Returns 1 when the direct path does
-// not apply (the caller then writes through the library's pipeline), ECCKD_OK or an error code otherwise.
-int write_deflated_chunks(WApi& a, H5Writer* w, int varindex, size_t row0, const double* data, size_t count) {
+// ---- deflated variables: chunks built by worker threads, written when the file is closed -----------------------------------
+// h5w_write converts its values to the file type, cuts them into the dataset's chunks and queues those; the writer's worker
+// threads shuffle and deflate them while the caller goes on (the next variable's chunks join the same queue: the six variables of
+// an ordering file keep every core busy); drain() waits for the queue and hands the finished chunks to the library from the
+// calling thread, in the order they were queued (the library is not thread-safe).
+void pool_worker(H5Writer* w) {
+  WApi& a = wapi();
+  std::vector<unsigned char> shuffled;
+  for (;;) {
+    H5Writer::Chunk* c = nullptr;
+    {
+      std::unique_lock<std::mutex> lock(w->m);
+      w->cv.wait(lock, [&] { return w->stop || w->next_job < w->queue.size(); });
+      if (w->next_job >= w->queue.size()) return;      // stop, nothing left
+      c = &w->queue[w->next_job++];
+    }
+    const size_t nbytes = c->raw.size();
+    shuffled.resize(nbytes);
+    shuffle_bytes(shuffled.data(), c->raw.data(), nbytes / c->type_size, c->type_size);
+    unsigned long size = a.z_compressBound((unsigned long)nbytes);
+    c->z.resize(size);
+    const int zrc = a.z_compress2(c->z.data(), &size, shuffled.data(), (unsigned long)nbytes, 2);
+    c->z.resize(zrc == 0 ? size : 0);
+    std::vector<unsigned char>().swap(c->raw);
+    {
+      std::lock_guard<std::mutex> lock(w->m);
+      c->state = zrc == 0 ? 1 : -1;
+      ++w->finished;
+    }
+    w->cv_done.notify_all();
+  }
+}
+
+int drain(H5Writer* w) {
+  WApi& a = wapi();
+  {
+    std::unique_lock<std::mutex> lock(w->m);
+    w->cv_done.wait(lock, [&] { return w->finished == w->queue.size(); });
+  }
+  int rc = ECCKD_OK;
+  for (H5Writer::Chunk& c : w->queue) {
+    if (rc != ECCKD_OK) break;
+    const H5WVar& var = w->vars[c.var];
+    if (c.state != 1) { rc = fail(ECCKD_PROCESSING_ERROR, "%s: deflate of \"%s\" failed", w->path.c_str(), var.name.c_str()); break; }
+    if (a.H5Dwrite_chunk(w->var_ids[c.var], 0, 0u, c.offset, c.z.size(), c.z.data()) < 0)
+      rc = fail(ECCKD_PROCESSING_ERROR, "%s: write of \"%s\" failed", w->path.c_str(), var.name.c_str());
+  }
+  {
+    std::lock_guard<std::mutex> lock(w->m);
+    w->queue.clear();
+    w->next_job = 0;
+    w->finished = 0;
+    w->queued_bytes = 0;
+  }
+  return rc;
+}
+
+void stop_pool(H5Writer* w) {
+  {
+    std::lock_guard<std::mutex> lock(w->m);
+    w->stop = true;
+  }
+  w->cv.notify_all();
+  for (std::thread& t : w->pool) t.join();
+  w->pool.clear();
+}
+
+// Queues the chunks of a deflated variable that the flat run data[0 .. count) covers - whole rows of the last dimension, from
+// row `row0` of the variable on.  Returns 1 when the direct path does not apply (the caller then writes through the library's
+// pipeline), ECCKD_OK or an error code otherwise.
+int queue_deflated_chunks(WApi& a, H5Writer* w, int varindex, size_t row0, const double* data, size_t count) {
   const H5WVar& var = w->vars[varindex];
   const int nd = (int)var.dimids.size();
   if (!var.deflate || nd == 0 || !a.H5Dwrite_chunk || !a.z_compress2 || std::getenv("ECCKD_H5_SERIAL_WRITE")) return 1;
   const size_t last = w->dims[var.dimids[nd - 1]].len;
   if (last == 0 || count % last != 0) return 1;
+  if (w->queued_bytes > ((size_t)1 << 30)) ECCKD_CHECK(drain(w));       // bounded memory for variables written slice after slice
   const size_t nrows = count / last;
   const size_t cv = (size_t)std::min<hsize_t>(last, kChunkValues);     // values per chunk (the dataset's chunk shape, h5w_create)
   const size_t per_row = (last + cv - 1) / cv;
   const size_t nchunks = nrows * per_row;
   const size_t ts = file_type_size(var.nc_type);
-  struct Done { std::vector<unsigned char> bytes; int rc = 0; };
-  std::vector<Done> done(nchunks);
-  std::atomic<size_t> next{0};
-  auto worker = [&] {
-    std::vector<unsigned char> raw(cv * ts), shuffled(cv * ts);
-    for (;;) {
-      const size_t c = next.fetch_add(1);
-      if (c >= nchunks) return;
-      const size_t row = c / per_row, first = (c % per_row) * cv;
-      const size_t n = std::min(cv, last - first);
-      to_file_values(raw.data(), var.nc_type, data + row * last + first, n);
-      if (n < cv) std::memset(raw.data() + n * ts, 0, (cv - n) * ts);        // an edge chunk is stored whole
-      shuffle_bytes(shuffled.data(), raw.data(), cv, ts);
-      unsigned long size = a.z_compressBound((unsigned long)(cv * ts));
-      done[c].bytes.resize(size);
-      if (a.z_compress2(done[c].bytes.data(), &size, shuffled.data(), (unsigned long)(cv * ts), 2) != 0) { done[c].rc = 1; continue; }
-      done[c].bytes.resize(size);
-    }
-  };
-  const size_t nthreads = std::min<size_t>(nchunks, (size_t)std::max(1, std::min(16, host_cores())));
-  std::vector<std::thread> pool;
-  for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-  worker();
-  for (std::thread& t : pool) t.join();
-  // the library is not thread-safe: the chunks go in from this thread, in order
-  hsize_t offset[32];
+  std::vector<H5Writer::Chunk> fresh(nchunks);
   for (size_t c = 0; c < nchunks; ++c) {
-    if (done[c].rc != 0) return fail(ECCKD_PROCESSING_ERROR, "%s: deflate of \"%s\" failed", w->path.c_str(), var.name.c_str());
+    H5Writer::Chunk& ch = fresh[c];
+    const size_t first = (c % per_row) * cv;
+    const size_t n = std::min(cv, last - first);
+    ch.var = varindex;
+    ch.type_size = ts;
+    ch.raw.assign(cv * ts, 0);                                         // an edge chunk is stored whole, zero behind its values
+    to_file_values(ch.raw.data(), var.nc_type, data + (c / per_row) * last + first, n);
     size_t row = row0 + c / per_row;
     for (int k = nd - 2; k >= 0; --k) {
       const size_t len = w->dims[var.dimids[k]].len;
-      offset[k] = row % len;
+      ch.offset[k] = row % len;
       row /= len;
     }
-    offset[nd - 1] = (hsize_t)((c % per_row) * cv);
-    if (a.H5Dwrite_chunk(w->var_ids[varindex], 0, 0u, offset, done[c].bytes.size(), done[c].bytes.data()) < 0)
-      return fail(ECCKD_PROCESSING_ERROR, "%s: write of \"%s\" failed", w->path.c_str(), var.name.c_str());
+    ch.offset[nd - 1] = (hsize_t)first;
   }
+  {
+    std::lock_guard<std::mutex> lock(w->m);
+    for (H5Writer::Chunk& ch : fresh) w->queue.push_back(std::move(ch));
+    w->queued_bytes += nchunks * cv * ts;
+    if (w->pool.empty()) {
+      const int nthreads = std::max(1, std::min(16, host_cores()));
+      for (int t = 0; t < nthreads; ++t) w->pool.emplace_back(pool_worker, w);
+    }
+  }
+  w->cv.notify_all();
   return ECCKD_OK;
 }
 }  // namespace
@@ -408,7 +482,7 @@ int h5w_write(H5Writer* w, int varindex, long long slice, const double* data, si
   if (var.deflate && nd > 0) {
     size_t rows_per_slice = 1;
     for (int k = 1; k + 1 < nd; ++k) rows_per_slice *= w->dims[var.dimids[k]].len;
-    const int rc = write_deflated_chunks(a, w, varindex, slice < 0 || nd == 1 ? 0 : (size_t)slice * rows_per_slice, data, count);
+    const int rc = queue_deflated_chunks(a, w, varindex, slice < 0 || nd == 1 ? 0 : (size_t)slice * rows_per_slice, data, count);
     if (rc != 1) return rc;
   }
   if (slice < 0 || nd == 0) {
@@ -445,11 +519,14 @@ int h5w_write(H5Writer* w, int varindex, long long slice, const double* data, si
 int h5w_close(H5Writer* w) {
   if (!w) return ECCKD_OK;
   WApi& a = wapi();
+  const int rc_chunks = drain(w);
+  stop_pool(w);
   for (hid_t d : w->var_ids) if (d >= 0) a.H5Dclose(d);
   for (hid_t d : w->dimonly_ids) if (d >= 0) a.H5Dclose(d);
   const herr_t e = w->file >= 0 ? a.H5Fclose(w->file) : 0;
   const std::string path = w->path;
   delete w;
+  if (rc_chunks != ECCKD_OK) return rc_chunks;
   if (e < 0) return fail(ECCKD_PROCESSING_ERROR, "%s: close failed", path.c_str());
   return ECCKD_OK;
 }
