@@ -32,7 +32,7 @@ for _p in (ROOT, os.path.join(ROOT, "tools")):
         sys.path.insert(0, _p)
 
 
-def run(ctx, nwav=7_200_000, nlay=54, tolerance=0.0161, workdir=None, keep=False, nlines=12000, compare_gas_after_gas=True):
+def run(ctx, nwav=7_200_000, nlay=54, tolerance=0.0161, workdir=None, keep=False, nlines=12000, compare_gas_after_gas=True, ext="nc"):
     import e2e_bench
     from ecckd_amd import fsck_job, ncio
     top = workdir or tempfile.mkdtemp(prefix="ecckd_fsck_")
@@ -77,31 +77,34 @@ def run(ctx, nwav=7_200_000, nlay=54, tolerance=0.0161, workdir=None, keep=False
 
         t_reorder = 0.0
         for g, target, _ in gases:
-            t_reorder += tool("reorder_spectrum", f"input={target}.nc", f"output=order_{g}.nc", "wavenumber1=0", "wavenumber2=3260")[0]
+            t_reorder += tool("reorder_spectrum", f"input={target}.nc", f"output=order_{g}.{ext}", "wavenumber1=0", "wavenumber2=3260")[0]
         with open(os.path.join(top, "find_g.cfg"), "w") as f:
             f.write("iprofile 0\naveraging_method \"transmission\"\ntolerance_tolerance 0.01\nflux_weight 0.0\nmax_iterations 60\n"
                     "heating_rate_tolerance %g\ngases %s\n" % (tolerance, " ".join(names)))
             for g, target, bgs in gases:
-                f.write("\\begin %s\n  input %s.nc\n  reordering_input order_%s.nc\n  background_input \"%s\"\n" %
-                        (g, target, g, "\n".join(b + ".nc" for b, _ in bgs)))
+                f.write("\\begin %s\n  input %s.nc\n  reordering_input order_%s.%s\n  background_input \"%s\"\n" %
+                        (g, target, g, ext, "\n".join(b + ".nc" for b, _ in bgs)))
                 if any(c >= 0 for _, c in bgs):
                     f.write("  background_conc %s\n" % " ".join("%g" % c if c >= 0 else "-1" for _, c in bgs))
                 f.write("\\end %s\n" % g)
-        t_find, r = tool("find_g_points", "find_g.cfg", "output=gpoints.nc")
-        gp = ncio.read_g_points(os.path.join(top, "gpoints.nc"))
+        t_find, r = tool("find_g_points", "find_g.cfg", f"output=gpoints.{ext}")
+        gp = ncio.read_g_points(os.path.join(top, "gpoints." + ext))
         comp = [float(v) for v in re.findall(r"computational cost = ([0-9.eE+-]+)", r.stdout)]
         ngs = [int(v) for v in re.findall(r": (\d+) g points, computational cost", r.stdout)]
         out = {"workload": "configs[1] by the tools on files: 6 x bin/reorder_spectrum + ONE bin/find_g_points over %s, backgrounds of "
                            "%s files merged in double, nwav=%d, nlay=%d, fsck band 0-3260 cm-1, tolerance %g K/d, tolerance_tolerance "
                            "0.01, max_iterations 60" % (" ".join(names), "/".join(str(len(b)) for _, _, b in gases), nwav, nlay, tolerance),
                "seconds": {"reorder_spectrum_x6": round(t_reorder, 3), "find_g_points": round(t_find, 3)},
+               "output_format": "NetCDF-4, per-wavenumber variables deflated (the scripts' *.h5 names)" if ext == "h5" else "NetCDF classic (*.nc names)",
+               "output_bytes": {"order_files": int(sum(os.path.getsize(os.path.join(top, f"order_{g}.{ext}")) for g, _, _ in gases)),
+                                "g_points_file": os.path.getsize(os.path.join(top, "gpoints." + ext))},
                "ng_merged": int(np.max(gp["g_point"])) + 1, "ng_per_gas": ngs, "n_pass_reference_counter": sum(comp),
                "input_bytes": int(sum(os.path.getsize(os.path.join(top, n + ".nc")) for n in fsck_job.SPECTRA if os.path.exists(os.path.join(top, n + ".nc")))),
                "setup_seconds_not_timed": {"writing_spectra_and_sync": round(write_s, 1)}}
         if compare_gas_after_gas:
-            ref_bytes = open(os.path.join(top, "gpoints.nc"), "rb").read()
-            t_seq, _ = tool("find_g_points", "find_g.cfg", "output=gpoints_seq.nc", "gases_side_by_side=1")
-            seq = ncio.read_g_points(os.path.join(top, "gpoints_seq.nc"))
+            ref_bytes = open(os.path.join(top, "gpoints." + ext), "rb").read()
+            t_seq, _ = tool("find_g_points", "find_g.cfg", f"output=gpoints_seq.{ext}", "gases_side_by_side=1")
+            seq = ncio.read_g_points(os.path.join(top, "gpoints_seq." + ext))
             out["seconds"]["find_g_points_gas_after_gas"] = round(t_seq, 3)
             out["side_by_side_speedup_of_the_tool"] = t_seq / t_find
             out["g_point_maps_identical"] = bool(np.array_equal(seq["g_point"], gp["g_point"]))
@@ -121,10 +124,11 @@ def main():
     ap.add_argument("--tolerance", type=float, default=0.0161)
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--netcdf4", action="store_true", help="name the ordering and g-points files *.h5 as the scripts do: NetCDF-4, deflated")
     args = ap.parse_args()
     from ecckd_amd import api
     with api.Context(0) as ctx:
-        print(json.dumps(run(ctx, args.nwav, args.nlay, args.tolerance, args.workdir, args.keep, args.nlines)))
+        print(json.dumps(run(ctx, args.nwav, args.nlay, args.tolerance, args.workdir, args.keep, args.nlines, ext="h5" if args.netcdf4 else "nc")))
 
 
 if __name__ == "__main__":

@@ -61,6 +61,7 @@ python3 tools/batch_breakdown.py $(ls $out/bb/*.db | head -1) > $out/batch_break
 # the searches of the six prepared gases: gas after gas / side by side; the job by the tools on files
 python3 tools/gases_probe.py --widths 1,6,3,1 --out $out/gases_probe.json > $out/gases_probe.log 2>&1
 python3 tools/fsck_tools_bench.py > $out/fsck_tools_bench.json 2> $out/ftb.err
+python3 tools/fsck_tools_bench.py --netcdf4 > $out/fsck_tools_bench_netcdf4.json 2>> $out/ftb.err
 python3 tools/sort_probe.py > $out/sort_probe.json 2> $out/sortp.err
 # the other configurations
 python3 bench.py --config 2 --steps 3 > $out/bench_config2.json 2> $out/c2.err
