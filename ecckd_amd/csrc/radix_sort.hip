@@ -106,22 +106,31 @@ template <int SORT_ITEMS>
 __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_hist(size_t n, int shift, const unsigned long long* __restrict__ skey, const unsigned* __restrict__ sidx, SegTable st,
             unsigned* __restrict__ tile_hist, unsigned ntiles) {
-  __shared__ unsigned s_hist[RADIX];
+  // eight copies of the histogram, a lane adds to copy (lane & 7): the high digits of a sorting key take a handful of values, and
+  // 64 lanes adding to the same few LDS words are served one after the other (the passes over the exponent bytes took twice as
+  // long as those over the mantissa)
   constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
+  constexpr int COPIES = 8;
+  __shared__ unsigned s_hist[COPIES][RADIX];
   const int tid = threadIdx.x;
-  s_hist[tid] = 0;  // SORT_THREADS == RADIX
+#pragma unroll
+  for (int c = 0; c < COPIES; ++c) s_hist[c][tid] = 0;  // SORT_THREADS == RADIX
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * SORT_TILE;
+  unsigned* mine = s_hist[tid & (COPIES - 1)];
 #pragma unroll
   for (int it = 0; it < SORT_ITEMS; ++it) {
     size_t i = base + (size_t)it * SORT_THREADS + tid;
     if (i < n) {
       unsigned d = digit_of(skey[i], shift < 64 ? 0u : sidx[i], shift, st);
-      atomicAdd(&s_hist[d], 1u);
+      atomicAdd(&mine[d], 1u);
     }
   }
   __syncthreads();
-  tile_hist[(size_t)tid * ntiles + blockIdx.x] = s_hist[tid];
+  unsigned total = 0;
+#pragma unroll
+  for (int c = 0; c < COPIES; ++c) total += s_hist[c][tid];
+  tile_hist[(size_t)tid * ntiles + blockIdx.x] = total;
 }
 
 // (2) one block per digit: exclusive scan of that digit's row of per-tile counts (in place) and the row total ->
