@@ -6,6 +6,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_A
   n=$(echo $set | tr " " "_")
   rocprofv3 --kernel-trace --pmc $set -d $out/$n -o p --output-format csv -- python3 tools/sort_probe.py --reps 2 > /dev/null 2> $out/$n.err
   for k in k_sort_scatter_lds k_sort_hist k_sort_scan_rows; do
+    echo "== $k" >> $out/pmc_sort.txt
     python3 tools/pmc_summary.py $k $out/$n/p_counter_collection.csv >> $out/pmc_sort.txt
   done
   rm -rf $out/$n

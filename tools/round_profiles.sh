@@ -63,6 +63,9 @@ python3 tools/gases_probe.py --widths 1,6,3,1 --out $out/gases_probe.json > $out
 python3 tools/fsck_tools_bench.py > $out/fsck_tools_bench.json 2> $out/ftb.err
 python3 tools/fsck_tools_bench.py --netcdf4 > $out/fsck_tools_bench_netcdf4.json 2>> $out/ftb.err
 python3 tools/sort_probe.py > $out/sort_probe.json 2> $out/sortp.err
+bash tools/probes/sort_pmc.sh > $out/pmc_sort.txt 2>> $out/sortp.err
+rocprofv3 --kernel-trace --stats -d $out/sortks -o s --output-format csv -- python3 tools/sort_probe.py --reps 5 > /dev/null 2>> $out/sortp.err
+grep -E "k_sort|k_iota|Name" $out/sortks/s_kernel_stats.csv > $out/sort_kernel_stats.csv 2>/dev/null; rm -rf $out/sortks gpurun_out/sortpmc
 # the other configurations
 python3 bench.py --config 2 --steps 3 > $out/bench_config2.json 2> $out/c2.err
 python3 bench.py --config 3 --steps 2 > $out/bench_config3.json 2> $out/c3.err
