@@ -697,26 +697,36 @@ def test_scale_lut(ctx, tmp_path):
     assert r.returncode == 147 and "gpointfile not provided" in r.stderr
 
 
-def test_do_all_lw_with_the_tools(ctx, oracle, tmp_path):
+@pytest.mark.parametrize("ext", ["nc", "h5"])
+def test_do_all_lw_with_the_tools(ctx, oracle, tmp_path, ext):
     """test/do_all_lw.sh with the binaries only: reorder_spectrum -> find_g_points -> create_look_up_table -> optimize_lut ->
     run_ckd (raw and optimised definitions), every hand-over a NetCDF file, every option a config key.  The line-by-line
     training fluxes (external ckdmip_lw in the reference's scripts) come from the LBL stand-in.  Judged like the scripts' own
-    evaluation: heating-rate RMS error against the line-by-line fluxes (plot/calc_hr_error.m)."""
+    evaluation: heating-rate RMS error against the line-by-line fluxes (plot/calc_hr_error.m).
+    ext: the ordering and g-points files named *.nc (classic) or, as the scripts name them (test/reorder_spectrum_lw.sh,
+    test/find_g_points_lw.sh), *.h5 - written as NetCDF-4 with deflated per-wavenumber variables and read back by the next tool."""
     from test_pipeline_gpu import hr_error_against_lbl, make_do_all_inputs
+    if ext == "h5":
+        import h5_fixture
+        if not h5_fixture.available():
+            pytest.skip("no HDF5 shared library with the deflate filter in this environment")
     d = tmp_path
     inp = make_do_all_inputs(ctx, d)
     ok = lambda r: (r.returncode == 0, r.stderr + r.stdout)
     for g in ("h2o", "co2"):
-        r = run_tool("reorder_spectrum", f"input=present_{g}.nc", f"output=order_{g}.nc", "wavenumber1=0 1300", "wavenumber2=1300 3260", cwd=d)
+        r = run_tool("reorder_spectrum", f"input=present_{g}.nc", f"output=order_{g}.{ext}", "wavenumber1=0 1300", "wavenumber2=1300 3260", cwd=d)
         assert ok(r)[0], ok(r)[1]
     (d / "find_g.cfg").write_text(
         "heating_rate_tolerance 0.3\nmax_iterations 30\naveraging_method transmission\ngases h2o co2\n"
-        "\\begin h2o\n input present_h2o.nc\n reordering_input order_h2o.nc\n background_input present_co2.nc\n\\end h2o\n"
-        "\\begin co2\n input present_co2.nc\n reordering_input order_co2.nc\n background_input present_h2o.nc\n\\end co2\n")
-    r = run_tool("find_g_points", "find_g.cfg", "output=gpoints.nc", cwd=d)
+        f"\\begin h2o\n input present_h2o.nc\n reordering_input order_h2o.{ext}\n background_input present_co2.nc\n\\end h2o\n"
+        f"\\begin co2\n input present_co2.nc\n reordering_input order_co2.{ext}\n background_input present_h2o.nc\n\\end co2\n")
+    r = run_tool("find_g_points", "find_g.cfg", f"output=gpoints.{ext}", cwd=d)
     assert ok(r)[0], ok(r)[1]
+    magic = b"\x89HDF\r\n\x1a\n" if ext == "h5" else b"CDF"
+    for name in ("order_h2o", "order_co2", "gpoints"):
+        assert open(d / f"{name}.{ext}", "rb").read(len(magic)) == magic
     (d / "lut.cfg").write_text(
-        "input gpoints.nc\noutput raw_ckd.nc\ngases h2o co2\n"
+        f"input gpoints.{ext}\noutput raw_ckd.nc\ngases h2o co2\n"
         "\\begin h2o\n conc_dependence lut\n input \"ideal_h2o.nc ideal_h2o_x4.nc\"\n\\end h2o\n"
         "\\begin co2\n conc_dependence linear\n input ideal_co2.nc\n\\end co2\n")
     r = run_tool("create_look_up_table", "lut.cfg", cwd=d)
