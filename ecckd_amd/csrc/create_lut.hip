@@ -184,22 +184,27 @@ k_gavg_partial(int nlay, size_t od_stride, const Chunk* __restrict__ chunks, con
   }
 }
 
-// K6b.  grid ng, block 128: combine the chunk partials of one g point in order, fit, clamp,
-// min/max repair and conversion to molar absorption (average_optical_depth.cpp:135-193).
-__global__ void __launch_bounds__(128)
+// K6b.  grid (ng, nlay), block 64: the chunk partials of one g point and layer - lane j adds the chunks j, j + 64, ... of the g
+// point in chunk order, the lanes' sums are folded in a fixed tree (a function of the chunk count alone) -, then fit, clamp,
+// min/max repair and conversion to molar absorption (average_optical_depth.cpp:135-193).  (One block per g point walking its
+// ~90 chunks layer by layer took 0.46 ms beside K6a's 1.8.)
+__global__ void __launch_bounds__(64)
 k_gavg_final(int nlay, int ng, const int* __restrict__ seg_chunk0 /*[ng+1]*/, const long long* __restrict__ seg_count /*[ng]*/,
              const int* __restrict__ layer_method, const double* __restrict__ partial, const double* __restrict__ dp /*[nlay]*/,
              double scale /* (g*0.001*M/vmr) or <= 0: plain optical depth */, double* __restrict__ out /*[3][nlay][ng]*/) {
-  const int g = blockIdx.x;
+  const int g = blockIdx.x, l = blockIdx.y, lane = threadIdx.x;
   const int c0 = seg_chunk0[g], c1 = seg_chunk0[g + 1];
   const double ntot = (double)seg_count[g];
-  for (int l = threadIdx.x; l < nlay; l += blockDim.x) {
+  {
     double num = 0.0, den = 0.0, den_nz = 0.0, cnt = 0.0, mn = INFINITY, mx = -INFINITY;
-    for (int c = c0; c < c1; ++c) {
+    for (int c = c0 + lane; c < c1; c += 64) {
       const double* p = partial + ((size_t)c * nlay + l) * 6;
       num += p[0]; den += p[1]; den_nz += p[2]; cnt += p[3];
       mn = fmin(mn, p[4]); mx = fmax(mx, p[5]);
     }
+    num = wave_sum(num); den = wave_sum(den); den_nz = wave_sum(den_nz); cnt = wave_sum(cnt);
+    mn = wave_min(mn); mx = wave_max(mx);
+    if (lane != 0) return;
     double fit = 0.0;
     if (c1 > c0) {
       const int lm = layer_method[l];
@@ -240,7 +245,6 @@ k_gavg_final(int nlay, int ng, const int* __restrict__ seg_chunk0 /*[ng+1]*/, co
 __global__ void __launch_bounds__(GA_THREADS)
 k_planck_lut_partial(int nlut, const Chunk* __restrict__ chunks, const double* __restrict__ wn_s,
                      const double* __restrict__ dwn_s, const double* __restrict__ hk_lut, double* __restrict__ partial) {
-  __shared__ double s_red[4];
   const Chunk c = chunks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double freq[GA_PPT], pref[GA_PPT];
@@ -253,6 +257,9 @@ k_planck_lut_partial(int nlut, const Chunk* __restrict__ chunks, const double* _
     freq[p] = wn_s[ii] * inv_cm_2_Hz;
     pref[p] = live ? (dwn_s[ii] * 2.0 * kPlanckH * inv_cm_2_Hz * kPi / (kLightC * kLightC)) * (freq[p] * freq[p] * freq[p]) : 0.0;
   }
+  // (1.66e9 Planck evaluations for 231 temperatures x 7.2e6 points: 2.2 ms, ~60 % of the fp64 issue rate; the < 1 ulp exp and
+  // division of fastmath.hpp with the waves' sums parked in LDS - no barrier in the loop - measured 2.4 ms: left as it was)
+  __shared__ double s_red[4];
   for (int it = 0; it < nlut; ++it) {
     const double h = hk_lut[it];
     double v = 0.0;
@@ -266,15 +273,19 @@ k_planck_lut_partial(int nlut, const Chunk* __restrict__ chunks, const double* _
   }
 }
 
+// grid (ng, ceil(nlut / 4)), block 256: a wave per (g point, temperature) - lane j adds the chunks j, j + 64, ... in chunk order, the
+// lanes' sums are folded in a fixed tree
 __global__ void __launch_bounds__(256)
 k_planck_lut_final(int nlut, int ng, const int* __restrict__ seg_chunk0, const double* __restrict__ partial,
                    double* __restrict__ out /*[nlut][ng]*/) {
   const int g = blockIdx.x;
-  for (int it = threadIdx.x; it < nlut; it += blockDim.x) {
-    double s = 0.0;
-    for (int c = seg_chunk0[g]; c < seg_chunk0[g + 1]; ++c) s += partial[(size_t)c * nlut + it];
-    out[(size_t)it * ng + g] = s;
-  }
+  const int lane = threadIdx.x & 63;
+  const int it = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (it >= nlut) return;
+  double s = 0.0;
+  for (int c = seg_chunk0[g] + lane; c < seg_chunk0[g + 1]; c += 64) s += partial[(size_t)c * nlut + it];
+  s = wave_sum(s);
+  if (lane == 0) out[(size_t)it * ng + g] = s;
 }
 
 // Row sums per g point (scale_lut.cpp:119-124): partial[chunk][nrows], gathered through the g-sorted order.
@@ -391,14 +402,15 @@ k_width_chunk_sums(const Chunk* __restrict__ chunks, const double* __restrict__ 
   if (tid == 0) partial[blockIdx.x] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
 }
 
-__global__ void __launch_bounds__(256)
+// grid ng, block 64: lane j adds the chunk sums j, j + 64, ... of the g point in chunk order, the lanes' sums are folded in a fixed tree
+__global__ void __launch_bounds__(64)
 k_width_totals(int ng, int nint, const int* __restrict__ seg_chunk0, const double* __restrict__ partial,
                double* __restrict__ width /*[ng][nint+1]*/) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= ng) return;
+  const int g = blockIdx.x, lane = threadIdx.x;
   double s = 0.0;
-  for (int c = seg_chunk0[g]; c < seg_chunk0[g + 1]; ++c) s += partial[c];
-  width[(size_t)g * (nint + 1) + nint] = s;
+  for (int c = seg_chunk0[g] + lane; c < seg_chunk0[g + 1]; c += 64) s += partial[c];
+  s = wave_sum(s);
+  if (lane == 0) width[(size_t)g * (nint + 1) + nint] = s;
 }
 
 }  // namespace
@@ -579,7 +591,7 @@ int ecckd_average_to_gpoints(ecckd_gmap* m, int nlay, const double* h_pressure_h
   }
   // :170-173 (ACCEL_GRAVITY * 0.001 * MOLAR_MASS_DRY_AIR) / reference_surface_vmr
   const double scale = reference_surface_vmr > 0.0 ? (ECCKD_ACCEL_GRAVITY * 0.001 * 28.970) / reference_surface_vmr : -1.0;
-  hipLaunchKernelGGL(k_gavg_final, dim3(ng), dim3(128), 0, ctx->stream, nlay, ng, m->d_seg_chunk0, m->d_seg_count, d_lm,
+  hipLaunchKernelGGL(k_gavg_final, dim3(ng, nlay), dim3(64), 0, ctx->stream, nlay, ng, m->d_seg_chunk0, m->d_seg_count, d_lm,
                      d_part, d_dp, scale, d_out);
   ECCKD_HIP_CHECK(hipGetLastError());
   const size_t one = (size_t)nlay * ng * sizeof(double);
@@ -611,7 +623,7 @@ int ecckd_gpoint_fraction(ecckd_gmap* m, int nint, const double* h_wavenumber1, 
                      d_w1, d_w2, d_width);
   if (nchunk > 0)
     hipLaunchKernelGGL(k_width_chunk_sums, dim3((unsigned)nchunk), dim3(GA_THREADS), 0, ctx->stream, m->d_chunks, m->dwn_s, d_csum);
-  hipLaunchKernelGGL(k_width_totals, dim3((ng + 255) / 256), dim3(256), 0, ctx->stream, ng, nint, m->d_seg_chunk0, d_csum, d_width);
+  hipLaunchKernelGGL(k_width_totals, dim3(ng), dim3(64), 0, ctx->stream, ng, nint, m->d_seg_chunk0, d_csum, d_width);
   ECCKD_HIP_CHECK(hipGetLastError());
   std::vector<double> width((size_t)ng * (nint + 1));
   ECCKD_CHECK(ecckd_d2h(ctx, width.data(), d_width, width.size() * sizeof(double)));
@@ -643,7 +655,7 @@ int ecckd_planck_lut(ecckd_gmap* m, int nlut, const double* h_temperature_lut, d
   if (nchunk > 0)
     hipLaunchKernelGGL(k_planck_lut_partial, dim3((unsigned)nchunk), dim3(GA_THREADS), 0, ctx->stream, nlut, m->d_chunks,
                        m->wn_s, m->dwn_s, d_hk, d_part);
-  hipLaunchKernelGGL(k_planck_lut_final, dim3(ng), dim3(256), 0, ctx->stream, nlut, ng, m->d_seg_chunk0, d_part, d_out);
+  hipLaunchKernelGGL(k_planck_lut_final, dim3(ng, (nlut + 3) / 4), dim3(256), 0, ctx->stream, nlut, ng, m->d_seg_chunk0, d_part, d_out);
   ECCKD_HIP_CHECK(hipGetLastError());
   return ecckd_d2h(ctx, h_planck_lut, d_out, (size_t)nlut * ng * sizeof(double));
 }
@@ -670,7 +682,7 @@ int ecckd_gmap_sum_rows(ecckd_gmap* m, int nrows, const void* d_rows, int rows_t
       hipLaunchKernelGGL(k_rowsum_partial<double>, dim3((unsigned)nchunk), dim3(GA_THREADS), 0, ctx->stream, nrows, row_stride,
                          m->d_chunks, m->order, (const double*)d_rows, d_part);
   }
-  hipLaunchKernelGGL(k_planck_lut_final, dim3(ng), dim3(256), 0, ctx->stream, nrows, ng, m->d_seg_chunk0, d_part, d_out);
+  hipLaunchKernelGGL(k_planck_lut_final, dim3(ng, (nrows + 3) / 4), dim3(256), 0, ctx->stream, nrows, ng, m->d_seg_chunk0, d_part, d_out);
   ECCKD_HIP_CHECK(hipGetLastError());
   return ecckd_d2h(ctx, h_sums, d_out, (size_t)nrows * ng * sizeof(double));
 }
@@ -690,7 +702,7 @@ int ecckd_gmap_erythemal_spectrum(ecckd_gmap* m, double* h_erythemal) {
   if (nchunk > 0)
     hipLaunchKernelGGL(k_erythemal_partial, dim3((unsigned)nchunk), dim3(GA_THREADS), 0, ctx->stream, m->d_chunks, m->wn_s,
                        m->dwn_s, d_part);
-  hipLaunchKernelGGL(k_planck_lut_final, dim3(ng), dim3(256), 0, ctx->stream, 2, ng, m->d_seg_chunk0, d_part, d_out);
+  hipLaunchKernelGGL(k_planck_lut_final, dim3(ng, 1), dim3(256), 0, ctx->stream, 2, ng, m->d_seg_chunk0, d_part, d_out);
   ECCKD_HIP_CHECK(hipGetLastError());
   std::vector<double> nd(2 * (size_t)ng);
   ECCKD_CHECK(ecckd_d2h(ctx, nd.data(), d_out, nd.size() * sizeof(double)));
