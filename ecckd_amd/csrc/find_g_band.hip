@@ -737,9 +737,10 @@ int ecckd_find_g_gases_add(ecckd_gas_search_job* job, ecckd_gas_search* r) {
   job->message.emplace_back();
   std::string* const msg = &job->message.back();
   // a gas with several bands runs a thread per band and one that serves their batches; they wait for each other by spinning
-  // and yield the core when there are more of them than cores (oversubscribed()), so the limit is generous: four threads per
-  // core (width <= 0: what that allows; 13 bands on 16 cores: four gases at a time)
-  const int cores = 4 * ecckd::host_cores();
+  // and yield the core when there are more of them than cores (oversubscribed()), so the limit is generous: sixteen threads per
+  // core (width <= 0: what that allows).  Measured on a 16-core share: the 32-band x 3-gas shortwave job 31.2 ms with one gas at a
+  // time (four threads per core), 25.4 ms with all three (99 threads); the 13-band x 8-gas longwave job 165 ms either way.
+  const int cores = 16 * ecckd::host_cores();
   const int per_gas = (r->nband > 1 || g->do_sw) ? r->nband + 1 : 1;
   // a search that re-ranks its base g point by wavenumber (ecckd_regroup_rank_by_wavenumber_dev) works on the context's stream
   // with the context's scratch, which the caller may be using for the next gas's preparation: such a gas is searched here and now
