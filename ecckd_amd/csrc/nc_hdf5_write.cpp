@@ -31,6 +31,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -459,14 +460,19 @@ int queue_deflated_chunks(WApi& a, H5Writer* w, int varindex, size_t row0, const
     }
     ch.offset[nd - 1] = (hsize_t)first;
   }
+  if (w->pool.empty()) {
+    // (a host that cannot start another thread: the library's own pipeline writes this variable)
+    const int nthreads = std::max(1, std::min(16, host_cores()));
+    try {
+      for (int t = 0; t < nthreads; ++t) w->pool.emplace_back(pool_worker, w);
+    } catch (const std::exception&) {
+      if (w->pool.empty()) return 1;
+    }
+  }
   {
     std::lock_guard<std::mutex> lock(w->m);
     for (H5Writer::Chunk& ch : fresh) w->queue.push_back(std::move(ch));
     w->queued_bytes += nchunks * cv * ts;
-    if (w->pool.empty()) {
-      const int nthreads = std::max(1, std::min(16, host_cores()));
-      for (int t = 0; t < nthreads; ++t) w->pool.emplace_back(pool_worker, w);
-    }
   }
   w->cv.notify_all();
   return ECCKD_OK;
